@@ -1,0 +1,161 @@
+"""
+ctypes binding of libdynamite_amd.so -- the C ABI declared in
+include/dynamite_amd.h.  This is the stub dynamite's Cython layer
+(bpetsc.pyx / bsubspace.pyx) is replaced by.  There is no fallback: if the
+library is missing it is built with hipcc, and if that fails we raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+i64p = C.POINTER(C.c_int64)
+f64p = C.POINTER(C.c_double)
+vp = C.c_void_p
+
+
+class Subspace(C.Structure):
+    """dnm_subspace"""
+    _fields_ = [("type", C.c_int32), ("L", C.c_int64), ("space", C.c_int64), ("k", C.c_int64),
+                ("ld_nchoosek", C.c_int64), ("nchoosek", i64p), ("dim", C.c_int64),
+                ("state_map", i64p), ("rmap_indices", i64p), ("rmap_states", i64p)]
+
+
+class Partition(C.Structure):
+    _fields_ = [("rank", C.c_int32), ("nranks", C.c_int32)]
+
+
+MULT_FN = C.CFUNCTYPE(C.c_int, vp, vp, vp)
+REDUCE_FN = C.CFUNCTYPE(C.c_int, vp, f64p, C.c_int)
+
+
+class Hooks(C.Structure):
+    _fields_ = [("ctx", vp), ("mult", MULT_FN), ("allreduce_sum", REDUCE_FN),
+                ("allreduce_max", REDUCE_FN)]
+
+
+class SolverStats(C.Structure):
+    _fields_ = [("reason", C.c_int32), ("its", C.c_int32), ("matvecs", C.c_int32),
+                ("nconv", C.c_int32), ("err_est", C.c_double)]
+
+
+# plan introspection structs (dynamite_amd/csrc/plan.h)
+MAXSEG, MAXR = 4, 16
+
+
+class DevTerm(C.Structure):
+    _fields_ = [("sign_ext", C.c_uint64), ("sign_tile", C.c_uint32), ("pad", C.c_uint32),
+                ("coeff", C.c_double)]
+
+
+class DevMask(C.Structure):
+    _fields_ = [("mask_tile", C.c_uint32), ("mask_loc", C.c_uint32), ("re_begin", C.c_uint32),
+                ("re_end", C.c_uint32), ("im_begin", C.c_uint32), ("im_end", C.c_uint32),
+                ("flags", C.c_uint32), ("src", C.c_uint32)]
+
+
+class DevPass(C.Structure):
+    _fields_ = [("nseg", C.c_int32), ("seg_off", C.c_int32 * MAXSEG), ("seg_len", C.c_int32 * MAXSEG),
+                ("seg_pos", C.c_int32 * MAXSEG), ("nbseg", C.c_int32), ("bseg_off", C.c_int32 * MAXSEG),
+                ("bseg_len", C.c_int32 * MAXSEG), ("bseg_pos", C.c_int32 * MAXSEG),
+                ("sign_base", C.c_uint64), ("accumulate", C.c_int32), ("need_tile", C.c_int32),
+                ("has_diag", C.c_int32), ("dext_begin", C.c_uint32), ("dext_end", C.c_uint32),
+                ("dbucket", C.c_uint32 * (MAXR + 1)), ("nmasks", C.c_int32), ("masks", vp),
+                ("terms", vp)]
+
+
+MAT_DEFAULT, MAT_FORCE_GATHER, MAT_NO_GLDS, MAT_HOST_ONLY = 0, 1, 2, 4
+WHICH = {"lowest": 0, "highest": 1, "exterior": 2}
+CONVERGED_TOL, CONVERGED_ITS, DIVERGED_ITS, DIVERGED_BREAKDOWN, DIVERGED_SYMMETRY_LOST = 1, 2, -1, -2, -3
+
+# name -> (restype, argtypes); every symbol include/dynamite_amd.h declares
+SIGNATURES = {
+    "dnm_last_error": (C.c_char_p, []),
+    "dnm_version": (C.c_int, []),
+    "dnm_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "dnm_set_device": (C.c_int, [C.c_int]),
+    "dnm_malloc": (C.c_int, [C.POINTER(vp), C.c_size_t]),
+    "dnm_free": (C.c_int, [vp]),
+    "dnm_memcpy_h2d": (C.c_int, [vp, vp, C.c_size_t, vp]),
+    "dnm_memcpy_d2h": (C.c_int, [vp, vp, C.c_size_t, vp]),
+    "dnm_stream_synchronize": (C.c_int, [vp]),
+    "dnm_subspace_dim": (C.c_int, [C.POINTER(Subspace), i64p]),
+    "dnm_idx_to_state": (C.c_int, [C.POINTER(Subspace), C.c_int64, i64p, i64p]),
+    "dnm_state_to_idx": (C.c_int, [C.POINTER(Subspace), C.c_int64, i64p, i64p]),
+    "dnm_mat_create": (C.c_int, [C.c_int64, i64p, i64p, i64p, f64p, C.POINTER(Subspace),
+                                 C.POINTER(Subspace), C.c_int, C.c_int, C.POINTER(Partition),
+                                 C.POINTER(vp)]),
+    "dnm_mat_destroy": (C.c_int, [vp]),
+    "dnm_mat_sizes": (C.c_int, [vp, i64p, i64p, i64p, i64p]),
+    "dnm_mat_precompute_diagonal": (C.c_int, [vp, vp]),
+    "dnm_mat_get_diagonal": (C.c_int, [vp, f64p, vp]),
+    "dnm_mat_mult": (C.c_int, [vp, vp, vp, vp]),
+    "dnm_mat_norm_inf": (C.c_int, [vp, f64p, vp]),
+    "dnm_mat_set_norm": (C.c_int, [vp, C.c_double]),
+    "dnm_mat_plan_describe": (C.c_int, [vp, C.c_char_p, C.c_size_t]),
+    "dnm_mat_plan_launches": (C.c_int, [vp, C.POINTER(C.c_int)]),
+    "dnm_mat_plan_counts": (C.c_int, [vp] + [C.POINTER(C.c_int)] * 6),
+    "dnm_mat_export_pass": (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_size_t, vp, C.c_int, vp, C.c_int,
+                                      C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "dnm_mat_partners": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int32)]),
+    "dnm_mat_mult_local": (C.c_int, [vp, vp, vp, vp]),
+    "dnm_mat_mult_remote": (C.c_int, [vp, C.c_int32, vp, vp, vp]),
+    "dnm_vec_set": (C.c_int, [vp, C.c_int64, C.c_double, C.c_double, vp]),
+    "dnm_vec_copy": (C.c_int, [vp, vp, C.c_int64, vp]),
+    "dnm_vec_scale": (C.c_int, [vp, C.c_int64, C.c_double, C.c_double, vp]),
+    "dnm_vec_axpby": (C.c_int, [vp, vp, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double, vp]),
+    "dnm_vec_dot": (C.c_int, [vp, vp, C.c_int64, f64p, vp]),
+    "dnm_vec_norm2": (C.c_int, [vp, C.c_int64, f64p, vp]),
+    "dnm_vec_set_random": (C.c_int, [vp, C.c_int64, C.c_uint64, C.c_int64, vp]),
+    "dnm_vec_mdot": (C.c_int, [vp, C.c_int64, C.c_int, vp, C.c_int64, f64p, vp]),
+    "dnm_vec_maxpy": (C.c_int, [vp, vp, C.c_int64, C.c_int, C.c_int64, f64p, vp]),
+    "dnm_vec_basis_update": (C.c_int, [vp, C.c_int64, C.c_int, C.c_int, C.c_int64, f64p, vp]),
+    "dnm_expm_multiply": (C.c_int, [vp, vp, vp, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_int,
+                                    C.c_int, C.c_size_t, C.POINTER(Hooks), C.POINTER(SolverStats), vp]),
+    "dnm_eigsolve": (C.c_int, [vp, C.c_int64, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int,
+                               C.c_uint64, C.POINTER(Hooks), C.c_int, f64p, vp,
+                               C.POINTER(SolverStats), vp]),
+}
+
+
+class BackendError(RuntimeError):
+    """Raised when a C-ABI call returns non-zero (the reference raises petsc4py.Error)."""
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = _build.build()       # no-op when the in-tree .so is current
+        L = C.CDLL(path)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)   # AttributeError if the library lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise BackendError(lib().dnm_last_error().decode())
+
+
+def p64(a):
+    return a.ctypes.data_as(i64p)
+
+
+def pf64(a):
+    return a.ctypes.data_as(f64p)
+
+
+def device_count():
+    n = C.c_int(0)
+    lib().dnm_device_count(C.byref(n))
+    return n.value

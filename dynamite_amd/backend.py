@@ -1,0 +1,268 @@
+"""
+Python face of the native backend: the objects dynamite gets from petsc4py /
+its Cython layer on this path.
+
+* ``build_mat`` / ``precompute_diagonal`` mirror ``bpetsc.build_mat`` and
+  ``bpetsc.precompute_diagonal`` (reference
+  ``src/dynamite/_backend/bpetsc.pyx:78-147``) and return a ``ShellMat`` with
+  the ``petsc4py.Mat`` methods the path uses: ``mult``, ``norm``, ``destroy``,
+  ``getSize``.
+* ``Vec`` carries the ``petsc4py.Vec`` methods ``states.py`` calls
+  (``states.py:102-123, 703-797``): a contiguous complex128 block per rank,
+  row-block partitioned (PETSc's default layout).
+
+Device memory, streams and the rank exchange come from torch (plumbing); all
+arithmetic is done by the HIP kernels behind the C ABI.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .config import config
+
+
+def _stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dist():
+    import torch.distributed as dist
+    return dist if (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) else None
+
+
+class Vec:
+    """Distributed complex128 vector: this rank's block lives in ``self.array``
+    (a 1-D torch tensor on the rank's GPU)."""
+
+    def __init__(self, size, array=None):
+        import torch
+        config._initialize()
+        self.size = int(size)
+        ws, rk = config.world_size, config.rank
+        if ws > 1 and self.size % ws:
+            raise ValueError('vector size must be divisible by the number of ranks')
+        self.local_size = self.size // ws
+        self.start = rk * self.local_size
+        if array is None:
+            array = torch.zeros(self.local_size, dtype=torch.complex128, device=config.device)
+        self.array = array
+
+    # -- petsc4py.Vec-like surface -------------------------------------------
+    def getSize(self):
+        return self.size
+
+    def getLocalSize(self):
+        return self.local_size
+
+    def getOwnershipRange(self):
+        return self.start, self.start + self.local_size
+
+    @property
+    def ptr(self):
+        return C.c_void_p(self.array.data_ptr())
+
+    def set(self, value):
+        v = complex(value)
+        _lib.check(_lib.lib().dnm_vec_set(self.ptr, self.local_size, v.real, v.imag, _stream()))
+
+    def copy(self, result=None):
+        if result is None:
+            result = Vec(self.size)
+        _lib.check(_lib.lib().dnm_vec_copy(self.ptr, result.ptr, self.local_size, _stream()))
+        return result
+
+    def scale(self, alpha):
+        a = complex(alpha)
+        _lib.check(_lib.lib().dnm_vec_scale(self.ptr, self.local_size, a.real, a.imag, _stream()))
+
+    def axpby(self, alpha, beta, x):
+        """self = alpha*x + beta*self (VecAXPBY)."""
+        a, b = complex(alpha), complex(beta)
+        _lib.check(_lib.lib().dnm_vec_axpby(self.ptr, x.ptr, self.local_size, a.real, a.imag,
+                                            b.real, b.imag, _stream()))
+
+    def _reduce(self, vals, op='sum'):
+        d = _dist()
+        if d is None:
+            return vals
+        import torch
+        t = torch.tensor(vals, dtype=torch.float64, device=self.array.device)
+        d.all_reduce(t, op=d.ReduceOp.SUM if op == 'sum' else d.ReduceOp.MAX)
+        return t.tolist()
+
+    def dot(self, other):
+        """VecDot(self, other) = sum_i self_i * conj(other_i)."""
+        out = (C.c_double * 2)()
+        _lib.check(_lib.lib().dnm_vec_dot(self.ptr, other.ptr, self.local_size, out, _stream()))
+        re, im = self._reduce([out[0], out[1]])
+        return complex(re, im)
+
+    def norm(self):
+        out = (C.c_double * 2)()
+        _lib.check(_lib.lib().dnm_vec_dot(self.ptr, self.ptr, self.local_size, out, _stream()))
+        re = self._reduce([out[0]])[0]
+        return float(np.sqrt(max(re, 0.0)))
+
+    def normalize(self):
+        n = self.norm()
+        self.scale(1.0 / n)
+        return n
+
+    def shift(self, alpha):
+        self.array += complex(alpha)
+
+    def set_random(self, seed):
+        _lib.check(_lib.lib().dnm_vec_set_random(self.ptr, self.local_size, seed & (2 ** 64 - 1),
+                                                 self.start, _stream()))
+
+    def set_local_from_numpy(self, arr):
+        import torch
+        arr = np.ascontiguousarray(arr, dtype=np.complex128)
+        assert arr.size == self.local_size
+        self.array.copy_(torch.from_numpy(arr))
+
+    def local_numpy(self):
+        return self.array.cpu().numpy()
+
+    def to_numpy(self, to_all=False):
+        """Gather to rank 0 (or everywhere): State._to_numpy (states.py:403-447)."""
+        d = _dist()
+        if d is None:
+            return self.local_numpy()
+        import torch
+        parts = [torch.empty_like(self.array) for _ in range(config.world_size)]
+        d.all_gather(parts, self.array)
+        if not to_all and config.rank != 0:
+            return None
+        return torch.cat(parts).cpu().numpy()
+
+    def destroy(self):
+        self.array = None
+
+
+class ShellMat:
+    """Matrix-free operator handle (PETSc MatShell + shell_context in the reference)."""
+
+    def __init__(self, handle, left_c, right_c, nranks, rank):
+        self._h = handle
+        self._keep = (left_c, right_c)
+        self.nranks, self.rank = nranks, rank
+        M, N, m, n = (C.c_int64() for _ in range(4))
+        _lib.check(_lib.lib().dnm_mat_sizes(handle, C.byref(M), C.byref(N), C.byref(m), C.byref(n)))
+        self.M, self.N, self.m_local, self.n_local = M.value, N.value, m.value, n.value
+        npart = C.c_int()
+        _lib.check(_lib.lib().dnm_mat_partners(handle, C.byref(npart), None))
+        buf = (C.c_int32 * max(1, npart.value))()
+        _lib.check(_lib.lib().dnm_mat_partners(handle, C.byref(npart), buf))
+        self.partners = [int(buf[i]) for i in range(npart.value)]
+        self._recv = {}
+
+    @property
+    def handle(self):
+        if self._h is None:
+            raise RuntimeError('matrix has been destroyed')
+        return self._h
+
+    def getSize(self):
+        return self.M, self.N
+
+    def createVecs(self):
+        return Vec(self.N), Vec(self.M)
+
+    def describe(self):
+        buf = C.create_string_buffer(8192)
+        _lib.check(_lib.lib().dnm_mat_plan_describe(self.handle, buf, len(buf)))
+        return buf.value.decode()
+
+    def mult(self, x, y):
+        """y = A x (MatMult).  Partitioned: the partners' blocks travel over RCCL
+        send/recv while the rank-local masks are applied; the off-rank masks
+        follow once their block has arrived."""
+        L = _lib.lib()
+        if x.array.data_ptr() == y.array.data_ptr():
+            raise ValueError('x and y must be different vectors')
+        if not self.partners:
+            _lib.check(L.dnm_mat_mult(self.handle, x.ptr, y.ptr, _stream()))
+            return
+        import torch
+        import torch.distributed as dist
+        ops = []
+        for p in self.partners:
+            if p not in self._recv:
+                self._recv[p] = torch.empty_like(x.array)
+            ops.append(dist.P2POp(dist.isend, x.array, p))
+            ops.append(dist.P2POp(dist.irecv, self._recv[p], p))
+        reqs = dist.batch_isend_irecv(ops)          # runs on RCCL's stream
+        _lib.check(L.dnm_mat_mult_local(self.handle, x.ptr, y.ptr, _stream()))   # overlaps
+        for r in reqs:
+            r.wait()
+        for p in self.partners:
+            _lib.check(L.dnm_mat_mult_remote(self.handle, p, C.c_void_p(self._recv[p].data_ptr()),
+                                             y.ptr, _stream()))
+
+    def norm(self, norm_type='infinity'):
+        if norm_type not in ('infinity', None):
+            raise ValueError('Only NORM_INFINITY is implemented for shell matrices.')
+        v = C.c_double()
+        _lib.check(_lib.lib().dnm_mat_norm_inf(self.handle, C.byref(v), _stream()))
+        d = _dist()
+        if d is not None:
+            import torch
+            t = torch.tensor([v.value], dtype=torch.float64, device=config.device)
+            d.all_reduce(t, op=d.ReduceOp.MAX)
+            v.value = float(t.item())
+            _lib.check(_lib.lib().dnm_mat_set_norm(self.handle, v.value))
+        return v.value
+
+    def precompute_diagonal(self):
+        _lib.check(_lib.lib().dnm_mat_precompute_diagonal(self.handle, _stream()))
+
+    def destroy(self):
+        if self._h is not None:
+            _lib.check(_lib.lib().dnm_mat_destroy(self._h))
+            self._h = None
+            self._recv = {}
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+def create_mat(masks, mask_offsets, signs, coeffs, left_c, right_c, xparity=False, flags=0,
+               rank=0, nranks=1):
+    """Raw dnm_mat_create; left_c / right_c are ctypes dnm_subspace structs."""
+    masks = np.ascontiguousarray(masks, dtype=np.int64)
+    mask_offsets = np.ascontiguousarray(mask_offsets, dtype=np.int64)
+    signs = np.ascontiguousarray(signs, dtype=np.int64)
+    coeffs = np.ascontiguousarray(coeffs, dtype=np.complex128)
+    part = _lib.Partition(rank, nranks)
+    h = C.c_void_p()
+    _lib.check(_lib.lib().dnm_mat_create(
+        masks.size, _lib.p64(masks), _lib.p64(mask_offsets), _lib.p64(signs),
+        coeffs.view(np.float64).ctypes.data_as(_lib.f64p), C.byref(left_c), C.byref(right_c),
+        int(bool(xparity)), int(flags), C.byref(part), C.byref(h)))
+    return h
+
+
+def build_mat(masks, mask_offsets, signs, coeffs, left_subspace, right_subspace, xparity=False,
+              shell=True, gpu=True, flags=0):
+    """Mirror of ``bpetsc.build_mat`` (bpetsc.pyx:78-138).  ``left_subspace`` /
+    ``right_subspace`` are the dicts ``Subspace._to_c()`` returns."""
+    if not shell:
+        raise ValueError('this engine builds matrix-free (shell) operators only')
+    if not gpu:
+        raise RuntimeError('dynamite_amd has no CPU path')
+    config._initialize()
+    lc, rc = left_subspace['data'], right_subspace['data']
+    h = create_mat(masks, mask_offsets, signs, coeffs, lc, rc, xparity, flags,
+                   rank=config.rank, nranks=config.world_size)
+    return ShellMat(h, lc, rc, config.world_size, config.rank)
+
+
+def precompute_diagonal(mat):
+    """Mirror of ``bpetsc.precompute_diagonal`` (bpetsc.pyx:141-147)."""
+    mat.precompute_diagonal()

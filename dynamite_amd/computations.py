@@ -1,0 +1,207 @@
+"""
+``evolve`` and ``eigsolve``: the Krylov callers of the hot path, with the
+signatures, defaults and error behaviour of ``dynamite.computations``
+(reference ``src/dynamite/computations.py:10-126, 128-292, 511-534``).  The
+solvers themselves are native (``dnm_expm_multiply`` / ``dnm_eigsolve``).
+"""
+import ctypes as C
+import warnings
+
+import numpy as np
+
+from . import _lib
+from .backend import _stream, _dist
+from .config import config
+
+
+class ConvergenceError(Exception):
+    pass
+
+
+class MaxIterationsError(ConvergenceError):
+    pass
+
+
+def _hooks(mat, keep):
+    """Distributed hooks for the native solvers: the partitioned multiply and
+    the small all-reduces run through torch.distributed (RCCL)."""
+    d = _dist()
+    if d is None:
+        return None
+    import torch
+    from .backend import Vec
+
+    def mult(ctx, xp, yp):
+        try:
+            n = mat.n_local
+            # wrap raw device pointers as Vec views without copying
+            x = Vec.__new__(Vec); y = Vec.__new__(Vec)
+            for v, p in ((x, xp), (y, yp)):
+                v.size, v.local_size, v.start = mat.N, n, config.rank * n
+                v.array = _tensor_from_ptr(p, n)
+            mat.mult(x, y)
+            return 0
+        except Exception as e:   # pragma: no cover
+            print('mult hook failed:', e)
+            return 1
+
+    def red(op):
+        def f(ctx, buf, n):
+            try:
+                arr = np.ctypeslib.as_array(buf, shape=(n,))
+                t = torch.tensor(arr, dtype=torch.float64, device=config.device)
+                d.all_reduce(t, op=op)
+                arr[:] = t.cpu().numpy()
+                return 0
+            except Exception as e:   # pragma: no cover
+                print('allreduce hook failed:', e)
+                return 1
+        return f
+
+    h = _lib.Hooks()
+    h.ctx = None
+    h.mult = _lib.MULT_FN(mult)
+    h.allreduce_sum = _lib.REDUCE_FN(red(d.ReduceOp.SUM))
+    h.allreduce_max = _lib.REDUCE_FN(red(d.ReduceOp.MAX))
+    keep.append(h)
+    return h
+
+
+def _tensor_from_ptr(ptr, n):
+    """torch complex128 tensor aliasing n amplitudes at a raw device pointer."""
+    import torch
+
+    class _W:
+        pass
+    w = _W()
+    w.__cuda_array_interface__ = {'shape': (2 * n,), 'typestr': '<f8', 'data': (int(ptr), False),
+                                  'version': 2}
+    return torch.as_tensor(w, device=config.device).view(torch.complex128)
+
+
+def evolve(H, state, t, result=None, tol=None, ncv=None, algo=None, max_its=None):
+    r"""result = exp(-i H t) state   (computations.py:10-126)."""
+    state.assert_initialized()
+    config._initialize()
+    H.establish_L()
+    if not H.has_subspace(state.subspace, state.subspace):
+        raise ValueError('Hamiltonian and state are defined on different subspaces.')
+    if result is None:
+        from .states import State
+        result = State(L=H.L, subspace=state.subspace)
+    elif state.subspace != result.subspace:
+        raise ValueError('input and result states are on different subspaces.')
+    if t == 0.0:
+        state.copy(result)
+        return result
+    if algo not in (None, 'expokit', 'krylov'):
+        raise ValueError("algo must be 'expokit' or 'krylov'")
+
+    scale = -1j * complex(t)
+    mat = H.get_mat(subspaces=(state.subspace, state.subspace))
+    keep = []
+    hooks = _hooks(mat, keep)
+    stats = _lib.SolverStats()
+    import torch
+    free, _ = torch.cuda.mem_get_info()
+    _lib.check(_lib.lib().dnm_expm_multiply(
+        mat.handle, state.vec.ptr, result.vec.ptr, mat.n_local, scale.real, scale.imag,
+        0.0 if tol is None else float(tol), 0 if ncv is None else int(ncv),
+        0 if max_its is None else int(max_its), int(free * 0.9),
+        C.byref(hooks) if hooks is not None else None, C.byref(stats), _stream()))
+    evolve.last_stats = {'reason': stats.reason, 'its': stats.its, 'matvecs': stats.matvecs,
+                         'err_est': stats.err_est}
+    # converged-reason mapping of computations.py:114-122
+    if stats.reason == _lib.DIVERGED_ITS:
+        raise MaxIterationsError('solver reached maximum number of iterations without '
+                                 'converging. perhaps try increasing the max iterations with '
+                                 'the max_its argument.')
+    elif stats.reason == _lib.DIVERGED_BREAKDOWN:
+        raise ConvergenceError('solver failed to converge with MFN_DIVERGED_BREAKDOWN.')
+    elif stats.reason <= 0:
+        raise ConvergenceError('solver failed to converge.')
+    result.set_initialized()
+    return result
+
+
+evolve.last_stats = None
+
+
+def eigsolve(H, getvecs=False, nev=1, which='lowest', target=None, tol=None, subspace=None,
+             max_its=None, ncv=None, seed=0):
+    """A few extremal eigenpairs (computations.py:128-292)."""
+    H.establish_L()
+    if subspace is None:
+        subspace = H.subspace
+    elif not H.has_subspace(subspace):
+        raise ValueError('Requested subspace has not been added to operator.')
+    config._initialize()
+    if target is not None:
+        # computations.py:211-220: refused for shell matrices and on GPUs
+        raise RuntimeError('Shift-invert ("target") not supported for shell matrices.')
+    if which == 'target':
+        raise ValueError("Must specify target when setting which='target'")
+    if which in ['smallest', 'largest']:
+        warnings.warn('values "smallest" and "largest" for eigsolve parameter "which" '
+                      'are deprecated, and have been replaced by "lowest" and "highest" respectively.',
+                      DeprecationWarning, stacklevel=2)
+        which = {'smallest': 'lowest', 'largest': 'highest'}[which]
+    if which not in _lib.WHICH:
+        raise ValueError(f'invalid value "{which}" for which')
+
+    mat = H.get_mat(subspaces=(subspace, subspace))
+    keep = []
+    hooks = _hooks(mat, keep)
+    nev_max = max(nev, int(ncv) if ncv else max(2 * nev, nev + 15))
+    evals = np.zeros(nev_max, dtype=np.float64)
+    evec_buf = None
+    if getvecs:
+        import torch
+        evec_buf = torch.empty(nev_max * mat.n_local, dtype=torch.complex128, device=config.device)
+    stats = _lib.SolverStats()
+    _lib.check(_lib.lib().dnm_eigsolve(
+        mat.handle, mat.n_local, int(nev), _lib.WHICH[which], 0.0 if tol is None else float(tol),
+        0 if ncv is None else int(ncv), 0 if max_its is None else int(max_its), int(seed),
+        C.byref(hooks) if hooks is not None else None, nev_max, _lib.pf64(evals),
+        C.c_void_p(evec_buf.data_ptr()) if evec_buf is not None else None, C.byref(stats), _stream()))
+    eigsolve.last_stats = {'reason': stats.reason, 'its': stats.its, 'matvecs': stats.matvecs,
+                           'nconv': stats.nconv}
+    nconv = stats.nconv
+    if stats.reason == _lib.DIVERGED_ITS:
+        raise MaxIterationsError('eigensolver reached maximum number of iterations without '
+                                 'converging. Try increasing the maximum iterations of the '
+                                 'eigensolver via the "max_its" argument to eigsolve() '
+                                 f'(current value: {max_its})')
+    elif stats.reason == _lib.DIVERGED_BREAKDOWN:
+        raise ConvergenceError('eigsolver failed to converge with reason EPS_DIVERGED_BREAKDOWN')
+    elif stats.reason <= 0 or nconv < nev:
+        raise ConvergenceError('eigsolver failed to converge')
+
+    vals = evals[:nconv].copy()
+    if not getvecs:
+        return vals
+    from .states import State
+    from .backend import Vec
+    evecs = []
+    for i in range(nconv):
+        v = State(L=H.L, subspace=subspace)
+        v._vec = Vec(mat.N, array=evec_buf[i * mat.n_local:(i + 1) * mat.n_local].clone())
+        v.set_initialized()
+        evecs.append(v)
+    return vals, evecs
+
+
+eigsolve.last_stats = None
+
+
+def get_tstep(ncv, nrm, tol=1E-7):
+    """First-step size of an Expokit solve (computations.py:511-519)."""
+    f = ((ncv + 1) / 2.72) ** (ncv + 1) * np.sqrt(2 * np.pi * (ncv + 1))
+    t = ((1 / nrm) * (f * tol) / (4.0 * nrm)) ** (1 / ncv)
+    s = 10.0 ** (np.floor(np.log10(t)) - 1)
+    return np.ceil(t / s) * s
+
+
+def estimate_compute_time(t, ncv, nrm, tol=1E-7):
+    """Cost estimate in matrix multiplies (computations.py:521-528)."""
+    return ncv * np.ceil(t / get_tstep(ncv, nrm, tol))

@@ -1,0 +1,94 @@
+"""
+Global configuration, the minimal equivalent of ``dynamite.config``
+(reference ``src/dynamite/__init__.py:12-227``): default ``L``, default
+``subspace``, the shell flag (this engine is matrix-free only) and the device /
+rank this process drives.  One process per GPU; ranks come from
+``torch.distributed`` when it is initialised (backend "nccl" = RCCL on ROCm,
+"gloo" in CPU tests).
+"""
+import os
+
+
+class _Config:
+    def __init__(self):
+        self._L = None
+        self._subspace = None
+        self._shell = True
+        self._initialized = False
+        self.gpu = True
+        self.device = None           # torch.device of this rank
+
+    # -- L / subspace / shell: same validation as the reference --------------
+    @property
+    def L(self):
+        return self._L
+
+    @L.setter
+    def L(self, value):
+        if value is not None:
+            if int(value) != value or value < 0 or value > 63:
+                raise ValueError('L must be an integer in [0, 63]')
+            value = int(value)
+        self._L = value
+
+    @property
+    def subspace(self):
+        return self._subspace
+
+    @subspace.setter
+    def subspace(self, value):
+        from .subspaces import Subspace
+        if value is not None and not isinstance(value, Subspace):
+            raise ValueError('subspace can only be set to objects of Subspace type')
+        self._subspace = value
+
+    @property
+    def shell(self):
+        return self._shell
+
+    @shell.setter
+    def shell(self, value):
+        if not isinstance(value, bool):
+            raise ValueError('Shell must be set to True or False.')
+        if not value:
+            raise ValueError('this engine is matrix-free: stored (AIJ) matrices are not built')
+        self._shell = value
+
+    # -- process / device -------------------------------------------------------
+    @property
+    def rank(self):
+        import torch.distributed as dist
+        return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+    @property
+    def world_size(self):
+        import torch.distributed as dist
+        return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+    def initialize(self, slepc_args=None, version_check=False, gpu=True):
+        """Once-only initialisation (``config.initialize``, __init__.py:24-49).
+        ``slepc_args`` is accepted for call compatibility and ignored."""
+        if self._initialized:
+            raise RuntimeError('initialize has already been called.')
+        self._initialize(gpu=gpu)
+
+    def _initialize(self, gpu=True):
+        if self._initialized:
+            return
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError('dynamite_amd needs an AMD GPU (torch.cuda.is_available() is False); '
+                               'there is no CPU fallback')
+        local = int(os.environ.get('LOCAL_RANK', '0'))
+        self.device = torch.device('cuda', local % max(1, torch.cuda.device_count()))
+        torch.cuda.set_device(self.device)
+        from . import _lib
+        _lib.check(_lib.lib().dnm_set_device(self.device.index))
+        self._initialized = True
+
+    @property
+    def initialized(self):
+        return self._initialized
+
+
+config = _Config()

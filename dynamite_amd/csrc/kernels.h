@@ -1,0 +1,58 @@
+// Launch interfaces of the HIP kernels (defined in matvec_kernels.hip and
+// vec_kernels.hip).  Everything here is host-callable and asynchronous on the
+// given stream.
+#pragma once
+
+#include "plan.h"
+#include "subspace.h"
+
+namespace dnm {
+
+// Generic operator tables for the row-gather kernels (any subspace pair):
+// the reference's shell_context arrays (shell_context.h:12-27) on the device.
+struct DevMsc {
+  int32_t nmasks;
+  const int64_t *masks;
+  const int64_t *mask_offsets;
+  const int64_t *signs;
+  const double *real_coeffs;   // one double per term (bpetsc_template_2.c:286-290)
+};
+
+bool tile_config_supported(int B, int logR);
+
+// One pass of the tiled hypercube kernel over the local vector.
+int launch_tile_pass(const DevPass &P, int B, int logR, bool glds, int n_loc,
+                     const void *x, void *y, const void *xr, hipStream_t st);
+
+// y (+)= H x by one thread per row with index maps (MatMult semantics of
+// bcuda_template_2.cu:200-273 / bpetsc_template_2.c:371-412).
+int launch_gather_matvec(const DevMsc &msc, const SubView &left, const SubView &right,
+                         int64_t M, const double *diag, const void *x, void *y,
+                         hipStream_t st);
+
+// diag[row] = sum over mask-0 terms (bcuda_template_1.cu:29-66)
+int launch_diag(const DevMsc &msc, const SubView &sub, int64_t M, double *diag, hipStream_t st);
+
+// per-block maxima of the row sums of |H| (bcuda_template_2.cu:331-403);
+// block_max must hold norm_num_blocks(M) doubles.
+int norm_num_blocks(int64_t M);
+int launch_norm(const DevMsc &msc, const SubView &left, const SubView &right, int64_t M,
+                int64_t row0, double *block_max, hipStream_t st);
+
+// ---- vector kernels ---------------------------------------------------------
+int vk_set(void *x, int64_t n, double re, double im, hipStream_t st);
+int vk_scale(void *x, int64_t n, double re, double im, hipStream_t st);
+int vk_axpby(void *y, const void *x, int64_t n, double are, double aim, double bre, double bim,
+             hipStream_t st);
+int vk_random(void *x, int64_t n, uint64_t seed, int64_t offset, hipStream_t st);
+// partial sums: out_dev[2*nv * nblocks]; reduce_blocks returns the block count
+int vk_mdot_blocks(int64_t n);
+int vk_mdot(const void *V, int64_t ldv, int nv, const void *w, int64_t n, double *partials_dev,
+            hipStream_t st);
+int vk_maxpy(void *w, const void *V, int64_t ldv, int nv, int64_t n, const double *c_dev,
+             hipStream_t st);
+int vk_basis_update(void *V, int64_t ldv, int nin, int nout, int64_t n, const double *S_dev,
+                    hipStream_t st);
+int vk_norm2_partials(const void *x, int64_t n, double *partials_dev, hipStream_t st);
+
+}  // namespace dnm

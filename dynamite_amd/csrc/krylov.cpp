@@ -1,0 +1,497 @@
+// Krylov drivers on top of the matrix-free multiply and the fused vector
+// kernels.  They replace the two SLEPc solvers dynamite calls
+// (src/dynamite/computations.py:89-112 MFN "expokit", :208-257 EPS
+// Krylov-Schur on a Hermitian problem).  SLEPc is a third-party dependency
+// that is not part of the reference tree (slepc4py == 3.20.2,
+// pyproject.toml:24): the algorithms below restate the published methods
+// (Sidje, "Expokit", ACM TOMS 24 (1998) -- the scheme SLEPc's MFNEXPOKIT
+// implements; Wu & Simon thick-restart Lanczos = Krylov-Schur for Hermitian
+// matrices, Stewart 2001).  Step counts / step sizes are not pinned by any
+// reference test; results are (tests/integration/test_evolve.py,
+// test_eigsolve.py tolerances).
+//
+// The host only handles (m+2)^2 dense matrices; every O(dim) operation is a
+// HIP kernel.
+#include <algorithm>
+#include <cmath>
+#include <complex>
+#include <vector>
+
+#include "vec_api.h"
+
+namespace dnm {
+
+typedef std::complex<double> zc;
+
+// ---------------------------------------------------------------------------
+// small dense helpers (column-major, leading dimension = n)
+// ---------------------------------------------------------------------------
+static void zgemm(int n, const std::vector<zc> &A, const std::vector<zc> &B, std::vector<zc> &C) {
+  C.assign((size_t)n * n, zc(0));
+  for (int j = 0; j < n; ++j)
+    for (int k = 0; k < n; ++k) {
+      const zc b = B[(size_t)j * n + k];
+      if (b == zc(0)) continue;
+      for (int i = 0; i < n; ++i) C[(size_t)j * n + i] += A[(size_t)k * n + i] * b;
+    }
+}
+
+// solve A X = B in place (B overwritten by X), partial pivoting; A destroyed
+static int zsolve(int n, std::vector<zc> &A, std::vector<zc> &Bm) {
+  for (int c = 0; c < n; ++c) {
+    int piv = c;
+    double best = std::abs(A[(size_t)c * n + c]);
+    for (int r = c + 1; r < n; ++r)
+      if (std::abs(A[(size_t)c * n + r]) > best) { best = std::abs(A[(size_t)c * n + r]); piv = r; }
+    if (best == 0.0) return 1;
+    if (piv != c) {
+      for (int j = 0; j < n; ++j) {
+        std::swap(A[(size_t)j * n + c], A[(size_t)j * n + piv]);
+        std::swap(Bm[(size_t)j * n + c], Bm[(size_t)j * n + piv]);
+      }
+    }
+    const zc inv = zc(1) / A[(size_t)c * n + c];
+    for (int r = c + 1; r < n; ++r) {
+      const zc f = A[(size_t)c * n + r] * inv;
+      if (f == zc(0)) continue;
+      for (int j = c; j < n; ++j) A[(size_t)j * n + r] -= f * A[(size_t)j * n + c];
+      for (int j = 0; j < n; ++j) Bm[(size_t)j * n + r] -= f * Bm[(size_t)j * n + c];
+    }
+  }
+  for (int j = 0; j < n; ++j)
+    for (int r = n - 1; r >= 0; --r) {
+      zc s = Bm[(size_t)j * n + r];
+      for (int k = r + 1; k < n; ++k) s -= A[(size_t)k * n + r] * Bm[(size_t)j * n + k];
+      Bm[(size_t)j * n + r] = s / A[(size_t)r * n + r];
+    }
+  return 0;
+}
+
+// exp(A) by scaling and squaring with the diagonal Pade approximant of degree
+// 13 (Higham 2005 coefficients), complex dense.
+static int zexpm(int n, const std::vector<zc> &Ain, std::vector<zc> &E) {
+  static const double b[14] = {64764752532480000., 32382376266240000., 7771770303897600.,
+                               1187353796428800.,  129060195264000.,   10559470521600.,
+                               670442572800.,      33522128640.,       1323241920.,
+                               40840800.,          960960.,            16380.,
+                               182.,               1.};
+  double nrm = 0;
+  for (int j = 0; j < n; ++j) {
+    double cs = 0;
+    for (int i = 0; i < n; ++i) cs += std::abs(Ain[(size_t)j * n + i]);
+    nrm = std::max(nrm, cs);
+  }
+  int s = 0;
+  const double theta13 = 5.371920351148152;
+  if (nrm > theta13) s = std::max(0, (int)std::ceil(std::log2(nrm / theta13)));
+  std::vector<zc> A = Ain;
+  const double sc = std::ldexp(1.0, -s);
+  for (auto &v : A) v *= sc;
+  std::vector<zc> A2, A4, A6, U, V, T1, T2;
+  zgemm(n, A, A, A2);
+  zgemm(n, A2, A2, A4);
+  zgemm(n, A4, A2, A6);
+  const size_t nn = (size_t)n * n;
+  // U = A [A6 (b13 A6 + b11 A4 + b9 A2) + b7 A6 + b5 A4 + b3 A2 + b1 I]
+  T1.assign(nn, zc(0));
+  for (size_t i = 0; i < nn; ++i) T1[i] = b[13] * A6[i] + b[11] * A4[i] + b[9] * A2[i];
+  zgemm(n, A6, T1, T2);
+  for (size_t i = 0; i < nn; ++i) T2[i] += b[7] * A6[i] + b[5] * A4[i] + b[3] * A2[i];
+  for (int i = 0; i < n; ++i) T2[(size_t)i * n + i] += b[1];
+  zgemm(n, A, T2, U);
+  // V = A6 (b12 A6 + b10 A4 + b8 A2) + b6 A6 + b4 A4 + b2 A2 + b0 I
+  for (size_t i = 0; i < nn; ++i) T1[i] = b[12] * A6[i] + b[10] * A4[i] + b[8] * A2[i];
+  zgemm(n, A6, T1, V);
+  for (size_t i = 0; i < nn; ++i) V[i] += b[6] * A6[i] + b[4] * A4[i] + b[2] * A2[i];
+  for (int i = 0; i < n; ++i) V[(size_t)i * n + i] += b[0];
+  // (V - U) E = (V + U)
+  std::vector<zc> P(nn), Q(nn);
+  for (size_t i = 0; i < nn; ++i) { P[i] = V[i] + U[i]; Q[i] = V[i] - U[i]; }
+  if (zsolve(n, Q, P)) return 1;
+  E.swap(P);
+  for (int k = 0; k < s; ++k) {
+    zgemm(n, E, E, T1);
+    E.swap(T1);
+  }
+  return 0;
+}
+
+// cyclic Jacobi for a dense real symmetric matrix: A = S diag(w) S^T
+static void jacobi_eig(int n, std::vector<double> &A, std::vector<double> &w, std::vector<double> &Sv) {
+  Sv.assign((size_t)n * n, 0.0);
+  for (int i = 0; i < n; ++i) Sv[(size_t)i * n + i] = 1.0;
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    double off = 0, diag = 0;
+    for (int j = 0; j < n; ++j)
+      for (int i = 0; i < n; ++i) {
+        if (i != j) off += A[(size_t)j * n + i] * A[(size_t)j * n + i];
+        else diag += A[(size_t)j * n + i] * A[(size_t)j * n + i];
+      }
+    if (off <= 1e-32 * (diag + 1e-300)) break;
+    for (int p = 0; p < n - 1; ++p)
+      for (int q = p + 1; q < n; ++q) {
+        const double apq = A[(size_t)q * n + p];
+        if (apq == 0.0) continue;
+        const double app = A[(size_t)p * n + p], aqq = A[(size_t)q * n + q];
+        const double tau = (aqq - app) / (2.0 * apq);
+        const double t = (tau >= 0 ? 1.0 : -1.0) / (std::fabs(tau) + std::sqrt(1.0 + tau * tau));
+        const double c = 1.0 / std::sqrt(1.0 + t * t), s = t * c;
+        for (int k = 0; k < n; ++k) {   // columns p, q
+          const double akp = A[(size_t)p * n + k], akq = A[(size_t)q * n + k];
+          A[(size_t)p * n + k] = c * akp - s * akq;
+          A[(size_t)q * n + k] = s * akp + c * akq;
+        }
+        for (int k = 0; k < n; ++k) {   // rows p, q
+          const double apk = A[(size_t)k * n + p], aqk = A[(size_t)k * n + q];
+          A[(size_t)k * n + p] = c * apk - s * aqk;
+          A[(size_t)k * n + q] = s * apk + c * aqk;
+        }
+        for (int k = 0; k < n; ++k) {
+          const double skp = Sv[(size_t)p * n + k], skq = Sv[(size_t)q * n + k];
+          Sv[(size_t)p * n + k] = c * skp - s * skq;
+          Sv[(size_t)q * n + k] = s * skp + c * skq;
+        }
+      }
+  }
+  w.resize(n);
+  for (int i = 0; i < n; ++i) w[i] = A[(size_t)i * n + i];
+}
+
+// ---------------------------------------------------------------------------
+// distributed plumbing
+// ---------------------------------------------------------------------------
+struct Ops {
+  dnm_mat *A;
+  const dnm_hooks *hooks;
+  hipStream_t st;
+  int64_t n;
+  int matvecs = 0;
+
+  int mult(const void *x, void *y) {
+    ++matvecs;
+    if (hooks && hooks->mult) {
+      DNM_CHECK(hooks->mult(hooks->ctx, x, y) == 0, "mult hook failed");
+      return 0;
+    }
+    return dnm_mat_mult(A, x, y, (void *)st);
+  }
+  int sum(double *buf, int cnt) {
+    if (hooks && hooks->allreduce_sum)
+      DNM_CHECK(hooks->allreduce_sum(hooks->ctx, buf, cnt) == 0, "allreduce_sum hook failed");
+    return 0;
+  }
+  int maxr(double *buf, int cnt) {
+    if (hooks && hooks->allreduce_max)
+      DNM_CHECK(hooks->allreduce_max(hooks->ctx, buf, cnt) == 0, "allreduce_max hook failed");
+    return 0;
+  }
+  // h = V[:, 0:nv)^H w (global)
+  int mdot(const void *V, int nv, const void *w, std::vector<zc> &h) {
+    std::vector<double> buf((size_t)2 * nv);
+    DNM_TRY(vec_mdot_host(V, n, nv, w, n, buf.data(), st));
+    DNM_TRY(sum(buf.data(), 2 * nv));
+    h.resize(nv);
+    for (int j = 0; j < nv; ++j) h[j] = zc(buf[2 * j], buf[2 * j + 1]);
+    return 0;
+  }
+  int norm(const void *w, double *out) {
+    double buf[2];
+    DNM_TRY(vec_mdot_host(w, n, 1, w, n, buf, st));
+    DNM_TRY(sum(buf, 1));
+    *out = std::sqrt(buf[0] > 0 ? buf[0] : 0.0);
+    return 0;
+  }
+  // w += V[:, 0:nv) c
+  int maxpy(void *w, const void *V, int nv, const std::vector<zc> &c) {
+    std::vector<double> buf((size_t)2 * nv);
+    for (int j = 0; j < nv; ++j) { buf[2 * j] = c[j].real(); buf[2 * j + 1] = c[j].imag(); }
+    const double *cd = nullptr;
+    DNM_TRY(vec_upload_coefs(buf.data(), buf.size(), st, &cd));
+    return vk_maxpy(w, V, n, nv, n, cd, st);
+  }
+  // orthogonalise p against V[:, 0:nv) (classical Gram-Schmidt, applied twice),
+  // accumulating the coefficients in h; returns ||p|| afterwards
+  int orthogonalize(void *p, const void *V, int nv, std::vector<zc> &h, double *nrm) {
+    std::vector<zc> h1, neg;
+    h.assign(nv, zc(0));
+    for (int pass = 0; pass < 2; ++pass) {
+      DNM_TRY(mdot(V, nv, p, h1));
+      neg.resize(nv);
+      for (int j = 0; j < nv; ++j) { neg[j] = -h1[j]; h[j] += h1[j]; }
+      DNM_TRY(maxpy(p, V, nv, neg));
+    }
+    return norm(p, nrm);
+  }
+};
+
+static char *vecptr(void *base, int64_t n, int j) { return (char *)base + (size_t)j * (size_t)n * 16; }
+
+static double round2(double t) {
+  // Expokit's two-significant-digit rounding of a step size
+  const double sqr1 = std::sqrt(0.1);
+  const double p1 = std::pow(10.0, std::round(std::log10(t) - sqr1) - 1.0);
+  return std::trunc(t / p1 + 0.55) * p1;
+}
+
+}  // namespace dnm
+
+using namespace dnm;
+
+extern "C" {
+
+int dnm_expm_multiply(dnm_mat *A, const void *x, void *y, int64_t n_local, double scale_re,
+                      double scale_im, double tol, int ncv, int max_its, size_t work_limit_bytes,
+                      const dnm_hooks *hooks, dnm_solver_stats *stats, void *stream) {
+  DNM_CHECK(A && x && y && stats, "null argument");
+  hipStream_t st = (hipStream_t)stream;
+  Ops ops{A, hooks, st, n_local};
+  stats->reason = 0; stats->its = 0; stats->matvecs = 0; stats->nconv = 0; stats->err_est = 0;
+  int64_t Nglob = A->N;
+  if (tol <= 0) tol = 1e-8;
+  if (max_its <= 0) max_its = 100;
+  int m = ncv > 0 ? ncv : 30;
+  if ((int64_t)m > Nglob) m = (int)Nglob;
+  if (work_limit_bytes) {
+    int64_t fit = (int64_t)(work_limit_bytes / ((size_t)n_local * 16)) - 2;
+    if (fit < 2) fit = 2;
+    if (m > fit) m = (int)fit;
+  }
+  if (m < 1) m = 1;
+
+  const zc scale(scale_re, scale_im);
+  const double t_out = std::abs(scale);
+  DNM_HIP(hipMemcpyAsync(y, x, (size_t)n_local * 16, hipMemcpyDeviceToDevice, st));
+  if (t_out == 0.0) { stats->reason = DNM_CONVERGED_TOL; return 0; }
+  const zc dir = scale / t_out;
+
+  double anorm = 0;
+  DNM_TRY(dnm_mat_norm_inf(A, &anorm, stream));
+  DNM_TRY(ops.maxr(&anorm, 1));
+  if (hooks && hooks->allreduce_max) dnm_mat_set_norm(A, anorm);
+
+  double beta = 0;
+  DNM_TRY(ops.norm(y, &beta));
+  if (beta == 0.0 || anorm == 0.0) { stats->reason = DNM_CONVERGED_TOL; return 0; }
+
+  DevBuf basis;   // v_0..v_m plus one scratch vector
+  DNM_TRY(basis.alloc((size_t)(m + 2) * (size_t)n_local * 16));
+  void *V = basis.p;
+  void *tmpv = vecptr(V, n_local, m + 1);
+
+  const double eps = 2.220446049250313e-16;
+  const double rndoff = anorm * eps, break_tol = 1e-7, gamma = 0.9, delta = 1.2;
+  const int mxrej = 10;
+  double xm = 1.0 / m;
+  double t_now = 0, s_error = 0;
+  const double fact = std::pow((m + 1) / std::exp(1.0), m + 1) * std::sqrt(2.0 * M_PI * (m + 1));
+  double t_new = (1.0 / anorm) * std::pow((fact * tol) / (4.0 * beta * anorm), xm);
+  t_new = round2(t_new);
+
+  const int mh = m + 2;
+  std::vector<zc> H, F, Hs;
+  int nstep = 0;
+  while (t_now < t_out) {
+    if (nstep >= max_its) {
+      stats->reason = DNM_DIVERGED_ITS;
+      stats->its = nstep; stats->matvecs = ops.matvecs; stats->err_est = s_error;
+      return 0;
+    }
+    ++nstep;
+    double t_step = std::min(t_out - t_now, t_new);
+    H.assign((size_t)mh * mh, zc(0));
+    // v_0 = w / beta
+    DNM_TRY(vk_axpby(vecptr(V, n_local, 0), y, n_local, 1.0 / beta, 0, 0, 0, st));
+    int mb = m, k1 = 2;
+    double avnorm = 0;
+    std::vector<zc> h;
+    for (int j = 0; j < m; ++j) {
+      void *p = vecptr(V, n_local, j + 1);
+      DNM_TRY(ops.mult(vecptr(V, n_local, j), p));
+      double hn = 0;
+      DNM_TRY(ops.orthogonalize(p, V, j + 1, h, &hn));
+      for (int i = 0; i <= j; ++i) H[(size_t)j * mh + i] = h[i];
+      if (hn <= break_tol * anorm) {   // happy breakdown
+        k1 = 0;
+        mb = j + 1;
+        t_step = t_out - t_now;
+        break;
+      }
+      H[(size_t)j * mh + (j + 1)] = hn;
+      DNM_TRY(vk_scale(p, n_local, 1.0 / hn, 0, st));
+    }
+    if (k1 != 0) {
+      H[(size_t)m * mh + (m + 1)] = 1.0;
+      // avnorm = || A v_m ||
+      DNM_TRY(ops.mult(vecptr(V, n_local, m), tmpv));
+      DNM_TRY(ops.norm(tmpv, &avnorm));
+    }
+    int ireject = 0;
+    double err_loc = 0;
+    int mx = mb + k1;
+    while (true) {
+      mx = mb + k1;
+      Hs.assign((size_t)mx * mx, zc(0));
+      for (int j = 0; j < mx; ++j)
+        for (int i = 0; i < mx; ++i) Hs[(size_t)j * mx + i] = dir * t_step * H[(size_t)j * mh + i];
+      DNM_CHECK(zexpm(mx, Hs, F) == 0, "dense expm failed");
+      if (k1 == 0) { err_loc = break_tol; break; }
+      const double p1 = std::abs(F[m]) * beta;
+      const double p2 = std::abs(F[m + 1]) * beta * avnorm;
+      if (p1 > 10.0 * p2) { err_loc = p2; xm = 1.0 / m; }
+      else if (p1 > p2) { err_loc = (p1 * p2) / (p1 - p2); xm = 1.0 / m; }
+      else { err_loc = p1; xm = 1.0 / std::max(1, m - 1); }
+      if (err_loc <= delta * t_step * tol) break;
+      t_step = gamma * t_step * std::pow(t_step * tol / err_loc, xm);
+      t_step = round2(t_step);
+      if (++ireject > mxrej) {
+        stats->reason = DNM_DIVERGED_BREAKDOWN;
+        stats->its = nstep; stats->matvecs = ops.matvecs; stats->err_est = s_error;
+        return 0;
+      }
+    }
+    // w = V[:, 0:mx') (beta F[0:mx', 0])
+    const int mxw = mb + std::max(0, k1 - 1);
+    std::vector<zc> c(mxw);
+    for (int i = 0; i < mxw; ++i) c[i] = beta * F[i];
+    DNM_TRY(vk_set(y, n_local, 0, 0, st));
+    DNM_TRY(ops.maxpy(y, V, mxw, c));
+    DNM_TRY(ops.norm(y, &beta));
+    t_now += t_step;
+    t_new = gamma * t_step * std::pow(t_step * tol / err_loc, xm);
+    t_new = round2(t_new);
+    err_loc = std::max(err_loc, rndoff);
+    s_error += err_loc;
+    if (beta == 0.0) break;
+  }
+  DNM_HIP(hipStreamSynchronize(st));
+  stats->reason = DNM_CONVERGED_TOL;
+  stats->its = nstep;
+  stats->matvecs = ops.matvecs;
+  stats->err_est = s_error;
+  return 0;
+}
+
+int dnm_eigsolve(dnm_mat *A, int64_t n_local, int nev, int which, double tol, int ncv, int max_its,
+                 uint64_t seed, const dnm_hooks *hooks, int nev_max, double *evals, void *evecs,
+                 dnm_solver_stats *stats, void *stream) {
+  DNM_CHECK(A && evals && stats && nev >= 1 && nev_max >= nev, "bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  Ops ops{A, hooks, st, n_local};
+  stats->reason = 0; stats->its = 0; stats->matvecs = 0; stats->nconv = 0; stats->err_est = 0;
+  const int64_t Nglob = A->N;
+  if (tol <= 0) tol = 1e-8;
+  int m = ncv > 0 ? ncv : std::max(2 * nev, nev + 15);
+  if ((int64_t)m > Nglob) m = (int)Nglob;
+  DNM_CHECK(m >= nev, "ncv smaller than nev");
+  if (max_its <= 0) max_its = (int)std::max<int64_t>(100, 2 * Nglob / m);
+  DNM_CHECK((size_t)(m + 1) * 64 * 16 <= 160 * 1024, "ncv too large for the basis-rotation kernel");
+
+  DevBuf basis;
+  DNM_TRY(basis.alloc((size_t)(m + 1) * (size_t)n_local * 16));
+  void *V = basis.p;
+
+  // start vector: counter-based normal deviates keyed by the global index
+  int64_t offset = 0;
+  if (hooks) offset = (int64_t)A->rank * n_local;
+  DNM_TRY(vk_random(vecptr(V, n_local, 0), n_local, seed, offset, st));
+  double nrm0 = 0;
+  DNM_TRY(ops.norm(vecptr(V, n_local, 0), &nrm0));
+  DNM_CHECK(nrm0 > 0, "zero start vector");
+  DNM_TRY(vk_scale(vecptr(V, n_local, 0), n_local, 1.0 / nrm0, 0, st));
+
+  std::vector<double> theta, spike;        // kept Ritz values and their coupling to v_l
+  std::vector<double> alpha(m, 0.0), betav(m, 0.0);
+  int l = 0, its = 0, nconv = 0;
+  std::vector<double> T, w, Sm;
+  std::vector<int> order(m);
+  std::vector<zc> h;
+  double anorm_est = 0;
+
+  while (true) {
+    ++its;
+    for (int j = l; j < m; ++j) {
+      void *p = vecptr(V, n_local, j + 1);
+      DNM_TRY(ops.mult(vecptr(V, n_local, j), p));
+      double bn = 0;
+      DNM_TRY(ops.orthogonalize(p, V, j + 1, h, &bn));
+      alpha[j] = h[j].real();
+      betav[j] = bn;
+      anorm_est = std::max(anorm_est, std::fabs(alpha[j]) + bn);
+      if (bn <= 1e-14 * std::max(1.0, anorm_est)) {
+        // invariant subspace: continue with a fresh direction orthogonal to the basis
+        betav[j] = 0.0;
+        DNM_TRY(vk_random(p, n_local, seed + 7919u * (uint64_t)(its * m + j + 1), offset, st));
+        double rn = 0;
+        DNM_TRY(ops.orthogonalize(p, V, j + 1, h, &rn));
+        DNM_CHECK(rn > 0, "Lanczos breakdown: could not extend the basis");
+        DNM_TRY(vk_scale(p, n_local, 1.0 / rn, 0, st));
+      } else {
+        DNM_TRY(vk_scale(p, n_local, 1.0 / bn, 0, st));
+      }
+    }
+    // projected matrix: diag(theta) + spike row/col at l, tridiagonal beyond
+    T.assign((size_t)m * m, 0.0);
+    for (int i = 0; i < l; ++i) {
+      T[(size_t)i * m + i] = theta[i];
+      T[(size_t)l * m + i] = T[(size_t)i * m + l] = spike[i];
+    }
+    for (int j = l; j < m; ++j) {
+      T[(size_t)j * m + j] = alpha[j];
+      if (j + 1 < m) T[(size_t)(j + 1) * m + j] = T[(size_t)j * m + (j + 1)] = betav[j];
+    }
+    jacobi_eig(m, T, w, Sm);
+    for (int i = 0; i < m; ++i) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](int a, int b) {
+      if (which == DNM_WHICH_LOWEST) return w[a] < w[b];
+      if (which == DNM_WHICH_HIGHEST) return w[a] > w[b];
+      return std::fabs(w[a]) > std::fabs(w[b]);
+    });
+    const double bm = betav[m - 1];
+    nconv = 0;
+    for (int i = 0; i < m; ++i) {
+      const int c = order[i];
+      const double res = std::fabs(bm * Sm[(size_t)c * m + (m - 1)]);
+      // relative to the eigenvalue (SLEPc EPS_CONV_REL)
+      if (res <= tol * std::max(std::fabs(w[c]), 1e-300)) ++nconv; else break;
+    }
+    if (nconv >= nev || its >= max_its) break;
+    // thick restart: keep the converged pairs plus half of the rest
+    int keep = nconv + std::max(1, (m - nconv) / 2);
+    if (keep > m - 1) keep = m - 1;
+    std::vector<double> Ssel((size_t)2 * m * keep, 0.0);
+    theta.assign(keep, 0.0);
+    spike.assign(keep, 0.0);
+    for (int o = 0; o < keep; ++o) {
+      const int c = order[o];
+      theta[o] = w[c];
+      spike[o] = bm * Sm[(size_t)c * m + (m - 1)];
+      for (int j = 0; j < m; ++j) Ssel[2 * ((size_t)o * m + j)] = Sm[(size_t)c * m + j];
+    }
+    const double *sd = nullptr;
+    DNM_TRY(vec_upload_coefs(Ssel.data(), Ssel.size(), st, &sd));
+    DNM_TRY(vk_basis_update(V, n_local, m, keep, n_local, sd, st));
+    DNM_HIP(hipMemcpyAsync(vecptr(V, n_local, keep), vecptr(V, n_local, m), (size_t)n_local * 16,
+                           hipMemcpyDeviceToDevice, st));
+    l = keep;
+  }
+
+  const int nout = std::min(nconv, nev_max);
+  for (int i = 0; i < nout; ++i) evals[i] = w[order[i]];
+  if (evecs && nout > 0) {
+    std::vector<double> Ssel((size_t)2 * m * nout, 0.0);
+    for (int o = 0; o < nout; ++o)
+      for (int j = 0; j < m; ++j) Ssel[2 * ((size_t)o * m + j)] = Sm[(size_t)order[o] * m + j];
+    const double *sd = nullptr;
+    DNM_TRY(vec_upload_coefs(Ssel.data(), Ssel.size(), st, &sd));
+    DNM_TRY(vk_basis_update(V, n_local, m, nout, n_local, sd, st));
+    DNM_HIP(hipMemcpyAsync(evecs, V, (size_t)nout * (size_t)n_local * 16, hipMemcpyDeviceToDevice, st));
+  }
+  DNM_HIP(hipStreamSynchronize(st));
+  stats->its = its;
+  stats->matvecs = ops.matvecs;
+  stats->nconv = nout;
+  stats->reason = (nconv >= nev) ? DNM_CONVERGED_TOL : DNM_DIVERGED_ITS;
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,579 @@
+// C ABI: device helpers, subspace maps, and the shell matrix (create / mult /
+// norm / diagonal / destroy).  See include/dynamite_amd.h for the reference
+// interfaces each entry point replaces.
+#include "mat.h"
+
+#include <algorithm>
+#include <cstring>
+
+namespace dnm {
+
+static thread_local std::string g_err;
+
+void set_error(const char *fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+}
+
+int DevBuf::alloc(size_t nbytes) {
+  release();
+  if (nbytes == 0) nbytes = 16;
+  DNM_HIP(hipMalloc(&p, nbytes));
+  bytes = nbytes;
+  return 0;
+}
+int DevBuf::upload(const void *host, size_t nbytes) {
+  DNM_TRY(alloc(nbytes));
+  if (nbytes) DNM_HIP(hipMemcpy(p, host, nbytes, hipMemcpyHostToDevice));
+  return 0;
+}
+void DevBuf::release() {
+  if (p) (void)hipFree(p);
+  p = nullptr;
+  bytes = 0;
+}
+
+static int view_from_c(const dnm_subspace *s, SubView *v) {
+  DNM_CHECK(s != nullptr, "null subspace descriptor");
+  DNM_CHECK(s->type >= DNM_FULL && s->type <= DNM_SPIN_CONSERVE, "unknown subspace type %d", s->type);
+  DNM_CHECK(s->L >= 1 && s->L <= 63, "L=%lld out of range", (long long)s->L);
+  v->type = s->type;
+  v->L = (int32_t)s->L;
+  v->space = (int32_t)s->space;
+  v->k = (int32_t)s->k;
+  v->ld = (int32_t)s->ld_nchoosek;
+  v->dim = s->dim;
+  v->nchoosek = s->nchoosek;
+  v->state_map = s->state_map;
+  v->rmap_indices = s->rmap_indices;
+  v->rmap_states = s->rmap_states;
+  if (s->type == DNM_PARITY) DNM_CHECK(s->space == 0 || s->space == 1, "parity space must be 0 or 1");
+  if (s->type == DNM_SPIN_CONSERVE) {
+    DNM_CHECK(s->nchoosek != nullptr && s->ld_nchoosek == s->L + 1 && s->k >= 0 && s->k <= s->L,
+              "bad SpinConserve descriptor");
+  }
+  if (s->type == DNM_EXPLICIT)
+    DNM_CHECK(s->state_map && s->rmap_states && s->dim >= 1, "bad Explicit descriptor");
+  return 0;
+}
+
+int SubOwned::init(const dnm_subspace *s, bool want_device) {
+  SubView v{};
+  DNM_TRY(view_from_c(s, &v));
+  host = v;
+  if (v.type == DNM_SPIN_CONSERVE) {
+    nck.assign(v.nchoosek, v.nchoosek + (size_t)(v.k + 1) * v.ld);
+    host.nchoosek = nck.data();
+  }
+  if (v.type == DNM_EXPLICIT) {
+    smap.assign(v.state_map, v.state_map + v.dim);
+    rstates.assign(v.rmap_states, v.rmap_states + v.dim);
+    host.state_map = smap.data();
+    host.rmap_states = rstates.data();
+    if (v.rmap_indices) {
+      rind.assign(v.rmap_indices, v.rmap_indices + v.dim);
+      host.rmap_indices = rind.data();
+    }
+  }
+  host.dim = sub_dim(host);
+  dev = host;
+  dev.nchoosek = nullptr;
+  dev.state_map = dev.rmap_indices = dev.rmap_states = nullptr;
+  if (want_device) {
+    if (!nck.empty()) {
+      DNM_TRY(d_nck.upload(nck.data(), nck.size() * 8));
+      dev.nchoosek = (const int64_t *)d_nck.p;
+    }
+    if (!smap.empty()) {
+      DNM_TRY(d_smap.upload(smap.data(), smap.size() * 8));
+      DNM_TRY(d_rstates.upload(rstates.data(), rstates.size() * 8));
+      dev.state_map = (const int64_t *)d_smap.p;
+      dev.rmap_states = (const int64_t *)d_rstates.p;
+      if (!rind.empty()) {
+        DNM_TRY(d_rind.upload(rind.data(), rind.size() * 8));
+        dev.rmap_indices = (const int64_t *)d_rind.p;
+      }
+    }
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// MSC -> row-evaluated index-space form (see plan.h).  Full: identity map.
+// Parity: index = state >> 1; the dropped bit parity(idx)^space is folded
+// into the sign masks (cf. the check_parity branch of sum_term,
+// bpetsc_template_2.c:659-662, 848-854).
+// ---------------------------------------------------------------------------
+static int build_opform(const dnm_mat &A, OpForm *op) {
+  const SubView &l = A.left.host, &r = A.right.host;
+  const bool par = l.type == DNM_PARITY;
+  const int n = par ? l.L - 1 : l.L;
+  op->n = n;
+  op->masks.clear();
+  const uint64_t ones = n >= 64 ? ~0ull : (((uint64_t)1 << n) - 1);
+  for (size_t mi = 0; mi < A.masks.size(); ++mi) {
+    const uint64_t mask = (uint64_t)A.masks[mi];
+    if (par && (parity64(mask) != (l.space ^ r.space))) continue;   // maps outside the right space
+    RowMask rm;
+    rm.mask = par ? (mask >> 1) : mask;
+    for (int64_t t = A.mask_offsets[mi]; t < A.mask_offsets[mi + 1]; ++t) {
+      const uint64_t sg = (uint64_t)A.signs[t];
+      RowTerm rt;
+      rt.is_imag = parity64(mask & sg);           // !TERM_REAL
+      double c = A.real_coeffs[t];
+      uint64_t s2 = sg;
+      if (par) {
+        s2 = sg >> 1;
+        if (sg & 1) {
+          s2 ^= ones;
+          if (r.space) c = -c;
+        }
+      }
+      // column-evaluated -> row-evaluated: col = row ^ mask
+      if (parity64(rm.mask & s2)) c = -c;
+      rt.sign = s2;
+      rt.coeff = c;
+      rm.terms.push_back(rt);
+    }
+    if (rm.mask == 0) {
+      RowMask im;
+      im.mask = 0;
+      im.zero_mask_offdiag = true;
+      std::vector<RowTerm> re;
+      for (const RowTerm &t : rm.terms) (t.is_imag ? im.terms : re).push_back(t);
+      rm.terms.swap(re);
+      if (!im.terms.empty()) op->masks.push_back(std::move(im));
+      if (rm.terms.empty()) continue;
+    }
+    op->masks.push_back(std::move(rm));
+  }
+  std::stable_sort(op->masks.begin(), op->masks.end(),
+            [](const RowMask &a, const RowMask &b) { return a.mask < b.mask; });
+  return 0;
+}
+
+static uint32_t compress_to_tile(uint64_t bits, const PassSpec &ps) {
+  uint32_t out = 0;
+  int off = 0;
+  for (int j = 0; j < ps.nseg; ++j) {
+    uint64_t seg = (bits >> ps.seg_pos[j]) & (((uint64_t)1 << ps.seg_len[j]) - 1);
+    out |= (uint32_t)seg << off;
+    off += ps.seg_len[j];
+  }
+  return out;
+}
+
+static int build_pass(const dnm_mat &A, const PassSpec &ps, PassOnDevice *out) {
+  const OpForm &op = A.op;
+  const Plan &pl = A.plan;
+  const int B = ps.B, logR = pl.cfg.logR, lognt = B - logR, R = 1 << logR;
+  const uint64_t tb = ps.tile_bits();
+  DevPass &d = out->desc;
+  memset(&d, 0, sizeof(d));
+  d.nseg = ps.nseg;
+  int off = 0;
+  for (int j = 0; j < ps.nseg; ++j) {
+    d.seg_off[j] = off;
+    d.seg_len[j] = ps.seg_len[j];
+    d.seg_pos[j] = ps.seg_pos[j];
+    off += ps.seg_len[j];
+  }
+  DNM_CHECK(off == B, "internal: tile segments do not add up to B");
+  // block-id bits fill the local index bits outside the tile, low to high
+  {
+    int nb = 0, boff = 0, pos = 0;
+    while (pos < pl.n_loc) {
+      if ((tb >> pos) & 1) { ++pos; continue; }
+      int start = pos;
+      while (pos < pl.n_loc && !((tb >> pos) & 1)) ++pos;
+      DNM_CHECK(nb < MAXSEG, "internal: too many block segments");
+      d.bseg_off[nb] = boff;
+      d.bseg_len[nb] = pos - start;
+      d.bseg_pos[nb] = start;
+      boff += pos - start;
+      ++nb;
+    }
+    d.nbseg = nb;
+    DNM_CHECK(boff == pl.n_loc - B, "internal: block bits do not add up");
+  }
+  d.sign_base = (uint64_t)pl.rank << pl.n_loc;
+  d.accumulate = ps.accumulate ? 1 : 0;
+  d.has_diag = 0;
+
+  std::vector<DevTerm> terms;
+  std::vector<DevMask> masks;
+  auto push_term = [&](const RowTerm &t) {
+    DevTerm dt;
+    dt.sign_ext = t.sign & ~tb;
+    dt.sign_tile = compress_to_tile(t.sign & tb, ps);
+    dt.pad = 0;
+    dt.coeff = t.coeff;
+    terms.push_back(dt);
+    return dt;
+  };
+
+  if (ps.has_diag) {
+    const RowMask *dm = nullptr;
+    for (const RowMask &m : op.masks) if (m.mask == 0 && !m.zero_mask_offdiag) dm = &m;
+    if (dm) {
+      d.has_diag = 1;
+      // mask-0 terms are real by construction (mask & sign == 0)
+      d.dext_begin = (uint32_t)terms.size();
+      for (const RowTerm &t : dm->terms)
+        if (compress_to_tile(t.sign & tb, ps) == 0) push_term(t);
+      d.dext_end = (uint32_t)terms.size();
+      for (int j = 0; j < R; ++j) {
+        d.dbucket[j] = (uint32_t)terms.size();
+        for (const RowTerm &t : dm->terms) {
+          uint32_t st = compress_to_tile(t.sign & tb, ps);
+          if (st != 0 && (int)(st >> lognt) == j) push_term(t);
+        }
+      }
+      for (int j = R; j <= MAXR; ++j) d.dbucket[j] = (uint32_t)terms.size();
+    }
+  }
+
+  auto push_mask = [&](int idx, bool gather, int src) {
+    const RowMask &m = op.masks[idx];
+    DevMask dm;
+    memset(&dm, 0, sizeof(dm));
+    const uint64_t mloc = m.mask & (((uint64_t)1 << pl.n_loc) - 1);
+    dm.mask_tile = compress_to_tile(mloc & tb, ps);
+    dm.mask_loc = (uint32_t)mloc;
+    dm.src = (uint32_t)src;
+    bool kvar = false;
+    dm.re_begin = (uint32_t)terms.size();
+    for (const RowTerm &t : m.terms)
+      if (!t.is_imag) kvar |= (push_term(t).sign_tile >> lognt) != 0;
+    dm.re_end = dm.im_begin = (uint32_t)terms.size();
+    for (const RowTerm &t : m.terms)
+      if (t.is_imag) kvar |= (push_term(t).sign_tile >> lognt) != 0;
+    dm.im_end = (uint32_t)terms.size();
+    dm.flags = (gather ? MF_GATHER : 0u) | (kvar ? MF_KVAR : 0u);
+    if (!gather) DNM_CHECK((mloc & ~tb) == 0, "internal: tile mask leaves the tile");
+    masks.push_back(dm);
+    return 0;
+  };
+  for (int idx : ps.tile_masks) DNM_TRY(push_mask(idx, false, 0));
+  for (size_t i = 0; i < ps.gather_masks.size(); ++i)
+    DNM_TRY(push_mask(ps.gather_masks[i], true, ps.gather_src[i]));
+
+  d.nmasks = (int32_t)masks.size();
+  d.need_tile = (d.has_diag || !ps.tile_masks.empty()) ? 1 : 0;
+  out->h_masks = masks;
+  out->h_terms = terms;
+  if (!A.host_only) {
+    DNM_TRY(out->masks.upload(masks.data(), masks.size() * sizeof(DevMask)));
+    DNM_TRY(out->terms.upload(terms.data(), terms.size() * sizeof(DevTerm)));
+  }
+  d.masks = (const DevMask *)out->masks.p;
+  d.terms = (const DevTerm *)out->terms.p;
+  out->partner = ps.partner;
+  return 0;
+}
+
+static hipStream_t S(void *stream) { return (hipStream_t)stream; }
+
+}  // namespace dnm
+
+using namespace dnm;
+
+extern "C" {
+
+const char *dnm_last_error(void) { return g_err.c_str(); }
+int dnm_version(void) { return 100; }
+
+int dnm_device_count(int *count) {
+  DNM_CHECK(count, "null pointer");
+  hipError_t e = hipGetDeviceCount(count);
+  if (e != hipSuccess) { *count = 0; (void)hipGetLastError(); }
+  return 0;
+}
+int dnm_set_device(int device) { DNM_HIP(hipSetDevice(device)); return 0; }
+int dnm_malloc(void **dptr, size_t bytes) { DNM_HIP(hipMalloc(dptr, bytes ? bytes : 16)); return 0; }
+int dnm_free(void *dptr) { DNM_HIP(hipFree(dptr)); return 0; }
+int dnm_memcpy_h2d(void *dst, const void *src, size_t bytes, void *stream) {
+  DNM_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, S(stream)));
+  DNM_HIP(hipStreamSynchronize(S(stream)));
+  return 0;
+}
+int dnm_memcpy_d2h(void *dst, const void *src, size_t bytes, void *stream) {
+  DNM_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, S(stream)));
+  DNM_HIP(hipStreamSynchronize(S(stream)));
+  return 0;
+}
+int dnm_stream_synchronize(void *stream) { DNM_HIP(hipStreamSynchronize(S(stream))); return 0; }
+
+// ---- subspaces --------------------------------------------------------------
+int dnm_subspace_dim(const dnm_subspace *s, int64_t *dim) {
+  SubView v{};
+  DNM_TRY(view_from_c(s, &v));
+  *dim = sub_dim(v);
+  return 0;
+}
+
+int dnm_idx_to_state(const dnm_subspace *s, int64_t n, const int64_t *idxs, int64_t *states) {
+  SubView v{};
+  DNM_TRY(view_from_c(s, &v));
+  const int64_t dim = sub_dim(v);
+  for (int64_t i = 0; i < n; ++i) {
+    // the reference raises for out-of-range indices (bsubspace.pyx:170-173)
+    DNM_CHECK(idxs[i] >= 0 && idxs[i] < dim, "index %lld out of bounds for subspace of dimension %lld",
+              (long long)idxs[i], (long long)dim);
+    states[i] = sub_i2s(idxs[i], v);
+  }
+  return 0;
+}
+
+int dnm_state_to_idx(const dnm_subspace *s, int64_t n, const int64_t *states, int64_t *idxs) {
+  SubView v{};
+  DNM_TRY(view_from_c(s, &v));
+  for (int64_t i = 0; i < n; ++i) idxs[i] = sub_s2i(states[i], v);
+  return 0;
+}
+
+// ---- shell matrix -------------------------------------------------------------
+int dnm_mat_create(int64_t nmasks, const int64_t *masks, const int64_t *mask_offsets,
+                   const int64_t *signs, const double *coeffs, const dnm_subspace *left,
+                   const dnm_subspace *right, int xparity, int flags, const dnm_partition *part,
+                   dnm_mat **out) {
+  DNM_CHECK(out, "null output handle");
+  *out = nullptr;
+  DNM_CHECK(nmasks >= 0 && (nmasks == 0 || (masks && mask_offsets && signs && coeffs)),
+            "null operator arrays");
+  DNM_CHECK(xparity == 0, "XParity subspaces are not supported by this engine yet");
+  std::unique_ptr<dnm_mat> A(new dnm_mat());
+  A->flags = flags;
+  A->host_only = (flags & DNM_MAT_HOST_ONLY) != 0;
+  const int64_t nterms = nmasks ? mask_offsets[nmasks] : 0;
+  A->masks.assign(masks, masks + nmasks);
+  if (nmasks) A->mask_offsets.assign(mask_offsets, mask_offsets + nmasks + 1);
+  else A->mask_offsets.assign(1, 0);
+  A->signs.assign(signs, signs + nterms);
+  A->real_coeffs.resize(nterms);
+  for (int64_t i = 1; i < nmasks; ++i)
+    DNM_CHECK(masks[i] > masks[i - 1], "masks must be sorted and unique");
+  for (int64_t t = 0; t < nterms; ++t) {
+    // one double per term: the real part if non-zero, else the imaginary part
+    const double re = coeffs[2 * t], im = coeffs[2 * t + 1];
+    A->real_coeffs[t] = (re != 0.0) ? re : im;
+  }
+  DNM_TRY(A->left.init(left, !A->host_only));
+  DNM_TRY(A->right.init(right, !A->host_only));
+  DNM_CHECK(A->left.host.L == A->right.host.L, "left and right subspaces have different L");
+  A->M = A->left.host.dim;
+  A->N = A->right.host.dim;
+  A->rank = part ? part->rank : 0;
+  A->nranks = part ? part->nranks : 1;
+  DNM_CHECK(A->nranks >= 1 && (A->nranks & (A->nranks - 1)) == 0 && A->rank >= 0 && A->rank < A->nranks,
+            "bad partition (rank %d of %d): nranks must be a power of two", A->rank, A->nranks);
+
+  const int lt = A->left.host.type, rt = A->right.host.type;
+  A->hypercube = (lt == rt) && (lt == DNM_FULL || lt == DNM_PARITY);
+  if (A->nranks > 1) {
+    DNM_CHECK(A->hypercube, "partitioned multiply needs Full/Full or Parity/Parity subspaces");
+    DNM_CHECK(A->M % A->nranks == 0, "dimension not divisible by nranks");
+  }
+  A->m_local = A->M / A->nranks;
+  A->n_local = A->N / A->nranks;
+
+  // tables for the generic kernels (always: norm and diagonal use them)
+  if (!A->host_only) {
+  DNM_TRY(A->d_masks.upload(A->masks.data(), A->masks.size() * 8));
+  DNM_TRY(A->d_offsets.upload(A->mask_offsets.data(), A->mask_offsets.size() * 8));
+  DNM_TRY(A->d_signs.upload(A->signs.data(), A->signs.size() * 8));
+  DNM_TRY(A->d_rcoeffs.upload(A->real_coeffs.data(), A->real_coeffs.size() * 8));
+  A->dmsc.nmasks = (int32_t)nmasks;
+  A->dmsc.masks = (const int64_t *)A->d_masks.p;
+  A->dmsc.mask_offsets = (const int64_t *)A->d_offsets.p;
+  A->dmsc.signs = (const int64_t *)A->d_signs.p;
+  A->dmsc.real_coeffs = (const double *)A->d_rcoeffs.p;
+  }
+
+  if (A->hypercube) {
+    DNM_TRY(build_opform(*A, &A->op));
+    PlanConfig cfg = plan_config_from_env();
+    if (!tile_config_supported(cfg.B, cfg.logR)) {
+      set_error("unsupported tile configuration B=%d logR=%d", cfg.B, cfg.logR);
+      return 1;
+    }
+    DNM_TRY(make_plan(A->op, A->rank, A->nranks, cfg, &A->plan));
+    if (flags & DNM_MAT_FORCE_GATHER) A->plan.use_tiled = false;
+    if (A->nranks > 1)
+      DNM_CHECK(A->plan.use_tiled, "local vector (2^%d) smaller than one tile (2^%d)", A->plan.n_loc,
+                A->plan.cfg.B);
+    if (A->plan.use_tiled) {
+      for (const PassSpec &ps : A->plan.local) {
+        std::unique_ptr<PassOnDevice> p(new PassOnDevice());
+        DNM_TRY(build_pass(*A, ps, p.get()));
+        A->local_passes.push_back(std::move(p));
+      }
+      for (const PassSpec &ps : A->plan.remote) {
+        std::unique_ptr<PassOnDevice> p(new PassOnDevice());
+        DNM_TRY(build_pass(*A, ps, p.get()));
+        A->remote_passes.push_back(std::move(p));
+      }
+    }
+  }
+  *out = A.release();
+  return 0;
+}
+
+int dnm_mat_destroy(dnm_mat *A) {
+  delete A;
+  return 0;
+}
+
+int dnm_mat_sizes(const dnm_mat *A, int64_t *M, int64_t *N, int64_t *m_local, int64_t *n_local) {
+  DNM_CHECK(A, "null matrix");
+  if (M) *M = A->M;
+  if (N) *N = A->N;
+  if (m_local) *m_local = A->m_local;
+  if (n_local) *n_local = A->n_local;
+  return 0;
+}
+
+int dnm_mat_precompute_diagonal(dnm_mat *A, void *stream) {
+  DNM_CHECK(A && !A->host_only, "null or host-only matrix");
+  // only when the first mask is the identity (bpetsc_template_1.c:177-180) and
+  // left == right (operators.py:627-629; the caller guarantees it)
+  if (A->masks.empty() || A->masks[0] != 0) return 0;
+  DNM_CHECK(A->nranks == 1, "precomputed diagonal is not used by the partitioned multiply");
+  DNM_CHECK(A->M == A->N, "precompute_diagonal needs a square matrix");
+  DNM_TRY(A->diag.alloc((size_t)A->M * sizeof(double)));
+  DNM_TRY(launch_diag(A->dmsc, A->right.dev, A->M, (double *)A->diag.p, S(stream)));
+  A->have_diag = true;
+  return 0;
+}
+
+int dnm_mat_get_diagonal(dnm_mat *A, double *diag_host, void *stream) {
+  DNM_CHECK(A && A->have_diag, "no precomputed diagonal");
+  return dnm_memcpy_d2h(diag_host, A->diag.p, (size_t)A->M * sizeof(double), stream);
+}
+
+static bool use_glds(const dnm_mat *A) { return !(A->flags & DNM_MAT_NO_GLDS); }
+
+int dnm_mat_mult_local(dnm_mat *A, const void *x, void *y, void *stream) {
+  DNM_CHECK(A && x && y, "null argument");
+  DNM_CHECK(!A->host_only, "host-only handle cannot multiply");
+  DNM_CHECK(x != y, "x and y must be different vectors");
+  if (A->hypercube && A->plan.use_tiled) {
+    for (auto &p : A->local_passes)
+      DNM_TRY(launch_tile_pass(p->desc, A->plan.cfg.B, A->plan.cfg.logR, use_glds(A), A->plan.n_loc, x, y,
+                               nullptr, S(stream)));
+    return 0;
+  }
+  DNM_CHECK(A->nranks == 1, "generic kernel cannot run partitioned");
+  return launch_gather_matvec(A->dmsc, A->left.dev, A->right.dev, A->M,
+                              A->have_diag ? (const double *)A->diag.p : nullptr, x, y, S(stream));
+}
+
+int dnm_mat_mult(dnm_mat *A, const void *x, void *y, void *stream) {
+  DNM_CHECK(A, "null matrix");
+  DNM_CHECK(A->remote_passes.empty(),
+            "operator couples different ranks: use dnm_mat_mult_local + dnm_mat_mult_remote");
+  return dnm_mat_mult_local(A, x, y, stream);
+}
+
+int dnm_mat_partners(const dnm_mat *A, int *n, int32_t *partner_ranks) {
+  DNM_CHECK(A && n, "null argument");
+  *n = (int)A->remote_passes.size();
+  if (partner_ranks)
+    for (size_t i = 0; i < A->remote_passes.size(); ++i) partner_ranks[i] = A->remote_passes[i]->partner;
+  return 0;
+}
+
+int dnm_mat_mult_remote(dnm_mat *A, int32_t partner_rank, const void *x_remote, void *y, void *stream) {
+  DNM_CHECK(A && x_remote && y, "null argument");
+  DNM_CHECK(!A->host_only, "host-only handle cannot multiply");
+  for (auto &p : A->remote_passes)
+    if (p->partner == partner_rank)
+      return launch_tile_pass(p->desc, A->plan.cfg.B, A->plan.cfg.logR, use_glds(A), A->plan.n_loc,
+                              x_remote, y, x_remote, S(stream));
+  set_error("rank %d is not a partner of rank %d", partner_rank, A->rank);
+  return 1;
+}
+
+int dnm_mat_norm_inf(dnm_mat *A, double *nrm, void *stream) {
+  DNM_CHECK(A && nrm, "null argument");
+  DNM_CHECK(!A->host_only, "host-only handle has no device tables");
+  if (A->nrm != -1.0) {
+    *nrm = A->nrm;
+    return 0;
+  }
+  const int nb = norm_num_blocks(A->m_local);
+  DNM_TRY(A->scratch.alloc((size_t)nb * sizeof(double)));
+  DNM_TRY(launch_norm(A->dmsc, A->left.dev, A->right.dev, A->m_local, (int64_t)A->rank * A->m_local,
+                      (double *)A->scratch.p, S(stream)));
+  std::vector<double> h(nb);
+  DNM_TRY(dnm_memcpy_d2h(h.data(), A->scratch.p, (size_t)nb * sizeof(double), stream));
+  double best = 0.0;
+  for (double v : h) best = std::max(best, v);
+  if (A->nranks == 1) A->nrm = best;   // partitioned: caller reduces, then dnm_mat_set_norm
+  *nrm = best;
+  return 0;
+}
+
+int dnm_mat_set_norm(dnm_mat *A, double nrm) {
+  DNM_CHECK(A, "null matrix");
+  A->nrm = nrm;
+  return 0;
+}
+
+int dnm_mat_plan_describe(const dnm_mat *A, char *buf, size_t buflen) {
+  DNM_CHECK(A && buf && buflen, "null argument");
+  std::string s;
+  if (A->hypercube) s = A->plan.describe(A->op);
+  else s = "generic row-gather kernel (non-hypercube subspace pair)\n";
+  if (A->hypercube && !A->plan.use_tiled) s += "generic row-gather kernel in use\n";
+  snprintf(buf, buflen, "%s", s.c_str());
+  return 0;
+}
+
+int dnm_mat_export_pass(const dnm_mat *A, int remote, int idx, void *desc_out, size_t desc_bytes,
+                        void *masks_out, int max_masks, void *terms_out, int max_terms,
+                        int *nmasks, int *nterms) {
+  DNM_CHECK(A && nmasks && nterms, "null argument");
+  const auto &v = remote ? A->remote_passes : A->local_passes;
+  DNM_CHECK(idx >= 0 && idx < (int)v.size(), "pass index out of range");
+  const PassOnDevice &p = *v[idx];
+  *nmasks = (int)p.h_masks.size();
+  *nterms = (int)p.h_terms.size();
+  if (desc_out) {
+    DNM_CHECK(desc_bytes == sizeof(DevPass), "DevPass size mismatch (%zu vs %zu)", desc_bytes, sizeof(DevPass));
+    memcpy(desc_out, &p.desc, sizeof(DevPass));
+  }
+  if (masks_out) {
+    DNM_CHECK(max_masks >= *nmasks, "mask buffer too small");
+    memcpy(masks_out, p.h_masks.data(), p.h_masks.size() * sizeof(DevMask));
+  }
+  if (terms_out) {
+    DNM_CHECK(max_terms >= *nterms, "term buffer too small");
+    memcpy(terms_out, p.h_terms.data(), p.h_terms.size() * sizeof(DevTerm));
+  }
+  return 0;
+}
+
+int dnm_mat_plan_counts(const dnm_mat *A, int *n_local_passes, int *n_remote_passes, int *tiled,
+                        int *B, int *logR, int *n_loc) {
+  DNM_CHECK(A, "null matrix");
+  if (n_local_passes) *n_local_passes = (int)A->local_passes.size();
+  if (n_remote_passes) *n_remote_passes = (int)A->remote_passes.size();
+  if (tiled) *tiled = (A->hypercube && A->plan.use_tiled) ? 1 : 0;
+  if (B) *B = A->plan.cfg.B;
+  if (logR) *logR = A->plan.cfg.logR;
+  if (n_loc) *n_loc = A->plan.n_loc;
+  return 0;
+}
+
+int dnm_mat_plan_launches(const dnm_mat *A, int *n) {
+  DNM_CHECK(A && n, "null argument");
+  *n = (A->hypercube && A->plan.use_tiled) ? (int)A->local_passes.size() : 1;
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,69 @@
+// The shell-matrix handle behind the C ABI (replaces PETSc MatShell +
+// shell_context, src/dynamite/_backend/shell_context.h:12-27).
+#pragma once
+
+#include <memory>
+#include <vector>
+
+#include "kernels.h"
+#include "plan.h"
+#include "subspace.h"
+
+namespace dnm {
+
+// Device allocation that frees itself.
+struct DevBuf {
+  void *p = nullptr;
+  size_t bytes = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf &) = delete;
+  DevBuf &operator=(const DevBuf &) = delete;
+  ~DevBuf() { release(); }
+  int alloc(size_t nbytes);
+  int upload(const void *host, size_t nbytes);
+  void release();
+};
+
+// A subspace with owned host tables and their device mirrors.
+struct SubOwned {
+  SubView host{};
+  SubView dev{};
+  std::vector<int64_t> nck, smap, rind, rstates;
+  DevBuf d_nck, d_smap, d_rind, d_rstates;
+  int init(const dnm_subspace *s, bool want_device);
+};
+
+struct PassOnDevice {
+  DevPass desc{};
+  std::vector<DevMask> h_masks;   // host copies (diagnostics / host-only handles)
+  std::vector<DevTerm> h_terms;
+  DevBuf masks, terms;
+  int partner = -1;
+};
+
+}  // namespace dnm
+
+struct dnm_mat {
+  // operator as given (deep copies, BuildContext semantics)
+  std::vector<int64_t> masks, mask_offsets, signs;
+  std::vector<double> real_coeffs;
+  dnm::SubOwned left, right;
+  int64_t M = 0, N = 0, m_local = 0, n_local = 0;
+  int rank = 0, nranks = 1;
+  int flags = 0;
+  bool host_only = false;         // DNM_MAT_HOST_ONLY: plan and tables only, no device
+
+  bool hypercube = false;        // Full/Full or Parity/Parity: index space is a hypercube
+  dnm::OpForm op;
+  dnm::Plan plan;
+  std::vector<std::unique_ptr<dnm::PassOnDevice>> local_passes, remote_passes;
+
+  // generic-kernel tables
+  dnm::DevBuf d_masks, d_offsets, d_signs, d_rcoeffs;
+  dnm::DevMsc dmsc{};
+
+  dnm::DevBuf diag;              // cached diagonal (double[m_local]) if precomputed
+  bool have_diag = false;
+  double nrm = -1.0;             // ctx->nrm cache, -1 = unset (bpetsc_template_2.c:926-929)
+  dnm::DevBuf scratch;
+};

@@ -1,0 +1,487 @@
+// HIP kernels for the matrix-free H|psi> of an MSC (mask, sign, coefficient)
+// Pauli-string operator, written for gfx950 (MI355X): 64-wide wavefronts,
+// 160 KB LDS per CU, HBM-bound.  No MFMA: there is no dense contraction here.
+//
+// tile_pass_kernel  -- hypercube index spaces (Full, Parity): a workgroup
+//   stages a 2^B-amplitude tile of x in LDS (direct global->LDS DMA), every
+//   wavefront owns contiguous 64-amplitude (1 KB) runs of it, coupled indices
+//   are XORs of LDS addresses, signs are popcounts, and each thread keeps
+//   2^LOGR output amplitudes in registers.  Term tables are wave-uniform and
+//   arrive through the scalar cache.
+// gather_matvec_kernel -- any subspace pair (SpinConserve, Explicit, mixed):
+//   one thread per row with the index maps of subspace.h.
+#include "kernels.h"
+
+namespace dnm {
+
+typedef double2 c128;
+
+#define GLOBAL_AS __attribute__((address_space(1)))
+#define LDS_AS __attribute__((address_space(3)))
+
+// +-c by a parity bit: flips the IEEE sign bit (v_xor on the high dword)
+__device__ __forceinline__ double flip_sign(double c, uint32_t parity_bit) {
+  int hi = __double2hiint(c) ^ (int)(parity_bit << 31);
+  return __hiloint2double(hi, __double2loint(c));
+}
+
+// sum over terms [b,e) of coeff * (-1)^popcount(row & sign); `tt` is the row's
+// tile coordinate, `sbase` the row's bits outside the tile (wave-uniform).
+__device__ __forceinline__ double term_sum(const DevTerm *__restrict__ terms, uint32_t b,
+                                           uint32_t e, uint32_t tt, uint64_t sbase) {
+  double s = 0.0;
+  for (uint32_t t = b; t < e; ++t) {
+    const uint64_t sext = terms[t].sign_ext;
+    const uint32_t stile = terms[t].sign_tile;
+    const double c = terms[t].coeff;
+    uint32_t p = (uint32_t)(__popc(tt & stile) + __popcll(sbase & sext)) & 1u;
+    s += flip_sign(c, p);
+  }
+  return s;
+}
+
+template <int MAXS>
+__device__ __forceinline__ uint32_t deposit(uint32_t v, int nseg, const int32_t *off,
+                                            const int32_t *len, const int32_t *pos) {
+  uint32_t r = 0;
+#pragma unroll
+  for (int j = 0; j < MAXS; ++j)
+    if (j < nseg) r |= ((v >> off[j]) & ((1u << len[j]) - 1u)) << pos[j];
+  return r;
+}
+
+template <int B, int LOGR, bool GLDS>
+__global__ void __launch_bounds__(1 << (B - LOGR))
+tile_pass_kernel(const DevPass P, const c128 *__restrict__ x, c128 *__restrict__ y,
+                 const c128 *__restrict__ xr) {
+  constexpr int R = 1 << LOGR;
+  constexpr int LOGNT = B - LOGR;
+  constexpr uint32_t NT = 1u << LOGNT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  c128 *tile = reinterpret_cast<c128 *>(smem);
+
+  const uint32_t tid = threadIdx.x;
+  const uint32_t base = deposit<MAXSEG>(blockIdx.x, P.nbseg, P.bseg_off, P.bseg_len, P.bseg_pos);
+  const uint32_t dep_t = deposit<MAXSEG>(tid, P.nseg, P.seg_off, P.seg_len, P.seg_pos);
+  const uint64_t sbase = P.sign_base | (uint64_t)base;
+
+  // local row of the k-th amplitude this thread owns: tile coordinate tid + k*NT
+  uint32_t rows[R];
+#pragma unroll
+  for (int k = 0; k < R; ++k)
+    rows[k] = base | dep_t | deposit<MAXSEG>((uint32_t)k << LOGNT, P.nseg, P.seg_off, P.seg_len, P.seg_pos);
+
+  // ---- stage the tile: each wavefront moves 1 KB runs, lane = low 6 tile bits
+  if (!P.need_tile) {
+    // pure gather pass (remote partner vector): nothing to stage
+  } else if constexpr (GLDS) {
+#pragma unroll
+    for (int k = 0; k < R; ++k)
+      __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *)(x + rows[k]),
+                                       (LDS_AS void *)(tile + (k * NT + (tid & ~63u))), 16, 0, 0);
+  } else {
+    c128 v[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) v[k] = x[rows[k]];
+#pragma unroll
+    for (int k = 0; k < R; ++k) tile[tid + k * NT] = v[k];
+  }
+
+  double ar[R], ai[R];
+  if (P.accumulate) {
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      c128 v = y[rows[k]];
+      ar[k] = v.x;
+      ai[k] = v.y;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < R; ++k) ar[k] = ai[k] = 0.0;
+  }
+  __syncthreads();
+
+  const DevTerm *__restrict__ terms = P.terms;
+
+  // ---- diagonal: sum_t c_t chi_t(row).  Terms are bucketed by the part of
+  // their sign mask that falls on this thread's k bits; a length-R
+  // Walsh-Hadamard butterfly then yields all R row values at once.
+  if (P.has_diag) {
+    double D[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) D[j] = 0.0;
+    {
+      double dext = 0.0;
+      for (uint32_t t = P.dext_begin; t < P.dext_end; ++t) {
+        uint32_t p = (uint32_t)__popcll(sbase & terms[t].sign_ext) & 1u;
+        dext += flip_sign(terms[t].coeff, p);
+      }
+      D[0] = dext;
+    }
+#pragma unroll
+    for (int j = 0; j < R; ++j) D[j] += term_sum(terms, P.dbucket[j], P.dbucket[j + 1], tid, sbase);
+#pragma unroll
+    for (int h = 1; h < R; h <<= 1) {
+#pragma unroll
+      for (int i = 0; i < R; ++i) {
+        if ((i & h) == 0) {
+          double a = D[i], b = D[i | h];
+          D[i] = a + b;
+          D[i | h] = a - b;
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      c128 xs = tile[tid + k * NT];
+      ar[k] = fma(D[k], xs.x, ar[k]);
+      ai[k] = fma(D[k], xs.y, ai[k]);
+    }
+  }
+
+  // ---- off-diagonal masks
+  const DevMask *__restrict__ masks = P.masks;
+  for (int m = 0; m < P.nmasks; ++m) {
+    const uint32_t flags = masks[m].flags;
+    const uint32_t reb = masks[m].re_begin, ree = masks[m].re_end;
+    const uint32_t imb = masks[m].im_begin, ime = masks[m].im_end;
+    const bool has_re = ree > reb, has_im = ime > imb;
+    if (flags & MF_GATHER) {
+      const c128 *__restrict__ src = masks[m].src ? xr : x;
+      const uint32_t mloc = masks[m].mask_loc;
+      if (!(flags & MF_KVAR)) {
+        const double cre = term_sum(terms, reb, ree, tid, sbase);
+        const double cim = term_sum(terms, imb, ime, tid, sbase);
+        if (cre != 0.0 || cim != 0.0) {   // lanes whose coefficient vanishes fetch nothing
+          c128 xv[R];
+#pragma unroll
+          for (int k = 0; k < R; ++k) xv[k] = src[rows[k] ^ mloc];
+#pragma unroll
+          for (int k = 0; k < R; ++k) {
+            ar[k] = fma(cre, xv[k].x, ar[k]);
+            ai[k] = fma(cre, xv[k].y, ai[k]);
+            ar[k] = fma(-cim, xv[k].y, ar[k]);
+            ai[k] = fma(cim, xv[k].x, ai[k]);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+          const uint32_t tt = tid | ((uint32_t)k << LOGNT);
+          const double cre = term_sum(terms, reb, ree, tt, sbase);
+          const double cim = term_sum(terms, imb, ime, tt, sbase);
+          if (cre != 0.0 || cim != 0.0) {
+            c128 xv = src[rows[k] ^ mloc];
+            ar[k] = fma(cre, xv.x, ar[k]);
+            ai[k] = fma(cre, xv.y, ai[k]);
+            ar[k] = fma(-cim, xv.y, ar[k]);
+            ai[k] = fma(cim, xv.x, ai[k]);
+          }
+        }
+      }
+    } else {
+      const uint32_t mt = masks[m].mask_tile;
+      const uint32_t p_lo = tid ^ (mt & (NT - 1u));
+      const uint32_t mk = mt >> LOGNT;
+      if (!(flags & MF_KVAR)) {
+        if (has_re && !has_im) {
+          const double cre = term_sum(terms, reb, ree, tid, sbase);
+#pragma unroll
+          for (int k = 0; k < R; ++k) {
+            c128 xv = tile[p_lo + (((uint32_t)k ^ mk) << LOGNT)];
+            ar[k] = fma(cre, xv.x, ar[k]);
+            ai[k] = fma(cre, xv.y, ai[k]);
+          }
+        } else if (has_im && !has_re) {
+          const double cim = term_sum(terms, imb, ime, tid, sbase);
+#pragma unroll
+          for (int k = 0; k < R; ++k) {
+            c128 xv = tile[p_lo + (((uint32_t)k ^ mk) << LOGNT)];
+            ar[k] = fma(-cim, xv.y, ar[k]);
+            ai[k] = fma(cim, xv.x, ai[k]);
+          }
+        } else {
+          const double cre = term_sum(terms, reb, ree, tid, sbase);
+          const double cim = term_sum(terms, imb, ime, tid, sbase);
+#pragma unroll
+          for (int k = 0; k < R; ++k) {
+            c128 xv = tile[p_lo + (((uint32_t)k ^ mk) << LOGNT)];
+            ar[k] = fma(cre, xv.x, ar[k]);
+            ai[k] = fma(cre, xv.y, ai[k]);
+            ar[k] = fma(-cim, xv.y, ar[k]);
+            ai[k] = fma(cim, xv.x, ai[k]);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+          const uint32_t tt = tid | ((uint32_t)k << LOGNT);
+          const double cre = term_sum(terms, reb, ree, tt, sbase);
+          const double cim = term_sum(terms, imb, ime, tt, sbase);
+          c128 xv = tile[p_lo + (((uint32_t)k ^ mk) << LOGNT)];
+          ar[k] = fma(cre, xv.x, ar[k]);
+          ai[k] = fma(cre, xv.y, ai[k]);
+          ar[k] = fma(-cim, xv.y, ar[k]);
+          ai[k] = fma(cim, xv.x, ai[k]);
+        }
+      }
+    }
+  }
+
+#pragma unroll
+  for (int k = 0; k < R; ++k) y[rows[k]] = make_double2(ar[k], ai[k]);
+}
+
+// ---------------------------------------------------------------------------
+template <int B, int LOGR>
+static int launch_cfg(const DevPass &P, bool glds, int n_loc, const void *x, void *y,
+                      const void *xr, hipStream_t st) {
+  constexpr int NT = 1 << (B - LOGR);
+  const size_t lds = (size_t)16 << B;
+  const unsigned grid = 1u << (n_loc - B);
+  auto kg = tile_pass_kernel<B, LOGR, true>;
+  auto kr = tile_pass_kernel<B, LOGR, false>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    DNM_HIP(hipFuncSetAttribute((const void *)kg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    DNM_HIP(hipFuncSetAttribute((const void *)kr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_done = true;
+  }
+  if (glds)
+    hipLaunchKernelGGL(kg, dim3(grid), dim3(NT), lds, st, P, (const c128 *)x, (c128 *)y, (const c128 *)xr);
+  else
+    hipLaunchKernelGGL(kr, dim3(grid), dim3(NT), lds, st, P, (const c128 *)x, (c128 *)y, (const c128 *)xr);
+  DNM_HIP(hipGetLastError());
+  return 0;
+}
+
+bool tile_config_supported(int B, int logR) {
+  switch (B * 16 + logR) {
+    case 8 * 16 + 2: case 10 * 16 + 3: case 10 * 16 + 4: case 11 * 16 + 3: case 11 * 16 + 4:
+    case 12 * 16 + 3: case 12 * 16 + 4: case 13 * 16 + 3: case 13 * 16 + 4:
+      return true;
+  }
+  return false;
+}
+
+int launch_tile_pass(const DevPass &P, int B, int logR, bool glds, int n_loc, const void *x,
+                     void *y, const void *xr, hipStream_t st) {
+  DNM_CHECK(n_loc >= B, "tile larger than the local vector");
+  switch (B * 16 + logR) {
+    case 8 * 16 + 2: return launch_cfg<8, 2>(P, glds, n_loc, x, y, xr, st);
+    case 10 * 16 + 3: return launch_cfg<10, 3>(P, glds, n_loc, x, y, xr, st);
+    case 10 * 16 + 4: return launch_cfg<10, 4>(P, glds, n_loc, x, y, xr, st);
+    case 11 * 16 + 3: return launch_cfg<11, 3>(P, glds, n_loc, x, y, xr, st);
+    case 11 * 16 + 4: return launch_cfg<11, 4>(P, glds, n_loc, x, y, xr, st);
+    case 12 * 16 + 3: return launch_cfg<12, 3>(P, glds, n_loc, x, y, xr, st);
+    case 12 * 16 + 4: return launch_cfg<12, 4>(P, glds, n_loc, x, y, xr, st);
+    case 13 * 16 + 3: return launch_cfg<13, 3>(P, glds, n_loc, x, y, xr, st);
+    case 13 * 16 + 4: return launch_cfg<13, 4>(P, glds, n_loc, x, y, xr, st);
+  }
+  set_error("unsupported tile configuration B=%d logR=%d", B, logR);
+  return 1;
+}
+
+// ===========================================================================
+// Generic row-gather kernels (any subspace pair)
+// ===========================================================================
+
+// SpinConserve binomial tables are staged in LDS once per workgroup.
+constexpr int NCK_LDS_MAX = 2 * 1024;   // int64 entries (16 KB)
+
+template <int T>
+__device__ __forceinline__ SubView stage_sub(const SubView &s, int64_t *lds_tab, int &used) {
+  SubView r = s;
+  if constexpr (T == DNM_SPIN_CONSERVE) {
+    int n = (s.k + 1) * s.ld;
+    if (used + n <= NCK_LDS_MAX) {
+      for (int i = threadIdx.x; i < n; i += blockDim.x) lds_tab[used + i] = s.nchoosek[i];
+      r.nchoosek = lds_tab + used;
+      used += n;
+    }
+  }
+  return r;
+}
+
+constexpr int GATHER_NT = 256;
+
+template <int LT, int RT>
+__global__ void __launch_bounds__(GATHER_NT)
+gather_matvec_kernel(const DevMsc msc, const SubView left_g, const SubView right_g, int64_t M,
+                     const double *__restrict__ diag, const c128 *__restrict__ x,
+                     c128 *__restrict__ y) {
+  __shared__ int64_t nck[NCK_LDS_MAX];
+  int used = 0;
+  const SubView left = stage_sub<LT>(left_g, nck, used);
+  const SubView right = stage_sub<RT>(right_g, nck, used);
+  if (used) __syncthreads();
+
+  const int64_t row = (int64_t)blockIdx.x * GATHER_NT + threadIdx.x;
+  if (row >= M) return;
+  const int64_t ket = Sub<LT>::i2s(row, left);
+  double accr = 0.0, acci = 0.0;
+  int m0 = 0;
+  if (diag) {   // bcuda_template_2.cu:230-236
+    c128 xs = x[row];
+    accr = diag[row] * xs.x;
+    acci = diag[row] * xs.y;
+    m0 = 1;
+  }
+  for (int m = m0; m < msc.nmasks; ++m) {
+    const int64_t mask = msc.masks[m];
+    const int64_t bra = ket ^ mask;
+    const int64_t col = Sub<RT>::s2i(bra, right);
+    if (col < 0) continue;   // projection semantics
+    double cre = 0.0, cim = 0.0;
+    for (int64_t t = msc.mask_offsets[m]; t < msc.mask_offsets[m + 1]; ++t) {
+      const int64_t sg = msc.signs[t];
+      const double c = flip_sign(msc.real_coeffs[t], (uint32_t)__popcll((uint64_t)(bra & sg)) & 1u);
+      if (__popcll((uint64_t)(mask & sg)) & 1) cim += c; else cre += c;   // TERM_REAL
+    }
+    const c128 xv = x[col];
+    accr = fma(cre, xv.x, accr);
+    acci = fma(cre, xv.y, acci);
+    accr = fma(-cim, xv.y, accr);
+    acci = fma(cim, xv.x, acci);
+  }
+  y[row] = make_double2(accr, acci);
+}
+
+template <int T>
+__global__ void __launch_bounds__(GATHER_NT)
+diag_kernel(const DevMsc msc, const SubView sub_g, int64_t M, double *__restrict__ diag) {
+  __shared__ int64_t nck[NCK_LDS_MAX];
+  int used = 0;
+  const SubView sub = stage_sub<T>(sub_g, nck, used);
+  if (used) __syncthreads();
+  const int64_t row = (int64_t)blockIdx.x * GATHER_NT + threadIdx.x;
+  if (row >= M) return;
+  const int64_t st = Sub<T>::i2s(row, sub);
+  double v = 0.0;
+  for (int64_t t = 0; t < msc.mask_offsets[1]; ++t)
+    v += flip_sign(msc.real_coeffs[t], (uint32_t)__popcll((uint64_t)(st & msc.signs[t])) & 1u);
+  diag[row] = v;
+}
+
+template <int LT, int RT>
+__global__ void __launch_bounds__(GATHER_NT)
+norm_kernel(const DevMsc msc, const SubView left_g, const SubView right_g, int64_t M, int64_t row0,
+            double *__restrict__ block_max) {
+  __shared__ int64_t nck[NCK_LDS_MAX];
+  __shared__ double wmax[GATHER_NT / 64];
+  int used = 0;
+  const SubView left = stage_sub<LT>(left_g, nck, used);
+  const SubView right = stage_sub<RT>(right_g, nck, used);
+  if (used) __syncthreads();
+  double best = 0.0;
+  for (int64_t row = (int64_t)blockIdx.x * GATHER_NT + threadIdx.x; row < M;
+       row += (int64_t)gridDim.x * GATHER_NT) {
+    const int64_t ket = Sub<LT>::i2s(row0 + row, left);
+    double sum = 0.0, err = 0.0;   // Kahan, as MatNorm_CPU (bpetsc_template_2.c:964-967)
+    for (int m = 0; m < msc.nmasks; ++m) {
+      const int64_t mask = msc.masks[m];
+      const int64_t bra = ket ^ mask;
+      if (Sub<RT>::s2i(bra, right) < 0) continue;
+      double cre = 0.0, cim = 0.0;
+      for (int64_t t = msc.mask_offsets[m]; t < msc.mask_offsets[m + 1]; ++t) {
+        const int64_t sg = msc.signs[t];
+        const double c = flip_sign(msc.real_coeffs[t], (uint32_t)__popcll((uint64_t)(bra & sg)) & 1u);
+        if (__popcll((uint64_t)(mask & sg)) & 1) cim += c; else cre += c;
+      }
+      const double comp = hypot(cre, cim) - err;
+      const double tot = sum + comp;
+      err = (tot - sum) - comp;
+      sum = tot;
+    }
+    best = fmax(best, sum);
+  }
+  // wave max via DPP-free shuffles, then one value per wave through LDS
+  for (int off = 32; off > 0; off >>= 1) best = fmax(best, __shfl_xor(best, off, 64));
+  if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = best;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double b = wmax[0];
+    for (int i = 1; i < GATHER_NT / 64; ++i) b = fmax(b, wmax[i]);
+    block_max[blockIdx.x] = b;
+  }
+}
+
+template <int LT>
+static int gather_dispatch_r(const DevMsc &msc, const SubView &l, const SubView &r, int64_t M,
+                             const double *diag, const void *x, void *y, hipStream_t st) {
+  const dim3 grid((unsigned)((M + GATHER_NT - 1) / GATHER_NT)), blk(GATHER_NT);
+#define DNM_G(RT)                                                                             \
+  case RT:                                                                                    \
+    hipLaunchKernelGGL((gather_matvec_kernel<LT, RT>), grid, blk, 0, st, msc, l, r, M, diag, \
+                       (const c128 *)x, (c128 *)y);                                           \
+    break;
+  switch (r.type) {
+    DNM_G(DNM_FULL) DNM_G(DNM_PARITY) DNM_G(DNM_SPIN_CONSERVE) DNM_G(DNM_EXPLICIT)
+    default: set_error("bad right subspace type"); return 1;
+  }
+#undef DNM_G
+  DNM_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_gather_matvec(const DevMsc &msc, const SubView &left, const SubView &right, int64_t M,
+                         const double *diag, const void *x, void *y, hipStream_t st) {
+  DNM_CHECK(M > 0 && (M + GATHER_NT - 1) / GATHER_NT < (int64_t)1 << 31, "row count out of range");
+  switch (left.type) {
+    case DNM_FULL: return gather_dispatch_r<DNM_FULL>(msc, left, right, M, diag, x, y, st);
+    case DNM_PARITY: return gather_dispatch_r<DNM_PARITY>(msc, left, right, M, diag, x, y, st);
+    case DNM_SPIN_CONSERVE: return gather_dispatch_r<DNM_SPIN_CONSERVE>(msc, left, right, M, diag, x, y, st);
+    case DNM_EXPLICIT: return gather_dispatch_r<DNM_EXPLICIT>(msc, left, right, M, diag, x, y, st);
+  }
+  set_error("bad left subspace type");
+  return 1;
+}
+
+int launch_diag(const DevMsc &msc, const SubView &sub, int64_t M, double *diag, hipStream_t st) {
+  const dim3 grid((unsigned)((M + GATHER_NT - 1) / GATHER_NT)), blk(GATHER_NT);
+  switch (sub.type) {
+    case DNM_FULL: hipLaunchKernelGGL((diag_kernel<DNM_FULL>), grid, blk, 0, st, msc, sub, M, diag); break;
+    case DNM_PARITY: hipLaunchKernelGGL((diag_kernel<DNM_PARITY>), grid, blk, 0, st, msc, sub, M, diag); break;
+    case DNM_SPIN_CONSERVE: hipLaunchKernelGGL((diag_kernel<DNM_SPIN_CONSERVE>), grid, blk, 0, st, msc, sub, M, diag); break;
+    case DNM_EXPLICIT: hipLaunchKernelGGL((diag_kernel<DNM_EXPLICIT>), grid, blk, 0, st, msc, sub, M, diag); break;
+    default: set_error("bad subspace type"); return 1;
+  }
+  DNM_HIP(hipGetLastError());
+  return 0;
+}
+
+int norm_num_blocks(int64_t M) {
+  int64_t nb = (M + GATHER_NT - 1) / GATHER_NT;
+  return (int)(nb < 4096 ? nb : 4096);
+}
+
+template <int LT>
+static int norm_dispatch_r(const DevMsc &msc, const SubView &l, const SubView &r, int64_t M,
+                           int64_t row0, double *bm, hipStream_t st) {
+  const dim3 grid((unsigned)norm_num_blocks(M)), blk(GATHER_NT);
+#define DNM_N(RT)                                                                           \
+  case RT:                                                                                  \
+    hipLaunchKernelGGL((norm_kernel<LT, RT>), grid, blk, 0, st, msc, l, r, M, row0, bm);    \
+    break;
+  switch (r.type) {
+    DNM_N(DNM_FULL) DNM_N(DNM_PARITY) DNM_N(DNM_SPIN_CONSERVE) DNM_N(DNM_EXPLICIT)
+    default: set_error("bad right subspace type"); return 1;
+  }
+#undef DNM_N
+  DNM_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_norm(const DevMsc &msc, const SubView &left, const SubView &right, int64_t M,
+                int64_t row0, double *block_max, hipStream_t st) {
+  switch (left.type) {
+    case DNM_FULL: return norm_dispatch_r<DNM_FULL>(msc, left, right, M, row0, block_max, st);
+    case DNM_PARITY: return norm_dispatch_r<DNM_PARITY>(msc, left, right, M, row0, block_max, st);
+    case DNM_SPIN_CONSERVE: return norm_dispatch_r<DNM_SPIN_CONSERVE>(msc, left, right, M, row0, block_max, st);
+    case DNM_EXPLICIT: return norm_dispatch_r<DNM_EXPLICIT>(msc, left, right, M, row0, block_max, st);
+  }
+  set_error("bad left subspace type");
+  return 1;
+}
+
+}  // namespace dnm

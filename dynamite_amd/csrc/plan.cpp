@@ -1,0 +1,194 @@
+// Host-side planner: decides which masks each pass of the tiled kernel serves
+// from its LDS tile and which it gathers from global memory.
+#include "plan.h"
+
+#include <algorithm>
+#include <cstdlib>
+#include <sstream>
+
+namespace dnm {
+
+static int env_int(const char *name, int dflt) {
+  const char *v = getenv(name);
+  if (!v || !*v) return dflt;
+  return atoi(v);
+}
+
+PlanConfig plan_config_from_env() {
+  PlanConfig c;
+  c.B = env_int("DNM_TILE_BITS", c.B);
+  c.logR = env_int("DNM_LOG_ROWS", c.logR);
+  c.amin = env_int("DNM_AMIN", c.amin);
+  c.mode = env_int("DNM_PLAN_MODE", c.mode);
+  return c;
+}
+
+static inline uint64_t lowmask(int nbits) {
+  return nbits >= 64 ? ~0ull : (((uint64_t)1 << nbits) - 1);
+}
+
+// Tile of B bits: low segment [0,a) plus window [w, w+B-a) (a==B: low only).
+static PassSpec tile_spec(int B, int a, int w) {
+  PassSpec p;
+  p.B = B;
+  if (a >= B) {
+    p.nseg = 1;
+    p.seg_len[0] = B;
+    p.seg_pos[0] = 0;
+  } else if (w == a) {        // contiguous after all
+    p.nseg = 1;
+    p.seg_len[0] = B;
+    p.seg_pos[0] = 0;
+  } else {
+    p.nseg = 2;
+    p.seg_len[0] = a;
+    p.seg_pos[0] = 0;
+    p.seg_len[1] = B - a;
+    p.seg_pos[1] = w;
+  }
+  return p;
+}
+
+int make_plan(const OpForm &op, int rank, int nranks, const PlanConfig &cfg_in, Plan *out) {
+  Plan &pl = *out;
+  pl = Plan();
+  pl.cfg = cfg_in;
+  PlanConfig &cfg = pl.cfg;
+  pl.n = op.n;
+  pl.rank = rank;
+  pl.nranks = nranks;
+  DNM_CHECK(nranks >= 1 && (nranks & (nranks - 1)) == 0, "nranks must be a power of two");
+  int p = ilog2((uint64_t)nranks);
+  pl.n_loc = op.n - p;
+  DNM_CHECK(pl.n_loc >= 1, "too many ranks for this dimension");
+  DNM_CHECK(pl.n_loc <= 32, "local vector longer than 2^32 amplitudes is not supported");
+  if (cfg.B < 8) cfg.B = 8;
+  if (cfg.B > 13) cfg.B = 13;
+  if (cfg.logR < 2) cfg.logR = 2;
+  if (cfg.logR > 4) cfg.logR = 4;
+  if (cfg.amin < 2) cfg.amin = 2;
+  const int B = cfg.B;
+  const int nl = pl.n_loc;
+  const uint64_t locmask = lowmask(nl);
+
+  // split masks into local (no rank bit flipped) and remote, by partner
+  std::vector<int> local_masks;
+  std::vector<std::pair<int, int>> remote;  // (partner, mask idx)
+  bool has_diag = false;
+  for (int i = 0; i < (int)op.masks.size(); ++i) {
+    uint64_t m = op.masks[i].mask;
+    uint64_t h = m >> nl;
+    if (h == 0) {
+      if (m == 0 && !op.masks[i].zero_mask_offdiag) has_diag = true; else local_masks.push_back(i);
+    } else {
+      remote.push_back({(int)(rank ^ (int)h), i});
+    }
+  }
+
+  pl.use_tiled = nl >= B;
+  if (!pl.use_tiled) return 0;
+
+  std::vector<int> remaining = local_masks;
+  auto covered_by = [&](const PassSpec &ps, std::vector<int> *cov) {
+    uint64_t tb = ps.tile_bits();
+    int c = 0;
+    for (int idx : remaining)
+      if ((op.masks[idx].mask & locmask & ~tb) == 0) {
+        ++c;
+        if (cov) cov->push_back(idx);
+      }
+    return c;
+  };
+
+  if (cfg.mode == 1) {
+    // single pass: contiguous low tile, everything outside it gathered
+    PassSpec ps = tile_spec(B, B, 0);
+    std::vector<int> cov;
+    covered_by(ps, &cov);
+    ps.tile_masks = cov;
+    for (int idx : remaining)
+      if (std::find(cov.begin(), cov.end(), idx) == cov.end()) {
+        ps.gather_masks.push_back(idx);
+        ps.gather_src.push_back(0);
+      }
+    ps.has_diag = has_diag;
+    pl.local.push_back(ps);
+  } else {
+    // greedy cover by LDS tiles
+    bool first = true;
+    while (!remaining.empty() || first) {
+      PassSpec best;
+      int best_score = -1;
+      // candidates: pure low tile, then low segment a + window
+      {
+        PassSpec ps = tile_spec(B, B, 0);
+        int sc = covered_by(ps, nullptr);
+        if (sc > best_score) { best_score = sc; best = ps; }
+      }
+      for (int a = cfg.amin; a < B && a <= 6; ++a) {
+        int b = B - a;
+        for (int w = a + 1; w + b <= nl; ++w) {
+          PassSpec ps = tile_spec(B, a, w);
+          int sc = covered_by(ps, nullptr);
+          // prefer more coverage, then longer contiguous runs
+          if (sc > best_score) { best_score = sc; best = ps; }
+        }
+      }
+      if (best_score <= 0 && !first) break;   // nothing placeable: gather the rest
+      std::vector<int> cov;
+      covered_by(best, &cov);
+      best.tile_masks = cov;
+      best.has_diag = first && has_diag;
+      best.accumulate = !first;
+      pl.local.push_back(best);
+      std::vector<int> rest;
+      for (int idx : remaining)
+        if (std::find(cov.begin(), cov.end(), idx) == cov.end()) rest.push_back(idx);
+      remaining.swap(rest);
+      first = false;
+    }
+    // masks no two-segment tile can hold: gathered in the first pass
+    for (int idx : remaining) {
+      pl.local[0].gather_masks.push_back(idx);
+      pl.local[0].gather_src.push_back(0);
+    }
+  }
+
+  // remote passes: one per partner, gathering from that partner's vector
+  std::sort(remote.begin(), remote.end());
+  for (size_t i = 0; i < remote.size();) {
+    int partner = remote[i].first;
+    PassSpec ps = tile_spec(B, B, 0);
+    ps.accumulate = true;
+    ps.partner = partner;
+    while (i < remote.size() && remote[i].first == partner) {
+      ps.gather_masks.push_back(remote[i].second);
+      ps.gather_src.push_back(1);
+      ++i;
+    }
+    pl.remote.push_back(ps);
+    pl.partners.push_back(partner);
+  }
+  return 0;
+}
+
+std::string Plan::describe(const OpForm &op) const {
+  std::ostringstream os;
+  os << "n=" << n << " n_loc=" << n_loc << " rank=" << rank << "/" << nranks
+     << " tiled=" << (use_tiled ? 1 : 0) << " B=" << cfg.B << " logR=" << cfg.logR
+     << " mode=" << cfg.mode << " masks=" << op.masks.size() << "\n";
+  auto dump = [&](const char *kind, const PassSpec &ps, size_t i) {
+    os << kind << " pass " << i << ": segs";
+    for (int j = 0; j < ps.nseg; ++j)
+      os << " [" << ps.seg_pos[j] << "," << ps.seg_pos[j] + ps.seg_len[j] << ")";
+    os << " diag=" << ps.has_diag << " acc=" << ps.accumulate << " tile_masks=" << ps.tile_masks.size()
+       << " gather_masks=" << ps.gather_masks.size();
+    if (ps.partner >= 0) os << " partner=" << ps.partner;
+    os << "\n";
+  };
+  for (size_t i = 0; i < local.size(); ++i) dump("local", local[i], i);
+  for (size_t i = 0; i < remote.size(); ++i) dump("remote", remote[i], i);
+  return os.str();
+}
+
+}  // namespace dnm

@@ -1,0 +1,111 @@
+// C ABI for the vector kernels (PETSc Vec / SLEPc BV replacements).
+#include "vec_api.h"
+
+#include <vector>
+
+namespace dnm {
+
+static DevBuf g_scratch;       // reduction partials + results
+static DevBuf g_coef;          // small host->device coefficient uploads
+
+int vec_scratch(size_t bytes, double **p) {
+  if (g_scratch.bytes < bytes) DNM_TRY(g_scratch.alloc(bytes));
+  *p = (double *)g_scratch.p;
+  return 0;
+}
+
+int vec_upload_coefs(const double *host, size_t ndoubles, hipStream_t st, const double **dev) {
+  if (g_coef.bytes < ndoubles * 8) DNM_TRY(g_coef.alloc(ndoubles * 8 > 65536 ? ndoubles * 8 : 65536));
+  // the previous use of the buffer must be complete before we overwrite it
+  DNM_HIP(hipStreamSynchronize(st));
+  DNM_HIP(hipMemcpyAsync(g_coef.p, host, ndoubles * 8, hipMemcpyHostToDevice, st));
+  DNM_HIP(hipStreamSynchronize(st));   // host buffer may be freed by the caller
+  *dev = (const double *)g_coef.p;
+  return 0;
+}
+
+int vec_mdot_host(const void *V, int64_t ldv, int nv, const void *w, int64_t n, double *h_host,
+                  hipStream_t st) {
+  DNM_CHECK(nv >= 1 && nv <= 256, "mdot: nv out of range");
+  const int nb = vk_mdot_blocks(n);
+  double *part = nullptr;
+  DNM_TRY(vec_scratch(((size_t)nb + 1) * 2 * nv * sizeof(double), &part));
+  DNM_TRY(vk_mdot(V, ldv, nv, w, n, part, st));
+  DNM_HIP(hipMemcpyAsync(h_host, part + (size_t)nb * 2 * nv, (size_t)2 * nv * sizeof(double),
+                         hipMemcpyDeviceToHost, st));
+  DNM_HIP(hipStreamSynchronize(st));
+  return 0;
+}
+
+}  // namespace dnm
+
+using namespace dnm;
+static hipStream_t S(void *s) { return (hipStream_t)s; }
+
+extern "C" {
+
+int dnm_vec_set(void *x, int64_t n, double re, double im, void *stream) {
+  DNM_CHECK(x && n >= 0, "bad vector");
+  return vk_set(x, n, re, im, S(stream));
+}
+
+int dnm_vec_copy(const void *x, void *y, int64_t n, void *stream) {
+  DNM_CHECK(x && y && n >= 0, "bad vector");
+  DNM_HIP(hipMemcpyAsync(y, x, (size_t)n * 16, hipMemcpyDeviceToDevice, S(stream)));
+  return 0;
+}
+
+int dnm_vec_scale(void *x, int64_t n, double re, double im, void *stream) {
+  DNM_CHECK(x && n >= 0, "bad vector");
+  return vk_scale(x, n, re, im, S(stream));
+}
+
+int dnm_vec_axpby(void *y, const void *x, int64_t n, double are, double aim, double bre, double bim,
+                  void *stream) {
+  DNM_CHECK(x && y && n >= 0, "bad vector");
+  DNM_CHECK(x != y, "x and y cannot be the same vector");
+  return vk_axpby(y, x, n, are, aim, bre, bim, S(stream));
+}
+
+int dnm_vec_dot(const void *x, const void *y, int64_t n, double *out, void *stream) {
+  DNM_CHECK(x && y && out, "bad argument");
+  // VecDot(x, y) = sum_i x_i conj(y_i) = (y^H x)
+  return vec_mdot_host(y, n, 1, x, n, out, S(stream));
+}
+
+int dnm_vec_norm2(const void *x, int64_t n, double *out, void *stream) {
+  DNM_CHECK(x && out, "bad argument");
+  double h[2];
+  DNM_TRY(vec_mdot_host(x, n, 1, x, n, h, S(stream)));
+  *out = sqrt(h[0] > 0 ? h[0] : 0.0);
+  return 0;
+}
+
+int dnm_vec_set_random(void *x, int64_t n, uint64_t seed, int64_t offset, void *stream) {
+  DNM_CHECK(x && n >= 0, "bad vector");
+  return vk_random(x, n, seed, offset, S(stream));
+}
+
+int dnm_vec_mdot(const void *V, int64_t ldv, int nv, const void *w, int64_t n, double *h_host,
+                 void *stream) {
+  DNM_CHECK(V && w && h_host, "bad argument");
+  return vec_mdot_host(V, ldv, nv, w, n, h_host, S(stream));
+}
+
+int dnm_vec_maxpy(void *w, const void *V, int64_t ldv, int nv, int64_t n, const double *c_host,
+                  void *stream) {
+  DNM_CHECK(V && w && c_host && nv >= 1, "bad argument");
+  const double *cd = nullptr;
+  DNM_TRY(vec_upload_coefs(c_host, (size_t)2 * nv, S(stream), &cd));
+  return vk_maxpy(w, V, ldv, nv, n, cd, S(stream));
+}
+
+int dnm_vec_basis_update(void *V, int64_t ldv, int nin, int nout, int64_t n, const double *S_host,
+                         void *stream) {
+  DNM_CHECK(V && S_host, "bad argument");
+  const double *sd = nullptr;
+  DNM_TRY(vec_upload_coefs(S_host, (size_t)2 * nin * nout, S(stream), &sd));
+  return vk_basis_update(V, ldv, nin, nout, n, sd, S(stream));
+}
+
+}  // extern "C"

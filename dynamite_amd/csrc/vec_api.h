@@ -1,0 +1,17 @@
+// Host-side helpers shared by the vector C ABI and the Krylov drivers.
+#pragma once
+
+#include <cmath>
+
+#include "kernels.h"
+#include "mat.h"
+
+namespace dnm {
+
+int vec_scratch(size_t bytes, double **p);
+int vec_upload_coefs(const double *host, size_t ndoubles, hipStream_t st, const double **dev);
+// h_host[2*j], h_host[2*j+1] = V_j^H w ; synchronises the stream
+int vec_mdot_host(const void *V, int64_t ldv, int nv, const void *w, int64_t n, double *h_host,
+                  hipStream_t st);
+
+}  // namespace dnm

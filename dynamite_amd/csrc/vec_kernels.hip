@@ -1,0 +1,274 @@
+// Vector kernels the Krylov loops need (what PETSc Vec / SLEPc BV provide to
+// SLEPc's MFN/EPS in the reference): fills, axpby, fused multi-dot and
+// multi-axpy over a block of basis vectors, in-place basis rotation, and a
+// counter-based normal generator.  All are HBM-streaming; 16 B per lane,
+// grid-stride, deterministic two-stage reductions (no atomics).
+#include "kernels.h"
+
+namespace dnm {
+
+typedef double2 c128;
+
+constexpr int VNT = 256;
+constexpr int VMAX_BLOCKS = 2048;   // 256 CUs x 8
+
+static inline unsigned vgrid(int64_t n, int per_thread = 1) {
+  int64_t nb = (n + (int64_t)VNT * per_thread - 1) / ((int64_t)VNT * per_thread);
+  if (nb < 1) nb = 1;
+  return (unsigned)(nb < VMAX_BLOCKS ? nb : VMAX_BLOCKS);
+}
+
+__global__ void __launch_bounds__(VNT) set_kernel(c128 *x, int64_t n, double re, double im) {
+  for (int64_t i = (int64_t)blockIdx.x * VNT + threadIdx.x; i < n; i += (int64_t)gridDim.x * VNT)
+    x[i] = make_double2(re, im);
+}
+
+__global__ void __launch_bounds__(VNT) scale_kernel(c128 *x, int64_t n, double re, double im) {
+  for (int64_t i = (int64_t)blockIdx.x * VNT + threadIdx.x; i < n; i += (int64_t)gridDim.x * VNT) {
+    c128 v = x[i];
+    x[i] = make_double2(re * v.x - im * v.y, re * v.y + im * v.x);
+  }
+}
+
+__global__ void __launch_bounds__(VNT)
+axpby_kernel(c128 *y, const c128 *__restrict__ x, int64_t n, double are, double aim, double bre,
+             double bim, int beta_zero) {
+  for (int64_t i = (int64_t)blockIdx.x * VNT + threadIdx.x; i < n; i += (int64_t)gridDim.x * VNT) {
+    c128 xv = x[i];
+    double rr = are * xv.x - aim * xv.y, ri = are * xv.y + aim * xv.x;
+    if (!beta_zero) {
+      c128 yv = y[i];
+      rr += bre * yv.x - bim * yv.y;
+      ri += bre * yv.y + bim * yv.x;
+    }
+    y[i] = make_double2(rr, ri);
+  }
+}
+
+int vk_set(void *x, int64_t n, double re, double im, hipStream_t st) {
+  hipLaunchKernelGGL(set_kernel, dim3(vgrid(n)), dim3(VNT), 0, st, (c128 *)x, n, re, im);
+  DNM_HIP(hipGetLastError());
+  return 0;
+}
+int vk_scale(void *x, int64_t n, double re, double im, hipStream_t st) {
+  hipLaunchKernelGGL(scale_kernel, dim3(vgrid(n)), dim3(VNT), 0, st, (c128 *)x, n, re, im);
+  DNM_HIP(hipGetLastError());
+  return 0;
+}
+int vk_axpby(void *y, const void *x, int64_t n, double are, double aim, double bre, double bim,
+             hipStream_t st) {
+  int bz = (bre == 0.0 && bim == 0.0);
+  hipLaunchKernelGGL(axpby_kernel, dim3(vgrid(n)), dim3(VNT), 0, st, (c128 *)y, (const c128 *)x, n,
+                     are, aim, bre, bim, bz);
+  DNM_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---- Philox-4x32-10 counter-based generator --------------------------------
+__device__ __forceinline__ void philox_round(uint32_t &c0, uint32_t &c1, uint32_t &c2, uint32_t &c3,
+                                             uint32_t k0, uint32_t k1) {
+  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+  uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
+  uint32_t hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
+  uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+  c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+}
+
+__global__ void __launch_bounds__(VNT)
+random_kernel(c128 *x, int64_t n, uint64_t seed, int64_t offset) {
+  for (int64_t i = (int64_t)blockIdx.x * VNT + threadIdx.x; i < n; i += (int64_t)gridDim.x * VNT) {
+    uint64_t ctr = (uint64_t)(offset + i);
+    uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = 0x243F6A88u, c3 = 0x85A308D3u;
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+      philox_round(c0, c1, c2, c3, k0, k1);
+      k0 += 0x9E3779B9u;
+      k1 += 0xBB67AE85u;
+    }
+    // two uniforms in (0,1] and [0,1) from 53 bits each -> Box-Muller pair
+    double u1 = ((double)((((uint64_t)c0 << 32) | c1) >> 11) + 1.0) * (1.0 / 9007199254740992.0);
+    double u2 = (double)((((uint64_t)c2 << 32) | c3) >> 11) * (1.0 / 9007199254740992.0);
+    double rad = sqrt(-2.0 * log(u1));
+    double s, c;
+    sincospi(2.0 * u2, &s, &c);
+    x[i] = make_double2(rad * c, rad * s);
+  }
+}
+
+int vk_random(void *x, int64_t n, uint64_t seed, int64_t offset, hipStream_t st) {
+  hipLaunchKernelGGL(random_kernel, dim3(vgrid(n)), dim3(VNT), 0, st, (c128 *)x, n, seed, offset);
+  DNM_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---- fused multi-dot: h[j] = sum_i conj(V_j[i]) w[i] -------------------------
+int vk_mdot_blocks(int64_t n) { return (int)vgrid(n, 4); }
+
+template <int NV>
+__global__ void __launch_bounds__(VNT)
+mdot_kernel(const c128 *__restrict__ V, int64_t ldv, const c128 *__restrict__ w, int64_t n,
+            double *__restrict__ partials, int nv_total, int j0) {
+  double sr[NV], si[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) sr[j] = si[j] = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * VNT + threadIdx.x; i < n; i += (int64_t)gridDim.x * VNT) {
+    const c128 wv = w[i];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const c128 v = V[(int64_t)(j0 + j) * ldv + i];
+      sr[j] = fma(v.x, wv.x, sr[j]);
+      sr[j] = fma(v.y, wv.y, sr[j]);
+      si[j] = fma(v.x, wv.y, si[j]);
+      si[j] = fma(-v.y, wv.x, si[j]);
+    }
+  }
+  __shared__ double red[VNT / 64][2 * NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    for (int off = 32; off > 0; off >>= 1) {
+      sr[j] += __shfl_xor(sr[j], off, 64);
+      si[j] += __shfl_xor(si[j], off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+      red[threadIdx.x >> 6][2 * j] = sr[j];
+      red[threadIdx.x >> 6][2 * j + 1] = si[j];
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 2 * NV) {
+    double s = 0.0;
+    for (int wv = 0; wv < VNT / 64; ++wv) s += red[wv][threadIdx.x];
+    partials[(int64_t)blockIdx.x * 2 * nv_total + 2 * j0 + threadIdx.x] = s;
+  }
+}
+
+// second stage: out[c] = sum_b partials[b][c]
+__global__ void __launch_bounds__(VNT)
+reduce_partials_kernel(const double *__restrict__ partials, int nblocks, int ncols,
+                       double *__restrict__ out) {
+  const int c = blockIdx.x;
+  double s = 0.0;
+  for (int b = threadIdx.x; b < nblocks; b += VNT) s += partials[(int64_t)b * ncols + c];
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+  __shared__ double red[VNT / 64];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int wv = 0; wv < VNT / 64; ++wv) t += red[wv];
+    out[c] = t;
+  }
+}
+
+// partials_dev: [nblocks * 2*nv] scratch followed by [2*nv] results
+int vk_mdot(const void *V, int64_t ldv, int nv, const void *w, int64_t n, double *partials_dev,
+            hipStream_t st) {
+  const unsigned nb = vgrid(n, 4);
+  const c128 *Vp = (const c128 *)V;
+  const c128 *wp = (const c128 *)w;
+  int j0 = 0;
+  while (j0 < nv) {
+    int rem = nv - j0;
+    if (rem >= 8) {
+      hipLaunchKernelGGL((mdot_kernel<8>), dim3(nb), dim3(VNT), 0, st, Vp, ldv, wp, n, partials_dev, nv, j0);
+      j0 += 8;
+    } else if (rem >= 4) {
+      hipLaunchKernelGGL((mdot_kernel<4>), dim3(nb), dim3(VNT), 0, st, Vp, ldv, wp, n, partials_dev, nv, j0);
+      j0 += 4;
+    } else if (rem >= 2) {
+      hipLaunchKernelGGL((mdot_kernel<2>), dim3(nb), dim3(VNT), 0, st, Vp, ldv, wp, n, partials_dev, nv, j0);
+      j0 += 2;
+    } else {
+      hipLaunchKernelGGL((mdot_kernel<1>), dim3(nb), dim3(VNT), 0, st, Vp, ldv, wp, n, partials_dev, nv, j0);
+      j0 += 1;
+    }
+  }
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(2 * nv), dim3(VNT), 0, st, partials_dev, (int)nb,
+                     2 * nv, partials_dev + (int64_t)nb * 2 * nv);
+  DNM_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---- fused multi-axpy: w += sum_j c[j] V_j ----------------------------------
+__global__ void __launch_bounds__(VNT)
+maxpy_kernel(c128 *w, const c128 *__restrict__ V, int64_t ldv, int nv, int64_t n,
+             const double *__restrict__ c) {
+  for (int64_t i = (int64_t)blockIdx.x * VNT + threadIdx.x; i < n; i += (int64_t)gridDim.x * VNT) {
+    c128 acc = w[i];
+    for (int j = 0; j < nv; ++j) {
+      const double cr = c[2 * j], ci = c[2 * j + 1];
+      const c128 v = V[(int64_t)j * ldv + i];
+      acc.x = fma(cr, v.x, acc.x);
+      acc.x = fma(-ci, v.y, acc.x);
+      acc.y = fma(cr, v.y, acc.y);
+      acc.y = fma(ci, v.x, acc.y);
+    }
+    w[i] = acc;
+  }
+}
+
+int vk_maxpy(void *w, const void *V, int64_t ldv, int nv, int64_t n, const double *c_dev,
+             hipStream_t st) {
+  hipLaunchKernelGGL(maxpy_kernel, dim3(vgrid(n)), dim3(VNT), 0, st, (c128 *)w, (const c128 *)V, ldv,
+                     nv, n, c_dev);
+  DNM_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---- in-place basis rotation V[:, 0:nout) = V[:, 0:nin) S --------------------
+// A workgroup stages 64 rows x nin columns in LDS, then writes the nout
+// combinations back over the same rows.
+constexpr int BU_ROWS = 64;
+
+__global__ void __launch_bounds__(VNT)
+basis_update_kernel(c128 *V, int64_t ldv, int nin, int nout, int64_t n,
+                    const double *__restrict__ S) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  c128 *rowsbuf = reinterpret_cast<c128 *>(smem);   // [nin][BU_ROWS]
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  for (int64_t r0 = (int64_t)blockIdx.x * BU_ROWS; r0 < n; r0 += (int64_t)gridDim.x * BU_ROWS) {
+    const int64_t row = r0 + lane;
+    for (int j = grp; j < nin; j += VNT / 64)
+      if (row < n) rowsbuf[j * BU_ROWS + lane] = V[(int64_t)j * ldv + row];
+    __syncthreads();
+    for (int o = grp; o < nout; o += VNT / 64) {
+      double ar = 0.0, ai = 0.0;
+      for (int j = 0; j < nin; ++j) {
+        const double sr = S[2 * ((int64_t)o * nin + j)], si = S[2 * ((int64_t)o * nin + j) + 1];
+        const c128 v = rowsbuf[j * BU_ROWS + lane];
+        ar = fma(sr, v.x, ar);
+        ar = fma(-si, v.y, ar);
+        ai = fma(sr, v.y, ai);
+        ai = fma(si, v.x, ai);
+      }
+      if (row < n) V[(int64_t)o * ldv + row] = make_double2(ar, ai);
+    }
+    __syncthreads();
+  }
+}
+
+int vk_basis_update(void *V, int64_t ldv, int nin, int nout, int64_t n, const double *S_dev,
+                    hipStream_t st) {
+  DNM_CHECK(nin >= 1 && nout >= 0 && nout <= nin, "basis_update: bad shapes");
+  const size_t lds = (size_t)nin * BU_ROWS * sizeof(c128);
+  DNM_CHECK(lds <= 160 * 1024, "basis_update: too many vectors for one LDS stage");
+  static size_t attr = 0;
+  if (lds > attr) {
+    DNM_HIP(hipFuncSetAttribute((const void *)basis_update_kernel,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr = lds;
+  }
+  int64_t nb = (n + BU_ROWS - 1) / BU_ROWS;
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(basis_update_kernel, dim3((unsigned)nb), dim3(VNT), lds, st, (c128 *)V, ldv, nin,
+                     nout, n, S_dev);
+  DNM_HIP(hipGetLastError());
+  return 0;
+}
+
+int vk_norm2_partials(const void *x, int64_t n, double *partials_dev, hipStream_t st) {
+  return vk_mdot(x, n, 1, x, n, partials_dev, st);
+}
+
+}  // namespace dnm

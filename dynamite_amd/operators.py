@@ -1,0 +1,537 @@
+"""
+``Operator`` and the Pauli-string constructors: the caller side of the hot
+path, mirroring the parts of ``dynamite.operators`` (reference
+``src/dynamite/operators.py``) that the path needs -- operator algebra on the
+MSC representation (:938-1142, 1168-1540), ``build_mat`` / ``get_mat`` with the
+same marshalling (:546-669), ``dot`` (:1063-1108), ``infinity_norm`` (:206-224),
+and ``evolve`` / ``eigsolve`` bound from ``computations`` (:78-79).  String /
+LaTeX representations and the stored-matrix (AIJ) path are out of scope.
+"""
+import numpy as np
+
+from . import msc_tools, backend
+from .computations import evolve, eigsolve
+from .config import config
+from .msc_tools import msc_dtype
+from .states import State
+from .subspaces import Full, Subspace
+
+
+class Operator:
+    def __init__(self, msc=None):
+        self._max_spin_idx = None
+        self._mats = {}
+        self._is_reduced = False
+        self._shell = True
+        self._precompute_diagonal = False
+        self._allow_projection = False
+        self._msc = None
+        self._L = None
+        if msc is not None:
+            self.msc = msc
+        if config.subspace is not None:
+            self._subspaces = [(config.subspace, config.subspace)]
+        else:
+            self._subspaces = [(Full(), Full())]
+        if config.L is not None:
+            self.L = config.L
+
+    evolve = evolve
+    eigsolve = eigsolve
+
+    def copy(self):
+        rtn = Operator()
+        rtn.msc = self.msc.copy()
+        rtn.is_reduced = self.is_reduced
+        rtn.shell = self.shell
+        rtn._precompute_diagonal = self._precompute_diagonal
+        rtn.allow_projection = self.allow_projection
+        if self._subspaces is not None:
+            rtn._subspaces = [(l.copy(), r.copy()) for l, r in self._subspaces]
+        if self._L is not None:
+            rtn.L = self._L
+        return rtn
+
+    # ------------------------------------------------------------------ sizes
+    @property
+    def max_spin_idx(self):
+        if self._max_spin_idx is None:
+            self._max_spin_idx = msc_tools.max_spin_idx(self.msc)
+        return self._max_spin_idx
+
+    @property
+    def L(self):
+        return self._L
+
+    @L.setter
+    def L(self, value):
+        if value is not None:
+            if int(value) != value or value < 0 or value > 63:
+                raise ValueError('invalid L')
+            value = int(value)
+            if value < self.max_spin_idx + 1:
+                raise ValueError('Cannot set L smaller than one plus the largest spin index '
+                                 'on which the operator has support (max_spin_idx = %d)' %
+                                 self.max_spin_idx)
+        self._L = value
+        if value is not None:
+            for left, right in self._subspaces:
+                left.L = value
+                right.L = value
+
+    def establish_L(self):
+        """If L was never set, fix it to the operator's support (operators.py:137-144)."""
+        if self._L is None:
+            self.L = self.max_spin_idx + 1
+
+    def get_length(self):
+        return self.L if self.L is not None else self.max_spin_idx + 1
+
+    @property
+    def dim(self):
+        return (self.left_subspace.get_dimension(), self.right_subspace.get_dimension())
+
+    @property
+    def nnz(self):
+        return msc_tools.nnz(self.msc)
+
+    @property
+    def nterms(self):
+        self.reduce_msc()
+        return self.msc.size
+
+    @property
+    def msc_size(self):
+        return self.msc.size
+
+    @property
+    def density(self):
+        return self.nnz / self.dim[1]
+
+    # ------------------------------------------------------------------ flags
+    @property
+    def shell(self):
+        return self._shell
+
+    @shell.setter
+    def shell(self, value):
+        if not isinstance(value, bool):
+            raise ValueError('Shell must be set to True or False.')
+        if not value:
+            raise ValueError('this engine is matrix-free: stored (AIJ) matrices are not built')
+        self._shell = value
+
+    @property
+    def precompute_diagonal(self):
+        """Cache the diagonal in HBM (+8 B per amplitude read per multiply).  The
+        reference defaults to True (operators.py:246-271); here the tiled kernels
+        evaluate the diagonal on the fly, so the default is False and the cache
+        only serves the generic kernel."""
+        return self._precompute_diagonal
+
+    @precompute_diagonal.setter
+    def precompute_diagonal(self, value):
+        value = bool(value)
+        if value != self._precompute_diagonal:
+            self.destroy_mat()
+        self._precompute_diagonal = value
+
+    @property
+    def allow_projection(self):
+        return self._allow_projection
+
+    @allow_projection.setter
+    def allow_projection(self, value):
+        self._allow_projection = bool(value)
+
+    # ------------------------------------------------------------------ subspaces
+    @property
+    def left_subspace(self):
+        return self._subspaces[-1][0]
+
+    @property
+    def right_subspace(self):
+        return self._subspaces[-1][1]
+
+    @property
+    def subspace(self):
+        left, right = self._subspaces[-1]
+        if not left.identical(right):
+            raise ValueError("Left subspace and right subspace are different. Use "
+                             "Operator.left_subspace and Operator.right_subspace to access them.")
+        return left
+
+    @subspace.setter
+    def subspace(self, value):
+        self.add_subspace(value, value)
+
+    def add_subspace(self, left, right=None):
+        """Register a (left, right) subspace pair (operators.py:307-349); the most
+        recently added pair is the default."""
+        if right is None:
+            right = left
+        for sp in (left, right):
+            if not isinstance(sp, Subspace):
+                raise ValueError('subspace can only be set to objects of Subspace type')
+        if self.L is None:
+            if left.L is not None:
+                self.L = left.L
+            elif right.L is not None:
+                self.L = right.L
+        if self.L is not None:
+            for sp in (left, right):
+                if sp.L is None:
+                    sp.L = self.L
+                elif sp.L != self.L:
+                    raise ValueError('operator and subspaces must all have same spin chain length')
+        if not self.has_subspace(left, right):
+            self._subspaces.append((left, right))
+
+    def get_subspace_list(self):
+        return list(self._subspaces)
+
+    def has_subspace(self, left, right=None):
+        if right is None:
+            right = left
+        return any(l.identical(left) and r.identical(right) for l, r in self._subspaces)
+
+    # ------------------------------------------------------------------ msc
+    @property
+    def msc(self):
+        return self._msc
+
+    @msc.setter
+    def msc(self, value):
+        self._msc = np.array(value, dtype=msc_dtype).reshape((-1,)).copy() \
+            if not isinstance(value, np.ndarray) else np.asarray(value, dtype=msc_dtype)
+        self._max_spin_idx = None
+        self.is_reduced = False
+        self.destroy_mat()
+
+    def reduce_msc(self):
+        """Sort, merge and drop zero terms (operators.py:815-822)."""
+        if not self.is_reduced:
+            self._msc = msc_tools.combine_and_sort(self._msc)
+            self.is_reduced = True
+
+    @property
+    def is_reduced(self):
+        return self._is_reduced
+
+    @is_reduced.setter
+    def is_reduced(self, value):
+        self._is_reduced = value
+
+    def get_shifted_msc(self, shift, wrap_idx=None):
+        return msc_tools.shift(self.msc, shift, wrap_idx)
+
+    def truncate(self, tol=1e-12):
+        self.msc = msc_tools.truncate(self.msc, tol)
+
+    def serialize(self):
+        self.reduce_msc()
+        return msc_tools.serialize(self.msc)
+
+    @classmethod
+    def from_bytes(cls, data):
+        return cls(msc=msc_tools.deserialize(data))
+
+    def to_numpy(self, subspaces=None, sparse=True):
+        """Explicit matrix on the host (small systems; operators.py:869-907)."""
+        if subspaces is None:
+            subspaces = (self.left_subspace, self.right_subspace)
+        self.establish_L()
+        self.reduce_msc()
+        return msc_tools.msc_to_numpy(
+            self.msc, (subspaces[0].get_dimension(), subspaces[1].get_dimension()),
+            subspaces[0].idx_to_state, subspaces[1].state_to_idx, sparse=sparse)
+
+    # ------------------------------------------------------------------ native matrix
+    def get_mat(self, subspaces=None):
+        if subspaces is None:
+            subspaces = (self.left_subspace, self.right_subspace)
+        key = (hash(subspaces[0]), hash(subspaces[1]))
+        if key not in self._mats:
+            self.build_mat(subspaces)
+        return self._mats[key]
+
+    def build_mat(self, subspaces=None):
+        """Same sequence as the reference (operators.py:570-631): reduce and sort
+        the MSC, Hermiticity gate, unique masks + offsets, hand four contiguous
+        arrays and two subspace descriptors to the backend, optionally cache the
+        diagonal."""
+        if subspaces is None:
+            subspaces = (self.left_subspace, self.right_subspace)
+        self.establish_L()
+        if not self.has_subspace(*subspaces):
+            raise ValueError('Attempted to build matrix for a subspace that has not '
+                             'been added to the operator.')
+        config._initialize()
+        self.reduce_msc()
+        msc = self.msc
+        if not self.allow_projection and not self.conserves(*subspaces):
+            raise ValueError("Constructing the operator's matrix on this subspace yields a "
+                             "projection (e.g. subspace is not conserved by the operator). If this "
+                             "behavior is desired, set the Operator.allow_projection parameter to True.")
+        if not msc_tools.is_hermitian(msc):
+            raise ValueError('Building non-Hermitian matrices currently not supported.')
+        masks, mask_offsets = msc_tools.get_mask_offsets(msc)
+        mat = backend.build_mat(
+            masks=np.ascontiguousarray(masks),
+            mask_offsets=np.ascontiguousarray(mask_offsets),
+            signs=np.ascontiguousarray(msc['signs']),
+            coeffs=np.ascontiguousarray(msc['coeffs']),
+            left_subspace=subspaces[0]._to_c(),
+            right_subspace=subspaces[1]._to_c(),
+            xparity=False, shell=self.shell, gpu=True)
+        if (self.shell and self.precompute_diagonal and subspaces[0] == subspaces[1]
+                and masks.size and masks[0] == 0 and config.world_size == 1):
+            backend.precompute_diagonal(mat)
+        self._mats[(hash(subspaces[0]), hash(subspaces[1]))] = mat
+
+    def destroy_mat(self, subspaces=None):
+        keys = [(hash(subspaces[0]), hash(subspaces[1]))] if subspaces is not None else list(self._mats)
+        for k in keys:
+            mat = self._mats.pop(k, None)
+            if mat is not None:
+                mat.destroy()
+
+    def conserves(self, left, right=None):
+        """Does the operator map the right subspace into the left one?  Host-side
+        sweep over the columns for small dimensions (CheckConserves,
+        bpetsc_template_2.c:990-1056); Full always conserves."""
+        if right is None:
+            right = left
+        if isinstance(left, Full) and isinstance(right, Full):
+            return True
+        self.establish_L()
+        self.reduce_msc()
+        N = right.get_dimension()
+        cols = np.arange(N, dtype=np.int64)
+        bras = np.asarray(right.idx_to_state(cols))
+        masks, offs = msc_tools.get_mask_offsets(self.msc)
+        for i, m in enumerate(masks):
+            out = np.asarray(left.state_to_idx(bras ^ m)) == -1
+            if not np.any(out):
+                continue
+            val = np.zeros(int(out.sum()), dtype=np.complex128)
+            for t in range(offs[i], offs[i + 1]):
+                val += (1 - 2 * msc_tools.parity(bras[out] & self.msc['signs'][t])) * self.msc['coeffs'][t]
+            if np.any(val != 0):
+                return False
+        return True
+
+    def infinity_norm(self, subspaces=None):
+        return self.get_mat(subspaces=subspaces).norm('infinity')
+
+    def create_states(self):
+        self.establish_L()
+        return (State(L=self.L, subspace=self.left_subspace),
+                State(L=self.L, subspace=self.right_subspace))
+
+    def dot(self, x, result=None):
+        r"""y = A x  (operators.py:1063-1108)."""
+        x.assert_initialized()
+        self.establish_L()
+        right_subspace = x.subspace
+        right_match = [(l, r) for l, r in self.get_subspace_list() if r.identical(right_subspace)]
+        if not right_match:
+            raise ValueError('No operator subspace found that matches input vector subspace. '
+                             'Try adding the subspace with the Operator.add_subspace method.')
+        if result is None:
+            if len(right_match) != 1:
+                raise ValueError('Ambiguous subspace for result vector. Pass a state with the '
+                                 'desired subspace as the "result" option to Operator.dot.')
+            left_subspace = right_match[0][0]
+            result = State(L=left_subspace.L, subspace=left_subspace)
+        else:
+            left_subspace = result.subspace
+        if not any(l.identical(left_subspace) for l, _ in right_match):
+            raise ValueError('Subspaces of matrix and result vector do not match.')
+        self.get_mat(subspaces=(left_subspace, right_subspace)).mult(x.vec, result.vec)
+        result.set_initialized()
+        return result
+
+    def expectation(self, state, tmp_state=None):
+        """<state|A|state> (operators.py:775-796)."""
+        if tmp_state is None:
+            tmp_state = self.dot(state)
+        else:
+            self.dot(state, tmp_state)
+        return state.dot(tmp_state).real
+
+    # ------------------------------------------------------------------ algebra
+    def _check_compatible(self, o):
+        if self.L != o.L:
+            raise ValueError("Operators to be combined must have the same value of the spin chain "
+                             "length L. To set it globally, set config.L")
+        if self.allow_projection != o.allow_projection:
+            raise ValueError("Operators must have the same value of the 'allow_projection' "
+                             "parameter to be combined.")
+
+    def __add__(self, x):
+        if not isinstance(x, Operator):
+            if x == 0:
+                return self.copy()
+            x = x * identity()
+        self._check_compatible(x)
+        rtn = self.copy()
+        rtn.msc = msc_tools.msc_sum([self.msc, x.msc])
+        return rtn
+
+    def __radd__(self, x):
+        return self.__add__(x)
+
+    def __sub__(self, x):
+        return self + -x
+
+    def __rsub__(self, x):
+        return x + -self
+
+    def __neg__(self):
+        return -1 * self
+
+    def __mul__(self, x):
+        if isinstance(x, Operator):
+            self._check_compatible(x)
+            rtn = self.copy()
+            rtn.msc = msc_tools.msc_product([self.msc, x.msc])
+            return rtn
+        if isinstance(x, State):
+            return self.dot(x)
+        return self._num_mul(x)
+
+    def __rmul__(self, x):
+        if isinstance(x, State):
+            raise TypeError('Left vector-matrix multiplication not currently supported.')
+        return self._num_mul(x)
+
+    def __truediv__(self, x):
+        if isinstance(x, Operator):
+            raise TypeError('Dividing by Operators not supported.')
+        return (1 / x) * self
+
+    def __eq__(self, x):
+        if isinstance(x, Operator):
+            self.reduce_msc()
+            x.reduce_msc()
+            return np.array_equal(self.msc, x.msc)
+        raise TypeError('Equality not supported for types %s and %s' % (type(self), type(x)))
+
+    __hash__ = None
+
+    def scale(self, x):
+        if x == 1:
+            return
+        try:
+            self.msc['coeffs'] *= x
+        except (ValueError, TypeError):
+            raise TypeError(f'Cannot scale operator by type {type(x)}')
+        self.destroy_mat()
+
+    def _num_mul(self, x):
+        rtn = self.copy()
+        rtn.scale(x)
+        return rtn
+
+
+# ---------------------------------------------------------------------- constructors
+
+def _spin_index(i):
+    if int(i) != i or i < 0 or i > 62:
+        raise ValueError('invalid spin index')
+    return int(i)
+
+
+def sigmax(i=0):
+    r""":math:`\sigma^x_i`  = msc (1<<i, 0, 1)   (operators.py:1426-1440)."""
+    i = _spin_index(i)
+    return Operator(msc=[(1 << i, 0, 1)])
+
+
+def sigmay(i=0):
+    r""":math:`\sigma^y_i`  = msc (1<<i, 1<<i, 1j)   (operators.py:1442-1456)."""
+    i = _spin_index(i)
+    return Operator(msc=[(1 << i, 1 << i, 1j)])
+
+
+def sigmaz(i=0):
+    r""":math:`\sigma^z_i`  = msc (0, 1<<i, 1)   (operators.py:1458-1472)."""
+    i = _spin_index(i)
+    return Operator(msc=[(0, 1 << i, 1)])
+
+
+def sigma_plus(i=0):
+    return sigmax(i) + 1j * sigmay(i)
+
+
+def sigma_minus(i=0):
+    return sigmax(i) - 1j * sigmay(i)
+
+
+def identity():
+    return Operator(msc=[(0, 0, 1)])
+
+
+def zero():
+    return Operator(msc=np.empty(0, dtype=msc_dtype))
+
+
+def op_sum(terms, nshow=3):
+    """Sum of operators (operators.py:1168-1218)."""
+    terms = list(terms)
+    if not terms:
+        return zero()
+    rtn = Operator(msc=msc_tools.msc_sum(t.msc for t in terms))
+    if terms[0].L is not None:
+        rtn.L = terms[0].L
+    return rtn
+
+
+def op_product(terms):
+    """Product of operators, in order (operators.py:1220-1264)."""
+    terms = list(terms)
+    if not terms:
+        return identity()
+    rtn = Operator(msc=msc_tools.msc_product(t.msc for t in terms))
+    if terms[0].L is not None:
+        rtn.L = terms[0].L
+    return rtn
+
+
+def index_sum(op, size=None, start=0, boundary='open'):
+    """Translate ``op`` along the chain and sum (operators.py:1266-1349)."""
+    if size is None:
+        if op.L is None:
+            raise ValueError('Must specify index_sum size with either the "size" argument '
+                             'or by setting Operator.L (possibly through config.L).')
+        size = op.L
+    if boundary == 'open':
+        stop = start + size - op.max_spin_idx
+        if stop <= start:
+            raise ValueError("requested size %d for sum operator's support smaller than "
+                             "summand's support %d; impossible to satisfy" % (size, op.max_spin_idx))
+        wrap_idx = None
+    elif boundary == 'closed':
+        stop = start + size
+        wrap_idx = stop
+        if start != 0:
+            raise ValueError('cannot set start != 0 for closed boundary conditions.')
+    else:
+        raise ValueError("invalid value for argument 'boundary' (can be 'open' or 'closed')")
+    rtn = Operator(msc=msc_tools.msc_sum(op.get_shifted_msc(i, wrap_idx) for i in range(start, stop)))
+    if op.L is not None:
+        rtn.L = op.L
+    return rtn
+
+
+def index_product(op, size=None, start=0):
+    """Translate ``op`` along the chain and multiply (operators.py:1351-1411)."""
+    if size is None:
+        if op.L is None:
+            raise ValueError('Must specify index_product size')
+        size = op.L
+    if size == 0:
+        return identity()
+    stop = start + size - op.max_spin_idx
+    return op_product(Operator(msc=op.get_shifted_msc(i, None)) for i in range(start, stop))

@@ -1,0 +1,246 @@
+/*
+ * dynamite_amd.h -- C ABI of the MI355X-native matrix-free spin-operator engine.
+ *
+ * This is the drop-in boundary for dynamite's `_backend` shell-matrix path:
+ * the entry points below are what dynamite's Cython layer (bpetsc.pyx /
+ * bsubspace.pyx) would bind instead of PETSc MatShell + SLEPc MFN/EPS.  Each
+ * declaration cites the reference interface it replaces (paths relative to
+ * the reference repository root).
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on failure;
+ *     dnm_last_error() returns a thread-local message (the reference returns
+ *     PetscErrorCode and raises petsc4py.Error, bpetsc.pyx:135-136);
+ *   - all integers describing states / masks / indices are int64_t (the
+ *     reference's PetscInt under --with-64-bit-indices, bbuild.pyx:28-33);
+ *   - state vectors are device pointers to interleaved complex128
+ *     (re, im doubles), length = subspace dimension (local part when
+ *     partitioned);
+ *   - host arrays passed in are BORROWED for the duration of the call; the
+ *     handle keeps its own copies (BuildContext deep-copies,
+ *     src/dynamite/_backend/bpetsc_template_2.c:275-297);
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).
+ *     Kernels are enqueued asynchronously; functions that return host scalars
+ *     synchronise that stream.
+ */
+#ifndef DYNAMITE_AMD_H
+#define DYNAMITE_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ */
+/* errors / device                                                    */
+/* ------------------------------------------------------------------ */
+const char *dnm_last_error(void);
+int dnm_version(void);
+int dnm_device_count(int *count);
+int dnm_set_device(int device);
+/* thin device-memory helpers so a non-torch host (Cython/C) can own vectors;
+ * replaces PETSc VecCreate/VecDestroy for VECCUDA
+ * (src/dynamite/_backend/bcuda_template_2.cu:110-139 MatCreateVecs_GPU). */
+int dnm_malloc(void **dptr, size_t bytes);
+int dnm_free(void *dptr);
+int dnm_memcpy_h2d(void *dst, const void *src, size_t bytes, void *stream);
+int dnm_memcpy_d2h(void *dst, const void *src, size_t bytes, void *stream);
+int dnm_stream_synchronize(void *stream);
+
+/* ------------------------------------------------------------------ */
+/* subspaces -- src/dynamite/_backend/bsubspace_impl.h                */
+/* ------------------------------------------------------------------ */
+/* subspace_type, bsubspace_impl.h:17-23 */
+enum { DNM_FULL = 0, DNM_PARITY = 1, DNM_EXPLICIT = 2, DNM_SPIN_CONSERVE = 3 };
+
+/* data_Full / data_Parity / data_SpinConserve / data_Explicit
+ * (bsubspace_impl.h:41-44, 95-99, 161-167, 265-272) folded into one POD.
+ * Python holders: bsubspace.pyx:68-114 (CFull, CParity, CSpinConserve,
+ * CExplicit). */
+typedef struct dnm_subspace {
+  int32_t type;
+  int64_t L;
+  int64_t space;               /* Parity: 0 even, 1 odd */
+  int64_t k;                   /* SpinConserve */
+  int64_t ld_nchoosek;         /* SpinConserve: L+1 */
+  const int64_t *nchoosek;     /* SpinConserve: (k+1)*(L+1), [kk*ld+LL] = C(LL,kk) */
+  int64_t dim;                 /* Explicit */
+  const int64_t *state_map;    /* Explicit: idx -> state */
+  const int64_t *rmap_indices; /* Explicit: NULL when state_map is sorted */
+  const int64_t *rmap_states;  /* Explicit: sorted states */
+} dnm_subspace;
+
+/* get_dimension_* (bsubspace.pyx:144-162) -> Dim_* */
+int dnm_subspace_dim(const dnm_subspace *s, int64_t *dim);
+/* idx_to_state_* (bsubspace.pyx:164-184) -> I2S_*_array; out-of-range idx is an error */
+int dnm_idx_to_state(const dnm_subspace *s, int64_t n, const int64_t *idxs, int64_t *states);
+/* state_to_idx_* (bsubspace.pyx:186-206) -> S2I_*_array; -1 when not in the subspace */
+int dnm_state_to_idx(const dnm_subspace *s, int64_t n, const int64_t *states, int64_t *idxs);
+
+/* ------------------------------------------------------------------ */
+/* shell matrix -- bpetsc.pyx:78-147, bpetsc_impl.h:42-63             */
+/* ------------------------------------------------------------------ */
+typedef struct dnm_mat dnm_mat;   /* replaces PETSc Mat(MATSHELL) + shell_context (shell_context.h:12-27) */
+
+/* flags for dnm_mat_create */
+enum {
+  DNM_MAT_DEFAULT      = 0,
+  DNM_MAT_FORCE_GATHER = 1,   /* use only the generic row-gather kernel */
+  DNM_MAT_NO_GLDS      = 2,   /* stage LDS tiles through registers instead of global_load_lds */
+  DNM_MAT_HOST_ONLY    = 4    /* build the plan and its tables on the host only (no device needed;
+                                 diagnostics and CPU tests) -- such a handle cannot multiply */
+};
+
+/* Row-block partition of the state vector over `nranks` devices
+ * (PetscSplitOwnership in BuildGPUShell, bcuda_template_2.cu:24-27).
+ * nranks must be a power of two and (for now) the subspace Full or Parity;
+ * rank r owns indices [r*dim/nranks, (r+1)*dim/nranks). */
+typedef struct dnm_partition {
+  int32_t rank;
+  int32_t nranks;
+} dnm_partition;
+
+/* BuildMat(msc, subspaces, GPU_SHELL, xparity, &A)  (bpetsc_impl.h:42,
+ * bpetsc.pyx:78-138): masks[nmasks] sorted unique, mask_offsets[nmasks+1],
+ * signs[nterms], coeffs[nterms] complex128 interleaved.  part may be NULL
+ * (single device).  The operator must be Hermitian in the reference's sense
+ * (msc_tools.py:94-118): each term purely real or purely imaginary as
+ * TERM_REAL(mask, sign) dictates (bpetsc_impl.h:34). */
+int dnm_mat_create(int64_t nmasks, const int64_t *masks, const int64_t *mask_offsets,
+                   const int64_t *signs, const double *coeffs,
+                   const dnm_subspace *left, const dnm_subspace *right,
+                   int xparity, int flags, const dnm_partition *part,
+                   dnm_mat **out);
+/* MATOP_DESTROY -> MatDestroyCtx_GPU (bcuda_template_2.cu:110-139) */
+int dnm_mat_destroy(dnm_mat *A);
+/* MatGetSize / MatGetLocalSize */
+int dnm_mat_sizes(const dnm_mat *A, int64_t *M, int64_t *N, int64_t *m_local, int64_t *n_local);
+/* PrecomputeDiagonal(A) (bpetsc.pyx:141-147, bcuda_template_1.cu:4-66).  The
+ * tiled Full/Parity kernels evaluate the diagonal on the fly and ignore the
+ * cache; the generic kernel uses it exactly as the reference does. */
+int dnm_mat_precompute_diagonal(dnm_mat *A, void *stream);
+/* copies the cached diagonal (double[m_local]) to the host; error if absent */
+int dnm_mat_get_diagonal(dnm_mat *A, double *diag_host, void *stream);
+/* MATOP_MULT -> MatMult_GPU (bcuda_template_2.cu:141-198): y = A x, y overwritten.
+ * Single device (or a partition whose operator has no off-rank masks). */
+int dnm_mat_mult(dnm_mat *A, const void *x, void *y, void *stream);
+/* MATOP_NORM, NORM_INFINITY only (bcuda_template_2.cu:275-329); cached in the
+ * handle like ctx->nrm.  With a partition this is the LOCAL max; the caller
+ * max-reduces over ranks (MPIU_Allreduce(MAX), bpetsc_template_2.c:975) and
+ * stores it back with dnm_mat_set_norm. */
+int dnm_mat_norm_inf(dnm_mat *A, double *nrm, void *stream);
+int dnm_mat_set_norm(dnm_mat *A, double nrm);
+/* human-readable description of the execution plan (passes, tiles) */
+int dnm_mat_plan_describe(const dnm_mat *A, char *buf, size_t buflen);
+/* number of kernel launches one dnm_mat_mult issues */
+int dnm_mat_plan_launches(const dnm_mat *A, int *n);
+/* plan introspection (diagnostics, CPU tests of the planner): pass counts, and
+ * a copy of one pass's tables (layouts: dynamite_amd/csrc/plan.h DevPass /
+ * DevMask / DevTerm; pointers inside the copied DevPass are meaningless). */
+int dnm_mat_plan_counts(const dnm_mat *A, int *n_local_passes, int *n_remote_passes, int *tiled,
+                        int *B, int *logR, int *n_loc);
+int dnm_mat_export_pass(const dnm_mat *A, int remote, int idx, void *desc_out, size_t desc_bytes,
+                        void *masks_out, int max_masks, void *terms_out, int max_terms,
+                        int *nmasks, int *nterms);
+
+/* --- partitioned multiply: replaces the VecScatterCreateToAll all-gather of
+ * bcuda_template_2.cu:161-171 with an XOR-partner exchange. ---------------- */
+/* number of distinct partner ranks this rank needs x from, and their ids
+ * (partner = rank ^ h for every distinct non-zero h = mask >> log2(n_local)) */
+int dnm_mat_partners(const dnm_mat *A, int *n, int32_t *partner_ranks /* [nranks] */);
+/* y = (masks that stay on this rank) x_local; y overwritten */
+int dnm_mat_mult_local(dnm_mat *A, const void *x_local, void *y, void *stream);
+/* y += (masks whose partner is `partner_rank`) x_remote, where x_remote is the
+ * partner's complete local vector (received into a local buffer) */
+int dnm_mat_mult_remote(dnm_mat *A, int32_t partner_rank, const void *x_remote,
+                        void *y, void *stream);
+
+/* ------------------------------------------------------------------ */
+/* vector kernels (what PETSc Vec / SLEPc BV supply to the Krylov     */
+/* loops; states.py:703-797 on the Python side)                       */
+/* ------------------------------------------------------------------ */
+int dnm_vec_set(void *x, int64_t n, double re, double im, void *stream);          /* VecSet */
+int dnm_vec_copy(const void *x, void *y, int64_t n, void *stream);                /* VecCopy */
+int dnm_vec_scale(void *x, int64_t n, double re, double im, void *stream);        /* VecScale */
+/* y = alpha x + beta y  (VecAXPBY, states.py:779-797) */
+int dnm_vec_axpby(void *y, const void *x, int64_t n, double are, double aim,
+                  double bre, double bim, void *stream);
+/* out[0..1] = sum_i x_i * conj(y_i)  (VecDot(x,y) = y^H x, states.py:703-719) */
+int dnm_vec_dot(const void *x, const void *y, int64_t n, double *out, void *stream);
+int dnm_vec_norm2(const void *x, int64_t n, double *out, void *stream);           /* VecNorm */
+/* Fills x with N(0,1)+iN(0,1) from a counter-based generator keyed by
+ * (seed, global index = offset + i): distribution of State.set_random
+ * (states.py:292-316), not its MT19937 stream. */
+int dnm_vec_set_random(void *x, int64_t n, uint64_t seed, int64_t offset, void *stream);
+/* h[j] = V_j^H w for j < nv (BVDotVec); V = nv vectors of length n, stride ldv elements.
+ * h_host: 2*nv doubles. */
+int dnm_vec_mdot(const void *V, int64_t ldv, int nv, const void *w, int64_t n,
+                 double *h_host, void *stream);
+/* w += sum_j c[j] V_j (BVMultVec); c_host: 2*nv doubles */
+int dnm_vec_maxpy(void *w, const void *V, int64_t ldv, int nv, int64_t n,
+                  const double *c_host, void *stream);
+/* V[:, 0:nout) = V[:, 0:nin) * S  (in place, S is nin x nout complex column-major,
+ * host): the thick-restart basis update (BVMultInPlace). */
+int dnm_vec_basis_update(void *V, int64_t ldv, int nin, int nout, int64_t n,
+                         const double *S_host, void *stream);
+
+/* ------------------------------------------------------------------ */
+/* Krylov solvers -- computations.py:10-126 (SLEPc MFN expokit) and   */
+/* computations.py:128-292 (SLEPc EPS Krylov-Schur, HEP)              */
+/* ------------------------------------------------------------------ */
+/* Distributed hooks: when non-NULL the solver calls them after every local
+ * reduction (sum over ranks of `n` doubles, in place / max) and uses `mult`
+ * instead of dnm_mat_mult.  A single-device run passes NULL. */
+typedef struct dnm_hooks {
+  void *ctx;
+  int (*mult)(void *ctx, const void *x, void *y);
+  int (*allreduce_sum)(void *ctx, double *buf, int n);
+  int (*allreduce_max)(void *ctx, double *buf, int n);
+} dnm_hooks;
+
+/* converged reasons (SLEPc MFNConvergedReason / EPSConvergedReason as mapped
+ * by computations.py:114-122 and :261-275) */
+enum {
+  DNM_CONVERGED_TOL = 1,
+  DNM_CONVERGED_ITS = 2,        /* MFN_CONVERGED_ITS */
+  DNM_DIVERGED_ITS = -1,        /* -> MaxIterationsError */
+  DNM_DIVERGED_BREAKDOWN = -2,  /* -> ConvergenceError */
+  DNM_DIVERGED_SYMMETRY_LOST = -3
+};
+
+typedef struct dnm_solver_stats {
+  int32_t reason;
+  int32_t its;          /* outer steps (MFN) / restarts (EPS) */
+  int32_t matvecs;
+  int32_t nconv;        /* EPS only */
+  double  err_est;      /* MFN: accumulated local error estimate */
+} dnm_solver_stats;
+
+/* y = exp(scale * A) x, scale = (scale_re + i scale_im); evolve() passes
+ * scale = -i t (computations.py:89-96).  Sidje-Expokit adaptive Krylov
+ * (SLEPc MFNEXPOKIT); because A is Hermitian the basis is built by Lanczos
+ * with full re-orthogonalisation.  tol<=0 -> 1e-8; ncv<=0 -> min(30, N);
+ * max_its<=0 -> 100 (SLEPc defaults).  work_limit_bytes bounds the basis
+ * allocation (0 = no limit): ncv is reduced to fit. */
+int dnm_expm_multiply(dnm_mat *A, const void *x, void *y, int64_t n_local,
+                      double scale_re, double scale_im, double tol, int ncv,
+                      int max_its, size_t work_limit_bytes, const dnm_hooks *hooks,
+                      dnm_solver_stats *stats, void *stream);
+
+enum { DNM_WHICH_LOWEST = 0, DNM_WHICH_HIGHEST = 1, DNM_WHICH_EXTERIOR = 2 };
+
+/* Thick-restart Lanczos (SLEPc EPSKRYLOVSCHUR on a HEP).  evals: [nev_max]
+ * doubles; evecs (optional, may be NULL): device buffer of nev_max vectors of
+ * n_local complex128 each, stride n_local.  nev_max >= nev.  tol<=0 -> 1e-8;
+ * ncv<=0 -> max(2*nev, nev+15); max_its<=0 -> max(100, 2N/ncv). */
+int dnm_eigsolve(dnm_mat *A, int64_t n_local, int nev, int which, double tol,
+                 int ncv, int max_its, uint64_t seed, const dnm_hooks *hooks,
+                 int nev_max, double *evals, void *evecs,
+                 dnm_solver_stats *stats, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,157 @@
+"""
+Test-only numpy emulation of ``tile_pass_kernel`` (dynamite_amd/csrc/
+matvec_kernels.hip), driven by the REAL pass tables the product's host code
+builds (exported through ``dnm_mat_export_pass`` from a DNM_MAT_HOST_ONLY
+handle).  It lets the CPU suite check the planner, the tile geometry and the
+term tables against the oracle without a GPU.  It is not a fallback: nothing in
+dynamite_amd imports it.
+"""
+import ctypes as C
+
+import numpy as np
+
+from dynamite_amd import _lib, backend
+
+
+def _popc(v):
+    v = np.asarray(v, dtype=np.uint64).copy()
+    c = np.zeros(v.shape, dtype=np.int64)
+    while np.any(v):
+        c += (v & np.uint64(1)).astype(np.int64)
+        v >>= np.uint64(1)
+    return c
+
+
+class HostMat:
+    """DNM_MAT_HOST_ONLY handle + exported pass tables."""
+
+    def __init__(self, masks, mask_offsets, signs, coeffs, left_c, right_c, rank=0, nranks=1, flags=0):
+        self._keep = (left_c, right_c)
+        self.h = backend.create_mat(masks, mask_offsets, signs, coeffs, left_c, right_c, False,
+                                    flags | _lib.MAT_HOST_ONLY, rank, nranks)
+        L = _lib.lib()
+        vals = [C.c_int() for _ in range(6)]
+        _lib.check(L.dnm_mat_plan_counts(self.h, *[C.byref(v) for v in vals]))
+        (self.n_local_passes, self.n_remote_passes, self.tiled, self.B, self.logR, self.n_loc) = \
+            [v.value for v in vals]
+        npart = C.c_int()
+        buf = (C.c_int32 * 64)()
+        _lib.check(L.dnm_mat_partners(self.h, C.byref(npart), buf))
+        self.partners = [int(buf[i]) for i in range(npart.value)]
+        self.local = [self._export(0, i) for i in range(self.n_local_passes)]
+        self.remote = [self._export(1, i) for i in range(self.n_remote_passes)]
+
+    def describe(self):
+        buf = C.create_string_buffer(8192)
+        _lib.check(_lib.lib().dnm_mat_plan_describe(self.h, buf, len(buf)))
+        return buf.value.decode()
+
+    def _export(self, remote, idx):
+        L = _lib.lib()
+        nm, nt = C.c_int(), C.c_int()
+        _lib.check(L.dnm_mat_export_pass(self.h, remote, idx, None, 0, None, 0, None, 0,
+                                         C.byref(nm), C.byref(nt)))
+        desc = _lib.DevPass()
+        masks = (_lib.DevMask * max(1, nm.value))()
+        terms = (_lib.DevTerm * max(1, nt.value))()
+        _lib.check(L.dnm_mat_export_pass(self.h, remote, idx, C.byref(desc), C.sizeof(desc), masks,
+                                         nm.value, terms, nt.value, C.byref(nm), C.byref(nt)))
+        return desc, [masks[i] for i in range(nm.value)], [terms[i] for i in range(nt.value)]
+
+    def __del__(self):
+        try:
+            _lib.lib().dnm_mat_destroy(self.h)
+        except Exception:
+            pass
+
+
+def run_pass(hm, p, x, y, xr=None):
+    """Apply one exported pass to the local vector x (numpy), updating y."""
+    desc, masks, terms = p
+    B, logR, n_loc = hm.B, hm.logR, hm.n_loc
+    lognt = B - logR
+    NT = 1 << lognt
+    n = 1 << n_loc
+    rows = np.arange(n, dtype=np.uint64)
+
+    tile_bits = np.uint64(0)
+    for j in range(desc.nseg):
+        tile_bits |= np.uint64(((1 << desc.seg_len[j]) - 1) << desc.seg_pos[j])
+    # geometry self-checks (what the kernel's deposit() relies on)
+    assert sum(desc.seg_len[j] for j in range(desc.nseg)) == B
+    blk_bits = 0
+    for j in range(desc.nbseg):
+        blk_bits |= ((1 << desc.bseg_len[j]) - 1) << desc.bseg_pos[j]
+    assert blk_bits & int(tile_bits) == 0 and (blk_bits | int(tile_bits)) == n - 1
+
+    def compress(v):
+        out = np.zeros(v.shape, dtype=np.uint64)
+        for j in range(desc.nseg):
+            seg = (v >> np.uint64(desc.seg_pos[j])) & np.uint64((1 << desc.seg_len[j]) - 1)
+            out |= seg << np.uint64(desc.seg_off[j])
+        return out
+
+    def deposit(t):
+        out = np.zeros(t.shape, dtype=np.uint64)
+        for j in range(desc.nseg):
+            seg = (t >> np.uint64(desc.seg_off[j])) & np.uint64((1 << desc.seg_len[j]) - 1)
+            out |= seg << np.uint64(desc.seg_pos[j])
+        return out
+
+    tt = compress(rows)
+    base = rows & ~tile_bits
+    assert np.array_equal(base | deposit(tt), rows)
+    sbase = base | np.uint64(desc.sign_base)
+    tid = tt & np.uint64(NT - 1)
+    kk = tt >> np.uint64(lognt)
+
+    def tsum(b, e, tcoord):
+        s = np.zeros(n, dtype=np.float64)
+        for t in range(b, e):
+            T = terms[t]
+            par = (_popc(tcoord & np.uint64(T.sign_tile)) + _popc(sbase & np.uint64(T.sign_ext))) & 1
+            s += np.where(par == 1, -T.coeff, T.coeff)
+        return s
+
+    acc = y.copy() if desc.accumulate else np.zeros(n, dtype=np.complex128)
+
+    if desc.has_diag:
+        R = 1 << logR
+        for t in range(desc.dext_begin, desc.dext_end):
+            assert terms[t].sign_tile == 0
+        D = [tsum(desc.dbucket[j], desc.dbucket[j + 1], tid) for j in range(R)]
+        for j in range(R):
+            for t in range(desc.dbucket[j], desc.dbucket[j + 1]):
+                assert terms[t].sign_tile != 0 and (terms[t].sign_tile >> lognt) == j
+        D[0] = D[0] + tsum(desc.dext_begin, desc.dext_end, np.zeros(n, dtype=np.uint64))
+        # Walsh-Hadamard over the k bits
+        d = np.zeros(n, dtype=np.float64)
+        for j in range(R):
+            d += np.where(_popc(kk & np.uint64(j)) & 1, -D[j], D[j])
+        acc += d * x
+
+    for M in masks:
+        kvar = bool(M.flags & 2)
+        tc = tt if kvar else tid
+        if not kvar:
+            for t in list(range(M.re_begin, M.re_end)) + list(range(M.im_begin, M.im_end)):
+                assert (terms[t].sign_tile >> lognt) == 0
+        cre = tsum(M.re_begin, M.re_end, tc)
+        cim = tsum(M.im_begin, M.im_end, tc)
+        if M.flags & 1:   # gather
+            src = xr if M.src else x
+            xv = src[(rows ^ np.uint64(M.mask_loc)).astype(np.int64)]
+        else:
+            assert desc.need_tile
+            partner = base | deposit(tt ^ np.uint64(M.mask_tile))
+            xv = x[partner.astype(np.int64)]
+        acc += (cre + 1j * cim) * xv
+    y[:] = acc
+
+
+def multiply(hm, x):
+    """Single-rank multiply through all local passes."""
+    y = np.zeros(1 << hm.n_loc, dtype=np.complex128)
+    for p in hm.local:
+        run_pass(hm, p, x, y)
+    return y
