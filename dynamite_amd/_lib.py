@@ -132,6 +132,10 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
+        # torch bundles its own HIP runtime with the same SONAME (libamdhip64.so.7)
+        # as /opt/rocm's: load torch first so this process has exactly one runtime
+        # and torch's streams / allocations are valid handles for our launches.
+        import torch  # noqa: F401
         path = _build.build()       # no-op when the in-tree .so is current
         L = C.CDLL(path)
         for name, (res, args) in SIGNATURES.items():

@@ -1,0 +1,59 @@
+"""Helpers shared by the -m gpu tests (they all go through the C ABI)."""
+import ctypes as C
+
+import numpy as np
+
+from dynamite_amd import _lib, backend, msc_tools
+from dynamite_amd.config import config
+from oracle import oracle as orc
+
+
+def marshal(H):
+    H.establish_L()
+    H.reduce_msc()
+    masks, offs = msc_tools.get_mask_offsets(H.msc)
+    return masks, offs, np.ascontiguousarray(H.msc['signs']), np.ascontiguousarray(H.msc['coeffs'])
+
+
+def orc_msc(H):
+    return orc.Msc(*marshal(H))
+
+
+def orc_sub(sub):
+    from dynamite_amd import subspaces as S
+    if isinstance(sub, S.Full):
+        return orc.full(sub.L)
+    if isinstance(sub, S.Parity):
+        return orc.parity(sub.L, sub.space)
+    if isinstance(sub, S.SpinConserve):
+        return orc.spin_conserve(sub.L, sub.k)
+    if isinstance(sub, S.Explicit):
+        return orc.explicit(sub.L, sub.state_map)
+    raise TypeError(sub)
+
+
+def shell(H, left, right=None, flags=0):
+    """ShellMat for (left, right) with explicit flags (bypasses Operator's cache)."""
+    right = left if right is None else right
+    config._initialize()
+    m = marshal(H)
+    return backend.build_mat(*m, left._to_c(), right._to_c(), flags=flags)
+
+
+def vec_from(arr):
+    v = backend.Vec(arr.size)
+    v.set_local_from_numpy(arr)
+    return v
+
+
+def mult_numpy(mat, x):
+    xv = vec_from(x)
+    yv = backend.Vec(mat.M)
+    yv.set(777.0)          # the multiply must overwrite, not accumulate
+    mat.mult(xv, yv)
+    return yv.local_numpy()
+
+
+def rand_state(n, seed=0):
+    rs = np.random.RandomState(seed)
+    return rs.standard_normal(n) + 1j * rs.standard_normal(n)

@@ -1,0 +1,258 @@
+"""
+Vector kernels and the native Krylov drivers, through the dynamite-style API
+(Operator.evolve / Operator.eigsolve / State), with the reference's own
+acceptance criteria: tests/integration/test_evolve.py:34-57 (|1 - <y,y_ref>/|y|^2|
+< 1e-9, norm preserved to 1e-9 for real t), test_eigsolve.py:17-88 (Rayleigh
+quotient, residual, orthogonality), and golden expm / eigenvalue vectors.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from dynamite_amd import _lib, models, backend
+from dynamite_amd.computations import MaxIterationsError, ConvergenceError
+from dynamite_amd.operators import Operator
+from dynamite_amd.states import State, UninitializedError
+from dynamite_amd.subspaces import Full, Parity, SpinConserve
+from gpu_util import vec_from, rand_state
+
+pytestmark = pytest.mark.gpu
+
+
+# ------------------------------------------------------------------ vector kernels
+
+def test_vec_kernels_vs_numpy():
+    n = 100003
+    x, y = rand_state(n, 1), rand_state(n, 2)
+    xv, yv = vec_from(x), vec_from(y)
+    assert abs(xv.dot(yv) - np.sum(x * np.conj(y))) < 1e-10      # VecDot(x,y) = sum x conj(y)
+    assert abs(xv.norm() - np.linalg.norm(x)) < 1e-10
+    yv.axpby(0.3 - 0.2j, 1.5j, xv)
+    y = (0.3 - 0.2j) * x + 1.5j * y
+    assert np.max(np.abs(yv.local_numpy() - y)) < 1e-13
+    yv.scale(2 - 1j)
+    assert np.max(np.abs(yv.local_numpy() - (2 - 1j) * y)) < 1e-13
+    c = xv.copy()
+    assert np.array_equal(c.local_numpy(), x)
+    c.set(1 + 2j)
+    assert np.all(c.local_numpy() == 1 + 2j)
+
+
+def test_mdot_maxpy_basis_update():
+    L = _lib.lib()
+    n, nv = 5000, 11
+    V = np.stack([rand_state(n, 10 + j) for j in range(nv)])
+    w = rand_state(n, 99)
+    Vd, wd = vec_from(V.reshape(-1)), vec_from(w)
+    h = np.zeros(2 * nv)
+    _lib.check(L.dnm_vec_mdot(Vd.ptr, n, nv, wd.ptr, n, _lib.pf64(h), None))
+    ref = V.conj() @ w
+    assert np.max(np.abs(h.view(complex) - ref)) < 1e-10
+    c = rand_state(nv, 5)
+    _lib.check(L.dnm_vec_maxpy(wd.ptr, Vd.ptr, n, nv, n, _lib.pf64(c.view(float).copy()), None))
+    assert np.max(np.abs(wd.local_numpy() - (w + c @ V))) < 1e-12
+    nout = 4
+    S = np.stack([rand_state(nv, 50 + o) for o in range(nout)])     # S[o, j] = S(j, o)
+    _lib.check(L.dnm_vec_basis_update(Vd.ptr, n, nv, nout, n, _lib.pf64(S.reshape(-1).view(float).copy()), None))
+    out = Vd.local_numpy().reshape(nv, n)
+    assert np.max(np.abs(out[:nout] - S @ V)) < 1e-11
+    assert np.array_equal(out[nout:], V[nout:])
+
+
+def test_device_rng_moments():
+    n = 1 << 20
+    v = backend.Vec(n)
+    v.set_random(1234)
+    a = v.local_numpy()
+    assert abs(a.real.mean()) < 5e-3 and abs(a.imag.mean()) < 5e-3
+    assert abs(a.real.var() - 1) < 1e-2 and abs(a.imag.var() - 1) < 1e-2
+    assert abs(np.mean(a.real * a.imag)) < 5e-3
+    v2 = backend.Vec(n)
+    v2.set_random(1234)
+    assert np.array_equal(v2.local_numpy(), a)          # counter-based: reproducible
+
+
+def test_state_set_random_matches_reference_stream(golden_full):
+    g = golden_full["mbl_L12"]
+    s = State(L=12, state='random', seed=0)
+    assert np.max(np.abs(s.to_numpy() - g["x"])) < 1e-15
+
+
+def test_state_basics():
+    s = State(L=6)
+    with pytest.raises(UninitializedError):
+        s.norm()
+    s.set_product('DUDUDU')
+    a = s.to_numpy()
+    assert a[0b010101] == 1 and np.count_nonzero(a) == 1
+    s.set_product(5)
+    assert s.to_numpy()[5] == 1
+    sc = State(L=6, subspace=SpinConserve(6, 3), state='UUUDDD')
+    assert sc.to_numpy()[sc.subspace.state_to_idx(0b111000)] == 1
+    with pytest.raises(ValueError):
+        State(L=6, subspace=SpinConserve(6, 3), state='UUDDDD')
+    u = State(L=6, state='uniform')
+    assert abs(u.norm() - 1) < 1e-14
+
+
+# ------------------------------------------------------------------ evolve
+
+def _evolve_check(H, x0, t, ref, **kw):
+    y = H.evolve(x0, t=t, **kw)
+    ynp = y.to_numpy()
+    if np.imag(t) == 0:
+        assert abs(1 - np.linalg.norm(ynp)) < 1e-9
+    ov = np.vdot(ref, ynp) / np.vdot(ref, ref)
+    assert abs(1 - ov) < 1e-9, (t, ov)
+    return ynp
+
+
+@pytest.mark.parametrize("name,L,ts", [("mbl", 12, ["1", "5", "0-0.25j"]), ("mbl", 10, ["1", "0.3-0.2j"]),
+                                       ("long_range", 8, ["1"]), ("syk", 5, ["1"]), ("ising", 10, ["1"])])
+def test_evolve_golden(golden_full, name, L, ts):
+    """BASELINE configs[0] (L=12 random-field Heisenberg, evolve(t=1)) and friends
+    against scipy expm_multiply on the reference-built matrix."""
+    g = golden_full[f"{name}_L{L}"]
+    H = models.BY_NAME[name](L)
+    x0 = State(L=L, state='random', seed=0)
+    for key in ts:
+        t = complex(key) if 'j' in key else float(key)
+        k = "expm_t=" + key if 'j' not in key else "expm_t=" + ("%g%+gj" % (t.real, t.imag))
+        _evolve_check(H, x0, t, g[k])
+
+
+def test_evolve_options_and_errors(golden_full):
+    g = golden_full["mbl_L12"]
+    H = models.mbl(12)
+    x0 = State(L=12, state='random', seed=0)
+    _evolve_check(H, x0, 1.0, g["expm_t=1"], ncv=10)
+    _evolve_check(H, x0, 1.0, g["expm_t=1"], ncv=40, tol=1e-12)
+    res = State(L=12)
+    out = H.evolve(x0, t=1.0, result=res)
+    assert out is res and res.initialized
+    z = H.evolve(x0, t=0.0)
+    assert np.array_equal(z.to_numpy(), x0.to_numpy())
+    with pytest.raises(MaxIterationsError):       # test_evolve.py:196-202
+        H.evolve(x0, t=500.0, max_its=2, ncv=5)
+    with pytest.raises(ValueError):
+        H.evolve(State(L=12, subspace=Parity('even'), state='random', seed=1), t=1.0)
+    with pytest.raises(UninitializedError):
+        H.evolve(State(L=12), t=1.0)
+    # backwards in time undoes forwards
+    back = H.evolve(H.evolve(x0, t=0.7), t=-0.7)
+    assert np.max(np.abs(back.to_numpy() - x0.to_numpy())) < 1e-8
+
+
+def test_evolve_pi_pulse():
+    """test_evolve.py:23-32: exp(-i (pi/2) sigma_x) flips every spin."""
+    L = 8
+    H = models.xsum(L)
+    y = H.evolve(State(L=L, state='U' * L), t=np.pi / 2)
+    a = y.to_numpy()
+    assert abs(abs(a[(1 << L) - 1]) - 1) < 1e-9
+
+
+def test_evolve_subspace(golden_sub):
+    L = 10
+    H = models.mbl(L)
+    sub = SpinConserve(L, 5)
+    H.add_subspace(sub)
+    x0 = State(L=L, subspace=sub, state='random', seed=0)
+    y = H.evolve(x0, t=1.0).to_numpy()
+    A = H.to_numpy(subspaces=(sub, sub)).toarray()
+    w, U = np.linalg.eigh(A)
+    ref = U @ (np.exp(-1j * w) * (U.conj().T @ x0.to_numpy()))
+    assert abs(1 - np.vdot(ref, y) / np.vdot(ref, ref)) < 1e-9
+
+
+# ------------------------------------------------------------------ eigsolve
+
+def _check_eigs(H, evals, evecs, tol=1e-12, evec_tol=1e-11):
+    """test_eigsolve.py:17-88."""
+    for i, (ev, v) in enumerate(zip(evals, evecs)):
+        Hv = H.dot(v)
+        rq = Hv.dot(v).real          # sum Hv_i conj(v_i) = <v|Hv>
+        assert abs(v.norm() - 1) < 1e-10
+        assert abs(rq - ev) < max(tol, abs(ev) * tol) * 10
+        r = Hv.copy()
+        r.axpy(-ev, v)
+        assert r.norm() < evec_tol * max(1.0, abs(ev)) * 10
+        for j in range(i):
+            assert abs(v.dot(evecs[j])) < 1e-9
+
+
+@pytest.mark.parametrize("name,L", [("mbl", 12), ("mbl", 10), ("heisenberg", 10), ("long_range", 8),
+                                    ("localized", 10), ("syk", 5), ("ising", 10)])
+def test_eigsolve_golden(golden_full, name, L):
+    g = golden_full[f"{name}_L{L}"]
+    H = models.BY_NAME[name](L)
+    ev, vecs = H.eigsolve(nev=5, which='lowest', tol=1e-12, getvecs=True)
+    assert len(ev) >= 5
+    # degenerate levels may be missed by Krylov solvers (computations.py:137-139):
+    # every returned value must be an eigenvalue, and the lowest must match
+    ref = g["evals_lowest"]
+    assert abs(ev[0] - ref[0]) < 1e-9
+    _check_eigs(H, ev[:5], vecs[:5])
+    hi = H.eigsolve(nev=2, which='highest', tol=1e-10)
+    assert abs(hi[0] - g["evals_highest"][0]) < 1e-8
+    ex = H.eigsolve(nev=1, which='exterior', tol=1e-10)
+    both = np.concatenate([g["evals_lowest"], g["evals_highest"]])
+    assert abs(abs(ex[0]) - np.max(np.abs(both))) < 1e-8
+
+
+def test_eigsolve_baseline_values(known):
+    b = known["baseline_mbl_L12"]
+    ev = models.mbl(12).eigsolve(nev=5, tol=1e-12)
+    assert np.allclose(ev[:5], b["evals_lowest"], atol=5e-8)
+
+
+def test_eigsolve_analytic_xsum():
+    """test_eigsolve.py:95-123: lowest eigenvalue of sum sigma_x is -L, then -L+2."""
+    L = 8
+    ev = models.xsum(L).eigsolve(nev=2, tol=1e-12)
+    assert abs(ev[0] + L) < 1e-10
+
+
+def test_eigsolve_subspaces_and_errors():
+    L = 12
+    H = models.mbl(L)
+    sub = SpinConserve(L, 6)
+    H.add_subspace(sub)
+    ev, vecs = H.eigsolve(nev=3, getvecs=True, tol=1e-12, subspace=sub)
+    A = H.to_numpy(subspaces=(sub, sub)).toarray()
+    w = np.linalg.eigvalsh(A)
+    assert np.max(np.abs(ev[:3] - w[:3])) < 1e-9
+    assert vecs[0].subspace == sub
+    with pytest.raises(MaxIterationsError):      # test_eigsolve.py:231-241
+        models.mbl(12).eigsolve(nev=8, max_its=1, tol=1e-14, ncv=9)
+    with pytest.raises(RuntimeError):
+        H.eigsolve(target=0.0)
+    with pytest.raises(ValueError):
+        H.eigsolve(which='target')
+    with pytest.raises(ValueError):
+        H.eigsolve(subspace=Parity('even', L=L))
+    # zero-diagonal operator (test_eigsolve.py:158-163)
+    Z = models.xsum(8)
+    assert abs(Z.eigsolve(nev=1, which='highest', tol=1e-12)[0] - 8) < 1e-9
+
+
+def test_operator_dot_api():
+    L = 10
+    H = models.ising(L)
+    x = State(L=L, state='random', seed=3)
+    y = H.dot(x)
+    ref = H.to_numpy() @ x.to_numpy()
+    assert np.max(np.abs(y.to_numpy() - ref)) < 1e-12
+    y2 = H * x
+    assert np.array_equal(y2.to_numpy(), y.to_numpy())
+    assert abs(H.expectation(x) - np.vdot(x.to_numpy(), ref).real) < 1e-12
+    assert abs(H.infinity_norm() - abs(H.to_numpy()).sum(axis=1).max()) < 1e-12
+    # projection gate (operators.py:598-603)
+    H.add_subspace(SpinConserve(L, 5))
+    with pytest.raises(ValueError):
+        H.build_mat()
+    H.allow_projection = True
+    H.build_mat()
+    with pytest.raises(ValueError):
+        Operator(msc=[(1, 0, 1j)]).dot(State(L=1, state='U'))   # non-Hermitian

@@ -1,0 +1,256 @@
+"""
+Parity tests proper: the HIP path (through the C ABI) against the golden
+fixtures, against the CPU oracle on seeded inputs, and -- at the full
+BASELINE sizes -- through size-independent properties.
+Tolerance (reference's own, tests/integration/test_multiply.py:194-195):
+|dy| <= nnz * 2.2e-16 per unit |coeff| and |x| (scaled by the data magnitudes).
+"""
+import numpy as np
+import pytest
+
+from dynamite_amd import _lib, models, backend
+from dynamite_amd.subspaces import Full, Parity, SpinConserve, Explicit
+from oracle import oracle as orc
+from gpu_util import marshal, orc_msc, orc_sub, shell, vec_from, mult_numpy, rand_state
+
+pytestmark = pytest.mark.gpu
+EPS = 2.2e-16
+
+
+def tol_for(arrs, x):
+    return 8 * len(arrs[0]) * EPS * max(1.0, np.abs(arrs[3]).max()) * max(1.0, np.abs(x).max())
+
+
+def cfg(monkeypatch, B=12, logR=4, mode=0, amin=3):
+    monkeypatch.setenv("DNM_TILE_BITS", str(B))
+    monkeypatch.setenv("DNM_LOG_ROWS", str(logR))
+    monkeypatch.setenv("DNM_PLAN_MODE", str(mode))
+    monkeypatch.setenv("DNM_AMIN", str(amin))
+
+
+GOLD = [('mbl', 6), ('mbl', 10), ('mbl', 12), ('heisenberg', 10), ('xxz', 10), ('ising', 10),
+        ('long_range', 8), ('localized', 10), ('syk', 5), ('xsum', 8)]
+
+
+@pytest.mark.parametrize("flags", [_lib.MAT_FORCE_GATHER, 0, _lib.MAT_NO_GLDS])
+@pytest.mark.parametrize("name,L", GOLD)
+def test_golden_full_space(monkeypatch, golden_full, name, L, flags):
+    """y = Hx, ||H||_inf and the diagonal against vectors derived from the
+    reference's msc_to_numpy."""
+    cfg(monkeypatch, B=8, logR=2)
+    g = golden_full[f"{name}_L{L}"]
+    H = models.BY_NAME[name](L)
+    arrs = marshal(H)
+    sub = Full(L=L)
+    mat = shell(H, sub, flags=flags)
+    if L >= 8 and not (flags & _lib.MAT_FORCE_GATHER):
+        assert "tiled=1" in mat.describe()
+    y = mult_numpy(mat, g["x"])
+    assert np.max(np.abs(y - g["y"])) <= tol_for(arrs, g["x"]), mat.describe()
+    nrm = mat.norm()
+    assert abs(nrm - float(g["infnorm"])) <= len(arrs[0]) * EPS * 100 * max(1.0, nrm)
+    if arrs[0][0] == 0:
+        mat.precompute_diagonal()
+        d = np.empty(1 << L)
+        _lib.check(_lib.lib().dnm_mat_get_diagonal(mat.handle, _lib.pf64(d), None))
+        assert np.max(np.abs(d - g["diag"].real)) <= 64 * EPS * np.abs(arrs[3]).sum()
+        y = mult_numpy(mat, g["x"])      # generic kernel now uses the cached diagonal
+        assert np.max(np.abs(y - g["y"])) <= tol_for(arrs, g["x"])
+    mat.destroy()
+
+
+def _subs_for(name, L, gs):
+    p = name.split("_")
+    def one(tag):
+        if tag.startswith("sc"):
+            return SpinConserve(L, int(tag[2:]))
+        return {"even": Parity(0, L=L), "odd": Parity(1, L=L), "full": Full(L=L)}[tag]
+    if "explicit" in name:
+        st = gs["explicit_states"]["unsorted" if name.endswith("unsorted") else "sorted"]
+        s = Explicit(st, L=L)
+        return s, s
+    if "_to_" in name:
+        i = p.index("to")
+        return one(p[i + 1]), one(p[i - 1])
+    s = one(p[-1])
+    return s, s
+
+
+def test_golden_subspaces(monkeypatch, golden_sub):
+    """SpinConserve / Parity / Explicit and the projection pairs (left != right)."""
+    cfg(monkeypatch, B=8, logR=2)
+    for name in golden_sub.names():
+        if name == "explicit_states":
+            continue
+        g = golden_sub[name]
+        L = int(g["L"])
+        hname = next(k for k in models.BY_NAME if name.startswith(k))
+        H = models.BY_NAME[hname](L)
+        arrs = marshal(H)
+        left, right = _subs_for(name, L, golden_sub)
+        for flags in (0, _lib.MAT_FORCE_GATHER):
+            mat = shell(H, left, right, flags=flags)
+            y = mult_numpy(mat, g["x"])
+            assert y.shape == g["y"].shape
+            assert np.max(np.abs(y - g["y"])) <= tol_for(arrs, g["x"]), (name, flags)
+            nrm = mat.norm()
+            assert abs(nrm - float(g["infnorm"])) <= len(arrs[0]) * EPS * 100 * max(1.0, nrm), name
+            mat.destroy()
+
+
+CONFIGS = [(12, 4, 0, 3), (12, 3, 0, 3), (13, 4, 0, 3), (13, 3, 0, 4), (11, 4, 0, 3), (10, 3, 0, 5),
+           (12, 4, 1, 3), (13, 4, 1, 3)]
+
+
+@pytest.mark.parametrize("B,logR,mode,amin", CONFIGS)
+@pytest.mark.parametrize("name,L", [("mbl", 20), ("long_range", 16), ("syk", 8)])
+def test_tiled_vs_oracle(monkeypatch, name, L, B, logR, mode, amin):
+    """Every tile configuration / plan mode against the CPU oracle, both tile
+    staging paths."""
+    cfg(monkeypatch, B, logR, mode, amin)
+    H = models.BY_NAME[name](L)
+    arrs = marshal(H)
+    sub = Full(L=L)
+    x = rand_state(1 << L, seed=L)
+    ref = orc.matvec(orc_msc(H), orc_sub(sub), orc_sub(sub), x, nthreads=4)
+    for flags in (0, _lib.MAT_NO_GLDS):
+        mat = shell(H, sub, flags=flags)
+        assert "tiled=1" in mat.describe()
+        y = mult_numpy(mat, x)
+        assert np.max(np.abs(y - ref)) <= tol_for(arrs, x), mat.describe()
+        mat.destroy()
+
+
+@pytest.mark.parametrize("spaces", [(0, 0), (1, 1), (0, 1)])
+def test_parity_tiled_vs_oracle(monkeypatch, spaces):
+    cfg(monkeypatch, 12, 4)
+    L = 18
+    H = models.long_range(L)
+    arrs = marshal(H)
+    left, right = Parity(spaces[0], L=L), Parity(spaces[1], L=L)
+    x = rand_state(1 << (L - 1), seed=5)
+    ref = orc.matvec(orc_msc(H), orc_sub(left), orc_sub(right), x, nthreads=4)
+    mat = shell(H, left, right)
+    assert "tiled=1" in mat.describe()
+    y = mult_numpy(mat, x)
+    assert np.max(np.abs(y - ref)) <= tol_for(arrs, x)
+
+
+def test_spinconserve_generic_vs_oracle():
+    L, k = 20, 10
+    H = models.mbl(L)
+    arrs = marshal(H)
+    sub = SpinConserve(L, k)
+    x = rand_state(sub.get_dimension(), seed=9)
+    ref = orc.matvec(orc_msc(H), orc_sub(sub), orc_sub(sub), x)
+    mat = shell(H, sub)
+    y = mult_numpy(mat, x)
+    assert np.max(np.abs(y - ref)) <= tol_for(arrs, x)
+    assert abs(mat.norm() - orc.infnorm(orc_msc(H), orc_sub(sub), orc_sub(sub))) < 1e-12
+
+
+def test_partitioned_kernels_on_one_gpu(monkeypatch):
+    """Rank-local and partner passes of a P-way partition, run rank by rank on
+    this one GPU (exchange = slicing), must add up to the single-rank result."""
+    cfg(monkeypatch, 12, 4)
+    L, P = 18, 4
+    H = models.mbl(L)
+    arrs = marshal(H)
+    sub = Full(L=L)
+    x = rand_state(1 << L, seed=4)
+    ref = orc.matvec(orc_msc(H), orc_sub(sub), orc_sub(sub), x, nthreads=4)
+    nloc = (1 << L) // P
+    Lb = _lib.lib()
+    y = np.empty(1 << L, dtype=complex)
+    for r in range(P):
+        h = backend.create_mat(*arrs, sub._c(), sub._c(), flags=0, rank=r, nranks=P)
+        mat = backend.ShellMat(h, sub._c(), sub._c(), P, r)
+        xl = vec_from(x[r * nloc:(r + 1) * nloc])
+        yl = backend.Vec(nloc)
+        _lib.check(Lb.dnm_mat_mult_local(mat.handle, xl.ptr, yl.ptr, None))
+        for p in mat.partners:
+            xr = vec_from(x[p * nloc:(p + 1) * nloc])
+            _lib.check(Lb.dnm_mat_mult_remote(mat.handle, p, xr.ptr, yl.ptr, None))
+        y[r * nloc:(r + 1) * nloc] = yl.local_numpy()
+        mat.destroy()
+    assert np.max(np.abs(y - ref)) <= tol_for(arrs, x)
+
+
+def _sample_rows_check(H, L, xv, yv, nsamp=64, seed=0):
+    """Recompute sampled rows of y = Hx on the host from the MSC definition
+    (msc_tools.py:63-80) using x entries fetched from the device."""
+    import torch
+    masks, offs, signs, coeffs = marshal(H)
+    rs = np.random.RandomState(seed)
+    rows = np.unique(np.concatenate([[0, (1 << L) - 1], rs.randint(0, 1 << L, nsamp)])).astype(np.int64)
+    worst = 0.0
+    ycheck = yv.array[torch.from_numpy(rows).to(yv.array.device)].cpu().numpy()
+    for i, r in enumerate(rows):
+        cols = r ^ masks
+        xs = xv.array[torch.from_numpy(cols).to(xv.array.device)].cpu().numpy()
+        acc = 0j
+        for m in range(len(masks)):
+            c = 0j
+            for t in range(offs[m], offs[m + 1]):
+                c += (1 - 2 * (bin(int(cols[m] & signs[t])).count("1") & 1)) * coeffs[t]
+            acc += c * xs[m]
+        worst = max(worst, abs(acc - ycheck[i]))
+    return worst
+
+
+@pytest.mark.parametrize("L", [26, 30])
+def test_full_size_properties(monkeypatch, L):
+    """BASELINE configs 2/3 (L=26 XXZ, L=30 random-field Heisenberg): sampled
+    rows against the MSC definition, Hermiticity <a|Hb> = <Ha|b>, linearity,
+    and agreement between two different plans."""
+    import torch
+    free, _ = torch.cuda.mem_get_info()
+    if free < 5 * 16 * (1 << L):
+        pytest.skip("not enough HBM")
+    H = models.xxz(L) if L == 26 else models.mbl(L)
+    sub = Full(L=L)
+    n = 1 << L
+    a, b, Ha, Hb = (backend.Vec(n) for _ in range(4))
+    a.set_random(1); b.set_random(2)
+    na, nb = a.normalize(), b.normalize()
+    cfg(monkeypatch, 12, 4, 0)
+    mat = shell(H, sub)
+    mat.mult(a, Ha)
+    mat.mult(b, Hb)
+    assert _sample_rows_check(H, L, a, Ha) < 1e-13
+    lhs = Hb.dot(a)      # sum Hb_i conj(a_i) = <a|Hb>
+    rhs = b.dot(Ha)      # <Ha|b>
+    assert abs(lhs - rhs) < 1e-10
+    # second plan (single pass, gathers) must agree element-wise
+    cfg(monkeypatch, 13, 4, 1)
+    mat2 = shell(H, sub)
+    Ha2 = backend.Vec(n)
+    mat2.mult(a, Ha2)
+    Ha2.axpby(-1.0, 1.0, Ha)
+    assert Ha2.norm() < 1e-12
+    # linearity: H(a + 2i b) = Ha + 2i Hb
+    a.axpby(2j, 1.0, b)
+    mat.mult(a, Ha2)
+    Ha.axpby(2j, 1.0, Hb)
+    Ha2.axpby(-1.0, 1.0, Ha)
+    assert Ha2.norm() < 1e-12
+    mat.destroy(); mat2.destroy()
+
+
+def test_error_behaviour():
+    H = models.mbl(12)
+    sub = Full(L=12)
+    mat = shell(H, sub)
+    x = vec_from(rand_state(1 << 12))
+    with pytest.raises(ValueError):
+        mat.mult(x, x)
+    with pytest.raises(ValueError):
+        mat.norm('frobenius')
+    mat.destroy()
+    with pytest.raises(RuntimeError):
+        mat.mult(x, backend.Vec(1 << 12))
+    # unsorted masks are rejected by the native layer
+    arrs = marshal(H)
+    bad = (arrs[0][::-1].copy(),) + arrs[1:]
+    with pytest.raises(_lib.BackendError):
+        backend.create_mat(*bad, sub._c(), sub._c())
