@@ -141,7 +141,7 @@ def main():
         if os.path.exists(pmc):
             try:
                 p = json.load(open(pmc))
-                if p.get("L") == L and p.get("n_gpus") == n_gpus and p.get("plan") == os.environ.get("DNM_PLAN_MODE", "0"):
+                if p.get("L") == L and p.get("n_gpus") == n_gpus and p.get("plan") == os.environ.get("DNM_PLAN_MODE", "2"):
                     traffic = p.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
@@ -159,7 +159,7 @@ def main():
                        "partition": f"{n_gpus} x 2^{L - int(math.log2(n_gpus))} contiguous blocks",
                        "launches_per_step": launches,
                        "tile_bits": int(os.environ.get("DNM_TILE_BITS", "12")),
-                       "plan_mode": int(os.environ.get("DNM_PLAN_MODE", "0"))},
+                       "plan_mode": int(os.environ.get("DNM_PLAN_MODE", "2"))},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "tile_pass_kernel", "avg_launch_ms": avg_launch_ms,

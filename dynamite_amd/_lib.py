@@ -44,31 +44,30 @@ class SolverStats(C.Structure):
 
 
 # plan introspection structs (dynamite_amd/csrc/plan.h)
-MAXSEG, MAXR = 4, 16
+MAXSEG, MAXBSEG, MAXR = 4, 8, 16
 
 
-class DevTerm(C.Structure):
-    _fields_ = [("sign_ext", C.c_uint64), ("sign_tile", C.c_uint32), ("pad", C.c_uint32),
-                ("coeff", C.c_double)]
+LP_COUNT = 6
+LP_NAMES = ["tile_real", "tile_cplx", "tile_kvar_real", "tile_kvar_cplx", "gather", "gather_kvar"]
 
 
-class DevMask(C.Structure):
-    _fields_ = [("mask_tile", C.c_uint32), ("mask_loc", C.c_uint32), ("re_begin", C.c_uint32),
-                ("re_end", C.c_uint32), ("im_begin", C.c_uint32), ("im_end", C.c_uint32),
-                ("flags", C.c_uint32), ("src", C.c_uint32)]
+class DevQuad(C.Structure):
+    _fields_ = [("mask_tile", C.c_uint32), ("mask_loc", C.c_uint32), ("src", C.c_uint32),
+                ("pad", C.c_uint32), ("sign_tile", C.c_uint32 * 4), ("sign_ext", C.c_uint64 * 4),
+                ("coeff", C.c_double * 4)]
 
 
 class DevPass(C.Structure):
     _fields_ = [("nseg", C.c_int32), ("seg_off", C.c_int32 * MAXSEG), ("seg_len", C.c_int32 * MAXSEG),
-                ("seg_pos", C.c_int32 * MAXSEG), ("nbseg", C.c_int32), ("bseg_off", C.c_int32 * MAXSEG),
-                ("bseg_len", C.c_int32 * MAXSEG), ("bseg_pos", C.c_int32 * MAXSEG),
+                ("seg_pos", C.c_int32 * MAXSEG), ("nbseg", C.c_int32), ("bseg_off", C.c_int32 * MAXBSEG),
+                ("bseg_len", C.c_int32 * MAXBSEG), ("bseg_pos", C.c_int32 * MAXBSEG),
                 ("sign_base", C.c_uint64), ("accumulate", C.c_int32), ("need_tile", C.c_int32),
-                ("has_diag", C.c_int32), ("dext_begin", C.c_uint32), ("dext_end", C.c_uint32),
-                ("dbucket", C.c_uint32 * (MAXR + 1)), ("nmasks", C.c_int32), ("masks", vp),
-                ("terms", vp)]
+                ("has_diag", C.c_int32), ("cache_policy", C.c_int32), ("dext_begin", C.c_uint32), ("dext_end", C.c_uint32),
+                ("dbucket", C.c_uint32 * (MAXR + 1)), ("loop", C.c_uint32 * (LP_COUNT + 1)),
+                ("nquads", C.c_int32), ("quads", vp)]
 
 
-MAT_DEFAULT, MAT_FORCE_GATHER, MAT_NO_GLDS, MAT_HOST_ONLY = 0, 1, 2, 4
+MAT_DEFAULT, MAT_FORCE_GATHER, MAT_USE_GLDS, MAT_HOST_ONLY = 0, 1, 2, 4
 WHICH = {"lowest": 0, "highest": 1, "exterior": 2}
 CONVERGED_TOL, CONVERGED_ITS, DIVERGED_ITS, DIVERGED_BREAKDOWN, DIVERGED_SYMMETRY_LOST = 1, 2, -1, -2, -3
 
@@ -99,8 +98,8 @@ SIGNATURES = {
     "dnm_mat_plan_describe": (C.c_int, [vp, C.c_char_p, C.c_size_t]),
     "dnm_mat_plan_launches": (C.c_int, [vp, C.POINTER(C.c_int)]),
     "dnm_mat_plan_counts": (C.c_int, [vp] + [C.POINTER(C.c_int)] * 6),
-    "dnm_mat_export_pass": (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_size_t, vp, C.c_int, vp, C.c_int,
-                                      C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "dnm_mat_export_pass": (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_size_t, vp, C.c_size_t, C.c_int,
+                                      C.POINTER(C.c_int)]),
     "dnm_mat_partners": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int32)]),
     "dnm_mat_mult_local": (C.c_int, [vp, vp, vp, vp]),
     "dnm_mat_mult_remote": (C.c_int, [vp, C.c_int32, vp, vp, vp]),

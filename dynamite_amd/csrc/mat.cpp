@@ -183,37 +183,55 @@ static int build_pass(const dnm_mat &A, const PassSpec &ps, PassOnDevice *out) {
     off += ps.seg_len[j];
   }
   DNM_CHECK(off == B, "internal: tile segments do not add up to B");
-  // block-id bits fill the local index bits outside the tile, low to high
+  // block-id bits -> local index bits outside the tile.  Order (low to high):
+  // three selector bits (workgroup b runs on XCD b % 8), the XCD-group bits, the rest.
   {
-    int nb = 0, boff = 0, pos = 0;
-    while (pos < pl.n_loc) {
-      if ((tb >> pos) & 1) { ++pos; continue; }
-      int start = pos;
-      while (pos < pl.n_loc && !((tb >> pos) & 1)) ++pos;
-      DNM_CHECK(nb < MAXSEG, "internal: too many block segments");
-      d.bseg_off[nb] = boff;
-      d.bseg_len[nb] = pos - start;
-      d.bseg_pos[nb] = start;
-      boff += pos - start;
+    std::vector<int> order;
+    uint64_t gb = ps.glen ? ((((uint64_t)1 << ps.glen) - 1) << ps.gpos) : 0;
+    std::vector<int> rest;
+    for (int pos = 0; pos < pl.n_loc; ++pos)
+      if (!((tb >> pos) & 1) && !((gb >> pos) & 1)) rest.push_back(pos);
+    size_t nsel = ps.glen ? std::min<size_t>(3, rest.size()) : 0;
+    for (size_t i = 0; i < nsel; ++i) order.push_back(rest[i]);
+    for (int pos = ps.gpos; pos < ps.gpos + ps.glen; ++pos) order.push_back(pos);
+    for (size_t i = nsel; i < rest.size(); ++i) order.push_back(rest[i]);
+    DNM_CHECK((int)order.size() == pl.n_loc - B, "internal: block bits do not add up");
+    int nb = 0;
+    for (size_t i = 0; i < order.size();) {
+      size_t j = i + 1;
+      while (j < order.size() && order[j] == order[j - 1] + 1) ++j;
+      DNM_CHECK(nb < MAXBSEG, "internal: too many block segments");
+      d.bseg_off[nb] = (int32_t)i;
+      d.bseg_len[nb] = (int32_t)(j - i);
+      d.bseg_pos[nb] = order[i];
       ++nb;
+      i = j;
     }
     d.nbseg = nb;
-    DNM_CHECK(boff == pl.n_loc - B, "internal: block bits do not add up");
   }
   d.sign_base = (uint64_t)pl.rank << pl.n_loc;
   d.accumulate = ps.accumulate ? 1 : 0;
   d.has_diag = 0;
+  d.cache_policy = pl.cfg.cache_policy;
 
-  std::vector<DevTerm> terms;
-  std::vector<DevMask> masks;
-  auto push_term = [&](const RowTerm &t) {
-    DevTerm dt;
-    dt.sign_ext = t.sign & ~tb;
-    dt.sign_tile = compress_to_tile(t.sign & tb, ps);
-    dt.pad = 0;
-    dt.coeff = t.coeff;
-    terms.push_back(dt);
-    return dt;
+  std::vector<DevQuad> quads;
+  auto empty_quad = [&]() {
+    DevQuad q;
+    memset(&q, 0, sizeof(q));
+    return q;
+  };
+  auto set_slot = [&](DevQuad &q, int slot, const RowTerm &t) {
+    q.sign_ext[slot] = t.sign & ~tb;
+    q.sign_tile[slot] = compress_to_tile(t.sign & tb, ps);
+    q.coeff[slot] = t.coeff;
+  };
+  // pack a list of (real) diagonal terms four to a record
+  auto push_diag_list = [&](const std::vector<RowTerm> &lst) {
+    for (size_t i = 0; i < lst.size(); i += 4) {
+      DevQuad q = empty_quad();
+      for (size_t j = i; j < lst.size() && j < i + 4; ++j) set_slot(q, (int)(j - i), lst[j]);
+      quads.push_back(q);
+    }
   };
 
   if (ps.has_diag) {
@@ -221,57 +239,73 @@ static int build_pass(const dnm_mat &A, const PassSpec &ps, PassOnDevice *out) {
     for (const RowMask &m : op.masks) if (m.mask == 0 && !m.zero_mask_offdiag) dm = &m;
     if (dm) {
       d.has_diag = 1;
-      // mask-0 terms are real by construction (mask & sign == 0)
-      d.dext_begin = (uint32_t)terms.size();
+      std::vector<RowTerm> lst;
       for (const RowTerm &t : dm->terms)
-        if (compress_to_tile(t.sign & tb, ps) == 0) push_term(t);
-      d.dext_end = (uint32_t)terms.size();
+        if (compress_to_tile(t.sign & tb, ps) == 0) lst.push_back(t);
+      d.dext_begin = (uint32_t)quads.size();
+      push_diag_list(lst);
+      d.dext_end = (uint32_t)quads.size();
       for (int j = 0; j < R; ++j) {
-        d.dbucket[j] = (uint32_t)terms.size();
+        lst.clear();
         for (const RowTerm &t : dm->terms) {
           uint32_t st = compress_to_tile(t.sign & tb, ps);
-          if (st != 0 && (int)(st >> lognt) == j) push_term(t);
+          if (st != 0 && (int)(st >> lognt) == j) lst.push_back(t);
         }
+        d.dbucket[j] = (uint32_t)quads.size();
+        push_diag_list(lst);
       }
-      for (int j = R; j <= MAXR; ++j) d.dbucket[j] = (uint32_t)terms.size();
+      for (int j = R; j <= MAXR; ++j) d.dbucket[j] = (uint32_t)quads.size();
     }
   }
 
+  // off-diagonal masks: records of <= 2 real + <= 2 imaginary terms, sorted into
+  // the kernel's loops (tile/gather x k-variant x real/complex)
+  struct Rec { int loop; DevQuad q; };
+  std::vector<Rec> recs;
   auto push_mask = [&](int idx, bool gather, int src) {
     const RowMask &m = op.masks[idx];
-    DevMask dm;
-    memset(&dm, 0, sizeof(dm));
     const uint64_t mloc = m.mask & (((uint64_t)1 << pl.n_loc) - 1);
-    dm.mask_tile = compress_to_tile(mloc & tb, ps);
-    dm.mask_loc = (uint32_t)mloc;
-    dm.src = (uint32_t)src;
-    bool kvar = false;
-    dm.re_begin = (uint32_t)terms.size();
-    for (const RowTerm &t : m.terms)
-      if (!t.is_imag) kvar |= (push_term(t).sign_tile >> lognt) != 0;
-    dm.re_end = dm.im_begin = (uint32_t)terms.size();
-    for (const RowTerm &t : m.terms)
-      if (t.is_imag) kvar |= (push_term(t).sign_tile >> lognt) != 0;
-    dm.im_end = (uint32_t)terms.size();
-    dm.flags = (gather ? MF_GATHER : 0u) | (kvar ? MF_KVAR : 0u);
     if (!gather) DNM_CHECK((mloc & ~tb) == 0, "internal: tile mask leaves the tile");
-    masks.push_back(dm);
+    std::vector<const RowTerm *> re, im;
+    for (const RowTerm &t : m.terms) (t.is_imag ? im : re).push_back(&t);
+    size_t ir = 0, ii = 0;
+    while (ir < re.size() || ii < im.size()) {
+      DevQuad q = empty_quad();
+      q.mask_tile = compress_to_tile(mloc & tb, ps);
+      q.mask_loc = (uint32_t)mloc;
+      q.src = (uint32_t)src;
+      bool kvar = false, cplx = false;
+      for (int s = 0; s < 2 && ir < re.size(); ++s, ++ir) {
+        set_slot(q, s, *re[ir]);
+        kvar |= (q.sign_tile[s] >> lognt) != 0;
+      }
+      for (int s = 2; s < 4 && ii < im.size(); ++s, ++ii) {
+        set_slot(q, s, *im[ii]);
+        kvar |= (q.sign_tile[s] >> lognt) != 0;
+        cplx = true;
+      }
+      int loop;
+      if (gather) loop = kvar ? LP_GATHER_KVAR : LP_GATHER;
+      else if (kvar) loop = cplx ? LP_TILE_KVAR_CPLX : LP_TILE_KVAR_REAL;
+      else loop = cplx ? LP_TILE_CPLX : LP_TILE_REAL;
+      recs.push_back({loop, q});
+    }
     return 0;
   };
   for (int idx : ps.tile_masks) DNM_TRY(push_mask(idx, false, 0));
   for (size_t i = 0; i < ps.gather_masks.size(); ++i)
     DNM_TRY(push_mask(ps.gather_masks[i], true, ps.gather_src[i]));
-
-  d.nmasks = (int32_t)masks.size();
-  d.need_tile = (d.has_diag || !ps.tile_masks.empty()) ? 1 : 0;
-  out->h_masks = masks;
-  out->h_terms = terms;
-  if (!A.host_only) {
-    DNM_TRY(out->masks.upload(masks.data(), masks.size() * sizeof(DevMask)));
-    DNM_TRY(out->terms.upload(terms.data(), terms.size() * sizeof(DevTerm)));
+  for (int lp = 0; lp < LP_COUNT; ++lp) {
+    d.loop[lp] = (uint32_t)quads.size();
+    for (const Rec &r : recs) if (r.loop == lp) quads.push_back(r.q);
   }
-  d.masks = (const DevMask *)out->masks.p;
-  d.terms = (const DevTerm *)out->terms.p;
+  d.loop[LP_COUNT] = (uint32_t)quads.size();
+
+  d.nquads = (int32_t)quads.size();
+  d.need_tile = (d.has_diag || !ps.tile_masks.empty()) ? 1 : 0;
+  out->h_quads = quads;
+  if (!A.host_only) DNM_TRY(out->quads.upload(quads.data(), quads.size() * sizeof(DevQuad)));
+  d.quads = (const DevQuad *)out->quads.p;
   out->partner = ps.partner;
   return 0;
 }
@@ -455,7 +489,7 @@ int dnm_mat_get_diagonal(dnm_mat *A, double *diag_host, void *stream) {
   return dnm_memcpy_d2h(diag_host, A->diag.p, (size_t)A->M * sizeof(double), stream);
 }
 
-static bool use_glds(const dnm_mat *A) { return !(A->flags & DNM_MAT_NO_GLDS); }
+static bool use_glds(const dnm_mat *A) { return (A->flags & DNM_MAT_USE_GLDS) != 0; }
 
 int dnm_mat_mult_local(dnm_mat *A, const void *x, void *y, void *stream) {
   DNM_CHECK(A && x && y, "null argument");
@@ -535,25 +569,20 @@ int dnm_mat_plan_describe(const dnm_mat *A, char *buf, size_t buflen) {
 }
 
 int dnm_mat_export_pass(const dnm_mat *A, int remote, int idx, void *desc_out, size_t desc_bytes,
-                        void *masks_out, int max_masks, void *terms_out, int max_terms,
-                        int *nmasks, int *nterms) {
-  DNM_CHECK(A && nmasks && nterms, "null argument");
+                        void *quads_out, size_t quad_bytes, int max_quads, int *nquads) {
+  DNM_CHECK(A && nquads, "null argument");
   const auto &v = remote ? A->remote_passes : A->local_passes;
   DNM_CHECK(idx >= 0 && idx < (int)v.size(), "pass index out of range");
   const PassOnDevice &p = *v[idx];
-  *nmasks = (int)p.h_masks.size();
-  *nterms = (int)p.h_terms.size();
+  *nquads = (int)p.h_quads.size();
   if (desc_out) {
     DNM_CHECK(desc_bytes == sizeof(DevPass), "DevPass size mismatch (%zu vs %zu)", desc_bytes, sizeof(DevPass));
     memcpy(desc_out, &p.desc, sizeof(DevPass));
   }
-  if (masks_out) {
-    DNM_CHECK(max_masks >= *nmasks, "mask buffer too small");
-    memcpy(masks_out, p.h_masks.data(), p.h_masks.size() * sizeof(DevMask));
-  }
-  if (terms_out) {
-    DNM_CHECK(max_terms >= *nterms, "term buffer too small");
-    memcpy(terms_out, p.h_terms.data(), p.h_terms.size() * sizeof(DevTerm));
+  if (quads_out) {
+    DNM_CHECK(quad_bytes == sizeof(DevQuad), "DevQuad size mismatch (%zu vs %zu)", quad_bytes, sizeof(DevQuad));
+    DNM_CHECK(max_quads >= *nquads, "record buffer too small");
+    memcpy(quads_out, p.h_quads.data(), p.h_quads.size() * sizeof(DevQuad));
   }
   return 0;
 }

@@ -35,9 +35,8 @@ struct SubOwned {
 
 struct PassOnDevice {
   DevPass desc{};
-  std::vector<DevMask> h_masks;   // host copies (diagnostics / host-only handles)
-  std::vector<DevTerm> h_terms;
-  DevBuf masks, terms;
+  std::vector<DevQuad> h_quads;   // host copy (diagnostics / host-only handles)
+  DevBuf quads;
   int partner = -1;
 };
 

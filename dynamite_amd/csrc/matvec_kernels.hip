@@ -19,25 +19,29 @@ typedef double2 c128;
 #define GLOBAL_AS __attribute__((address_space(1)))
 #define LDS_AS __attribute__((address_space(3)))
 
+typedef double d2v __attribute__((ext_vector_type(2)));
+
+// y store that does not keep the line in this XCD's L2 (write-through, sc1)
+__device__ __forceinline__ void store_through(c128 *p, double re, double im) {
+  d2v v = {re, im};
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ c128 load_streaming(const c128 *p) {
+  d2v v = __builtin_nontemporal_load(reinterpret_cast<const d2v *>(p));
+  return make_double2(v.x, v.y);
+}
+
 // +-c by a parity bit: flips the IEEE sign bit (v_xor on the high dword)
 __device__ __forceinline__ double flip_sign(double c, uint32_t parity_bit) {
   int hi = __double2hiint(c) ^ (int)(parity_bit << 31);
   return __hiloint2double(hi, __double2loint(c));
 }
 
-// sum over terms [b,e) of coeff * (-1)^popcount(row & sign); `tt` is the row's
-// tile coordinate, `sbase` the row's bits outside the tile (wave-uniform).
-__device__ __forceinline__ double term_sum(const DevTerm *__restrict__ terms, uint32_t b,
-                                           uint32_t e, uint32_t tt, uint64_t sbase) {
-  double s = 0.0;
-  for (uint32_t t = b; t < e; ++t) {
-    const uint64_t sext = terms[t].sign_ext;
-    const uint32_t stile = terms[t].sign_tile;
-    const double c = terms[t].coeff;
-    uint32_t p = (uint32_t)(__popc(tt & stile) + __popcll(sbase & sext)) & 1u;
-    s += flip_sign(c, p);
-  }
-  return s;
+// signed amplitude of slot j of a record for this thread: coeff * (-1)^popcount(row & sign)
+// restricted to the thread-constant part of the row (tile coordinate `tt`, block part `sbase`)
+__device__ __forceinline__ double slot_amp(const DevQuad &q, int j, uint32_t tt, uint64_t sbase) {
+  uint32_t p = (uint32_t)(__popc(tt & q.sign_tile[j]) + __popcll(sbase & q.sign_ext[j])) & 1u;
+  return flip_sign(q.coeff[j], p);
 }
 
 template <int MAXS>
@@ -50,8 +54,91 @@ __device__ __forceinline__ uint32_t deposit(uint32_t v, int nseg, const int32_t 
   return r;
 }
 
+// One loop of the off-diagonal part: records [b, e) all share the compile-time
+// traits, so the accumulators stay in place and the body has no branches.
+//   KVAR  : some sign mask reaches this thread's k bits -> the coefficient is
+//           rebuilt per owned row from the per-thread slot amplitudes
+//   CPLX  : slots 2,3 (imaginary part) are populated
+//   GATHER: partner amplitudes come from global memory instead of the LDS tile
+template <int R, int LOGNT, bool KVAR, bool CPLX, bool GATHER>
+__device__ __forceinline__ void apply_records(const DevQuad *__restrict__ quads, uint32_t b, uint32_t e,
+                                              double (&ar)[R], double (&ai)[R], const c128 *tile,
+                                              const uint32_t (&rows)[R], const c128 *__restrict__ x,
+                                              const c128 *__restrict__ xr, uint32_t tid, uint64_t sbase) {
+  constexpr uint32_t NT = 1u << LOGNT;
+  for (uint32_t qi = b; qi < e; ++qi) {
+    const DevQuad &Q = quads[qi];
+    const double a0 = slot_amp(Q, 0, tid, sbase);
+    const double a1 = slot_amp(Q, 1, tid, sbase);
+    double a2 = 0.0, a3 = 0.0;
+    if constexpr (CPLX) {
+      a2 = slot_amp(Q, 2, tid, sbase);
+      a3 = slot_amp(Q, 3, tid, sbase);
+    }
+    c128 xv[R];
+    if constexpr (GATHER) {
+      const c128 *__restrict__ src = Q.src ? xr : x;
+      const uint32_t mloc = Q.mask_loc;
+      // rows whose coefficient vanishes for every owned amplitude fetch nothing
+      const bool live = KVAR || (a0 + a1 != 0.0) || (a2 + a3 != 0.0);
+      if (live) {
+#pragma unroll
+        for (int k = 0; k < R; ++k) xv[k] = src[rows[k] ^ mloc];
+      } else {
+#pragma unroll
+        for (int k = 0; k < R; ++k) xv[k] = make_double2(0.0, 0.0);
+      }
+    } else {
+      const uint32_t mt = Q.mask_tile;
+      const uint32_t p_lo = tid ^ (mt & (NT - 1u));
+      const uint32_t mk = mt >> LOGNT;
+#pragma unroll
+      for (int k = 0; k < R; ++k) xv[k] = tile[p_lo + (((uint32_t)k ^ mk) << LOGNT)];
+    }
+    if constexpr (!KVAR) {
+      const double cre = a0 + a1;
+#pragma unroll
+      for (int k = 0; k < R; ++k) {
+        ar[k] = fma(cre, xv[k].x, ar[k]);
+        ai[k] = fma(cre, xv[k].y, ai[k]);
+      }
+      if constexpr (CPLX) {
+        const double cim = a2 + a3;
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+          ar[k] = fma(-cim, xv[k].y, ar[k]);
+          ai[k] = fma(cim, xv[k].x, ai[k]);
+        }
+      }
+    } else {
+      const uint32_t s0 = Q.sign_tile[0] >> LOGNT, s1 = Q.sign_tile[1] >> LOGNT;
+      const uint32_t s2 = Q.sign_tile[2] >> LOGNT, s3 = Q.sign_tile[3] >> LOGNT;
+#pragma unroll
+      for (int k = 0; k < R; ++k) {
+        const double cre = flip_sign(a0, (uint32_t)__popc(k & s0) & 1u) + flip_sign(a1, (uint32_t)__popc(k & s1) & 1u);
+        ar[k] = fma(cre, xv[k].x, ar[k]);
+        ai[k] = fma(cre, xv[k].y, ai[k]);
+        if constexpr (CPLX) {
+          const double cim = flip_sign(a2, (uint32_t)__popc(k & s2) & 1u) + flip_sign(a3, (uint32_t)__popc(k & s3) & 1u);
+          ar[k] = fma(-cim, xv[k].y, ar[k]);
+          ai[k] = fma(cim, xv[k].x, ai[k]);
+        }
+      }
+    }
+  }
+}
+
+// waves per SIMD the launch bounds ask for: what LDS lets be resident, capped at 4
+constexpr int tile_waves_per_simd(int B, int LOGR) {
+  int nt = 1 << (B - LOGR);
+  int blocks = (160 * 1024) / (16 << B);
+  if (blocks < 1) blocks = 1;
+  int w = blocks * nt / 256;
+  return w < 1 ? 1 : (w > 4 ? 4 : w);
+}
+
 template <int B, int LOGR, bool GLDS>
-__global__ void __launch_bounds__(1 << (B - LOGR))
+__global__ void __launch_bounds__(1 << (B - LOGR), tile_waves_per_simd(B, LOGR))
 tile_pass_kernel(const DevPass P, const c128 *__restrict__ x, c128 *__restrict__ y,
                  const c128 *__restrict__ xr) {
   constexpr int R = 1 << LOGR;
@@ -61,7 +148,7 @@ tile_pass_kernel(const DevPass P, const c128 *__restrict__ x, c128 *__restrict__
   c128 *tile = reinterpret_cast<c128 *>(smem);
 
   const uint32_t tid = threadIdx.x;
-  const uint32_t base = deposit<MAXSEG>(blockIdx.x, P.nbseg, P.bseg_off, P.bseg_len, P.bseg_pos);
+  const uint32_t base = deposit<MAXBSEG>(blockIdx.x, P.nbseg, P.bseg_off, P.bseg_len, P.bseg_pos);
   const uint32_t dep_t = deposit<MAXSEG>(tid, P.nseg, P.seg_off, P.seg_len, P.seg_pos);
   const uint64_t sbase = P.sign_base | (uint64_t)base;
 
@@ -81,19 +168,33 @@ tile_pass_kernel(const DevPass P, const c128 *__restrict__ x, c128 *__restrict__
                                        (LDS_AS void *)(tile + (k * NT + (tid & ~63u))), 16, 0, 0);
   } else {
     c128 v[R];
+    if (P.cache_policy & 4) {
 #pragma unroll
-    for (int k = 0; k < R; ++k) v[k] = x[rows[k]];
+      for (int k = 0; k < R; ++k) v[k] = load_streaming(x + rows[k]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < R; ++k) v[k] = x[rows[k]];
+    }
 #pragma unroll
     for (int k = 0; k < R; ++k) tile[tid + k * NT] = v[k];
   }
 
   double ar[R], ai[R];
   if (P.accumulate) {
+    if (P.cache_policy & 2) {
 #pragma unroll
-    for (int k = 0; k < R; ++k) {
-      c128 v = y[rows[k]];
-      ar[k] = v.x;
-      ai[k] = v.y;
+      for (int k = 0; k < R; ++k) {
+        c128 v = load_streaming(y + rows[k]);
+        ar[k] = v.x;
+        ai[k] = v.y;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < R; ++k) {
+        c128 v = y[rows[k]];
+        ar[k] = v.x;
+        ai[k] = v.y;
+      }
     }
   } else {
 #pragma unroll
@@ -101,7 +202,7 @@ tile_pass_kernel(const DevPass P, const c128 *__restrict__ x, c128 *__restrict__
   }
   __syncthreads();
 
-  const DevTerm *__restrict__ terms = P.terms;
+  const DevQuad *__restrict__ quads = P.quads;
 
   // ---- diagonal: sum_t c_t chi_t(row).  Terms are bucketed by the part of
   // their sign mask that falls on this thread's k bits; a length-R
@@ -110,16 +211,14 @@ tile_pass_kernel(const DevPass P, const c128 *__restrict__ x, c128 *__restrict__
     double D[R];
 #pragma unroll
     for (int j = 0; j < R; ++j) D[j] = 0.0;
-    {
-      double dext = 0.0;
-      for (uint32_t t = P.dext_begin; t < P.dext_end; ++t) {
-        uint32_t p = (uint32_t)__popcll(sbase & terms[t].sign_ext) & 1u;
-        dext += flip_sign(terms[t].coeff, p);
-      }
-      D[0] = dext;
-    }
+    for (uint32_t q = P.dext_begin; q < P.dext_end; ++q)
+      D[0] += (slot_amp(quads[q], 0, 0u, sbase) + slot_amp(quads[q], 1, 0u, sbase)) +
+              (slot_amp(quads[q], 2, 0u, sbase) + slot_amp(quads[q], 3, 0u, sbase));
 #pragma unroll
-    for (int j = 0; j < R; ++j) D[j] += term_sum(terms, P.dbucket[j], P.dbucket[j + 1], tid, sbase);
+    for (int j = 0; j < R; ++j)
+      for (uint32_t q = P.dbucket[j]; q < P.dbucket[j + 1]; ++q)
+        D[j] += (slot_amp(quads[q], 0, tid, sbase) + slot_amp(quads[q], 1, tid, sbase)) +
+                (slot_amp(quads[q], 2, tid, sbase) + slot_amp(quads[q], 3, tid, sbase));
 #pragma unroll
     for (int h = 1; h < R; h <<= 1) {
 #pragma unroll
@@ -139,97 +238,27 @@ tile_pass_kernel(const DevPass P, const c128 *__restrict__ x, c128 *__restrict__
     }
   }
 
-  // ---- off-diagonal masks
-  const DevMask *__restrict__ masks = P.masks;
-  for (int m = 0; m < P.nmasks; ++m) {
-    const uint32_t flags = masks[m].flags;
-    const uint32_t reb = masks[m].re_begin, ree = masks[m].re_end;
-    const uint32_t imb = masks[m].im_begin, ime = masks[m].im_end;
-    const bool has_re = ree > reb, has_im = ime > imb;
-    if (flags & MF_GATHER) {
-      const c128 *__restrict__ src = masks[m].src ? xr : x;
-      const uint32_t mloc = masks[m].mask_loc;
-      if (!(flags & MF_KVAR)) {
-        const double cre = term_sum(terms, reb, ree, tid, sbase);
-        const double cim = term_sum(terms, imb, ime, tid, sbase);
-        if (cre != 0.0 || cim != 0.0) {   // lanes whose coefficient vanishes fetch nothing
-          c128 xv[R];
-#pragma unroll
-          for (int k = 0; k < R; ++k) xv[k] = src[rows[k] ^ mloc];
-#pragma unroll
-          for (int k = 0; k < R; ++k) {
-            ar[k] = fma(cre, xv[k].x, ar[k]);
-            ai[k] = fma(cre, xv[k].y, ai[k]);
-            ar[k] = fma(-cim, xv[k].y, ar[k]);
-            ai[k] = fma(cim, xv[k].x, ai[k]);
-          }
-        }
-      } else {
-#pragma unroll
-        for (int k = 0; k < R; ++k) {
-          const uint32_t tt = tid | ((uint32_t)k << LOGNT);
-          const double cre = term_sum(terms, reb, ree, tt, sbase);
-          const double cim = term_sum(terms, imb, ime, tt, sbase);
-          if (cre != 0.0 || cim != 0.0) {
-            c128 xv = src[rows[k] ^ mloc];
-            ar[k] = fma(cre, xv.x, ar[k]);
-            ai[k] = fma(cre, xv.y, ai[k]);
-            ar[k] = fma(-cim, xv.y, ar[k]);
-            ai[k] = fma(cim, xv.x, ai[k]);
-          }
-        }
-      }
-    } else {
-      const uint32_t mt = masks[m].mask_tile;
-      const uint32_t p_lo = tid ^ (mt & (NT - 1u));
-      const uint32_t mk = mt >> LOGNT;
-      if (!(flags & MF_KVAR)) {
-        if (has_re && !has_im) {
-          const double cre = term_sum(terms, reb, ree, tid, sbase);
-#pragma unroll
-          for (int k = 0; k < R; ++k) {
-            c128 xv = tile[p_lo + (((uint32_t)k ^ mk) << LOGNT)];
-            ar[k] = fma(cre, xv.x, ar[k]);
-            ai[k] = fma(cre, xv.y, ai[k]);
-          }
-        } else if (has_im && !has_re) {
-          const double cim = term_sum(terms, imb, ime, tid, sbase);
-#pragma unroll
-          for (int k = 0; k < R; ++k) {
-            c128 xv = tile[p_lo + (((uint32_t)k ^ mk) << LOGNT)];
-            ar[k] = fma(-cim, xv.y, ar[k]);
-            ai[k] = fma(cim, xv.x, ai[k]);
-          }
-        } else {
-          const double cre = term_sum(terms, reb, ree, tid, sbase);
-          const double cim = term_sum(terms, imb, ime, tid, sbase);
-#pragma unroll
-          for (int k = 0; k < R; ++k) {
-            c128 xv = tile[p_lo + (((uint32_t)k ^ mk) << LOGNT)];
-            ar[k] = fma(cre, xv.x, ar[k]);
-            ai[k] = fma(cre, xv.y, ai[k]);
-            ar[k] = fma(-cim, xv.y, ar[k]);
-            ai[k] = fma(cim, xv.x, ai[k]);
-          }
-        }
-      } else {
-#pragma unroll
-        for (int k = 0; k < R; ++k) {
-          const uint32_t tt = tid | ((uint32_t)k << LOGNT);
-          const double cre = term_sum(terms, reb, ree, tt, sbase);
-          const double cim = term_sum(terms, imb, ime, tt, sbase);
-          c128 xv = tile[p_lo + (((uint32_t)k ^ mk) << LOGNT)];
-          ar[k] = fma(cre, xv.x, ar[k]);
-          ai[k] = fma(cre, xv.y, ai[k]);
-          ar[k] = fma(-cim, xv.y, ar[k]);
-          ai[k] = fma(cim, xv.x, ai[k]);
-        }
-      }
-    }
+  // ---- off-diagonal masks, one branch-free loop per record class
+  if (P.cache_policy & 8) {   // gathers first: partner lines are freshest in L2 right after the loads
+    apply_records<R, LOGNT, false, true, true>(quads, P.loop[LP_GATHER], P.loop[LP_GATHER + 1], ar, ai, tile, rows, x, xr, tid, sbase);
+    apply_records<R, LOGNT, true, true, true>(quads, P.loop[LP_GATHER_KVAR], P.loop[LP_GATHER_KVAR + 1], ar, ai, tile, rows, x, xr, tid, sbase);
+  }
+  apply_records<R, LOGNT, false, false, false>(quads, P.loop[LP_TILE_REAL], P.loop[LP_TILE_REAL + 1], ar, ai, tile, rows, x, xr, tid, sbase);
+  apply_records<R, LOGNT, false, true, false>(quads, P.loop[LP_TILE_CPLX], P.loop[LP_TILE_CPLX + 1], ar, ai, tile, rows, x, xr, tid, sbase);
+  apply_records<R, LOGNT, true, false, false>(quads, P.loop[LP_TILE_KVAR_REAL], P.loop[LP_TILE_KVAR_REAL + 1], ar, ai, tile, rows, x, xr, tid, sbase);
+  apply_records<R, LOGNT, true, true, false>(quads, P.loop[LP_TILE_KVAR_CPLX], P.loop[LP_TILE_KVAR_CPLX + 1], ar, ai, tile, rows, x, xr, tid, sbase);
+  if (!(P.cache_policy & 8)) {
+    apply_records<R, LOGNT, false, true, true>(quads, P.loop[LP_GATHER], P.loop[LP_GATHER + 1], ar, ai, tile, rows, x, xr, tid, sbase);
+    apply_records<R, LOGNT, true, true, true>(quads, P.loop[LP_GATHER_KVAR], P.loop[LP_GATHER_KVAR + 1], ar, ai, tile, rows, x, xr, tid, sbase);
   }
 
+  if (P.cache_policy & 1) {
 #pragma unroll
-  for (int k = 0; k < R; ++k) y[rows[k]] = make_double2(ar[k], ai[k]);
+    for (int k = 0; k < R; ++k) store_through(y + rows[k], ar[k], ai[k]);
+  } else {
+#pragma unroll
+    for (int k = 0; k < R; ++k) y[rows[k]] = make_double2(ar[k], ai[k]);
+  }
 }
 
 // ---------------------------------------------------------------------------

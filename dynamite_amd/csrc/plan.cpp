@@ -20,6 +20,8 @@ PlanConfig plan_config_from_env() {
   c.logR = env_int("DNM_LOG_ROWS", c.logR);
   c.amin = env_int("DNM_AMIN", c.amin);
   c.mode = env_int("DNM_PLAN_MODE", c.mode);
+  c.gbits = env_int("DNM_GBITS", c.gbits);
+  c.cache_policy = env_int("DNM_CACHE_POLICY", c.cache_policy);
   return c;
 }
 
@@ -113,6 +115,58 @@ int make_plan(const OpForm &op, int rank, int nranks, const PlanConfig &cfg_in, 
       }
     ps.has_diag = has_diag;
     pl.local.push_back(ps);
+  } else if (cfg.mode == 2) {
+    // greedy cover by (LDS tile, XCD group) pairs: masks inside the tile come
+    // from LDS, masks that also touch the group bits are gathered (L2)
+    if (cfg.gbits < 0) cfg.gbits = 0;
+    if (cfg.gbits > 8) cfg.gbits = 8;
+    bool first = true;
+    while (!remaining.empty() || first) {
+      PassSpec best;
+      int best_score = -1;
+      auto consider = [&](PassSpec ps) {
+        const uint64_t tb = ps.tile_bits();
+        for (int glen = 0; glen <= cfg.gbits; ++glen) {
+          for (int g = 0; g + glen <= nl; ++g) {
+            const uint64_t gb = glen ? ((((uint64_t)1 << glen) - 1) << g) : 0;
+            if (gb & tb) continue;
+            int sc = 0;
+            for (int idx : remaining)
+              if ((op.masks[idx].mask & locmask & ~(tb | gb)) == 0) ++sc;
+            // prefer coverage, then fewer group bits
+            if (sc > best_score) {
+              best_score = sc;
+              best = ps;
+              best.glen = glen;
+              best.gpos = g;
+            }
+            if (glen == 0) break;
+          }
+        }
+      };
+      consider(tile_spec(B, B, 0));
+      for (int a = cfg.amin; a < B && a <= 6; ++a)
+        for (int w = a + 1; w + (B - a) <= nl; ++w) consider(tile_spec(B, a, w));
+      if (best_score <= 0 && !first) break;
+      const uint64_t tb = best.tile_bits();
+      const uint64_t gb = best.glen ? ((((uint64_t)1 << best.glen) - 1) << best.gpos) : 0;
+      std::vector<int> rest;
+      for (int idx : remaining) {
+        const uint64_t m = op.masks[idx].mask & locmask;
+        if ((m & ~tb) == 0) best.tile_masks.push_back(idx);
+        else if ((m & ~(tb | gb)) == 0) { best.gather_masks.push_back(idx); best.gather_src.push_back(0); }
+        else rest.push_back(idx);
+      }
+      best.has_diag = first && has_diag;
+      best.accumulate = !first;
+      pl.local.push_back(best);
+      remaining.swap(rest);
+      first = false;
+    }
+    for (int idx : remaining) {
+      pl.local[0].gather_masks.push_back(idx);
+      pl.local[0].gather_src.push_back(0);
+    }
   } else {
     // greedy cover by LDS tiles
     bool first = true;
@@ -181,6 +235,7 @@ std::string Plan::describe(const OpForm &op) const {
     os << kind << " pass " << i << ": segs";
     for (int j = 0; j < ps.nseg; ++j)
       os << " [" << ps.seg_pos[j] << "," << ps.seg_pos[j] + ps.seg_len[j] << ")";
+    if (ps.glen) os << " xcd-group [" << ps.gpos << "," << ps.gpos + ps.glen << ")";
     os << " diag=" << ps.has_diag << " acc=" << ps.accumulate << " tile_masks=" << ps.tile_masks.size()
        << " gather_masks=" << ps.gather_masks.size();
     if (ps.partner >= 0) os << " partner=" << ps.partner;

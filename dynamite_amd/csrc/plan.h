@@ -26,6 +26,7 @@
 namespace dnm {
 
 constexpr int MAXSEG = 4;
+constexpr int MAXBSEG = 8;    // block-id bit ranges
 constexpr int MAXSRC = 8;     // gather sources: 0 = x, 1.. = received partner vectors
 constexpr int MAXR = 16;
 
@@ -53,24 +54,23 @@ struct OpForm {
   std::vector<RowMask> masks;    // sorted by mask; masks[0].mask == 0 is the diagonal
 };
 
-// ---- device tables (plain structs, read with scalar loads) -----------------
-struct DevTerm {
-  uint64_t sign_ext;   // sign bits outside the tile (global positions, incl. rank bits)
-  uint32_t sign_tile;  // sign bits inside the tile, in tile coordinates
+// ---- device tables (plain structs, wave-uniform, read with scalar loads) ------
+// One record carries up to four terms that share a mask: slots 0,1 add to the
+// real part of the matrix element, slots 2,3 to the imaginary part (diagonal
+// records: all four slots are real terms).  Unused slots have coeff == 0.
+struct DevQuad {
+  uint32_t mask_tile;     // tile masks: flipped bits in tile coordinates
+  uint32_t mask_loc;      // gather masks: flipped bits of the local index (global positions)
+  uint32_t src;           // gather source slot (0 = x, 1 = partner vector)
   uint32_t pad;
-  double coeff;
+  uint32_t sign_tile[4];  // sign bits inside the tile, in tile coordinates
+  uint64_t sign_ext[4];   // sign bits outside the tile (global positions, incl. rank bits)
+  double coeff[4];
 };
 
-enum : uint32_t { MF_GATHER = 1, MF_KVAR = 2 };
-
-struct DevMask {
-  uint32_t mask_tile;   // tile masks: flipped bits in tile coordinates
-  uint32_t mask_loc;    // gather masks: flipped bits of the local index (global positions)
-  uint32_t re_begin, re_end;   // real terms   [re_begin, re_end)
-  uint32_t im_begin, im_end;   // imag terms   [im_begin, im_end)
-  uint32_t flags;
-  uint32_t src;         // gather source slot
-};
+// off-diagonal record ranges, in table order
+enum { LP_TILE_REAL = 0, LP_TILE_CPLX, LP_TILE_KVAR_REAL, LP_TILE_KVAR_CPLX, LP_GATHER, LP_GATHER_KVAR,
+       LP_COUNT };
 
 struct DevPass {
   // geometry: tile coordinate bits [seg_off[j], seg_off[j]+seg_len[j]) <-> local
@@ -78,17 +78,19 @@ struct DevPass {
   int32_t nseg;
   int32_t seg_off[MAXSEG], seg_len[MAXSEG], seg_pos[MAXSEG];
   int32_t nbseg;
-  int32_t bseg_off[MAXSEG], bseg_len[MAXSEG], bseg_pos[MAXSEG];
+  int32_t bseg_off[MAXBSEG], bseg_len[MAXBSEG], bseg_pos[MAXBSEG];
   uint64_t sign_base;   // constant OR-ed into the row for sign evaluation (rank bits)
   int32_t accumulate;   // 0: y = ..., 1: y += ...
   int32_t need_tile;    // 0: no tile mask and no diagonal -> skip the LDS stage
   int32_t has_diag;
-  // diagonal terms: tile-external ones, then per-k-bucket lists
+  int32_t cache_policy; // bit0: write y through L2 (sc1 stores, line not kept); bit1: non-temporal y loads;
+                        // bit2: non-temporal x tile loads; bit3: gathers before the LDS masks
+  // diagonal records: tile-external terms, then one list per k-bucket
   uint32_t dext_begin, dext_end;
   uint32_t dbucket[MAXR + 1];
-  int32_t nmasks;
-  const DevMask *masks;
-  const DevTerm *terms;
+  uint32_t loop[LP_COUNT + 1];   // record range of loop i: [loop[i], loop[i+1])
+  int32_t nquads;
+  const DevQuad *quads;
 };
 
 // ---- host-side description --------------------------------------------------
@@ -102,6 +104,10 @@ struct PassSpec {
   bool has_diag = false;
   bool accumulate = false;
   int partner = -1;                // remote pass: partner rank, else -1
+  // XCD group: local index bits [gpos, gpos+glen) are mapped to the block-id bits
+  // just above the XCD selector, so the workgroups resident on one XCD at a time
+  // span them and gathers across these bits are served by that XCD's L2.
+  int glen = 0, gpos = 0;
   uint64_t tile_bits() const {
     uint64_t m = 0;
     for (int j = 0; j < nseg; ++j) m |= (((uint64_t)1 << seg_len[j]) - 1) << seg_pos[j];
@@ -111,9 +117,12 @@ struct PassSpec {
 
 struct PlanConfig {
   int B = 12;          // log2 tile amplitudes
-  int logR = 4;        // log2 rows per thread
-  int amin = 3;        // smallest allowed low segment (2^amin * 16 B contiguous runs)
-  int mode = 0;        // 0: multi-pass LDS tiles; 1: single pass, everything else gathered
+  int logR = 3;        // log2 rows per thread
+  int amin = 4;        // smallest allowed low segment (2^amin * 16 B contiguous runs)
+  int mode = 2;        // 0: multi-pass LDS tiles; 1: single pass, everything else gathered;
+                       // 2: multi-pass LDS tiles + L2-served gathers over an XCD group
+  int gbits = 6;       // mode 2: bits per XCD group
+  int cache_policy = 0; // DevPass::cache_policy for every pass (experiments)
   int max_gather_span = 0;   // mode 0: masks the tiler cannot place are gathered
 };
 

@@ -88,7 +88,8 @@ typedef struct dnm_mat dnm_mat;   /* replaces PETSc Mat(MATSHELL) + shell_contex
 enum {
   DNM_MAT_DEFAULT      = 0,
   DNM_MAT_FORCE_GATHER = 1,   /* use only the generic row-gather kernel */
-  DNM_MAT_NO_GLDS      = 2,   /* stage LDS tiles through registers instead of global_load_lds */
+  DNM_MAT_USE_GLDS     = 2,   /* stage LDS tiles with global_load_lds DMA instead of through registers
+                                 (measured slower on MI355X for this access pattern; kept for A/B runs) */
   DNM_MAT_HOST_ONLY    = 4    /* build the plan and its tables on the host only (no device needed;
                                  diagnostics and CPU tests) -- such a handle cannot multiply */
 };
@@ -138,12 +139,11 @@ int dnm_mat_plan_describe(const dnm_mat *A, char *buf, size_t buflen);
 int dnm_mat_plan_launches(const dnm_mat *A, int *n);
 /* plan introspection (diagnostics, CPU tests of the planner): pass counts, and
  * a copy of one pass's tables (layouts: dynamite_amd/csrc/plan.h DevPass /
- * DevMask / DevTerm; pointers inside the copied DevPass are meaningless). */
+ * DevQuad; pointers inside the copied DevPass are meaningless). */
 int dnm_mat_plan_counts(const dnm_mat *A, int *n_local_passes, int *n_remote_passes, int *tiled,
                         int *B, int *logR, int *n_loc);
 int dnm_mat_export_pass(const dnm_mat *A, int remote, int idx, void *desc_out, size_t desc_bytes,
-                        void *masks_out, int max_masks, void *terms_out, int max_terms,
-                        int *nmasks, int *nterms);
+                        void *quads_out, size_t quad_bytes, int max_quads, int *nquads);
 
 /* --- partitioned multiply: replaces the VecScatterCreateToAll all-gather of
  * bcuda_template_2.cu:161-171 with an XOR-partner exchange. ---------------- */

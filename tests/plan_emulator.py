@@ -48,15 +48,13 @@ class HostMat:
 
     def _export(self, remote, idx):
         L = _lib.lib()
-        nm, nt = C.c_int(), C.c_int()
-        _lib.check(L.dnm_mat_export_pass(self.h, remote, idx, None, 0, None, 0, None, 0,
-                                         C.byref(nm), C.byref(nt)))
+        nq = C.c_int()
+        _lib.check(L.dnm_mat_export_pass(self.h, remote, idx, None, 0, None, 0, 0, C.byref(nq)))
         desc = _lib.DevPass()
-        masks = (_lib.DevMask * max(1, nm.value))()
-        terms = (_lib.DevTerm * max(1, nt.value))()
-        _lib.check(L.dnm_mat_export_pass(self.h, remote, idx, C.byref(desc), C.sizeof(desc), masks,
-                                         nm.value, terms, nt.value, C.byref(nm), C.byref(nt)))
-        return desc, [masks[i] for i in range(nm.value)], [terms[i] for i in range(nt.value)]
+        quads = (_lib.DevQuad * max(1, nq.value))()
+        _lib.check(L.dnm_mat_export_pass(self.h, remote, idx, C.byref(desc), C.sizeof(desc), quads,
+                                         C.sizeof(_lib.DevQuad), nq.value, C.byref(nq)))
+        return desc, [quads[i] for i in range(nq.value)]
 
     def __del__(self):
         try:
@@ -67,10 +65,11 @@ class HostMat:
 
 def run_pass(hm, p, x, y, xr=None):
     """Apply one exported pass to the local vector x (numpy), updating y."""
-    desc, masks, terms = p
+    desc, quads = p
     B, logR, n_loc = hm.B, hm.logR, hm.n_loc
     lognt = B - logR
     NT = 1 << lognt
+    R = 1 << logR
     n = 1 << n_loc
     rows = np.arange(n, dtype=np.uint64)
 
@@ -83,6 +82,9 @@ def run_pass(hm, p, x, y, xr=None):
     for j in range(desc.nbseg):
         blk_bits |= ((1 << desc.bseg_len[j]) - 1) << desc.bseg_pos[j]
     assert blk_bits & int(tile_bits) == 0 and (blk_bits | int(tile_bits)) == n - 1
+    assert sum(desc.bseg_len[j] for j in range(desc.nbseg)) == n_loc - B
+    offs = sorted((desc.bseg_off[j], desc.bseg_len[j]) for j in range(desc.nbseg))
+    assert all(offs[i][0] + offs[i][1] == offs[i + 1][0] for i in range(len(offs) - 1))
 
     def compress(v):
         out = np.zeros(v.shape, dtype=np.uint64)
@@ -105,47 +107,59 @@ def run_pass(hm, p, x, y, xr=None):
     tid = tt & np.uint64(NT - 1)
     kk = tt >> np.uint64(lognt)
 
-    def tsum(b, e, tcoord):
-        s = np.zeros(n, dtype=np.float64)
-        for t in range(b, e):
-            T = terms[t]
-            par = (_popc(tcoord & np.uint64(T.sign_tile)) + _popc(sbase & np.uint64(T.sign_ext))) & 1
-            s += np.where(par == 1, -T.coeff, T.coeff)
-        return s
+    def amp(Q, j, tcoord):
+        """slot_amp(): coeff * (-1)^(popc(tcoord & sign_tile) + popc(sbase & sign_ext))"""
+        par = (_popc(tcoord & np.uint64(Q.sign_tile[j])) + _popc(sbase & np.uint64(Q.sign_ext[j]))) & 1
+        return np.where(par == 1, -Q.coeff[j], Q.coeff[j])
+
+    def kflip(a, Q, j):
+        """the per-owned-row sign of a k-variant slot"""
+        par = _popc(kk & np.uint64(Q.sign_tile[j] >> lognt)) & 1
+        return np.where(par == 1, -a, a)
 
     acc = y.copy() if desc.accumulate else np.zeros(n, dtype=np.complex128)
+    zero = np.zeros(n, dtype=np.uint64)
 
     if desc.has_diag:
-        R = 1 << logR
-        for t in range(desc.dext_begin, desc.dext_end):
-            assert terms[t].sign_tile == 0
-        D = [tsum(desc.dbucket[j], desc.dbucket[j + 1], tid) for j in range(R)]
-        for j in range(R):
-            for t in range(desc.dbucket[j], desc.dbucket[j + 1]):
-                assert terms[t].sign_tile != 0 and (terms[t].sign_tile >> lognt) == j
-        D[0] = D[0] + tsum(desc.dext_begin, desc.dext_end, np.zeros(n, dtype=np.uint64))
-        # Walsh-Hadamard over the k bits
-        d = np.zeros(n, dtype=np.float64)
-        for j in range(R):
-            d += np.where(_popc(kk & np.uint64(j)) & 1, -D[j], D[j])
+        D = [np.zeros(n) for _ in range(R)]
+        for q in range(desc.dext_begin, desc.dext_end):
+            for j in range(4):
+                assert quads[q].sign_tile[j] == 0
+                D[0] = D[0] + amp(quads[q], j, zero)
+        for b in range(R):
+            for q in range(desc.dbucket[b], desc.dbucket[b + 1]):
+                for j in range(4):
+                    if quads[q].coeff[j] != 0:
+                        assert quads[q].sign_tile[j] != 0 and (quads[q].sign_tile[j] >> lognt) == b
+                    D[b] = D[b] + amp(quads[q], j, tid)
+        d = np.zeros(n, dtype=np.float64)      # Walsh-Hadamard over the k bits
+        for b in range(R):
+            d += np.where(_popc(kk & np.uint64(b)) & 1, -D[b], D[b])
         acc += d * x
 
-    for M in masks:
-        kvar = bool(M.flags & 2)
-        tc = tt if kvar else tid
-        if not kvar:
-            for t in list(range(M.re_begin, M.re_end)) + list(range(M.im_begin, M.im_end)):
-                assert (terms[t].sign_tile >> lognt) == 0
-        cre = tsum(M.re_begin, M.re_end, tc)
-        cim = tsum(M.im_begin, M.im_end, tc)
-        if M.flags & 1:   # gather
-            src = xr if M.src else x
-            xv = src[(rows ^ np.uint64(M.mask_loc)).astype(np.int64)]
-        else:
-            assert desc.need_tile
-            partner = base | deposit(tt ^ np.uint64(M.mask_tile))
-            xv = x[partner.astype(np.int64)]
-        acc += (cre + 1j * cim) * xv
+    for lp in range(_lib.LP_COUNT):
+        kvar = lp in (2, 3, 5)
+        cplx = lp in (1, 3, 4, 5)
+        gather = lp in (4, 5)
+        for q in range(desc.loop[lp], desc.loop[lp + 1]):
+            Q = quads[q]
+            if not cplx:
+                assert Q.coeff[2] == 0 and Q.coeff[3] == 0
+            a = [amp(Q, j, tid) for j in range(4)]
+            if kvar:
+                a = [kflip(a[j], Q, j) for j in range(4)]
+            else:
+                for j in range(4):
+                    assert Q.coeff[j] == 0 or (Q.sign_tile[j] >> lognt) == 0
+            cre, cim = a[0] + a[1], a[2] + a[3]
+            if gather:
+                src = xr if Q.src else x
+                xv = src[(rows ^ np.uint64(Q.mask_loc)).astype(np.int64)]
+            else:
+                assert desc.need_tile
+                partner = base | deposit(tt ^ np.uint64(Q.mask_tile))
+                xv = x[partner.astype(np.int64)]
+            acc += (cre + 1j * cim) * xv
     y[:] = acc
 
 

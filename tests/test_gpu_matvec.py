@@ -21,7 +21,8 @@ def tol_for(arrs, x):
     return 8 * len(arrs[0]) * EPS * max(1.0, np.abs(arrs[3]).max()) * max(1.0, np.abs(x).max())
 
 
-def cfg(monkeypatch, B=12, logR=4, mode=0, amin=3):
+def cfg(monkeypatch, B=12, logR=4, mode=0, amin=3, gbits=6):
+    monkeypatch.setenv("DNM_GBITS", str(gbits))
     monkeypatch.setenv("DNM_TILE_BITS", str(B))
     monkeypatch.setenv("DNM_LOG_ROWS", str(logR))
     monkeypatch.setenv("DNM_PLAN_MODE", str(mode))
@@ -32,7 +33,7 @@ GOLD = [('mbl', 6), ('mbl', 10), ('mbl', 12), ('heisenberg', 10), ('xxz', 10), (
         ('long_range', 8), ('localized', 10), ('syk', 5), ('xsum', 8)]
 
 
-@pytest.mark.parametrize("flags", [_lib.MAT_FORCE_GATHER, 0, _lib.MAT_NO_GLDS])
+@pytest.mark.parametrize("flags", [_lib.MAT_FORCE_GATHER, 0, _lib.MAT_USE_GLDS])
 @pytest.mark.parametrize("name,L", GOLD)
 def test_golden_full_space(monkeypatch, golden_full, name, L, flags):
     """y = Hx, ||H||_inf and the diagonal against vectors derived from the
@@ -99,11 +100,11 @@ def test_golden_subspaces(monkeypatch, golden_sub):
 
 
 CONFIGS = [(12, 4, 0, 3), (12, 3, 0, 3), (13, 4, 0, 3), (13, 3, 0, 4), (11, 4, 0, 3), (10, 3, 0, 5),
-           (12, 4, 1, 3), (13, 4, 1, 3)]
+           (12, 4, 1, 3), (13, 4, 1, 3), (12, 3, 2, 4), (13, 3, 2, 4), (11, 3, 2, 3), (10, 4, 2, 4)]
 
 
 @pytest.mark.parametrize("B,logR,mode,amin", CONFIGS)
-@pytest.mark.parametrize("name,L", [("mbl", 20), ("long_range", 16), ("syk", 8)])
+@pytest.mark.parametrize("name,L", [("mbl", 20), ("long_range", 16), ("syk", 7)])
 def test_tiled_vs_oracle(monkeypatch, name, L, B, logR, mode, amin):
     """Every tile configuration / plan mode against the CPU oracle, both tile
     staging paths."""
@@ -113,9 +114,9 @@ def test_tiled_vs_oracle(monkeypatch, name, L, B, logR, mode, amin):
     sub = Full(L=L)
     x = rand_state(1 << L, seed=L)
     ref = orc.matvec(orc_msc(H), orc_sub(sub), orc_sub(sub), x, nthreads=4)
-    for flags in (0, _lib.MAT_NO_GLDS):
+    for flags in (0, _lib.MAT_USE_GLDS):
         mat = shell(H, sub, flags=flags)
-        assert "tiled=1" in mat.describe()
+        assert ("tiled=1" in mat.describe()) == (L >= B)
         y = mult_numpy(mat, x)
         assert np.max(np.abs(y - ref)) <= tol_for(arrs, x), mat.describe()
         mat.destroy()

@@ -157,7 +157,8 @@ def _cfg(monkeypatch, B, logR, mode=0, amin=3):
     monkeypatch.setenv("DNM_AMIN", str(amin))
 
 
-@pytest.mark.parametrize("B,logR,mode", [(8, 2, 0), (10, 3, 0), (10, 4, 0), (12, 4, 0), (8, 2, 1), (10, 3, 1)])
+@pytest.mark.parametrize("B,logR,mode", [(8, 2, 0), (10, 3, 0), (10, 4, 0), (12, 4, 0), (8, 2, 1), (10, 3, 1),
+                                         (8, 2, 2), (10, 3, 2)])
 @pytest.mark.parametrize("name", ["mbl", "long_range", "ising", "syk"])
 def test_tiled_plan_full_space(monkeypatch, name, B, logR, mode):
     L = 13 if name != "syk" else 12
@@ -204,14 +205,14 @@ def test_plan_shape_chain_L30(monkeypatch):
         _, arrs = _orc_msc(H)
         sub = Full(L=30)
         hm = HostMat(*arrs, sub._c(), sub._c())
-        total = sum(len(m) for _, m, _ in hm.local)
-        assert total == len(arrs[0]) - 1          # all off-diagonal masks
+        total = sum(p[0].loop[_lib.LP_COUNT] - p[0].loop[0] for p in hm.local)
+        assert total == len(arrs[0]) - 1          # one record per off-diagonal mask
         assert sum(p[0].has_diag for p in hm.local) == 1
         assert hm.local[0][0].accumulate == 0 and all(p[0].accumulate for p in hm.local[1:])
         seen = set()
-        for desc, masks, _ in hm.local:
-            for M in masks:
-                assert not (M.flags & 1)
+        for desc, quads in hm.local:
+            assert desc.loop[4] == desc.loop[6]       # no gathers
+            for M in quads[desc.loop[0]:desc.loop[4]]:
                 # recover the global mask from its tile coordinates
                 g = 0
                 for j in range(desc.nseg):

@@ -20,13 +20,11 @@ def main():
     L = int(sys.argv[1])
     model = sys.argv[2] if len(sys.argv) > 2 else "mbl"
     cfgs = json.loads(os.environ.get("SWEEP", "null")) or [
-        dict(B=12, R=4, mode=0, amin=3, glds=1), dict(B=12, R=4, mode=0, amin=3, glds=0),
-        dict(B=12, R=3, mode=0, amin=3, glds=1), dict(B=13, R=4, mode=0, amin=3, glds=1),
-        dict(B=13, R=3, mode=0, amin=3, glds=1), dict(B=13, R=4, mode=0, amin=4, glds=1),
-        dict(B=12, R=4, mode=0, amin=4, glds=1), dict(B=12, R=4, mode=0, amin=6, glds=1),
-        dict(B=12, R=4, mode=1, amin=3, glds=1), dict(B=13, R=4, mode=1, amin=3, glds=1),
-        dict(B=12, R=3, mode=1, amin=3, glds=1), dict(B=11, R=4, mode=1, amin=3, glds=1),
-        dict(gather=1),
+        dict(B=12, R=3, mode=0, amin=3), dict(B=12, R=4, mode=0, amin=3), dict(B=12, R=3, mode=0, amin=3, glds=1),
+        dict(B=13, R=3, mode=0, amin=3), dict(B=13, R=4, mode=0, amin=3), dict(B=13, R=3, mode=0, amin=4),
+        dict(B=11, R=3, mode=0, amin=3), dict(B=12, R=3, mode=0, amin=4), dict(B=12, R=3, mode=0, amin=6),
+        dict(B=12, R=3, mode=1, amin=3), dict(B=13, R=3, mode=1, amin=3), dict(B=13, R=4, mode=1, amin=3),
+        dict(B=11, R=3, mode=1, amin=3), dict(gather=1),
     ]
     config._initialize()
     H = models.BY_NAME[model](L)
@@ -47,8 +45,10 @@ def main():
             os.environ["DNM_LOG_ROWS"] = str(c["R"])
             os.environ["DNM_PLAN_MODE"] = str(c["mode"])
             os.environ["DNM_AMIN"] = str(c["amin"])
-            if not c.get("glds", 1):
-                flags |= _lib.MAT_NO_GLDS
+            os.environ["DNM_GBITS"] = str(c.get("g", 5))
+            os.environ["DNM_CACHE_POLICY"] = str(c.get("cp", 0))
+            if c.get("glds", 0):
+                flags |= _lib.MAT_USE_GLDS
         mat = backend.build_mat(masks, offs, H.msc['signs'], H.msc['coeffs'], sub._to_c(), sub._to_c(),
                                 flags=flags)
         nl = C.c_int()
