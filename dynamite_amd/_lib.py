@@ -47,13 +47,15 @@ class SolverStats(C.Structure):
 MAXSEG, MAXBSEG, MAXR = 4, 8, 16
 
 
-LP_COUNT = 6
-LP_NAMES = ["tile_real", "tile_cplx", "tile_kvar_real", "tile_kvar_cplx", "gather", "gather_kvar"]
+LP_COUNT = 8
+LP_NAMES = ["tile_real_k0", "tile_real", "tile_cplx", "tile_kvar_real", "tile_kvar_cplx", "gather_real",
+            "gather_cplx", "gather_kvar"]
+LP_KVAR, LP_CPLX, LP_GATHER = (3, 4, 7), (2, 4, 6, 7), (5, 6, 7)
 
 
 class DevQuad(C.Structure):
     _fields_ = [("mask_tile", C.c_uint32), ("mask_loc", C.c_uint32), ("src", C.c_uint32),
-                ("pad", C.c_uint32), ("sign_tile", C.c_uint32 * 4), ("sign_ext", C.c_uint64 * 4),
+                ("nslots", C.c_uint32), ("sign_tile", C.c_uint32 * 4), ("sign_ext", C.c_uint64 * 4),
                 ("coeff", C.c_double * 4)]
 
 

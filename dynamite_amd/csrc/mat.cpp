@@ -229,7 +229,10 @@ static int build_pass(const dnm_mat &A, const PassSpec &ps, PassOnDevice *out) {
   auto push_diag_list = [&](const std::vector<RowTerm> &lst) {
     for (size_t i = 0; i < lst.size(); i += 4) {
       DevQuad q = empty_quad();
-      for (size_t j = i; j < lst.size() && j < i + 4; ++j) set_slot(q, (int)(j - i), lst[j]);
+      for (size_t j = i; j < lst.size() && j < i + 4; ++j) {
+        set_slot(q, (int)(j - i), lst[j]);
+        q.nslots = (uint32_t)(j - i + 1);
+      }
       quads.push_back(q);
     }
   };
@@ -285,9 +288,10 @@ static int build_pass(const dnm_mat &A, const PassSpec &ps, PassOnDevice *out) {
         cplx = true;
       }
       int loop;
-      if (gather) loop = kvar ? LP_GATHER_KVAR : LP_GATHER;
+      if (gather) loop = kvar ? LP_GATHER_KVAR : (cplx ? LP_GATHER_CPLX : LP_GATHER_REAL);
       else if (kvar) loop = cplx ? LP_TILE_KVAR_CPLX : LP_TILE_KVAR_REAL;
-      else loop = cplx ? LP_TILE_CPLX : LP_TILE_REAL;
+      else if (cplx) loop = LP_TILE_CPLX;
+      else loop = (q.mask_tile >> lognt) == 0 ? LP_TILE_REAL_K0 : LP_TILE_REAL;
       recs.push_back({loop, q});
     }
     return 0;

@@ -10,6 +10,9 @@
 //   arrive through the scalar cache.
 // gather_matvec_kernel -- any subspace pair (SpinConserve, Explicit, mixed):
 //   one thread per row with the index maps of subspace.h.
+#include <algorithm>
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace dnm {
@@ -60,7 +63,9 @@ __device__ __forceinline__ uint32_t deposit(uint32_t v, int nseg, const int32_t 
 //           rebuilt per owned row from the per-thread slot amplitudes
 //   CPLX  : slots 2,3 (imaginary part) are populated
 //   GATHER: partner amplitudes come from global memory instead of the LDS tile
-template <int R, int LOGNT, bool KVAR, bool CPLX, bool GATHER>
+//   K0    : (LDS, !KVAR) the mask does not touch the k bits: the R partner rows
+//           sit at fixed LDS offsets from one address
+template <int R, int LOGNT, bool KVAR, bool CPLX, bool GATHER, bool K0>
 __device__ __forceinline__ void apply_records(const DevQuad *__restrict__ quads, uint32_t b, uint32_t e,
                                               double (&ar)[R], double (&ai)[R], const c128 *tile,
                                               const uint32_t (&rows)[R], const c128 *__restrict__ x,
@@ -77,10 +82,12 @@ __device__ __forceinline__ void apply_records(const DevQuad *__restrict__ quads,
     }
     c128 xv[R];
     if constexpr (GATHER) {
+      // lanes whose coefficient vanishes for every owned amplitude fetch nothing;
+      // a wavefront with no live lane skips the record
+      const bool live = KVAR || (a0 + a1 != 0.0) || (CPLX && (a2 + a3 != 0.0));
+      if (!__any(live)) continue;
       const c128 *__restrict__ src = Q.src ? xr : x;
       const uint32_t mloc = Q.mask_loc;
-      // rows whose coefficient vanishes for every owned amplitude fetch nothing
-      const bool live = KVAR || (a0 + a1 != 0.0) || (a2 + a3 != 0.0);
       if (live) {
 #pragma unroll
         for (int k = 0; k < R; ++k) xv[k] = src[rows[k] ^ mloc];
@@ -88,6 +95,10 @@ __device__ __forceinline__ void apply_records(const DevQuad *__restrict__ quads,
 #pragma unroll
         for (int k = 0; k < R; ++k) xv[k] = make_double2(0.0, 0.0);
       }
+    } else if constexpr (K0) {
+      const c128 *p = tile + (tid ^ Q.mask_tile);
+#pragma unroll
+      for (int k = 0; k < R; ++k) xv[k] = p[k * NT];
     } else {
       const uint32_t mt = Q.mask_tile;
       const uint32_t p_lo = tid ^ (mt & (NT - 1u));
@@ -111,6 +122,7 @@ __device__ __forceinline__ void apply_records(const DevQuad *__restrict__ quads,
         }
       }
     } else {
+      // per-row sign of each slot: one scalar parity, one v_xor on the high dword
       const uint32_t s0 = Q.sign_tile[0] >> LOGNT, s1 = Q.sign_tile[1] >> LOGNT;
       const uint32_t s2 = Q.sign_tile[2] >> LOGNT, s3 = Q.sign_tile[3] >> LOGNT;
 #pragma unroll
@@ -125,6 +137,67 @@ __device__ __forceinline__ void apply_records(const DevQuad *__restrict__ quads,
         }
       }
     }
+  }
+}
+
+// Gather loops, software-pipelined two records deep: the loads of record q+1
+// are in flight while record q is consumed (the compiler's counted vmcnt keeps
+// the younger loads outstanding).  !KVAR classes only.
+template <int R, bool CPLX>
+struct GatherStage {
+  c128 xv[R];
+  double cre, cim;
+};
+
+template <int R, bool CPLX>
+__device__ __forceinline__ void gather_issue(GatherStage<R, CPLX> &st, const DevQuad &Q,
+                                             const uint32_t (&rows)[R], const c128 *__restrict__ x,
+                                             const c128 *__restrict__ xr, uint32_t tid, uint64_t sbase) {
+  st.cre = slot_amp(Q, 0, tid, sbase) + slot_amp(Q, 1, tid, sbase);
+  st.cim = 0.0;
+  if constexpr (CPLX) st.cim = slot_amp(Q, 2, tid, sbase) + slot_amp(Q, 3, tid, sbase);
+  const bool live = (st.cre != 0.0) || (CPLX && st.cim != 0.0);
+  const c128 *__restrict__ src = Q.src ? xr : x;
+  const uint32_t mloc = Q.mask_loc;
+  if (live) {
+#pragma unroll
+    for (int k = 0; k < R; ++k) st.xv[k] = src[rows[k] ^ mloc];
+  } else {
+#pragma unroll
+    for (int k = 0; k < R; ++k) st.xv[k] = make_double2(0.0, 0.0);
+  }
+}
+
+template <int R, bool CPLX>
+__device__ __forceinline__ void gather_consume(const GatherStage<R, CPLX> &st, double (&ar)[R], double (&ai)[R]) {
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    ar[k] = fma(st.cre, st.xv[k].x, ar[k]);
+    ai[k] = fma(st.cre, st.xv[k].y, ai[k]);
+    if constexpr (CPLX) {
+      ar[k] = fma(-st.cim, st.xv[k].y, ar[k]);
+      ai[k] = fma(st.cim, st.xv[k].x, ai[k]);
+    }
+  }
+}
+
+template <int R, bool CPLX>
+__device__ __forceinline__ void apply_gathers_pipelined(const DevQuad *__restrict__ quads, uint32_t b, uint32_t e,
+                                                        double (&ar)[R], double (&ai)[R],
+                                                        const uint32_t (&rows)[R], const c128 *__restrict__ x,
+                                                        const c128 *__restrict__ xr, uint32_t tid, uint64_t sbase) {
+  if constexpr (R > 4) return;   // would spill under the 128-VGPR budget
+  if (b >= e) return;
+  GatherStage<R, CPLX> s0, s1;
+  gather_issue<R, CPLX>(s0, quads[b], rows, x, xr, tid, sbase);
+  uint32_t qi = b;
+  while (true) {
+    if (qi + 1 < e) gather_issue<R, CPLX>(s1, quads[qi + 1], rows, x, xr, tid, sbase);
+    gather_consume<R, CPLX>(s0, ar, ai);
+    if (++qi >= e) break;
+    if (qi + 1 < e) gather_issue<R, CPLX>(s0, quads[qi + 1], rows, x, xr, tid, sbase);
+    gather_consume<R, CPLX>(s1, ar, ai);
+    if (++qi >= e) break;
   }
 }
 
@@ -200,25 +273,51 @@ tile_pass_kernel(const DevPass P, const c128 *__restrict__ x, c128 *__restrict__
 #pragma unroll
     for (int k = 0; k < R; ++k) ar[k] = ai[k] = 0.0;
   }
-  __syncthreads();
 
   const DevQuad *__restrict__ quads = P.quads;
 
-  // ---- diagonal: sum_t c_t chi_t(row).  Terms are bucketed by the part of
-  // their sign mask that falls on this thread's k bits; a length-R
-  // Walsh-Hadamard butterfly then yields all R row values at once.
+  // ---- diagonal, part 1 (before the barrier, under the tile loads): the terms
+  // whose sign mask lies outside the tile are the same for the whole workgroup.
+  // Each lane evaluates one term, a butterfly sums them across the wavefront.
+  double dext = 0.0;
+  if (P.has_diag) {
+    const uint32_t lane = tid & 63u;
+    const uint32_t nterm = (P.dext_end - P.dext_begin) * 4u;
+    for (uint32_t t0 = 0; t0 < nterm; t0 += 64u) {
+      const uint32_t t = t0 + lane;
+      double v = 0.0;
+      if (t < nterm) {
+        const DevQuad &Q = quads[P.dext_begin + (t >> 2)];
+        const uint32_t j = t & 3u;
+        const uint32_t p = (uint32_t)__popcll(sbase & Q.sign_ext[j]) & 1u;
+        v = flip_sign(Q.coeff[j], p);
+      }
+      dext += v;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) dext += __shfl_xor(dext, off, 64);
+  }
+  __syncthreads();
+
+  // ---- diagonal, part 2: sum_t c_t chi_t(row) for the terms that see the tile.
+  // Terms are bucketed by the part of their sign mask that falls on this
+  // thread's k bits; a length-R Walsh-Hadamard butterfly then yields all R row
+  // values at once.
   if (P.has_diag) {
     double D[R];
 #pragma unroll
     for (int j = 0; j < R; ++j) D[j] = 0.0;
-    for (uint32_t q = P.dext_begin; q < P.dext_end; ++q)
-      D[0] += (slot_amp(quads[q], 0, 0u, sbase) + slot_amp(quads[q], 1, 0u, sbase)) +
-              (slot_amp(quads[q], 2, 0u, sbase) + slot_amp(quads[q], 3, 0u, sbase));
+    D[0] = dext;
 #pragma unroll
     for (int j = 0; j < R; ++j)
-      for (uint32_t q = P.dbucket[j]; q < P.dbucket[j + 1]; ++q)
-        D[j] += (slot_amp(quads[q], 0, tid, sbase) + slot_amp(quads[q], 1, tid, sbase)) +
-                (slot_amp(quads[q], 2, tid, sbase) + slot_amp(quads[q], 3, tid, sbase));
+      for (uint32_t q = P.dbucket[j]; q < P.dbucket[j + 1]; ++q) {
+        const uint32_t ns = quads[q].nslots;
+        double v = slot_amp(quads[q], 0, tid, sbase);
+        if (ns > 1) v += slot_amp(quads[q], 1, tid, sbase);
+        if (ns > 2) v += slot_amp(quads[q], 2, tid, sbase);
+        if (ns > 3) v += slot_amp(quads[q], 3, tid, sbase);
+        D[j] += v;
+      }
 #pragma unroll
     for (int h = 1; h < R; h <<= 1) {
 #pragma unroll
@@ -239,18 +338,34 @@ tile_pass_kernel(const DevPass P, const c128 *__restrict__ x, c128 *__restrict__
   }
 
   // ---- off-diagonal masks, one branch-free loop per record class
+#define DNM_LOOP(LP, KV, CX, GA, KZ) \
+  apply_records<R, LOGNT, KV, CX, GA, KZ>(quads, P.loop[LP], P.loop[LP + 1], ar, ai, tile, rows, x, xr, tid, sbase)
   if (P.cache_policy & 8) {   // gathers first: partner lines are freshest in L2 right after the loads
-    apply_records<R, LOGNT, false, true, true>(quads, P.loop[LP_GATHER], P.loop[LP_GATHER + 1], ar, ai, tile, rows, x, xr, tid, sbase);
-    apply_records<R, LOGNT, true, true, true>(quads, P.loop[LP_GATHER_KVAR], P.loop[LP_GATHER_KVAR + 1], ar, ai, tile, rows, x, xr, tid, sbase);
+    if ((R <= 4) && (P.cache_policy & 16)) {
+      apply_gathers_pipelined<R, false>(quads, P.loop[LP_GATHER_REAL], P.loop[LP_GATHER_REAL + 1], ar, ai, rows, x, xr, tid, sbase);
+      apply_gathers_pipelined<R, true>(quads, P.loop[LP_GATHER_CPLX], P.loop[LP_GATHER_CPLX + 1], ar, ai, rows, x, xr, tid, sbase);
+    } else {
+      DNM_LOOP(LP_GATHER_REAL, false, false, true, false);
+      DNM_LOOP(LP_GATHER_CPLX, false, true, true, false);
+    }
+    DNM_LOOP(LP_GATHER_KVAR, true, true, true, false);
   }
-  apply_records<R, LOGNT, false, false, false>(quads, P.loop[LP_TILE_REAL], P.loop[LP_TILE_REAL + 1], ar, ai, tile, rows, x, xr, tid, sbase);
-  apply_records<R, LOGNT, false, true, false>(quads, P.loop[LP_TILE_CPLX], P.loop[LP_TILE_CPLX + 1], ar, ai, tile, rows, x, xr, tid, sbase);
-  apply_records<R, LOGNT, true, false, false>(quads, P.loop[LP_TILE_KVAR_REAL], P.loop[LP_TILE_KVAR_REAL + 1], ar, ai, tile, rows, x, xr, tid, sbase);
-  apply_records<R, LOGNT, true, true, false>(quads, P.loop[LP_TILE_KVAR_CPLX], P.loop[LP_TILE_KVAR_CPLX + 1], ar, ai, tile, rows, x, xr, tid, sbase);
+  DNM_LOOP(LP_TILE_REAL_K0, false, false, false, true);
+  DNM_LOOP(LP_TILE_REAL, false, false, false, false);
+  DNM_LOOP(LP_TILE_CPLX, false, true, false, false);
+  DNM_LOOP(LP_TILE_KVAR_REAL, true, false, false, false);
+  DNM_LOOP(LP_TILE_KVAR_CPLX, true, true, false, false);
   if (!(P.cache_policy & 8)) {
-    apply_records<R, LOGNT, false, true, true>(quads, P.loop[LP_GATHER], P.loop[LP_GATHER + 1], ar, ai, tile, rows, x, xr, tid, sbase);
-    apply_records<R, LOGNT, true, true, true>(quads, P.loop[LP_GATHER_KVAR], P.loop[LP_GATHER_KVAR + 1], ar, ai, tile, rows, x, xr, tid, sbase);
+    if ((R <= 4) && (P.cache_policy & 16)) {
+      apply_gathers_pipelined<R, false>(quads, P.loop[LP_GATHER_REAL], P.loop[LP_GATHER_REAL + 1], ar, ai, rows, x, xr, tid, sbase);
+      apply_gathers_pipelined<R, true>(quads, P.loop[LP_GATHER_CPLX], P.loop[LP_GATHER_CPLX + 1], ar, ai, rows, x, xr, tid, sbase);
+    } else {
+      DNM_LOOP(LP_GATHER_REAL, false, false, true, false);
+      DNM_LOOP(LP_GATHER_CPLX, false, true, true, false);
+    }
+    DNM_LOOP(LP_GATHER_KVAR, true, true, true, false);
   }
+#undef DNM_LOOP
 
   if (P.cache_policy & 1) {
 #pragma unroll
@@ -266,7 +381,13 @@ template <int B, int LOGR>
 static int launch_cfg(const DevPass &P, bool glds, int n_loc, const void *x, void *y,
                       const void *xr, hipStream_t st) {
   constexpr int NT = 1 << (B - LOGR);
-  const size_t lds = (size_t)16 << B;
+  // DNM_LDS_KB (experiments): request more LDS than the tile needs to cap the
+  // number of resident workgroups per CU
+  static const size_t lds_req = []() {
+    const char *e = getenv("DNM_LDS_KB");
+    return e ? (size_t)atoi(e) * 1024 : (size_t)0;
+  }();
+  const size_t lds = std::max((size_t)16 << B, lds_req);
   const unsigned grid = 1u << (n_loc - B);
   auto kg = tile_pass_kernel<B, LOGR, true>;
   auto kr = tile_pass_kernel<B, LOGR, false>;
@@ -286,6 +407,7 @@ static int launch_cfg(const DevPass &P, bool glds, int n_loc, const void *x, voi
 
 bool tile_config_supported(int B, int logR) {
   switch (B * 16 + logR) {
+    case 10 * 16 + 2: case 11 * 16 + 2: case 12 * 16 + 2:
     case 8 * 16 + 2: case 10 * 16 + 3: case 10 * 16 + 4: case 11 * 16 + 3: case 11 * 16 + 4:
     case 12 * 16 + 3: case 12 * 16 + 4: case 13 * 16 + 3: case 13 * 16 + 4:
       return true;
@@ -298,6 +420,9 @@ int launch_tile_pass(const DevPass &P, int B, int logR, bool glds, int n_loc, co
   DNM_CHECK(n_loc >= B, "tile larger than the local vector");
   switch (B * 16 + logR) {
     case 8 * 16 + 2: return launch_cfg<8, 2>(P, glds, n_loc, x, y, xr, st);
+    case 10 * 16 + 2: return launch_cfg<10, 2>(P, glds, n_loc, x, y, xr, st);
+    case 11 * 16 + 2: return launch_cfg<11, 2>(P, glds, n_loc, x, y, xr, st);
+    case 12 * 16 + 2: return launch_cfg<12, 2>(P, glds, n_loc, x, y, xr, st);
     case 10 * 16 + 3: return launch_cfg<10, 3>(P, glds, n_loc, x, y, xr, st);
     case 10 * 16 + 4: return launch_cfg<10, 4>(P, glds, n_loc, x, y, xr, st);
     case 11 * 16 + 3: return launch_cfg<11, 3>(P, glds, n_loc, x, y, xr, st);

@@ -133,8 +133,9 @@ int make_plan(const OpForm &op, int rank, int nranks, const PlanConfig &cfg_in, 
             int sc = 0;
             for (int idx : remaining)
               if ((op.masks[idx].mask & locmask & ~(tb | gb)) == 0) ++sc;
-            // prefer coverage, then fewer group bits
-            if (sc > best_score) {
+            // prefer coverage, then fewer group bits (DNM_PREFER_HIGH: later candidates win ties)
+            static const bool prefer_high = env_int("DNM_PREFER_HIGH", 0) != 0;
+            if (sc > best_score || (prefer_high && sc == best_score && sc > 0 && glen == best.glen)) {
               best_score = sc;
               best = ps;
               best.glen = glen;

@@ -62,15 +62,24 @@ struct DevQuad {
   uint32_t mask_tile;     // tile masks: flipped bits in tile coordinates
   uint32_t mask_loc;      // gather masks: flipped bits of the local index (global positions)
   uint32_t src;           // gather source slot (0 = x, 1 = partner vector)
-  uint32_t pad;
+  uint32_t nslots;        // diagonal records: populated slots (1..4)
   uint32_t sign_tile[4];  // sign bits inside the tile, in tile coordinates
   uint64_t sign_ext[4];   // sign bits outside the tile (global positions, incl. rank bits)
   double coeff[4];
 };
 
 // off-diagonal record ranges, in table order
-enum { LP_TILE_REAL = 0, LP_TILE_CPLX, LP_TILE_KVAR_REAL, LP_TILE_KVAR_CPLX, LP_GATHER, LP_GATHER_KVAR,
-       LP_COUNT };
+enum {
+  LP_TILE_REAL_K0 = 0,   // LDS, real coefficient, k-invariant, partner keeps this thread's k (immediate LDS offsets)
+  LP_TILE_REAL,          // LDS, real, k-invariant
+  LP_TILE_CPLX,          // LDS, complex, k-invariant
+  LP_TILE_KVAR_REAL,     // LDS, real, sign reaches the k bits
+  LP_TILE_KVAR_CPLX,
+  LP_GATHER_REAL,        // global gather, real, k-invariant
+  LP_GATHER_CPLX,
+  LP_GATHER_KVAR,
+  LP_COUNT
+};
 
 struct DevPass {
   // geometry: tile coordinate bits [seg_off[j], seg_off[j]+seg_len[j]) <-> local

@@ -123,12 +123,15 @@ def run_pass(hm, p, x, y, xr=None):
     if desc.has_diag:
         D = [np.zeros(n) for _ in range(R)]
         for q in range(desc.dext_begin, desc.dext_end):
+            assert 1 <= quads[q].nslots <= 4
             for j in range(4):
                 assert quads[q].sign_tile[j] == 0
+                assert j < quads[q].nslots or quads[q].coeff[j] == 0
                 D[0] = D[0] + amp(quads[q], j, zero)
         for b in range(R):
             for q in range(desc.dbucket[b], desc.dbucket[b + 1]):
-                for j in range(4):
+                assert 1 <= quads[q].nslots <= 4
+                for j in range(quads[q].nslots):
                     if quads[q].coeff[j] != 0:
                         assert quads[q].sign_tile[j] != 0 and (quads[q].sign_tile[j] >> lognt) == b
                     D[b] = D[b] + amp(quads[q], j, tid)
@@ -138,13 +141,15 @@ def run_pass(hm, p, x, y, xr=None):
         acc += d * x
 
     for lp in range(_lib.LP_COUNT):
-        kvar = lp in (2, 3, 5)
-        cplx = lp in (1, 3, 4, 5)
-        gather = lp in (4, 5)
+        kvar = lp in _lib.LP_KVAR
+        cplx = lp in _lib.LP_CPLX
+        gather = lp in _lib.LP_GATHER
         for q in range(desc.loop[lp], desc.loop[lp + 1]):
             Q = quads[q]
             if not cplx:
                 assert Q.coeff[2] == 0 and Q.coeff[3] == 0
+            if lp == 0:
+                assert (Q.mask_tile >> lognt) == 0
             a = [amp(Q, j, tid) for j in range(4)]
             if kvar:
                 a = [kflip(a[j], Q, j) for j in range(4)]

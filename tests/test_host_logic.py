@@ -211,8 +211,8 @@ def test_plan_shape_chain_L30(monkeypatch):
         assert hm.local[0][0].accumulate == 0 and all(p[0].accumulate for p in hm.local[1:])
         seen = set()
         for desc, quads in hm.local:
-            assert desc.loop[4] == desc.loop[6]       # no gathers
-            for M in quads[desc.loop[0]:desc.loop[4]]:
+            assert desc.loop[5] == desc.loop[8]       # no gathers
+            for M in quads[desc.loop[0]:desc.loop[5]]:
                 # recover the global mask from its tile coordinates
                 g = 0
                 for j in range(desc.nseg):
