@@ -26,7 +26,7 @@ HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 ALG_BYTES_PER_AMP = 32.0  # read x once + write y once
 
 
-def cpu_baseline(sample_L=24, reps=2):
+def cpu_baseline(sample_L=27, reps=3):
     """Oracle (C restatement of the reference's MatMult_CPU_Fast) timed on this
     box's host cores; a reported baseline, not the target."""
     import numpy as np

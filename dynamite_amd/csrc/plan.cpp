@@ -123,9 +123,12 @@ int make_plan(const OpForm &op, int rank, int nranks, const PlanConfig &cfg_in, 
     bool first = true;
     while (!remaining.empty() || first) {
       PassSpec best;
-      int best_score = -1;
+      int best_score = -1, best_tile = -1;
       auto consider = [&](PassSpec ps) {
         const uint64_t tb = ps.tile_bits();
+        int in_tile = 0;
+        for (int idx : remaining)
+          if ((op.masks[idx].mask & locmask & ~tb) == 0) ++in_tile;
         for (int glen = 0; glen <= cfg.gbits; ++glen) {
           for (int g = 0; g + glen <= nl; ++g) {
             const uint64_t gb = glen ? ((((uint64_t)1 << glen) - 1) << g) : 0;
@@ -133,10 +136,13 @@ int make_plan(const OpForm &op, int rank, int nranks, const PlanConfig &cfg_in, 
             int sc = 0;
             for (int idx : remaining)
               if ((op.masks[idx].mask & locmask & ~(tb | gb)) == 0) ++sc;
-            // prefer coverage, then fewer group bits (DNM_PREFER_HIGH: later candidates win ties)
-            static const bool prefer_high = env_int("DNM_PREFER_HIGH", 0) != 0;
-            if (sc > best_score || (prefer_high && sc == best_score && sc > 0 && glen == best.glen)) {
+            // most masks covered; then most of them from LDS (fewest gathers);
+            // then the smallest XCD group; earlier candidates win remaining ties
+            const bool better = sc > best_score || (sc == best_score && in_tile > best_tile) ||
+                                (sc == best_score && in_tile == best_tile && glen < best.glen);
+            if (better) {
               best_score = sc;
+              best_tile = in_tile;
               best = ps;
               best.glen = glen;
               best.gpos = g;
