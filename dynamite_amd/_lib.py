@@ -102,6 +102,9 @@ SIGNATURES = {
     "dnm_mat_plan_counts": (C.c_int, [vp] + [C.POINTER(C.c_int)] * 6),
     "dnm_mat_export_pass": (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_size_t, vp, C.c_size_t, C.c_int,
                                       C.POINTER(C.c_int)]),
+    "dnm_mat_ownership": (C.c_int, [vp, i64p, i64p]),
+    "dnm_mat_column_window": (C.c_int, [vp, i64p, i64p, vp]),
+    "dnm_mat_mult_window": (C.c_int, [vp, vp, C.c_int64, C.c_int64, vp, vp]),
     "dnm_mat_partners": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int32)]),
     "dnm_mat_mult_local": (C.c_int, [vp, vp, vp, vp]),
     "dnm_mat_mult_remote": (C.c_int, [vp, C.c_int32, vp, vp, vp]),

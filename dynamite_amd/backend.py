@@ -32,6 +32,57 @@ def _dist():
     return dist if (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) else None
 
 
+def split_ownership(size, world, rank):
+    """PetscSplitOwnership: size // world entries each, the first size % world ranks one more.
+    Returns (start, local_size)."""
+    q, rem = divmod(int(size), world)
+    return rank * q + min(rank, rem), q + (1 if rank < rem else 0)
+
+
+def window_exchange_ops(owned, windows, me):
+    """Who sends what to whom so that every rank holds the columns of its window.
+    owned[q] = (start, n) of rank q's block; windows[q] = inclusive (cmin, cmax) rank q reads.
+    Returns (recvs, sends): recvs = [(src, lo, hi)] global index ranges [lo, hi) to receive from
+    src, sends = [(dst, lo, hi)] ranges of MY block to send."""
+    recvs, sends = [], []
+    my0, myn = owned[me]
+    wlo, whi = windows[me][0], windows[me][1] + 1
+    for q, (q0, qn) in enumerate(owned):
+        if q == me:
+            continue
+        lo, hi = max(wlo, q0), min(whi, q0 + qn)
+        if lo < hi:
+            recvs.append((q, lo, hi))
+        qlo, qhi = windows[q][0], windows[q][1] + 1
+        lo, hi = max(qlo, my0), min(qhi, my0 + myn)
+        if lo < hi:
+            sends.append((q, lo, hi))
+    return recvs, sends
+
+
+def exchange_window(x_local, owned, windows, me, window_buf=None):
+    """Assemble this rank's column window from the owners' blocks with
+    torch.distributed send/recv (RCCL over xGMI on GPUs, gloo in CPU tests)."""
+    import torch
+    import torch.distributed as dist
+    wlo, whi = windows[me][0], windows[me][1] + 1
+    if window_buf is None or window_buf.numel() != whi - wlo:
+        window_buf = torch.empty(whi - wlo, dtype=x_local.dtype, device=x_local.device)
+    my0, myn = owned[me]
+    recvs, sends = window_exchange_ops(owned, windows, me)
+    ops = []
+    for q, lo, hi in sends:
+        ops.append(dist.P2POp(dist.isend, x_local[lo - my0:hi - my0], q))
+    for q, lo, hi in recvs:
+        ops.append(dist.P2POp(dist.irecv, window_buf[lo - wlo:hi - wlo], q))
+    reqs = dist.batch_isend_irecv(ops) if ops else []
+    a, b = max(wlo, my0), min(whi, my0 + myn)
+    window_buf[a - wlo:b - wlo].copy_(x_local[a - my0:b - my0])
+    for r in reqs:
+        r.wait()
+    return window_buf
+
+
 class Vec:
     """Distributed complex128 vector: this rank's block lives in ``self.array``
     (a 1-D torch tensor on the rank's GPU)."""
@@ -40,11 +91,7 @@ class Vec:
         import torch
         config._initialize()
         self.size = int(size)
-        ws, rk = config.world_size, config.rank
-        if ws > 1 and self.size % ws:
-            raise ValueError('vector size must be divisible by the number of ranks')
-        self.local_size = self.size // ws
-        self.start = rk * self.local_size
+        self.start, self.local_size = split_ownership(self.size, config.world_size, config.rank)
         if array is None:
             array = torch.zeros(self.local_size, dtype=torch.complex128, device=config.device)
         self.array = array
@@ -132,8 +179,18 @@ class Vec:
         if d is None:
             return self.local_numpy()
         import torch
-        parts = [torch.empty_like(self.array) for _ in range(config.world_size)]
-        d.all_gather(parts, self.array)
+        ws = config.world_size
+        sizes = [split_ownership(self.size, ws, q)[1] for q in range(ws)]
+        if len(set(sizes)) == 1:
+            parts = [torch.empty_like(self.array) for _ in range(ws)]
+            d.all_gather(parts, self.array)
+        else:   # uneven blocks: pad to the largest
+            mx = max(sizes)
+            pad = torch.zeros(mx, dtype=self.array.dtype, device=self.array.device)
+            pad[:self.local_size] = self.array
+            got = [torch.empty_like(pad) for _ in range(ws)]
+            d.all_gather(got, pad)
+            parts = [g[:n] for g, n in zip(got, sizes)]
         if not to_all and config.rank != 0:
             return None
         return torch.cat(parts).cpu().numpy()
@@ -158,6 +215,11 @@ class ShellMat:
         _lib.check(_lib.lib().dnm_mat_partners(handle, C.byref(npart), buf))
         self.partners = [int(buf[i]) for i in range(npart.value)]
         self._recv = {}
+        r0, ml = C.c_int64(), C.c_int64()
+        _lib.check(_lib.lib().dnm_mat_ownership(handle, C.byref(r0), C.byref(ml)))
+        self.row0 = r0.value
+        self._windows = None      # partitioned SpinConserve: every rank's column window
+        self._window_buf = None
 
     @property
     def handle(self):
@@ -183,6 +245,8 @@ class ShellMat:
         L = _lib.lib()
         if x.array.data_ptr() == y.array.data_ptr():
             raise ValueError('x and y must be different vectors')
+        if self.nranks > 1 and not self.partners and self._is_windowed():
+            return self._mult_window(x, y)
         if not self.partners:
             _lib.check(L.dnm_mat_mult(self.handle, x.ptr, y.ptr, _stream()))
             return
@@ -201,6 +265,28 @@ class ShellMat:
         for p in self.partners:
             _lib.check(L.dnm_mat_mult_remote(self.handle, p, C.c_void_p(self._recv[p].data_ptr()),
                                              y.ptr, _stream()))
+
+    def _is_windowed(self):
+        return 'SpinConserve kernel' in self.describe()
+
+    def column_window(self):
+        lo, hi = C.c_int64(), C.c_int64()
+        _lib.check(_lib.lib().dnm_mat_column_window(self.handle, C.byref(lo), C.byref(hi), _stream()))
+        return lo.value, hi.value
+
+    def _mult_window(self, x, y):
+        """Partitioned SpinConserve: gather the column window, then one kernel."""
+        import torch.distributed as dist
+        if self._windows is None:
+            mine = self.column_window()
+            allw = [None] * self.nranks
+            dist.all_gather_object(allw, mine)
+            self._windows = allw
+            self._owned = [split_ownership(self.N, self.nranks, q) for q in range(self.nranks)]
+        self._window_buf = exchange_window(x.array, self._owned, self._windows, self.rank, self._window_buf)
+        w0 = self._windows[self.rank][0]
+        _lib.check(_lib.lib().dnm_mat_mult_window(self.handle, C.c_void_p(self._window_buf.data_ptr()), w0,
+                                                  self._window_buf.numel(), y.ptr, _stream()))
 
     def norm(self, norm_type='infinity'):
         if norm_type not in ('infinity', None):

@@ -37,7 +37,7 @@ def _hooks(mat, keep):
             # wrap raw device pointers as Vec views without copying
             x = Vec.__new__(Vec); y = Vec.__new__(Vec)
             for v, p in ((x, xp), (y, yp)):
-                v.size, v.local_size, v.start = mat.N, n, config.rank * n
+                v.size, v.local_size, v.start = mat.N, n, mat.row0
                 v.array = _tensor_from_ptr(p, n)
             mat.mult(x, y)
             return 0

@@ -30,8 +30,26 @@ int launch_gather_matvec(const DevMsc &msc, const SubView &left, const SubView &
                          int64_t M, const double *diag, const void *x, void *y,
                          hipStream_t st);
 
+// Per-mask precomputation for the SpinConserve kernel.  fast != 0: the mask is a
+// bond of two adjacent spins (3 << lo) whose sign masks all lie inside the bond,
+// so the matrix element takes one of two values: `up` when the down spin moves
+// from site lo to lo+1 (ket has bit lo set), `dn` for the opposite hop.
+struct ScMask {
+  int32_t fast;
+  int32_t lo;
+  double up_re, up_im, dn_re, dn_im;
+};
+
+// SpinConserve(L,k) on both sides: columns by incremental colex rank (row + delta)
+// rows [row0, row0+M); xw holds columns [win_start, ...); y / diag are local.  colrange != null:
+// no multiply, only per-workgroup (min, max) of the columns read (2 * sc_num_blocks(M) int64).
+int sc_num_blocks(int64_t M);
+int launch_sc_matvec(const DevMsc &msc, const ScMask *scm, const SubView &sub, int64_t M, int64_t row0,
+                     int64_t win_start, const double *diag, const void *xw, void *y, int64_t *colrange,
+                     hipStream_t st);
+
 // diag[row] = sum over mask-0 terms (bcuda_template_1.cu:29-66)
-int launch_diag(const DevMsc &msc, const SubView &sub, int64_t M, double *diag, hipStream_t st);
+int launch_diag(const DevMsc &msc, const SubView &sub, int64_t M, int64_t row0, double *diag, hipStream_t st);
 
 // per-block maxima of the row sums of |H| (bcuda_template_2.cu:331-403);
 // block_max must hold norm_num_blocks(M) doubles.

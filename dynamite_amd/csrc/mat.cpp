@@ -407,17 +407,29 @@ int dnm_mat_create(int64_t nmasks, const int64_t *masks, const int64_t *mask_off
   A->N = A->right.host.dim;
   A->rank = part ? part->rank : 0;
   A->nranks = part ? part->nranks : 1;
-  DNM_CHECK(A->nranks >= 1 && (A->nranks & (A->nranks - 1)) == 0 && A->rank >= 0 && A->rank < A->nranks,
-            "bad partition (rank %d of %d): nranks must be a power of two", A->rank, A->nranks);
+  DNM_CHECK(A->nranks >= 1 && A->rank >= 0 && A->rank < A->nranks, "bad partition (rank %d of %d)", A->rank,
+            A->nranks);
 
   const int lt = A->left.host.type, rt = A->right.host.type;
   A->hypercube = (lt == rt) && (lt == DNM_FULL || lt == DNM_PARITY);
+  A->sc_pair = lt == DNM_SPIN_CONSERVE && rt == DNM_SPIN_CONSERVE && A->left.host.k == A->right.host.k &&
+               !(flags & DNM_MAT_FORCE_GATHER);
   if (A->nranks > 1) {
-    DNM_CHECK(A->hypercube, "partitioned multiply needs Full/Full or Parity/Parity subspaces");
-    DNM_CHECK(A->M % A->nranks == 0, "dimension not divisible by nranks");
+    DNM_CHECK(A->hypercube || A->sc_pair,
+              "partitioned multiply needs Full/Full, Parity/Parity or SpinConserve/SpinConserve subspaces");
+    if (A->hypercube) {
+      DNM_CHECK((A->nranks & (A->nranks - 1)) == 0, "nranks must be a power of two for Full/Parity");
+      DNM_CHECK(A->M % A->nranks == 0, "dimension not divisible by nranks");
+    }
   }
-  A->m_local = A->M / A->nranks;
-  A->n_local = A->N / A->nranks;
+  // PetscSplitOwnership: M / P rows each, the first M % P ranks one more
+  {
+    const int64_t q = A->M / A->nranks, rem = A->M % A->nranks;
+    A->m_local = q + (A->rank < rem ? 1 : 0);
+    A->row0 = (int64_t)A->rank * q + std::min<int64_t>(A->rank, rem);
+    A->n_local = A->m_local;
+    if (A->M != A->N) A->n_local = A->N / A->nranks;
+  }
 
   // tables for the generic kernels (always: norm and diagonal use them)
   if (!A->host_only) {
@@ -430,6 +442,34 @@ int dnm_mat_create(int64_t nmasks, const int64_t *masks, const int64_t *mask_off
   A->dmsc.mask_offsets = (const int64_t *)A->d_offsets.p;
   A->dmsc.signs = (const int64_t *)A->d_signs.p;
   A->dmsc.real_coeffs = (const double *)A->d_rcoeffs.p;
+  if (lt == DNM_SPIN_CONSERVE && rt == DNM_SPIN_CONSERVE) {
+    std::vector<ScMask> scm((size_t)nmasks);
+    for (int64_t mi = 0; mi < nmasks; ++mi) {
+      ScMask &e = scm[mi];
+      memset(&e, 0, sizeof(e));
+      const uint64_t mask = (uint64_t)A->masks[mi];
+      if (__builtin_popcountll(mask) != 2) continue;
+      const int lo = __builtin_ctzll(mask);
+      if (mask != (3ull << lo)) continue;
+      bool local = true;
+      for (int64_t t = A->mask_offsets[mi]; t < A->mask_offsets[mi + 1]; ++t)
+        if ((uint64_t)A->signs[t] & ~mask) local = false;
+      if (!local) continue;
+      e.fast = 1;
+      e.lo = lo;
+      for (int64_t t = A->mask_offsets[mi]; t < A->mask_offsets[mi + 1]; ++t) {
+        const uint64_t sg = (uint64_t)A->signs[t];
+        const double rc = A->real_coeffs[t];
+        const bool imag = parity64(mask & sg);
+        // column state (bra) carries the moved spin: bit lo+1 for an up hop, bit lo for a down hop
+        const double up = ((sg >> (lo + 1)) & 1) ? -rc : rc;
+        const double dn = ((sg >> lo) & 1) ? -rc : rc;
+        (imag ? e.up_im : e.up_re) += up;
+        (imag ? e.dn_im : e.dn_re) += dn;
+      }
+    }
+    DNM_TRY(A->d_scmasks.upload(scm.data(), scm.size() * sizeof(ScMask)));
+  }
   }
 
   if (A->hypercube) {
@@ -480,17 +520,17 @@ int dnm_mat_precompute_diagonal(dnm_mat *A, void *stream) {
   // only when the first mask is the identity (bpetsc_template_1.c:177-180) and
   // left == right (operators.py:627-629; the caller guarantees it)
   if (A->masks.empty() || A->masks[0] != 0) return 0;
-  DNM_CHECK(A->nranks == 1, "precomputed diagonal is not used by the partitioned multiply");
+  DNM_CHECK(A->nranks == 1 || A->sc_pair, "precomputed diagonal is not used by the partitioned tiled multiply");
   DNM_CHECK(A->M == A->N, "precompute_diagonal needs a square matrix");
-  DNM_TRY(A->diag.alloc((size_t)A->M * sizeof(double)));
-  DNM_TRY(launch_diag(A->dmsc, A->right.dev, A->M, (double *)A->diag.p, S(stream)));
+  DNM_TRY(A->diag.alloc((size_t)A->m_local * sizeof(double)));
+  DNM_TRY(launch_diag(A->dmsc, A->right.dev, A->m_local, A->row0, (double *)A->diag.p, S(stream)));
   A->have_diag = true;
   return 0;
 }
 
 int dnm_mat_get_diagonal(dnm_mat *A, double *diag_host, void *stream) {
   DNM_CHECK(A && A->have_diag, "no precomputed diagonal");
-  return dnm_memcpy_d2h(diag_host, A->diag.p, (size_t)A->M * sizeof(double), stream);
+  return dnm_memcpy_d2h(diag_host, A->diag.p, (size_t)A->m_local * sizeof(double), stream);
 }
 
 static bool use_glds(const dnm_mat *A) { return (A->flags & DNM_MAT_USE_GLDS) != 0; }
@@ -505,7 +545,10 @@ int dnm_mat_mult_local(dnm_mat *A, const void *x, void *y, void *stream) {
                                nullptr, S(stream)));
     return 0;
   }
-  DNM_CHECK(A->nranks == 1, "generic kernel cannot run partitioned");
+  DNM_CHECK(A->nranks == 1, "this subspace pair cannot run partitioned (use dnm_mat_mult_window)");
+  if (A->sc_pair)
+    return launch_sc_matvec(A->dmsc, (const ScMask *)A->d_scmasks.p, A->right.dev, A->M, 0, 0,
+                            A->have_diag ? (const double *)A->diag.p : nullptr, x, y, nullptr, S(stream));
   return launch_gather_matvec(A->dmsc, A->left.dev, A->right.dev, A->M,
                               A->have_diag ? (const double *)A->diag.p : nullptr, x, y, S(stream));
 }
@@ -515,6 +558,48 @@ int dnm_mat_mult(dnm_mat *A, const void *x, void *y, void *stream) {
   DNM_CHECK(A->remote_passes.empty(),
             "operator couples different ranks: use dnm_mat_mult_local + dnm_mat_mult_remote");
   return dnm_mat_mult_local(A, x, y, stream);
+}
+
+int dnm_mat_ownership(const dnm_mat *A, int64_t *row0, int64_t *m_local) {
+  DNM_CHECK(A, "null matrix");
+  if (row0) *row0 = A->row0;
+  if (m_local) *m_local = A->m_local;
+  return 0;
+}
+
+int dnm_mat_column_window(dnm_mat *A, int64_t *cmin, int64_t *cmax, void *stream) {
+  DNM_CHECK(A && cmin && cmax && !A->host_only, "bad argument");
+  DNM_CHECK(A->sc_pair, "column windows are defined for SpinConserve/SpinConserve matrices");
+  if (A->win_max < A->win_min) {
+    const int nb = sc_num_blocks(A->m_local);
+    DevBuf buf;
+    DNM_TRY(buf.alloc((size_t)nb * 2 * sizeof(int64_t)));
+    DNM_TRY(launch_sc_matvec(A->dmsc, (const ScMask *)A->d_scmasks.p, A->right.dev, A->m_local, A->row0, 0,
+                             nullptr, nullptr, nullptr, (int64_t *)buf.p, S(stream)));
+    std::vector<int64_t> h((size_t)nb * 2);
+    DNM_TRY(dnm_memcpy_d2h(h.data(), buf.p, h.size() * sizeof(int64_t), stream));
+    int64_t lo = A->row0, hi = A->row0 + A->m_local - 1;
+    for (int b = 0; b < nb; ++b) { lo = std::min(lo, h[2 * b]); hi = std::max(hi, h[2 * b + 1]); }
+    A->win_min = lo;
+    A->win_max = hi;
+  }
+  *cmin = A->win_min;
+  *cmax = A->win_max;
+  return 0;
+}
+
+int dnm_mat_mult_window(dnm_mat *A, const void *x_window, int64_t win_start, int64_t win_len, void *y_local,
+                        void *stream) {
+  DNM_CHECK(A && x_window && y_local && !A->host_only, "bad argument");
+  DNM_CHECK(A->sc_pair, "dnm_mat_mult_window needs a SpinConserve/SpinConserve matrix");
+  int64_t lo, hi;
+  DNM_TRY(dnm_mat_column_window(A, &lo, &hi, stream));
+  DNM_CHECK(win_start <= lo && win_start + win_len > hi,
+            "window [%lld, %lld) does not cover the columns [%lld, %lld] this rank reads", (long long)win_start,
+            (long long)(win_start + win_len), (long long)lo, (long long)hi);
+  return launch_sc_matvec(A->dmsc, (const ScMask *)A->d_scmasks.p, A->right.dev, A->m_local, A->row0, win_start,
+                          A->have_diag ? (const double *)A->diag.p : nullptr, x_window, y_local, nullptr,
+                          S(stream));
 }
 
 int dnm_mat_partners(const dnm_mat *A, int *n, int32_t *partner_ranks) {
@@ -545,7 +630,7 @@ int dnm_mat_norm_inf(dnm_mat *A, double *nrm, void *stream) {
   }
   const int nb = norm_num_blocks(A->m_local);
   DNM_TRY(A->scratch.alloc((size_t)nb * sizeof(double)));
-  DNM_TRY(launch_norm(A->dmsc, A->left.dev, A->right.dev, A->m_local, (int64_t)A->rank * A->m_local,
+  DNM_TRY(launch_norm(A->dmsc, A->left.dev, A->right.dev, A->m_local, A->row0,
                       (double *)A->scratch.p, S(stream)));
   std::vector<double> h(nb);
   DNM_TRY(dnm_memcpy_d2h(h.data(), A->scratch.p, (size_t)nb * sizeof(double), stream));
@@ -566,6 +651,8 @@ int dnm_mat_plan_describe(const dnm_mat *A, char *buf, size_t buflen) {
   DNM_CHECK(A && buf && buflen, "null argument");
   std::string s;
   if (A->hypercube) s = A->plan.describe(A->op);
+  else if (A->sc_pair)
+    s = "SpinConserve kernel (incremental colex rank)\n";
   else s = "generic row-gather kernel (non-hypercube subspace pair)\n";
   if (A->hypercube && !A->plan.use_tiled) s += "generic row-gather kernel in use\n";
   snprintf(buf, buflen, "%s", s.c_str());

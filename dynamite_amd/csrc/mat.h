@@ -48,6 +48,9 @@ struct dnm_mat {
   std::vector<double> real_coeffs;
   dnm::SubOwned left, right;
   int64_t M = 0, N = 0, m_local = 0, n_local = 0;
+  int64_t row0 = 0;               // first row / column this rank owns
+  bool sc_pair = false;           // SpinConserve(L,k) on both sides: incremental-rank kernel
+  int64_t win_min = 0, win_max = -1;   // partitioned SpinConserve: columns this rank reads (cached)
   int rank = 0, nranks = 1;
   int flags = 0;
   bool host_only = false;         // DNM_MAT_HOST_ONLY: plan and tables only, no device
@@ -60,6 +63,7 @@ struct dnm_mat {
   // generic-kernel tables
   dnm::DevBuf d_masks, d_offsets, d_signs, d_rcoeffs;
   dnm::DevMsc dmsc{};
+  dnm::DevBuf d_scmasks;          // SpinConserve kernel: per-mask precomputation (ScMask[nmasks])
 
   dnm::DevBuf diag;              // cached diagonal (double[m_local]) if precomputed
   bool have_diag = false;

@@ -11,6 +11,7 @@
 // gather_matvec_kernel -- any subspace pair (SpinConserve, Explicit, mixed):
 //   one thread per row with the index maps of subspace.h.
 #include <algorithm>
+#include <cstdint>
 #include <cstdlib>
 
 #include "kernels.h"
@@ -501,16 +502,178 @@ gather_matvec_kernel(const DevMsc msc, const SubView left_g, const SubView right
   y[row] = make_double2(accr, acci);
 }
 
+// ---------------------------------------------------------------------------
+// SpinConserve / SpinConserve (same L, k): consecutive basis indices are
+// consecutive k-subsets in colex order, so the column of a coupled state is
+// row + delta with delta a difference of a few binomials:
+//   rank(s) = sum_j C(p_j, j)  (bsubspace_impl.h:191-202); flipping the bits of
+//   `mask` keeps every one outside the mask's span [lo, hi] at its position and
+//   ordinal (the popcount is conserved), so only the ones inside the span
+//   contribute to rank(bra) - rank(ket).
+// For the two-bit bond masks that is one table lookup.  Lanes hold consecutive
+// rows, so x[row + delta] is a contiguous (shifted) run wherever the rows of a
+// wavefront share the bits above the bond -- long runs for the high bonds.
+// Each lane unranks its own row (L steps on the LDS-resident binomial table).
+// ---------------------------------------------------------------------------
+constexpr int SC_NT = 256;
+
+__global__ void __launch_bounds__(SC_NT)
+sc_matvec_kernel(const DevMsc msc, const ScMask *__restrict__ scm, const SubView sub_g, int64_t M,
+                 int64_t row0, int64_t win_start, const double *__restrict__ diag,
+                 const c128 *__restrict__ xw, c128 *__restrict__ y, int64_t *__restrict__ colrange) {
+  // rows [row0, row0 + M) of the matrix; xw holds columns [win_start, ...); y and diag are
+  // local (index row - row0).  colrange != nullptr: only record min/max column per workgroup.
+  __shared__ int64_t nck[NCK_LDS_MAX];
+  const int ld = sub_g.ld, kk = sub_g.k, Lb = sub_g.L;
+  const int ntab = (kk + 1) * ld;
+  const bool in_lds = ntab <= NCK_LDS_MAX;
+  if (in_lds) {
+    for (int i = threadIdx.x; i < ntab; i += SC_NT) nck[i] = sub_g.nchoosek[i];
+    __syncthreads();
+  }
+  const int64_t *__restrict__ tab = in_lds ? nck : sub_g.nchoosek;
+
+  const int64_t lrow = (int64_t)blockIdx.x * SC_NT + threadIdx.x;
+  const int64_t row = row0 + lrow;
+  const c128 *__restrict__ x = xw - win_start;
+  int64_t cmin = row, cmax = row;
+  const bool active = lrow < M;
+  if (!active && !colrange) return;
+  if (active) {
+  // I2S_SpinConserve (bsubspace_impl.h:210-228)
+  uint64_t ket = 0;
+  {
+    int64_t idx = row;
+    int k = kk;
+    for (int n = Lb; n > 0; --n) {
+      const int64_t here = (k > n - 1) ? 0 : tab[(int64_t)k * ld + (n - 1)];
+      ket <<= 1;
+      if (idx >= here) { idx -= here; --k; ket |= 1; }
+    }
+  }
+  double accr = 0.0, acci = 0.0;
+  int m0 = 0;
+  if (diag && !colrange) {
+    const c128 xs = x[row];
+    accr = diag[lrow] * xs.x;
+    acci = diag[lrow] * xs.y;
+    m0 = 1;
+  }
+  for (int m = m0; m < msc.nmasks; ++m) {
+    if (scm[m].fast) {
+      // adjacent bond with local signs: one lookup, two possible coefficients
+      const int lo = scm[m].lo;
+      const uint32_t pair = (uint32_t)(ket >> lo) & 3u;
+      if (pair == 1u || pair == 2u) {
+        const bool up = pair == 1u;
+        const int ord0 = __popcll(ket & ((1ull << lo) - 1));
+        const int64_t d = tab[(int64_t)ord0 * ld + lo];       // C(lo, ord0)
+        if (colrange) {
+          const int64_t c = up ? row + d : row - d;
+          cmin = c < cmin ? c : cmin;
+          cmax = c > cmax ? c : cmax;
+          continue;
+        }
+        const c128 xv = x[up ? row + d : row - d];
+        const double cre = up ? scm[m].up_re : scm[m].dn_re;
+        const double cim = up ? scm[m].up_im : scm[m].dn_im;
+        accr = fma(cre, xv.x, accr);
+        acci = fma(cre, xv.y, acci);
+        accr = fma(-cim, xv.y, accr);
+        acci = fma(cim, xv.x, acci);
+      }
+      continue;
+    }
+    const uint64_t mask = (uint64_t)msc.masks[m];
+    const uint64_t bra = ket ^ mask;
+    int64_t delta = 0;
+    if (mask) {
+      if (__popcll(bra) != kk) continue;             // leaves the subspace: projection semantics
+      const int lo = __ffsll((long long)mask) - 1;    // wave-uniform
+      const int hi = 63 - __clzll((long long)mask);
+      const uint64_t span = (hi >= 63 ? ~0ull : ((2ull << hi) - 1)) & ~((1ull << lo) - 1);
+      const int ord0 = __popcll(ket & ((1ull << lo) - 1));
+      uint64_t bb = bra & span, kb = ket & span;
+      int o = ord0;
+      while (bb) {
+        const int p = __ffsll((long long)bb) - 1;
+        ++o;
+        if (o <= p) delta += tab[(int64_t)o * ld + p];
+        bb &= bb - 1;
+      }
+      o = ord0;
+      while (kb) {
+        const int p = __ffsll((long long)kb) - 1;
+        ++o;
+        if (o <= p) delta -= tab[(int64_t)o * ld + p];
+        kb &= kb - 1;
+      }
+    }
+    if (colrange) {
+      const int64_t c = row + delta;
+      cmin = c < cmin ? c : cmin;
+      cmax = c > cmax ? c : cmax;
+      continue;
+    }
+    double cre = 0.0, cim = 0.0;
+    for (int64_t t = msc.mask_offsets[m]; t < msc.mask_offsets[m + 1]; ++t) {
+      const uint64_t sg = (uint64_t)msc.signs[t];
+      const double c = flip_sign(msc.real_coeffs[t], (uint32_t)__popcll(bra & sg) & 1u);
+      if (__popcll(mask & sg) & 1) cim += c; else cre += c;   // TERM_REAL
+    }
+    const c128 xv = x[row + delta];
+    accr = fma(cre, xv.x, accr);
+    acci = fma(cre, xv.y, acci);
+    accr = fma(-cim, xv.y, accr);
+    acci = fma(cim, xv.x, acci);
+  }
+  if (!colrange) y[lrow] = make_double2(accr, acci);
+  }  // active
+  if (colrange) {
+    // workgroup min / max of the columns touched (one-time sweep when a partition is set up)
+    __shared__ int64_t smin[SC_NT / 64], smax[SC_NT / 64];
+    if (!active) { cmin = INT64_MAX; cmax = INT64_MIN; }
+    for (int off = 32; off > 0; off >>= 1) {
+      const int64_t a = __shfl_xor(cmin, off, 64), b = __shfl_xor(cmax, off, 64);
+      cmin = a < cmin ? a : cmin;
+      cmax = b > cmax ? b : cmax;
+    }
+    if ((threadIdx.x & 63) == 0) { smin[threadIdx.x >> 6] = cmin; smax[threadIdx.x >> 6] = cmax; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int i = 1; i < SC_NT / 64; ++i) {
+        cmin = smin[i] < cmin ? smin[i] : cmin;
+        cmax = smax[i] > cmax ? smax[i] : cmax;
+      }
+      colrange[2 * (int64_t)blockIdx.x] = cmin;
+      colrange[2 * (int64_t)blockIdx.x + 1] = cmax;
+    }
+  }
+}
+
+int sc_num_blocks(int64_t M) { return (int)((M + SC_NT - 1) / SC_NT); }
+
+int launch_sc_matvec(const DevMsc &msc, const ScMask *scm, const SubView &sub, int64_t M, int64_t row0,
+                     int64_t win_start, const double *diag, const void *xw, void *y, int64_t *colrange,
+                     hipStream_t st) {
+  DNM_CHECK(M > 0 && (M + SC_NT - 1) / SC_NT < (int64_t)1 << 31, "row count out of range");
+  const dim3 grid((unsigned)sc_num_blocks(M)), blk(SC_NT);
+  hipLaunchKernelGGL(sc_matvec_kernel, grid, blk, 0, st, msc, scm, sub, M, row0, win_start, diag,
+                     (const c128 *)xw, (c128 *)y, colrange);
+  DNM_HIP(hipGetLastError());
+  return 0;
+}
+
 template <int T>
 __global__ void __launch_bounds__(GATHER_NT)
-diag_kernel(const DevMsc msc, const SubView sub_g, int64_t M, double *__restrict__ diag) {
+diag_kernel(const DevMsc msc, const SubView sub_g, int64_t M, int64_t row0, double *__restrict__ diag) {
   __shared__ int64_t nck[NCK_LDS_MAX];
   int used = 0;
   const SubView sub = stage_sub<T>(sub_g, nck, used);
   if (used) __syncthreads();
   const int64_t row = (int64_t)blockIdx.x * GATHER_NT + threadIdx.x;
   if (row >= M) return;
-  const int64_t st = Sub<T>::i2s(row, sub);
+  const int64_t st = Sub<T>::i2s(row0 + row, sub);
   double v = 0.0;
   for (int64_t t = 0; t < msc.mask_offsets[1]; ++t)
     v += flip_sign(msc.real_coeffs[t], (uint32_t)__popcll((uint64_t)(st & msc.signs[t])) & 1u);
@@ -591,13 +754,13 @@ int launch_gather_matvec(const DevMsc &msc, const SubView &left, const SubView &
   return 1;
 }
 
-int launch_diag(const DevMsc &msc, const SubView &sub, int64_t M, double *diag, hipStream_t st) {
+int launch_diag(const DevMsc &msc, const SubView &sub, int64_t M, int64_t row0, double *diag, hipStream_t st) {
   const dim3 grid((unsigned)((M + GATHER_NT - 1) / GATHER_NT)), blk(GATHER_NT);
   switch (sub.type) {
-    case DNM_FULL: hipLaunchKernelGGL((diag_kernel<DNM_FULL>), grid, blk, 0, st, msc, sub, M, diag); break;
-    case DNM_PARITY: hipLaunchKernelGGL((diag_kernel<DNM_PARITY>), grid, blk, 0, st, msc, sub, M, diag); break;
-    case DNM_SPIN_CONSERVE: hipLaunchKernelGGL((diag_kernel<DNM_SPIN_CONSERVE>), grid, blk, 0, st, msc, sub, M, diag); break;
-    case DNM_EXPLICIT: hipLaunchKernelGGL((diag_kernel<DNM_EXPLICIT>), grid, blk, 0, st, msc, sub, M, diag); break;
+    case DNM_FULL: hipLaunchKernelGGL((diag_kernel<DNM_FULL>), grid, blk, 0, st, msc, sub, M, row0, diag); break;
+    case DNM_PARITY: hipLaunchKernelGGL((diag_kernel<DNM_PARITY>), grid, blk, 0, st, msc, sub, M, row0, diag); break;
+    case DNM_SPIN_CONSERVE: hipLaunchKernelGGL((diag_kernel<DNM_SPIN_CONSERVE>), grid, blk, 0, st, msc, sub, M, row0, diag); break;
+    case DNM_EXPLICIT: hipLaunchKernelGGL((diag_kernel<DNM_EXPLICIT>), grid, blk, 0, st, msc, sub, M, row0, diag); break;
     default: set_error("bad subspace type"); return 1;
   }
   DNM_HIP(hipGetLastError());

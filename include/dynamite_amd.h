@@ -157,6 +157,18 @@ int dnm_mat_mult_local(dnm_mat *A, const void *x_local, void *y, void *stream);
 int dnm_mat_mult_remote(dnm_mat *A, int32_t partner_rank, const void *x_remote,
                         void *y, void *stream);
 
+/* --- partitioned SpinConserve/SpinConserve multiply ("column window") ------
+ * Basis indices are split as PetscSplitOwnership does (M / P rows each, the
+ * first M % P ranks one more; any P).  The columns a rank's rows read form a
+ * window around its own block (col = row +- binomials); the host
+ * assembles that window from the owners' blocks (send/recv) and multiplies. */
+int dnm_mat_ownership(const dnm_mat *A, int64_t *row0, int64_t *m_local);
+/* inclusive column range this rank's rows read; one device sweep, then cached */
+int dnm_mat_column_window(dnm_mat *A, int64_t *cmin, int64_t *cmax, void *stream);
+/* y_local = A[own rows, :] x, x_window holding columns [win_start, win_start + win_len) */
+int dnm_mat_mult_window(dnm_mat *A, const void *x_window, int64_t win_start, int64_t win_len,
+                        void *y_local, void *stream);
+
 /* ------------------------------------------------------------------ */
 /* vector kernels (what PETSc Vec / SLEPc BV supply to the Krylov     */
 /* loops; states.py:703-797 on the Python side)                       */

@@ -93,3 +93,38 @@ def test_partitioned_multiply_gloo(tmp_path, world):
     assert abs(complex(res["dot"][0], res["dot"][1]) - d) < 1e-9
     assert abs(res["mx"][0] - np.abs(ref).max()) < 1e-12
     assert len(res["partners"]) == (1 if world == 2 else 2)
+
+
+def _window_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dynamite_amd.backend import split_ownership, exchange_window
+    N = 1003
+    xg = torch.arange(N, dtype=torch.float64).to(torch.complex128) * (1 + 2j)
+    owned = [split_ownership(N, world, q) for q in range(world)]
+    # windows reach unevenly into the neighbours (and, for rank 0, across two ranks)
+    windows = []
+    for q, (s, n) in enumerate(owned):
+        lo = max(0, s - 17 * (q + 1))
+        hi = min(N - 1, s + n - 1 + (400 if q == 0 else 29))
+        windows.append((lo, hi))
+    s, n = owned[rank]
+    buf = exchange_window(xg[s:s + n].clone(), owned, windows, rank)
+    lo, hi = windows[rank]
+    ok = torch.equal(buf, xg[lo:hi + 1])
+    flag = torch.tensor([1.0 if ok else 0.0])
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        open(os.path.join(out_dir, "ok.txt"), "w").write(str(flag.item()))
+    dist.destroy_process_group()
+
+
+def test_window_exchange_gloo(tmp_path):
+    """The column-window exchange of the partitioned SpinConserve multiply (uneven
+    blocks, windows spanning several ranks) on 3 gloo ranks."""
+    import torch.multiprocessing as mp
+    mp.spawn(_window_worker, args=(3, _free_port(), str(tmp_path)), nprocs=3, join=True)
+    assert float(open(tmp_path / "ok.txt").read()) == 1.0

@@ -150,6 +150,37 @@ def test_spinconserve_generic_vs_oracle():
     assert abs(mat.norm() - orc.infnorm(orc_msc(H), orc_sub(sub), orc_sub(sub))) < 1e-12
 
 
+def test_spinconserve_kernel_general_masks():
+    """Sz-conserving operator with non-adjacent two-bit masks and four-bit masks:
+    exercises the span loop of the incremental colex rank."""
+    from dynamite_amd.operators import sigmax, sigmay, sigmaz, op_sum
+    L, k = 16, 7
+    rs = np.random.RandomState(3)
+    hop = lambda i, j: sigmax(i) * sigmax(j) + sigmay(i) * sigmay(j)
+    H = op_sum(float(rs.uniform(-1, 1)) * hop(i, j) for i in range(L) for j in range(i + 1, L) if (i + j) % 3 != 0)
+    H += op_sum(0.3 * hop(i, i + 2) * hop(i + 5, i + 9) for i in range(0, 6))
+    H += op_sum(float(rs.uniform(-1, 1)) * sigmaz(i) * sigmaz((i + 4) % L) for i in range(L))
+    H.L = L
+    arrs = marshal(H)
+    sub = SpinConserve(L, k)
+    x = rand_state(sub.get_dimension(), seed=2)
+    ref = orc.matvec(orc_msc(H), orc_sub(sub), orc_sub(sub), x)
+    for diag in (False, True):
+        mat = shell(H, sub)
+        assert "SpinConserve kernel" in mat.describe()
+        if diag:
+            mat.precompute_diagonal()
+        y = mult_numpy(mat, x)
+        assert np.max(np.abs(y - ref)) <= tol_for(arrs, x)
+        mat.destroy()
+    for kk in (0, 1, L - 1, L):       # edge sectors (dimension 1 or L)
+        sub = SpinConserve(L, kk)
+        x = rand_state(sub.get_dimension(), seed=kk)
+        ref = orc.matvec(orc_msc(H), orc_sub(sub), orc_sub(sub), x)
+        y = mult_numpy(shell(H, sub), x)
+        assert np.max(np.abs(y - ref)) <= tol_for(arrs, x)
+
+
 def test_partitioned_kernels_on_one_gpu(monkeypatch):
     """Rank-local and partner passes of a P-way partition, run rank by rank on
     this one GPU (exchange = slicing), must add up to the single-rank result."""
@@ -175,6 +206,53 @@ def test_partitioned_kernels_on_one_gpu(monkeypatch):
         y[r * nloc:(r + 1) * nloc] = yl.local_numpy()
         mat.destroy()
     assert np.max(np.abs(y - ref)) <= tol_for(arrs, x)
+
+
+@pytest.mark.parametrize("P", [2, 3, 5])
+def test_spinconserve_partitioned_windows(P):
+    """Partitioned SpinConserve multiply rank by rank on this one GPU: PETSc-style
+    ownership (uneven for P = 3, 5), the device-computed column window, and the
+    windowed kernel must reproduce the single-rank oracle result."""
+    L, k = 18, 9
+    H = models.mbl(L)
+    arrs = marshal(H)
+    sub = SpinConserve(L, k)
+    dim = sub.get_dimension()
+    x = rand_state(dim, seed=6)
+    ref = orc.matvec(orc_msc(H), orc_sub(sub), orc_sub(sub), x)
+    Lb = _lib.lib()
+    import ctypes as C
+    windows, owned = [], []
+    for diag in (False, True):
+        y = np.empty(dim, dtype=complex)
+        for r in range(P):
+            h = backend.create_mat(*arrs, sub._c(), sub._c(), flags=0, rank=r, nranks=P)
+            mat = backend.ShellMat(h, sub._c(), sub._c(), P, r)
+            start, n = backend.split_ownership(dim, P, r)
+            assert (mat.row0, mat.m_local) == (start, n)
+            lo, hi = mat.column_window()
+            assert 0 <= lo <= start and start + n - 1 <= hi < dim
+            if not diag:
+                windows.append((lo, hi)); owned.append((start, n))
+            if diag:
+                mat.precompute_diagonal()
+            xw = vec_from(x[lo:hi + 1])
+            yl = vec_from(np.zeros(n, dtype=complex))
+            _lib.check(Lb.dnm_mat_mult_window(mat.handle, xw.ptr, lo, hi - lo + 1, yl.ptr, None))
+            y[start:start + n] = yl.local_numpy()
+            with pytest.raises(_lib.BackendError):     # a window that misses needed columns is refused
+                if hi - lo + 1 > n:
+                    _lib.check(Lb.dnm_mat_mult_window(mat.handle, xw.ptr, lo + 1, hi - lo, yl.ptr, None))
+                else:
+                    raise _lib.BackendError("window equals block")
+            mat.destroy()
+        assert np.max(np.abs(y - ref)) <= tol_for(arrs, x)
+    # the exchange schedule is consistent: what q receives from r is what r sends to q
+    for me in range(P):
+        recvs, _ = backend.window_exchange_ops(owned, windows, me)
+        for src, lo, hi in recvs:
+            _, sends = backend.window_exchange_ops(owned, windows, src)
+            assert (me, lo, hi) in sends
 
 
 def _sample_rows_check(H, L, xv, yv, nsamp=64, seed=0):

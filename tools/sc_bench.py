@@ -1,0 +1,50 @@
+#!/usr/bin/env python
+"""Times the multiply in SpinConserve subspaces (generic row-gather kernel)."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+from dynamite_amd import models, backend, msc_tools  # noqa: E402
+from dynamite_amd.config import config  # noqa: E402
+from dynamite_amd.subspaces import SpinConserve  # noqa: E402
+
+
+def main():
+    config._initialize()
+    for L in [int(a) for a in sys.argv[1:]] or [24, 28, 32]:
+        k = L // 2
+        H = models.mbl(L)
+        H.reduce_msc()
+        masks, offs = msc_tools.get_mask_offsets(H.msc)
+        sub = SpinConserve(L, k)
+        dim = sub.get_dimension()
+        mat = backend.build_mat(masks, offs, H.msc['signs'], H.msc['coeffs'], sub._to_c(), sub._to_c())
+        x, y = backend.Vec(dim), backend.Vec(dim)
+        x.set_random(0)
+        for diag in (False, True):
+            if diag:
+                mat.precompute_diagonal()
+            for _ in range(2):
+                mat.mult(x, y)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            n = 5
+            for _ in range(n):
+                mat.mult(x, y)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / n
+            print("SpinConserve L=%d k=%d dim=%d diag_cached=%d: %.3f ms  %.2f Gamp/s  %.1f GB/s(32B)" %
+                  (L, k, dim, diag, ms, dim / ms / 1e6, 32.0 * dim / ms / 1e6), flush=True)
+        t0 = time.perf_counter()
+        nrm = mat.norm()
+        print("   norm %.6f in %.3f s" % (nrm, time.perf_counter() - t0), flush=True)
+        mat.destroy()
+
+
+if __name__ == "__main__":
+    main()
