@@ -90,6 +90,8 @@ SIGNATURES = {
     "dnm_mat_create": (C.c_int, [C.c_int64, i64p, i64p, i64p, f64p, C.POINTER(Subspace),
                                  C.POINTER(Subspace), C.c_int, C.c_int, C.POINTER(Partition),
                                  C.POINTER(vp)]),
+    "dnm_check_conserves": (C.c_int, [C.c_int64, i64p, i64p, i64p, f64p, C.POINTER(Subspace),
+                                      C.POINTER(Subspace), C.c_int, C.POINTER(C.c_int), vp]),
     "dnm_mat_destroy": (C.c_int, [vp]),
     "dnm_mat_sizes": (C.c_int, [vp, i64p, i64p, i64p, i64p]),
     "dnm_mat_precompute_diagonal": (C.c_int, [vp, vp]),
@@ -118,6 +120,7 @@ SIGNATURES = {
     "dnm_vec_mdot": (C.c_int, [vp, C.c_int64, C.c_int, vp, C.c_int64, f64p, vp]),
     "dnm_vec_maxpy": (C.c_int, [vp, vp, C.c_int64, C.c_int, C.c_int64, f64p, vp]),
     "dnm_vec_basis_update": (C.c_int, [vp, C.c_int64, C.c_int, C.c_int, C.c_int64, f64p, vp]),
+    "dnm_release_workspace": (C.c_int, []),
     "dnm_expm_multiply": (C.c_int, [vp, vp, vp, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_int,
                                     C.c_int, C.c_size_t, C.POINTER(Hooks), C.POINTER(SolverStats), vp]),
     "dnm_eigsolve": (C.c_int, [vp, C.c_int64, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int,

@@ -349,6 +349,21 @@ def build_mat(masks, mask_offsets, signs, coeffs, left_subspace, right_subspace,
     return ShellMat(h, lc, rc, config.world_size, config.rank)
 
 
+def check_conserves(masks, mask_offsets, signs, coeffs, left_subspace, right_subspace, xparity=False):
+    """Mirror of ``bpetsc.check_conserves`` (bpetsc.pyx:150-193), run on the GPU."""
+    config._initialize()
+    masks = np.ascontiguousarray(masks, dtype=np.int64)
+    mask_offsets = np.ascontiguousarray(mask_offsets, dtype=np.int64)
+    signs = np.ascontiguousarray(signs, dtype=np.int64)
+    coeffs = np.ascontiguousarray(coeffs, dtype=np.complex128)
+    res = C.c_int()
+    _lib.check(_lib.lib().dnm_check_conserves(
+        masks.size, _lib.p64(masks), _lib.p64(mask_offsets), _lib.p64(signs),
+        coeffs.view(np.float64).ctypes.data_as(_lib.f64p), C.byref(left_subspace['data']),
+        C.byref(right_subspace['data']), int(bool(xparity)), C.byref(res), _stream()))
+    return bool(res.value)
+
+
 def precompute_diagonal(mat):
     """Mirror of ``bpetsc.precompute_diagonal`` (bpetsc.pyx:141-147)."""
     mat.precompute_diagonal()

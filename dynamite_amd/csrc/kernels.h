@@ -57,6 +57,10 @@ int norm_num_blocks(int64_t M);
 int launch_norm(const DevMsc &msc, const SubView &left, const SubView &right, int64_t M,
                 int64_t row0, double *block_max, hipStream_t st);
 
+// CheckConserves: *bad is set to 1 if some column of the right subspace is mapped outside the left one
+int launch_conserves(const DevMsc &msc, const double *coeffs_im, const SubView &left, const SubView &right,
+                     int64_t N, int *bad, hipStream_t st);
+
 // ---- vector kernels ---------------------------------------------------------
 int vk_set(void *x, int64_t n, double re, double im, hipStream_t st);
 int vk_scale(void *x, int64_t n, double re, double im, hipStream_t st);

@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <cmath>
 #include <complex>
+#include <cstdlib>
 #include <vector>
 
 #include "vec_api.h"
@@ -240,6 +241,70 @@ struct Ops {
   }
 };
 
+// Simon's omega-recurrence: a running estimate of |v_{j+1}^H v_k| for a Lanczos
+// process without re-orthogonalisation.  While every estimate stays below
+// sqrt(eps) the three-term recurrence is kept (5 vector passes per step);
+// when one crosses it the new vector and its successor are orthogonalised
+// against the whole basis (partial re-orthogonalisation, Simon 1984).
+struct LanczosMonitor {
+  std::vector<double> alpha, beta;      // alpha[j]; beta[j] = ||r_{j-1}|| (beta[0] = 0)
+  std::vector<double> wprev, wcur;      // omega_{j-1,.}, omega_{j,.}
+  double eps1 = 0, thresh = 0;
+  bool force_next = false;
+  int reorths = 0;
+  void reset(int m, double n_global) {
+    alpha.assign(m + 2, 0.0);
+    beta.assign(m + 2, 0.0);
+    wprev.assign(m + 2, 0.0);
+    wcur.assign(m + 2, 0.0);
+    wcur[0] = 1.0;
+    const double eps = 2.220446049250313e-16;
+    eps1 = eps * std::sqrt(n_global) / 2.0;
+    if (eps1 > 1e-11) eps1 = 1e-11;
+    thresh = std::sqrt(eps);
+    force_next = false;
+  }
+  // step j produced alpha_j and beta_{j+1}; returns true when v_{j+1} needs a full pass
+  bool update(int j, double a_j, double b_next) {
+    alpha[j] = a_j;
+    beta[j + 1] = b_next;
+    std::vector<double> wnew(wcur.size(), 0.0);
+    double worst = 0.0;
+    if (b_next > 0) {
+      for (int k = 0; k < j; ++k) {
+        double v = beta[k + 1] * wcur[k + 1] + (alpha[k] - a_j) * wcur[k] - beta[j] * wprev[k];
+        if (k > 0) v += beta[k] * wcur[k - 1];
+        v = (v + (v >= 0 ? eps1 : -eps1)) / b_next;
+        wnew[k] = v;
+        worst = std::max(worst, std::fabs(v));
+      }
+    }
+    if (j >= 0) wnew[j] = eps1;
+    wnew[j + 1] = 1.0;
+    wprev.swap(wcur);
+    wcur.swap(wnew);
+    const bool need = force_next || worst > thresh;
+    if (need) {
+      force_next = !force_next;          // the successor of a re-orthogonalised vector gets a pass too
+      for (int k = 0; k <= j; ++k) wcur[k] = eps1;
+      ++reorths;
+    }
+    return need;
+  }
+};
+
+// Krylov basis workspace, kept between solves (hipMalloc/hipFree of tens of GiB per
+// call costs more than a solve); dnm_release_workspace() returns it.
+static DevBuf g_basis;
+static int basis_workspace(size_t bytes, void **p) {
+  if (g_basis.bytes < bytes) {
+    g_basis.release();
+    DNM_TRY(g_basis.alloc(bytes));
+  }
+  *p = g_basis.p;
+  return 0;
+}
+
 static char *vecptr(void *base, int64_t n, int j) { return (char *)base + (size_t)j * (size_t)n * 16; }
 
 static double round2(double t) {
@@ -255,6 +320,11 @@ using namespace dnm;
 
 extern "C" {
 
+int dnm_release_workspace(void) {
+  g_basis.release();
+  return 0;
+}
+
 int dnm_expm_multiply(dnm_mat *A, const void *x, void *y, int64_t n_local, double scale_re,
                       double scale_im, double tol, int ncv, int max_its, size_t work_limit_bytes,
                       const dnm_hooks *hooks, dnm_solver_stats *stats, void *stream) {
@@ -268,7 +338,8 @@ int dnm_expm_multiply(dnm_mat *A, const void *x, void *y, int64_t n_local, doubl
   int m = ncv > 0 ? ncv : 30;
   if ((int64_t)m > Nglob) m = (int)Nglob;
   if (work_limit_bytes) {
-    int64_t fit = (int64_t)(work_limit_bytes / ((size_t)n_local * 16)) - 2;
+    // the limit is the caller's view of free device memory; the cached workspace is ours to reuse
+    int64_t fit = (int64_t)((work_limit_bytes + g_basis.bytes) / ((size_t)n_local * 16)) - 2;
     if (fit < 2) fit = 2;
     if (m > fit) m = (int)fit;
   }
@@ -289,9 +360,8 @@ int dnm_expm_multiply(dnm_mat *A, const void *x, void *y, int64_t n_local, doubl
   DNM_TRY(ops.norm(y, &beta));
   if (beta == 0.0 || anorm == 0.0) { stats->reason = DNM_CONVERGED_TOL; return 0; }
 
-  DevBuf basis;   // v_0..v_m plus one scratch vector
-  DNM_TRY(basis.alloc((size_t)(m + 2) * (size_t)n_local * 16));
-  void *V = basis.p;
+  void *V = nullptr;   // v_0..v_m plus one scratch vector
+  DNM_TRY(basis_workspace((size_t)(m + 2) * (size_t)n_local * 16, &V));
   void *tmpv = vecptr(V, n_local, m + 1);
 
   const double eps = 2.220446049250313e-16;
@@ -306,6 +376,11 @@ int dnm_expm_multiply(dnm_mat *A, const void *x, void *y, int64_t n_local, doubl
   const int mh = m + 2;
   std::vector<zc> H, F, Hs;
   int nstep = 0;
+  // DNM_EXPM_ORTHO=full: orthogonalise every Krylov vector against the whole basis (what
+  // SLEPc's BV does); default: Lanczos with partial re-orthogonalisation
+  const char *oenv = getenv("DNM_EXPM_ORTHO");
+  const bool use_pro = !(oenv && oenv[0] == 'f');
+  LanczosMonitor mon;
   while (t_now < t_out) {
     if (nstep >= max_its) {
       stats->reason = DNM_DIVERGED_ITS;
@@ -320,11 +395,31 @@ int dnm_expm_multiply(dnm_mat *A, const void *x, void *y, int64_t n_local, doubl
     int mb = m, k1 = 2;
     double avnorm = 0;
     std::vector<zc> h;
+    if (use_pro) mon.reset(m, (double)Nglob);
     for (int j = 0; j < m; ++j) {
       void *p = vecptr(V, n_local, j + 1);
       DNM_TRY(ops.mult(vecptr(V, n_local, j), p));
       double hn = 0;
-      DNM_TRY(ops.orthogonalize(p, V, j + 1, h, &hn));
+      if (use_pro) {
+        // three-term step: remove the components along v_{j-1}, v_j only
+        const int lo = j > 0 ? j - 1 : 0, nvl = j + 1 - lo;
+        std::vector<zc> h1, neg(nvl);
+        h.assign(j + 1, zc(0));
+        DNM_TRY(ops.mdot(vecptr(V, n_local, lo), nvl, p, h1));
+        for (int i = 0; i < nvl; ++i) { neg[i] = -h1[i]; h[lo + i] = h1[i]; }
+        DNM_TRY(ops.maxpy(p, vecptr(V, n_local, lo), nvl, neg));
+        DNM_TRY(ops.norm(p, &hn));
+        if (mon.update(j, h[j].real(), hn)) {
+          std::vector<zc> hf, negf(j + 1);
+          DNM_TRY(ops.mdot(V, j + 1, p, hf));
+          for (int i = 0; i <= j; ++i) { negf[i] = -hf[i]; h[i] += hf[i]; }
+          DNM_TRY(ops.maxpy(p, V, j + 1, negf));
+          DNM_TRY(ops.norm(p, &hn));
+          mon.beta[j + 1] = hn;
+        }
+      } else {
+        DNM_TRY(ops.orthogonalize(p, V, j + 1, h, &hn));
+      }
       for (int i = 0; i <= j; ++i) H[(size_t)j * mh + i] = h[i];
       if (hn <= break_tol * anorm) {   // happy breakdown
         k1 = 0;
@@ -402,9 +497,8 @@ int dnm_eigsolve(dnm_mat *A, int64_t n_local, int nev, int which, double tol, in
   if (max_its <= 0) max_its = (int)std::max<int64_t>(100, 2 * Nglob / m);
   DNM_CHECK((size_t)(m + 1) * 64 * 16 <= 160 * 1024, "ncv too large for the basis-rotation kernel");
 
-  DevBuf basis;
-  DNM_TRY(basis.alloc((size_t)(m + 1) * (size_t)n_local * 16));
-  void *V = basis.p;
+  void *V = nullptr;
+  DNM_TRY(basis_workspace((size_t)(m + 1) * (size_t)n_local * 16, &V));
 
   // start vector: counter-based normal deviates keyed by the global index
   int64_t offset = 0;

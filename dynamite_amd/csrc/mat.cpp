@@ -374,6 +374,35 @@ int dnm_state_to_idx(const dnm_subspace *s, int64_t n, const int64_t *states, in
   return 0;
 }
 
+// ---- CheckConserves ---------------------------------------------------------------
+int dnm_check_conserves(int64_t nmasks, const int64_t *masks, const int64_t *mask_offsets,
+                        const int64_t *signs, const double *coeffs, const dnm_subspace *left,
+                        const dnm_subspace *right, int xparity, int *result, void *stream) {
+  DNM_CHECK(result && (nmasks == 0 || (masks && mask_offsets && signs && coeffs)), "null argument");
+  DNM_CHECK(xparity == 0, "XParity subspaces are not supported by this engine yet");
+  SubOwned l, r;
+  DNM_TRY(l.init(left, true));
+  DNM_TRY(r.init(right, true));
+  const int64_t nterms = nmasks ? mask_offsets[nmasks] : 0;
+  std::vector<double> re(nterms), im(nterms);
+  for (int64_t t = 0; t < nterms; ++t) { re[t] = coeffs[2 * t]; im[t] = coeffs[2 * t + 1]; }
+  DevBuf dm, doff, ds, dre, dim_, dbad;
+  DNM_TRY(dm.upload(masks, (size_t)nmasks * 8));
+  DNM_TRY(doff.upload(mask_offsets, (size_t)(nmasks + 1) * 8));
+  DNM_TRY(ds.upload(signs, (size_t)nterms * 8));
+  DNM_TRY(dre.upload(re.data(), (size_t)nterms * 8));
+  DNM_TRY(dim_.upload(im.data(), (size_t)nterms * 8));
+  int zero = 0;
+  DNM_TRY(dbad.upload(&zero, sizeof(int)));
+  DevMsc msc{(int32_t)nmasks, (const int64_t *)dm.p, (const int64_t *)doff.p, (const int64_t *)ds.p,
+             (const double *)dre.p};
+  DNM_TRY(launch_conserves(msc, (const double *)dim_.p, l.dev, r.dev, r.host.dim, (int *)dbad.p, S(stream)));
+  int bad = 0;
+  DNM_TRY(dnm_memcpy_d2h(&bad, dbad.p, sizeof(int), stream));
+  *result = bad ? 0 : 1;
+  return 0;
+}
+
 // ---- shell matrix -------------------------------------------------------------
 int dnm_mat_create(int64_t nmasks, const int64_t *masks, const int64_t *mask_offsets,
                    const int64_t *signs, const double *coeffs, const dnm_subspace *left,

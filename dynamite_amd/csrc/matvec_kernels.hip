@@ -723,6 +723,68 @@ norm_kernel(const DevMsc msc, const SubView left_g, const SubView right_g, int64
   }
 }
 
+// CheckConserves (bpetsc_template_2.c:990-1056): does H map the right subspace
+// into the left one?  One thread per column; any column whose image leaves the
+// left subspace with a non-zero matrix element clears the flag.
+template <int LT, int RT>
+__global__ void __launch_bounds__(GATHER_NT)
+conserves_kernel(const DevMsc msc, const double *__restrict__ coeffs_im, const SubView left_g,
+                 const SubView right_g, int64_t N, int *__restrict__ bad) {
+  __shared__ int64_t nck[NCK_LDS_MAX];
+  int used = 0;
+  const SubView left = stage_sub<LT>(left_g, nck, used);
+  const SubView right = stage_sub<RT>(right_g, nck, used);
+  if (used) __syncthreads();
+  const int64_t col = (int64_t)blockIdx.x * GATHER_NT + threadIdx.x;
+  if (col >= N) return;
+  const int64_t bra = Sub<RT>::i2s(col, right);
+  for (int m = 0; m < msc.nmasks; ++m) {
+    const int64_t ket = bra ^ msc.masks[m];
+    if (Sub<LT>::s2i(ket, left) >= 0) continue;
+    // complex sum of the terms of this matrix element (the reference sums msc->coeffs)
+    double vr = 0.0, vi = 0.0;
+    for (int64_t t = msc.mask_offsets[m]; t < msc.mask_offsets[m + 1]; ++t) {
+      const uint32_t p = (uint32_t)__popcll((uint64_t)(bra & msc.signs[t])) & 1u;
+      vr += flip_sign(msc.real_coeffs[t], p);
+      vi += flip_sign(coeffs_im[t], p);
+    }
+    if (vr != 0.0 || vi != 0.0) {
+      *bad = 1;
+      return;
+    }
+  }
+}
+
+template <int LT>
+static int conserves_dispatch_r(const DevMsc &msc, const double *cim, const SubView &l, const SubView &r,
+                                int64_t N, int *bad, hipStream_t st) {
+  const dim3 grid((unsigned)((N + GATHER_NT - 1) / GATHER_NT)), blk(GATHER_NT);
+#define DNM_C(RT)                                                                                 \
+  case RT:                                                                                        \
+    hipLaunchKernelGGL((conserves_kernel<LT, RT>), grid, blk, 0, st, msc, cim, l, r, N, bad);     \
+    break;
+  switch (r.type) {
+    DNM_C(DNM_FULL) DNM_C(DNM_PARITY) DNM_C(DNM_SPIN_CONSERVE) DNM_C(DNM_EXPLICIT)
+    default: set_error("bad right subspace type"); return 1;
+  }
+#undef DNM_C
+  DNM_HIP(hipGetLastError());
+  return 0;
+}
+
+// msc.real_coeffs must hold the REAL parts here and coeffs_im the imaginary parts
+int launch_conserves(const DevMsc &msc, const double *coeffs_im, const SubView &left, const SubView &right,
+                     int64_t N, int *bad, hipStream_t st) {
+  switch (left.type) {
+    case DNM_FULL: return conserves_dispatch_r<DNM_FULL>(msc, coeffs_im, left, right, N, bad, st);
+    case DNM_PARITY: return conserves_dispatch_r<DNM_PARITY>(msc, coeffs_im, left, right, N, bad, st);
+    case DNM_SPIN_CONSERVE: return conserves_dispatch_r<DNM_SPIN_CONSERVE>(msc, coeffs_im, left, right, N, bad, st);
+    case DNM_EXPLICIT: return conserves_dispatch_r<DNM_EXPLICIT>(msc, coeffs_im, left, right, N, bad, st);
+  }
+  set_error("bad left subspace type");
+  return 1;
+}
+
 template <int LT>
 static int gather_dispatch_r(const DevMsc &msc, const SubView &l, const SubView &r, int64_t M,
                              const double *diag, const void *x, void *y, hipStream_t st) {

@@ -297,29 +297,22 @@ class Operator:
                 mat.destroy()
 
     def conserves(self, left, right=None):
-        """Does the operator map the right subspace into the left one?  Host-side
-        sweep over the columns for small dimensions (CheckConserves,
-        bpetsc_template_2.c:990-1056); Full always conserves."""
+        """Does the operator map the right subspace into the left one?
+        (operators.py:382-423 -> bpetsc.check_conserves -> CheckConserves,
+        bpetsc_template_2.c:990-1056; a full sweep over the columns, on the GPU.)"""
         if right is None:
             right = left
         if isinstance(left, Full) and isinstance(right, Full):
             return True
         self.establish_L()
+        for sp in (left, right):
+            if sp.L is None:
+                sp.L = self.L
         self.reduce_msc()
-        N = right.get_dimension()
-        cols = np.arange(N, dtype=np.int64)
-        bras = np.asarray(right.idx_to_state(cols))
         masks, offs = msc_tools.get_mask_offsets(self.msc)
-        for i, m in enumerate(masks):
-            out = np.asarray(left.state_to_idx(bras ^ m)) == -1
-            if not np.any(out):
-                continue
-            val = np.zeros(int(out.sum()), dtype=np.complex128)
-            for t in range(offs[i], offs[i + 1]):
-                val += (1 - 2 * msc_tools.parity(bras[out] & self.msc['signs'][t])) * self.msc['coeffs'][t]
-            if np.any(val != 0):
-                return False
-        return True
+        return backend.check_conserves(masks, offs, np.ascontiguousarray(self.msc['signs']),
+                                       np.ascontiguousarray(self.msc['coeffs']),
+                                       left._to_c(), right._to_c())
 
     def infinity_norm(self, subspaces=None):
         return self.get_mat(subspaces=subspaces).norm('infinity')

@@ -114,6 +114,13 @@ int dnm_mat_create(int64_t nmasks, const int64_t *masks, const int64_t *mask_off
                    const dnm_subspace *left, const dnm_subspace *right,
                    int xparity, int flags, const dnm_partition *part,
                    dnm_mat **out);
+/* CheckConserves(msc, subspaces, xparity, &result)  (bpetsc.pyx:150-193,
+ * bpetsc_template_2.c:990-1056): *result = 1 iff every column of the right
+ * subspace is mapped into the left subspace (or onto a zero matrix element). */
+int dnm_check_conserves(int64_t nmasks, const int64_t *masks, const int64_t *mask_offsets,
+                        const int64_t *signs, const double *coeffs,
+                        const dnm_subspace *left, const dnm_subspace *right,
+                        int xparity, int *result, void *stream);
 /* MATOP_DESTROY -> MatDestroyCtx_GPU (bcuda_template_2.cu:110-139) */
 int dnm_mat_destroy(dnm_mat *A);
 /* MatGetSize / MatGetLocalSize */
@@ -240,6 +247,9 @@ int dnm_expm_multiply(dnm_mat *A, const void *x, void *y, int64_t n_local,
                       double scale_re, double scale_im, double tol, int ncv,
                       int max_its, size_t work_limit_bytes, const dnm_hooks *hooks,
                       dnm_solver_stats *stats, void *stream);
+
+/* The solvers keep their Krylov-basis allocation between calls; this frees it. */
+int dnm_release_workspace(void);
 
 enum { DNM_WHICH_LOWEST = 0, DNM_WHICH_HIGHEST = 1, DNM_WHICH_EXTERIOR = 2 };
 

@@ -256,3 +256,23 @@ def test_operator_dot_api():
     H.build_mat()
     with pytest.raises(ValueError):
         Operator(msc=[(1, 0, 1j)]).dot(State(L=1, state='U'))   # non-Hermitian
+
+
+def test_conserves_gpu():
+    """CheckConserves on the device against the oracle's restatement
+    (tests/integration/test_operators.py:20-188 cases in spirit)."""
+    from oracle import oracle as orc
+    from gpu_util import orc_msc, orc_sub
+    cases = [(models.heisenberg(10), SpinConserve(10, 5), True), (models.heisenberg(10), Parity('even', L=10), True),
+             (models.xsum(8), SpinConserve(8, 4), False), (models.ising(8), SpinConserve(8, 4), False),
+             (models.ising(8), Parity('odd', L=8), False), (models.xxz(8), Parity('odd', L=8), True),
+             (models.long_range(8), Parity('even', L=8), False), (models.mbl(12), SpinConserve(12, 3), True)]
+    for H, sub, want in cases:
+        got = H.conserves(sub)
+        assert got == want
+        assert got == orc.check_conserves(orc_msc(H), orc_sub(sub), orc_sub(sub))
+    # projection between different subspaces
+    H = models.heisenberg(8)
+    assert H.conserves(Full(L=8), SpinConserve(8, 4))          # sector into full space: always inside
+    assert not H.conserves(SpinConserve(8, 4), Full(L=8))      # full space into one sector: leaves it
+    assert not H.conserves(SpinConserve(8, 3), SpinConserve(8, 4))

@@ -127,16 +127,6 @@ def test_algebra_pauli(known):
         assert np.array_equal(op.to_numpy(sparse=False), cmatrix(known["pauli"][name]["matrix"]))
 
 
-def test_conserves_host():
-    H = models.heisenberg(8)
-    assert H.conserves(SpinConserve(8, 4))
-    assert H.conserves(Parity('even', L=8))
-    assert not models.xsum(8).conserves(SpinConserve(8, 4))
-    assert not models.ising(8).conserves(SpinConserve(8, 4))
-    assert not models.ising(8).conserves(Parity('odd', L=8))   # single-site sigma_x flips parity
-    assert models.xxz(8).conserves(Parity('odd', L=8))
-
-
 # ------------------------------------------------------------------ planner + tables via emulator
 
 def _orc_msc(H):
