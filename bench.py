@@ -98,7 +98,7 @@ def main():
     import ctypes as C
     nl = C.c_int()
     _lib.check(_lib.lib().dnm_mat_plan_launches(mat.handle, C.byref(nl)))
-    launches = nl.value + len(mat.partners)
+    launches = nl.value + len(mat.recvs)
 
     def barrier():
         torch.cuda.synchronize()

@@ -83,6 +83,30 @@ def exchange_window(x_local, owned, windows, me, window_buf=None):
     return window_buf
 
 
+def exchange_plan(handle):
+    """(sends, recvs) of the partitioned multiply: lists of (partner, offset, count),
+    offsets/counts in amplitudes of the SENDER's local vector; recvs[i] feeds
+    dnm_mat_mult_remote(handle, i, ...)."""
+    ns, nr = C.c_int(), C.c_int()
+    L = _lib.lib()
+    _lib.check(L.dnm_mat_exchange_plan(handle, C.byref(ns), None, C.byref(nr), None))
+    sb, rb = (_lib.Xfer * max(1, ns.value))(), (_lib.Xfer * max(1, nr.value))()
+    _lib.check(L.dnm_mat_exchange_plan(handle, C.byref(ns), sb, C.byref(nr), rb))
+    sends = [(int(sb[i].partner), int(sb[i].offset), int(sb[i].count)) for i in range(ns.value)]
+    recvs = [(int(rb[i].partner), int(rb[i].offset), int(rb[i].count)) for i in range(nr.value)]
+    return sends, recvs
+
+
+def post_exchange(x_local, sends, recvs, recv_bufs):
+    """Post every send/receive of one multiply as one batch (RCCL send/recv on a
+    GPU, gloo on CPU).  Between a pair of ranks the sends of one side are listed in
+    the order of the other side's receives, so in-order matching pairs them up."""
+    import torch.distributed as dist
+    ops = [dist.P2POp(dist.isend, x_local[off:off + cnt], p) for p, off, cnt in sends]
+    ops += [dist.P2POp(dist.irecv, buf, p) for (p, _, _), buf in zip(recvs, recv_bufs)]
+    return dist.batch_isend_irecv(ops) if ops else []
+
+
 class Vec:
     """Distributed complex128 vector: this rank's block lives in ``self.array``
     (a 1-D torch tensor on the rank's GPU)."""
@@ -209,11 +233,8 @@ class ShellMat:
         M, N, m, n = (C.c_int64() for _ in range(4))
         _lib.check(_lib.lib().dnm_mat_sizes(handle, C.byref(M), C.byref(N), C.byref(m), C.byref(n)))
         self.M, self.N, self.m_local, self.n_local = M.value, N.value, m.value, n.value
-        npart = C.c_int()
-        _lib.check(_lib.lib().dnm_mat_partners(handle, C.byref(npart), None))
-        buf = (C.c_int32 * max(1, npart.value))()
-        _lib.check(_lib.lib().dnm_mat_partners(handle, C.byref(npart), buf))
-        self.partners = [int(buf[i]) for i in range(npart.value)]
+        self.sends, self.recvs = exchange_plan(handle)
+        self.partners = sorted({r[0] for r in self.recvs})
         self._recv = {}
         r0, ml = C.c_int64(), C.c_int64()
         _lib.check(_lib.lib().dnm_mat_ownership(handle, C.byref(r0), C.byref(ml)))
@@ -247,24 +268,21 @@ class ShellMat:
             raise ValueError('x and y must be different vectors')
         if self.nranks > 1 and not self.partners and self._is_windowed():
             return self._mult_window(x, y)
-        if not self.partners:
+        if not self.recvs and not self.sends:
             _lib.check(L.dnm_mat_mult(self.handle, x.ptr, y.ptr, _stream()))
             return
         import torch
-        import torch.distributed as dist
-        ops = []
-        for p in self.partners:
-            if p not in self._recv:
-                self._recv[p] = torch.empty_like(x.array)
-            ops.append(dist.P2POp(dist.isend, x.array, p))
-            ops.append(dist.P2POp(dist.irecv, self._recv[p], p))
-        reqs = dist.batch_isend_irecv(ops)          # runs on RCCL's stream
+        bufs = []
+        for i, (p, off, cnt) in enumerate(self.recvs):
+            if i not in self._recv:
+                self._recv[i] = torch.empty(cnt, dtype=x.array.dtype, device=x.array.device)
+            bufs.append(self._recv[i])
+        reqs = post_exchange(x.array, self.sends, self.recvs, bufs)     # runs on RCCL's stream
         _lib.check(L.dnm_mat_mult_local(self.handle, x.ptr, y.ptr, _stream()))   # overlaps
         for r in reqs:
             r.wait()
-        for p in self.partners:
-            _lib.check(L.dnm_mat_mult_remote(self.handle, p, C.c_void_p(self._recv[p].data_ptr()),
-                                             y.ptr, _stream()))
+        for i in range(len(self.recvs)):
+            _lib.check(L.dnm_mat_mult_remote(self.handle, i, C.c_void_p(bufs[i].data_ptr()), y.ptr, _stream()))
 
     def _is_windowed(self):
         return 'SpinConserve kernel' in self.describe()

@@ -171,6 +171,7 @@ static int build_pass(const dnm_mat &A, const PassSpec &ps, PassOnDevice *out) {
   const OpForm &op = A.op;
   const Plan &pl = A.plan;
   const int B = ps.B, logR = pl.cfg.logR, lognt = B - logR, R = 1 << logR;
+  const int n_eff = ps.n_eff ? ps.n_eff : pl.n_loc;     // index bits this pass sweeps
   const uint64_t tb = ps.tile_bits();
   DevPass &d = out->desc;
   memset(&d, 0, sizeof(d));
@@ -189,13 +190,13 @@ static int build_pass(const dnm_mat &A, const PassSpec &ps, PassOnDevice *out) {
     std::vector<int> order;
     uint64_t gb = ps.glen ? ((((uint64_t)1 << ps.glen) - 1) << ps.gpos) : 0;
     std::vector<int> rest;
-    for (int pos = 0; pos < pl.n_loc; ++pos)
+    for (int pos = 0; pos < n_eff; ++pos)
       if (!((tb >> pos) & 1) && !((gb >> pos) & 1)) rest.push_back(pos);
     size_t nsel = ps.glen ? std::min<size_t>(3, rest.size()) : 0;
     for (size_t i = 0; i < nsel; ++i) order.push_back(rest[i]);
     for (int pos = ps.gpos; pos < ps.gpos + ps.glen; ++pos) order.push_back(pos);
     for (size_t i = nsel; i < rest.size(); ++i) order.push_back(rest[i]);
-    DNM_CHECK((int)order.size() == pl.n_loc - B, "internal: block bits do not add up");
+    DNM_CHECK((int)order.size() == n_eff - B, "internal: block bits do not add up");
     int nb = 0;
     for (size_t i = 0; i < order.size();) {
       size_t j = i + 1;
@@ -209,7 +210,8 @@ static int build_pass(const dnm_mat &A, const PassSpec &ps, PassOnDevice *out) {
     }
     d.nbseg = nb;
   }
-  d.sign_base = (uint64_t)pl.rank << pl.n_loc;
+  d.sign_base = ((uint64_t)pl.rank << pl.n_loc) | ps.sign_extra;
+  d.n_eff = n_eff;
   d.accumulate = ps.accumulate ? 1 : 0;
   d.has_diag = 0;
   d.cache_policy = pl.cfg.cache_policy;
@@ -267,7 +269,7 @@ static int build_pass(const dnm_mat &A, const PassSpec &ps, PassOnDevice *out) {
   std::vector<Rec> recs;
   auto push_mask = [&](int idx, bool gather, int src) {
     const RowMask &m = op.masks[idx];
-    const uint64_t mloc = m.mask & (((uint64_t)1 << pl.n_loc) - 1);
+    const uint64_t mloc = m.mask & (((uint64_t)1 << n_eff) - 1);
     if (!gather) DNM_CHECK((mloc & ~tb) == 0, "internal: tile mask leaves the tile");
     std::vector<const RowTerm *> re, im;
     for (const RowTerm &t : m.terms) (t.is_imag ? im : re).push_back(&t);
@@ -311,6 +313,9 @@ static int build_pass(const dnm_mat &A, const PassSpec &ps, PassOnDevice *out) {
   if (!A.host_only) DNM_TRY(out->quads.upload(quads.data(), quads.size() * sizeof(DevQuad)));
   d.quads = (const DevQuad *)out->quads.p;
   out->partner = ps.partner;
+  out->n_eff = n_eff;
+  out->y_off = ps.y_off;
+  out->src_off = ps.src_off;
   return 0;
 }
 
@@ -570,7 +575,7 @@ int dnm_mat_mult_local(dnm_mat *A, const void *x, void *y, void *stream) {
   DNM_CHECK(x != y, "x and y must be different vectors");
   if (A->hypercube && A->plan.use_tiled) {
     for (auto &p : A->local_passes)
-      DNM_TRY(launch_tile_pass(p->desc, A->plan.cfg.B, A->plan.cfg.logR, use_glds(A), A->plan.n_loc, x, y,
+      DNM_TRY(launch_tile_pass(p->desc, A->plan.cfg.B, A->plan.cfg.logR, use_glds(A), p->n_eff, x, y,
                                nullptr, S(stream)));
     return 0;
   }
@@ -631,23 +636,29 @@ int dnm_mat_mult_window(dnm_mat *A, const void *x_window, int64_t win_start, int
                           S(stream));
 }
 
-int dnm_mat_partners(const dnm_mat *A, int *n, int32_t *partner_ranks) {
-  DNM_CHECK(A && n, "null argument");
-  *n = (int)A->remote_passes.size();
-  if (partner_ranks)
-    for (size_t i = 0; i < A->remote_passes.size(); ++i) partner_ranks[i] = A->remote_passes[i]->partner;
+int dnm_mat_exchange_plan(const dnm_mat *A, int *nsend, dnm_xfer *sends, int *nrecv, dnm_xfer *recvs) {
+  DNM_CHECK(A && nsend && nrecv, "null argument");
+  *nsend = (int)A->plan.sends.size();
+  *nrecv = (int)A->remote_passes.size();
+  if (sends)
+    for (size_t i = 0; i < A->plan.sends.size(); ++i)
+      sends[i] = {A->plan.sends[i].partner, -1, A->plan.sends[i].offset, A->plan.sends[i].count};
+  if (recvs)
+    for (size_t i = 0; i < A->remote_passes.size(); ++i) {
+      const auto &p = A->remote_passes[i];
+      recvs[i] = {p->partner, (int32_t)i, p->src_off, (int64_t)1 << p->n_eff};
+    }
   return 0;
 }
 
-int dnm_mat_mult_remote(dnm_mat *A, int32_t partner_rank, const void *x_remote, void *y, void *stream) {
-  DNM_CHECK(A && x_remote && y, "null argument");
+int dnm_mat_mult_remote(dnm_mat *A, int32_t recv_index, const void *x_recv, void *y, void *stream) {
+  DNM_CHECK(A && x_recv && y, "null argument");
   DNM_CHECK(!A->host_only, "host-only handle cannot multiply");
-  for (auto &p : A->remote_passes)
-    if (p->partner == partner_rank)
-      return launch_tile_pass(p->desc, A->plan.cfg.B, A->plan.cfg.logR, use_glds(A), A->plan.n_loc,
-                              x_remote, y, x_remote, S(stream));
-  set_error("rank %d is not a partner of rank %d", partner_rank, A->rank);
-  return 1;
+  DNM_CHECK(recv_index >= 0 && recv_index < (int)A->remote_passes.size(), "rank %d has no receive %d", A->rank,
+            recv_index);
+  const auto &p = A->remote_passes[recv_index];
+  return launch_tile_pass(p->desc, A->plan.cfg.B, A->plan.cfg.logR, use_glds(A), p->n_eff, x_recv,
+                          (char *)y + (size_t)p->y_off * 16, x_recv, S(stream));
 }
 
 int dnm_mat_norm_inf(dnm_mat *A, double *nrm, void *stream) {

@@ -38,6 +38,8 @@ struct PassOnDevice {
   std::vector<DevQuad> h_quads;   // host copy (diagnostics / host-only handles)
   DevBuf quads;
   int partner = -1;
+  int n_eff = 0;                  // index bits the pass sweeps
+  int64_t y_off = 0, src_off = 0; // partner passes: first local row / first partner amplitude
 };
 
 }  // namespace dnm

@@ -51,6 +51,69 @@ static PassSpec tile_spec(int B, int a, int w) {
   return p;
 }
 
+// ---- partner exchange ----------------------------------------------------------
+// A mask that flips rank bits couples this rank's rows to the block of rank
+// `rank ^ (mask >> nl)`.  Its matrix elements are
+//     c(row) = sum_t coeff_t (-1)^popcount(row & sign_t),
+// a combination of Walsh functions of the row bits, which vanishes on a sub-block
+// (rank bits and the top local bit fixed) iff the coefficients of every distinct
+// Walsh function of the remaining bits cancel.  Flip-flop terms (XX+YY) vanish on
+// half of the sub-blocks, so half of the traffic and passes disappear.
+struct Need {
+  int partner;
+  int n_eff;
+  int64_t y_off, src_off;
+  std::vector<int> masks;
+};
+
+static bool vanishes_on(const RowMask &m, uint64_t fixed_bits, uint64_t fixed_value) {
+  std::vector<std::pair<std::pair<uint64_t, int>, double>> groups;   // (free sign bits, is_imag) -> sum
+  for (const RowTerm &t : m.terms) {
+    const double c = (__builtin_popcountll(t.sign & fixed_value) & 1) ? -t.coeff : t.coeff;
+    const std::pair<uint64_t, int> key{t.sign & ~fixed_bits, t.is_imag};
+    bool found = false;
+    for (auto &g : groups)
+      if (g.first == key) { g.second += c; found = true; break; }
+    if (!found) groups.push_back({key, c});
+  }
+  for (auto &g : groups) if (g.second != 0.0) return false;
+  return true;
+}
+
+// Receives of rank `rank`, sorted by (partner, sub-block): the same function is
+// evaluated for the partner ranks to derive the matching sends.
+static void remote_needs(const OpForm &op, int rank, int nl, int B, std::vector<Need> *out) {
+  out->clear();
+  const int levels = (nl - 1 >= B) ? 1 : 0;          // split the block in halves when a half still tiles
+  const int n_eff = nl - levels;
+  const uint64_t highbits = ~lowmask(n_eff);
+  for (int i = 0; i < (int)op.masks.size(); ++i) {
+    const uint64_t m = op.masks[i].mask;
+    const uint64_t h = m >> nl;
+    if (h == 0) continue;
+    const int partner = rank ^ (int)h;
+    for (int half = 0; half < (1 << levels); ++half) {
+      const uint64_t fixed = ((uint64_t)rank << nl) | ((uint64_t)half << n_eff);
+      if (vanishes_on(op.masks[i], highbits, fixed)) continue;
+      const int64_t y_off = (int64_t)half << n_eff;
+      const int64_t src_off = (int64_t)((((uint64_t)half << n_eff) ^ m) & lowmask(nl) & highbits);
+      Need *slot = nullptr;
+      for (Need &nd : *out)
+        if (nd.partner == partner && nd.y_off == y_off && nd.src_off == src_off) slot = &nd;
+      if (!slot) {
+        out->push_back({partner, n_eff, y_off, src_off, {}});
+        slot = &out->back();
+      }
+      slot->masks.push_back(i);
+    }
+  }
+  std::stable_sort(out->begin(), out->end(), [](const Need &a, const Need &b) {
+    if (a.partner != b.partner) return a.partner < b.partner;
+    if (a.y_off != b.y_off) return a.y_off < b.y_off;
+    return a.src_off < b.src_off;
+  });
+}
+
 int make_plan(const OpForm &op, int rank, int nranks, const PlanConfig &cfg_in, Plan *out) {
   Plan &pl = *out;
   pl = Plan();
@@ -215,20 +278,33 @@ int make_plan(const OpForm &op, int rank, int nranks, const PlanConfig &cfg_in, 
     }
   }
 
-  // remote passes: one per partner, gathering from that partner's vector
-  std::sort(remote.begin(), remote.end());
-  for (size_t i = 0; i < remote.size();) {
-    int partner = remote[i].first;
+  // remote passes: what this rank receives and applies
+  std::vector<Need> mine;
+  remote_needs(op, rank, nl, B, &mine);
+  for (const Need &nd : mine) {
     PassSpec ps = tile_spec(B, B, 0);
     ps.accumulate = true;
-    ps.partner = partner;
-    while (i < remote.size() && remote[i].first == partner) {
-      ps.gather_masks.push_back(remote[i].second);
+    ps.partner = nd.partner;
+    ps.n_eff = nd.n_eff;
+    ps.y_off = nd.y_off;
+    ps.src_off = nd.src_off;
+    ps.sign_extra = (uint64_t)nd.y_off;
+    for (int idx : nd.masks) {
+      ps.gather_masks.push_back(idx);
       ps.gather_src.push_back(1);
-      ++i;
     }
     pl.remote.push_back(ps);
-    pl.partners.push_back(partner);
+  }
+  // ... and what the partners receive from it: evaluate their needs the same way
+  std::vector<int> peers;
+  for (const auto &r : remote)
+    if (std::find(peers.begin(), peers.end(), r.first) == peers.end()) peers.push_back(r.first);
+  std::sort(peers.begin(), peers.end());
+  for (int q : peers) {
+    std::vector<Need> theirs;
+    remote_needs(op, q, nl, B, &theirs);
+    for (const Need &nd : theirs)
+      if (nd.partner == rank) pl.sends.push_back({q, nd.src_off, (int64_t)1 << nd.n_eff});
   }
   return 0;
 }
@@ -245,7 +321,9 @@ std::string Plan::describe(const OpForm &op) const {
     if (ps.glen) os << " xcd-group [" << ps.gpos << "," << ps.gpos + ps.glen << ")";
     os << " diag=" << ps.has_diag << " acc=" << ps.accumulate << " tile_masks=" << ps.tile_masks.size()
        << " gather_masks=" << ps.gather_masks.size();
-    if (ps.partner >= 0) os << " partner=" << ps.partner;
+    if (ps.partner >= 0)
+      os << " partner=" << ps.partner << " rows [" << ps.y_off << ",+2^" << ps.n_eff << ") from partner offset "
+         << ps.src_off;
     os << "\n";
   };
   for (size_t i = 0; i < local.size(); ++i) dump("local", local[i], i);

@@ -99,6 +99,7 @@ struct DevPass {
   uint32_t dbucket[MAXR + 1];
   uint32_t loop[LP_COUNT + 1];   // record range of loop i: [loop[i], loop[i+1])
   int32_t nquads;
+  int32_t n_eff;        // index bits this pass runs over (n_loc, or n_loc - 1 for a half-block partner pass)
   const DevQuad *quads;
 };
 
@@ -113,6 +114,12 @@ struct PassSpec {
   bool has_diag = false;
   bool accumulate = false;
   int partner = -1;                // remote pass: partner rank, else -1
+  // Remote passes run over a sub-block of the rank's rows: 2^n_eff rows starting at
+  // row y_off, reading the 2^n_eff amplitudes that start at src_off of the partner's
+  // block.  sign_extra holds the index bits fixed inside the sub-block.
+  int n_eff = 0;                   // 0: the whole local block (n_loc bits)
+  int64_t y_off = 0, src_off = 0;
+  uint64_t sign_extra = 0;
   // XCD group: local index bits [gpos, gpos+glen) are mapped to the block-id bits
   // just above the XCD selector, so the workgroups resident on one XCD at a time
   // span them and gathers across these bits are served by that XCD's L2.
@@ -140,8 +147,10 @@ struct Plan {
   int rank = 0, nranks = 1;
   PlanConfig cfg;
   std::vector<PassSpec> local;                 // passes on x_local
-  std::vector<PassSpec> remote;                // one per partner rank
-  std::vector<int> partners;                   // partner rank per remote pass
+  std::vector<PassSpec> remote;                // one per received (partner, sub-block)
+  // what the partners need from this rank, in the order they post their receives
+  struct Send { int partner; int64_t offset, count; };
+  std::vector<Send> sends;
   bool use_tiled = false;                      // false: generic row-gather kernel only
   std::string describe(const OpForm &op) const;
 };

@@ -154,14 +154,29 @@ int dnm_mat_export_pass(const dnm_mat *A, int remote, int idx, void *desc_out, s
 
 /* --- partitioned multiply: replaces the VecScatterCreateToAll all-gather of
  * bcuda_template_2.cu:161-171 with an XOR-partner exchange. ---------------- */
-/* number of distinct partner ranks this rank needs x from, and their ids
- * (partner = rank ^ h for every distinct non-zero h = mask >> log2(n_local)) */
-int dnm_mat_partners(const dnm_mat *A, int *n, int32_t *partner_ranks /* [nranks] */);
+/* One block transfer of the exchange: `count` amplitudes starting at `offset`
+ * of the SENDER's local vector.  sends[]: what this rank must send (pass_id = -1);
+ * recvs[]: what it receives, recvs[i] feeding dnm_mat_mult_remote(A, i, ...).
+ * A mask that flips rank bits couples this rank to rank ^ (mask >> log2(n_local));
+ * blocks on which its matrix elements vanish identically (e.g. the half of the
+ * rows a flip-flop term XX+YY annihilates) are neither sent nor swept, and the
+ * rank's block is split in halves so that only the needed half travels.  Between
+ * one pair of ranks the sends of one side are listed in the order of the
+ * receives of the other, so in-order point-to-point matching is sufficient. */
+typedef struct {
+  int32_t partner;   /* peer rank */
+  int32_t pass_id;   /* recvs: index for dnm_mat_mult_remote; sends: -1 */
+  int64_t offset;    /* first amplitude, in the sender's local vector */
+  int64_t count;     /* amplitudes (complex128) */
+} dnm_xfer;
+int dnm_mat_exchange_plan(const dnm_mat *A, int *nsend, dnm_xfer *sends /* may be NULL */,
+                          int *nrecv, dnm_xfer *recvs /* may be NULL */);
 /* y = (masks that stay on this rank) x_local; y overwritten */
 int dnm_mat_mult_local(dnm_mat *A, const void *x_local, void *y, void *stream);
-/* y += (masks whose partner is `partner_rank`) x_remote, where x_remote is the
- * partner's complete local vector (received into a local buffer) */
-int dnm_mat_mult_remote(dnm_mat *A, int32_t partner_rank, const void *x_remote,
+/* y += (masks served by receive `recv_index`) x_recv, where x_recv holds the
+ * recvs[recv_index].count amplitudes received from that partner; y is the
+ * rank's whole local vector (the pass offsets into it itself) */
+int dnm_mat_mult_remote(dnm_mat *A, int32_t recv_index, const void *x_recv,
                         void *y, void *stream);
 
 /* --- partitioned SpinConserve/SpinConserve multiply ("column window") ------

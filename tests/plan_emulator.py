@@ -34,10 +34,8 @@ class HostMat:
         _lib.check(L.dnm_mat_plan_counts(self.h, *[C.byref(v) for v in vals]))
         (self.n_local_passes, self.n_remote_passes, self.tiled, self.B, self.logR, self.n_loc) = \
             [v.value for v in vals]
-        npart = C.c_int()
-        buf = (C.c_int32 * 64)()
-        _lib.check(L.dnm_mat_partners(self.h, C.byref(npart), buf))
-        self.partners = [int(buf[i]) for i in range(npart.value)]
+        self.sends, self.recvs = backend.exchange_plan(self.h)
+        self.partners = sorted({r[0] for r in self.recvs})
         self.local = [self._export(0, i) for i in range(self.n_local_passes)]
         self.remote = [self._export(1, i) for i in range(self.n_remote_passes)]
 
@@ -66,7 +64,8 @@ class HostMat:
 def run_pass(hm, p, x, y, xr=None):
     """Apply one exported pass to the local vector x (numpy), updating y."""
     desc, quads = p
-    B, logR, n_loc = hm.B, hm.logR, hm.n_loc
+    B, logR, n_loc = hm.B, hm.logR, desc.n_eff
+    assert x.shape[0] == 1 << n_loc and y.shape[0] == 1 << n_loc
     lognt = B - logR
     NT = 1 << lognt
     R = 1 << logR
@@ -166,6 +165,14 @@ def run_pass(hm, p, x, y, xr=None):
                 xv = x[partner.astype(np.int64)]
             acc += (cre + 1j * cim) * xv
     y[:] = acc
+
+
+def run_remote(hm, i, x_recv, y):
+    """Apply partner pass i (fed by hm.recvs[i]) to the rank's local y."""
+    desc, _ = hm.remote[i]
+    y_off = int(desc.sign_base) & ((1 << hm.n_loc) - 1)
+    assert x_recv.shape[0] == hm.recvs[i][2] == 1 << desc.n_eff
+    run_pass(hm, hm.remote[i], x_recv, y[y_off:y_off + (1 << desc.n_eff)], xr=x_recv)
 
 
 def multiply(hm, x):

@@ -200,9 +200,9 @@ def test_partitioned_kernels_on_one_gpu(monkeypatch):
         xl = vec_from(x[r * nloc:(r + 1) * nloc])
         yl = backend.Vec(nloc)
         _lib.check(Lb.dnm_mat_mult_local(mat.handle, xl.ptr, yl.ptr, None))
-        for p in mat.partners:
-            xr = vec_from(x[p * nloc:(p + 1) * nloc])
-            _lib.check(Lb.dnm_mat_mult_remote(mat.handle, p, xr.ptr, yl.ptr, None))
+        for i, (p, off, cnt) in enumerate(mat.recvs):
+            xr = vec_from(x[p * nloc + off:p * nloc + off + cnt])
+            _lib.check(Lb.dnm_mat_mult_remote(mat.handle, i, xr.ptr, yl.ptr, None))
         y[r * nloc:(r + 1) * nloc] = yl.local_numpy()
         mat.destroy()
     assert np.max(np.abs(y - ref)) <= tol_for(arrs, x)

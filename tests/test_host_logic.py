@@ -10,7 +10,7 @@ import pytest
 from dynamite_amd import _lib, models, msc_tools
 from dynamite_amd.subspaces import Full, Parity, SpinConserve, Explicit
 from oracle import oracle as orc
-from plan_emulator import HostMat, multiply, run_pass
+from plan_emulator import HostMat, multiply, run_pass, run_remote
 
 EPS = 2.2e-16
 
@@ -212,6 +212,30 @@ def test_plan_shape_chain_L30(monkeypatch):
         assert seen == set(int(m) for m in arrs[0][1:])
 
 
+@pytest.mark.parametrize("model,P", [("ising", 2), ("ising", 4), ("long_range", 4), ("xsum", 8)])
+def test_partitioned_plan_other_models(monkeypatch, model, P):
+    """Operators whose rank-bit masks never vanish (single-spin flips, long-range XX)
+    take both halves of every partner block."""
+    L = 13
+    _cfg(monkeypatch, 8, 2)
+    H = models.BY_NAME[model](L)
+    omsc, arrs = _orc_msc(H)
+    sub = Full(L=L)
+    x = _rand(1 << L, 5)
+    nloc = (1 << L) // P
+    y = np.zeros(1 << L, dtype=complex)
+    for r in range(P):
+        hm = HostMat(*arrs, sub._c(), sub._c(), rank=r, nranks=P)
+        yl = np.zeros(nloc, dtype=complex)
+        for p in hm.local:
+            run_pass(hm, p, x[r * nloc:(r + 1) * nloc], yl)
+        for i, (partner, off, cnt) in enumerate(hm.recvs):
+            run_remote(hm, i, x[partner * nloc + off:partner * nloc + off + cnt], yl)
+        y[r * nloc:(r + 1) * nloc] = yl
+    ref = orc.matvec(omsc, orc.full(L), orc.full(L), x)
+    assert np.max(np.abs(y - ref)) <= 64 * len(arrs[0]) * EPS * np.abs(x).max() * max(1.0, np.abs(arrs[3]).max())
+
+
 @pytest.mark.parametrize("P", [2, 4, 8])
 def test_partitioned_plan_matches_oracle_ranks(monkeypatch, P):
     """Rank-local + partner passes reproduce the reference's multi-rank Fast
@@ -225,18 +249,19 @@ def test_partitioned_plan_matches_oracle_ranks(monkeypatch, P):
     nloc = (1 << L) // P
     y = np.zeros(1 << L, dtype=complex)
     partners_seen = set()
+    plans = {}
     for r in range(P):
         hm = HostMat(*arrs, sub._c(), sub._c(), rank=r, nranks=P)
         yl = np.zeros(nloc, dtype=complex)
         xl = x[r * nloc:(r + 1) * nloc]
         for p in hm.local:
             run_pass(hm, p, xl, yl)
-        assert len(hm.remote) == len(hm.partners)
-        for p, partner in zip(hm.remote, hm.partners):
+        assert len(hm.remote) == len(hm.recvs)
+        for i, (partner, off, cnt) in enumerate(hm.recvs):
             assert partner != r and 0 <= partner < P
             partners_seen.add((r, partner))
-            xr = x[partner * nloc:(partner + 1) * nloc]
-            run_pass(hm, p, xr, yl, xr=xr)
+            run_remote(hm, i, x[partner * nloc + off:partner * nloc + off + cnt], yl)
+        plans[r] = (hm.sends, hm.recvs)
         y[r * nloc:(r + 1) * nloc] = yl
     osub = orc.full(L)
     ref = orc.matvec_fast_ranks(omsc, osub, x, P)
@@ -246,3 +271,14 @@ def test_partitioned_plan_matches_oracle_ranks(monkeypatch, P):
     want = {1} | ({3, 2} if P >= 4 else set()) | ({6, 4} if P >= 8 else set())
     hs = {a ^ b for a, b in partners_seen}
     assert hs <= {1, 2, 3, 4, 6} and 1 in hs
+    # the schedules agree pairwise: r's sends to q, in order, are q's receives from r
+    for r in range(P):
+        for q in range(P):
+            assert [(o, c) for p_, o, c in plans[r][0] if p_ == q] == [(o, c) for p_, o, c in plans[q][1] if p_ == r]
+    # flip-flop bonds: the boundary bond moves half a block, a bond inside the rank bits a whole
+    # block but only between ranks whose two bits differ -- never more than the old whole-block exchange
+    total = sum(c for r in range(P) for _, _, c in plans[r][1])
+    full = sum(len({p_ for p_, _, _ in plans[r][1]}) for r in range(P)) * nloc
+    assert total < full or P == 1
+    if P == 2:
+        assert total == nloc
