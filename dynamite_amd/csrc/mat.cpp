@@ -384,7 +384,6 @@ int dnm_check_conserves(int64_t nmasks, const int64_t *masks, const int64_t *mas
                         const int64_t *signs, const double *coeffs, const dnm_subspace *left,
                         const dnm_subspace *right, int xparity, int *result, void *stream) {
   DNM_CHECK(result && (nmasks == 0 || (masks && mask_offsets && signs && coeffs)), "null argument");
-  DNM_CHECK(xparity == 0, "XParity subspaces are not supported by this engine yet");
   SubOwned l, r;
   DNM_TRY(l.init(left, true));
   DNM_TRY(r.init(right, true));
@@ -401,7 +400,9 @@ int dnm_check_conserves(int64_t nmasks, const int64_t *masks, const int64_t *mas
   DNM_TRY(dbad.upload(&zero, sizeof(int)));
   DevMsc msc{(int32_t)nmasks, (const int64_t *)dm.p, (const int64_t *)doff.p, (const int64_t *)ds.p,
              (const double *)dre.p};
-  DNM_TRY(launch_conserves(msc, (const double *)dim_.p, l.dev, r.dev, r.host.dim, (int *)dbad.p, S(stream)));
+  // XParity: the columns are the first half of the parent's (bpetsc_template_2.c:1005-1008)
+  const int64_t ncols = xparity ? r.host.dim / 2 : r.host.dim;
+  DNM_TRY(launch_conserves(msc, (const double *)dim_.p, l.dev, r.dev, ncols, (int *)dbad.p, S(stream)));
   int bad = 0;
   DNM_TRY(dnm_memcpy_d2h(&bad, dbad.p, sizeof(int), stream));
   *result = bad ? 0 : 1;
@@ -417,8 +418,8 @@ int dnm_mat_create(int64_t nmasks, const int64_t *masks, const int64_t *mask_off
   *out = nullptr;
   DNM_CHECK(nmasks >= 0 && (nmasks == 0 || (masks && mask_offsets && signs && coeffs)),
             "null operator arrays");
-  DNM_CHECK(xparity == 0, "XParity subspaces are not supported by this engine yet");
   std::unique_ptr<dnm_mat> A(new dnm_mat());
+  A->xparity = xparity != 0;
   A->flags = flags;
   A->host_only = (flags & DNM_MAT_HOST_ONLY) != 0;
   const int64_t nterms = nmasks ? mask_offsets[nmasks] : 0;
@@ -439,6 +440,18 @@ int dnm_mat_create(int64_t nmasks, const int64_t *masks, const int64_t *mask_off
   DNM_CHECK(A->left.host.L == A->right.host.L, "left and right subspaces have different L");
   A->M = A->left.host.dim;
   A->N = A->right.host.dim;
+  if (A->xparity) {
+    // The operator has been rewritten by XParity.reduce_msc (subspaces.py:632-674) and the basis is
+    // the first half of the parent's: halving the dimensions is all the backend does
+    // (bpetsc_template_2.c:78-85,223-230).  No mask may flip spin L-1 any more.
+    DNM_CHECK(A->M % 2 == 0 && A->N % 2 == 0, "XParity needs parent subspaces of even dimension");
+    const int64_t top = (int64_t)1 << (A->left.host.L - 1);
+    for (int64_t i = 0; i < nmasks; ++i)
+      DNM_CHECK(!(masks[i] & top), "XParity: mask %lld flips spin L-1 (operator not reduced by XParity.reduce_msc)",
+                (long long)masks[i]);
+    A->M /= 2;
+    A->N /= 2;
+  }
   A->rank = part ? part->rank : 0;
   A->nranks = part ? part->nranks : 1;
   DNM_CHECK(A->nranks >= 1 && A->rank >= 0 && A->rank < A->nranks, "bad partition (rank %d of %d)", A->rank,
@@ -508,6 +521,15 @@ int dnm_mat_create(int64_t nmasks, const int64_t *masks, const int64_t *mask_off
 
   if (A->hypercube) {
     DNM_TRY(build_opform(*A, &A->op));
+    if (A->xparity) {
+      // rows and columns have the top index bit clear: the hypercube loses one dimension
+      const uint64_t topbit = (uint64_t)1 << (A->op.n - 1);
+      for (RowMask &rm : A->op.masks) {
+        DNM_CHECK(!(rm.mask & topbit), "internal: XParity mask reaches the top index bit");
+        for (RowTerm &t : rm.terms) t.sign &= ~topbit;
+      }
+      A->op.n -= 1;
+    }
     PlanConfig cfg = plan_config_from_env();
     if (!tile_config_supported(cfg.B, cfg.logR)) {
       set_error("unsupported tile configuration B=%d logR=%d", cfg.B, cfg.logR);

@@ -55,6 +55,7 @@ struct dnm_mat {
   int64_t win_min = 0, win_max = -1;   // partitioned SpinConserve: columns this rank reads (cached)
   int rank = 0, nranks = 1;
   int flags = 0;
+  bool xparity = false;
   bool host_only = false;         // DNM_MAT_HOST_ONLY: plan and tables only, no device
 
   bool hypercube = false;        // Full/Full or Parity/Parity: index space is a hypercube

@@ -14,7 +14,7 @@ from .computations import evolve, eigsolve
 from .config import config
 from .msc_tools import msc_dtype
 from .states import State
-from .subspaces import Full, Subspace
+from .subspaces import Full, Subspace, XParity
 
 
 class Operator:
@@ -173,6 +173,9 @@ class Operator:
         for sp in (left, right):
             if not isinstance(sp, Subspace):
                 raise ValueError('subspace can only be set to objects of Subspace type')
+        if left is not right and (not left.product_state_basis or not right.product_state_basis):
+            raise ValueError("subspaces must be the same object if either is not a "
+                             "product state basis")
         if self.L is None:
             if left.L is not None:
                 self.L = left.L
@@ -242,8 +245,9 @@ class Operator:
             subspaces = (self.left_subspace, self.right_subspace)
         self.establish_L()
         self.reduce_msc()
+        msc = self.msc if subspaces[0].product_state_basis else subspaces[0].reduce_msc(self.msc)
         return msc_tools.msc_to_numpy(
-            self.msc, (subspaces[0].get_dimension(), subspaces[1].get_dimension()),
+            msc, (subspaces[0].get_dimension(), subspaces[1].get_dimension()),
             subspaces[0].idx_to_state, subspaces[1].state_to_idx, sparse=sparse)
 
     # ------------------------------------------------------------------ native matrix
@@ -268,7 +272,8 @@ class Operator:
                              'been added to the operator.')
         config._initialize()
         self.reduce_msc()
-        msc = self.msc
+        # XParity is the only non-product-state basis (operators.py:591-594,612-614)
+        msc = self.msc if subspaces[0].product_state_basis else subspaces[0].reduce_msc(self.msc)
         if not self.allow_projection and not self.conserves(*subspaces):
             raise ValueError("Constructing the operator's matrix on this subspace yields a "
                              "projection (e.g. subspace is not conserved by the operator). If this "
@@ -283,7 +288,7 @@ class Operator:
             coeffs=np.ascontiguousarray(msc['coeffs']),
             left_subspace=subspaces[0]._to_c(),
             right_subspace=subspaces[1]._to_c(),
-            xparity=False, shell=self.shell, gpu=True)
+            xparity=isinstance(subspaces[0], XParity), shell=self.shell, gpu=True)
         if (self.shell and self.precompute_diagonal and subspaces[0] == subspaces[1]
                 and masks.size and masks[0] == 0 and config.world_size == 1):
             backend.precompute_diagonal(mat)
@@ -302,6 +307,10 @@ class Operator:
         bpetsc_template_2.c:990-1056; a full sweep over the columns, on the GPU.)"""
         if right is None:
             right = left
+        if not left.product_state_basis or not right.product_state_basis:
+            if left is not right:
+                raise ValueError('if left or right subspace is not a product '
+                                 'state basis, they must be the same object')
         if isinstance(left, Full) and isinstance(right, Full):
             return True
         self.establish_L()
@@ -309,10 +318,16 @@ class Operator:
             if sp.L is None:
                 sp.L = self.L
         self.reduce_msc()
-        masks, offs = msc_tools.get_mask_offsets(self.msc)
-        return backend.check_conserves(masks, offs, np.ascontiguousarray(self.msc['signs']),
-                                       np.ascontiguousarray(self.msc['coeffs']),
-                                       left._to_c(), right._to_c())
+        if not left.product_state_basis:
+            msc, conserved = left.reduce_msc(self.msc, check_conserves=True)
+            if not conserved:
+                return False
+        else:
+            msc = self.msc
+        masks, offs = msc_tools.get_mask_offsets(msc)
+        return backend.check_conserves(masks, offs, np.ascontiguousarray(msc['signs']),
+                                       np.ascontiguousarray(msc['coeffs']),
+                                       left._to_c(), right._to_c(), xparity=isinstance(left, XParity))
 
     def infinity_norm(self, subspaces=None):
         return self.get_mat(subspaces=subspaces).norm('infinity')

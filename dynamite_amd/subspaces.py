@@ -3,7 +3,7 @@ Subspaces on which operators and states live: the Python faces of the native
 index maps, mirroring ``dynamite.subspaces`` (reference
 ``src/dynamite/subspaces.py``: Subspace :20-213, Full :214-246, Parity
 :248-297, SpinConserve :299-377, Explicit :380-452) for the hot path.
-``Auto`` and ``XParity`` are not part of this path yet.
+``XParity`` (:532-800) wraps one of them; ``Auto`` is not part of this path yet.
 
 All maps go through the C ABI (``dnm_idx_to_state`` / ``dnm_state_to_idx`` /
 ``dnm_subspace_dim``), which replaces ``bsubspace.pyx``.
@@ -282,3 +282,160 @@ class Explicit(Subspace):
         if self.rmap_indices is not None:
             d.rmap_indices = _lib.p64(self.rmap_indices)
         return d
+
+
+class XParity(Subspace):
+    """Symmetric / antisymmetric sector of the global spin flip prod_i sigma^x_i on top of a
+    product-state parent subspace (subspaces.py:532-800).  Basis states are
+    (|c> +- |c-bar>)/sqrt(2), represented by whichever of c, c-bar has spin L-1 up (bit L-1
+    clear), i.e. by the first half of the parent's basis.  The operator is rewritten by
+    ``reduce_msc``; the backend then only halves the dimension (bpetsc_template_2.c:223-230)."""
+
+    _product_state_basis = False
+
+    def __init__(self, parent=None, sector='+', L=None):
+        if parent is None:
+            parent = Full()
+        self._parent = parent
+        self._chksum = None
+        self._cdesc = None
+        if L is not None:
+            self.parent.L = L
+        self._validate_parent(self.parent)
+        if sector in ['+', +1]:
+            self._sector = +1
+        elif sector in ['-', -1]:
+            self._sector = -1
+        else:
+            raise ValueError('invalid value for sector')
+
+    @classmethod
+    def _validate_parent(cls, parent):
+        # subspaces.py:566-617
+        if not parent.product_state_basis:
+            raise ValueError('parent must be a product state subspace')
+        if isinstance(parent, Full):
+            return
+        if parent.L is None:
+            raise ValueError('L must be set for the parent subspace')
+        if isinstance(parent, Parity):
+            if parent.L % 2 == 0:
+                return
+            raise ValueError('Parity is only compatible with XParity when L is even')
+        if isinstance(parent, SpinConserve):
+            if parent.L == 2 * parent.k:
+                return
+            raise ValueError('SpinConserve is only compatible with XParity when k=L/2')
+        dim = parent.get_dimension()
+        if dim % 2 != 0:
+            raise ValueError('parent subspace must have even dimension')
+        block_size = 1024
+        for start in range(0, dim // 2, block_size):
+            end = min(start + block_size, dim // 2)
+            state_block = parent.idx_to_state(np.arange(start, end))
+            if np.count_nonzero(state_block >> (parent.L - 1)):
+                raise ValueError('first dim/2 basis states must have spin L-1 up '
+                                 '(0 in integer notation)')
+            flipped = state_block ^ ((1 << parent.L) - 1)
+            if np.any(parent.state_to_idx(flipped) == -1):
+                raise ValueError('the complement of every state in subspace (all spins flipped) '
+                                 'must also be in subspace')
+
+    @property
+    def parent(self):
+        return self._parent
+
+    @property
+    def sector(self):
+        return self._sector
+
+    @property
+    def L(self):
+        return self.parent.L
+
+    @L.setter
+    def L(self, value):
+        self.parent.L = value
+        self._cdesc = None
+
+    def reduce_msc(self, msc, check_conserves=False):
+        """Equivalent operator inside the sector (subspaces.py:632-674): terms that
+        anticommute with the symmetry are dropped, masks that flip spin L-1 are complemented
+        (with the sector's sign), like terms merged."""
+        from . import msc_tools
+        msc = msc.copy()
+        keep = msc_tools.parity(msc['signs']) == 0
+        conserved = bool(np.all(keep))
+        msc = msc[keep]
+        terms_to_mod = np.nonzero(msc['masks'] >> (self.L - 1))
+        msc['masks'][terms_to_mod] ^= (1 << self.L) - 1
+        if self.sector == -1:
+            msc['coeffs'][terms_to_mod] *= -1
+        msc = msc_tools.combine_and_sort(msc)
+        if check_conserves:
+            return msc, conserved
+        return msc
+
+    def convert_state(self, state):
+        """A state on this subspace -> its parent, or back (subspaces.py:676-762)."""
+        from . import states
+        state.assert_initialized()
+        flip_mask = (1 << self.L) - 1
+        half = self.get_dimension()
+        v = state.to_numpy(to_all=True)
+        if state.subspace is self:
+            rtn = states.State(subspace=self.parent)
+            out = np.zeros(2 * half, dtype=np.complex128)
+            idxs = np.arange(half, dtype=dnm_int_t)
+            to_idxs = self.parent.state_to_idx(flip_mask ^ self.idx_to_state(idxs))
+            out[to_idxs] = self.sector * v
+            out[:half] = v
+        elif state.subspace is self.parent:
+            rtn = states.State(subspace=self)
+            idxs = np.arange(half, 2 * half, dtype=dnm_int_t)
+            to_idxs = self.state_to_idx(flip_mask ^ self.parent.idx_to_state(idxs))
+            out = np.zeros(half, dtype=np.complex128)
+            out[to_idxs] = self.sector * v[half:]
+            out += v[:half]
+        else:
+            raise ValueError('subspace of input state must be this XParity subspace or its parent')
+        out /= np.sqrt(2)
+        istart, iend = rtn.vec.getOwnershipRange()
+        rtn.vec.set_local_from_numpy(out[istart:iend])
+        rtn.set_initialized()
+        return rtn
+
+    def __eq__(self, s):
+        if s is self:
+            return True
+        if not isinstance(s, XParity):
+            if not isinstance(s, Subspace):
+                raise ValueError('Cannot compare Subspace to non-Subspace type')
+            return False
+        return self.sector == s.sector and self.parent == s.parent
+
+    def __hash__(self):
+        return hash(('XParity', self.sector, self.parent))
+
+    def __repr__(self):
+        return f'XParity({repr(self.parent)}, sector={self.sector:+d})'
+
+    def get_dimension(self):
+        return self.parent.get_dimension() // 2
+
+    def idx_to_state(self, idx):
+        # representative states are the first N/2 of the parent
+        if np.any(np.asarray(idx) >= self.get_dimension()):
+            raise ValueError('index out of bounds for this subspace')
+        return self.parent.idx_to_state(idx)
+
+    def state_to_idx(self, state):
+        if np.count_nonzero(np.asarray(state) >> (self.L - 1)):
+            raise ValueError('invalid state')
+        return self.parent.state_to_idx(state)
+
+    def _c(self):
+        return self.parent._c()
+
+    def _to_c(self):
+        return self.parent._to_c()

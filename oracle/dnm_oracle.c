@@ -34,13 +34,15 @@ int orc_max_threads(void)
  * (SpinConserve, read from the binomial table), :302-304 (Explicit). */
 orc_int orc_dim(const orc_subspace *s)
 {
+  orc_int d = -1;
   switch (s->type) {
-    case ORC_FULL:          return (orc_int)1 << s->L;
-    case ORC_PARITY:        return (orc_int)1 << (s->L - 1);
-    case ORC_SPIN_CONSERVE: return s->nchoosek[s->k * s->ld_nchoosek + s->L];
-    case ORC_EXPLICIT:      return s->dim;
+    case ORC_FULL:          d = (orc_int)1 << s->L; break;
+    case ORC_PARITY:        d = (orc_int)1 << (s->L - 1); break;
+    case ORC_SPIN_CONSERVE: d = s->nchoosek[s->k * s->ld_nchoosek + s->L]; break;
+    case ORC_EXPLICIT:      d = s->dim; break;
   }
-  return -1;
+  if (s->xparity) d /= 2;   /* M /= 2; N /= 2;  bpetsc_template_2.c:227-230 */
+  return d;
 }
 
 /* S2I_nocheck_SpinConserve, bsubspace_impl.h:191-202: colex rank, the j-th

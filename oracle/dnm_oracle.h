@@ -51,6 +51,11 @@ typedef struct {
   const orc_int *state_map;    /* Explicit: idx -> state */
   const orc_int *rmap_indices; /* Explicit: NULL if state_map is sorted */
   const orc_int *rmap_states;  /* Explicit: sorted states */
+  /* XParity (subspaces.py:532-800): the operator has been rewritten by
+   * XParity.reduce_msc and the basis is the first half of the parent's, so
+   * "the only thing we have to do in the backend" is halve the dimension
+   * (bpetsc_template_2.c:78-85,223-230,1005-1008). */
+  orc_int xparity;
 } orc_subspace;
 
 orc_int orc_dim(const orc_subspace *s);

@@ -34,7 +34,7 @@ class _Sub(C.Structure):
     _fields_ = [("type", C.c_int), ("L", C.c_int64), ("space", C.c_int64),
                 ("k", C.c_int64), ("ld_nchoosek", C.c_int64), ("nchoosek", _i64p),
                 ("dim", C.c_int64), ("state_map", _i64p), ("rmap_indices", _i64p),
-                ("rmap_states", _i64p)]
+                ("rmap_states", _i64p), ("xparity", C.c_int64)]
 
 
 class _Msc(C.Structure):
@@ -157,6 +157,37 @@ def spin_conserve(L, k):
 
 def explicit(L, states):
     return Subspace(EXPLICIT, L, states=states)
+
+
+def xparity(parent):
+    """The backend's view of XParity(parent): the parent's maps on the first half
+    of its indices (bpetsc_template_2.c:223-230).  The operator must have been
+    rewritten with ``xparity_reduce_msc`` first."""
+    import copy
+    s = copy.copy(parent)
+    s.c = _Sub.from_buffer_copy(parent.c)
+    s.c.xparity = 1
+    return s
+
+
+def xparity_reduce_msc(terms, L, sector):
+    """XParity.reduce_msc (subspaces.py:632-674) on a list of (mask, sign, coeff):
+    drop terms that anticommute with prod(sigma_x) (odd sign popcount), complement
+    masks that flip spin L-1 (times the sector), then merge equal (mask, sign).
+    Returns (terms sorted by (mask, sign), conserved)."""
+    out, conserved = {}, True
+    for m, g, c in terms:
+        if _parity(np.array([g], dtype=np.int64))[0]:
+            conserved = False
+            continue
+        c = complex(c)
+        if (m >> (L - 1)) & 1:
+            m ^= (1 << L) - 1
+            if sector == -1:
+                c = -c
+        out[(m, g)] = out.get((m, g), 0) + c
+    # combine_and_sort (msc_tools.py:225-252) drops terms that cancel to zero
+    return [(m, g, c) for (m, g), c in sorted(out.items()) if c != 0], conserved
 
 
 class Msc:

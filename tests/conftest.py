@@ -44,6 +44,11 @@ def golden_sub():
 
 
 @pytest.fixture(scope="session")
+def golden_xp():
+    return Golden("xparity.npz")
+
+
+@pytest.fixture(scope="session")
 def known():
     with open(os.path.join(GOLDEN, "known_answers.json")) as f:
         return json.load(f)

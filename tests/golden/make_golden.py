@@ -237,6 +237,31 @@ def case_sub(name, H, L, left, right, out):
     return d
 
 
+def case_xparity(name, H, L, parent_ref, parent_orc, sector, out):
+    """XParity(parent, sector): the reference's own ``XParity.reduce_msc``
+    (subspaces.py:632-674) rewrites the operator; the matrix is then the reference
+    builder's on the first half of the parent's basis (bpetsc_template_2.c:223-230)."""
+    from dynamite.subspaces import XParity
+    H.reduce_msc()
+    msc_in = H.msc.copy()
+    sub = XParity(parent_ref, sector=sector)
+    red, conserved = sub.reduce_msc(msc_in, check_conserves=True)
+    masks, offs = H._get_mask_offsets(red)
+    dim = parent_orc.dim // 2
+    A = msc_tools.msc_to_numpy(
+        red, (dim, dim),
+        idx_to_state=lambda r: int(parent_orc.i2s(r)[0]),
+        state_to_idx=lambda st: parent_orc.s2i(st)).tocsr()
+    x = random_state(dim, 0)
+    out[name] = dict(L=L, sector=sector, conserved=bool(conserved),
+                     in_masks=np.ascontiguousarray(msc_in["masks"]), in_signs=np.ascontiguousarray(msc_in["signs"]),
+                     in_coeffs=np.ascontiguousarray(msc_in["coeffs"]),
+                     masks=np.ascontiguousarray(masks), mask_offsets=np.ascontiguousarray(offs),
+                     signs=np.ascontiguousarray(red["signs"]), coeffs=np.ascontiguousarray(red["coeffs"]),
+                     x=x, y=A @ x, infnorm=float(abs(A).sum(axis=1).max()), diag=np.asarray(A.diagonal()),
+                     evals_lowest=np.linalg.eigvalsh(A.toarray())[:4])
+
+
 def save(fname, cases):
     flat = {}
     for cname, d in cases.items():
@@ -285,6 +310,24 @@ def main():
     case_sub("long_range_L10_explicit", h_long_range(L), L, ex, ex, sub)
     case_sub("long_range_L10_explicit_unsorted", h_long_range(L), L, exu, exu, sub)
     save("subspaces.npz", sub)
+
+    from dynamite import subspaces as rsub
+    xp = {}
+    L = 10
+    for sector in (+1, -1):
+        tag = "plus" if sector == 1 else "minus"
+        case_xparity("heisenberg_L10_full_" + tag, h_heisenberg(L), L, rsub.Full(L=L), orc.full(L), sector, xp)
+        case_xparity("ising_L10_full_" + tag, h_ising(L), L, rsub.Full(L=L), orc.full(L), sector, xp)
+        case_xparity("heisenberg_L10_sc5_" + tag, h_heisenberg(L), L, rsub.SpinConserve(L, 5),
+                     orc.spin_conserve(L, 5), sector, xp)
+        case_xparity("ising_L10_parity_even_" + tag, h_ising(L), L, rsub.Parity("even", L=L), orc.parity(L, 0),
+                     sector, xp)
+        case_xparity("ising_L10_parity_odd_" + tag, h_ising(L), L, rsub.Parity("odd", L=L), orc.parity(L, 1),
+                     sector, xp)
+    # not conserved: sigma_y / sigma_z fields anticommute with the global flip and are dropped
+    case_xparity("long_range_L8_full_plus", h_long_range(8), 8, rsub.Full(L=8), orc.full(8), +1, xp)
+    case_xparity("mbl_L10_full_minus", h_mbl(L), L, rsub.Full(L=L), orc.full(L), -1, xp)
+    save("xparity.npz", xp)
 
 
 if __name__ == "__main__":

@@ -14,7 +14,7 @@ from dynamite_amd import _lib, models, backend
 from dynamite_amd.computations import MaxIterationsError, ConvergenceError
 from dynamite_amd.operators import Operator
 from dynamite_amd.states import State, UninitializedError
-from dynamite_amd.subspaces import Full, Parity, SpinConserve
+from dynamite_amd.subspaces import Full, Parity, SpinConserve, XParity
 from gpu_util import vec_from, rand_state
 
 pytestmark = pytest.mark.gpu
@@ -276,3 +276,78 @@ def test_conserves_gpu():
     assert H.conserves(Full(L=8), SpinConserve(8, 4))          # sector into full space: always inside
     assert not H.conserves(SpinConserve(8, 4), Full(L=8))      # full space into one sector: leaves it
     assert not H.conserves(SpinConserve(8, 3), SpinConserve(8, 4))
+
+
+def _state_from(sub, arr):
+    st = State(L=sub.L, subspace=sub)
+    st.vec.set_local_from_numpy(np.ascontiguousarray(arr, dtype=complex))
+    st.set_initialized()
+    return st
+
+
+def _xp_parent(name, L):
+    if "_sc" in name:
+        return SpinConserve(L, L // 2)
+    if "parity" in name:
+        return Parity("even" if "even" in name else "odd", L=L)
+    return Full(L=L)
+
+
+def test_xparity_golden_gpu(golden_xp, monkeypatch):
+    """Operator.dot / infinity_norm / conserves / eigsolve on XParity subspaces against the
+    fixtures made with the reference's XParity.reduce_msc + msc_to_numpy
+    (tests/integration/test_multiply.py XParity cases in spirit)."""
+    monkeypatch.setenv("DNM_TILE_BITS", "8")
+    monkeypatch.setenv("DNM_LOG_ROWS", "2")
+    for name in golden_xp.names():
+        g = golden_xp[name]
+        L, sector = int(g["L"]), int(g["sector"])
+        hname = next(k for k in models.BY_NAME if name.startswith(k))
+        H = models.BY_NAME[hname](L)
+        sub = XParity(_xp_parent(name, L), sector=sector)
+        H.add_subspace(sub)
+        conserved = bool(g["conserved"]) and not ("ising" in name and "parity" in name)
+        assert H.conserves(sub) == conserved, name
+        if not conserved:
+            with pytest.raises(ValueError):
+                H.build_mat()
+            H.allow_projection = True
+        y = H.dot(_state_from(sub, g["x"]))
+        assert y.subspace is sub
+        nnz = g["coeffs"].size
+        assert np.max(np.abs(y.to_numpy() - g["y"])) <= 8 * nnz * 2.2e-16 * max(1.0, np.abs(g["coeffs"]).max()), name
+        nrm = H.infinity_norm()
+        assert abs(nrm - float(g["infnorm"])) <= nnz * 2.2e-16 * 100 * max(1.0, nrm), name
+        assert np.max(np.abs(H.to_numpy().toarray() @ g["x"] - g["y"])) < 1e-12
+        if conserved:
+            ev = H.eigsolve(nev=1, tol=1e-11)
+            assert abs(ev[0] - g["evals_lowest"][0]) < 1e-9, name
+        H.destroy_mat()
+
+
+@pytest.mark.parametrize("parent", ["full", "sc", "parity"])
+@pytest.mark.parametrize("sector", [+1, -1])
+def test_xparity_convert_state(parent, sector):
+    """convert_state (subspaces.py:676-762) is the isometry between the sector and its
+    parent: norm-preserving, inverted by the way back, and it intertwines the reduced and
+    the parent operator for a Hamiltonian that commutes with the global flip."""
+    L = 10
+    par = {"full": Full(L=L), "sc": SpinConserve(L, 5), "parity": Parity("even", L=L)}[parent]
+    sub = XParity(par, sector=sector)
+    H = models.heisenberg(L)
+    H.add_subspace(sub)
+    H.add_subspace(par)
+    psi = State(L=L, subspace=sub, state="random", seed=4)
+    up = sub.convert_state(psi)
+    assert up.subspace is par and abs(up.norm() - 1) < 1e-13
+    v = up.to_numpy()
+    flipped = par.state_to_idx(par.idx_to_state(np.arange(par.get_dimension())) ^ ((1 << L) - 1))
+    assert np.max(np.abs(v[flipped] - sector * v)) < 1e-15          # eigenvector of the global flip
+    back = sub.convert_state(up)
+    assert np.max(np.abs(back.to_numpy() - psi.to_numpy())) < 1e-14
+    lhs = sub.convert_state(H.dot(psi)).to_numpy()
+    rhs = H.dot(up).to_numpy()
+    assert np.max(np.abs(lhs - rhs)) < 1e-12
+    with pytest.raises(ValueError):
+        sub.convert_state(State(L=L, subspace=Full(L=L) if parent != "full" else Parity("odd", L=L),
+                                state="random", seed=1))

@@ -282,3 +282,49 @@ def test_partitioned_plan_matches_oracle_ranks(monkeypatch, P):
     assert total < full or P == 1
     if P == 2:
         assert total == nloc
+
+
+# ------------------------------------------------------------------ XParity host side
+
+def test_xparity_reduce_msc_golden(golden_xp):
+    """dynamite_amd.subspaces.XParity.reduce_msc against the reference's
+    (subspaces.py:632-674) on every fixture, plus its validation rules (:566-617)."""
+    from dynamite_amd.subspaces import XParity, Explicit
+    for name in golden_xp.names():
+        g = golden_xp[name]
+        L, sector = int(g["L"]), int(g["sector"])
+        msc = np.zeros(g["in_masks"].size, dtype=msc_tools.msc_dtype)
+        msc["masks"], msc["signs"], msc["coeffs"] = g["in_masks"], g["in_signs"], g["in_coeffs"]
+        if "_sc" in name:
+            parent = SpinConserve(L, L // 2)
+        elif "parity" in name:
+            parent = Parity("even" if "even" in name else "odd", L=L)
+        else:
+            parent = Full(L=L)
+        sub = XParity(parent, sector=sector)
+        red, conserved = sub.reduce_msc(msc, check_conserves=True)
+        assert conserved == bool(g["conserved"]), name
+        masks, offs = msc_tools.get_mask_offsets(red)
+        assert np.array_equal(masks, g["masks"]) and np.array_equal(offs, g["mask_offsets"]), name
+        assert np.array_equal(red["signs"], g["signs"]) and np.array_equal(red["coeffs"], g["coeffs"]), name
+        assert sub.get_dimension() == g["x"].size
+        assert not sub.product_state_basis and sub.L == L
+        assert sub.idx_to_state(3) == parent.idx_to_state(3)
+        with pytest.raises(ValueError):
+            sub.state_to_idx(1 << (L - 1))
+    with pytest.raises(ValueError):
+        XParity(Parity("even", L=7))
+    with pytest.raises(ValueError):
+        XParity(SpinConserve(8, 3))
+    with pytest.raises(ValueError):
+        XParity(Full(L=6), sector=2)
+    with pytest.raises(ValueError):
+        XParity(XParity(Full(L=6)))
+    XParity(Explicit([0, 1, 6, 7], L=3))                     # closed under the flip, first half has spin 2 up
+    with pytest.raises(ValueError):
+        XParity(Explicit([0, 1, 2, 7], L=3))                 # complement of 1 (=6) missing
+    with pytest.raises(ValueError):
+        XParity(Explicit([0, 7, 1, 6], L=3))                 # a first-half state has spin 2 down
+    assert XParity(Full(L=6), "+") == XParity(Full(L=6), +1)
+    assert XParity(Full(L=6), "+") != XParity(Full(L=6), "-")
+    assert hash(XParity(Full(L=6), "-")) == hash(XParity(Full(L=6), -1))
