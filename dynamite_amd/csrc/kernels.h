@@ -75,6 +75,9 @@ int vk_maxpy(void *w, const void *V, int64_t ldv, int nv, int64_t n, const doubl
              hipStream_t st);
 int vk_basis_update(void *V, int64_t ldv, int nin, int nout, int64_t n, const double *S_dev,
                     hipStream_t st);
+// p -= (are + i aim) v + b u (u may be null); partials_dev[vk_mdot_blocks(n)] then the sum of |p|^2
+int vk_lanczos_update(void *p, const void *v, const void *u, int64_t n, double are, double aim, double b,
+                      double *partials_dev, hipStream_t st);
 int vk_norm2_partials(const void *x, int64_t n, double *partials_dev, hipStream_t st);
 
 }  // namespace dnm

@@ -390,32 +390,57 @@ int dnm_expm_multiply(dnm_mat *A, const void *x, void *y, int64_t n_local, doubl
     ++nstep;
     double t_step = std::min(t_out - t_now, t_new);
     H.assign((size_t)mh * mh, zc(0));
-    // v_0 = w / beta
-    DNM_TRY(vk_axpby(vecptr(V, n_local, 0), y, n_local, 1.0 / beta, 0, 0, 0, st));
     int mb = m, k1 = 2;
     double avnorm = 0;
     std::vector<zc> h;
-    if (use_pro) mon.reset(m, (double)Nglob);
+    // PRO path: the basis is stored UNNORMALISED, w_j = nv[j] v_j, so no vector is ever rescaled:
+    //   w_{j+1} = H w_j - alpha_j w_j - (beta_j nv[j]/nv[j-1]) w_{j-1},  nv[j+1] = |w_{j+1}| = nv[j] beta_{j+1}
+    // (one dot + one fused update per step); the scales enter every coefficient on the host.
+    std::vector<double> nv(m + 2, 1.0), bet(m + 2, 0.0);
+    if (use_pro) {
+      mon.reset(m, (double)Nglob);
+      DNM_HIP(hipMemcpyAsync(vecptr(V, n_local, 0), y, (size_t)n_local * 16, hipMemcpyDeviceToDevice, st));
+      nv[0] = beta;
+    } else {
+      // v_0 = w / beta
+      DNM_TRY(vk_axpby(vecptr(V, n_local, 0), y, n_local, 1.0 / beta, 0, 0, 0, st));
+    }
     for (int j = 0; j < m; ++j) {
       void *p = vecptr(V, n_local, j + 1);
       DNM_TRY(ops.mult(vecptr(V, n_local, j), p));
       double hn = 0;
       if (use_pro) {
-        // three-term step: remove the components along v_{j-1}, v_j only
-        const int lo = j > 0 ? j - 1 : 0, nvl = j + 1 - lo;
-        std::vector<zc> h1, neg(nvl);
+        std::vector<zc> d;
+        DNM_TRY(ops.mdot(vecptr(V, n_local, j), 1, p, d));
+        const zc alpha = d[0] / (nv[j] * nv[j]);
         h.assign(j + 1, zc(0));
-        DNM_TRY(ops.mdot(vecptr(V, n_local, lo), nvl, p, h1));
-        for (int i = 0; i < nvl; ++i) { neg[i] = -h1[i]; h[lo + i] = h1[i]; }
-        DNM_TRY(ops.maxpy(p, vecptr(V, n_local, lo), nvl, neg));
-        DNM_TRY(ops.norm(p, &hn));
-        if (mon.update(j, h[j].real(), hn)) {
-          std::vector<zc> hf, negf(j + 1);
-          DNM_TRY(ops.mdot(V, j + 1, p, hf));
-          for (int i = 0; i <= j; ++i) { negf[i] = -hf[i]; h[i] += hf[i]; }
-          DNM_TRY(ops.maxpy(p, V, j + 1, negf));
-          DNM_TRY(ops.norm(p, &hn));
+        h[j] = alpha;
+        if (j > 0) h[j - 1] = bet[j];
+        double n2 = 0;
+        DNM_TRY(vec_lanczos_update_host(p, vecptr(V, n_local, j), j > 0 ? vecptr(V, n_local, j - 1) : nullptr,
+                                        n_local, alpha.real(), alpha.imag(),
+                                        j > 0 ? bet[j] * nv[j] / nv[j - 1] : 0.0, &n2, st));
+        DNM_TRY(ops.sum(&n2, 1));
+        nv[j + 1] = std::sqrt(n2 > 0 ? n2 : 0.0);
+        hn = nv[j + 1] / nv[j];
+        if (mon.update(j, alpha.real(), hn)) {
+          std::vector<zc> g, c(j + 1);
+          DNM_TRY(ops.mdot(V, j + 1, p, g));            // g_i = <w_i, w_{j+1}>
+          for (int i = 0; i <= j; ++i) {
+            c[i] = -g[i] / (nv[i] * nv[i]);
+            h[i] += g[i] / (nv[i] * nv[j]);
+          }
+          DNM_TRY(ops.maxpy(p, V, j + 1, c));
+          double nn = 0;
+          DNM_TRY(ops.norm(p, &nn));
+          nv[j + 1] = nn;
+          hn = nn / nv[j];
           mon.beta[j + 1] = hn;
+        }
+        bet[j + 1] = hn;
+        if (hn > break_tol * anorm && (nv[j + 1] > 1e120 || nv[j + 1] < 1e-120)) {
+          DNM_TRY(vk_scale(p, n_local, 1.0 / nv[j + 1], 0, st));     // keep the scales representable
+          nv[j + 1] = 1.0;
         }
       } else {
         DNM_TRY(ops.orthogonalize(p, V, j + 1, h, &hn));
@@ -428,13 +453,14 @@ int dnm_expm_multiply(dnm_mat *A, const void *x, void *y, int64_t n_local, doubl
         break;
       }
       H[(size_t)j * mh + (j + 1)] = hn;
-      DNM_TRY(vk_scale(p, n_local, 1.0 / hn, 0, st));
+      if (!use_pro) DNM_TRY(vk_scale(p, n_local, 1.0 / hn, 0, st));
     }
     if (k1 != 0) {
       H[(size_t)m * mh + (m + 1)] = 1.0;
       // avnorm = || A v_m ||
       DNM_TRY(ops.mult(vecptr(V, n_local, m), tmpv));
       DNM_TRY(ops.norm(tmpv, &avnorm));
+      if (use_pro) avnorm /= nv[m];
     }
     int ireject = 0;
     double err_loc = 0;
@@ -463,7 +489,7 @@ int dnm_expm_multiply(dnm_mat *A, const void *x, void *y, int64_t n_local, doubl
     // w = V[:, 0:mx') (beta F[0:mx', 0])
     const int mxw = mb + std::max(0, k1 - 1);
     std::vector<zc> c(mxw);
-    for (int i = 0; i < mxw; ++i) c[i] = beta * F[i];
+    for (int i = 0; i < mxw; ++i) c[i] = beta * F[i] / (use_pro ? nv[i] : 1.0);
     DNM_TRY(vk_set(y, n_local, 0, 0, st));
     DNM_TRY(ops.maxpy(y, V, mxw, c));
     DNM_TRY(ops.norm(y, &beta));

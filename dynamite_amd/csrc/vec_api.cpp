@@ -37,6 +37,17 @@ int vec_mdot_host(const void *V, int64_t ldv, int nv, const void *w, int64_t n, 
   return 0;
 }
 
+int vec_lanczos_update_host(void *p, const void *v, const void *u, int64_t n, double are, double aim, double b,
+                            double *norm2_host, hipStream_t st) {
+  const int nb = vk_mdot_blocks(n);
+  double *part = nullptr;
+  DNM_TRY(vec_scratch(((size_t)nb + 1) * sizeof(double), &part));
+  DNM_TRY(vk_lanczos_update(p, v, u, n, are, aim, b, part, st));
+  DNM_HIP(hipMemcpyAsync(norm2_host, part + nb, sizeof(double), hipMemcpyDeviceToHost, st));
+  DNM_HIP(hipStreamSynchronize(st));
+  return 0;
+}
+
 }  // namespace dnm
 
 using namespace dnm;

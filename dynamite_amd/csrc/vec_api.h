@@ -14,4 +14,8 @@ int vec_upload_coefs(const double *host, size_t ndoubles, hipStream_t st, const 
 int vec_mdot_host(const void *V, int64_t ldv, int nv, const void *w, int64_t n, double *h_host,
                   hipStream_t st);
 
+// p -= a v + b u in one sweep; *norm2_host = |p|^2 afterwards (local part); synchronises the stream
+int vec_lanczos_update_host(void *p, const void *v, const void *u, int64_t n, double are, double aim, double b,
+                            double *norm2_host, hipStream_t st);
+
 }  // namespace dnm

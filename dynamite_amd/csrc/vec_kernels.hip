@@ -267,6 +267,51 @@ int vk_basis_update(void *V, int64_t ldv, int nin, int nout, int64_t n, const do
   return 0;
 }
 
+// ---- fused Lanczos update: p -= a v + b u, partial sums of |p|^2 ----------------
+// (one sweep instead of multi-axpy + norm; u may be null)
+__global__ void __launch_bounds__(VNT)
+lanczos_update_kernel(c128 *p, const c128 *__restrict__ v, const c128 *__restrict__ u, int64_t n, double are,
+                      double aim, double b, double *__restrict__ partials) {
+  double s = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * VNT + threadIdx.x; i < n; i += (int64_t)gridDim.x * VNT) {
+    c128 acc = p[i];
+    const c128 vv = v[i];
+    acc.x = fma(-are, vv.x, acc.x);
+    acc.x = fma(aim, vv.y, acc.x);
+    acc.y = fma(-are, vv.y, acc.y);
+    acc.y = fma(-aim, vv.x, acc.y);
+    if (u) {
+      const c128 uv = u[i];
+      acc.x = fma(-b, uv.x, acc.x);
+      acc.y = fma(-b, uv.y, acc.y);
+    }
+    p[i] = acc;
+    s = fma(acc.x, acc.x, s);
+    s = fma(acc.y, acc.y, s);
+  }
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+  __shared__ double red[VNT / 64];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int wv = 0; wv < VNT / 64; ++wv) t += red[wv];
+    partials[blockIdx.x] = t;
+  }
+}
+
+// partials_dev: [nblocks] scratch followed by [1] result; nblocks = vk_mdot_blocks(n)
+int vk_lanczos_update(void *p, const void *v, const void *u, int64_t n, double are, double aim, double b,
+                      double *partials_dev, hipStream_t st) {
+  const unsigned nb = vgrid(n, 4);
+  hipLaunchKernelGGL(lanczos_update_kernel, dim3(nb), dim3(VNT), 0, st, (c128 *)p, (const c128 *)v,
+                     (const c128 *)u, n, are, aim, b, partials_dev);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(VNT), 0, st, partials_dev, (int)nb, 1,
+                     partials_dev + nb);
+  DNM_HIP(hipGetLastError());
+  return 0;
+}
+
 int vk_norm2_partials(const void *x, int64_t n, double *partials_dev, hipStream_t st) {
   return vk_mdot(x, n, 1, x, n, partials_dev, st);
 }
