@@ -213,7 +213,7 @@ struct Ops {
   // orthogonalise p against V[:, 0:nv): classical Gram-Schmidt with one
   // refinement pass when needed (the DGKS test SLEPc's BV uses by default,
   // eta = 1/sqrt(2)); coefficients accumulate in h; returns ||p|| afterwards
-  int orthogonalize(void *p, const void *V, int nv, std::vector<zc> &h, double *nrm) {
+  int orthogonalize(void *p, const void *V, int nv, std::vector<zc> &h, double *nrm, int min_passes = 1) {
     std::vector<zc> h1, neg;
     h.assign(nv, zc(0));
     if (nv > 4) {
@@ -235,7 +235,7 @@ struct Ops {
       DNM_TRY(maxpy(p, V, nv, neg));
       DNM_TRY(norm(p, nrm));
       const double before = std::sqrt((*nrm) * (*nrm) + hn2);   // ||p|| before this pass
-      if (*nrm >= 0.7071067811865476 * before) break;            // no cancellation: done
+      if (pass + 1 >= min_passes && *nrm >= 0.7071067811865476 * before) break;   // no cancellation: done
     }
     return 0;
   }
@@ -246,13 +246,27 @@ struct Ops {
 // sqrt(eps) the three-term recurrence is kept (5 vector passes per step);
 // when one crosses it the new vector and its successor are orthogonalised
 // against the whole basis (partial re-orthogonalisation, Simon 1984).
+// Components removed by a re-orthogonalisation pass are not recorded in the projected
+// matrix, so a Ritz pair's true residual exceeds its estimate by about
+// (level at which the pass is triggered) x |H|.  The trigger level therefore follows the
+// requested tolerance: tol/10, at most sqrt(eps) (Simon's semi-orthogonality bound), at
+// least a few times the rounding floor eps1 of a dot product (below that every step is a
+// full pass, which is what full re-orthogonalisation achieves anyway).
+static double pro_threshold(double eps1, double tol) {
+  double t = std::sqrt(2.220446049250313e-16);
+  if (tol > 0 && 0.1 * tol < t) t = 0.1 * tol;
+  if (t < 4.0 * eps1) t = 4.0 * eps1;
+  if (getenv("DNM_PRO_THRESH")) t = atof(getenv("DNM_PRO_THRESH"));
+  return t;
+}
+
 struct LanczosMonitor {
   std::vector<double> alpha, beta;      // alpha[j]; beta[j] = ||r_{j-1}|| (beta[0] = 0)
   std::vector<double> wprev, wcur;      // omega_{j-1,.}, omega_{j,.}
   double eps1 = 0, thresh = 0;
   bool force_next = false;
   int reorths = 0;
-  void reset(int m, double n_global) {
+  void reset(int m, double n_global, double tol) {
     alpha.assign(m + 2, 0.0);
     beta.assign(m + 2, 0.0);
     wprev.assign(m + 2, 0.0);
@@ -261,7 +275,7 @@ struct LanczosMonitor {
     const double eps = 2.220446049250313e-16;
     eps1 = eps * std::sqrt(n_global) / 2.0;
     if (eps1 > 1e-11) eps1 = 1e-11;
-    thresh = std::sqrt(eps);
+    thresh = pro_threshold(eps1, tol);
     force_next = false;
   }
   // step j produced alpha_j and beta_{j+1}; returns true when v_{j+1} needs a full pass
@@ -286,6 +300,88 @@ struct LanczosMonitor {
     const bool need = force_next || worst > thresh;
     if (need) {
       force_next = !force_next;          // the successor of a re-orthogonalised vector gets a pass too
+      for (int k = 0; k <= j; ++k) wcur[k] = eps1;
+      ++reorths;
+    }
+    return need;
+  }
+};
+
+// The same estimate for thick-restart Lanczos.  The basis of a cycle is
+// q_0..q_{l-1} (kept Ritz vectors, H u_i = theta_i u_i + s_i q_l), then Lanczos vectors
+// q_l, q_{l+1}, ...; with T the projected matrix (diag(theta) + spike row/column l +
+// tridiagonal beyond), omega_{j+1,i} = q_{j+1}^H q_i obeys
+//   beta_{j+1} omega_{j+1,i} = sum_k T_{k,i} omega_{j,k} - alpha_j omega_{j,i} - beta_j omega_{j-1,i}   (j > l),
+// the step j = l being orthogonalised against the whole basis explicitly (it has to
+// remove the spike components anyway).
+struct RestartMonitor {
+  int l = 0;
+  std::vector<double> th, sp, alpha, beta, wprev, wcur;
+  double eps1 = 0, thresh = 0;
+  bool force_next = false;
+  int reorths = 0, steps = 0;
+  void init(int m, double n_global, double tol) {
+    const double eps = 2.220446049250313e-16;
+    eps1 = eps * std::sqrt(n_global) / 2.0;
+    if (eps1 > 1e-11) eps1 = 1e-11;
+    thresh = pro_threshold(eps1, tol);
+    alpha.assign(m + 2, 0.0);
+    beta.assign(m + 2, 0.0);
+    wprev.assign(m + 2, 0.0);
+    wcur.assign(m + 2, 0.0);
+  }
+  // start of a cycle: row_l[i] bounds |q_l^H u_i|
+  void begin_cycle(int l_, const std::vector<double> &theta, const std::vector<double> &spike,
+                   const std::vector<double> &row_l) {
+    l = l_;
+    th = theta;
+    sp = spike;
+    std::fill(wprev.begin(), wprev.end(), 0.0);
+    std::fill(wcur.begin(), wcur.end(), 0.0);
+    for (int i = 0; i < l; ++i) wcur[i] = std::max(eps1, i < (int)row_l.size() ? row_l[i] : eps1);
+    wcur[l] = 1.0;
+    force_next = false;
+  }
+  // step j = l was orthogonalised against q_0..q_l explicitly
+  void first_step(double a_l, double b_next) {
+    alpha[l] = a_l;
+    beta[l + 1] = b_next;
+    wprev = wcur;
+    std::fill(wcur.begin(), wcur.end(), 0.0);
+    for (int i = 0; i <= l; ++i) wcur[i] = eps1;
+    wcur[l + 1] = 1.0;
+  }
+  // step j > l produced alpha_j, beta_{j+1} by the three-term recurrence; true: q_{j+1} needs a full pass
+  bool update(int j, double a_j, double b_next) {
+    alpha[j] = a_j;
+    beta[j + 1] = b_next;
+    ++steps;
+    std::vector<double> wnew(wcur.size(), 0.0);
+    double worst = 0.0;
+    if (b_next > 0) {
+      for (int i = 0; i < j; ++i) {
+        double v;
+        if (i < l) {
+          v = th[i] * wcur[i] + sp[i] * wcur[l];
+        } else if (i == l) {
+          v = alpha[l] * wcur[l] + beta[l + 1] * wcur[l + 1];
+          for (int k = 0; k < l; ++k) v += sp[k] * wcur[k];
+        } else {
+          v = beta[i] * wcur[i - 1] + alpha[i] * wcur[i] + beta[i + 1] * wcur[i + 1];
+        }
+        v -= a_j * wcur[i] + beta[j] * wprev[i];
+        v = (v + (v >= 0 ? eps1 : -eps1)) / b_next;
+        wnew[i] = v;
+        worst = std::max(worst, std::fabs(v));
+      }
+    }
+    wnew[j] = eps1;
+    wnew[j + 1] = 1.0;
+    wprev.swap(wcur);
+    wcur.swap(wnew);
+    const bool need = force_next || worst > thresh;
+    if (need) {
+      force_next = !force_next;
       for (int k = 0; k <= j; ++k) wcur[k] = eps1;
       ++reorths;
     }
@@ -398,7 +494,7 @@ int dnm_expm_multiply(dnm_mat *A, const void *x, void *y, int64_t n_local, doubl
     // (one dot + one fused update per step); the scales enter every coefficient on the host.
     std::vector<double> nv(m + 2, 1.0), bet(m + 2, 0.0);
     if (use_pro) {
-      mon.reset(m, (double)Nglob);
+      mon.reset(m, (double)Nglob, tol);
       DNM_HIP(hipMemcpyAsync(vecptr(V, n_local, 0), y, (size_t)n_local * 16, hipMemcpyDeviceToDevice, st));
       nv[0] = beta;
     } else {
@@ -543,14 +639,44 @@ int dnm_eigsolve(dnm_mat *A, int64_t n_local, int nev, int which, double tol, in
   std::vector<zc> h;
   double anorm_est = 0;
 
+  // DNM_EIGS_ORTHO=full: orthogonalise every Lanczos vector against the whole basis (what SLEPc's
+  // Krylov-Schur does); default: partial re-orthogonalisation driven by the omega-recurrence
+  const char *oenv = getenv("DNM_EIGS_ORTHO");
+  const bool use_pro = !(oenv && oenv[0] == 'f');
+  RestartMonitor mon;
+  mon.init(m, (double)Nglob, tol);
+  std::vector<double> row_l;
   while (true) {
     ++its;
+    if (use_pro) mon.begin_cycle(l, theta, spike, row_l);
     for (int j = l; j < m; ++j) {
       void *p = vecptr(V, n_local, j + 1);
       DNM_TRY(ops.mult(vecptr(V, n_local, j), p));
       double bn = 0;
-      DNM_TRY(ops.orthogonalize(p, V, j + 1, h, &bn));
-      alpha[j] = h[j].real();
+      if (!use_pro || j == l) {
+        // the first step of a cycle removes the spike components: whole basis, twice when Ritz vectors are
+        // present (they are orthonormal to sqrt(eps) only under partial re-orthogonalisation)
+        DNM_TRY(ops.orthogonalize(p, V, j + 1, h, &bn, (use_pro && l > 0) ? 2 : 1));
+        alpha[j] = h[j].real();
+        if (use_pro) mon.first_step(alpha[j], bn);
+      } else {
+        std::vector<zc> d;
+        DNM_TRY(ops.mdot(vecptr(V, n_local, j), 1, p, d));
+        alpha[j] = d[0].real();
+        double n2 = 0;
+        DNM_TRY(vec_lanczos_update_host(p, vecptr(V, n_local, j), vecptr(V, n_local, j - 1), n_local, d[0].real(),
+                                        d[0].imag(), betav[j - 1], &n2, st));
+        DNM_TRY(ops.sum(&n2, 1));
+        bn = std::sqrt(n2 > 0 ? n2 : 0.0);
+        if (mon.update(j, alpha[j], bn)) {
+          std::vector<zc> g, c(j + 1);
+          DNM_TRY(ops.mdot(V, j + 1, p, g));
+          for (int i = 0; i <= j; ++i) c[i] = -g[i];
+          DNM_TRY(ops.maxpy(p, V, j + 1, c));
+          DNM_TRY(ops.norm(p, &bn));
+          mon.beta[j + 1] = bn;
+        }
+      }
       betav[j] = bn;
       anorm_est = std::max(anorm_est, std::fabs(alpha[j]) + bn);
       if (bn <= 1e-14 * std::max(1.0, anorm_est)) {
@@ -558,9 +684,13 @@ int dnm_eigsolve(dnm_mat *A, int64_t n_local, int nev, int which, double tol, in
         betav[j] = 0.0;
         DNM_TRY(vk_random(p, n_local, seed + 7919u * (uint64_t)(its * m + j + 1), offset, st));
         double rn = 0;
-        DNM_TRY(ops.orthogonalize(p, V, j + 1, h, &rn));
+        DNM_TRY(ops.orthogonalize(p, V, j + 1, h, &rn, 2));
         DNM_CHECK(rn > 0, "Lanczos breakdown: could not extend the basis");
         DNM_TRY(vk_scale(p, n_local, 1.0 / rn, 0, st));
+        if (use_pro) {
+          mon.beta[j + 1] = 0.0;
+          for (int k = 0; k <= j; ++k) mon.wcur[k] = mon.eps1;
+        }
       } else {
         DNM_TRY(vk_scale(p, n_local, 1.0 / bn, 0, st));
       }
@@ -608,6 +738,12 @@ int dnm_eigsolve(dnm_mat *A, int64_t n_local, int nev, int which, double tol, in
     DNM_TRY(vk_basis_update(V, n_local, m, keep, n_local, sd, st));
     DNM_HIP(hipMemcpyAsync(vecptr(V, n_local, keep), vecptr(V, n_local, m), (size_t)n_local * 16,
                            hipMemcpyDeviceToDevice, st));
+    if (use_pro) {
+      // |q_m^H u_o| <= sum_k |S_ko| |omega_{m,k}|: the new q_l against the rotated basis
+      row_l.assign(keep, 0.0);
+      for (int o = 0; o < keep; ++o)
+        for (int k = 0; k < m; ++k) row_l[o] += std::fabs(Sm[(size_t)order[o] * m + k]) * std::fabs(mon.wcur[k]);
+    }
     l = keep;
   }
 
@@ -620,8 +756,19 @@ int dnm_eigsolve(dnm_mat *A, int64_t n_local, int nev, int which, double tol, in
     const double *sd = nullptr;
     DNM_TRY(vec_upload_coefs(Ssel.data(), Ssel.size(), st, &sd));
     DNM_TRY(vk_basis_update(V, n_local, m, nout, n_local, sd, st));
+    if (use_pro)     // a semi-orthogonal basis leaves the Ritz vectors orthonormal to sqrt(eps) only: Gram-Schmidt
+      for (int o = 0; o < nout; ++o) {   // (inside a degenerate level the gap argument does not protect them)
+        double nn = 0;
+        if (o > 0) DNM_TRY(ops.orthogonalize(vecptr(V, n_local, o), V, o, h, &nn));
+        else DNM_TRY(ops.norm(vecptr(V, n_local, o), &nn));
+        DNM_CHECK(nn > 0, "zero Ritz vector");
+        DNM_TRY(vk_scale(vecptr(V, n_local, o), n_local, 1.0 / nn, 0, st));
+      }
     DNM_HIP(hipMemcpyAsync(evecs, V, (size_t)nout * (size_t)n_local * 16, hipMemcpyDeviceToDevice, st));
   }
+  if (getenv("DNM_KRYLOV_DEBUG"))
+    fprintf(stderr, "dnm_eigsolve: %d restarts, %d matvecs, %d three-term steps, %d full re-orthogonalisations\n", its,
+            ops.matvecs, mon.steps, mon.reorths);
   DNM_HIP(hipStreamSynchronize(st));
   stats->its = its;
   stats->matvecs = ops.matvecs;
