@@ -96,6 +96,7 @@ SIGNATURES = {
                                  C.POINTER(vp)]),
     "dnm_check_conserves": (C.c_int, [C.c_int64, i64p, i64p, i64p, f64p, C.POINTER(Subspace),
                                       C.POINTER(Subspace), C.c_int, C.POINTER(C.c_int), vp]),
+    "dnm_reduced_density_matrix": (C.c_int, [vp, C.POINTER(Subspace), C.c_int, i64p, vp, vp]),
     "dnm_mat_destroy": (C.c_int, [vp]),
     "dnm_mat_sizes": (C.c_int, [vp, i64p, i64p, i64p, i64p]),
     "dnm_mat_precompute_diagonal": (C.c_int, [vp, vp]),

@@ -382,6 +382,30 @@ def check_conserves(masks, mask_offsets, signs, coeffs, left_subspace, right_sub
     return bool(res.value)
 
 
+def reduced_density_matrix(vec, subspace, keep):
+    """Mirror of ``bpetsc.reduced_density_matrix`` (bpetsc.pyx:245-276): host array of
+    shape (2^len(keep),)*2 on rank 0, ``[[-1]]`` elsewhere."""
+    import torch
+    config._initialize()
+    keep = np.ascontiguousarray(keep, dtype=np.int64)
+    d = _dist()
+    x = vec.array
+    if d is not None and d.get_world_size() > 1:
+        # the reference scatters the state to rank 0 (bpetsc_template_1.c:126-141); so do we
+        parts = [torch.empty(split_ownership(vec.size, config.world_size, q)[1], dtype=x.dtype, device=x.device)
+                 for q in range(config.world_size)] if config.rank == 0 else None
+        d.gather(x, parts, dst=0)
+        if config.rank != 0:
+            return np.array([[-1]], dtype=np.complex128)
+        x = torch.cat(parts)
+    K = 1 << keep.size
+    rho = torch.empty(K * K, dtype=torch.complex128, device=x.device)
+    _lib.check(_lib.lib().dnm_reduced_density_matrix(
+        C.c_void_p(x.data_ptr()), C.byref(subspace['data']), keep.size, _lib.p64(keep),
+        C.c_void_p(rho.data_ptr()), _stream()))
+    return rho.cpu().numpy().reshape(K, K)
+
+
 def precompute_diagonal(mat):
     """Mirror of ``bpetsc.precompute_diagonal`` (bpetsc.pyx:141-147)."""
     mat.precompute_diagonal()

@@ -194,6 +194,75 @@ def eigsolve(H, getvecs=False, nev=1, which='lowest', target=None, tol=None, sub
 eigsolve.last_stats = None
 
 
+def reduced_density_matrix(state, keep):
+    """Reduced density matrix of ``state`` on the (sorted) spins ``keep``, everything else
+    traced out (computations.py:294-349).  Computed on the GPU; returned as a numpy array on
+    process 0, ``[[-1]]`` on the other processes, as the reference does."""
+    from . import backend
+    state.assert_initialized()
+    config._initialize()
+    if not state.subspace.product_state_basis:
+        raise ValueError('reduced density matrices currently only supported '
+                         'for product state basis subspace types.')
+    keep = np.array(keep, dtype=np.int64)
+    if keep.size == 0:
+        return np.array([[1]], dtype=np.complex128)
+    for n in range(1, keep.size):
+        if keep[n] <= keep[n - 1]:
+            raise ValueError('keep array must be strictly increasing')
+    if any(idx < 0 for idx in keep):
+        raise ValueError('spin index less than zero. keep: %s' % str(keep))
+    if any(idx >= state.L for idx in keep):
+        raise ValueError('spin index greater than spin chain length minus one. keep: %s' % str(keep))
+    return backend.reduced_density_matrix(state.vec, state.subspace._to_c(), keep)
+
+
+def entanglement_entropy(state, keep):
+    """Bipartite entanglement entropy across the cut keep | rest (computations.py:351-383)."""
+    reduced = reduced_density_matrix(state, keep)
+    if reduced[0, 0] == -1:      # everything is computed on process 0
+        return -1
+    return dm_entanglement_entropy(reduced)
+
+
+def dm_entanglement_entropy(dm):
+    """Von Neumann entropy of a density matrix (computations.py:385-408)."""
+    w = np.linalg.eigvalsh(dm)
+    log = np.zeros(w.shape)
+    np.log(w, where=w > 0, out=log)
+    return -np.sum(w * log)
+
+
+def renyi_entropy(state, keep, alpha, method='eigsolve'):
+    """Renyi entropy of the reduced density matrix (computations.py:410-454)."""
+    reduced = reduced_density_matrix(state, keep)
+    if reduced[0, 0] == -1:
+        return -1
+    return dm_renyi_entropy(reduced, alpha, method)
+
+
+def dm_renyi_entropy(dm, alpha, method='eigsolve'):
+    """H_alpha = log Tr rho^alpha / (1 - alpha), with the alpha = 0, 1, 'inf' limits
+    (computations.py:456-507)."""
+    if alpha == 0:
+        eigs = np.linalg.eigvalsh(dm)
+        return np.log(np.sum(eigs > 1E-10))
+    if alpha == 1:
+        return dm_entanglement_entropy(dm)
+    if alpha == 'inf':
+        return -np.log(np.max(np.linalg.eigvalsh(dm)))
+    if method == 'matrix_power':
+        if alpha == int(alpha):
+            trace = np.trace(np.linalg.matrix_power(dm, int(alpha))).real
+        else:
+            raise TypeError('alpha must be an integer for matrix_power method.')
+    elif method == 'eigsolve':
+        trace = np.sum(np.linalg.eigvalsh(dm) ** alpha)
+    else:
+        raise ValueError('Valid methods are "eigsolve" and "matrix_power"')
+    return 1 / (1 - alpha) * np.log(trace)
+
+
 def get_tstep(ncv, nrm, tol=1E-7):
     """First-step size of an Expokit solve (computations.py:511-519)."""
     f = ((ncv + 1) / 2.72) ** (ncv + 1) * np.sqrt(2 * np.pi * (ncv + 1))

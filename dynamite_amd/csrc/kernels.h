@@ -61,6 +61,20 @@ int launch_norm(const DevMsc &msc, const SubView &left, const SubView &right, in
 int launch_conserves(const DevMsc &msc, const double *coeffs_im, const SubView &left, const SubView &right,
                      int64_t N, int *bad, hipStream_t st);
 
+// Reduced density matrix.  Bit layout of a kept / traced configuration: segment i takes the next len[i]
+// bits of the compact value and puts them at spin position pos[i] (segments in ascending order).
+struct RdmGeom {
+  int32_t k, L;               // kept spins, all spins
+  int32_t nseg_keep, nseg_tr;
+  int8_t klen[33], kpos[33];
+  int8_t tlen[33], tpos[33];
+};
+// workgroup geometry for a given RdmGeom and the scratch it needs
+void rdm_plan(const RdmGeom &geo, int *logtm, int *ntiles, int *nsplit, int64_t *chunks_per_split,
+              size_t *partial_bytes);
+// rho (2^k x 2^k complex128, row-major) from the state x on `sub`; partial: scratch of rdm_plan's size
+int launch_rdm(const void *x, const SubView &sub, const RdmGeom &geo, void *partial, void *rho, hipStream_t st);
+
 // ---- vector kernels ---------------------------------------------------------
 int vk_set(void *x, int64_t n, double re, double im, hipStream_t st);
 int vk_scale(void *x, int64_t n, double re, double im, hipStream_t st);

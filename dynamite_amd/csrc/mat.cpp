@@ -409,6 +409,62 @@ int dnm_check_conserves(int64_t nmasks, const int64_t *masks, const int64_t *mas
   return 0;
 }
 
+// ---- reduced density matrix -----------------------------------------------------------
+int dnm_reduced_density_matrix(const void *x, const dnm_subspace *sub, int keep_size, const int64_t *keep,
+                               void *rho, void *stream) {
+  DNM_CHECK(x && sub && rho && keep_size >= 0 && (keep_size == 0 || keep), "null argument");
+  SubOwned s;
+  DNM_TRY(s.init(sub, true));
+  const int L = s.host.L;
+  DNM_CHECK(keep_size <= L, "more kept spins than spins");
+  DNM_CHECK(keep_size <= 15, "reduced density matrix of %d spins (4^%d entries) is too large", keep_size, keep_size);
+  for (int i = 0; i < keep_size; ++i) {
+    DNM_CHECK(keep[i] >= 0 && keep[i] < L, "kept spin index %lld out of range [0, %d)", (long long)keep[i], L);
+    // bpetsc_template_1.c:117-121
+    DNM_CHECK(i == 0 || keep[i] > keep[i - 1], "keep array must be strictly increasing");
+  }
+  RdmGeom geo;
+  memset(&geo, 0, sizeof(geo));
+  geo.k = keep_size;
+  geo.L = L;
+  uint64_t keepmask = 0;
+  for (int i = 0; i < keep_size; ++i) keepmask |= (uint64_t)1 << keep[i];
+  for (int pos = 0; pos < L;) {     // runs of kept / traced positions
+    const bool kept = (keepmask >> pos) & 1;
+    int end = pos;
+    while (end < L && (((keepmask >> end) & 1) != 0) == kept) ++end;
+    if (kept) {
+      geo.klen[geo.nseg_keep] = (int8_t)(end - pos);
+      geo.kpos[geo.nseg_keep++] = (int8_t)pos;
+    } else {
+      geo.tlen[geo.nseg_tr] = (int8_t)(end - pos);
+      geo.tpos[geo.nseg_tr++] = (int8_t)pos;
+    }
+    pos = end;
+  }
+  int logtm, ntiles, nsplit;
+  int64_t cps;
+  size_t pbytes;
+  rdm_plan(geo, &logtm, &ntiles, &nsplit, &cps, &pbytes);
+  // scratch for the partial tiles: small ones are kept between calls (hipMalloc costs more than the kernel)
+  static DevBuf cached;
+  DevBuf big;
+  void *scratch = nullptr;
+  if (pbytes <= ((size_t)1 << 30)) {
+    if (cached.bytes < pbytes) {
+      cached.release();
+      DNM_TRY(cached.alloc(pbytes));
+    }
+    scratch = cached.p;
+  } else {
+    DNM_TRY(big.alloc(pbytes));
+    scratch = big.p;
+  }
+  DNM_TRY(launch_rdm(x, s.dev, geo, scratch, rho, S(stream)));
+  DNM_HIP(hipStreamSynchronize(S(stream)));     // `big` is released on return
+  return 0;
+}
+
 // ---- shell matrix -------------------------------------------------------------
 int dnm_mat_create(int64_t nmasks, const int64_t *masks, const int64_t *mask_offsets,
                    const int64_t *signs, const double *coeffs, const dnm_subspace *left,

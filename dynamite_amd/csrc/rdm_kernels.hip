@@ -1,0 +1,285 @@
+// Reduced density matrix  rho[a,b] = sum_tr psi(a,tr) conj(psi(b,tr))  of a state on any
+// subspace (reference: rdm_<SUBSPACE>, bpetsc_template_1.c:87-165, serial on rank 0).
+//
+// psi(a,tr) = x[S2I(deposit(a, kept bits) | deposit(tr, traced bits))], zero outside the
+// subspace.  The sum is a Hermitian rank-T update (ZHERK) of a K x K matrix, K = 2^k, with
+// the operand gathered on the fly -- the K x T matrix is never materialised.  One workgroup
+// owns a TM x TM tile of the lower triangle and a slice of the traced configurations:
+// chunks of 1024 amplitudes per operand are staged in LDS, every thread keeps a 4 x 4
+// block of complex accumulators in registers; for tiles smaller than 64 x 64 the threads
+// split the traced index among themselves and combine at the end (wave shuffles, then LDS).
+// Partial tiles go to a scratch buffer and a second kernel sums the slices and mirrors the
+// upper triangle, so the result is deterministic (no atomics).
+#include "kernels.h"
+
+namespace dnm {
+
+typedef double2 c128;
+
+constexpr int RDM_NT = 256;
+constexpr int RDM_STAGE = 1024;   // amplitudes per operand per chunk
+
+template <int ST>
+__device__ __forceinline__ c128 rdm_fetch(const c128 *__restrict__ x, uint64_t state, const SubView &sub) {
+  const int64_t idx = Sub<ST>::s2i((int64_t)state, sub);
+  return idx >= 0 ? x[idx] : make_double2(0.0, 0.0);
+}
+
+__device__ __forceinline__ uint64_t rdm_deposit(uint64_t v, const int8_t *len, const int8_t *pos, int nseg) {
+  uint64_t out = 0;
+  for (int i = 0; i < nseg; ++i) {
+    out |= (v & (((uint64_t)1 << len[i]) - 1)) << pos[i];
+    v >>= len[i];
+  }
+  return out;
+}
+
+template <int ST, int LOGTM>
+__global__ void __launch_bounds__(RDM_NT)
+rdm_tile_kernel(const c128 *__restrict__ x, const SubView sub, const RdmGeom geo, int64_t chunks_per_split,
+                int ntiles, c128 *__restrict__ partial) {
+  constexpr int TM = 1 << LOGTM;
+  constexpr int SUBT = TM / 4;            // 4x4 register blocks per tile side
+  constexpr int NSUB = SUBT * SUBT;       // threads that cover one tile
+  constexpr int G = RDM_NT / NSUB;        // groups splitting the traced index
+  constexpr int TK = RDM_STAGE / TM;      // traced configurations per chunk
+  __shared__ c128 As[RDM_STAGE];
+  __shared__ c128 Bs[RDM_STAGE];
+  __shared__ uint64_t pa[TM], pb[TM];
+
+  const int tid = threadIdx.x;
+  // tile (ti, tj), tj <= ti, from the linear lower-triangle index
+  const int tile = blockIdx.x;
+  int ti = (int)((sqrt(8.0 * (double)tile + 1.0) - 1.0) * 0.5);
+  while ((int64_t)(ti + 1) * (ti + 2) / 2 <= tile) ++ti;
+  while ((int64_t)ti * (ti + 1) / 2 > tile) --ti;
+  const int tj = tile - (int)((int64_t)ti * (ti + 1) / 2);
+  const bool diag_tile = ti == tj;
+  const int64_t K = (int64_t)1 << geo.k, T = (int64_t)1 << (geo.L - geo.k);
+  const int64_t a0 = (int64_t)ti * TM, b0 = (int64_t)tj * TM;
+
+  if (tid < TM) {
+    pa[tid] = rdm_deposit((uint64_t)(a0 + tid), geo.klen, geo.kpos, geo.nseg_keep);
+    pb[tid] = rdm_deposit((uint64_t)(b0 + tid), geo.klen, geo.kpos, geo.nseg_keep);
+  }
+  __syncthreads();
+
+  const int sub_id = tid % NSUB, g = tid / NSUB;
+  const int ty = sub_id / SUBT, tx = sub_id % SUBT;
+  double accr[4][4], acci[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) accr[i][j] = acci[i][j] = 0.0;
+
+  const int64_t nchunks = (T + TK - 1) / TK;
+  const int64_t c_begin = (int64_t)blockIdx.y * chunks_per_split;
+  int64_t c_end = c_begin + chunks_per_split;
+  if (c_end > nchunks) c_end = nchunks;
+  const c128 *Bp = diag_tile ? As : Bs;
+
+  for (int64_t c = c_begin; c < c_end; ++c) {
+    // stage: element e -> (row r, traced slot t); consecutive threads take consecutive rows
+#pragma unroll
+    for (int e = tid; e < RDM_STAGE; e += RDM_NT) {
+      const int r = e % TM, t = e / TM;
+      const int64_t tr = c * TK + t;
+      c128 va = make_double2(0.0, 0.0), vb = va;
+      if (tr < T) {
+        const uint64_t pt = rdm_deposit((uint64_t)tr, geo.tlen, geo.tpos, geo.nseg_tr);
+        if (a0 + r < K) va = rdm_fetch<ST>(x, pa[r] | pt, sub);
+        if (!diag_tile && b0 + r < K) vb = rdm_fetch<ST>(x, pb[r] | pt, sub);
+      }
+      As[e] = va;
+      if (!diag_tile) Bs[e] = vb;
+    }
+    __syncthreads();
+    for (int t = g; t < TK; t += G) {
+      c128 a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = As[t * TM + ty * 4 + i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = Bp[t * TM + tx * 4 + j];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          // a * conj(b)
+          accr[i][j] = fma(a[i].x, b[j].x, accr[i][j]);
+          accr[i][j] = fma(a[i].y, b[j].y, accr[i][j]);
+          acci[i][j] = fma(a[i].y, b[j].x, acci[i][j]);
+          acci[i][j] = fma(-a[i].x, b[j].y, acci[i][j]);
+        }
+    }
+    __syncthreads();
+  }
+
+  // combine the groups: lanes of a wave that hold the same register block, then the waves
+  if (G > 1) {
+    if (NSUB < 64) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          for (int off = NSUB; off < 64; off <<= 1) {
+            accr[i][j] += __shfl_xor(accr[i][j], off, 64);
+            acci[i][j] += __shfl_xor(acci[i][j], off, 64);
+          }
+    }
+    constexpr int LIVE = NSUB < 64 ? NSUB : 64;       // lanes per wave holding distinct blocks
+    double *red = reinterpret_cast<double *>(As);     // LIVE * 32 doubles <= 16 KB
+    const int wave = tid >> 6, lane = tid & 63;
+    for (int w = 1; w < RDM_NT / 64; ++w) {
+      __syncthreads();
+      if (wave == w && lane < LIVE) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            red[(lane * 16 + i * 4 + j) * 2] = accr[i][j];
+            red[(lane * 16 + i * 4 + j) * 2 + 1] = acci[i][j];
+          }
+      }
+      __syncthreads();
+      if (wave == 0 && lane < LIVE) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            accr[i][j] += red[(lane * 16 + i * 4 + j) * 2];
+            acci[i][j] += red[(lane * 16 + i * 4 + j) * 2 + 1];
+          }
+      }
+    }
+  }
+  if (tid < NSUB) {
+    c128 *out = partial + ((int64_t)blockIdx.y * ntiles + tile) * (TM * TM);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) out[(ty * 4 + i) * TM + tx * 4 + j] = make_double2(accr[i][j], acci[i][j]);
+  }
+}
+
+// rho = sum over slices of the partial tiles; the upper triangle is the conjugate transpose
+template <int LOGTM>
+__global__ void __launch_bounds__(RDM_NT)
+rdm_finalize_kernel(const c128 *__restrict__ partial, int ntiles, int nsplit, int64_t K, c128 *__restrict__ rho) {
+  constexpr int TM = 1 << LOGTM;
+  const int tile = blockIdx.x;
+  int ti = (int)((sqrt(8.0 * (double)tile + 1.0) - 1.0) * 0.5);
+  while ((int64_t)(ti + 1) * (ti + 2) / 2 <= tile) ++ti;
+  while ((int64_t)ti * (ti + 1) / 2 > tile) --ti;
+  const int tj = tile - (int)((int64_t)ti * (ti + 1) / 2);
+  for (int e = threadIdx.x; e < TM * TM; e += RDM_NT) {
+    const int r = e / TM, cidx = e % TM;
+    const int64_t a = (int64_t)ti * TM + r, b = (int64_t)tj * TM + cidx;
+    if (a >= K || b >= K) continue;
+    double sr = 0.0, si = 0.0;
+    for (int s = 0; s < nsplit; ++s) {
+      const c128 v = partial[((int64_t)s * ntiles + tile) * (TM * TM) + e];
+      sr += v.x;
+      si += v.y;
+    }
+    if (a == b) si = 0.0;     // |psi|^2 sums: the reference's a * conj(a) has no imaginary part either
+    rho[a * K + b] = make_double2(sr, si);
+    if (ti != tj) rho[b * K + a] = make_double2(sr, -si);
+  }
+}
+
+// tree stage of the slice sum: out[s'] = sum of up to `fan` consecutive slices of `in` (whole slices are
+// nelem = ntiles * TM * TM amplitudes, consecutive threads read consecutive amplitudes)
+constexpr int RDM_FAN = 32;
+__global__ void __launch_bounds__(RDM_NT)
+rdm_reduce_kernel(const c128 *__restrict__ in, c128 *__restrict__ out, int64_t nelem, int nsplit_in) {
+  const int64_t e = (int64_t)blockIdx.x * RDM_NT + threadIdx.x;
+  if (e >= nelem) return;
+  const int s0 = blockIdx.y * RDM_FAN;
+  int s1 = s0 + RDM_FAN;
+  if (s1 > nsplit_in) s1 = nsplit_in;
+  double sr = 0.0, si = 0.0;
+  for (int s = s0; s < s1; ++s) {
+    const c128 v = in[(int64_t)s * nelem + e];
+    sr += v.x;
+    si += v.y;
+  }
+  out[(int64_t)blockIdx.y * nelem + e] = make_double2(sr, si);
+}
+
+template <int ST, int LOGTM>
+static int rdm_launch(const c128 *x, const SubView &sub, const RdmGeom &geo, int ntiles, int nsplit,
+                      int64_t chunks_per_split, c128 *partial, c128 *rho, hipStream_t st) {
+  constexpr int TM = 1 << LOGTM;
+  hipLaunchKernelGGL((rdm_tile_kernel<ST, LOGTM>), dim3((unsigned)ntiles, (unsigned)nsplit), dim3(RDM_NT), 0, st, x,
+                     sub, geo, chunks_per_split, ntiles, partial);
+  // sum the slices by a fan-in-32 tree (ping-pong inside the scratch), then mirror
+  const int64_t nelem = (int64_t)ntiles * TM * TM;
+  c128 *cur = partial, *nxt = partial + (int64_t)nsplit * nelem;
+  while (nsplit > RDM_FAN) {
+    const int nout = (nsplit + RDM_FAN - 1) / RDM_FAN;
+    hipLaunchKernelGGL(rdm_reduce_kernel, dim3((unsigned)((nelem + RDM_NT - 1) / RDM_NT), (unsigned)nout),
+                       dim3(RDM_NT), 0, st, cur, nxt, nelem, nsplit);
+    cur = nxt;
+    nxt = cur + (int64_t)nout * nelem;
+    nsplit = nout;
+  }
+  hipLaunchKernelGGL((rdm_finalize_kernel<LOGTM>), dim3((unsigned)ntiles), dim3(RDM_NT), 0, st, cur, ntiles,
+                     nsplit, (int64_t)1 << geo.k, rho);
+  DNM_HIP(hipGetLastError());
+  return 0;
+}
+
+template <int ST>
+static int rdm_dispatch_tm(int logtm, const c128 *x, const SubView &sub, const RdmGeom &geo, int ntiles, int nsplit,
+                           int64_t cps, c128 *partial, c128 *rho, hipStream_t st) {
+  switch (logtm) {
+    case 2: return rdm_launch<ST, 2>(x, sub, geo, ntiles, nsplit, cps, partial, rho, st);
+    case 3: return rdm_launch<ST, 3>(x, sub, geo, ntiles, nsplit, cps, partial, rho, st);
+    case 4: return rdm_launch<ST, 4>(x, sub, geo, ntiles, nsplit, cps, partial, rho, st);
+    case 5: return rdm_launch<ST, 5>(x, sub, geo, ntiles, nsplit, cps, partial, rho, st);
+    case 6: return rdm_launch<ST, 6>(x, sub, geo, ntiles, nsplit, cps, partial, rho, st);
+  }
+  set_error("internal: bad RDM tile size");
+  return 1;
+}
+
+void rdm_plan(const RdmGeom &geo, int *logtm, int *ntiles, int *nsplit, int64_t *chunks_per_split,
+              size_t *partial_bytes) {
+  int ltm = geo.k < 2 ? 2 : (geo.k > 6 ? 6 : geo.k);
+  const int64_t K = (int64_t)1 << geo.k, T = (int64_t)1 << (geo.L - geo.k);
+  const int64_t TM = (int64_t)1 << ltm, TK = RDM_STAGE / TM;
+  const int64_t side = (K + TM - 1) / TM;
+  const int64_t nt = side * (side + 1) / 2;
+  const int64_t nchunks = (T + TK - 1) / TK;
+  int64_t ns = (4096 + nt - 1) / nt;          // enough workgroups to fill 256 CUs several times over
+  if (ns > nchunks) ns = nchunks;
+  if (ns < 1) ns = 1;
+  int64_t cps = (nchunks + ns - 1) / ns;
+  ns = (nchunks + cps - 1) / cps;
+  *logtm = ltm;
+  *ntiles = (int)nt;
+  *nsplit = (int)ns;
+  *chunks_per_split = cps;
+  // slices + the intermediate levels of the fan-in-32 sum (ns/32 + ns/1024 + ... < ns/31 + 2)
+  *partial_bytes = ((size_t)ns + (size_t)ns / 31 + 2) * (size_t)nt * (size_t)(TM * TM) * sizeof(c128);
+}
+
+int launch_rdm(const void *x, const SubView &sub, const RdmGeom &geo, void *partial, void *rho, hipStream_t st) {
+  int logtm, ntiles, nsplit;
+  int64_t cps;
+  size_t pbytes;
+  rdm_plan(geo, &logtm, &ntiles, &nsplit, &cps, &pbytes);
+  const c128 *xp = (const c128 *)x;
+  c128 *pp = (c128 *)partial, *rp = (c128 *)rho;
+  switch (sub.type) {
+    case DNM_FULL: return rdm_dispatch_tm<DNM_FULL>(logtm, xp, sub, geo, ntiles, nsplit, cps, pp, rp, st);
+    case DNM_PARITY: return rdm_dispatch_tm<DNM_PARITY>(logtm, xp, sub, geo, ntiles, nsplit, cps, pp, rp, st);
+    case DNM_SPIN_CONSERVE:
+      return rdm_dispatch_tm<DNM_SPIN_CONSERVE>(logtm, xp, sub, geo, ntiles, nsplit, cps, pp, rp, st);
+    case DNM_EXPLICIT: return rdm_dispatch_tm<DNM_EXPLICIT>(logtm, xp, sub, geo, ntiles, nsplit, cps, pp, rp, st);
+  }
+  set_error("bad subspace type");
+  return 1;
+}
+
+}  // namespace dnm

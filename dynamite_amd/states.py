@@ -146,6 +146,11 @@ class State:
         self.assert_initialized()
         return self.vec.to_numpy(to_all)
 
+    def entanglement_entropy(self, keep):
+        """states.py:362 -> computations.entanglement_entropy."""
+        from . import computations
+        return computations.entanglement_entropy(self, keep)
+
     # ------------------------------------------------------------------ BLAS-1
     def dot(self, x):
         self.assert_initialized()

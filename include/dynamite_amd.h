@@ -121,6 +121,13 @@ int dnm_check_conserves(int64_t nmasks, const int64_t *masks, const int64_t *mas
                         const int64_t *signs, const double *coeffs,
                         const dnm_subspace *left, const dnm_subspace *right,
                         int xparity, int *result, void *stream);
+/* ReducedDensityMatrix(vec, sub_type, sub_data, keep_size, keep, triang, rtn_dim, rtn)
+ * (bpetsc_impl.h:52-63, bpetsc_template_1.c:87-165, bpetsc.pyx:245-276): the density
+ * matrix of the spins keep[0] < keep[1] < ... of the state x (device pointer, the
+ * whole vector), all other spins traced out.  rho: device buffer of 4^keep_size
+ * complex128, row-major, bit i of a row/column index = spin keep[i]. */
+int dnm_reduced_density_matrix(const void *x, const dnm_subspace *sub, int keep_size,
+                               const int64_t *keep, void *rho, void *stream);
 /* MATOP_DESTROY -> MatDestroyCtx_GPU (bcuda_template_2.cu:110-139) */
 int dnm_mat_destroy(dnm_mat *A);
 /* MatGetSize / MatGetLocalSize */

@@ -475,3 +475,54 @@ int orc_check_conserves(const orc_msc *msc, const orc_subspace *left,
   *result = ok;
   return 0;
 }
+
+
+/* ------------------------------------------------------------------ */
+/* Reduced density matrix (bpetsc_template_1.c:15-165)                */
+/* ------------------------------------------------------------------ */
+
+/* combine_states, :30-56: interleave the kept and the traced bits (keep sorted) */
+static orc_int rdm_combine(orc_int keep_state, orc_int tr_state, const orc_int *keep,
+                           orc_int keep_size, orc_int L)
+{
+  orc_int rtn = 0, keep_idx = 0, tr_idx = 0;
+  for (orc_int pos = 0; pos < L; ++pos) {
+    orc_int bit;
+    if (keep_idx < keep_size && pos == keep[keep_idx]) {
+      bit = (keep_state >> keep_idx) & 1;
+      ++keep_idx;
+    } else {
+      bit = (tr_state >> tr_idx) & 1;
+      ++tr_idx;
+    }
+    rtn |= bit << pos;
+  }
+  return rtn;
+}
+
+int orc_rdm(const orc_subspace *sub, const orc_cplx *x, orc_int keep_size,
+            const orc_int *keep, orc_cplx *rtn)
+{
+  for (orc_int i = 1; i < keep_size; ++i)
+    if (keep[i] <= keep[i - 1]) return 1;                       /* :117-121 */
+  orc_int kd = (orc_int)1 << keep_size;
+  orc_int *st = (orc_int *)malloc(sizeof(orc_int) * (size_t)kd);
+  orc_cplx *cv = (orc_cplx *)malloc(sizeof(orc_cplx) * (size_t)kd);
+  memset(rtn, 0, sizeof(orc_cplx) * (size_t)kd * (size_t)kd);
+  orc_int tr_dim = (orc_int)1 << (sub->L - keep_size);          /* :150 */
+  for (orc_int tr = 0; tr < tr_dim; ++tr) {
+    orc_int nf = 0;                                             /* fill_combine_array, :58-85 */
+    for (orc_int ks = 0; ks < kd; ++ks) {
+      orc_int idx = orc_s2i(rdm_combine(ks, tr, keep, keep_size, sub->L), sub);
+      if (idx != -1) { st[nf] = ks; cv[nf] = x[idx]; ++nf; }
+    }
+    for (orc_int i = 0; i < nf; ++i) {                          /* :153-159 */
+      orc_int off = st[i] * kd;
+      orc_cplx a = cv[i];
+      for (orc_int j = 0; j < nf; ++j) rtn[off + st[j]] += a * conj(cv[j]);
+    }
+  }
+  free(st);
+  free(cv);
+  return 0;
+}

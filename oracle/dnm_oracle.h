@@ -127,4 +127,13 @@ int orc_max_threads(void);
 #ifdef __cplusplus
 }
 #endif
+
+/* rdm_<SUBSPACE> (bpetsc_template_1.c:15-165): reduced density matrix of the state x
+ * on the spins keep[0] < keep[1] < ... (bit i of a kept configuration is spin keep[i],
+ * reduce_state :15-28).  rtn is (2^keep_size)^2 row-major, rtn[i*dim+j] = sum over the
+ * traced configurations of psi(i,tr) conj(psi(j,tr)), psi = 0 outside the subspace
+ * (fill_combine_array :58-85).  Returns 1 if keep is not strictly increasing (:117-121). */
+int orc_rdm(const orc_subspace *sub, const orc_cplx *x, orc_int keep_size,
+            const orc_int *keep, orc_cplx *rtn);
+
 #endif

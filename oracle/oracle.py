@@ -77,6 +77,7 @@ def lib():
         L.orc_matvec_fast_ranks.argtypes = [mp, sp, _f64p, C.c_void_p, C.c_void_p, C.c_int]
         L.orc_infnorm.argtypes = [mp, sp, sp, _f64p]
         L.orc_check_conserves.argtypes = [mp, sp, sp, C.POINTER(C.c_int)]
+        L.orc_rdm.argtypes = [sp, C.c_void_p, C.c_int64, _i64p, C.c_void_p]
         L.orc_max_threads.restype = C.c_int
         _lib = L
     return _lib
@@ -296,6 +297,18 @@ def check_conserves(msc, left, right):
     r = C.c_int()
     lib().orc_check_conserves(msc.ref, left.ref, right.ref, C.byref(r))
     return bool(r.value)
+
+
+def rdm(sub, x, keep):
+    """Reduced density matrix on the spins ``keep`` (bpetsc_template_1.c:87-165)."""
+    keep = np.ascontiguousarray(keep, dtype=np.int64)
+    x = np.ascontiguousarray(x, dtype=np.complex128)
+    assert x.size == sub.dim
+    k = keep.size
+    out = np.zeros((1 << k, 1 << k), dtype=np.complex128)
+    if lib().orc_rdm(sub.ref, x.ctypes.data, k, _p64(keep), out.ctypes.data):
+        raise ValueError('keep array must be strictly increasing')
+    return out
 
 
 def max_threads():

@@ -14,7 +14,7 @@ from dynamite_amd import _lib, models, backend
 from dynamite_amd.computations import MaxIterationsError, ConvergenceError
 from dynamite_amd.operators import Operator
 from dynamite_amd.states import State, UninitializedError
-from dynamite_amd.subspaces import Full, Parity, SpinConserve, XParity
+from dynamite_amd.subspaces import Full, Parity, SpinConserve, XParity, Explicit
 from gpu_util import vec_from, rand_state
 
 pytestmark = pytest.mark.gpu
@@ -351,3 +351,89 @@ def test_xparity_convert_state(parent, sector):
     with pytest.raises(ValueError):
         sub.convert_state(State(L=L, subspace=Full(L=L) if parent != "full" else Parity("odd", L=L),
                                 state="random", seed=1))
+
+
+# ------------------------------------------------------------------ reduced density matrix / entropies
+
+def test_rdm_known_answers_gpu(known):
+    """tests/integration/test_rdm.py: error cases (:70-86), empty keep (:88-103), complex
+    sign (:105-122), the L=4 tables with entanglement / Renyi entropies (:124-192)."""
+    from conftest import cplx, cmatrix
+    from dynamite_amd.computations import reduced_density_matrix, renyi_entropy
+    r = known["rdm"]
+    st = State(L=4, state='U' * 4)
+    for bad in ([-1, 0], [0, 1, 50], [1, 0]):
+        with pytest.raises(ValueError):
+            reduced_density_matrix(st, bad)
+    e = r["empty_keep"]
+    s2 = _state_from(Full(L=2), [cplx(v) for v in e["state"]])
+    assert np.array_equal(reduced_density_matrix(s2, []), cmatrix(e["dm"]))
+    cs = r["complex_sign"]
+    s2 = _state_from(Full(L=2), [cplx(v) for v in cs["state"]])
+    assert np.allclose(reduced_density_matrix(s2, cs["keep"]), cmatrix(cs["dm"]), atol=1e-15)
+    s4 = _state_from(Full(L=4), [cplx(v) for v in r["L4"]["state"]])
+    for c in r["L4"]["cases"]:
+        dm = reduced_density_matrix(s4, c["keep"])
+        assert np.allclose(dm, cmatrix(c["dm"]), atol=2e-6, rtol=0)
+        assert abs(s4.entanglement_entropy(c["keep"]) - c["entropy"]) < 1e-5
+        assert abs(renyi_entropy(s4, c["keep"], 1) - c["entropy"]) < 1e-5
+        assert abs(renyi_entropy(s4, c["keep"], 0) - np.log(2 ** len(c["keep"]))) < 1e-12
+    # product state: zero entropy, projector RDM (test_rdm.py:209-216)
+    sp = State(L=6, state=0b010011)
+    dm = reduced_density_matrix(sp, [0, 1])
+    want = np.zeros((4, 4)); want[3, 3] = 1
+    assert np.array_equal(dm, want) and sp.entanglement_entropy([0, 1, 2]) == 0
+    with pytest.raises(ValueError):          # test_rdm.py:289-303
+        reduced_density_matrix(State(L=6, subspace=XParity(SpinConserve(6, 3)), state='random', seed=0), [0])
+
+
+@pytest.mark.parametrize("kind", ["full", "even", "odd", "sc", "explicit"])
+def test_rdm_vs_oracle_and_reshape(kind):
+    """Every subspace type, every tile size of the kernel (k = 1..9), contiguous and scattered
+    keep sets: against the oracle restatement of rdm_<SUBSPACE> and against the reference
+    tests' own check (embed in the full space, reshape, multiply: test_rdm.py:218-270)."""
+    from oracle import oracle as orc
+    from gpu_util import orc_sub
+    from dynamite_amd.computations import reduced_density_matrix
+    L = 12
+    rs = np.random.RandomState(5)
+    sub = {"full": Full(L=L), "even": Parity('even', L=L), "odd": Parity('odd', L=L), "sc": SpinConserve(L, 6),
+           "explicit": Explicit(np.sort(rs.choice(1 << L, 900, replace=False)), L=L)}[kind]
+    st = State(L=L, subspace=sub, state='random', seed=2)
+    v = st.to_numpy()
+    full = np.zeros(1 << L, dtype=complex)
+    full[sub.idx_to_state(np.arange(sub.get_dimension()))] = v
+    osub = orc_sub(sub)
+    for n in range(1, L - 2):
+        m = full.reshape((full.size // 2 ** n, -1))
+        dm = reduced_density_matrix(st, list(range(n, L))) if L - n <= 9 else None
+        if dm is not None:
+            assert np.max(np.abs(dm - m @ m.conj().T)) < 1e-14
+        if n <= 9:
+            dm = reduced_density_matrix(st, list(range(n)))
+            assert np.max(np.abs(dm - m.T @ m.conj())) < 1e-14
+    for keep in ([0], [L - 1], [1, 4, 6], [0, 2, 3, 7, 8, 11], [2, 3, 4, 5, 6, 7, 8, 9]):
+        dm = reduced_density_matrix(st, keep)
+        assert np.max(np.abs(dm - orc.rdm(osub, v, keep))) < 1e-14
+        assert abs(np.trace(dm) - 1) < 1e-13 and np.allclose(dm, dm.conj().T, atol=1e-17, rtol=0)
+
+
+def test_rdm_large_properties():
+    """L = 24 (2^24 amplitudes): trace, Hermiticity, S(A) = S(complement) for a pure state,
+    and agreement with the host on a sampled 2-spin block."""
+    from dynamite_amd.computations import reduced_density_matrix, dm_entanglement_entropy
+    L = 24
+    st = State(L=L, state='random', seed=9)
+    a = reduced_density_matrix(st, list(range(8)))
+    assert abs(np.trace(a) - 1) < 1e-12 and np.allclose(a, a.conj().T, atol=1e-17, rtol=0)
+    v = st.to_numpy()
+    m = v.reshape((1 << 16, 1 << 8))
+    assert np.max(np.abs(a - m.T @ m.conj())) < 1e-13
+    b = reduced_density_matrix(st, [3, 20])
+    # axes of the reshape: spins 23..21 | 20 | 19..4 | 3 | 2..0; rows of the RDM = (spin 20, spin 3)
+    m2 = v.reshape(8, 2, 1 << 16, 2, 8).transpose(1, 3, 0, 2, 4).reshape(4, -1)
+    assert np.max(np.abs(b - m2 @ m2.conj().T)) < 1e-13
+    st = State(L=20, state='random', seed=10)       # (the host eigensolver bounds the size of this one)
+    sA = dm_entanglement_entropy(reduced_density_matrix(st, list(range(9))))
+    sB = dm_entanglement_entropy(reduced_density_matrix(st, list(range(9, 20))))
+    assert abs(sA - sB) < 1e-9 and 0 < sA <= 9 * np.log(2)

@@ -328,3 +328,25 @@ def test_xparity_reduce_msc_golden(golden_xp):
     assert XParity(Full(L=6), "+") == XParity(Full(L=6), +1)
     assert XParity(Full(L=6), "+") != XParity(Full(L=6), "-")
     assert hash(XParity(Full(L=6), "-")) == hash(XParity(Full(L=6), -1))
+
+
+# ------------------------------------------------------------------ entropies (host numpy, tests/unit/test_entropies.py)
+
+def test_entropy_functions(known):
+    from conftest import cmatrix
+    from dynamite_amd.computations import dm_entanglement_entropy, dm_renyi_entropy
+    e = known["entropies"]
+    for c in e["von_neumann"]:
+        assert abs(dm_entanglement_entropy(cmatrix(c["dm"])) - c["value"]) < 1e-5     # 6-digit tables
+    for c in e["cases"]:
+        dm = cmatrix(c["dm"])
+        for alpha, val in c["renyi"]:
+            assert abs(dm_renyi_entropy(dm, alpha, 'eigsolve') - val) < 1e-14
+            if alpha == 'inf' or int(alpha) == alpha:
+                assert abs(dm_renyi_entropy(dm, alpha, 'matrix_power') - val) < 1e-14
+            else:
+                with pytest.raises(TypeError):
+                    dm_renyi_entropy(dm, alpha, 'matrix_power')
+        assert abs(dm_entanglement_entropy(dm) - dict((str(a), v) for a, v in c["renyi"])["1"]) < 1e-14
+    with pytest.raises(ValueError):
+        dm_renyi_entropy(np.eye(2) / 2, 2, 'bogus')
