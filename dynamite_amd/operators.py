@@ -239,6 +239,21 @@ class Operator:
     def from_bytes(cls, data):
         return cls(msc=msc_tools.deserialize(data))
 
+    def save(self, filename):
+        """Write ``serialize()`` to a file (operators.py:505-521); subspaces are not saved."""
+        from .backend import _dist
+        if config.rank == 0:
+            with open(filename, mode='wb') as f:
+                f.write(self.serialize())
+        if _dist() is not None:
+            _dist().barrier()
+
+    @classmethod
+    def load(cls, filename):
+        """operators.py:523-542."""
+        with open(filename, 'rb') as f:
+            return cls.from_bytes(f.read())
+
     def to_numpy(self, subspaces=None, sparse=True):
         """Explicit matrix on the host (small systems; operators.py:869-907)."""
         if subspaces is None:

@@ -9,6 +9,9 @@ The data live in HBM as one contiguous complex128 block per rank
 from os import urandom
 from time import time
 
+import io
+import pickle
+
 import numpy as np
 
 from . import subspaces
@@ -146,6 +149,69 @@ class State:
         self.assert_initialized()
         return self.vec.to_numpy(to_all)
 
+    # ------------------------------------------------------------------ files
+    # <fname>.metadata: the pickled subspace; <fname>.vec: PETSc's binary Vec format, which is what
+    # ``Vec.view`` on a binary viewer writes (states.py:627-650): big-endian, VEC_FILE_CLASSID
+    # (1211214), the length, then the entries as (re, im) doubles.  The two header integers are
+    # PetscInt-sized: 64-bit for the usual dynamite build (--with-64-bit-indices), 32-bit otherwise;
+    # ``int_size`` selects what is written, reading detects it.  (The layout follows PETSc's
+    # documentation of its binary format -- no fixture of the reference pins it.)
+    VEC_FILE_CLASSID = 1211214
+    _IO_CHUNK = 1 << 22
+
+    def save(self, fname, int_size=64):
+        self.assert_initialized()
+        if int_size not in (32, 64):
+            raise ValueError('int_size must be 32 or 64')
+        from .backend import _dist
+        d = _dist()
+        if config.rank == 0:
+            with open(fname + '.metadata', 'wb') as f:
+                pickle.dump(self.subspace, f)
+            with open(fname + '.vec', 'wb') as f:
+                f.write(np.array([self.VEC_FILE_CLASSID, self.vec.size], dtype='>i%d' % (int_size // 8)).tobytes())
+        if d is not None:
+            d.barrier()
+        start, end = self.vec.getOwnershipRange()
+        with open(fname + '.vec', 'r+b') as f:
+            f.seek(2 * (int_size // 8) + 16 * start)
+            for lo in range(0, end - start, self._IO_CHUNK):
+                hi = min(end - start, lo + self._IO_CHUNK)
+                f.write(self.vec.array[lo:hi].cpu().numpy().astype('>c16').tobytes())
+        if d is not None:
+            d.barrier()
+
+    @classmethod
+    def from_file(cls, fname):
+        """Load a state saved by ``save`` -- or by dynamite itself (states.py:652-701).  Uses
+        pickle: do not load files from untrusted sources."""
+        with open(fname + '.metadata', 'rb') as f:
+            subspace = _SubspaceUnpickler(f).load()
+        subspace = _convert_reference_subspace(subspace)
+        with open(fname + '.vec', 'rb') as f:
+            head = f.read(16)
+            h32, h64 = np.frombuffer(head[:8], dtype='>i4'), np.frombuffer(head, dtype='>i8')
+            if len(head) == 16 and h64[0] == cls.VEC_FILE_CLASSID:
+                n, off = int(h64[1]), 16
+            elif len(head) >= 8 and h32[0] == cls.VEC_FILE_CLASSID:
+                n, off = int(h32[1]), 8
+            else:
+                raise RuntimeError("corrupt data encountered when loading state from file")
+            if subspace.get_dimension() != n:
+                raise RuntimeError("corrupt data encountered when loading state from file")
+            rtn = cls(subspace=subspace)
+            start, end = rtn.vec.getOwnershipRange()
+            import torch
+            for lo in range(0, end - start, cls._IO_CHUNK):
+                hi = min(end - start, lo + cls._IO_CHUNK)
+                f.seek(off + 16 * (start + lo))
+                buf = f.read(16 * (hi - lo))
+                if len(buf) != 16 * (hi - lo):
+                    raise RuntimeError("corrupt data encountered when loading state from file")
+                rtn.vec.array[lo:hi] = torch.from_numpy(np.frombuffer(buf, dtype='>c16').astype(np.complex128))
+        rtn.set_initialized()
+        return rtn
+
     def entanglement_entropy(self, keep):
         """states.py:362 -> computations.entanglement_entropy."""
         from . import computations
@@ -225,3 +291,36 @@ class State:
 
     def __len__(self):
         return self.subspace.get_dimension()
+
+
+class _RefSubspace:
+    """Stand-in for a pickled ``dynamite.subspaces`` object: only its attribute dict is kept."""
+    _ref_name = None
+
+
+class _SubspaceUnpickler(pickle.Unpickler):
+    """Files written by dynamite pickle ``dynamite.subspaces.<Class>`` instances
+    (states.py:643-645); they are read as attribute bags and rebuilt as the classes here."""
+
+    def find_class(self, module, name):
+        if module.split('.')[0] == 'dynamite' and module.endswith('subspaces'):
+            return type(name, (_RefSubspace,), {'_ref_name': name})
+        return super().find_class(module, name)
+
+
+def _convert_reference_subspace(obj):
+    if not isinstance(obj, _RefSubspace):
+        return obj
+    d, name = obj.__dict__, obj._ref_name
+    L = d.get('_L')
+    if name == 'Full':
+        return subspaces.Full(L=L)
+    if name == 'Parity':
+        return subspaces.Parity(d['_space'], L=L)
+    if name == 'SpinConserve':
+        return subspaces.SpinConserve(L, d['_k'])
+    if name in ('Explicit', 'Auto'):
+        return subspaces.Explicit(np.asarray(d['state_map']), L=L)
+    if name == 'XParity':
+        return subspaces.XParity(_convert_reference_subspace(d['_parent']), sector=d['_sector'])
+    raise RuntimeError('unknown subspace type "%s" in state metadata' % name)

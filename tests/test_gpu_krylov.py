@@ -437,3 +437,57 @@ def test_rdm_large_properties():
     sA = dm_entanglement_entropy(reduced_density_matrix(st, list(range(9))))
     sB = dm_entanglement_entropy(reduced_density_matrix(st, list(range(9, 20))))
     assert abs(sA - sB) < 1e-9 and 0 < sA <= 9 * np.log(2)
+
+
+# ------------------------------------------------------------------ files
+
+def test_state_and_operator_files(tmp_path):
+    """State.save / from_file (states.py:627-701: <name>.metadata + PETSc binary <name>.vec) and
+    Operator.save / load (operators.py:505-542)."""
+    import pickle
+    import struct
+    for sub in (Full(L=9), SpinConserve(10, 4), Parity('odd', L=8), XParity(SpinConserve(8, 4), '-'),
+                Explicit([5, 3, 12, 9], L=4)):
+        st = State(L=sub.L, subspace=sub, state='random', seed=1)
+        for int_size in (64, 32):
+            fn = str(tmp_path / ("s%d" % int_size))
+            st.save(fn, int_size=int_size)
+            raw = open(fn + '.vec', 'rb').read()
+            hb = int_size // 8
+            cid, n = struct.unpack('>qq' if int_size == 64 else '>ii', raw[:2 * hb])
+            assert (cid, n) == (1211214, sub.get_dimension()) and len(raw) == 2 * hb + 16 * n
+            assert np.array_equal(np.frombuffer(raw[2 * hb:], dtype='>c16'), st.to_numpy())
+            back = State.from_file(fn)
+            assert back.subspace == sub and type(back.subspace) is type(sub)
+            assert np.array_equal(back.to_numpy(), st.to_numpy())
+    # metadata as dynamite writes it: a pickled dynamite.subspaces object (attribute names of subspaces.py)
+    import sys, types
+    fake = types.ModuleType('dynamite.subspaces')
+    for name in ('Parity', 'XParity', 'SpinConserve'):
+        setattr(fake, name, type(name, (), {'__module__': 'dynamite.subspaces'}))
+    sys.modules.setdefault('dynamite', types.ModuleType('dynamite'))
+    sys.modules['dynamite.subspaces'] = fake
+    try:
+        par = fake.SpinConserve(); par.__dict__.update(_L=8, _k=4, _chksum=None)
+        xp = fake.XParity(); xp.__dict__.update(_parent=par, _sector=-1)
+        with open(fn + '.metadata', 'wb') as f:
+            pickle.dump(xp, f)
+    finally:
+        del sys.modules['dynamite.subspaces']
+    sub = XParity(SpinConserve(8, 4), '-')
+    st = State(L=8, subspace=sub, state='random', seed=2)
+    st.save(str(tmp_path / "x"))
+    import shutil
+    shutil.copy(fn + '.metadata', str(tmp_path / "x.metadata"))
+    back = State.from_file(str(tmp_path / "x"))
+    assert back.subspace == sub and np.array_equal(back.to_numpy(), st.to_numpy())
+    # corrupt: wrong length for the subspace
+    Full(L=3)
+    with open(str(tmp_path / "x.metadata"), 'wb') as f:
+        pickle.dump(Full(L=3), f)
+    with pytest.raises(RuntimeError):
+        State.from_file(str(tmp_path / "x"))
+    H = models.long_range(7)
+    H.save(str(tmp_path / "op"))
+    H2 = Operator.load(str(tmp_path / "op"))
+    assert np.array_equal(H2.msc, H.msc) and H2 == H
