@@ -3,7 +3,7 @@ Subspaces on which operators and states live: the Python faces of the native
 index maps, mirroring ``dynamite.subspaces`` (reference
 ``src/dynamite/subspaces.py``: Subspace :20-213, Full :214-246, Parity
 :248-297, SpinConserve :299-377, Explicit :380-452) for the hot path.
-``XParity`` (:532-800) wraps one of them; ``Auto`` is not part of this path yet.
+``XParity`` (:532-800) wraps one of them; ``Auto`` (:465-530) is the connected component of a state.
 
 All maps go through the C ABI (``dnm_idx_to_state`` / ``dnm_state_to_idx`` /
 ``dnm_subspace_dim``), which replaces ``bsubspace.pyx``.
@@ -282,6 +282,61 @@ class Explicit(Subspace):
         if self.rmap_indices is not None:
             d.rmap_indices = _lib.p64(self.rmap_indices)
         return d
+
+
+class Auto(Explicit):
+    """The subspace containing ``state`` that the operator ``H`` cannot leave: breadth-first
+    search with H as adjacency matrix (subspaces.py:465-530, bsubspace.pyx:212-261).  An edge
+    state -> state ^ mask exists when the terms sharing the mask do not cancel on that state.
+    ``sort=True`` orders the states numerically; ``sort=False`` keeps the reversed search
+    order (reverse Cuthill-McKee), reproduced here level by level."""
+
+    def __init__(self, H, state, size_guess=None, sort=True):
+        from . import states, msc_tools
+        H.establish_L()
+        self._repr_args = f'H={repr(H)}, state={repr(state)}'
+        if size_guess is not None:
+            self._repr_args += f', size_guess={size_guess}'
+        if not sort:
+            self._repr_args += ', sort=False'
+        self.state = states.State.str_to_state(state, H.L)
+        if size_guess is None:
+            size_guess = 2 ** H.L
+        H.reduce_msc()
+        masks, offs = msc_tools.get_mask_offsets(H.msc)
+        signs, coeffs = H.msc['signs'], H.msc['coeffs']
+        found = [np.array([self.state], dtype=dnm_int_t)]
+        seen = found[0].copy()
+        frontier = found[0]
+        total = 1
+        while frontier.size:
+            cand = []      # candidates in the order the serial search meets them: state-major, mask-minor
+            for mi in range(masks.size):
+                tot = np.zeros(frontier.size, dtype=np.complex128)
+                for t in range(offs[mi], offs[mi + 1]):
+                    tot += (1 - 2 * msc_tools.parity(frontier & signs[t])) * coeffs[t]
+                cand.append(np.where(tot != 0, frontier ^ masks[mi], -1))
+            cand = np.stack(cand, axis=1).reshape(-1) if cand else np.empty(0, dtype=dnm_int_t)
+            cand = cand[cand >= 0]
+            cand = cand[~np.isin(cand, seen)]
+            _, first = np.unique(cand, return_index=True)
+            new = cand[np.sort(first)].astype(dnm_int_t)
+            total += new.size
+            if total > size_guess:
+                raise RuntimeError('state_map size too small')
+            if new.size:
+                found.append(new)
+                seen = np.union1d(seen, new)
+            frontier = new
+        state_map = np.concatenate(found)
+        if sort:
+            state_map.sort()
+        else:
+            state_map = state_map[::-1]
+        Explicit.__init__(self, state_map, L=H.L)
+
+    def __repr__(self):
+        return f'Auto({self._repr_args})'
 
 
 class XParity(Subspace):

@@ -350,3 +350,40 @@ def test_entropy_functions(known):
         assert abs(dm_entanglement_entropy(dm) - dict((str(a), v) for a, v in c["renyi"])["1"]) < 1e-14
     with pytest.raises(ValueError):
         dm_renyi_entropy(np.eye(2) / 2, 2, 'bogus')
+
+
+def test_auto_subspace():
+    """Auto (subspaces.py:465-530): the component of a state under H.  XX+YY from a half-filled
+    state gives the SpinConserve sector (tests/unit/test_subspaces.py Auto cases in spirit);
+    sort=False is the reversed serial breadth-first order of bsubspace.pyx:212-261."""
+    from dynamite_amd.subspaces import Auto
+    from dynamite_amd.operators import sigmax, sigmay, sigmaz, index_sum
+    L = 8
+    H = index_sum(sigmax(0) * sigmax(1) + sigmay(0) * sigmay(1), size=L)
+    a = Auto(H, 'U' * 4 + 'D' * 4)
+    sc = SpinConserve(L, 4)
+    assert np.array_equal(a.state_map, sc.idx_to_state(np.arange(sc.get_dimension())))
+    assert a == sc and a.get_dimension() == 70
+    b = Auto(H, 'U' * 4 + 'D' * 4, sort=False)
+    # serial reference search
+    H.reduce_msc()
+    masks, offs = msc_tools.get_mask_offsets(H.msc)
+    order, seen, i = [0b11110000], {0b11110000}, 0
+    while i < len(order):
+        st = order[i]
+        for mi in range(masks.size):
+            tot = sum((1 - 2 * (bin(st & int(H.msc['signs'][t])).count('1') & 1)) * H.msc['coeffs'][t]
+                      for t in range(offs[mi], offs[mi + 1]))
+            e = st ^ int(masks[mi])
+            if tot != 0 and e not in seen:
+                seen.add(e); order.append(e)
+        i += 1
+    assert b.state_map.tolist() == order[::-1]
+    assert sorted(b.state_map.tolist()) == a.state_map.tolist()
+    # an operator that connects everything: the full space; too small a guess is refused
+    X = index_sum(sigmax(), size=5)
+    assert Auto(X, 0).get_dimension() == 32
+    with pytest.raises(RuntimeError):
+        Auto(X, 0, size_guess=10)
+    Z = index_sum(sigmaz(), size=5)
+    assert Auto(Z, 'DUDUU').state_map.tolist() == [0b00101]
