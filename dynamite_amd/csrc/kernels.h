@@ -92,6 +92,8 @@ int vk_basis_update(void *V, int64_t ldv, int nin, int nout, int64_t n, const do
 // p -= (are + i aim) v + b u (u may be null); partials_dev[vk_mdot_blocks(n)] then the sum of |p|^2
 int vk_lanczos_update(void *p, const void *v, const void *u, int64_t n, double are, double aim, double b,
                       double *partials_dev, hipStream_t st);
+// out[c] = sum_b partials[b * ncols + c]
+int vk_reduce_partials(const double *partials, int nblocks, int ncols, double *out, hipStream_t st);
 int vk_norm2_partials(const void *x, int64_t n, double *partials_dev, hipStream_t st);
 
 }  // namespace dnm

@@ -176,6 +176,21 @@ struct Ops {
     }
     return dnm_mat_mult(A, x, y, (void *)st);
   }
+  // y = A x and d = <x, y>
+  int mult_dot(const void *x, void *y, zc *d) {
+    if (hooks && hooks->mult) {
+      std::vector<zc> h;
+      DNM_TRY(mult(x, y));
+      DNM_TRY(mdot(x, 1, y, h));
+      *d = h[0];
+      return 0;
+    }
+    ++matvecs;
+    double buf[2];
+    DNM_TRY(dnm_mat_mult_dot(A, x, y, buf, (void *)st));
+    *d = zc(buf[0], buf[1]);
+    return 0;
+  }
   int sum(double *buf, int cnt) {
     if (hooks && hooks->allreduce_sum)
       DNM_CHECK(hooks->allreduce_sum(hooks->ctx, buf, cnt) == 0, "allreduce_sum hook failed");
@@ -503,12 +518,12 @@ int dnm_expm_multiply(dnm_mat *A, const void *x, void *y, int64_t n_local, doubl
     }
     for (int j = 0; j < m; ++j) {
       void *p = vecptr(V, n_local, j + 1);
-      DNM_TRY(ops.mult(vecptr(V, n_local, j), p));
+      zc d0(0);
+      if (use_pro) DNM_TRY(ops.mult_dot(vecptr(V, n_local, j), p, &d0));
+      else DNM_TRY(ops.mult(vecptr(V, n_local, j), p));
       double hn = 0;
       if (use_pro) {
-        std::vector<zc> d;
-        DNM_TRY(ops.mdot(vecptr(V, n_local, j), 1, p, d));
-        const zc alpha = d[0] / (nv[j] * nv[j]);
+        const zc alpha = d0 / (nv[j] * nv[j]);
         h.assign(j + 1, zc(0));
         h[j] = alpha;
         if (j > 0) h[j - 1] = bet[j];
@@ -651,21 +666,22 @@ int dnm_eigsolve(dnm_mat *A, int64_t n_local, int nev, int which, double tol, in
     if (use_pro) mon.begin_cycle(l, theta, spike, row_l);
     for (int j = l; j < m; ++j) {
       void *p = vecptr(V, n_local, j + 1);
-      DNM_TRY(ops.mult(vecptr(V, n_local, j), p));
+      const bool three_term = use_pro && j != l;
+      zc d0(0);
+      if (three_term) DNM_TRY(ops.mult_dot(vecptr(V, n_local, j), p, &d0));
+      else DNM_TRY(ops.mult(vecptr(V, n_local, j), p));
       double bn = 0;
-      if (!use_pro || j == l) {
+      if (!three_term) {
         // the first step of a cycle removes the spike components: whole basis, twice when Ritz vectors are
         // present (they are orthonormal to sqrt(eps) only under partial re-orthogonalisation)
         DNM_TRY(ops.orthogonalize(p, V, j + 1, h, &bn, (use_pro && l > 0) ? 2 : 1));
         alpha[j] = h[j].real();
         if (use_pro) mon.first_step(alpha[j], bn);
       } else {
-        std::vector<zc> d;
-        DNM_TRY(ops.mdot(vecptr(V, n_local, j), 1, p, d));
-        alpha[j] = d[0].real();
+        alpha[j] = d0.real();
         double n2 = 0;
-        DNM_TRY(vec_lanczos_update_host(p, vecptr(V, n_local, j), vecptr(V, n_local, j - 1), n_local, d[0].real(),
-                                        d[0].imag(), betav[j - 1], &n2, st));
+        DNM_TRY(vec_lanczos_update_host(p, vecptr(V, n_local, j), vecptr(V, n_local, j - 1), n_local, d0.real(),
+                                        d0.imag(), betav[j - 1], &n2, st));
         DNM_TRY(ops.sum(&n2, 1));
         bn = std::sqrt(n2 > 0 ? n2 : 0.0);
         if (mon.update(j, alpha[j], bn)) {

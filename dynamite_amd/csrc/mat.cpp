@@ -2,6 +2,7 @@
 // norm / diagonal / destroy).  See include/dynamite_amd.h for the reference
 // interfaces each entry point replaces.
 #include "mat.h"
+#include "vec_api.h"
 
 #include <algorithm>
 #include <cstring>
@@ -663,6 +664,32 @@ int dnm_mat_mult_local(dnm_mat *A, const void *x, void *y, void *stream) {
                             A->have_diag ? (const double *)A->diag.p : nullptr, x, y, nullptr, S(stream));
   return launch_gather_matvec(A->dmsc, A->left.dev, A->right.dev, A->M,
                               A->have_diag ? (const double *)A->diag.p : nullptr, x, y, S(stream));
+}
+
+// y = A x and <x, y> = sum conj(x_i) y_i.  When the last pass of the plan stages x in LDS the dot product is
+// accumulated there (per-workgroup partials, summed by a second tiny kernel); otherwise a separate sweep.
+int dnm_mat_mult_dot(dnm_mat *A, const void *x, void *y, double *dot, void *stream) {
+  DNM_CHECK(A && x && y && dot, "null argument");
+  DNM_CHECK(A->remote_passes.empty(), "operator couples different ranks: no fused dot product");
+  const bool fused = A->hypercube && A->plan.use_tiled && !A->local_passes.empty() &&
+                     A->local_passes.back()->desc.need_tile && !A->host_only;
+  if (!fused) {
+    DNM_TRY(dnm_mat_mult_local(A, x, y, stream));
+    return vec_mdot_host(x, A->m_local, 1, y, A->m_local, dot, S(stream));
+  }
+  const size_t nblk = (size_t)1 << (A->local_passes.back()->n_eff - A->plan.cfg.B);
+  double *part = nullptr;
+  DNM_TRY(vec_scratch((nblk + 1) * 2 * sizeof(double), &part));
+  for (size_t i = 0; i < A->local_passes.size(); ++i) {
+    DevPass d = A->local_passes[i]->desc;
+    if (i + 1 == A->local_passes.size()) d.dot_out = part;
+    DNM_TRY(launch_tile_pass(d, A->plan.cfg.B, A->plan.cfg.logR, use_glds(A), A->local_passes[i]->n_eff, x, y,
+                             nullptr, S(stream)));
+  }
+  DNM_TRY(vk_reduce_partials(part, (int)nblk, 2, part + 2 * nblk, S(stream)));
+  DNM_HIP(hipMemcpyAsync(dot, part + 2 * nblk, 2 * sizeof(double), hipMemcpyDeviceToHost, S(stream)));
+  DNM_HIP(hipStreamSynchronize(S(stream)));
+  return 0;
 }
 
 int dnm_mat_mult(dnm_mat *A, const void *x, void *y, void *stream) {

@@ -101,6 +101,7 @@ struct DevPass {
   int32_t nquads;
   int32_t n_eff;        // index bits this pass runs over (n_loc, or n_loc - 1 for a half-block partner pass)
   const DevQuad *quads;
+  double *dot_out;      // non-null (last pass, tile staged): per-workgroup partial sums of conj(x_row) y_row
 };
 
 // ---- host-side description --------------------------------------------------

@@ -312,6 +312,12 @@ int vk_lanczos_update(void *p, const void *v, const void *u, int64_t n, double a
   return 0;
 }
 
+int vk_reduce_partials(const double *partials, int nblocks, int ncols, double *out, hipStream_t st) {
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(ncols), dim3(VNT), 0, st, partials, nblocks, ncols, out);
+  DNM_HIP(hipGetLastError());
+  return 0;
+}
+
 int vk_norm2_partials(const void *x, int64_t n, double *partials_dev, hipStream_t st) {
   return vk_mdot(x, n, 1, x, n, partials_dev, st);
 }

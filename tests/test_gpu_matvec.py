@@ -333,3 +333,25 @@ def test_error_behaviour():
     bad = (arrs[0][::-1].copy(),) + arrs[1:]
     with pytest.raises(_lib.BackendError):
         backend.create_mat(*bad, sub._c(), sub._c())
+
+
+@pytest.mark.parametrize("name,L,sub", [("mbl", 16, "full"), ("long_range", 12, "full"), ("ising", 14, "parity"),
+                                        ("mbl", 6, "full"), ("heisenberg", 12, "sc")])
+def test_mult_dot_fused(monkeypatch, name, L, sub):
+    """dnm_mat_mult_dot: y identical to dnm_mat_mult, <x, y> equal to the separate dot product
+    (fused into the last tiled pass when x is staged there; separate sweep otherwise)."""
+    import ctypes as C
+    cfg(monkeypatch, B=8, logR=2, mode=2, amin=3, gbits=3)
+    H = models.BY_NAME[name](L)
+    s = {"full": Full(L=L), "parity": Parity('even', L=L), "sc": SpinConserve(L, L // 2)}[sub]
+    mat = shell(H, s)
+    x = rand_state(s.get_dimension(), seed=8)
+    xv, y1, y2 = vec_from(x), backend.Vec(mat.M), backend.Vec(mat.M)
+    mat.mult(xv, y1)
+    d = (C.c_double * 2)()
+    _lib.check(_lib.lib().dnm_mat_mult_dot(mat.handle, xv.ptr, y2.ptr, d, None))
+    assert np.array_equal(y1.local_numpy(), y2.local_numpy())
+    ref = np.vdot(x, y1.local_numpy())
+    assert abs(complex(d[0], d[1]) - ref) <= 1e-13 * max(1.0, abs(ref)) * np.sqrt(x.size)
+    assert abs(d[1]) <= 1e-12 * max(1.0, abs(ref))      # Hermitian operator: real expectation value
+    mat.destroy()
