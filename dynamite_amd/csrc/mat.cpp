@@ -197,6 +197,21 @@ static int build_pass(const dnm_mat &A, const PassSpec &ps, PassOnDevice *out) {
     for (size_t i = 0; i < nsel; ++i) order.push_back(rest[i]);
     for (int pos = ps.gpos; pos < ps.gpos + ps.glen; ++pos) order.push_back(pos);
     for (size_t i = nsel; i < rest.size(); ++i) order.push_back(rest[i]);
+    if (const char *e = getenv("DNM_ORDER_WINDOW")) {     // experiments: explicit block-id bit order (low to high)
+      if (ps.nseg > 1 && ps.partner < 0) {
+        std::vector<int> o;
+        for (const char *q = e; *q;) {
+          o.push_back(atoi(q));
+          while (*q && *q != ',') ++q;
+          if (*q == ',') ++q;
+        }
+        std::vector<int> a = o, b2 = order;
+        std::sort(a.begin(), a.end());
+        std::sort(b2.begin(), b2.end());
+        DNM_CHECK(a == b2, "DNM_ORDER_WINDOW is not a permutation of the block bits");
+        order = o;
+      }
+    }
     DNM_CHECK((int)order.size() == n_eff - B, "internal: block bits do not add up");
     int nb = 0;
     for (size_t i = 0; i < order.size();) {

@@ -21,6 +21,7 @@ PlanConfig plan_config_from_env() {
   c.amin = env_int("DNM_AMIN", c.amin);
   c.mode = env_int("DNM_PLAN_MODE", c.mode);
   c.gbits = env_int("DNM_GBITS", c.gbits);
+  c.gbits_window = env_int("DNM_GBITS_WINDOW", c.gbits_window);
   c.cache_policy = env_int("DNM_CACHE_POLICY", c.cache_policy);
   return c;
 }
@@ -229,6 +230,13 @@ int make_plan(const OpForm &op, int rank, int nranks, const PlanConfig &cfg_in, 
       }
       best.has_diag = first && has_diag;
       best.accumulate = !first;
+      // Window tiles (runs of 2^a amplitudes far apart) alias in the L2 sets: only a few hundred KB of
+      // them stay resident (tools/l2map_probe.hip).  Keep the masks, but order the workgroups by a
+      // smaller subcube -- the top bits of the span -- so that at least those gathers find their lines.
+      if (best.nseg > 1 && cfg.gbits_window >= 0 && best.glen > cfg.gbits_window) {
+        best.gpos += best.glen - cfg.gbits_window;
+        best.glen = cfg.gbits_window;
+      }
       pl.local.push_back(best);
       remaining.swap(rest);
       first = false;

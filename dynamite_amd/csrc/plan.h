@@ -139,6 +139,7 @@ struct PlanConfig {
   int mode = 2;        // 0: multi-pass LDS tiles; 1: single pass, everything else gathered;
                        // 2: multi-pass LDS tiles + L2-served gathers over an XCD group
   int gbits = 6;       // mode 2: bits per XCD group
+  int gbits_window = -1; // mode 2: cap of the group bits of window-tile passes (-1: no cap)
   int cache_policy = 0; // DevPass::cache_policy for every pass (experiments)
   int max_gather_span = 0;   // mode 0: masks the tiler cannot place are gathered
 };
