@@ -145,6 +145,45 @@ class State:
             v.normalize()
         self.set_initialized()
 
+    def set_all_by_function(self, val_fn, vectorize=False):
+        """Set every amplitude to ``val_fn(spin configuration)`` (states.py:320-360)."""
+        v = self.vec
+        istart, iend = v.getOwnershipRange()
+        out = np.empty(iend - istart, dtype=np.complex128)
+        block = 1 << 16
+        for b0 in range(istart, iend, block):
+            b1 = min(iend, b0 + block)
+            sts = self.subspace.idx_to_state(np.arange(b0, b1))
+            if vectorize:
+                out[b0 - istart:b1 - istart] = val_fn(sts)
+            else:
+                out[b0 - istart:b1 - istart] = [val_fn(int(st)) for st in sts]
+        v.set_local_from_numpy(out)
+        self.set_initialized()
+
+    def project(self, index, value):
+        """Projective measurement of spin ``index`` with outcome ``value``, in place, renormalised
+        (states.py:364-402)."""
+        import torch
+        self.assert_initialized()
+        if index < 0 or index >= self.L:
+            raise ValueError("spin index out of range")
+        if value not in (0, 1):
+            raise ValueError("value must be 0 or 1")
+        v = self.vec
+        istart, iend = v.getOwnershipRange()
+        block = 1 << 22
+        for b0 in range(istart, iend, block):
+            b1 = min(iend, b0 + block)
+            if isinstance(self.subspace, subspaces.Full):     # index == configuration: mask built on the device
+                idx = torch.arange(b0, b1, device=v.array.device)
+                kill = ((idx >> index) & 1) != value
+            else:
+                sts = self.subspace.idx_to_state(np.arange(b0, b1))
+                kill = torch.from_numpy(((sts >> index) & 1) != value).to(v.array.device)
+            v.array[b0 - istart:b1 - istart][kill] = 0
+        v.normalize()
+
     def to_numpy(self, to_all=False):
         self.assert_initialized()
         return self.vec.to_numpy(to_all)
@@ -287,6 +326,12 @@ class State:
     def __sub__(self, x):
         rtn = self.copy()
         rtn -= x
+        return rtn
+
+    def __rsub__(self, x):
+        rtn = self.copy()
+        rtn.scale(-1)
+        rtn += x
         return rtn
 
     def __len__(self):

@@ -491,3 +491,30 @@ def test_state_and_operator_files(tmp_path):
     H.save(str(tmp_path / "op"))
     H2 = Operator.load(str(tmp_path / "op"))
     assert np.array_equal(H2.msc, H.msc) and H2 == H
+
+
+def test_state_project_and_function():
+    """State.project (states.py:364-402; tests/integration/test_states.py projection cases) and
+    set_all_by_function (:320-360)."""
+    for sub in (Full(L=10), SpinConserve(10, 5), Parity('even', L=10)):
+        st = State(L=10, subspace=sub, state='random', seed=3)
+        v = st.to_numpy()
+        sts = sub.idx_to_state(np.arange(sub.get_dimension()))
+        for index, value in ((0, 1), (7, 0)):
+            p = st.copy()
+            p.project(index, value)
+            ref = np.where(((sts >> index) & 1) == value, v, 0)
+            ref = ref / np.linalg.norm(ref)
+            assert np.max(np.abs(p.to_numpy() - ref)) < 1e-15
+        with pytest.raises(ValueError):
+            st.project(10, 0)
+        with pytest.raises(ValueError):
+            st.project(0, 2)
+        f = State(L=10, subspace=sub)
+        f.set_all_by_function(lambda s: (s % 7) + 1j * (s & 3), vectorize=True)
+        g = State(L=10, subspace=sub)
+        g.set_all_by_function(lambda s: (s % 7) + 1j * (s & 3))
+        assert np.array_equal(f.to_numpy(), (sts % 7) + 1j * (sts & 3)) and np.array_equal(f.to_numpy(), g.to_numpy())
+    a = State(L=6, state='random', seed=1)
+    b = 2 - a
+    assert np.allclose(b.to_numpy(), 2 - a.to_numpy(), atol=1e-15)
