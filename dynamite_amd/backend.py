@@ -284,6 +284,14 @@ class ShellMat:
         for i in range(len(self.recvs)):
             _lib.check(L.dnm_mat_mult_remote(self.handle, i, C.c_void_p(bufs[i].data_ptr()), y.ptr, _stream()))
 
+    def uses_cached_diagonal(self):
+        """True for the kernels that read a cached diagonal: the SpinConserve kernel (also
+        partitioned) and the generic row-gather kernel on one rank."""
+        d = self.describe()
+        if 'SpinConserve kernel' in d:
+            return True
+        return self.nranks == 1 and 'row-gather kernel' in d
+
     def _is_windowed(self):
         return 'SpinConserve kernel' in self.describe()
 

@@ -43,8 +43,14 @@ struct ScMask {
 // SpinConserve(L,k) on both sides: columns by incremental colex rank (row + delta)
 // rows [row0, row0+M); xw holds columns [win_start, ...); y / diag are local.  colrange != null:
 // no multiply, only per-workgroup (min, max) of the columns read (2 * sc_num_blocks(M) int64).
+// Low half of the unranking: the 16-bit patterns with j ones in ascending (= colex) order start at
+// tab[off[j]]; a row's configuration is (16 steps over the high positions) + one lookup here.
+struct ScLow {
+  const uint16_t *tab;     // 65536 entries
+  int32_t off[18];
+};
 int sc_num_blocks(int64_t M);
-int launch_sc_matvec(const DevMsc &msc, const ScMask *scm, const SubView &sub, int64_t M, int64_t row0,
+int launch_sc_matvec(const DevMsc &msc, const ScMask *scm, const ScLow &low, const SubView &sub, int64_t M, int64_t row0,
                      int64_t win_start, const double *diag, const void *xw, void *y, int64_t *colrange,
                      hipStream_t st);
 

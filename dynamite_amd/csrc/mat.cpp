@@ -588,6 +588,17 @@ int dnm_mat_create(int64_t nmasks, const int64_t *masks, const int64_t *mask_off
       }
     }
     DNM_TRY(A->d_scmasks.upload(scm.data(), scm.size() * sizeof(ScMask)));
+    // 16-bit patterns grouped by popcount, ascending inside a group (colex order = numeric order)
+    std::vector<uint16_t> low(65536);
+    int cnt[18] = {0};
+    for (int v = 0; v < 65536; ++v) ++cnt[__builtin_popcount(v) + 1];
+    for (int j = 0; j < 17; ++j) { cnt[j + 1] += cnt[j]; A->sclow.off[j] = cnt[j]; }
+    A->sclow.off[17] = 65536;
+    int fill[17];
+    for (int j = 0; j < 17; ++j) fill[j] = A->sclow.off[j];
+    for (int v = 0; v < 65536; ++v) low[fill[__builtin_popcount(v)]++] = (uint16_t)v;
+    DNM_TRY(A->d_sclow.upload(low.data(), low.size() * sizeof(uint16_t)));
+    A->sclow.tab = (const uint16_t *)A->d_sclow.p;
   }
   }
 
@@ -675,7 +686,7 @@ int dnm_mat_mult_local(dnm_mat *A, const void *x, void *y, void *stream) {
   }
   DNM_CHECK(A->nranks == 1, "this subspace pair cannot run partitioned (use dnm_mat_mult_window)");
   if (A->sc_pair)
-    return launch_sc_matvec(A->dmsc, (const ScMask *)A->d_scmasks.p, A->right.dev, A->M, 0, 0,
+    return launch_sc_matvec(A->dmsc, (const ScMask *)A->d_scmasks.p, A->sclow, A->right.dev, A->M, 0, 0,
                             A->have_diag ? (const double *)A->diag.p : nullptr, x, y, nullptr, S(stream));
   return launch_gather_matvec(A->dmsc, A->left.dev, A->right.dev, A->M,
                               A->have_diag ? (const double *)A->diag.p : nullptr, x, y, S(stream));
@@ -728,7 +739,7 @@ int dnm_mat_column_window(dnm_mat *A, int64_t *cmin, int64_t *cmax, void *stream
     const int nb = sc_num_blocks(A->m_local);
     DevBuf buf;
     DNM_TRY(buf.alloc((size_t)nb * 2 * sizeof(int64_t)));
-    DNM_TRY(launch_sc_matvec(A->dmsc, (const ScMask *)A->d_scmasks.p, A->right.dev, A->m_local, A->row0, 0,
+    DNM_TRY(launch_sc_matvec(A->dmsc, (const ScMask *)A->d_scmasks.p, A->sclow, A->right.dev, A->m_local, A->row0, 0,
                              nullptr, nullptr, nullptr, (int64_t *)buf.p, S(stream)));
     std::vector<int64_t> h((size_t)nb * 2);
     DNM_TRY(dnm_memcpy_d2h(h.data(), buf.p, h.size() * sizeof(int64_t), stream));
@@ -751,7 +762,7 @@ int dnm_mat_mult_window(dnm_mat *A, const void *x_window, int64_t win_start, int
   DNM_CHECK(win_start <= lo && win_start + win_len > hi,
             "window [%lld, %lld) does not cover the columns [%lld, %lld] this rank reads", (long long)win_start,
             (long long)(win_start + win_len), (long long)lo, (long long)hi);
-  return launch_sc_matvec(A->dmsc, (const ScMask *)A->d_scmasks.p, A->right.dev, A->m_local, A->row0, win_start,
+  return launch_sc_matvec(A->dmsc, (const ScMask *)A->d_scmasks.p, A->sclow, A->right.dev, A->m_local, A->row0, win_start,
                           A->have_diag ? (const double *)A->diag.p : nullptr, x_window, y_local, nullptr,
                           S(stream));
 }

@@ -66,6 +66,8 @@ struct dnm_mat {
   // generic-kernel tables
   dnm::DevBuf d_masks, d_offsets, d_signs, d_rcoeffs;
   dnm::DevMsc dmsc{};
+  dnm::DevBuf d_sclow;            // SpinConserve kernel: 16-bit unranking table
+  dnm::ScLow sclow{};
   dnm::DevBuf d_scmasks;          // SpinConserve kernel: per-mask precomputation (ScMask[nmasks])
 
   dnm::DevBuf diag;              // cached diagonal (double[m_local]) if precomputed

@@ -550,8 +550,9 @@ gather_matvec_kernel(const DevMsc msc, const SubView left_g, const SubView right
 // ---------------------------------------------------------------------------
 constexpr int SC_NT = 256;
 
+template <bool IN_LDS>
 __global__ void __launch_bounds__(SC_NT)
-sc_matvec_kernel(const DevMsc msc, const ScMask *__restrict__ scm, const SubView sub_g, int64_t M,
+sc_matvec_kernel(const DevMsc msc, const ScMask *__restrict__ scm, const ScLow low, const SubView sub_g, int64_t M,
                  int64_t row0, int64_t win_start, const double *__restrict__ diag,
                  const c128 *__restrict__ xw, c128 *__restrict__ y, int64_t *__restrict__ colrange) {
   // rows [row0, row0 + M) of the matrix; xw holds columns [win_start, ...); y and diag are
@@ -559,12 +560,13 @@ sc_matvec_kernel(const DevMsc msc, const ScMask *__restrict__ scm, const SubView
   __shared__ int64_t nck[NCK_LDS_MAX];
   const int ld = sub_g.ld, kk = sub_g.k, Lb = sub_g.L;
   const int ntab = (kk + 1) * ld;
-  const bool in_lds = ntab <= NCK_LDS_MAX;
-  if (in_lds) {
+  if (IN_LDS) {
     for (int i = threadIdx.x; i < ntab; i += SC_NT) nck[i] = sub_g.nchoosek[i];
     __syncthreads();
   }
-  const int64_t *__restrict__ tab = in_lds ? nck : sub_g.nchoosek;
+  // the binomial table: LDS reads (ds_read_b64) when it fits -- a pointer that may be either LDS or global
+  // compiles to FLAT loads, which go through the texture addresser and saturate it
+#define SC_TAB(i) (IN_LDS ? nck[(i)] : sub_g.nchoosek[(i)])
 
   const int64_t lrow = (int64_t)blockIdx.x * SC_NT + threadIdx.x;
   const int64_t row = row0 + lrow;
@@ -573,16 +575,20 @@ sc_matvec_kernel(const DevMsc msc, const ScMask *__restrict__ scm, const SubView
   const bool active = lrow < M;
   if (!active && !colrange) return;
   if (active) {
-  // I2S_SpinConserve (bsubspace_impl.h:210-228)
+  // I2S_SpinConserve (bsubspace_impl.h:210-228): the greedy walk over the positions >= 16, then the
+  // remaining (index, number of ones) selects the low 16 bits from a table -- the walk over the low
+  // positions would unrank exactly that pair among the 16-bit patterns
   uint64_t ket = 0;
   {
     int64_t idx = row;
     int k = kk;
-    for (int n = Lb; n > 0; --n) {
-      const int64_t here = (k > n - 1) ? 0 : tab[(int64_t)k * ld + (n - 1)];
+    for (int n = Lb; n > 16; --n) {
+      const int64_t here = (k > n - 1) ? 0 : SC_TAB(k * ld + (n - 1));
       ket <<= 1;
       if (idx >= here) { idx -= here; --k; ket |= 1; }
     }
+    const uint64_t lowbits = low.tab[low.off[k] + (int32_t)idx];
+    ket = Lb > 16 ? ((ket << 16) | lowbits) : lowbits;
   }
   double accr = 0.0, acci = 0.0;
   int m0 = 0;
@@ -600,7 +606,7 @@ sc_matvec_kernel(const DevMsc msc, const ScMask *__restrict__ scm, const SubView
       if (pair == 1u || pair == 2u) {
         const bool up = pair == 1u;
         const int ord0 = __popcll(ket & ((1ull << lo) - 1));
-        const int64_t d = tab[(int64_t)ord0 * ld + lo];       // C(lo, ord0)
+        const int64_t d = SC_TAB(ord0 * ld + lo);       // C(lo, ord0)
         if (colrange) {
           const int64_t c = up ? row + d : row - d;
           cmin = c < cmin ? c : cmin;
@@ -631,14 +637,14 @@ sc_matvec_kernel(const DevMsc msc, const ScMask *__restrict__ scm, const SubView
       while (bb) {
         const int p = __ffsll((long long)bb) - 1;
         ++o;
-        if (o <= p) delta += tab[(int64_t)o * ld + p];
+        if (o <= p) delta += SC_TAB(o * ld + p);
         bb &= bb - 1;
       }
       o = ord0;
       while (kb) {
         const int p = __ffsll((long long)kb) - 1;
         ++o;
-        if (o <= p) delta -= tab[(int64_t)o * ld + p];
+        if (o <= p) delta -= SC_TAB(o * ld + p);
         kb &= kb - 1;
       }
     }
@@ -684,15 +690,21 @@ sc_matvec_kernel(const DevMsc msc, const ScMask *__restrict__ scm, const SubView
   }
 }
 
+#undef SC_TAB
+
 int sc_num_blocks(int64_t M) { return (int)((M + SC_NT - 1) / SC_NT); }
 
-int launch_sc_matvec(const DevMsc &msc, const ScMask *scm, const SubView &sub, int64_t M, int64_t row0,
+int launch_sc_matvec(const DevMsc &msc, const ScMask *scm, const ScLow &low, const SubView &sub, int64_t M, int64_t row0,
                      int64_t win_start, const double *diag, const void *xw, void *y, int64_t *colrange,
                      hipStream_t st) {
   DNM_CHECK(M > 0 && (M + SC_NT - 1) / SC_NT < (int64_t)1 << 31, "row count out of range");
   const dim3 grid((unsigned)sc_num_blocks(M)), blk(SC_NT);
-  hipLaunchKernelGGL(sc_matvec_kernel, grid, blk, 0, st, msc, scm, sub, M, row0, win_start, diag,
-                     (const c128 *)xw, (c128 *)y, colrange);
+  if ((sub.k + 1) * sub.ld <= NCK_LDS_MAX)
+    hipLaunchKernelGGL(sc_matvec_kernel<true>, grid, blk, 0, st, msc, scm, low, sub, M, row0, win_start, diag,
+                       (const c128 *)xw, (c128 *)y, colrange);
+  else
+    hipLaunchKernelGGL(sc_matvec_kernel<false>, grid, blk, 0, st, msc, scm, low, sub, M, row0, win_start, diag,
+                       (const c128 *)xw, (c128 *)y, colrange);
   DNM_HIP(hipGetLastError());
   return 0;
 }

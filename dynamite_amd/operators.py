@@ -23,7 +23,7 @@ class Operator:
         self._mats = {}
         self._is_reduced = False
         self._shell = True
-        self._precompute_diagonal = False
+        self._precompute_diagonal = True
         self._allow_projection = False
         self._msc = None
         self._L = None
@@ -304,8 +304,10 @@ class Operator:
             left_subspace=subspaces[0]._to_c(),
             right_subspace=subspaces[1]._to_c(),
             xparity=isinstance(subspaces[0], XParity), shell=self.shell, gpu=True)
+        # operators.py:627-629.  The tiled hypercube kernel evaluates the diagonal on the fly (cheaper than
+        # 8 B/amplitude of extra traffic), so the cache is only built for the kernels that read it.
         if (self.shell and self.precompute_diagonal and subspaces[0] == subspaces[1]
-                and masks.size and masks[0] == 0 and config.world_size == 1):
+                and masks.size and masks[0] == 0 and mat.uses_cached_diagonal()):
             backend.precompute_diagonal(mat)
         self._mats[(hash(subspaces[0]), hash(subspaces[1]))] = mat
 
