@@ -518,3 +518,33 @@ def test_state_project_and_function():
     a = State(L=6, state='random', seed=1)
     b = 2 - a
     assert np.allclose(b.to_numpy(), 2 - a.to_numpy(), atol=1e-15)
+
+
+# ------------------------------------------------------------------ BASELINE config 2 size
+
+def test_krylov_full_size_properties():
+    """L=26 XXZ, 2^26 amplitudes (BASELINE configs[1]): evolve conserves the norm and the energy and is
+    undone by the reverse evolution; the eigsolve result satisfies the residual bound it promises."""
+    import torch
+    free, _ = torch.cuda.mem_get_info()
+    if free < 40 * 16 * (1 << 26):
+        pytest.skip("not enough HBM")
+    L = 26
+    H = models.xxz(L)
+    x = State(L=L, state='random', seed=5)
+    e0 = H.expectation(x)
+    y = H.evolve(x, t=0.7)
+    assert abs(y.norm() - 1) < 1e-9
+    assert abs(H.expectation(y) - e0) < 1e-7
+    z = H.evolve(y, t=-0.7)
+    z.axpy(-1.0, x)
+    assert z.norm() < 1e-7
+    yi = H.evolve(x, t=-0.2j)                    # imaginary time lowers the energy
+    yi.normalize()
+    assert H.expectation(yi) < e0
+    ev, vecs = H.eigsolve(nev=1, getvecs=True, tol=1e-9)
+    v = vecs[0]
+    r = H.dot(v)
+    r.axpy(-ev[0], v)
+    assert abs(v.norm() - 1) < 1e-10 and r.norm() < 1e-8 * abs(ev[0])
+    assert ev[0] < H.expectation(yi) < e0

@@ -316,6 +316,64 @@ def test_full_size_properties(monkeypatch, L):
     mat.destroy(); mat2.destroy()
 
 
+@pytest.mark.parametrize("L", [26, 30])
+def test_full_size_default_plan(monkeypatch, L):
+    """The plan bench.py times (defaults: B=12, 8 rows per thread, LDS tiles + XCD-group gathers, fused
+    dot product) against the plain multi-pass LDS plan, element-wise, at the BASELINE sizes."""
+    import ctypes as C
+    import torch
+    free, _ = torch.cuda.mem_get_info()
+    if free < 4 * 16 * (1 << L):
+        pytest.skip("not enough HBM")
+    for k in ("DNM_TILE_BITS", "DNM_LOG_ROWS", "DNM_PLAN_MODE", "DNM_AMIN", "DNM_GBITS"):
+        monkeypatch.delenv(k, raising=False)
+    H = models.xxz(L) if L == 26 else models.mbl(L)
+    sub = Full(L=L)
+    n = 1 << L
+    a, y0, y1 = (backend.Vec(n) for _ in range(3))
+    a.set_random(4)
+    a.normalize()
+    mat = shell(H, sub)
+    assert "mode=2" in mat.describe() and "B=12 logR=3" in mat.describe()
+    d = (C.c_double * 2)()
+    _lib.check(_lib.lib().dnm_mat_mult_dot(mat.handle, a.ptr, y0.ptr, d, None))
+    ref_dot = a.dot(y0)                        # sum a_i conj(y0_i) = conj(<a, y0>)
+    assert abs(complex(d[0], -d[1]) - ref_dot) < 1e-10
+    cfg(monkeypatch, 12, 4, 0)
+    mat2 = shell(H, sub)
+    mat2.mult(a, y1)
+    assert _sample_rows_check(H, L, a, y0) < 1e-13
+    y1.axpby(-1.0, 1.0, y0)
+    assert y1.norm() < 1e-12
+    mat.destroy(); mat2.destroy()
+
+
+def test_spinconserve_large_properties():
+    """SpinConserve L=28, k=14 (40 M amplitudes): the incremental-rank kernel against the generic
+    row-gather kernel element-wise, with and without the cached diagonal, and Hermiticity."""
+    L, k = 28, 14
+    H = models.mbl(L)
+    sub = SpinConserve(L, k)
+    n = sub.get_dimension()
+    a, b, Ha, Hb, Hg = (backend.Vec(n) for _ in range(5))
+    a.set_random(1); b.set_random(2)
+    a.normalize(); b.normalize()
+    mat = shell(H, sub)
+    matg = shell(H, sub, flags=_lib.MAT_FORCE_GATHER)
+    assert "SpinConserve kernel" in mat.describe() and "row-gather" in matg.describe()
+    mat.mult(a, Ha)
+    matg.mult(a, Hg)
+    Hg.axpby(-1.0, 1.0, Ha)
+    assert Hg.norm() < 1e-12
+    mat.mult(b, Hb)
+    assert abs(Hb.dot(a) - b.dot(Ha)) < 1e-10
+    mat.precompute_diagonal()
+    mat.mult(a, Hg)
+    Hg.axpby(-1.0, 1.0, Ha)
+    assert Hg.norm() < 1e-12
+    mat.destroy(); matg.destroy()
+
+
 def test_error_behaviour():
     H = models.mbl(12)
     sub = Full(L=12)
