@@ -165,7 +165,7 @@ def eigsolve(H, getvecs=False, nev=1, which='lowest', target=None, tol=None, sub
         C.byref(hooks) if hooks is not None else None, nev_max, _lib.pf64(evals),
         C.c_void_p(evec_buf.data_ptr()) if evec_buf is not None else None, C.byref(stats), _stream()))
     eigsolve.last_stats = {'reason': stats.reason, 'its': stats.its, 'matvecs': stats.matvecs,
-                           'nconv': stats.nconv}
+                           'nconv': stats.nconv, 'max_rel_residual': stats.err_est}
     nconv = stats.nconv
     if stats.reason == _lib.DIVERGED_ITS:
         raise MaxIterationsError('eigensolver reached maximum number of iterations without '

@@ -259,7 +259,8 @@ typedef struct dnm_solver_stats {
   int32_t its;          /* outer steps (MFN) / restarts (EPS) */
   int32_t matvecs;
   int32_t nconv;        /* EPS only */
-  double  err_est;      /* MFN: accumulated local error estimate */
+  double  err_est;      /* MFN: accumulated local error estimate; EPS: largest measured
+                         * |H u - theta u| / |theta| of the returned pairs */
 } dnm_solver_stats;
 
 /* y = exp(scale * A) x, scale = (scale_re + i scale_im); evolve() passes

@@ -547,4 +547,6 @@ def test_krylov_full_size_properties():
     r = H.dot(v)
     r.axpy(-ev[0], v)
     assert abs(v.norm() - 1) < 1e-10 and r.norm() < 1e-8 * abs(ev[0])
+    from dynamite_amd.computations import eigsolve as _es
+    assert abs(_es.last_stats['max_rel_residual'] - r.norm() / abs(ev[0])) < 1e-12      # the solver measured the same
     assert ev[0] < H.expectation(yi) < e0
