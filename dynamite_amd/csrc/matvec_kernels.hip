@@ -277,6 +277,17 @@ tile_pass_kernel(const DevPass P, const c128 *__restrict__ x, c128 *__restrict__
 
   const DevQuad *__restrict__ quads = P.quads;
 
+#define DNM_LOOP(LP, KV, CX, GA, KZ) \
+  apply_records<R, LOGNT, KV, CX, GA, KZ>(quads, P.loop[LP], P.loop[LP + 1], ar, ai, tile, rows, x, xr, tid, sbase)
+  // experiment (cache_policy bit 5): the gathers right behind the tile loads, before the barrier, so that
+  // sibling workgroups request the same lines within the same microsecond (L2 lines live ~5 us here)
+  if (P.cache_policy & 32) {
+    DNM_LOOP(LP_GATHER_REAL, false, false, true, false);
+    DNM_LOOP(LP_GATHER_CPLX, false, true, true, false);
+    DNM_LOOP(LP_GATHER_KVAR, true, true, true, false);
+  }
+#undef DNM_LOOP
+
   // ---- diagonal, part 1 (before the barrier, under the tile loads): the terms
   // whose sign mask lies outside the tile are the same for the whole workgroup.
   // Each lane evaluates one term, a butterfly sums them across the wavefront.
@@ -341,7 +352,9 @@ tile_pass_kernel(const DevPass P, const c128 *__restrict__ x, c128 *__restrict__
   // ---- off-diagonal masks, one branch-free loop per record class
 #define DNM_LOOP(LP, KV, CX, GA, KZ) \
   apply_records<R, LOGNT, KV, CX, GA, KZ>(quads, P.loop[LP], P.loop[LP + 1], ar, ai, tile, rows, x, xr, tid, sbase)
-  if (P.cache_policy & 8) {   // gathers first: partner lines are freshest in L2 right after the loads
+  if (P.cache_policy & 32) {
+    // done before the barrier
+  } else if (P.cache_policy & 8) {   // gathers first: partner lines are freshest in L2 right after the loads
     if ((R <= 4) && (P.cache_policy & 16)) {
       apply_gathers_pipelined<R, false>(quads, P.loop[LP_GATHER_REAL], P.loop[LP_GATHER_REAL + 1], ar, ai, rows, x, xr, tid, sbase);
       apply_gathers_pipelined<R, true>(quads, P.loop[LP_GATHER_CPLX], P.loop[LP_GATHER_CPLX + 1], ar, ai, rows, x, xr, tid, sbase);
@@ -356,7 +369,7 @@ tile_pass_kernel(const DevPass P, const c128 *__restrict__ x, c128 *__restrict__
   DNM_LOOP(LP_TILE_CPLX, false, true, false, false);
   DNM_LOOP(LP_TILE_KVAR_REAL, true, false, false, false);
   DNM_LOOP(LP_TILE_KVAR_CPLX, true, true, false, false);
-  if (!(P.cache_policy & 8)) {
+  if (!(P.cache_policy & (8 | 32))) {
     if ((R <= 4) && (P.cache_policy & 16)) {
       apply_gathers_pipelined<R, false>(quads, P.loop[LP_GATHER_REAL], P.loop[LP_GATHER_REAL + 1], ar, ai, rows, x, xr, tid, sbase);
       apply_gathers_pipelined<R, true>(quads, P.loop[LP_GATHER_CPLX], P.loop[LP_GATHER_CPLX + 1], ar, ai, rows, x, xr, tid, sbase);

@@ -182,7 +182,8 @@ int make_plan(const OpForm &op, int rank, int nranks, const PlanConfig &cfg_in, 
   } else if (cfg.mode == 2) {
     // greedy cover by (LDS tile, XCD group) pairs: masks inside the tile come
     // from LDS, masks that also touch the group bits are gathered (L2)
-    if (cfg.gbits < 0) cfg.gbits = 0;
+    // measured on MI355X (profiles/r01_sweep5_*.txt): 8 group bits pay at 2^30 amplitudes, 6 below
+    if (cfg.gbits < 0) cfg.gbits = nl >= 30 ? 8 : 6;
     if (cfg.gbits > 8) cfg.gbits = 8;
     bool first = true;
     while (!remaining.empty() || first) {

@@ -93,7 +93,8 @@ struct DevPass {
   int32_t need_tile;    // 0: no tile mask and no diagonal -> skip the LDS stage
   int32_t has_diag;
   int32_t cache_policy; // bit0: write y through L2 (sc1 stores, line not kept); bit1: non-temporal y loads;
-                        // bit2: non-temporal x tile loads; bit3: gathers before the LDS masks
+                        // bit2: non-temporal x tile loads; bit3: gathers before the LDS masks;
+                        // bit5: gathers before the barrier, right behind the tile loads (default)
   // diagonal records: tile-external terms, then one list per k-bucket
   uint32_t dext_begin, dext_end;
   uint32_t dbucket[MAXR + 1];
@@ -138,9 +139,9 @@ struct PlanConfig {
   int amin = 4;        // smallest allowed low segment (2^amin * 16 B contiguous runs)
   int mode = 2;        // 0: multi-pass LDS tiles; 1: single pass, everything else gathered;
                        // 2: multi-pass LDS tiles + L2-served gathers over an XCD group
-  int gbits = 6;       // mode 2: bits per XCD group
+  int gbits = -1;      // mode 2: bits per XCD group (-1: 8 when the local vector has >= 2^30 amplitudes, else 6)
   int gbits_window = -1; // mode 2: cap of the group bits of window-tile passes (-1: no cap)
-  int cache_policy = 0; // DevPass::cache_policy for every pass (experiments)
+  int cache_policy = 32; // DevPass::cache_policy for every pass; default: gathers right behind the tile loads
   int max_gather_span = 0;   // mode 0: masks the tiler cannot place are gathered
 };
 
