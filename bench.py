@@ -159,7 +159,8 @@ def main():
                        "partition": f"{n_gpus} x 2^{L - int(math.log2(n_gpus))} contiguous blocks",
                        "launches_per_step": launches,
                        "tile_bits": int(os.environ.get("DNM_TILE_BITS", "12")),
-                       "plan_mode": int(os.environ.get("DNM_PLAN_MODE", "2"))},
+                       "plan_mode": int(os.environ.get("DNM_PLAN_MODE", "2")),
+                       "plan": mat.describe().strip().replace("\n", " | ")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "tile_pass_kernel", "avg_launch_ms": avg_launch_ms,

@@ -141,67 +141,6 @@ __device__ __forceinline__ void apply_records(const DevQuad *__restrict__ quads,
   }
 }
 
-// Gather loops, software-pipelined two records deep: the loads of record q+1
-// are in flight while record q is consumed (the compiler's counted vmcnt keeps
-// the younger loads outstanding).  !KVAR classes only.
-template <int R, bool CPLX>
-struct GatherStage {
-  c128 xv[R];
-  double cre, cim;
-};
-
-template <int R, bool CPLX>
-__device__ __forceinline__ void gather_issue(GatherStage<R, CPLX> &st, const DevQuad &Q,
-                                             const uint32_t (&rows)[R], const c128 *__restrict__ x,
-                                             const c128 *__restrict__ xr, uint32_t tid, uint64_t sbase) {
-  st.cre = slot_amp(Q, 0, tid, sbase) + slot_amp(Q, 1, tid, sbase);
-  st.cim = 0.0;
-  if constexpr (CPLX) st.cim = slot_amp(Q, 2, tid, sbase) + slot_amp(Q, 3, tid, sbase);
-  const bool live = (st.cre != 0.0) || (CPLX && st.cim != 0.0);
-  const c128 *__restrict__ src = Q.src ? xr : x;
-  const uint32_t mloc = Q.mask_loc;
-  if (live) {
-#pragma unroll
-    for (int k = 0; k < R; ++k) st.xv[k] = src[rows[k] ^ mloc];
-  } else {
-#pragma unroll
-    for (int k = 0; k < R; ++k) st.xv[k] = make_double2(0.0, 0.0);
-  }
-}
-
-template <int R, bool CPLX>
-__device__ __forceinline__ void gather_consume(const GatherStage<R, CPLX> &st, double (&ar)[R], double (&ai)[R]) {
-#pragma unroll
-  for (int k = 0; k < R; ++k) {
-    ar[k] = fma(st.cre, st.xv[k].x, ar[k]);
-    ai[k] = fma(st.cre, st.xv[k].y, ai[k]);
-    if constexpr (CPLX) {
-      ar[k] = fma(-st.cim, st.xv[k].y, ar[k]);
-      ai[k] = fma(st.cim, st.xv[k].x, ai[k]);
-    }
-  }
-}
-
-template <int R, bool CPLX>
-__device__ __forceinline__ void apply_gathers_pipelined(const DevQuad *__restrict__ quads, uint32_t b, uint32_t e,
-                                                        double (&ar)[R], double (&ai)[R],
-                                                        const uint32_t (&rows)[R], const c128 *__restrict__ x,
-                                                        const c128 *__restrict__ xr, uint32_t tid, uint64_t sbase) {
-  if constexpr (R > 4) return;   // would spill under the 128-VGPR budget
-  if (b >= e) return;
-  GatherStage<R, CPLX> s0, s1;
-  gather_issue<R, CPLX>(s0, quads[b], rows, x, xr, tid, sbase);
-  uint32_t qi = b;
-  while (true) {
-    if (qi + 1 < e) gather_issue<R, CPLX>(s1, quads[qi + 1], rows, x, xr, tid, sbase);
-    gather_consume<R, CPLX>(s0, ar, ai);
-    if (++qi >= e) break;
-    if (qi + 1 < e) gather_issue<R, CPLX>(s0, quads[qi + 1], rows, x, xr, tid, sbase);
-    gather_consume<R, CPLX>(s1, ar, ai);
-    if (++qi >= e) break;
-  }
-}
-
 // waves per SIMD the launch bounds ask for: what LDS lets be resident, capped at 4
 constexpr int tile_waves_per_simd(int B, int LOGR) {
   int nt = 1 << (B - LOGR);
@@ -211,7 +150,10 @@ constexpr int tile_waves_per_simd(int B, int LOGR) {
   return w < 1 ? 1 : (w > 4 ? 4 : w);
 }
 
-template <int B, int LOGR, bool GLDS>
+// GV (gather variant): 0 = gathers after the LDS masks; 1 = right behind the tile loads, before the barrier
+// (default: sibling workgroups then ask for the same lines within the same microsecond and the L2 merges the
+// requests).  (Two records in flight was tried: spills at 8 rows per thread, no gain at 16.)
+template <int B, int LOGR, bool GLDS, int GV>
 __global__ void __launch_bounds__(1 << (B - LOGR), tile_waves_per_simd(B, LOGR))
 tile_pass_kernel(const DevPass P, const c128 *__restrict__ x, c128 *__restrict__ y,
                  const c128 *__restrict__ xr) {
@@ -279,9 +221,7 @@ tile_pass_kernel(const DevPass P, const c128 *__restrict__ x, c128 *__restrict__
 
 #define DNM_LOOP(LP, KV, CX, GA, KZ) \
   apply_records<R, LOGNT, KV, CX, GA, KZ>(quads, P.loop[LP], P.loop[LP + 1], ar, ai, tile, rows, x, xr, tid, sbase)
-  // experiment (cache_policy bit 5): the gathers right behind the tile loads, before the barrier, so that
-  // sibling workgroups request the same lines within the same microsecond (L2 lines live ~5 us here)
-  if (P.cache_policy & 32) {
+  if constexpr (GV >= 1) {
     DNM_LOOP(LP_GATHER_REAL, false, false, true, false);
     DNM_LOOP(LP_GATHER_CPLX, false, true, true, false);
     DNM_LOOP(LP_GATHER_KVAR, true, true, true, false);
@@ -352,31 +292,14 @@ tile_pass_kernel(const DevPass P, const c128 *__restrict__ x, c128 *__restrict__
   // ---- off-diagonal masks, one branch-free loop per record class
 #define DNM_LOOP(LP, KV, CX, GA, KZ) \
   apply_records<R, LOGNT, KV, CX, GA, KZ>(quads, P.loop[LP], P.loop[LP + 1], ar, ai, tile, rows, x, xr, tid, sbase)
-  if (P.cache_policy & 32) {
-    // done before the barrier
-  } else if (P.cache_policy & 8) {   // gathers first: partner lines are freshest in L2 right after the loads
-    if ((R <= 4) && (P.cache_policy & 16)) {
-      apply_gathers_pipelined<R, false>(quads, P.loop[LP_GATHER_REAL], P.loop[LP_GATHER_REAL + 1], ar, ai, rows, x, xr, tid, sbase);
-      apply_gathers_pipelined<R, true>(quads, P.loop[LP_GATHER_CPLX], P.loop[LP_GATHER_CPLX + 1], ar, ai, rows, x, xr, tid, sbase);
-    } else {
-      DNM_LOOP(LP_GATHER_REAL, false, false, true, false);
-      DNM_LOOP(LP_GATHER_CPLX, false, true, true, false);
-    }
-    DNM_LOOP(LP_GATHER_KVAR, true, true, true, false);
-  }
   DNM_LOOP(LP_TILE_REAL_K0, false, false, false, true);
   DNM_LOOP(LP_TILE_REAL, false, false, false, false);
   DNM_LOOP(LP_TILE_CPLX, false, true, false, false);
   DNM_LOOP(LP_TILE_KVAR_REAL, true, false, false, false);
   DNM_LOOP(LP_TILE_KVAR_CPLX, true, true, false, false);
-  if (!(P.cache_policy & (8 | 32))) {
-    if ((R <= 4) && (P.cache_policy & 16)) {
-      apply_gathers_pipelined<R, false>(quads, P.loop[LP_GATHER_REAL], P.loop[LP_GATHER_REAL + 1], ar, ai, rows, x, xr, tid, sbase);
-      apply_gathers_pipelined<R, true>(quads, P.loop[LP_GATHER_CPLX], P.loop[LP_GATHER_CPLX + 1], ar, ai, rows, x, xr, tid, sbase);
-    } else {
-      DNM_LOOP(LP_GATHER_REAL, false, false, true, false);
-      DNM_LOOP(LP_GATHER_CPLX, false, true, true, false);
-    }
+  if constexpr (GV == 0) {
+    DNM_LOOP(LP_GATHER_REAL, false, false, true, false);
+    DNM_LOOP(LP_GATHER_CPLX, false, true, true, false);
     DNM_LOOP(LP_GATHER_KVAR, true, true, true, false);
   }
 #undef DNM_LOOP
@@ -436,18 +359,20 @@ static int launch_cfg(const DevPass &P, bool glds, int n_loc, const void *x, voi
   }();
   const size_t lds = std::max((size_t)16 << B, lds_req);
   const unsigned grid = 1u << (n_loc - B);
-  auto kg = tile_pass_kernel<B, LOGR, true>;
-  auto kr = tile_pass_kernel<B, LOGR, false>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    DNM_HIP(hipFuncSetAttribute((const void *)kg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    DNM_HIP(hipFuncSetAttribute((const void *)kr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_done = true;
+  // gather variant from the plan's cache policy: bit5 = early (default)
+  const int gv = (P.cache_policy & 32) ? 1 : 0;
+  using kern_t = void (*)(const DevPass, const c128 *, c128 *, const c128 *);
+  kern_t k = nullptr;
+  if (glds) k = tile_pass_kernel<B, LOGR, true, 1>;
+  else if (gv == 0) k = tile_pass_kernel<B, LOGR, false, 0>;
+  else k = tile_pass_kernel<B, LOGR, false, 1>;
+  static size_t attr_done[4] = {0, 0, 0, 0};
+  const int slot = glds ? 3 : gv;
+  if (attr_done[slot] < lds) {
+    DNM_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_done[slot] = lds;
   }
-  if (glds)
-    hipLaunchKernelGGL(kg, dim3(grid), dim3(NT), lds, st, P, (const c128 *)x, (c128 *)y, (const c128 *)xr);
-  else
-    hipLaunchKernelGGL(kr, dim3(grid), dim3(NT), lds, st, P, (const c128 *)x, (c128 *)y, (const c128 *)xr);
+  hipLaunchKernelGGL(k, dim3(grid), dim3(NT), lds, st, P, (const c128 *)x, (c128 *)y, (const c128 *)xr);
   DNM_HIP(hipGetLastError());
   return 0;
 }

@@ -93,8 +93,8 @@ struct DevPass {
   int32_t need_tile;    // 0: no tile mask and no diagonal -> skip the LDS stage
   int32_t has_diag;
   int32_t cache_policy; // bit0: write y through L2 (sc1 stores, line not kept); bit1: non-temporal y loads;
-                        // bit2: non-temporal x tile loads; bit3: gathers before the LDS masks;
-                        // bit5: gathers before the barrier, right behind the tile loads (default)
+                        // bit2: non-temporal x tile loads; bit5: gathers before the barrier, right behind
+                        // the tile loads (default)
   // diagonal records: tile-external terms, then one list per k-bucket
   uint32_t dext_begin, dext_end;
   uint32_t dbucket[MAXR + 1];
@@ -135,7 +135,7 @@ struct PassSpec {
 
 struct PlanConfig {
   int B = 12;          // log2 tile amplitudes
-  int logR = 3;        // log2 rows per thread
+  int logR = -1;       // log2 rows per thread (-1: 4 when the local vector has >= 2^30 amplitudes, else 3)
   int amin = 4;        // smallest allowed low segment (2^amin * 16 B contiguous runs)
   int mode = 2;        // 0: multi-pass LDS tiles; 1: single pass, everything else gathered;
                        // 2: multi-pass LDS tiles + L2-served gathers over an XCD group
