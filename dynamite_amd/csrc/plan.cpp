@@ -184,7 +184,7 @@ int make_plan(const OpForm &op, int rank, int nranks, const PlanConfig &cfg_in, 
     // from LDS, masks that also touch the group bits are gathered (L2)
     // measured on MI355X (profiles/r01_sweep5_*.txt): 8 group bits pay at 2^30 amplitudes, 6 below
     if (cfg.gbits < 0) cfg.gbits = nl >= 30 ? 8 : 6;
-    if (cfg.gbits > 8) cfg.gbits = 8;
+    if (cfg.gbits > 10) cfg.gbits = 10;
     bool first = true;
     while (!remaining.empty() || first) {
       PassSpec best;
