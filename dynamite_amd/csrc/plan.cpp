@@ -22,6 +22,7 @@ PlanConfig plan_config_from_env() {
   c.mode = env_int("DNM_PLAN_MODE", c.mode);
   c.gbits = env_int("DNM_GBITS", c.gbits);
   c.gbits_window = env_int("DNM_GBITS_WINDOW", c.gbits_window);
+  c.window_first = env_int("DNM_WINDOW_FIRST", c.window_first);
   c.cache_policy = env_int("DNM_CACHE_POLICY", c.cache_policy);
   return c;
 }
@@ -284,6 +285,18 @@ int make_plan(const OpForm &op, int rank, int nranks, const PlanConfig &cfg_in, 
     for (int idx : remaining) {
       pl.local[0].gather_masks.push_back(idx);
       pl.local[0].gather_src.push_back(0);
+    }
+  }
+
+  // Execution order (experiment, DNM_WINDOW_FIRST=1): window passes first, the contiguous pass accumulating
+  // last -- the idea being that the bandwidth-bound window pass then need not read y.  Measured slower: a
+  // window pass that only writes y takes 13.9 ms for 35 B/amp (profiles/r01_prof_multi18.txt).
+  if (cfg.window_first && pl.local.size() > 1) {
+    std::stable_sort(pl.local.begin(), pl.local.end(),
+                     [](const PassSpec &a, const PassSpec &b) { return (a.nseg > 1) > (b.nseg > 1); });
+    for (size_t i = 0; i < pl.local.size(); ++i) {
+      pl.local[i].accumulate = i > 0;
+      pl.local[i].has_diag = i == 0 && has_diag;
     }
   }
 

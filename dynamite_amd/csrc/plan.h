@@ -140,6 +140,7 @@ struct PlanConfig {
   int mode = 2;        // 0: multi-pass LDS tiles; 1: single pass, everything else gathered;
                        // 2: multi-pass LDS tiles + L2-served gathers over an XCD group
   int gbits = -1;      // mode 2: bits per XCD group (-1: 8 when the local vector has >= 2^30 amplitudes, else 6)
+  int window_first = 0; // mode 2 experiment: run the window passes before the contiguous one (measured slower)
   int gbits_window = -1; // mode 2: cap of the group bits of window-tile passes (-1: no cap)
   int cache_policy = 32; // DevPass::cache_policy for every pass; default: gathers right behind the tile loads
   int max_gather_span = 0;   // mode 0: masks the tiler cannot place are gathered
