@@ -433,6 +433,7 @@ extern "C" {
 
 int dnm_release_workspace(void) {
   g_basis.release();
+  rdm_release_scratch();
   return 0;
 }
 

@@ -426,6 +426,16 @@ int dnm_check_conserves(int64_t nmasks, const int64_t *masks, const int64_t *mas
 }
 
 // ---- reduced density matrix -----------------------------------------------------------
+static DevBuf g_rdm_scratch;     // released by dnm_release_workspace()
+}  // extern "C"
+namespace dnm {
+int rdm_release_scratch() {
+  g_rdm_scratch.release();
+  return 0;
+}
+}  // namespace dnm
+extern "C" {
+
 int dnm_reduced_density_matrix(const void *x, const dnm_subspace *sub, int keep_size, const int64_t *keep,
                                void *rho, void *stream) {
   DNM_CHECK(x && sub && rho && keep_size >= 0 && (keep_size == 0 || keep), "null argument");
@@ -463,7 +473,7 @@ int dnm_reduced_density_matrix(const void *x, const dnm_subspace *sub, int keep_
   size_t pbytes;
   rdm_plan(geo, &logtm, &ntiles, &nsplit, &cps, &pbytes);
   // scratch for the partial tiles: small ones are kept between calls (hipMalloc costs more than the kernel)
-  static DevBuf cached;
+  DevBuf &cached = g_rdm_scratch;
   DevBuf big;
   void *scratch = nullptr;
   if (pbytes <= ((size_t)1 << 30)) {

@@ -42,6 +42,8 @@ struct PassOnDevice {
   int64_t y_off = 0, src_off = 0; // partner passes: first local row / first partner amplitude
 };
 
+int rdm_release_scratch();   // frees the cached scratch of dnm_reduced_density_matrix
+
 }  // namespace dnm
 
 struct dnm_mat {

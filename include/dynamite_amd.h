@@ -266,7 +266,8 @@ typedef struct dnm_solver_stats {
 /* y = exp(scale * A) x, scale = (scale_re + i scale_im); evolve() passes
  * scale = -i t (computations.py:89-96).  Sidje-Expokit adaptive Krylov
  * (SLEPc MFNEXPOKIT); because A is Hermitian the basis is built by Lanczos
- * with full re-orthogonalisation.  tol<=0 -> 1e-8; ncv<=0 -> min(30, N);
+ * with partial re-orthogonalisation (DNM_EXPM_ORTHO=full: against the whole
+ * basis every step, as SLEPc's BV).  tol<=0 -> 1e-8; ncv<=0 -> min(30, N);
  * max_its<=0 -> 100 (SLEPc defaults).  work_limit_bytes bounds the basis
  * allocation (0 = no limit): ncv is reduced to fit. */
 int dnm_expm_multiply(dnm_mat *A, const void *x, void *y, int64_t n_local,
@@ -274,7 +275,10 @@ int dnm_expm_multiply(dnm_mat *A, const void *x, void *y, int64_t n_local,
                       int max_its, size_t work_limit_bytes, const dnm_hooks *hooks,
                       dnm_solver_stats *stats, void *stream);
 
-/* The solvers keep their Krylov-basis allocation between calls; this frees it. */
+/* The solvers keep their Krylov-basis allocation between calls and the reduced
+ * density matrix its tile scratch; this frees them.  (The library keeps such
+ * per-process buffers and small reduction scratch: calls are not re-entrant --
+ * one host thread per process, as the reference's one thread per MPI rank.) */
 int dnm_release_workspace(void);
 
 enum { DNM_WHICH_LOWEST = 0, DNM_WHICH_HIGHEST = 1, DNM_WHICH_EXTERIOR = 2 };
@@ -282,7 +286,10 @@ enum { DNM_WHICH_LOWEST = 0, DNM_WHICH_HIGHEST = 1, DNM_WHICH_EXTERIOR = 2 };
 /* Thick-restart Lanczos (SLEPc EPSKRYLOVSCHUR on a HEP).  evals: [nev_max]
  * doubles; evecs (optional, may be NULL): device buffer of nev_max vectors of
  * n_local complex128 each, stride n_local.  nev_max >= nev.  tol<=0 -> 1e-8;
- * ncv<=0 -> max(2*nev, nev+15); max_its<=0 -> max(100, 2N/ncv). */
+ * ncv<=0 -> max(2*nev, nev+15); max_its<=0 -> max(100, 2N/ncv).  Partial
+ * re-orthogonalisation with a tolerance-driven trigger (DNM_EIGS_ORTHO=full:
+ * every step against the whole basis, as SLEPc); stats->err_est returns the
+ * measured largest relative residual of the returned pairs. */
 int dnm_eigsolve(dnm_mat *A, int64_t n_local, int nev, int which, double tol,
                  int ncv, int max_its, uint64_t seed, const dnm_hooks *hooks,
                  int nev_max, double *evals, void *evecs,
