@@ -374,6 +374,70 @@ def test_spinconserve_large_properties():
     mat.destroy(); matg.destroy()
 
 
+def _random_hermitian(L, nterms, rs):
+    """Sum of random Pauli strings with real coefficients (Hermitian by construction)."""
+    from dynamite_amd.operators import sigmax, sigmay, sigmaz, op_sum, op_product
+    terms = []
+    for _ in range(nterms):
+        w = rs.randint(1, min(L, 5) + 1)
+        sites = rs.choice(L, size=w, replace=False)
+        ops = [(sigmax, sigmay, sigmaz)[rs.randint(3)](int(i)) for i in sites]
+        terms.append(float(rs.uniform(-1, 1)) * op_product(ops))
+    H = op_sum(terms)
+    H.L = L
+    return H
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("DNM_FUZZ_N", "8"))))
+def test_fuzz_random_operators(monkeypatch, seed):
+    """Random Pauli-string Hamiltonians (long strings, imaginary matrix elements, many terms per mask,
+    masks straddling tile / group / window boundaries) on random subspaces, tile shapes and plan modes,
+    rank-partitioned or not, against the CPU oracle."""
+    rs = np.random.RandomState(100 + seed)
+    L = int(rs.randint(9, 19))
+    B, logR = [(8, 2), (10, 2), (10, 3), (11, 3), (12, 3), (12, 4)][rs.randint(6)]
+    mode = int(rs.randint(3))
+    cfg(monkeypatch, B=B, logR=logR, mode=mode, amin=int(rs.randint(3, 6)), gbits=int(rs.randint(0, 7)))
+    monkeypatch.setenv("DNM_CACHE_POLICY", str([0, 32][rs.randint(2)]))
+    H = _random_hermitian(L, int(rs.randint(3, 40)), rs)
+    arrs = marshal(H)
+    kind = ["full", "full", "parity", "sc", "explicit"][rs.randint(5)]
+    if kind == "full":
+        left = right = Full(L=L)
+    elif kind == "parity":
+        left, right = Parity(int(rs.randint(2)), L=L), Parity(int(rs.randint(2)), L=L)
+    elif kind == "sc":
+        left = right = SpinConserve(L, int(rs.randint(1, L)))
+    else:
+        left = right = Explicit(np.sort(rs.choice(1 << L, size=min(1 << L, 3000), replace=False)), L=L)
+    x = rand_state(right.get_dimension(), seed=seed)
+    ref = orc.matvec(orc_msc(H), orc_sub(left), orc_sub(right), x)
+    mat = shell(H, left, right)
+    y = mult_numpy(mat, x)
+    assert np.max(np.abs(y - ref)) <= tol_for(arrs, x), (L, B, logR, mode, kind, mat.describe())
+    assert abs(mat.norm() - orc.infnorm(orc_msc(H), orc_sub(left), orc_sub(right))) <= 1e-12 * max(1.0, mat.norm())
+    mat.destroy()
+    # the same operator partitioned over P ranks (hypercube subspaces with a local block >= one tile)
+    P = int(2 ** rs.randint(1, 3))
+    n = L if kind == "full" else L - 1
+    if kind in ("full", "parity") and left is right or (kind == "parity" and left.space == right.space):
+        if n - int(np.log2(P)) - 1 >= B:
+            Lb = _lib.lib()
+            nloc = left.get_dimension() // P
+            yp = np.empty(left.get_dimension(), dtype=complex)
+            for r in range(P):
+                h = backend.create_mat(*arrs, left._c(), right._c(), flags=0, rank=r, nranks=P)
+                m = backend.ShellMat(h, left._c(), right._c(), P, r)
+                xl, yl = vec_from(x[r * nloc:(r + 1) * nloc]), backend.Vec(nloc)
+                _lib.check(Lb.dnm_mat_mult_local(m.handle, xl.ptr, yl.ptr, None))
+                for i, (p, off, cnt) in enumerate(m.recvs):
+                    xr = vec_from(x[p * nloc + off:p * nloc + off + cnt])
+                    _lib.check(Lb.dnm_mat_mult_remote(m.handle, i, xr.ptr, yl.ptr, None))
+                yp[r * nloc:(r + 1) * nloc] = yl.local_numpy()
+                m.destroy()
+            assert np.max(np.abs(yp - ref)) <= tol_for(arrs, x), (L, B, P, kind)
+
+
 def test_error_behaviour():
     H = models.mbl(12)
     sub = Full(L=12)
