@@ -550,3 +550,34 @@ def test_krylov_full_size_properties():
     from dynamite_amd.computations import eigsolve as _es
     assert abs(_es.last_stats['max_rel_residual'] - r.norm() / abs(ev[0])) < 1e-12      # the solver measured the same
     assert ev[0] < H.expectation(yi) < e0
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fuzz_krylov_random_operators(seed):
+    """evolve (real, imaginary and complex times) and eigsolve on random Pauli-string Hamiltonians and
+    subspaces against dense linear algebra on the host."""
+    from test_gpu_matvec import _random_hermitian
+    rs = np.random.RandomState(500 + seed)
+    L = int(rs.randint(6, 11))
+    H = _random_hermitian(L, int(rs.randint(4, 25)), rs)
+    kind = ["full", "parity", "xparity"][rs.randint(3)]
+    sub = Full(L=L)
+    if kind == "parity":
+        sub = Parity(int(rs.randint(2)), L=L)
+    elif kind == "xparity":
+        sub = XParity(Full(L=L), sector=[+1, -1][rs.randint(2)])
+    H.add_subspace(sub)
+    H.allow_projection = True
+    A = H.to_numpy(subspaces=(sub, sub)).toarray()
+    A = (A + A.conj().T) / 2 if kind != "full" else A      # projections of a Hermitian operator stay Hermitian
+    w, U = np.linalg.eigh(A)
+    x = State(L=L, subspace=sub, state='random', seed=seed)
+    for t in (float(rs.uniform(0.1, 2.0)), -1j * float(rs.uniform(0.05, 0.5)), complex(rs.uniform(0.1, 1), -rs.uniform(0.05, 0.3))):
+        y = H.evolve(x, t=t, tol=1e-10).to_numpy()
+        ref = U @ (np.exp(-1j * t * w) * (U.conj().T @ x.to_numpy()))
+        assert np.linalg.norm(y - ref) < 1e-8 * max(1.0, np.linalg.norm(ref)), (kind, t)
+    if np.ptp(w) > 1e-6:
+        ev = H.eigsolve(nev=2, tol=1e-11, subspace=sub)
+        assert abs(ev[0] - w[0]) < 1e-9
+        hi = H.eigsolve(nev=1, which='highest', tol=1e-11, subspace=sub)
+        assert abs(hi[0] - w[-1]) < 1e-9
