@@ -66,7 +66,7 @@ class DevPass(C.Structure):
                 ("sign_base", C.c_uint64), ("accumulate", C.c_int32), ("need_tile", C.c_int32),
                 ("has_diag", C.c_int32), ("cache_policy", C.c_int32), ("dext_begin", C.c_uint32), ("dext_end", C.c_uint32),
                 ("dbucket", C.c_uint32 * (MAXR + 1)), ("loop", C.c_uint32 * (LP_COUNT + 1)),
-                ("nquads", C.c_int32), ("n_eff", C.c_int32), ("quads", vp), ("dot_out", vp)]
+                ("nquads", C.c_int32), ("n_eff", C.c_int32), ("quads", vp), ("dot_out", vp), ("zinit", vp), ("zscale", C.c_double)]
 
 
 class Xfer(C.Structure):
@@ -115,6 +115,7 @@ SIGNATURES = {
     "dnm_mat_exchange_plan": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(Xfer), C.POINTER(C.c_int),
                                         C.POINTER(Xfer)]),
     "dnm_mat_mult_dot": (C.c_int, [vp, vp, vp, f64p, vp]),
+    "dnm_mat_mult_lanczos": (C.c_int, [vp, vp, vp, vp, C.c_double, f64p, vp]),
     "dnm_mat_mult_local": (C.c_int, [vp, vp, vp, vp]),
     "dnm_mat_mult_remote": (C.c_int, [vp, C.c_int32, vp, vp, vp]),
     "dnm_vec_set": (C.c_int, [vp, C.c_int64, C.c_double, C.c_double, vp]),

@@ -176,18 +176,19 @@ struct Ops {
     }
     return dnm_mat_mult(A, x, y, (void *)st);
   }
-  // y = A x and d = <x, y>
-  int mult_dot(const void *x, void *y, zc *d) {
+  // y = A x - b z (z may be null) and d = <x, y>: the multiply of one three-term Lanczos step
+  int mult_dot(const void *x, void *y, zc *d, const void *z = nullptr, double b = 0.0) {
     if (hooks && hooks->mult) {
       std::vector<zc> h;
       DNM_TRY(mult(x, y));
+      if (z) DNM_TRY(vk_axpby(y, z, n, -b, 0.0, 1.0, 0.0, st));
       DNM_TRY(mdot(x, 1, y, h));
       *d = h[0];
       return 0;
     }
     ++matvecs;
     double buf[2];
-    DNM_TRY(dnm_mat_mult_dot(A, x, y, buf, (void *)st));
+    DNM_TRY(dnm_mat_mult_lanczos(A, x, y, z, b, buf, (void *)st));
     *d = zc(buf[0], buf[1]);
     return 0;
   }
@@ -520,7 +521,10 @@ int dnm_expm_multiply(dnm_mat *A, const void *x, void *y, int64_t n_local, doubl
     for (int j = 0; j < m; ++j) {
       void *p = vecptr(V, n_local, j + 1);
       zc d0(0);
-      if (use_pro) DNM_TRY(ops.mult_dot(vecptr(V, n_local, j), p, &d0));
+      // the beta term of the recurrence rides on the multiply: p = H w_j - (beta_j nv_j / nv_{j-1}) w_{j-1}
+      if (use_pro)
+        DNM_TRY(ops.mult_dot(vecptr(V, n_local, j), p, &d0, j > 0 ? vecptr(V, n_local, j - 1) : nullptr,
+                             j > 0 ? bet[j] * nv[j] / nv[j - 1] : 0.0));
       else DNM_TRY(ops.mult(vecptr(V, n_local, j), p));
       double hn = 0;
       if (use_pro) {
@@ -529,9 +533,8 @@ int dnm_expm_multiply(dnm_mat *A, const void *x, void *y, int64_t n_local, doubl
         h[j] = alpha;
         if (j > 0) h[j - 1] = bet[j];
         double n2 = 0;
-        DNM_TRY(vec_lanczos_update_host(p, vecptr(V, n_local, j), j > 0 ? vecptr(V, n_local, j - 1) : nullptr,
-                                        n_local, alpha.real(), alpha.imag(),
-                                        j > 0 ? bet[j] * nv[j] / nv[j - 1] : 0.0, &n2, st));
+        DNM_TRY(vec_lanczos_update_host(p, vecptr(V, n_local, j), nullptr, n_local, alpha.real(), alpha.imag(), 0.0,
+                                        &n2, st));
         DNM_TRY(ops.sum(&n2, 1));
         nv[j + 1] = std::sqrt(n2 > 0 ? n2 : 0.0);
         hn = nv[j + 1] / nv[j];
@@ -669,7 +672,7 @@ int dnm_eigsolve(dnm_mat *A, int64_t n_local, int nev, int which, double tol, in
       void *p = vecptr(V, n_local, j + 1);
       const bool three_term = use_pro && j != l;
       zc d0(0);
-      if (three_term) DNM_TRY(ops.mult_dot(vecptr(V, n_local, j), p, &d0));
+      if (three_term) DNM_TRY(ops.mult_dot(vecptr(V, n_local, j), p, &d0, vecptr(V, n_local, j - 1), betav[j - 1]));
       else DNM_TRY(ops.mult(vecptr(V, n_local, j), p));
       double bn = 0;
       if (!three_term) {
@@ -681,8 +684,8 @@ int dnm_eigsolve(dnm_mat *A, int64_t n_local, int nev, int which, double tol, in
       } else {
         alpha[j] = d0.real();
         double n2 = 0;
-        DNM_TRY(vec_lanczos_update_host(p, vecptr(V, n_local, j), vecptr(V, n_local, j - 1), n_local, d0.real(),
-                                        d0.imag(), betav[j - 1], &n2, st));
+        DNM_TRY(vec_lanczos_update_host(p, vecptr(V, n_local, j), nullptr, n_local, d0.real(), d0.imag(), 0.0, &n2,
+                                        st));
         DNM_TRY(ops.sum(&n2, 1));
         bn = std::sqrt(n2 > 0 ? n2 : 0.0);
         if (mon.update(j, alpha[j], bn)) {

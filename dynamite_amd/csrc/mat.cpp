@@ -707,30 +707,43 @@ int dnm_mat_mult_local(dnm_mat *A, const void *x, void *y, void *stream) {
                               A->have_diag ? (const double *)A->diag.p : nullptr, x, y, S(stream));
 }
 
-// y = A x and <x, y> = sum conj(x_i) y_i.  When the last pass of the plan stages x in LDS the dot product is
-// accumulated there (per-workgroup partials, summed by a second tiny kernel); otherwise a separate sweep.
-int dnm_mat_mult_dot(dnm_mat *A, const void *x, void *y, double *dot, void *stream) {
+// y = A x - b z and <x, y> = sum conj(x_i) y_i (z may be null).  When the plan is tiled, the first pass starts its
+// accumulators from -b z instead of zero and the last pass -- if it stages x in LDS -- accumulates the dot product
+// (per-workgroup partials, summed by a second tiny kernel); otherwise separate sweeps do the same.
+int dnm_mat_mult_lanczos(dnm_mat *A, const void *x, void *y, const void *z, double b, double *dot, void *stream) {
   DNM_CHECK(A && x && y && dot, "null argument");
-  DNM_CHECK(A->remote_passes.empty(), "operator couples different ranks: no fused dot product");
-  const bool fused = A->hypercube && A->plan.use_tiled && !A->local_passes.empty() &&
-                     A->local_passes.back()->desc.need_tile && !A->host_only;
-  if (!fused) {
+  DNM_CHECK(A->remote_passes.empty(), "operator couples different ranks: no fused Lanczos step");
+  DNM_CHECK(z != y && x != y, "y must not alias x or z");
+  const bool tiled = A->hypercube && A->plan.use_tiled && !A->local_passes.empty() && !A->host_only;
+  if (!tiled) {
     DNM_TRY(dnm_mat_mult_local(A, x, y, stream));
+    if (z) DNM_TRY(vk_axpby(y, z, A->m_local, -b, 0.0, 1.0, 0.0, S(stream)));
     return vec_mdot_host(x, A->m_local, 1, y, A->m_local, dot, S(stream));
   }
+  const bool fused_dot = A->local_passes.back()->desc.need_tile != 0;
   const size_t nblk = (size_t)1 << (A->local_passes.back()->n_eff - A->plan.cfg.B);
   double *part = nullptr;
-  DNM_TRY(vec_scratch((nblk + 1) * 2 * sizeof(double), &part));
+  if (fused_dot) DNM_TRY(vec_scratch((nblk + 1) * 2 * sizeof(double), &part));
   for (size_t i = 0; i < A->local_passes.size(); ++i) {
     DevPass d = A->local_passes[i]->desc;
-    if (i + 1 == A->local_passes.size()) d.dot_out = part;
+    if (i == 0 && z) {
+      DNM_CHECK(!d.accumulate, "internal: first pass accumulates");
+      d.zinit = z;
+      d.zscale = b;
+    }
+    if (fused_dot && i + 1 == A->local_passes.size()) d.dot_out = part;
     DNM_TRY(launch_tile_pass(d, A->plan.cfg.B, A->plan.cfg.logR, use_glds(A), A->local_passes[i]->n_eff, x, y,
                              nullptr, S(stream)));
   }
+  if (!fused_dot) return vec_mdot_host(x, A->m_local, 1, y, A->m_local, dot, S(stream));
   DNM_TRY(vk_reduce_partials(part, (int)nblk, 2, part + 2 * nblk, S(stream)));
   DNM_HIP(hipMemcpyAsync(dot, part + 2 * nblk, 2 * sizeof(double), hipMemcpyDeviceToHost, S(stream)));
   DNM_HIP(hipStreamSynchronize(S(stream)));
   return 0;
+}
+
+int dnm_mat_mult_dot(dnm_mat *A, const void *x, void *y, double *dot, void *stream) {
+  return dnm_mat_mult_lanczos(A, x, y, nullptr, 0.0, dot, stream);
 }
 
 int dnm_mat_mult(dnm_mat *A, const void *x, void *y, void *stream) {

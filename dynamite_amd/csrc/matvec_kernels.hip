@@ -212,6 +212,15 @@ tile_pass_kernel(const DevPass P, const c128 *__restrict__ x, c128 *__restrict__
         ai[k] = v.y;
       }
     }
+  } else if (P.zinit) {
+    const c128 *__restrict__ z = (const c128 *)P.zinit;
+    const double zs = -P.zscale;
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      const c128 v = z[rows[k]];
+      ar[k] = zs * v.x;
+      ai[k] = zs * v.y;
+    }
   } else {
 #pragma unroll
     for (int k = 0; k < R; ++k) ar[k] = ai[k] = 0.0;

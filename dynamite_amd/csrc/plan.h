@@ -103,6 +103,8 @@ struct DevPass {
   int32_t n_eff;        // index bits this pass runs over (n_loc, or n_loc - 1 for a half-block partner pass)
   const DevQuad *quads;
   double *dot_out;      // non-null (last pass, tile staged): per-workgroup partial sums of conj(x_row) y_row
+  const void *zinit;    // non-null (first, non-accumulating pass): y starts from -zscale * zinit (Lanczos: the
+  double zscale;        //   beta term of the three-term recurrence rides on the multiply)
 };
 
 // ---- host-side description --------------------------------------------------

@@ -476,4 +476,12 @@ def test_mult_dot_fused(monkeypatch, name, L, sub):
     ref = np.vdot(x, y1.local_numpy())
     assert abs(complex(d[0], d[1]) - ref) <= 1e-13 * max(1.0, abs(ref)) * np.sqrt(x.size)
     assert abs(d[1]) <= 1e-12 * max(1.0, abs(ref))      # Hermitian operator: real expectation value
+    # the whole Lanczos multiply: y = Hx - b z, <x, y>
+    z = rand_state(s.get_dimension(), seed=9)
+    zv, y3 = vec_from(z), backend.Vec(mat.M)
+    _lib.check(_lib.lib().dnm_mat_mult_lanczos(mat.handle, xv.ptr, y3.ptr, zv.ptr, 0.37, d, None))
+    want = y1.local_numpy() - 0.37 * z
+    assert np.max(np.abs(y3.local_numpy() - want)) <= 4e-16 * max(1.0, np.abs(want).max())
+    ref = np.vdot(x, want)
+    assert abs(complex(d[0], d[1]) - ref) <= 1e-13 * max(1.0, abs(ref)) * np.sqrt(x.size)
     mat.destroy()
