@@ -366,7 +366,8 @@ class XParity(Subspace):
 
     @classmethod
     def _validate_parent(cls, parent):
-        # subspaces.py:566-617
+        """What subspaces.py:566-617 requires of a parent: a product-state basis, closed under the
+        global flip, whose first half is exactly the configurations with spin L-1 up."""
         if not parent.product_state_basis:
             raise ValueError('parent must be a product state subspace')
         if isinstance(parent, Full):
@@ -374,27 +375,25 @@ class XParity(Subspace):
         if parent.L is None:
             raise ValueError('L must be set for the parent subspace')
         if isinstance(parent, Parity):
-            if parent.L % 2 == 0:
-                return
-            raise ValueError('Parity is only compatible with XParity when L is even')
+            if parent.L % 2:
+                raise ValueError('Parity is only compatible with XParity when L is even')
+            return
         if isinstance(parent, SpinConserve):
-            if parent.L == 2 * parent.k:
-                return
-            raise ValueError('SpinConserve is only compatible with XParity when k=L/2')
+            if parent.L != 2 * parent.k:
+                raise ValueError('SpinConserve is only compatible with XParity when k=L/2')
+            return
+        # anything else (Explicit, Auto): look at the states themselves
         dim = parent.get_dimension()
-        if dim % 2 != 0:
+        if dim % 2:
             raise ValueError('parent subspace must have even dimension')
-        block_size = 1024
-        for start in range(0, dim // 2, block_size):
-            end = min(start + block_size, dim // 2)
-            state_block = parent.idx_to_state(np.arange(start, end))
-            if np.count_nonzero(state_block >> (parent.L - 1)):
-                raise ValueError('first dim/2 basis states must have spin L-1 up '
-                                 '(0 in integer notation)')
-            flipped = state_block ^ ((1 << parent.L) - 1)
-            if np.any(parent.state_to_idx(flipped) == -1):
-                raise ValueError('the complement of every state in subspace (all spins flipped) '
-                                 'must also be in subspace')
+        reps = parent.idx_to_state(np.arange(dim // 2))
+        if np.any(reps >> (parent.L - 1)):
+            raise ValueError('first dim/2 basis states must have spin L-1 up '
+                             '(0 in integer notation)')
+        partners = parent.state_to_idx(reps ^ ((1 << parent.L) - 1))
+        if np.any(partners < 0):
+            raise ValueError('the complement of every state in subspace (all spins flipped) '
+                             'must also be in subspace')
 
     @property
     def parent(self):
@@ -414,22 +413,18 @@ class XParity(Subspace):
         self._cdesc = None
 
     def reduce_msc(self, msc, check_conserves=False):
-        """Equivalent operator inside the sector (subspaces.py:632-674): terms that
-        anticommute with the symmetry are dropped, masks that flip spin L-1 are complemented
-        (with the sector's sign), like terms merged."""
+        """The operator as it acts inside the sector (subspaces.py:632-674).  A Pauli string with an
+        odd number of sigma_z/sigma_y factors anticommutes with the global flip and is dropped; a
+        string that flips spin L-1 is multiplied by the flip operator (mask complemented, coefficient
+        times the sector) so that representatives map to representatives; like terms are merged."""
         from . import msc_tools
-        msc = msc.copy()
-        keep = msc_tools.parity(msc['signs']) == 0
-        conserved = bool(np.all(keep))
-        msc = msc[keep]
-        terms_to_mod = np.nonzero(msc['masks'] >> (self.L - 1))
-        msc['masks'][terms_to_mod] ^= (1 << self.L) - 1
-        if self.sector == -1:
-            msc['coeffs'][terms_to_mod] *= -1
-        msc = msc_tools.combine_and_sort(msc)
-        if check_conserves:
-            return msc, conserved
-        return msc
+        commuting = msc_tools.parity(msc['signs']) == 0
+        out = msc[commuting].copy()
+        leaves = (out['masks'] >> (self.L - 1)) != 0
+        out['masks'][leaves] ^= (1 << self.L) - 1
+        out['coeffs'][leaves] *= self.sector
+        out = msc_tools.combine_and_sort(out)
+        return (out, bool(commuting.all())) if check_conserves else out
 
     def convert_state(self, state):
         """A state on this subspace -> its parent, or back (subspaces.py:676-762)."""
