@@ -116,7 +116,7 @@ static void remote_needs(const OpForm &op, int rank, int nl, int B, std::vector<
   });
 }
 
-int make_plan(const OpForm &op, int rank, int nranks, const PlanConfig &cfg_in, Plan *out) {
+static int make_plan_with(const OpForm &op, int rank, int nranks, const PlanConfig &cfg_in, Plan *out) {
   Plan &pl = *out;
   pl = Plan();
   pl.cfg = cfg_in;
@@ -218,7 +218,7 @@ int make_plan(const OpForm &op, int rank, int nranks, const PlanConfig &cfg_in, 
         }
       };
       consider(tile_spec(B, B, 0));
-      for (int a = cfg.amin; a < B && a <= 6; ++a)
+      for (int a = cfg.amin; a < B && a <= 9; ++a)
         for (int w = a + 1; w + (B - a) <= nl; ++w) consider(tile_spec(B, a, w));
       if (best_score <= 0 && !first) break;
       const uint64_t tb = best.tile_bits();
@@ -259,7 +259,7 @@ int make_plan(const OpForm &op, int rank, int nranks, const PlanConfig &cfg_in, 
         int sc = covered_by(ps, nullptr);
         if (sc > best_score) { best_score = sc; best = ps; }
       }
-      for (int a = cfg.amin; a < B && a <= 6; ++a) {
+      for (int a = cfg.amin; a < B && a <= 9; ++a) {
         int b = B - a;
         for (int w = a + 1; w + b <= nl; ++w) {
           PassSpec ps = tile_spec(B, a, w);
@@ -327,6 +327,24 @@ int make_plan(const OpForm &op, int rank, int nranks, const PlanConfig &cfg_in, 
     remote_needs(op, q, nl, B, &theirs);
     for (const Need &nd : theirs)
       if (nd.partner == rank) pl.sends.push_back({q, nd.src_off, (int64_t)1 << nd.n_eff});
+  }
+  return 0;
+}
+
+int make_plan(const OpForm &op, int rank, int nranks, const PlanConfig &cfg_in, Plan *out) {
+  if (cfg_in.amin >= 0) return make_plan_with(op, rank, nranks, cfg_in, out);
+  // default run length of the window passes: 256 B (amin = 4); at >= 2^30 local amplitudes 1 KB runs (amin = 6)
+  // measured 2.5 % faster with the wide group (the L2 merges part of the window pass's gathers,
+  // profiles/r01_prof_multi16.txt) -- unless they cost a launch
+  PlanConfig c4 = cfg_in;
+  c4.amin = 4;
+  DNM_TRY(make_plan_with(op, rank, nranks, c4, out));
+  if (out->use_tiled && out->n_loc >= 30 && out->cfg.mode == 2) {
+    PlanConfig c6 = cfg_in;
+    c6.amin = 6;
+    Plan p6;
+    DNM_TRY(make_plan_with(op, rank, nranks, c6, &p6));
+    if (p6.local.size() <= out->local.size()) *out = p6;
   }
   return 0;
 }

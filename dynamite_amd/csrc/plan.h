@@ -138,7 +138,7 @@ struct PassSpec {
 struct PlanConfig {
   int B = 12;          // log2 tile amplitudes
   int logR = -1;       // log2 rows per thread (-1: 4 when the local vector has >= 2^30 amplitudes, else 3)
-  int amin = 4;        // smallest allowed low segment (2^amin * 16 B contiguous runs)
+  int amin = -1;       // smallest allowed low segment (2^amin * 16 B contiguous runs); -1: see make_plan
   int mode = 2;        // 0: multi-pass LDS tiles; 1: single pass, everything else gathered;
                        // 2: multi-pass LDS tiles + L2-served gathers over an XCD group
   int gbits = -1;      // mode 2: bits per XCD group (-1: 8 when the local vector has >= 2^30 amplitudes, else 6)
