@@ -1,0 +1,31 @@
+#!/usr/bin/env python
+"""BASELINE config 5 on one GPU: lowest eigenvalue of the Heisenberg chain in the SpinConserve(L, L/2) sector."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+from dynamite_amd import models  # noqa: E402
+from dynamite_amd.config import config  # noqa: E402
+from dynamite_amd.subspaces import SpinConserve  # noqa: E402
+from dynamite_amd.computations import eigsolve  # noqa: E402
+
+
+def main():
+    L = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+    tol = float(sys.argv[2]) if len(sys.argv) > 2 else 1e-8
+    config._initialize()
+    H = models.heisenberg(L)
+    sub = SpinConserve(L, L // 2)
+    H.add_subspace(sub)
+    t0 = time.perf_counter()
+    ev = H.eigsolve(nev=1, tol=tol, subspace=sub)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    st = eigsolve.last_stats
+    print("SpinConserve(%d,%d) dim=%d eigsolve nev=1 tol=%g: %.2f s, %d restarts, %d matvecs, E0=%.10f (E0/L=%.6f), "
+          "measured relative residual %.1e" % (L, L // 2, sub.get_dimension(), tol, dt, st['its'], st['matvecs'], ev[0],
+                                               ev[0] / L, st['max_rel_residual']), flush=True)
+
+
+if __name__ == "__main__":
+    main()
