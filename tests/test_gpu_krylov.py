@@ -581,3 +581,16 @@ def test_fuzz_krylov_random_operators(seed):
         assert abs(ev[0] - w[0]) < 1e-9
         hi = H.eigsolve(nev=1, which='highest', tol=1e-11, subspace=sub)
         assert abs(hi[0] - w[-1]) < 1e-9
+
+
+def test_tools_memory():
+    from dynamite_amd import tools
+    tools.track_memory()
+    before = tools.get_memory_usage(group_by='rank')
+    st = State(L=24, state='random', seed=0)           # 256 MiB of HBM
+    after = tools.get_memory_usage(group_by='rank')
+    assert after - before > 0.2 and tools.get_memory_usage(max_usage=True) > 0.2
+    assert 'dynamite_amd' in tools.get_version() and 'ABI' in tools.get_version_str()
+    with pytest.raises(ValueError):
+        tools.get_memory_usage(group_by='socket')
+    del st

@@ -387,3 +387,14 @@ def test_auto_subspace():
         Auto(X, 0, size_guess=10)
     Z = index_sum(sigmaz(), size=5)
     assert Auto(Z, 'DUDUU').state_map.tolist() == [0b00101]
+
+
+def test_tools_host(capsys):
+    """dynamite_amd.tools (reference tools.py): rank-aware print and the fixed build facts."""
+    from dynamite_amd import tools
+    tools.mpi_print("hello", rank=0)
+    tools.mpi_print("silent", rank=1)
+    assert capsys.readouterr().out == "hello\n"
+    assert tools.complex_enabled()
+    with pytest.raises(ValueError):
+        tools.get_max_memory_usage(which='rank')
