@@ -55,6 +55,8 @@ class Operator:
     # ------------------------------------------------------------------ sizes
     @property
     def max_spin_idx(self):
+        if self._msc is None:
+            return -1                  # empty operator (msc_tools.max_spin_idx convention)
         if self._max_spin_idx is None:
             self._max_spin_idx = msc_tools.max_spin_idx(self.msc)
         return self._max_spin_idx

@@ -48,7 +48,10 @@ def get_memory_usage(group_by='all', max_usage=False):
     if group_by not in ('rank', 'node', 'all'):
         raise ValueError(f"group_by must be 'rank', 'node', or 'all'; got '{group_by}'")
     free, total = torch.cuda.mem_get_info()
-    local = (torch.cuda.max_memory_allocated() if max_usage else (total - free)) / 1E9
+    local = total - free
+    if max_usage:      # torch's own peak, or what is held now (the cached Krylov workspace is not torch's)
+        local = max(local, torch.cuda.max_memory_allocated())
+    local /= 1E9
     if group_by == 'rank' or config.world_size == 1:
         return local
     import torch.distributed as dist

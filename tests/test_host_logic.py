@@ -398,3 +398,21 @@ def test_tools_host(capsys):
     assert tools.complex_enabled()
     with pytest.raises(ValueError):
         tools.get_max_memory_usage(which='rank')
+
+
+def test_global_config_L():
+    """config.L set globally (how the reference's scripts and benchmark.py work): operator algebra,
+    copies and default subspaces pick it up."""
+    from dynamite_amd import config
+    from dynamite_amd.operators import sigmax, sigmaz, index_sum, Operator
+    old = config.L
+    try:
+        config.L = 9
+        H = index_sum(0.25 * sigmaz(0) * sigmaz(1)) + 0.1 * index_sum(sigmax())
+        assert H.L == 9 and H.copy().L == 9 and Operator().L == 9
+        assert H.max_spin_idx == 8 and H.nterms == 8 + 9
+        assert (2 * H).L == 9 and H.left_subspace.L == 9
+        with pytest.raises(ValueError):
+            sigmax(9).L = 9
+    finally:
+        config.L = old
