@@ -8,6 +8,28 @@ import warnings
 from .config import config
 
 
+class _CommWorld:
+    """What scripts use of ``MPI_COMM_WORLD()`` (tools.py:8-16): rank, size, barrier -- over
+    torch.distributed here."""
+
+    @property
+    def rank(self):
+        return config.rank
+
+    @property
+    def size(self):
+        return config.world_size
+
+    def barrier(self):
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            dist.barrier()
+
+
+def MPI_COMM_WORLD():
+    return _CommWorld()
+
+
 def mpi_print(*args, rank=0, **kwargs):
     """``print`` from a single rank only (tools.py:19-27); ranks are torch.distributed ranks."""
     if config.rank == rank:

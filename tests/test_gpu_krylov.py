@@ -594,3 +594,54 @@ def test_tools_memory():
     with pytest.raises(ValueError):
         tools.get_memory_usage(group_by='socket')
     del st
+
+
+def test_floquet_script_flow(tmp_path):
+    """The flow of the reference's examples/scripts/floquet/run_floquet.py on this engine (global
+    config.L, operator products, evolve into a result state, pi pulse by an operator, expectation values
+    with a scratch state, half-chain entropy with a range, checkpoint save / resume), checked against dense
+    linear algebra."""
+    from dynamite_amd import config
+    from dynamite_amd.operators import sigmax, sigmay, sigmaz, index_sum, index_product, op_sum
+    from dynamite_amd.computations import entanglement_entropy, dm_entanglement_entropy
+    from dynamite_amd.tools import MPI_COMM_WORLD
+    old = config.L
+    try:
+        L = config.L = 8
+        alpha, Jx, h, T = 1.25, 0.19, [0.21, 0.17, 0.13], 0.12
+        H = (op_sum(1 / r ** alpha * index_sum(0.25 * sigmaz(0) * sigmaz(r)) for r in range(1, L))
+             + Jx * index_sum(0.25 * sigmax(0) * sigmax(1))
+             + index_sum(op_sum(hi * 0.5 * s() for hi, s in zip(h, [sigmax, sigmay, sigmaz]))))
+        X = index_product(sigmax())
+        Deff = (H + X * H * X) / 2
+        Sz = [0.5 * sigmaz(i) for i in range(L)]
+        state = State(state='U' * 4 + 'D' * 4)
+        tmp = state.copy()
+        Hd, Xd, Dd = (O.to_numpy().toarray() for O in (H, X, Deff))
+        assert np.allclose(Dd, (Hd + Xd @ Hd @ Xd) / 2, atol=1e-14)
+        w, U = np.linalg.eigh(Hd)
+        step = Xd @ (U @ np.diag(np.exp(-1j * T * w)) @ U.conj().T)
+        ref = state.to_numpy()
+        for cycle in range(1, 7):
+            H.evolve(state, result=tmp, t=T)
+            X.dot(tmp, result=state)
+            ref = step @ ref
+            assert np.linalg.norm(state.to_numpy() - ref) < 1e-8
+            e = Deff.expectation(state, tmp_state=tmp)
+            assert abs(e - np.vdot(ref, Dd @ ref).real) < 1e-8
+            ent = entanglement_entropy(state, keep=range(L // 2))
+            m = ref.reshape(1 << (L - L // 2), 1 << (L // 2))
+            assert abs(ent - dm_entanglement_entropy(m.T @ m.conj())) < 1e-8
+            sz = [Sz[i].expectation(state, tmp_state=tmp) for i in range(L)]
+            bits = (np.arange(1 << L)[:, None] >> np.arange(L)) & 1
+            assert np.allclose(sz, (np.abs(ref) ** 2) @ (0.5 - bits), atol=1e-8)
+            if cycle == 3:
+                state.save(str(tmp_path / "floquet_cycle_3"))
+        assert MPI_COMM_WORLD().rank == 0 and MPI_COMM_WORLD().size == 1
+        resumed = State.from_file(str(tmp_path / "floquet_cycle_3"))
+        for cycle in range(4, 7):
+            H.evolve(resumed, result=tmp, t=T)
+            X.dot(tmp, result=resumed)
+        assert np.linalg.norm(resumed.to_numpy() - state.to_numpy()) < 1e-12
+    finally:
+        config.L = old
