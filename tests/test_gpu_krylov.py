@@ -645,3 +645,40 @@ def test_floquet_script_flow(tmp_path):
         assert np.linalg.norm(resumed.to_numpy() - state.to_numpy()) < 1e-12
     finally:
         config.L = old
+
+
+def test_mbl_script_flow():
+    """The flow of the reference's examples/scripts/MBL/run_mbl.py (global config.L and config.subspace,
+    Python sum() of operators, extremal eigenpairs with vectors, half-chain entropies and gap ratios) --
+    without the interior `target` solves, which the reference refuses for shell matrices too."""
+    from dynamite_amd import config
+    from dynamite_amd.operators import sigmax, sigmay, sigmaz, index_sum
+    from dynamite_amd.computations import dm_entanglement_entropy
+    oldL, olds = config.L, config.subspace
+    try:
+        L = config.L = 10
+        sub = config.subspace = SpinConserve(L, L // 2)
+        np.random.seed(0xB0BA)
+        H = index_sum(0.25 * sum(s(0) * s(1) for s in [sigmax, sigmay, sigmaz]))
+        H = H + sum(0.5 * np.random.uniform(-2.0, 2.0) * sigmaz(i) for i in range(L))
+        A = H.to_numpy().toarray()
+        assert A.shape == (252, 252)
+        w, U = np.linalg.eigh(A)
+        states = sub.idx_to_state(np.arange(252))
+        for which, wref, cols in (('lowest', w[:4], U[:, :4]), ('highest', w[::-1][:4], U[:, ::-1][:, :4])):
+            evals, evecs = H.eigsolve(nev=4, which=which, getvecs=True, tol=1e-11)
+            assert np.allclose(evals[:4], wref, atol=1e-9)
+            for i, v in enumerate(evecs[:4]):
+                assert v.subspace == sub
+                full = np.zeros(1 << L, dtype=complex)
+                full[states] = cols[:, i]
+                m = full.reshape(1 << (L - L // 2), 1 << (L // 2))
+                assert abs(v.entanglement_entropy(keep=range(L // 2)) - dm_entanglement_entropy(m.T @ m.conj())) < 1e-7
+            ev = sorted(evals[:4])
+            ratio = np.mean([min(ev[i] - ev[i - 1], ev[i + 1] - ev[i]) / max(ev[i] - ev[i - 1], ev[i + 1] - ev[i])
+                             for i in range(1, 3)])
+            assert 0 < ratio <= 1
+        with pytest.raises(RuntimeError):
+            H.eigsolve(nev=2, target=0.0)
+    finally:
+        config.L, config.subspace = oldL, olds
