@@ -51,8 +51,9 @@ class _Config:
         if not isinstance(value, bool):
             raise ValueError('Shell must be set to True or False.')
         if not value:
-            raise ValueError('this engine is matrix-free: stored (AIJ) matrices are not built')
-        self._shell = value
+            import warnings
+            warnings.warn('dynamite_amd is matrix-free: shell=False is accepted and ignored', stacklevel=2)
+        self._shell = True
 
     # -- process / device -------------------------------------------------------
     @property

@@ -7,6 +7,8 @@ same marshalling (:546-669), ``dot`` (:1063-1108), ``infinity_norm`` (:206-224),
 and ``evolve`` / ``eigsolve`` bound from ``computations`` (:78-79).  String /
 LaTeX representations and the stored-matrix (AIJ) path are out of scope.
 """
+import warnings
+
 import numpy as np
 
 from . import msc_tools, backend
@@ -120,15 +122,16 @@ class Operator:
         if not isinstance(value, bool):
             raise ValueError('Shell must be set to True or False.')
         if not value:
-            raise ValueError('this engine is matrix-free: stored (AIJ) matrices are not built')
-        self._shell = value
+            # scripts written for the reference pass shell=False for stored matrices: the result is the
+            # same operator, applied matrix-free
+            warnings.warn('dynamite_amd is matrix-free: shell=False is accepted and ignored', stacklevel=2)
+        self._shell = True
 
     @property
     def precompute_diagonal(self):
-        """Cache the diagonal in HBM (+8 B per amplitude read per multiply).  The
-        reference defaults to True (operators.py:246-271); here the tiled kernels
-        evaluate the diagonal on the fly, so the default is False and the cache
-        only serves the generic kernel."""
+        """Cache the diagonal in HBM (+8 B per amplitude read per multiply; default True as in the
+        reference, operators.py:246-271).  It is built only for the kernels that read it: the tiled
+        hypercube kernel evaluates the diagonal on the fly."""
         return self._precompute_diagonal
 
     @precompute_diagonal.setter

@@ -682,3 +682,32 @@ def test_mbl_script_flow():
             H.eigsolve(nev=2, target=0.0)
     finally:
         config.L, config.subspace = oldL, olds
+
+
+def test_kagome_script_flow():
+    """The flow of the reference's examples/scripts/kagome/run_kagome.py: Heisenberg couplings on an
+    arbitrary graph (non-adjacent bonds), SpinConserve at half filling wrapped in XParity, `H.shell =
+    False` as the script passes without --shell (accepted, still matrix-free), eigsolve(nev=2) -> gap."""
+    from dynamite_amd.operators import sigmax, sigmay, sigmaz, op_sum
+    # a 12-site ring of corner-sharing triangles (kagome strip): triangles (2i, 2i+1, 2i+2)
+    N = 12
+    edges = set()
+    for t in range(0, N, 2):
+        a, b, c = t, (t + 1) % N, (t + 2) % N
+        edges |= {(min(a, b), max(a, b)), (min(b, c), max(b, c)), (min(a, c), max(a, c))}
+    H = op_sum(op_sum(0.25 * s(i) * s(j) for s in [sigmax, sigmay, sigmaz]) for i, j in sorted(edges))
+    assert H.get_length() == N
+    sub = XParity(SpinConserve(N, N // 2), sector=+1 if N % 4 == 0 else -1)
+    H.subspace = sub
+    with pytest.warns(UserWarning):
+        H.shell = False
+    assert H.shell is True
+    gs, e1 = H.eigsolve(nev=2, tol=1e-11)[:2]
+    w = np.linalg.eigvalsh(H.to_numpy().toarray())
+    # (the lowest level of this cluster is degenerate; the second value is then its other copy or the next level)
+    assert abs(gs - w[0]) < 1e-9 and e1 >= gs - 1e-9 and np.min(np.abs(w - e1)) < 1e-8
+    # the sector's lowest level is a level of the parent's spectrum
+    par = SpinConserve(N, N // 2)
+    H.add_subspace(par)
+    wp = np.linalg.eigvalsh(H.to_numpy(subspaces=(par, par)).toarray())
+    assert np.min(np.abs(wp - gs)) < 1e-9
