@@ -70,9 +70,10 @@ def get_memory_usage(group_by='all', max_usage=False):
     if group_by not in ('rank', 'node', 'all'):
         raise ValueError(f"group_by must be 'rank', 'node', or 'all'; got '{group_by}'")
     free, total = torch.cuda.mem_get_info()
-    local = total - free
-    if max_usage:      # torch's own peak, or what is held now (the cached Krylov workspace is not torch's)
-        local = max(local, torch.cuda.max_memory_allocated())
+    # device memory in use outside torch's caching allocator (the engine's tables and cached Krylov
+    # workspace) plus what torch has handed out (states, vectors)
+    outside = max(0, (total - free) - torch.cuda.memory_reserved())
+    local = outside + (torch.cuda.max_memory_allocated() if max_usage else torch.cuda.memory_allocated())
     local /= 1E9
     if group_by == 'rank' or config.world_size == 1:
         return local
