@@ -711,3 +711,71 @@ def test_kagome_script_flow():
     H.add_subspace(par)
     wp = np.linalg.eigvalsh(H.to_numpy(subspaces=(par, par)).toarray())
     assert np.min(np.abs(wp - gs)) < 1e-9
+
+
+def test_syk_script_flow():
+    """The flow of the reference's examples/scripts/SYK/run_syk.py: Majorana operators that map between the
+    two Parity sectors (left != right subspaces), an SYK Hamiltonian carrying both sectors, imaginary-time
+    cooling with copy(result=), and the out-of-time-order correlator by chained evolve / dot calls --
+    against dense linear algebra in the full space."""
+    from itertools import combinations
+    from dynamite_amd import config
+    from dynamite_amd.operators import op_sum, op_product
+    from dynamite_amd.extras import majorana
+    old = config.L
+    try:
+        N = 12
+        L = config.L = (N + 1) // 2
+        np.random.seed(7)
+        even, odd = Parity('even'), Parity('odd')
+        W, V = majorana(0), majorana(1)
+        for O in (W, V):
+            O.add_subspace(even, odd)
+            O.add_subspace(odd, even)
+        maj = [majorana(i) for i in range(N)]
+
+        def products():
+            for idxs in combinations(range(N), 4):
+                p = op_product(maj[i] for i in idxs)
+                p.scale(np.random.normal())
+                yield p
+        H = op_sum(products())
+        H.scale(np.sqrt(6 / N ** 3))
+        H.add_subspace(even)
+        H.add_subspace(odd)
+
+        full = Full(L=L)
+        Hd, Wd, Vd = (O.to_numpy(subspaces=(full, full)).toarray() for O in (H, W, V))
+        w, U = np.linalg.eigh(Hd)
+        expH = lambda z: U @ np.diag(np.exp(z * w)) @ U.conj().T       # noqa: E731
+
+        def embed(st):
+            out = np.zeros(1 << L, dtype=complex)
+            out[st.subspace.idx_to_state(np.arange(len(st)))] = st.to_numpy()
+            return out
+
+        psi0 = State(state='random', subspace=even, seed=3)
+        psi1 = psi0.copy()
+        ref0 = embed(psi0)
+        H.evolve(psi0, t=-1j * 0.4, result=psi1)          # cool: exp(-0.4 H)
+        psi1.normalize()
+        psi1.copy(result=psi0)
+        ref0 = expH(-0.4) @ ref0
+        ref0 /= np.linalg.norm(ref0)
+        assert np.linalg.norm(embed(psi0) - ref0) < 1e-8
+        t = 0.9
+        tmp_odd_0 = V * psi0
+        assert tmp_odd_0.subspace == odd
+        tmp_odd_1 = H.evolve(tmp_odd_0, t=t)
+        W.dot(tmp_odd_1, result=psi0)
+        tmp_even = H.evolve(psi0, t=-t)
+        V.dot(tmp_even, result=tmp_odd_0)
+        H.evolve(tmp_odd_0, t=t, result=tmp_odd_1)
+        W.dot(tmp_odd_1, result=psi0)
+        H.evolve(psi0, t=-t, result=tmp_even)
+        got = 2 * psi1.dot(tmp_even).real + 0.5
+        Wt = expH(1j * t) @ Wd @ expH(-1j * t)
+        want = 2 * np.vdot(ref0, Wt @ Vd @ Wt @ Vd @ ref0).real + 0.5
+        assert abs(got - want) < 1e-7
+    finally:
+        config.L = old
