@@ -779,3 +779,83 @@ def test_syk_script_flow():
         assert abs(got - want) < 1e-7
     finally:
         config.L = old
+
+
+def test_tutorial_flows():
+    """Code paths of the reference's tutorial notebooks (examples/tutorial/2-States, 3-Eigensolving,
+    4-TimeEvolution, 5-Subspaces), checked against closed forms / dense algebra."""
+    from dynamite_amd import config
+    from dynamite_amd.operators import sigmax, sigmay, sigmaz, index_sum, index_product, op_sum
+    from dynamite_amd.subspaces import Auto
+    oldL, olds = config.L, config.subspace
+    try:
+        # --- 2-States
+        config.L = 6
+        assert sigmaz(0).expectation(State(state='UUUUUU')) == 1 and sigmaz(0).expectation(State(state='DUUUUU')) == -1
+        ghz = State(state='UUUUUU')
+        ghz += State(state='DDDDDD')
+        ghz.normalize()
+        v = ghz.to_numpy()
+        assert abs(v[0] - 2 ** -0.5) < 1e-15 and abs(v[-1] - 2 ** -0.5) < 1e-15 and np.count_nonzero(v) == 2
+        w = State(state='100000')
+        for i in range(1, w.L):
+            w += State(state='0' * i + '1' + '0' * (w.L - i - 1))
+        w.normalize()
+        assert np.allclose(np.nonzero(w.to_numpy())[0], [1, 2, 4, 8, 16, 32]) and abs(w.norm() - 1) < 1e-15
+        f = lambda st: np.exp(2 * np.pi * 1j * (st / 64))                       # noqa: E731
+        s1, s2 = State(), State()
+        s1.set_all_by_function(f)
+        s2.set_all_by_function(f, vectorize=True)
+        assert np.allclose(s1.to_numpy(), f(np.arange(64))) and np.array_equal(s1.to_numpy(), s2.to_numpy())
+        assert abs(State(state='random', seed=1).norm() - 1) < 1e-14
+        # --- 3-Eigensolving: transverse-field Ising ring
+        config.L = 10
+        H = 1 * index_sum(sigmaz(0) * sigmaz(1), boundary='closed') + 0.1 * index_sum(sigmax(0))
+        dense = np.linalg.eigvalsh(H.to_numpy().toarray())
+        assert abs(H.eigsolve()[0] - dense[0]) < 1e-7
+        ev, vecs = H.eigsolve(nev=3, getvecs=True, tol=1e-10)
+        assert len(ev) >= 3 and abs(H.expectation(vecs[0]) - ev[0]) < 1e-8
+        mtot = index_sum(sigmaz(0))
+        assert abs(mtot.expectation(vecs[0])) <= 10 + 1e-9
+        # --- 4-TimeEvolution: domain wall melting, swapping state and result
+        config.L = 10
+        H = index_sum(sum(0.25 * p(0) * p(1) for p in [sigmax, sigmay, sigmaz]))
+        Sz = [0.5 * sigmaz(i) for i in range(config.L)]
+        cur = State(state='U' * 5 + 'D' * 5)
+        res = cur.copy()
+        tot0 = sum(S.expectation(cur) for S in Sz)
+        for _ in range(5):
+            H.evolve(cur, t=0.2, result=res)
+            cur, res = res, cur
+        w_, U = np.linalg.eigh(H.to_numpy().toarray())
+        x0 = np.zeros(1 << 10, dtype=complex); x0[0b1111100000] = 1
+        ref = U @ (np.exp(-1j * w_) * (U.conj().T @ x0))
+        assert np.linalg.norm(cur.to_numpy() - ref) < 1e-7
+        assert abs(sum(S.expectation(cur) for S in Sz) - tot0) < 1e-9        # total Sz conserved
+        # --- 5-Subspaces
+        config.L = 12
+        H = index_sum(sum(0.25 * p(0) * p(1) for p in [sigmax, sigmay, sigmaz]))
+        assert H.dim == (4096, 4096)
+        H.subspace = SpinConserve(L=config.L, k=config.L // 2)
+        assert H.dim == (924, 924)
+        assert len(State(state='U' * 6 + 'D' * 6, subspace=SpinConserve(L=12, k=6))) == 924
+        with pytest.raises(ValueError):
+            State(state='U' * 5 + 'D' * 7, subspace=SpinConserve(L=12, k=6))
+        for sector, eig in (('+', 1), ('-', -1)):
+            config.subspace = XParity(SpinConserve(L=12, k=6), sector=sector)
+            assert config.subspace.get_dimension() == 462
+            flip = index_product(sigmax())
+            psi = State(state='random', seed=2)
+            assert abs(flip.expectation(psi) - eig) < 1e-12
+        config.subspace = None
+        XXZ = op_sum(index_sum(sigmax(0) * sigmax(i)) for i in range(1, 12)) + 0.5 * index_sum(sigmaz())
+        XXZ.subspace = Parity('even')
+        assert XXZ.dim == (2048, 2048)
+        half = [x for x in range(1 << 12) if bin(x).count('1') == 6]
+        assert Explicit(half) == SpinConserve(12, 6)
+        heis = index_sum(sum(0.25 * p(0) * p(1) for p in [sigmax, sigmay, sigmaz]))
+        assert Auto(heis, 'U' * 6 + 'D' * 6) == SpinConserve(12, 6)
+        uns = Auto(heis, 'U' * 6 + 'D' * 6, sort=False)
+        assert uns.get_dimension() == 924 and not np.array_equal(uns.state_map, np.sort(uns.state_map))
+    finally:
+        config.L, config.subspace = oldL, olds
