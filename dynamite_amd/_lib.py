@@ -128,6 +128,7 @@ SIGNATURES = {
     "dnm_vec_mdot": (C.c_int, [vp, C.c_int64, C.c_int, vp, C.c_int64, f64p, vp]),
     "dnm_vec_maxpy": (C.c_int, [vp, vp, C.c_int64, C.c_int, C.c_int64, f64p, vp]),
     "dnm_vec_basis_update": (C.c_int, [vp, C.c_int64, C.c_int, C.c_int, C.c_int64, f64p, vp]),
+    "dnm_workspace_bytes": (C.c_int, [C.POINTER(C.c_size_t)]),
     "dnm_release_workspace": (C.c_int, []),
     "dnm_expm_multiply": (C.c_int, [vp, vp, vp, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_int,
                                     C.c_int, C.c_size_t, C.POINTER(Hooks), C.POINTER(SolverStats), vp]),

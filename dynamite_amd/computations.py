@@ -152,11 +152,29 @@ def eigsolve(H, getvecs=False, nev=1, which='lowest', target=None, tol=None, sub
     mat = H.get_mat(subspaces=(subspace, subspace))
     keep = []
     hooks = _hooks(mat, keep)
+    import torch
+    vec_bytes = 16 * mat.n_local
+    # all converged pairs are returned (computations.py:259-281) -- but not at the price of a second basis:
+    # large vectors are limited to the nev requested
     nev_max = max(nev, int(ncv) if ncv else max(2 * nev, nev + 15))
+    if getvecs and vec_bytes * nev_max > (1 << 30):
+        nev_max = nev
+    if ncv is None:
+        # SLEPc's default max(2 nev, nev + 15) (+1 for the residual vector), reduced to what fits in HBM
+        cached = C.c_size_t()
+        _lib.check(_lib.lib().dnm_workspace_bytes(C.byref(cached)))
+        free, _ = torch.cuda.mem_get_info()
+        fit = int((free + cached.value) // vec_bytes) - 1 - (nev_max if getvecs else 0)
+        want = max(2 * nev, nev + 15)
+        if fit < want:
+            if fit < nev + 2:
+                raise RuntimeError('not enough device memory for a Krylov basis: %d vectors of %.1f GiB fit, '
+                                   'eigsolve(nev=%d) needs at least %d' % (max(fit, 0), vec_bytes / 2 ** 30, nev,
+                                                                            nev + 2))
+            ncv = fit
     evals = np.zeros(nev_max, dtype=np.float64)
     evec_buf = None
     if getvecs:
-        import torch
         evec_buf = torch.empty(nev_max * mat.n_local, dtype=torch.complex128, device=config.device)
     stats = _lib.SolverStats()
     _lib.check(_lib.lib().dnm_eigsolve(
@@ -185,7 +203,8 @@ def eigsolve(H, getvecs=False, nev=1, which='lowest', target=None, tol=None, sub
     evecs = []
     for i in range(nconv):
         v = State(L=H.L, subspace=subspace)
-        v._vec = Vec(mat.N, array=evec_buf[i * mat.n_local:(i + 1) * mat.n_local].clone())
+        # (views of one buffer: no second copy of the vectors)
+        v._vec = Vec(mat.N, array=evec_buf[i * mat.n_local:(i + 1) * mat.n_local])
         v.set_initialized()
         evecs.append(v)
     return vals, evecs

@@ -432,6 +432,12 @@ using namespace dnm;
 
 extern "C" {
 
+int dnm_workspace_bytes(size_t *bytes) {
+  DNM_CHECK(bytes, "null argument");
+  *bytes = g_basis.bytes;
+  return 0;
+}
+
 int dnm_release_workspace(void) {
   g_basis.release();
   rdm_release_scratch();

@@ -284,6 +284,8 @@ int dnm_expm_multiply(dnm_mat *A, const void *x, void *y, int64_t n_local,
  * per-process buffers and small reduction scratch: calls are not re-entrant --
  * one host thread per process, as the reference's one thread per MPI rank.) */
 int dnm_release_workspace(void);
+/* bytes of Krylov basis currently cached (reusable by the next solve) */
+int dnm_workspace_bytes(size_t *bytes);
 
 enum { DNM_WHICH_LOWEST = 0, DNM_WHICH_HIGHEST = 1, DNM_WHICH_EXTERIOR = 2 };
 

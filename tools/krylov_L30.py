@@ -1,0 +1,32 @@
+#!/usr/bin/env python
+"""The Krylov loops at the headline size: L=30 random-field Heisenberg, 2^30 amplitudes (16 GiB per vector),
+basis sizes chosen by what fits in HBM."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+from dynamite_amd import models  # noqa: E402
+from dynamite_amd.config import config  # noqa: E402
+from dynamite_amd.states import State  # noqa: E402
+from dynamite_amd.computations import evolve, eigsolve  # noqa: E402
+
+L = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+config._initialize()
+H = models.mbl(L)
+psi = State(L=L)
+psi.set_random(seed=0)
+out = State(L=L)
+for t in (0.2, 0.2):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    H.evolve(psi, t=t, result=out)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    st = evolve.last_stats
+    print("L=%d evolve t=%.2f: %.2f s, %d outer steps, %d matvecs (%.1f ms per matvec-equivalent), |y|=%.12f"
+          % (L, t, dt, st['its'], st['matvecs'], dt / st['matvecs'] * 1e3, out.norm()), flush=True)
+del out
+torch.cuda.synchronize(); t0 = time.perf_counter()
+ev = H.eigsolve(nev=1, tol=1e-6)
+torch.cuda.synchronize(); dt = time.perf_counter() - t0
+st = eigsolve.last_stats
+print("L=%d eigsolve nev=1 tol=1e-6: %.2f s, %d restarts, %d matvecs, E0=%.8f, measured relative residual %.1e"
+      % (L, dt, st['its'], st['matvecs'], ev[0], st['max_rel_residual']), flush=True)
