@@ -34,8 +34,11 @@ def main():
             from dynamite_amd.operators import Operator
             terms = []
             for i in c["bonds"]:
-                terms += [(3 << i, 0, 0.25), (3 << i, 3 << i, -0.25), (0, 3 << i, 0.25)]
-            terms += [(0, 1 << i, 0.1 * (i + 1)) for i in range(L)]
+                terms += [(3 << i, 0, 0.25), (3 << i, 3 << i, -0.25)]
+                if not c.get("nodiag"):
+                    terms += [(0, 3 << i, 0.25)]
+            if not c.get("nodiag"):
+                terms += [(0, 1 << i, 0.1 * (i + 1)) for i in range(L)]
             H = Operator(msc=terms)
             H.L = L
         else:
