@@ -390,28 +390,64 @@ def check_conserves(masks, mask_offsets, signs, coeffs, left_subspace, right_sub
     return bool(res.value)
 
 
+def rdm_block_subspace(subspace, rank, nranks, keep):
+    """The subspace a rank's block of a partitioned state lives on, as far as the reduced density
+    matrix of ``keep`` is concerned -- or None if the kept spins are not all inside one block.
+    Full(L) on P = 2^p ranks: the block is a Full(L - p) vector (the top p spins are the rank).
+    Parity(L, s): basis index = configuration >> 1, so the block fixes the top p spins and is a
+    Parity(L - p, s ^ parity(rank)) vector.  Other subspaces are not cut along spins."""
+    d = subspace['data']
+    p = nranks.bit_length() - 1
+    if nranks != 1 << p or subspace['type'] not in (0, 1):      # FULL, PARITY
+        return None
+    Lb = int(d.L) - p
+    if Lb < 1 or (len(keep) and int(max(keep)) >= Lb):
+        return None
+    out = _lib.Subspace()
+    out.type, out.L = d.type, Lb
+    if subspace['type'] == 1:
+        out.space = int(d.space) ^ (bin(rank).count('1') & 1)
+    return out
+
+
+def rdm_partial(x_block, sub_c, keep):
+    """Device tensor (4^len(keep) complex128): sum over the traced configurations of one block."""
+    import torch
+    K = 1 << keep.size
+    rho = torch.empty(K * K, dtype=torch.complex128, device=x_block.device)
+    _lib.check(_lib.lib().dnm_reduced_density_matrix(
+        C.c_void_p(x_block.data_ptr()), C.byref(sub_c), keep.size, _lib.p64(keep),
+        C.c_void_p(rho.data_ptr()), _stream()))
+    return rho
+
+
 def reduced_density_matrix(vec, subspace, keep):
     """Mirror of ``bpetsc.reduced_density_matrix`` (bpetsc.pyx:245-276): host array of
-    shape (2^len(keep),)*2 on rank 0, ``[[-1]]`` elsewhere."""
+    shape (2^len(keep),)*2 on rank 0, ``[[-1]]`` elsewhere.  Partitioned states: when the kept
+    spins lie inside every rank's block (Full / Parity), each rank sums over its own traced
+    configurations and the partial matrices are added on rank 0; otherwise the state is gathered on
+    rank 0 as the reference does (bpetsc_template_1.c:126-141)."""
     import torch
     config._initialize()
     keep = np.ascontiguousarray(keep, dtype=np.int64)
     d = _dist()
     x = vec.array
+    K = 1 << keep.size
     if d is not None and d.get_world_size() > 1:
-        # the reference scatters the state to rank 0 (bpetsc_template_1.c:126-141); so do we
+        blk = rdm_block_subspace(subspace, config.rank, config.world_size, keep)
+        if blk is not None:
+            rho = rdm_partial(x, blk, keep)
+            d.reduce(rho, dst=0)
+            if config.rank != 0:
+                return np.array([[-1]], dtype=np.complex128)
+            return rho.cpu().numpy().reshape(K, K)
         parts = [torch.empty(split_ownership(vec.size, config.world_size, q)[1], dtype=x.dtype, device=x.device)
                  for q in range(config.world_size)] if config.rank == 0 else None
         d.gather(x, parts, dst=0)
         if config.rank != 0:
             return np.array([[-1]], dtype=np.complex128)
         x = torch.cat(parts)
-    K = 1 << keep.size
-    rho = torch.empty(K * K, dtype=torch.complex128, device=x.device)
-    _lib.check(_lib.lib().dnm_reduced_density_matrix(
-        C.c_void_p(x.data_ptr()), C.byref(subspace['data']), keep.size, _lib.p64(keep),
-        C.c_void_p(rho.data_ptr()), _stream()))
-    return rho.cpu().numpy().reshape(K, K)
+    return rdm_partial(x, subspace['data'], keep).cpu().numpy().reshape(K, K)
 
 
 def precompute_diagonal(mat):

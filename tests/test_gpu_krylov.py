@@ -859,3 +859,29 @@ def test_tutorial_flows():
         assert uns.get_dimension() == 924 and not np.array_equal(uns.state_map, np.sort(uns.state_map))
     finally:
         config.L, config.subspace = oldL, olds
+
+
+@pytest.mark.parametrize("kind,P", [("full", 2), ("full", 8), ("even", 4), ("odd", 2)])
+def test_rdm_partitioned_blocks(kind, P):
+    """The partitioned reduced density matrix rank by rank on one GPU: every block's partial matrix on
+    its block subspace (backend.rdm_block_subspace) summed over the ranks equals the matrix of the
+    whole state; kept spins that reach the rank bits fall back to the gather."""
+    from dynamite_amd.computations import reduced_density_matrix
+    L = 12
+    sub = {"full": Full(L=L), "even": Parity('even', L=L), "odd": Parity('odd', L=L)}[kind]
+    st = State(L=L, subspace=sub, state='random', seed=6)
+    x = st.vec.array
+    nloc = len(st) // P
+    p = P.bit_length() - 1
+    for keep in ([0], [1, 3, 4], list(range(6)), [2, L - p - 1]):
+        keep = np.array(keep, dtype=np.int64)
+        tot = 0
+        for r in range(P):
+            blk = backend.rdm_block_subspace(sub._to_c(), r, P, keep)
+            assert blk is not None and blk.L == L - p
+            tot = tot + backend.rdm_partial(x[r * nloc:(r + 1) * nloc], blk, keep)
+        K = 1 << keep.size
+        assert np.max(np.abs(tot.cpu().numpy().reshape(K, K) - reduced_density_matrix(st, keep))) < 1e-14
+    assert backend.rdm_block_subspace(sub._to_c(), 0, P, np.array([L - p])) is None
+    assert backend.rdm_block_subspace(SpinConserve(L, 6)._to_c(), 0, P, np.array([0])) is None
+    assert backend.rdm_block_subspace(sub._to_c(), 0, 3, np.array([0])) is None
