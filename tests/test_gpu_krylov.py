@@ -552,7 +552,7 @@ def test_krylov_full_size_properties():
     assert ev[0] < H.expectation(yi) < e0
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("DNM_FUZZ_KRYLOV_N", "6"))))
 def test_fuzz_krylov_random_operators(seed):
     """evolve (real, imaginary and complex times) and eigsolve on random Pauli-string Hamiltonians and
     subspaces against dense linear algebra on the host."""
