@@ -436,6 +436,24 @@ def test_fuzz_random_operators(monkeypatch, seed):
                 yp[r * nloc:(r + 1) * nloc] = yl.local_numpy()
                 m.destroy()
             assert np.max(np.abs(yp - ref)) <= tol_for(arrs, x), (L, B, P, kind)
+    if kind == "sc":
+        # SpinConserve partitioned by column windows (uneven PETSc-style ownership)
+        Pw = int(rs.randint(2, 5))
+        dim = left.get_dimension()
+        if dim >= 4 * Pw:
+            Lb = _lib.lib()
+            yp = np.empty(dim, dtype=complex)
+            for r in range(Pw):
+                h = backend.create_mat(*arrs, left._c(), right._c(), flags=0, rank=r, nranks=Pw)
+                m = backend.ShellMat(h, left._c(), right._c(), Pw, r)
+                start, n = backend.split_ownership(dim, Pw, r)
+                lo, hi = m.column_window()
+                assert 0 <= lo <= start and start + n - 1 <= hi < dim
+                xw, yl = vec_from(x[lo:hi + 1]), vec_from(np.zeros(n, dtype=complex))
+                _lib.check(Lb.dnm_mat_mult_window(m.handle, xw.ptr, lo, hi - lo + 1, yl.ptr, None))
+                yp[start:start + n] = yl.local_numpy()
+                m.destroy()
+            assert np.max(np.abs(yp - ref)) <= tol_for(arrs, x), (L, Pw, "sc windows")
 
 
 def test_error_behaviour():
