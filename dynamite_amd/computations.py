@@ -104,6 +104,9 @@ def evolve(H, state, t, result=None, tol=None, ncv=None, algo=None, max_its=None
     stats = _lib.SolverStats()
     import torch
     free, _ = torch.cuda.mem_get_info()
+    if free < 34 * 16 * mat.n_local:      # the default basis would not fit: hand torch's cached blocks back first
+        torch.cuda.empty_cache()
+        free, _ = torch.cuda.mem_get_info()
     _lib.check(_lib.lib().dnm_expm_multiply(
         mat.handle, state.vec.ptr, result.vec.ptr, mat.n_local, scale.real, scale.imag,
         0.0 if tol is None else float(tol), 0 if ncv is None else int(ncv),
@@ -163,9 +166,15 @@ def eigsolve(H, getvecs=False, nev=1, which='lowest', target=None, tol=None, sub
         # SLEPc's default max(2 nev, nev + 15) (+1 for the residual vector), reduced to what fits in HBM
         cached = C.c_size_t()
         _lib.check(_lib.lib().dnm_workspace_bytes(C.byref(cached)))
-        free, _ = torch.cuda.mem_get_info()
-        fit = int((free + cached.value) // vec_bytes) - 1 - (nev_max if getvecs else 0)
         want = max(2 * nev, nev + 15)
+
+        def fitting():
+            free, _ = torch.cuda.mem_get_info()
+            return int((free + cached.value) // vec_bytes) - 1 - (nev_max if getvecs else 0)
+        fit = fitting()
+        if fit < want:
+            torch.cuda.empty_cache()        # memory torch holds for reuse counts as free
+            fit = fitting()
         if fit < want:
             if fit < nev + 2:
                 raise RuntimeError('not enough device memory for a Krylov basis: %d vectors of %.1f GiB fit, '
