@@ -144,7 +144,7 @@ struct PlanConfig {
   int gbits = -1;      // mode 2: bits per XCD group (-1: 8 when the local vector has >= 2^30 amplitudes, else 6)
   int window_first = 0; // mode 2 experiment: run the window passes before the contiguous one (measured slower)
   int gbits_window = -1; // mode 2: cap of the group bits of window-tile passes (-1: no cap)
-  int cache_policy = 32; // DevPass::cache_policy for every pass; default: gathers right behind the tile loads
+  int cache_policy = 34; // DevPass::cache_policy for every pass; default: gathers right behind the tile loads (32) + streaming loads of y in accumulating passes (2)
   int max_gather_span = 0;   // mode 0: masks the tiler cannot place are gathered
 };
 
