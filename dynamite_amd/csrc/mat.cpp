@@ -624,10 +624,10 @@ int dnm_mat_create(int64_t nmasks, const int64_t *masks, const int64_t *mask_off
       A->op.n -= 1;
     }
     PlanConfig cfg = plan_config_from_env();
-    if (cfg.logR < 0) {   // measured (profiles/r01_sweep5_L30.txt): 16 rows per thread pay at 2^30 local amplitudes
+    if (cfg.logR < 0) {   // measured (profiles/r01_sweep6.txt): 16 rows per thread pay from 2^26 local amplitudes on
       int nl = A->op.n;
       for (int r = A->nranks; r > 1; r >>= 1) --nl;
-      cfg.logR = nl >= 30 ? 4 : 3;
+      cfg.logR = nl >= 26 ? 4 : 3;
     }
     if (!tile_config_supported(cfg.B, cfg.logR)) {
       set_error("unsupported tile configuration B=%d logR=%d", cfg.B, cfg.logR);

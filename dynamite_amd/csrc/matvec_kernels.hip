@@ -30,6 +30,10 @@ __device__ __forceinline__ void store_through(c128 *p, double re, double im) {
   d2v v = {re, im};
   asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
+__device__ __forceinline__ void store_streaming(c128 *p, double re, double im) {
+  d2v v = {re, im};
+  __builtin_nontemporal_store(v, reinterpret_cast<d2v *>(p));
+}
 __device__ __forceinline__ c128 load_streaming(const c128 *p) {
   d2v v = __builtin_nontemporal_load(reinterpret_cast<const d2v *>(p));
   return make_double2(v.x, v.y);
@@ -217,7 +221,7 @@ tile_pass_kernel(const DevPass P, const c128 *__restrict__ x, c128 *__restrict__
     const double zs = -P.zscale;
 #pragma unroll
     for (int k = 0; k < R; ++k) {
-      const c128 v = z[rows[k]];
+      const c128 v = load_streaming(z + rows[k]);      // read once
       ar[k] = zs * v.x;
       ai[k] = zs * v.y;
     }
@@ -313,7 +317,10 @@ tile_pass_kernel(const DevPass P, const c128 *__restrict__ x, c128 *__restrict__
   }
 #undef DNM_LOOP
 
-  if (P.cache_policy & 1) {
+  if (P.cache_policy & 64) {
+#pragma unroll
+    for (int k = 0; k < R; ++k) store_streaming(y + rows[k], ar[k], ai[k]);
+  } else if (P.cache_policy & 1) {
 #pragma unroll
     for (int k = 0; k < R; ++k) store_through(y + rows[k], ar[k], ai[k]);
   } else {

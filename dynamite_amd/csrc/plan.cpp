@@ -183,8 +183,9 @@ static int make_plan_with(const OpForm &op, int rank, int nranks, const PlanConf
   } else if (cfg.mode == 2) {
     // greedy cover by (LDS tile, XCD group) pairs: masks inside the tile come
     // from LDS, masks that also touch the group bits are gathered (L2)
-    // measured on MI355X (profiles/r01_sweep5_*.txt): 8 group bits pay at 2^30 amplitudes, 6 below
-    if (cfg.gbits < 0) cfg.gbits = nl >= 30 ? 8 : 6;
+    // measured on MI355X (profiles/r01_sweep6.txt): with early gathers and streaming y traffic a wide group pays
+    // from 2^26 local amplitudes on (9 bits at 2^30)
+    if (cfg.gbits < 0) cfg.gbits = nl >= 30 ? 9 : (nl >= 26 ? 8 : 6);
     if (cfg.gbits > 10) cfg.gbits = 10;
     bool first = true;
     while (!remaining.empty() || first) {

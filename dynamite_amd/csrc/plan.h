@@ -93,7 +93,8 @@ struct DevPass {
   int32_t need_tile;    // 0: no tile mask and no diagonal -> skip the LDS stage
   int32_t has_diag;
   int32_t cache_policy; // bit0: write y through L2 (sc1 stores, line not kept); bit1: non-temporal y loads;
-                        // bit2: non-temporal x tile loads; bit5: gathers before the barrier, right behind
+                        // bit2: non-temporal x tile loads; bit6: non-temporal y stores;
+                        // bit5: gathers before the barrier, right behind
                         // the tile loads (default)
   // diagonal records: tile-external terms, then one list per k-bucket
   uint32_t dext_begin, dext_end;
@@ -137,14 +138,14 @@ struct PassSpec {
 
 struct PlanConfig {
   int B = 12;          // log2 tile amplitudes
-  int logR = -1;       // log2 rows per thread (-1: 4 when the local vector has >= 2^30 amplitudes, else 3)
+  int logR = -1;       // log2 rows per thread (-1: 4 when the local vector has >= 2^26 amplitudes, else 3)
   int amin = -1;       // smallest allowed low segment (2^amin * 16 B contiguous runs); -1: see make_plan
   int mode = 2;        // 0: multi-pass LDS tiles; 1: single pass, everything else gathered;
                        // 2: multi-pass LDS tiles + L2-served gathers over an XCD group
-  int gbits = -1;      // mode 2: bits per XCD group (-1: 8 when the local vector has >= 2^30 amplitudes, else 6)
+  int gbits = -1;      // mode 2: bits per XCD group (-1: 9 / 8 / 6 for local vectors of >= 2^30 / >= 2^26 / fewer amplitudes)
   int window_first = 0; // mode 2 experiment: run the window passes before the contiguous one (measured slower)
   int gbits_window = -1; // mode 2: cap of the group bits of window-tile passes (-1: no cap)
-  int cache_policy = 34; // DevPass::cache_policy for every pass; default: gathers right behind the tile loads (32) + streaming loads of y in accumulating passes (2)
+  int cache_policy = 98; // DevPass::cache_policy for every pass; default: gathers right behind the tile loads (32) + streaming loads (2) and stores (64) of y
   int max_gather_span = 0;   // mode 0: masks the tiler cannot place are gathered
 };
 

@@ -334,7 +334,7 @@ def test_full_size_default_plan(monkeypatch, L):
     a.set_random(4)
     a.normalize()
     mat = shell(H, sub)
-    assert "mode=2" in mat.describe() and ("B=12 logR=%d" % (4 if L >= 30 else 3)) in mat.describe()
+    assert "mode=2" in mat.describe() and "B=12 logR=4" in mat.describe()
     d = (C.c_double * 2)()
     _lib.check(_lib.lib().dnm_mat_mult_dot(mat.handle, a.ptr, y0.ptr, d, None))
     ref_dot = a.dot(y0)                        # sum a_i conj(y0_i) = conj(<a, y0>)
