@@ -548,8 +548,9 @@ sc_matvec_kernel(const DevMsc msc, const ScMask *__restrict__ scm, const ScLow l
   int m0 = 0;
   if (diag && !colrange) {
     const c128 xs = x[row];
-    accr = diag[lrow] * xs.x;
-    acci = diag[lrow] * xs.y;
+    const double dg = __builtin_nontemporal_load(diag + lrow);     // read once: keep it out of the caches' way
+    accr = dg * xs.x;
+    acci = dg * xs.y;
     m0 = 1;
   }
   for (int m = m0; m < msc.nmasks; ++m) {
@@ -620,7 +621,7 @@ sc_matvec_kernel(const DevMsc msc, const ScMask *__restrict__ scm, const ScLow l
     accr = fma(-cim, xv.y, accr);
     acci = fma(cim, xv.x, acci);
   }
-  if (!colrange) y[lrow] = make_double2(accr, acci);
+  if (!colrange) store_streaming(y + lrow, accr, acci);
   }  // active
   if (colrange) {
     // workgroup min / max of the columns touched (one-time sweep when a partition is set up)

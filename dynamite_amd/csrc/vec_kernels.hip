@@ -8,6 +8,17 @@
 namespace dnm {
 
 typedef double2 c128;
+typedef double d2v __attribute__((ext_vector_type(2)));
+
+// streaming (non-temporal) accesses for data touched once per sweep
+__device__ __forceinline__ c128 ld_stream(const c128 *p) {
+  d2v v = __builtin_nontemporal_load(reinterpret_cast<const d2v *>(p));
+  return make_double2(v.x, v.y);
+}
+__device__ __forceinline__ void st_stream(c128 *p, c128 a) {
+  d2v v = {a.x, a.y};
+  __builtin_nontemporal_store(v, reinterpret_cast<d2v *>(p));
+}
 
 constexpr int VNT = 256;
 constexpr int VMAX_BLOCKS = 2048;   // 256 CUs x 8
@@ -113,10 +124,10 @@ mdot_kernel(const c128 *__restrict__ V, int64_t ldv, const c128 *__restrict__ w,
 #pragma unroll
   for (int j = 0; j < NV; ++j) sr[j] = si[j] = 0.0;
   for (int64_t i = (int64_t)blockIdx.x * VNT + threadIdx.x; i < n; i += (int64_t)gridDim.x * VNT) {
-    const c128 wv = w[i];
+    const c128 wv = ld_stream(w + i);
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
-      const c128 v = V[(int64_t)(j0 + j) * ldv + i];
+      const c128 v = ld_stream(V + (int64_t)(j0 + j) * ldv + i);
       sr[j] = fma(v.x, wv.x, sr[j]);
       sr[j] = fma(v.y, wv.y, sr[j]);
       si[j] = fma(v.x, wv.y, si[j]);
@@ -195,16 +206,16 @@ __global__ void __launch_bounds__(VNT)
 maxpy_kernel(c128 *w, const c128 *__restrict__ V, int64_t ldv, int nv, int64_t n,
              const double *__restrict__ c) {
   for (int64_t i = (int64_t)blockIdx.x * VNT + threadIdx.x; i < n; i += (int64_t)gridDim.x * VNT) {
-    c128 acc = w[i];
+    c128 acc = ld_stream(w + i);
     for (int j = 0; j < nv; ++j) {
       const double cr = c[2 * j], ci = c[2 * j + 1];
-      const c128 v = V[(int64_t)j * ldv + i];
+      const c128 v = ld_stream(V + (int64_t)j * ldv + i);
       acc.x = fma(cr, v.x, acc.x);
       acc.x = fma(-ci, v.y, acc.x);
       acc.y = fma(cr, v.y, acc.y);
       acc.y = fma(ci, v.x, acc.y);
     }
-    w[i] = acc;
+    st_stream(w + i, acc);
   }
 }
 
@@ -274,18 +285,18 @@ lanczos_update_kernel(c128 *p, const c128 *__restrict__ v, const c128 *__restric
                       double aim, double b, double *__restrict__ partials) {
   double s = 0.0;
   for (int64_t i = (int64_t)blockIdx.x * VNT + threadIdx.x; i < n; i += (int64_t)gridDim.x * VNT) {
-    c128 acc = p[i];
-    const c128 vv = v[i];
+    c128 acc = ld_stream(p + i);
+    const c128 vv = ld_stream(v + i);
     acc.x = fma(-are, vv.x, acc.x);
     acc.x = fma(aim, vv.y, acc.x);
     acc.y = fma(-are, vv.y, acc.y);
     acc.y = fma(-aim, vv.x, acc.y);
     if (u) {
-      const c128 uv = u[i];
+      const c128 uv = ld_stream(u + i);
       acc.x = fma(-b, uv.x, acc.x);
       acc.y = fma(-b, uv.y, acc.y);
     }
-    p[i] = acc;
+    st_stream(p + i, acc);
     s = fma(acc.x, acc.x, s);
     s = fma(acc.y, acc.y, s);
   }
