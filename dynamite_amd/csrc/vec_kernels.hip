@@ -36,8 +36,8 @@ __global__ void __launch_bounds__(VNT) set_kernel(c128 *x, int64_t n, double re,
 
 __global__ void __launch_bounds__(VNT) scale_kernel(c128 *x, int64_t n, double re, double im) {
   for (int64_t i = (int64_t)blockIdx.x * VNT + threadIdx.x; i < n; i += (int64_t)gridDim.x * VNT) {
-    c128 v = x[i];
-    x[i] = make_double2(re * v.x - im * v.y, re * v.y + im * v.x);
+    c128 v = ld_stream(x + i);
+    st_stream(x + i, make_double2(re * v.x - im * v.y, re * v.y + im * v.x));
   }
 }
 
@@ -45,14 +45,14 @@ __global__ void __launch_bounds__(VNT)
 axpby_kernel(c128 *y, const c128 *__restrict__ x, int64_t n, double are, double aim, double bre,
              double bim, int beta_zero) {
   for (int64_t i = (int64_t)blockIdx.x * VNT + threadIdx.x; i < n; i += (int64_t)gridDim.x * VNT) {
-    c128 xv = x[i];
+    c128 xv = ld_stream(x + i);
     double rr = are * xv.x - aim * xv.y, ri = are * xv.y + aim * xv.x;
     if (!beta_zero) {
-      c128 yv = y[i];
+      c128 yv = ld_stream(y + i);
       rr += bre * yv.x - bim * yv.y;
       ri += bre * yv.y + bim * yv.x;
     }
-    y[i] = make_double2(rr, ri);
+    st_stream(y + i, make_double2(rr, ri));
   }
 }
 
@@ -241,7 +241,7 @@ basis_update_kernel(c128 *V, int64_t ldv, int nin, int nout, int64_t n,
   for (int64_t r0 = (int64_t)blockIdx.x * BU_ROWS; r0 < n; r0 += (int64_t)gridDim.x * BU_ROWS) {
     const int64_t row = r0 + lane;
     for (int j = grp; j < nin; j += VNT / 64)
-      if (row < n) rowsbuf[j * BU_ROWS + lane] = V[(int64_t)j * ldv + row];
+      if (row < n) rowsbuf[j * BU_ROWS + lane] = ld_stream(V + (int64_t)j * ldv + row);
     __syncthreads();
     for (int o = grp; o < nout; o += VNT / 64) {
       double ar = 0.0, ai = 0.0;
@@ -253,7 +253,7 @@ basis_update_kernel(c128 *V, int64_t ldv, int nin, int nout, int64_t n,
         ai = fma(sr, v.y, ai);
         ai = fma(si, v.x, ai);
       }
-      if (row < n) V[(int64_t)o * ldv + row] = make_double2(ar, ai);
+      if (row < n) st_stream(V + (int64_t)o * ldv + row, make_double2(ar, ai));
     }
     __syncthreads();
   }
