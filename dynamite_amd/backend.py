@@ -83,6 +83,19 @@ def exchange_window(x_local, owned, windows, me, window_buf=None):
     return window_buf
 
 
+def device_zeros(n, empty=False):
+    """complex128 device buffer; if HBM is exhausted the solvers' cached Krylov workspace (tens of GiB
+    after a large solve) is handed back and the allocation retried once."""
+    import torch
+    make = torch.empty if empty else torch.zeros
+    try:
+        return make(n, dtype=torch.complex128, device=config.device)
+    except torch.OutOfMemoryError:
+        _lib.check(_lib.lib().dnm_release_workspace())
+        torch.cuda.empty_cache()
+        return make(n, dtype=torch.complex128, device=config.device)
+
+
 def exchange_plan(handle):
     """(sends, recvs) of the partitioned multiply: lists of (partner, offset, count),
     offsets/counts in amplitudes of the SENDER's local vector; recvs[i] feeds
@@ -117,7 +130,7 @@ class Vec:
         self.size = int(size)
         self.start, self.local_size = split_ownership(self.size, config.world_size, config.rank)
         if array is None:
-            array = torch.zeros(self.local_size, dtype=torch.complex128, device=config.device)
+            array = device_zeros(self.local_size)
         self.array = array
 
     # -- petsc4py.Vec-like surface -------------------------------------------

@@ -184,7 +184,8 @@ def eigsolve(H, getvecs=False, nev=1, which='lowest', target=None, tol=None, sub
     evals = np.zeros(nev_max, dtype=np.float64)
     evec_buf = None
     if getvecs:
-        evec_buf = torch.empty(nev_max * mat.n_local, dtype=torch.complex128, device=config.device)
+        from .backend import device_zeros
+        evec_buf = device_zeros(nev_max * mat.n_local, empty=True)
     stats = _lib.SolverStats()
     _lib.check(_lib.lib().dnm_eigsolve(
         mat.handle, mat.n_local, int(nev), _lib.WHICH[which], 0.0 if tol is None else float(tol),

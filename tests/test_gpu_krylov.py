@@ -885,3 +885,29 @@ def test_rdm_partitioned_blocks(kind, P):
     assert backend.rdm_block_subspace(sub._to_c(), 0, P, np.array([L - p])) is None
     assert backend.rdm_block_subspace(SpinConserve(L, 6)._to_c(), 0, P, np.array([0])) is None
     assert backend.rdm_block_subspace(sub._to_c(), 0, 3, np.array([0])) is None
+
+
+@pytest.mark.skipif(not __import__("os").environ.get("DNM_TEST_MEMORY_PRESSURE"),
+                    reason="fills the whole HBM (20 s); run with DNM_TEST_MEMORY_PRESSURE=1")
+def test_workspace_released_on_memory_pressure():
+    """The Krylov workspace cached after a solve is handed back when a later device allocation would
+    otherwise fail.  (Verified on MI355X; opt-in because it allocates all of the device memory.)"""
+    import ctypes as C
+    import torch
+    L = 24
+    H = models.mbl(L)
+    x = State(L=L, state='random', seed=0)
+    H.evolve(x, t=0.1)
+    cached = C.c_size_t()
+    _lib.check(_lib.lib().dnm_workspace_bytes(C.byref(cached)))
+    assert cached.value >= 30 * 16 * (1 << L)                 # 32 vectors of 256 MiB
+    torch.cuda.empty_cache()                                  # nothing torch could recycle instead
+    free, _ = torch.cuda.mem_get_info()
+    hog = torch.empty(free - (100 << 20), dtype=torch.uint8, device='cuda')      # leave 100 MiB
+    y = State(L=L)                                            # 256 MiB: needs the workspace back
+    y.vec.set(1.0)
+    _lib.check(_lib.lib().dnm_workspace_bytes(C.byref(cached)))
+    assert cached.value == 0 and abs(y.vec.norm() - (1 << L) ** 0.5) < 1e-6
+    del hog
+    torch.cuda.empty_cache()
+    H.evolve(x, t=0.1)                                        # and solves allocate it again
