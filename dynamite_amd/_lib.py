@@ -66,7 +66,8 @@ class DevPass(C.Structure):
                 ("sign_base", C.c_uint64), ("accumulate", C.c_int32), ("need_tile", C.c_int32),
                 ("has_diag", C.c_int32), ("cache_policy", C.c_int32), ("dext_begin", C.c_uint32), ("dext_end", C.c_uint32),
                 ("dbucket", C.c_uint32 * (MAXR + 1)), ("loop", C.c_uint32 * (LP_COUNT + 1)),
-                ("nquads", C.c_int32), ("n_eff", C.c_int32), ("quads", vp), ("dot_out", vp), ("zinit", vp), ("zscale", C.c_double)]
+                ("nquads", C.c_int32), ("n_eff", C.c_int32), ("quads", vp), ("dot_out", vp), ("zinit", vp), ("zscale", C.c_double),
+                ("tile_bits", C.c_int32), ("log_rows", C.c_int32)]
 
 
 class Xfer(C.Structure):

@@ -171,7 +171,7 @@ static uint32_t compress_to_tile(uint64_t bits, const PassSpec &ps) {
 static int build_pass(const dnm_mat &A, const PassSpec &ps, PassOnDevice *out) {
   const OpForm &op = A.op;
   const Plan &pl = A.plan;
-  const int B = ps.B, logR = pl.cfg.logR, lognt = B - logR, R = 1 << logR;
+  const int B = ps.B, logR = ps.logR ? ps.logR : pl.cfg.logR, lognt = B - logR, R = 1 << logR;
   const int n_eff = ps.n_eff ? ps.n_eff : pl.n_loc;     // index bits this pass sweeps
   const uint64_t tb = ps.tile_bits();
   DevPass &d = out->desc;
@@ -228,6 +228,9 @@ static int build_pass(const dnm_mat &A, const PassSpec &ps, PassOnDevice *out) {
   }
   d.sign_base = ((uint64_t)pl.rank << pl.n_loc) | ps.sign_extra;
   d.n_eff = n_eff;
+  d.tile_bits = B;
+  d.log_rows = logR;
+  DNM_CHECK(tile_config_supported(B, logR), "unsupported tile configuration B=%d logR=%d", B, logR);
   d.accumulate = ps.accumulate ? 1 : 0;
   d.has_diag = 0;
   d.cache_policy = pl.cfg.cache_policy;
@@ -695,7 +698,7 @@ int dnm_mat_mult_local(dnm_mat *A, const void *x, void *y, void *stream) {
   DNM_CHECK(x != y, "x and y must be different vectors");
   if (A->hypercube && A->plan.use_tiled) {
     for (auto &p : A->local_passes)
-      DNM_TRY(launch_tile_pass(p->desc, A->plan.cfg.B, A->plan.cfg.logR, use_glds(A), p->n_eff, x, y,
+      DNM_TRY(launch_tile_pass(p->desc, p->desc.tile_bits, p->desc.log_rows, use_glds(A), p->n_eff, x, y,
                                nullptr, S(stream)));
     return 0;
   }
@@ -721,7 +724,7 @@ int dnm_mat_mult_lanczos(dnm_mat *A, const void *x, void *y, const void *z, doub
     return vec_mdot_host(x, A->m_local, 1, y, A->m_local, dot, S(stream));
   }
   const bool fused_dot = A->local_passes.back()->desc.need_tile != 0;
-  const size_t nblk = (size_t)1 << (A->local_passes.back()->n_eff - A->plan.cfg.B);
+  const size_t nblk = (size_t)1 << (A->local_passes.back()->n_eff - A->local_passes.back()->desc.tile_bits);
   double *part = nullptr;
   if (fused_dot) DNM_TRY(vec_scratch((nblk + 1) * 2 * sizeof(double), &part));
   for (size_t i = 0; i < A->local_passes.size(); ++i) {
@@ -732,7 +735,7 @@ int dnm_mat_mult_lanczos(dnm_mat *A, const void *x, void *y, const void *z, doub
       d.zscale = b;
     }
     if (fused_dot && i + 1 == A->local_passes.size()) d.dot_out = part;
-    DNM_TRY(launch_tile_pass(d, A->plan.cfg.B, A->plan.cfg.logR, use_glds(A), A->local_passes[i]->n_eff, x, y,
+    DNM_TRY(launch_tile_pass(d, d.tile_bits, d.log_rows, use_glds(A), A->local_passes[i]->n_eff, x, y,
                              nullptr, S(stream)));
   }
   if (!fused_dot) return vec_mdot_host(x, A->m_local, 1, y, A->m_local, dot, S(stream));
@@ -816,7 +819,7 @@ int dnm_mat_mult_remote(dnm_mat *A, int32_t recv_index, const void *x_recv, void
   DNM_CHECK(recv_index >= 0 && recv_index < (int)A->remote_passes.size(), "rank %d has no receive %d", A->rank,
             recv_index);
   const auto &p = A->remote_passes[recv_index];
-  return launch_tile_pass(p->desc, A->plan.cfg.B, A->plan.cfg.logR, use_glds(A), p->n_eff, x_recv,
+  return launch_tile_pass(p->desc, p->desc.tile_bits, p->desc.log_rows, use_glds(A), p->n_eff, x_recv,
                           (char *)y + (size_t)p->y_off * 16, x_recv, S(stream));
 }
 

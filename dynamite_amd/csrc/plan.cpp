@@ -23,6 +23,8 @@ PlanConfig plan_config_from_env() {
   c.gbits = env_int("DNM_GBITS", c.gbits);
   c.gbits_window = env_int("DNM_GBITS_WINDOW", c.gbits_window);
   c.window_first = env_int("DNM_WINDOW_FIRST", c.window_first);
+  c.Bw = env_int("DNM_TILE_BITS_WINDOW", c.Bw);
+  c.logRw = env_int("DNM_LOG_ROWS_WINDOW", c.logRw);
   c.cache_policy = env_int("DNM_CACHE_POLICY", c.cache_policy);
   return c;
 }
@@ -219,8 +221,9 @@ static int make_plan_with(const OpForm &op, int rank, int nranks, const PlanConf
         }
       };
       consider(tile_spec(B, B, 0));
-      for (int a = cfg.amin; a < B && a <= 9; ++a)
-        for (int w = a + 1; w + (B - a) <= nl; ++w) consider(tile_spec(B, a, w));
+      const int Bw = (cfg.Bw >= 8 && cfg.Bw <= 13 && nl >= cfg.Bw) ? cfg.Bw : B;
+      for (int a = cfg.amin; a < Bw && a <= 9; ++a)
+        for (int w = a + 1; w + (Bw - a) <= nl; ++w) consider(tile_spec(Bw, a, w));
       if (best_score <= 0 && !first) break;
       const uint64_t tb = best.tile_bits();
       const uint64_t gb = best.glen ? ((((uint64_t)1 << best.glen) - 1) << best.gpos) : 0;
@@ -233,6 +236,7 @@ static int make_plan_with(const OpForm &op, int rank, int nranks, const PlanConf
       }
       best.has_diag = first && has_diag;
       best.accumulate = !first;
+      if (best.nseg > 1 && cfg.logRw > 0) best.logR = cfg.logRw;
       // Window tiles (runs of 2^a amplitudes far apart) alias in the L2 sets: only a few hundred KB of
       // them stay resident (tools/l2map_probe.hip).  Keep the masks, but order the workgroups by a
       // smaller subcube -- the top bits of the span -- so that at least those gathers find their lines.
@@ -356,7 +360,9 @@ std::string Plan::describe(const OpForm &op) const {
      << " tiled=" << (use_tiled ? 1 : 0) << " B=" << cfg.B << " logR=" << cfg.logR
      << " mode=" << cfg.mode << " masks=" << op.masks.size() << "\n";
   auto dump = [&](const char *kind, const PassSpec &ps, size_t i) {
-    os << kind << " pass " << i << ": segs";
+    os << kind << " pass " << i << ":";
+    if (ps.B != cfg.B || (ps.logR && ps.logR != cfg.logR)) os << " B=" << ps.B << " logR=" << (ps.logR ? ps.logR : cfg.logR);
+    os << " segs";
     for (int j = 0; j < ps.nseg; ++j)
       os << " [" << ps.seg_pos[j] << "," << ps.seg_pos[j] + ps.seg_len[j] << ")";
     if (ps.glen) os << " xcd-group [" << ps.gpos << "," << ps.gpos + ps.glen << ")";

@@ -106,11 +106,14 @@ struct DevPass {
   double *dot_out;      // non-null (last pass, tile staged): per-workgroup partial sums of conj(x_row) y_row
   const void *zinit;    // non-null (first, non-accumulating pass): y starts from -zscale * zinit (Lanczos: the
   double zscale;        //   beta term of the three-term recurrence rides on the multiply)
+  int32_t tile_bits;    // B and LOGR of the kernel instance this pass runs on (passes of one plan may differ)
+  int32_t log_rows;
 };
 
 // ---- host-side description --------------------------------------------------
 struct PassSpec {
   int B = 0;                       // tile bits
+  int logR = 0;                    // log2 rows per thread (0: the plan's)
   int nseg = 0;
   int seg_len[MAXSEG] = {0}, seg_pos[MAXSEG] = {0};
   std::vector<int> tile_masks;     // indices into OpForm.masks served from LDS
@@ -143,6 +146,7 @@ struct PlanConfig {
   int mode = 2;        // 0: multi-pass LDS tiles; 1: single pass, everything else gathered;
                        // 2: multi-pass LDS tiles + L2-served gathers over an XCD group
   int gbits = -1;      // mode 2: bits per XCD group (-1: 9 / 8 / 6 for local vectors of >= 2^30 / >= 2^26 / fewer amplitudes)
+  int Bw = 0, logRw = 0; // mode 2 experiment: tile bits / rows per thread of the window passes (0: as B / logR)
   int window_first = 0; // mode 2 experiment: run the window passes before the contiguous one (measured slower)
   int gbits_window = -1; // mode 2: cap of the group bits of window-tile passes (-1: no cap)
   int cache_policy = 98; // DevPass::cache_policy for every pass; default: gathers right behind the tile loads (32) + streaming loads (2) and stores (64) of y

@@ -64,7 +64,7 @@ class HostMat:
 def run_pass(hm, p, x, y, xr=None):
     """Apply one exported pass to the local vector x (numpy), updating y."""
     desc, quads = p
-    B, logR, n_loc = hm.B, hm.logR, desc.n_eff
+    B, logR, n_loc = desc.tile_bits, desc.log_rows, desc.n_eff
     assert x.shape[0] == 1 << n_loc and y.shape[0] == 1 << n_loc
     lognt = B - logR
     NT = 1 << lognt

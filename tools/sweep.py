@@ -52,6 +52,11 @@ def main():
     ref = None
     for c in cfgs:
         flags = 0
+        for k in list(os.environ):
+            if k.startswith("DNM_") and k not in ("DNM_FUZZ_N",):
+                os.environ.pop(k)
+        for k, v in c.get("env", {}).items():
+            os.environ[k] = str(v)
         if c.get("gather"):
             flags |= _lib.MAT_FORCE_GATHER
         else:
