@@ -1,3 +1,6 @@
+#!/usr/bin/env python
+"""eigsolve on a named model: prints every returned pair with its explicitly computed residual, norm and
+overlaps (usage: eig_debug.py MODEL L NEV [TOL]); with DNM_KRYLOV_DEBUG=1 the solver adds its statistics."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
