@@ -259,9 +259,53 @@ basis_update_kernel(c128 *V, int64_t ldv, int nin, int nout, int64_t n,
   }
 }
 
+// Register variant for nout <= 16 (every thick restart with the default ncv): one thread per row keeps the
+// nout outputs in registers while it streams the nin inputs of its row in chunks of 8 columns -- all loads of a
+// chunk are in flight together and nothing goes through LDS.  In place: a row's outputs are written only after
+// all of its inputs have been read.
+constexpr int BU_MAXOUT = 16;
+__global__ void __launch_bounds__(VNT)
+basis_update_reg_kernel(c128 *V, int64_t ldv, int nin, int nout, int64_t n, const double *__restrict__ S) {
+  for (int64_t row = (int64_t)blockIdx.x * VNT + threadIdx.x; row < n; row += (int64_t)gridDim.x * VNT) {
+    double ar[BU_MAXOUT], ai[BU_MAXOUT];
+#pragma unroll
+    for (int o = 0; o < BU_MAXOUT; ++o) ar[o] = ai[o] = 0.0;
+    for (int j0 = 0; j0 < nin; j0 += 8) {
+      c128 v[8];
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj)
+        v[jj] = (j0 + jj < nin) ? ld_stream(V + (int64_t)(j0 + jj) * ldv + row) : make_double2(0.0, 0.0);
+#pragma unroll
+      for (int o = 0; o < BU_MAXOUT; ++o) {
+        if (o < nout) {
+#pragma unroll
+          for (int jj = 0; jj < 8; ++jj) {
+            if (j0 + jj < nin) {
+              const double sr = S[2 * ((int64_t)o * nin + j0 + jj)], si = S[2 * ((int64_t)o * nin + j0 + jj) + 1];
+              ar[o] = fma(sr, v[jj].x, ar[o]);
+              ar[o] = fma(-si, v[jj].y, ar[o]);
+              ai[o] = fma(sr, v[jj].y, ai[o]);
+              ai[o] = fma(si, v[jj].x, ai[o]);
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 0; o < BU_MAXOUT; ++o)
+      if (o < nout) st_stream(V + (int64_t)o * ldv + row, make_double2(ar[o], ai[o]));
+  }
+}
+
 int vk_basis_update(void *V, int64_t ldv, int nin, int nout, int64_t n, const double *S_dev,
                     hipStream_t st) {
   DNM_CHECK(nin >= 1 && nout >= 0 && nout <= nin, "basis_update: bad shapes");
+  if (nout <= BU_MAXOUT) {
+    hipLaunchKernelGGL(basis_update_reg_kernel, dim3(vgrid(n)), dim3(VNT), 0, st, (c128 *)V, ldv, nin, nout, n,
+                       S_dev);
+    DNM_HIP(hipGetLastError());
+    return 0;
+  }
   const size_t lds = (size_t)nin * BU_ROWS * sizeof(c128);
   DNM_CHECK(lds <= 160 * 1024, "basis_update: too many vectors for one LDS stage");
   static size_t attr = 0;

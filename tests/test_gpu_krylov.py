@@ -58,6 +58,14 @@ def test_mdot_maxpy_basis_update():
     out = Vd.local_numpy().reshape(nv, n)
     assert np.max(np.abs(out[:nout] - S @ V)) < 1e-11
     assert np.array_equal(out[nout:], V[nout:])
+    # both kernels behind it: registers (nout <= 16) and the LDS-staged one (more outputs), odd shapes
+    for nv2, nout2, n2 in ((16, 8, 70001), (17, 16, 4099), (33, 20, 3000), (30, 29, 1025)):
+        V2 = np.stack([rand_state(n2, 200 + j) for j in range(nv2)])
+        S2 = np.stack([rand_state(nv2, 300 + o) for o in range(nout2)])
+        Vd2 = vec_from(V2.reshape(-1))
+        _lib.check(L.dnm_vec_basis_update(Vd2.ptr, n2, nv2, nout2, n2, _lib.pf64(S2.reshape(-1).view(float).copy()), None))
+        out2 = Vd2.local_numpy().reshape(nv2, n2)
+        assert np.max(np.abs(out2[:nout2] - S2 @ V2)) < 1e-10 and np.array_equal(out2[nout2:], V2[nout2:])
 
 
 def test_device_rng_moments():
