@@ -54,6 +54,20 @@ int launch_sc_matvec(const DevMsc &msc, const ScMask *scm, const ScLow &low, con
                      int64_t win_start, const double *diag, const void *xw, void *y, int64_t *colrange,
                      hipStream_t st);
 
+// Block form of the same product (sc_block_kernel): one workgroup per high part H = state >> lb.
+struct ScBlock {
+  const uint16_t *lowtab;  // the lb-bit patterns grouped by popcount, ascending inside a group
+  int32_t off[18];         // group j starts at lowtab[off[j]]
+  int32_t lb;              // low bits per block
+  int32_t swizzle;         // XCD-aware block order (needs h_first % 512 == 0)
+  int64_t h_first, h_last; // high parts covered by the launch
+};
+bool sc_block_supported(int lb);
+int sc_block_max_masks();
+int launch_sc_block(const DevMsc &msc, const ScMask *scm, const ScBlock &blk, const SubView &sub, int64_t M, int64_t row0,
+                    int64_t win_start, int64_t win_len, const double *diag, const void *xw, void *y,
+                    hipStream_t st);
+
 // diag[row] = sum over mask-0 terms (bcuda_template_1.cu:29-66)
 int launch_diag(const DevMsc &msc, const SubView &sub, int64_t M, int64_t row0, double *diag, hipStream_t st);
 

@@ -495,6 +495,45 @@ int dnm_reduced_density_matrix(const void *x, const dnm_subspace *sub, int keep_
 }
 
 // ---- shell matrix -------------------------------------------------------------
+// Decide whether the SpinConserve block kernel runs and build its table.  DNM_SC_BLOCK = 0 (row kernel),
+// 10 / 13 / 14 (low bits per block); default: 13 when the blocks are large enough to fill a workgroup.
+static int setup_sc_block(dnm_mat *A) {
+  A->scblock.lb = 0;
+  if (!A->sc_pair || A->m_local <= 0) return 0;
+  const SubView &h = A->left.host;
+  const int L = h.L, k = h.k;
+  int lb = -1;
+  if (const char *e = getenv("DNM_SC_BLOCK")) lb = atoi(e);
+  if (lb == 0) return 0;
+  const bool forced = lb > 0;
+  if (!forced) lb = 13;
+  if (!sc_block_supported(lb) || L <= lb || L - lb > 48 || (int64_t)A->masks.size() > sc_block_max_masks()) {
+    DNM_CHECK(!forced, "DNM_SC_BLOCK=%d not usable for L=%d, k=%d", lb, L, k);
+    return 0;
+  }
+  if (!forced && (A->M >> (L - lb)) < 256) return 0;     // blocks too small on average: one row per thread instead
+  std::vector<uint16_t> tab((size_t)1 << lb);
+  int cnt[18] = {0};
+  for (int v = 0; v < (1 << lb); ++v) ++cnt[__builtin_popcount(v) + 1];
+  for (int j = 0; j < 17; ++j) { cnt[j + 1] += cnt[j]; A->scblock.off[j] = cnt[j]; }
+  A->scblock.off[17] = 1 << lb;
+  int fill[17];
+  for (int j = 0; j < 17; ++j) fill[j] = A->scblock.off[j];
+  for (int v = 0; v < (1 << lb); ++v) tab[fill[__builtin_popcount(v)]++] = (uint16_t)v;
+  DNM_TRY(A->d_scblock.upload(tab.data(), tab.size() * sizeof(uint16_t)));
+  A->scblock.lowtab = (const uint16_t *)A->d_scblock.p;
+  int64_t hf = sub_i2s(A->row0, h) >> lb, hl = sub_i2s(A->row0 + A->m_local - 1, h) >> lb;
+  A->scblock.swizzle = 0;
+  if (hl - (hf & ~(int64_t)511) + 1 >= 1024) {
+    A->scblock.swizzle = 1;
+    hf &= ~(int64_t)511;
+  }
+  A->scblock.h_first = hf;
+  A->scblock.h_last = hl;
+  A->scblock.lb = lb;
+  return 0;
+}
+
 int dnm_mat_create(int64_t nmasks, const int64_t *masks, const int64_t *mask_offsets,
                    const int64_t *signs, const double *coeffs, const dnm_subspace *left,
                    const dnm_subspace *right, int xparity, int flags, const dnm_partition *part,
@@ -612,6 +651,7 @@ int dnm_mat_create(int64_t nmasks, const int64_t *masks, const int64_t *mask_off
     for (int v = 0; v < 65536; ++v) low[fill[__builtin_popcount(v)]++] = (uint16_t)v;
     DNM_TRY(A->d_sclow.upload(low.data(), low.size() * sizeof(uint16_t)));
     A->sclow.tab = (const uint16_t *)A->d_sclow.p;
+    DNM_TRY(setup_sc_block(A.get()));
   }
   }
 
@@ -690,6 +730,16 @@ int dnm_mat_get_diagonal(dnm_mat *A, double *diag_host, void *stream) {
   return dnm_memcpy_d2h(diag_host, A->diag.p, (size_t)A->m_local * sizeof(double), stream);
 }
 
+// SpinConserve block kernel: the launch covers the high parts of the rows this rank owns.
+static int launch_sc(dnm_mat *A, int64_t win_start, int64_t win_len, const void *xw, void *y, void *stream) {
+  const double *dg = A->have_diag ? (const double *)A->diag.p : nullptr;
+  if (A->scblock.lb)
+    return launch_sc_block(A->dmsc, (const ScMask *)A->d_scmasks.p, A->scblock, A->right.dev, A->m_local, A->row0,
+                           win_start, win_len, dg, xw, y, S(stream));
+  return launch_sc_matvec(A->dmsc, (const ScMask *)A->d_scmasks.p, A->sclow, A->right.dev, A->m_local, A->row0,
+                          win_start, dg, xw, y, nullptr, S(stream));
+}
+
 static bool use_glds(const dnm_mat *A) { return (A->flags & DNM_MAT_USE_GLDS) != 0; }
 
 int dnm_mat_mult_local(dnm_mat *A, const void *x, void *y, void *stream) {
@@ -703,9 +753,7 @@ int dnm_mat_mult_local(dnm_mat *A, const void *x, void *y, void *stream) {
     return 0;
   }
   DNM_CHECK(A->nranks == 1, "this subspace pair cannot run partitioned (use dnm_mat_mult_window)");
-  if (A->sc_pair)
-    return launch_sc_matvec(A->dmsc, (const ScMask *)A->d_scmasks.p, A->sclow, A->right.dev, A->M, 0, 0,
-                            A->have_diag ? (const double *)A->diag.p : nullptr, x, y, nullptr, S(stream));
+  if (A->sc_pair) return launch_sc(A, 0, A->N, x, y, stream);
   return launch_gather_matvec(A->dmsc, A->left.dev, A->right.dev, A->M,
                               A->have_diag ? (const double *)A->diag.p : nullptr, x, y, S(stream));
 }
@@ -793,9 +841,7 @@ int dnm_mat_mult_window(dnm_mat *A, const void *x_window, int64_t win_start, int
   DNM_CHECK(win_start <= lo && win_start + win_len > hi,
             "window [%lld, %lld) does not cover the columns [%lld, %lld] this rank reads", (long long)win_start,
             (long long)(win_start + win_len), (long long)lo, (long long)hi);
-  return launch_sc_matvec(A->dmsc, (const ScMask *)A->d_scmasks.p, A->sclow, A->right.dev, A->m_local, A->row0, win_start,
-                          A->have_diag ? (const double *)A->diag.p : nullptr, x_window, y_local, nullptr,
-                          S(stream));
+  return launch_sc(A, win_start, win_len, x_window, y_local, stream);
 }
 
 int dnm_mat_exchange_plan(const dnm_mat *A, int *nsend, dnm_xfer *sends, int *nrecv, dnm_xfer *recvs) {
@@ -854,7 +900,9 @@ int dnm_mat_plan_describe(const dnm_mat *A, char *buf, size_t buflen) {
   std::string s;
   if (A->hypercube) s = A->plan.describe(A->op);
   else if (A->sc_pair)
-    s = "SpinConserve kernel (incremental colex rank)\n";
+    s = A->scblock.lb ? "SpinConserve kernel, block form (" + std::to_string(A->scblock.lb) +
+                            " low bits per workgroup in LDS, high bonds as block runs)\n"
+                      : std::string("SpinConserve kernel (one row per thread, incremental colex rank)\n");
   else s = "generic row-gather kernel (non-hypercube subspace pair)\n";
   if (A->hypercube && !A->plan.use_tiled) s += "generic row-gather kernel in use\n";
   snprintf(buf, buflen, "%s", s.c_str());

@@ -70,6 +70,8 @@ struct dnm_mat {
   dnm::DevMsc dmsc{};
   dnm::DevBuf d_sclow;            // SpinConserve kernel: 16-bit unranking table
   dnm::ScLow sclow{};
+  dnm::DevBuf d_scblock;          // block kernel: lb-bit patterns grouped by popcount
+  dnm::ScBlock scblock{};         // lb == 0: block kernel not used
   dnm::DevBuf d_scmasks;          // SpinConserve kernel: per-mask precomputation (ScMask[nmasks])
 
   dnm::DevBuf diag;              // cached diagonal (double[m_local]) if precomputed

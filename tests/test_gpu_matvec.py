@@ -181,6 +181,69 @@ def test_spinconserve_kernel_general_masks():
         assert np.max(np.abs(y - ref)) <= tol_for(arrs, x)
 
 
+@pytest.mark.parametrize("lb,L,k", [(10, 12, 6), (10, 16, 7), (10, 17, 3), (10, 18, 14), (13, 20, 10), (14, 20, 9),
+                                    (14, 22, 11)])
+def test_spinconserve_block_kernel(monkeypatch, lb, L, k):
+    """Block form of the SpinConserve kernel (one workgroup per high part): chain bonds inside the low
+    part (LDS), inside the high part (block runs), the bond across the boundary and long-range /
+    four-spin masks (per-row path), with and without the cached diagonal, against the oracle."""
+    from dynamite_amd.operators import sigmax, sigmay, sigmaz, op_sum
+    monkeypatch.setenv("DNM_SC_BLOCK", str(lb))
+    rs = np.random.RandomState(L * 31 + k)
+    hop = lambda i, j: sigmax(i) * sigmax(j) + sigmay(i) * sigmay(j)
+    Hs = [models.mbl(L)]
+    if L <= 18:
+        E = op_sum(float(rs.uniform(-1, 1)) * hop(i, (i + 3) % L) for i in range(L))
+        E += op_sum(0.3 * hop(i, i + 2) * hop(i + 5, i + 9) for i in range(0, L - 9, 2))
+        E += op_sum(float(rs.uniform(-1, 1)) * sigmaz(i) * hop((i + 1) % L, (i + 2) % L) for i in range(L))
+        E.L = L
+        Hs.append(models.mbl(L) + E)
+    sub = SpinConserve(L, k)
+    x = rand_state(sub.get_dimension(), seed=L + k)
+    for H in Hs:
+        arrs = marshal(H)
+        ref = orc.matvec(orc_msc(H), orc_sub(sub), orc_sub(sub), x, nthreads=4)
+        for diag in (False, True):
+            mat = shell(H, sub)
+            assert "block form (%d" % lb in mat.describe()
+            if diag:
+                mat.precompute_diagonal()
+            y = mult_numpy(mat, x)
+            assert np.max(np.abs(y - ref)) <= tol_for(arrs, x)
+            mat.destroy()
+
+
+@pytest.mark.parametrize("P", [2, 3, 5])
+def test_spinconserve_block_kernel_windows(monkeypatch, P):
+    """The block kernel on a partition: blocks cut by the ownership boundaries, x given as a column window."""
+    monkeypatch.setenv("DNM_SC_BLOCK", "10")
+    L, k = 17, 8
+    H = models.mbl(L)
+    arrs = marshal(H)
+    sub = SpinConserve(L, k)
+    dim = sub.get_dimension()
+    x = rand_state(dim, seed=16)
+    ref = orc.matvec(orc_msc(H), orc_sub(sub), orc_sub(sub), x, nthreads=4)
+    Lb = _lib.lib()
+    for diag in (False, True):
+        y = np.empty(dim, dtype=complex)
+        for r in range(P):
+            h = backend.create_mat(*arrs, sub._c(), sub._c(), flags=0, rank=r, nranks=P)
+            mat = backend.ShellMat(h, sub._c(), sub._c(), P, r)
+            assert "block form" in mat.describe()
+            start, n = backend.split_ownership(dim, P, r)
+            lo, hi = mat.column_window()
+            if diag:
+                mat.precompute_diagonal()
+            # guard amplitudes around the window: anything read outside it would poison the result
+            xw = vec_from(x[lo:hi + 1])
+            yl = vec_from(np.full(n, np.nan + 0j))
+            _lib.check(Lb.dnm_mat_mult_window(mat.handle, xw.ptr, lo, hi - lo + 1, yl.ptr, None))
+            y[start:start + n] = yl.local_numpy()
+            mat.destroy()
+        assert np.max(np.abs(y - ref)) <= tol_for(arrs, x)
+
+
 def test_partitioned_kernels_on_one_gpu(monkeypatch):
     """Rank-local and partner passes of a P-way partition, run rank by rank on
     this one GPU (exchange = slicing), must add up to the single-rank result."""
