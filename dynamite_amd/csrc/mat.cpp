@@ -496,7 +496,7 @@ int dnm_reduced_density_matrix(const void *x, const dnm_subspace *sub, int keep_
 
 // ---- shell matrix -------------------------------------------------------------
 // Decide whether the SpinConserve block kernel runs and build its table.  DNM_SC_BLOCK = 0 (row kernel),
-// 10 / 13 / 14 (low bits per block); default: 13 when the blocks are large enough to fill a workgroup.
+// 10 / 13 (low bits per block); default: 13 when the blocks are large enough to fill a workgroup.
 static int setup_sc_block(dnm_mat *A) {
   A->scblock.lb = 0;
   if (!A->sc_pair || A->m_local <= 0) return 0;

@@ -682,7 +682,14 @@ constexpr int sc_binom(int n, int k) {
   for (int i = 1; i <= k; ++i) r = r * (n - k + i) / i;
   return (int)r;
 }
-constexpr int SCB_MAXM = 64;    // masks per operator the block kernel keeps lists for
+constexpr int SCB_MAXM = 64;    // masks per operator: one lane of a wavefront each
+
+__device__ __forceinline__ int64_t rl_i64(int64_t v, int l) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(v & 0xffffffff), l);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(v >> 32), l);
+  return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ double rl_f64(double v, int l) { return __longlong_as_double(rl_i64(__double_as_longlong(v), l)); }
 
 template <int LB, int NT>
 __global__ void __launch_bounds__(NT, 4)
@@ -693,13 +700,10 @@ sc_block_kernel(const DevMsc msc, const ScMask *__restrict__ scm, const ScBlock 
   constexpr int RPT = (MAXROWS + NT - 1) / NT;
   __shared__ c128 xs[MAXROWS];
   __shared__ int32_t cl[LB * (LB + 1)];      // cl[lo * (LB+1) + o] = C(lo, o)
-  // per-block mask lists, built by the first wavefront (ascending mask order: deterministic sums)
-  __shared__ int64_t hb_delta[SCB_MAXM];     // bonds inside the high part that act on this block: column offset
-  __shared__ double hb_cre[SCB_MAXM], hb_cim[SCB_MAXM];
-  __shared__ int32_t lf_lo[SCB_MAXM];        // bonds that touch the low part
+  __shared__ int32_t lf_lo[SCB_MAXM];        // bonds that touch the low part (written by the first wavefront)
   __shared__ double lf_c[SCB_MAXM][4];       // up_re, up_im, dn_re, dn_im
   __shared__ int32_t gen_m[SCB_MAXM];        // masks on the per-row path
-  __shared__ int32_t cnt[3];
+  __shared__ int32_t cnt[2];
   const int ld = sub_g.ld, kk = sub_g.k;
   const int64_t *__restrict__ gtab = sub_g.nchoosek;
   const int lane = threadIdx.x & 63;
@@ -726,99 +730,107 @@ sc_block_kernel(const DevMsc msc, const ScMask *__restrict__ scm, const ScBlock 
     int64_t term = 0;
     if ((H >> lane) & 1ull) term = gtab[(kl + __popcll(H & ((2ull << lane) - 1))) * ld + LB + lane];
     for (int off = 32; off > 0; off >>= 1) term += __shfl_xor(term, off, 64);
-    base = __builtin_amdgcn_readfirstlane((int)(term & 0xffffffff)) |
-           ((int64_t)__builtin_amdgcn_readfirstlane((int)(term >> 32)) << 32);
+    base = rl_i64(term, 0);
   }
   const int nrows = (int)gtab[kl * ld + LB];
   const int64_t lo_row = row0 - base, hi_row = row0 + M - base;     // local rows of this rank: [lo_row, hi_row)
   if (hi_row <= 0 || lo_row >= nrows) return;
   const int r_lo = lo_row > 0 ? (int)lo_row : 0;
   const int r_hi = hi_row < nrows ? (int)hi_row : nrows;
-  const int m0 = diag ? 1 : 0;
-
-  if (threadIdx.x < 64) {
-    const int m = lane;
-    int cls = -1;
-    int64_t delta = 0;
-    double c0 = 0.0, c1 = 0.0, c2 = 0.0, c3 = 0.0;
-    int mlo = 0;
-    if (m >= m0 && m < msc.nmasks) {
-      const ScMask sm = scm[m];
-      mlo = sm.lo;
-      if (sm.fast && sm.lo >= LB) {
-        const uint32_t pair = (uint32_t)(H >> (sm.lo - LB)) & 3u;
-        if (pair == 1u || pair == 2u) {
-          const bool up = pair == 1u;
-          const int ord0 = kl + __popcll(H & ((1ull << (sm.lo - LB)) - 1));
-          const int64_t d = gtab[ord0 * ld + sm.lo];
-          delta = up ? d : -d;
-          c0 = up ? sm.up_re : sm.dn_re;
-          c1 = up ? sm.up_im : sm.dn_im;
-          cls = 0;
-        }
-      } else if (sm.fast) {
-        c0 = sm.up_re; c1 = sm.up_im; c2 = sm.dn_re; c3 = sm.dn_im;
-        cls = 1;
-      } else {
-        cls = 2;
-      }
-    }
-    const uint64_t below = (1ull << lane) - 1;
-    const uint64_t b0 = __ballot(cls == 0), b1 = __ballot(cls == 1), b2 = __ballot(cls == 2);
-    if (cls == 0) {
-      const int p = __popcll(b0 & below);
-      hb_delta[p] = delta; hb_cre[p] = c0; hb_cim[p] = c1;
-    } else if (cls == 1) {
-      const int p = __popcll(b1 & below);
-      lf_lo[p] = mlo;
-      lf_c[p][0] = c0; lf_c[p][1] = c1; lf_c[p][2] = c2; lf_c[p][3] = c3;
-    } else if (cls == 2) {
-      gen_m[__popcll(b2 & below)] = m;
-    }
-    if (lane == 0) { cnt[0] = __popcll(b0); cnt[1] = __popcll(b1); cnt[2] = __popcll(b2); }
-  }
-  for (int t = threadIdx.x; t < LB * (LB + 1); t += NT) {
-    const int lo = t / (LB + 1), o = t % (LB + 1);
-    cl[t] = (o <= lo && o <= kk) ? (int32_t)gtab[o * ld + lo] : 0;
-  }
-
   const c128 *__restrict__ x = xw - win_start;
+
+  // this block of x and the low patterns of its rows
   uint32_t lowb[RPT];
-  double accr[RPT], acci[RPT];
+  c128 xv[RPT];
   const uint16_t *__restrict__ pat = blk.lowtab + blk.off[kl];
   const bool whole = (base >= win_start) && (base + nrows <= win_start + win_len);
   uint32_t live = 0;       // bit i: row i of this thread belongs to this rank
 #pragma unroll
   for (int i = 0; i < RPT; ++i) {
     const int r = threadIdx.x + i * NT;
-    accr[i] = 0.0;
-    acci[i] = 0.0;
     lowb[i] = 0;
+    xv[i] = make_double2(0.0, 0.0);
     if (r < nrows) {
       lowb[i] = pat[r];
-      c128 xv = make_double2(0.0, 0.0);
-      if (whole || (base + r >= win_start && base + r < win_start + win_len)) xv = x[base + r];
-      xs[r] = xv;
-      if (r >= r_lo && r < r_hi) {
-        live |= 1u << i;
-        if (diag) {
-          const double dg = __builtin_nontemporal_load(diag + (base + r - row0));
-          accr[i] = dg * xv.x;
-          acci[i] = dg * xv.y;
-        }
+      if (whole || (base + r >= win_start && base + r < win_start + win_len)) xv[i] = x[base + r];
+      if (r >= r_lo && r < r_hi) live |= 1u << i;
+    }
+  }
+
+  // every wavefront classifies the masks for this block, one mask per lane (ascending mask order in the
+  // ballots: deterministic sums): 0 = bond inside the high part that acts on the block, 1 = bond touching
+  // the low part, 2 = per-row path
+  const int m0 = diag ? 1 : 0;
+  int cls = -1;
+  int64_t delta_v = 0;
+  double c0 = 0.0, c1 = 0.0;
+  if (lane >= m0 && lane < msc.nmasks) {
+    const ScMask sm = scm[lane];
+    if (sm.fast && sm.lo >= LB) {
+      const uint32_t pair = (uint32_t)(H >> (sm.lo - LB)) & 3u;
+      if (pair == 1u || pair == 2u) {
+        const bool up = pair == 1u;
+        const int ord0 = kl + __popcll(H & ((1ull << (sm.lo - LB)) - 1));
+        const int64_t d = gtab[ord0 * ld + sm.lo];
+        delta_v = up ? d : -d;
+        c0 = up ? sm.up_re : sm.dn_re;
+        c1 = up ? sm.up_im : sm.dn_im;
+        cls = 0;
+      }
+    } else {
+      cls = sm.fast ? 1 : 2;
+    }
+  }
+  uint64_t hb = __ballot(cls == 0);
+  {
+    const uint64_t lfb = __ballot(cls == 1), genb = __ballot(cls == 2);
+    if (threadIdx.x < 64) {
+      const uint64_t below = (1ull << lane) - 1;
+      if (cls == 1) {
+        const ScMask sm = scm[lane];
+        const int p = __popcll(lfb & below);
+        lf_lo[p] = sm.lo;
+        lf_c[p][0] = sm.up_re; lf_c[p][1] = sm.up_im; lf_c[p][2] = sm.dn_re; lf_c[p][3] = sm.dn_im;
+      } else if (cls == 2) {
+        gen_m[__popcll(genb & below)] = lane;
+      }
+      if (lane == 0) { cnt[0] = __popcll(lfb); cnt[1] = __popcll(genb); }
+    }
+  }
+
+  for (int t = threadIdx.x; t < LB * (LB + 1); t += NT) {
+    const int lo = t / (LB + 1), o = t % (LB + 1);
+    cl[t] = (o <= lo && o <= kk) ? (int32_t)gtab[o * ld + lo] : 0;
+  }
+  double accr[RPT], acci[RPT];
+#pragma unroll
+  for (int i = 0; i < RPT; ++i) {
+    const int r = threadIdx.x + i * NT;
+    accr[i] = 0.0;
+    acci[i] = 0.0;
+    if (r < nrows) {
+      xs[r] = xv[i];
+      if (diag && ((live >> i) & 1u)) {
+        const double dg = __builtin_nontemporal_load(diag + (base + r - row0));
+        accr[i] = dg * xv[i].x;
+        acci[i] = dg * xv[i].y;
       }
     }
   }
-  __syncthreads();
 
-  // bonds inside the high part, two at a time: 2 * RPT independent coalesced loads in flight per thread
-  const int nhb = cnt[0];
-  for (int a = 0; a < nhb; a += 2) {
-    const bool two = a + 1 < nhb;
-    const c128 *__restrict__ p0 = x + (base + hb_delta[a]);
-    const c128 *__restrict__ p1 = x + (base + hb_delta[two ? a + 1 : a]);
-    const double c0r = hb_cre[a], c0i = hb_cim[a];
-    const double c1r = two ? hb_cre[a + 1] : 0.0, c1i = two ? hb_cim[a + 1] : 0.0;
+  // bonds inside the high part, lowest first and before the barrier: the partner blocks under the lowest high
+  // bonds are resident on this XCD and were requested by their owners a moment ago.  Two bonds at a time:
+  // 2 * RPT independent coalesced loads in flight per thread.
+  while (hb) {
+    const int ma = __ffsll((long long)hb) - 1;
+    hb &= hb - 1;
+    const bool two = hb != 0;
+    const int mb = two ? __ffsll((long long)hb) - 1 : ma;
+    hb &= hb - 1;
+    const c128 *__restrict__ p0 = x + (base + rl_i64(delta_v, ma));
+    const c128 *__restrict__ p1 = x + (base + rl_i64(delta_v, mb));
+    const double c0r = rl_f64(c0, ma), c0i = rl_f64(c1, ma);
+    const double c1r = two ? rl_f64(c0, mb) : 0.0, c1i = two ? rl_f64(c1, mb) : 0.0;
     c128 v0[RPT], v1[RPT];
 #pragma unroll
     for (int i = 0; i < RPT; ++i) {
@@ -839,11 +851,12 @@ sc_block_kernel(const DevMsc msc, const ScMask *__restrict__ scm, const ScBlock 
       acci[i] = fma(c1i, v1[i].x, acci[i]);
     }
   }
+  __syncthreads();
 
   // bonds that touch the low part: partner row of the same block from LDS; the bond across the boundary
   // (lo == LB - 1) pairs the top low bit with the lowest high bit and reads its partner from memory
-  const int nlf = cnt[1];
   const uint32_t hbit = (uint32_t)(H & 1ull) << LB;
+  const int nlf = cnt[0];
   for (int a = 0; a < nlf; ++a) {
     const int lo = lf_lo[a];
     const double ure = lf_c[a][0], uim = lf_c[a][1], dre = lf_c[a][2], dim_ = lf_c[a][3];
@@ -857,18 +870,18 @@ sc_block_kernel(const DevMsc msc, const ScMask *__restrict__ scm, const ScBlock 
         const int ord0 = __popc(lowb[i] & ((1u << lo) - 1u));
         const int d = cl[lo * (LB + 1) + ord0];
         const int rp = up ? r + d : r - d;
-        const c128 xv = cross ? x[base + rp] : xs[rp];
+        const c128 xp = cross ? x[base + rp] : xs[rp];
         const double cre = up ? ure : dre, cim = up ? uim : dim_;
-        accr[i] = fma(cre, xv.x, accr[i]);
-        acci[i] = fma(cre, xv.y, acci[i]);
-        accr[i] = fma(-cim, xv.y, accr[i]);
-        acci[i] = fma(cim, xv.x, acci[i]);
+        accr[i] = fma(cre, xp.x, accr[i]);
+        acci[i] = fma(cre, xp.y, acci[i]);
+        accr[i] = fma(-cim, xp.y, accr[i]);
+        acci[i] = fma(cim, xp.x, acci[i]);
       }
     }
   }
 
   // everything else: per row, columns by incremental rank (as in sc_matvec_kernel)
-  const int ngen = cnt[2];
+  const int ngen = cnt[1];
   for (int a = 0; a < ngen; ++a) {
     const int m = gen_m[a];
     const uint64_t mask = (uint64_t)msc.masks[m];
@@ -881,10 +894,10 @@ sc_block_kernel(const DevMsc msc, const ScMask *__restrict__ scm, const ScBlock 
       int64_t delta = 0;
       if (mask) {
         if (__popcll(bra) != kk) continue;             // leaves the subspace: projection semantics
-        const int mlo = __ffsll((long long)mask) - 1;
+        const int mlo_ = __ffsll((long long)mask) - 1;
         const int mhi = 63 - __clzll((long long)mask);
-        const uint64_t span = (mhi >= 63 ? ~0ull : ((2ull << mhi) - 1)) & ~((1ull << mlo) - 1);
-        const int ord0 = __popcll(ket & ((1ull << mlo) - 1));
+        const uint64_t span = (mhi >= 63 ? ~0ull : ((2ull << mhi) - 1)) & ~((1ull << mlo_) - 1);
+        const int ord0 = __popcll(ket & ((1ull << mlo_) - 1));
         uint64_t bb = bra & span, kb = ket & span;
         int o = ord0;
         while (bb) {
@@ -907,11 +920,11 @@ sc_block_kernel(const DevMsc msc, const ScMask *__restrict__ scm, const ScBlock 
         const double c = flip_sign(msc.real_coeffs[t], (uint32_t)__popcll(bra & sg) & 1u);
         if (__popcll(mask & sg) & 1) cim += c; else cre += c;   // TERM_REAL
       }
-      const c128 xv = x[base + r + delta];
-      accr[i] = fma(cre, xv.x, accr[i]);
-      acci[i] = fma(cre, xv.y, acci[i]);
-      accr[i] = fma(-cim, xv.y, accr[i]);
-      acci[i] = fma(cim, xv.x, acci[i]);
+      const c128 xg = x[base + r + delta];
+      accr[i] = fma(cre, xg.x, accr[i]);
+      acci[i] = fma(cre, xg.y, acci[i]);
+      accr[i] = fma(-cim, xg.y, accr[i]);
+      acci[i] = fma(cim, xg.x, acci[i]);
     }
   }
 #pragma unroll
@@ -921,7 +934,7 @@ sc_block_kernel(const DevMsc msc, const ScMask *__restrict__ scm, const ScBlock 
   }
 }
 
-bool sc_block_supported(int lb) { return lb == 10 || lb == 13 || lb == 14; }
+bool sc_block_supported(int lb) { return lb == 10 || lb == 13; }
 int sc_block_max_masks() { return SCB_MAXM; }
 
 int launch_sc_block(const DevMsc &msc, const ScMask *scm, const ScBlock &blk, const SubView &sub, int64_t M, int64_t row0,
@@ -936,8 +949,7 @@ int launch_sc_block(const DevMsc &msc, const ScMask *scm, const ScBlock &blk, co
                      win_start, win_len, diag, (const c128 *)xw, (c128 *)y)
   switch (blk.lb) {
     case 10: DNM_SCB(10, 64); break;
-    case 13: DNM_SCB(13, 256); break;
-    case 14: DNM_SCB(14, 512); break;
+    case 13: DNM_SCB(13, 512); break;
     default: DNM_CHECK(false, "unsupported block size %d", blk.lb);
   }
 #undef DNM_SCB

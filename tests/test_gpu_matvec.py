@@ -181,8 +181,8 @@ def test_spinconserve_kernel_general_masks():
         assert np.max(np.abs(y - ref)) <= tol_for(arrs, x)
 
 
-@pytest.mark.parametrize("lb,L,k", [(10, 12, 6), (10, 16, 7), (10, 17, 3), (10, 18, 14), (13, 20, 10), (14, 20, 9),
-                                    (14, 22, 11)])
+@pytest.mark.parametrize("lb,L,k", [(10, 12, 6), (10, 16, 7), (10, 17, 3), (10, 18, 14), (13, 20, 10), (13, 20, 9),
+                                    (13, 22, 11)])
 def test_spinconserve_block_kernel(monkeypatch, lb, L, k):
     """Block form of the SpinConserve kernel (one workgroup per high part): chain bonds inside the low
     part (LDS), inside the high part (block runs), the bond across the boundary and long-range /
