@@ -109,9 +109,12 @@ int vk_maxpy(void *w, const void *V, int64_t ldv, int nv, int64_t n, const doubl
              hipStream_t st);
 int vk_basis_update(void *V, int64_t ldv, int nin, int nout, int64_t n, const double *S_dev,
                     hipStream_t st);
-// p -= (are + i aim) v + b u (u may be null); partials_dev[vk_mdot_blocks(n)] then the sum of |p|^2
+// p = scale * (p - (are + i aim) v - b u) (u may be null); partials_dev[vk_mdot_blocks(n)] then the sum of |p|^2
 int vk_lanczos_update(void *p, const void *v, const void *u, int64_t n, double are, double aim, double b,
-                      double *partials_dev, hipStream_t st);
+                      double scale, double *partials_dev, hipStream_t st);
+// y -= b z (z may be null) and the sums conj(x) y (re, im), |y|^2: partials_dev[3 * vk_mdot_blocks(n)] then [3]
+int vk_lanczos_dot(void *y, const void *z, const void *x, int64_t n, double b, double *partials_dev,
+                   hipStream_t st);
 // out[c] = sum_b partials[b * ncols + c]
 int vk_reduce_partials(const double *partials, int nblocks, int ncols, double *out, hipStream_t st);
 int vk_norm2_partials(const void *x, int64_t n, double *partials_dev, hipStream_t st);

@@ -176,20 +176,20 @@ struct Ops {
     }
     return dnm_mat_mult(A, x, y, (void *)st);
   }
-  // y = A x - b z (z may be null) and d = <x, y>: the multiply of one three-term Lanczos step
-  int mult_dot(const void *x, void *y, zc *d, const void *z = nullptr, double b = 0.0) {
+  // y = A x - b z (z may be null), d = <x, y> and, if asked for, nn = |y|^2: the multiply of one three-term
+  // Lanczos step
+  int mult_dot(const void *x, void *y, zc *d, const void *z = nullptr, double b = 0.0, double *nn = nullptr) {
+    double buf[3];
     if (hooks && hooks->mult) {
-      std::vector<zc> h;
       DNM_TRY(mult(x, y));
-      if (z) DNM_TRY(vk_axpby(y, z, n, -b, 0.0, 1.0, 0.0, st));
-      DNM_TRY(mdot(x, 1, y, h));
-      *d = h[0];
-      return 0;
+      DNM_TRY(vec_lanczos_dot_host(y, z, x, n, b, buf, st));
+      DNM_TRY(sum(buf, 3));
+    } else {
+      ++matvecs;
+      DNM_TRY(dnm_mat_mult_lanczos(A, x, y, z, b, buf, (void *)st));
     }
-    ++matvecs;
-    double buf[2];
-    DNM_TRY(dnm_mat_mult_lanczos(A, x, y, z, b, buf, (void *)st));
     *d = zc(buf[0], buf[1]);
+    if (nn) *nn = buf[2];
     return 0;
   }
   int sum(double *buf, int cnt) {
@@ -678,9 +678,12 @@ int dnm_eigsolve(dnm_mat *A, int64_t n_local, int nev, int which, double tol, in
       void *p = vecptr(V, n_local, j + 1);
       const bool three_term = use_pro && j != l;
       zc d0(0);
-      if (three_term) DNM_TRY(ops.mult_dot(vecptr(V, n_local, j), p, &d0, vecptr(V, n_local, j - 1), betav[j - 1]));
+      double pn2 = 0;
+      if (three_term)
+        DNM_TRY(ops.mult_dot(vecptr(V, n_local, j), p, &d0, vecptr(V, n_local, j - 1), betav[j - 1], &pn2));
       else DNM_TRY(ops.mult(vecptr(V, n_local, j), p));
       double bn = 0;
+      bool normalised = false;
       if (!three_term) {
         // the first step of a cycle removes the spike components: whole basis, twice when Ritz vectors are
         // present (they are orthonormal to sqrt(eps) only under partial re-orthogonalisation)
@@ -689,18 +692,34 @@ int dnm_eigsolve(dnm_mat *A, int64_t n_local, int nev, int which, double tol, in
         if (use_pro) mon.first_step(alpha[j], bn);
       } else {
         alpha[j] = d0.real();
+        // |p - alpha q_j|^2 = |p|^2 - |alpha|^2 (q_j has unit norm): beta is known before the update sweep, which
+        // then writes q_{j+1} = (p - alpha q_j) / beta directly; its own sum of squares (1 up to the cancellation
+        // in the difference) corrects beta and, if it is off, the vector
+        const double b2 = pn2 - std::norm(d0);
+        const bool fused = b2 > 1e-4 * pn2 && pn2 > 0;
+        const double best = fused ? std::sqrt(b2) : 0.0;
+        const bool reorth = fused ? mon.update(j, alpha[j], best) : false;
         double n2 = 0;
         DNM_TRY(vec_lanczos_update_host(p, vecptr(V, n_local, j), nullptr, n_local, d0.real(), d0.imag(), 0.0, &n2,
-                                        st));
+                                        st, (fused && !reorth) ? 1.0 / best : 1.0));
         DNM_TRY(ops.sum(&n2, 1));
-        bn = std::sqrt(n2 > 0 ? n2 : 0.0);
-        if (mon.update(j, alpha[j], bn)) {
-          std::vector<zc> g, c(j + 1);
-          DNM_TRY(ops.mdot(V, j + 1, p, g));
-          for (int i = 0; i <= j; ++i) c[i] = -g[i];
-          DNM_TRY(ops.maxpy(p, V, j + 1, c));
-          DNM_TRY(ops.norm(p, &bn));
+        if (fused && !reorth) {
+          const double nu = std::sqrt(n2 > 0 ? n2 : 0.0);
+          bn = best * nu;
           mon.beta[j + 1] = bn;
+          normalised = true;
+          if (std::fabs(n2 - 1.0) > 1e-12 && nu > 0) DNM_TRY(vk_scale(p, n_local, 1.0 / nu, 0, st));
+        } else {
+          bn = std::sqrt(n2 > 0 ? n2 : 0.0);
+          if (fused) mon.beta[j + 1] = bn;
+          if (reorth || (!fused && mon.update(j, alpha[j], bn))) {
+            std::vector<zc> g, c(j + 1);
+            DNM_TRY(ops.mdot(V, j + 1, p, g));
+            for (int i = 0; i <= j; ++i) c[i] = -g[i];
+            DNM_TRY(ops.maxpy(p, V, j + 1, c));
+            DNM_TRY(ops.norm(p, &bn));
+            mon.beta[j + 1] = bn;
+          }
         }
       }
       betav[j] = bn;
@@ -717,7 +736,7 @@ int dnm_eigsolve(dnm_mat *A, int64_t n_local, int nev, int which, double tol, in
           mon.beta[j + 1] = 0.0;
           for (int k = 0; k <= j; ++k) mon.wcur[k] = mon.eps1;
         }
-      } else {
+      } else if (!normalised) {
         DNM_TRY(vk_scale(p, n_local, 1.0 / bn, 0, st));
       }
     }

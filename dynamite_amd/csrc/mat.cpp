@@ -758,9 +758,9 @@ int dnm_mat_mult_local(dnm_mat *A, const void *x, void *y, void *stream) {
                               A->have_diag ? (const double *)A->diag.p : nullptr, x, y, S(stream));
 }
 
-// y = A x - b z and <x, y> = sum conj(x_i) y_i (z may be null).  When the plan is tiled, the first pass starts its
-// accumulators from -b z instead of zero and the last pass -- if it stages x in LDS -- accumulates the dot product
-// (per-workgroup partials, summed by a second tiny kernel); otherwise separate sweeps do the same.
+// y = A x - b z, <x, y> = sum conj(x_i) y_i and |y|^2 (z may be null).  When the plan is tiled, the first pass
+// starts its accumulators from -b z instead of zero and the last pass -- if it stages x in LDS -- accumulates the
+// sums (per-workgroup partials, summed by a second tiny kernel); otherwise one fused sweep does the same.
 int dnm_mat_mult_lanczos(dnm_mat *A, const void *x, void *y, const void *z, double b, double *dot, void *stream) {
   DNM_CHECK(A && x && y && dot, "null argument");
   DNM_CHECK(A->remote_passes.empty(), "operator couples different ranks: no fused Lanczos step");
@@ -768,13 +768,12 @@ int dnm_mat_mult_lanczos(dnm_mat *A, const void *x, void *y, const void *z, doub
   const bool tiled = A->hypercube && A->plan.use_tiled && !A->local_passes.empty() && !A->host_only;
   if (!tiled) {
     DNM_TRY(dnm_mat_mult_local(A, x, y, stream));
-    if (z) DNM_TRY(vk_axpby(y, z, A->m_local, -b, 0.0, 1.0, 0.0, S(stream)));
-    return vec_mdot_host(x, A->m_local, 1, y, A->m_local, dot, S(stream));
+    return vec_lanczos_dot_host(y, z, x, A->m_local, b, dot, S(stream));
   }
   const bool fused_dot = A->local_passes.back()->desc.need_tile != 0;
   const size_t nblk = (size_t)1 << (A->local_passes.back()->n_eff - A->local_passes.back()->desc.tile_bits);
   double *part = nullptr;
-  if (fused_dot) DNM_TRY(vec_scratch((nblk + 1) * 2 * sizeof(double), &part));
+  if (fused_dot) DNM_TRY(vec_scratch((nblk + 1) * 3 * sizeof(double), &part));
   for (size_t i = 0; i < A->local_passes.size(); ++i) {
     DevPass d = A->local_passes[i]->desc;
     if (i == 0 && z) {
@@ -786,15 +785,20 @@ int dnm_mat_mult_lanczos(dnm_mat *A, const void *x, void *y, const void *z, doub
     DNM_TRY(launch_tile_pass(d, d.tile_bits, d.log_rows, use_glds(A), A->local_passes[i]->n_eff, x, y,
                              nullptr, S(stream)));
   }
-  if (!fused_dot) return vec_mdot_host(x, A->m_local, 1, y, A->m_local, dot, S(stream));
-  DNM_TRY(vk_reduce_partials(part, (int)nblk, 2, part + 2 * nblk, S(stream)));
-  DNM_HIP(hipMemcpyAsync(dot, part + 2 * nblk, 2 * sizeof(double), hipMemcpyDeviceToHost, S(stream)));
+  if (!fused_dot) return vec_lanczos_dot_host(y, nullptr, x, A->m_local, 0.0, dot, S(stream));
+  DNM_TRY(vk_reduce_partials(part, (int)nblk, 3, part + 3 * nblk, S(stream)));
+  DNM_HIP(hipMemcpyAsync(dot, part + 3 * nblk, 3 * sizeof(double), hipMemcpyDeviceToHost, S(stream)));
   DNM_HIP(hipStreamSynchronize(S(stream)));
   return 0;
 }
 
 int dnm_mat_mult_dot(dnm_mat *A, const void *x, void *y, double *dot, void *stream) {
-  return dnm_mat_mult_lanczos(A, x, y, nullptr, 0.0, dot, stream);
+  DNM_CHECK(dot, "null argument");
+  double d3[3];
+  DNM_TRY(dnm_mat_mult_lanczos(A, x, y, nullptr, 0.0, d3, stream));
+  dot[0] = d3[0];
+  dot[1] = d3[1];
+  return 0;
 }
 
 int dnm_mat_mult(dnm_mat *A, const void *x, void *y, void *stream) {

@@ -328,9 +328,9 @@ tile_pass_kernel(const DevPass P, const c128 *__restrict__ x, c128 *__restrict__
     for (int k = 0; k < R; ++k) y[rows[k]] = make_double2(ar[k], ai[k]);
   }
 
-  // ---- fused <x, y> (Lanczos alpha): the rows' own x values are still in the tile
+  // ---- fused <x, y> (Lanczos alpha) and |y|^2: the rows' own x values are still in the tile
   if (P.dot_out) {
-    double dr = 0.0, di = 0.0;
+    double dr = 0.0, di = 0.0, dn = 0.0;
 #pragma unroll
     for (int k = 0; k < R; ++k) {
       const c128 xs = tile[tid + k * NT];
@@ -338,26 +338,32 @@ tile_pass_kernel(const DevPass P, const c128 *__restrict__ x, c128 *__restrict__
       dr = fma(xs.y, ai[k], dr);
       di = fma(xs.x, ai[k], di);
       di = fma(-xs.y, ar[k], di);
+      dn = fma(ar[k], ar[k], dn);
+      dn = fma(ai[k], ai[k], dn);
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
       dr += __shfl_xor(dr, off, 64);
       di += __shfl_xor(di, off, 64);
+      dn += __shfl_xor(dn, off, 64);
     }
-    __shared__ double dred[2 * (NT / 64 > 0 ? NT / 64 : 1)];
+    __shared__ double dred[3 * (NT / 64 > 0 ? NT / 64 : 1)];
     if ((tid & 63u) == 0) {
-      dred[2 * (tid >> 6)] = dr;
-      dred[2 * (tid >> 6) + 1] = di;
+      dred[3 * (tid >> 6)] = dr;
+      dred[3 * (tid >> 6) + 1] = di;
+      dred[3 * (tid >> 6) + 2] = dn;
     }
     __syncthreads();
     if (tid == 0) {
-      double sr = 0.0, si = 0.0;
+      double sr = 0.0, si = 0.0, sn = 0.0;
       for (uint32_t w = 0; w < NT / 64; ++w) {
-        sr += dred[2 * w];
-        si += dred[2 * w + 1];
+        sr += dred[3 * w];
+        si += dred[3 * w + 1];
+        sn += dred[3 * w + 2];
       }
-      P.dot_out[2 * (size_t)blockIdx.x] = sr;
-      P.dot_out[2 * (size_t)blockIdx.x + 1] = si;
+      P.dot_out[3 * (size_t)blockIdx.x] = sr;
+      P.dot_out[3 * (size_t)blockIdx.x + 1] = si;
+      P.dot_out[3 * (size_t)blockIdx.x + 2] = sn;
     }
   }
 }

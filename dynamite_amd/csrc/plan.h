@@ -103,7 +103,7 @@ struct DevPass {
   int32_t nquads;
   int32_t n_eff;        // index bits this pass runs over (n_loc, or n_loc - 1 for a half-block partner pass)
   const DevQuad *quads;
-  double *dot_out;      // non-null (last pass, tile staged): per-workgroup partial sums of conj(x_row) y_row
+  double *dot_out;      // non-null (last pass, tile staged): per-workgroup partial sums of conj(x_row) y_row (re, im) and |y_row|^2
   const void *zinit;    // non-null (first, non-accumulating pass): y starts from -zscale * zinit (Lanczos: the
   double zscale;        //   beta term of the three-term recurrence rides on the multiply)
   int32_t tile_bits;    // B and LOGR of the kernel instance this pass runs on (passes of one plan may differ)

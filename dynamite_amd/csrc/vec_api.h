@@ -15,7 +15,11 @@ int vec_mdot_host(const void *V, int64_t ldv, int nv, const void *w, int64_t n, 
                   hipStream_t st);
 
 // p -= a v + b u in one sweep; *norm2_host = |p|^2 afterwards (local part); synchronises the stream
+// p = scale * (p - (are + i aim) v - b u); *norm2_host = |p|^2 of the result (this rank's part)
 int vec_lanczos_update_host(void *p, const void *v, const void *u, int64_t n, double are, double aim, double b,
-                            double *norm2_host, hipStream_t st);
+                            double *norm2_host, hipStream_t st, double scale = 1.0);
+// y -= b z (z may be null); out3_host = { Re <x,y>, Im <x,y>, |y|^2 } (this rank's part)
+int vec_lanczos_dot_host(void *y, const void *z, const void *x, int64_t n, double b, double *out3_host,
+                         hipStream_t st);
 
 }  // namespace dnm

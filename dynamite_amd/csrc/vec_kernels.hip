@@ -326,7 +326,7 @@ int vk_basis_update(void *V, int64_t ldv, int nin, int nout, int64_t n, const do
 // (one sweep instead of multi-axpy + norm; u may be null)
 __global__ void __launch_bounds__(VNT)
 lanczos_update_kernel(c128 *p, const c128 *__restrict__ v, const c128 *__restrict__ u, int64_t n, double are,
-                      double aim, double b, double *__restrict__ partials) {
+                      double aim, double b, double scale, double *__restrict__ partials) {
   double s = 0.0;
   for (int64_t i = (int64_t)blockIdx.x * VNT + threadIdx.x; i < n; i += (int64_t)gridDim.x * VNT) {
     c128 acc = ld_stream(p + i);
@@ -340,6 +340,8 @@ lanczos_update_kernel(c128 *p, const c128 *__restrict__ v, const c128 *__restric
       acc.x = fma(-b, uv.x, acc.x);
       acc.y = fma(-b, uv.y, acc.y);
     }
+    acc.x *= scale;
+    acc.y *= scale;
     st_stream(p + i, acc);
     s = fma(acc.x, acc.x, s);
     s = fma(acc.y, acc.y, s);
@@ -357,12 +359,66 @@ lanczos_update_kernel(c128 *p, const c128 *__restrict__ v, const c128 *__restric
 
 // partials_dev: [nblocks] scratch followed by [1] result; nblocks = vk_mdot_blocks(n)
 int vk_lanczos_update(void *p, const void *v, const void *u, int64_t n, double are, double aim, double b,
-                      double *partials_dev, hipStream_t st) {
+                      double scale, double *partials_dev, hipStream_t st) {
   const unsigned nb = vgrid(n, 4);
   hipLaunchKernelGGL(lanczos_update_kernel, dim3(nb), dim3(VNT), 0, st, (c128 *)p, (const c128 *)v,
-                     (const c128 *)u, n, are, aim, b, partials_dev);
+                     (const c128 *)u, n, are, aim, b, scale, partials_dev);
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(VNT), 0, st, partials_dev, (int)nb, 1,
                      partials_dev + nb);
+  DNM_HIP(hipGetLastError());
+  return 0;
+}
+
+// y -= b z (z may be null: y untouched) with the partial sums of conj(x) y (re, im) and |y|^2 of the result
+__global__ void __launch_bounds__(VNT)
+lanczos_dot_kernel(c128 *y, const c128 *__restrict__ z, const c128 *__restrict__ x, int64_t n, double b,
+                   double *__restrict__ partials) {
+  double dr = 0.0, di = 0.0, dn = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * VNT + threadIdx.x; i < n; i += (int64_t)gridDim.x * VNT) {
+    c128 acc = ld_stream(y + i);
+    if (z) {
+      const c128 zv = ld_stream(z + i);
+      acc.x = fma(-b, zv.x, acc.x);
+      acc.y = fma(-b, zv.y, acc.y);
+      st_stream(y + i, acc);
+    }
+    const c128 xv = ld_stream(x + i);
+    dr = fma(xv.x, acc.x, dr);
+    dr = fma(xv.y, acc.y, dr);
+    di = fma(xv.x, acc.y, di);
+    di = fma(-xv.y, acc.x, di);
+    dn = fma(acc.x, acc.x, dn);
+    dn = fma(acc.y, acc.y, dn);
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    dr += __shfl_xor(dr, off, 64);
+    di += __shfl_xor(di, off, 64);
+    dn += __shfl_xor(dn, off, 64);
+  }
+  __shared__ double red[3 * (VNT / 64)];
+  if ((threadIdx.x & 63) == 0) {
+    red[3 * (threadIdx.x >> 6)] = dr;
+    red[3 * (threadIdx.x >> 6) + 1] = di;
+    red[3 * (threadIdx.x >> 6) + 2] = dn;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double tr = 0.0, ti = 0.0, tn = 0.0;
+    for (int wv = 0; wv < VNT / 64; ++wv) { tr += red[3 * wv]; ti += red[3 * wv + 1]; tn += red[3 * wv + 2]; }
+    partials[3 * (int64_t)blockIdx.x] = tr;
+    partials[3 * (int64_t)blockIdx.x + 1] = ti;
+    partials[3 * (int64_t)blockIdx.x + 2] = tn;
+  }
+}
+
+// partials_dev: [3 * nblocks] scratch followed by [3] results; nblocks = vk_mdot_blocks(n)
+int vk_lanczos_dot(void *y, const void *z, const void *x, int64_t n, double b, double *partials_dev,
+                   hipStream_t st) {
+  const unsigned nb = vgrid(n, 4);
+  hipLaunchKernelGGL(lanczos_dot_kernel, dim3(nb), dim3(VNT), 0, st, (c128 *)y, (const c128 *)z, (const c128 *)x, n,
+                     b, partials_dev);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(3), dim3(VNT), 0, st, partials_dev, (int)nb, 3,
+                     partials_dev + 3 * (int64_t)nb);
   DNM_HIP(hipGetLastError());
   return 0;
 }

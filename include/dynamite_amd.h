@@ -181,10 +181,11 @@ int dnm_mat_exchange_plan(const dnm_mat *A, int *nsend, dnm_xfer *sends /* may b
 /* y = A x and dot[0] + i dot[1] = sum_i conj(x_i) y_i in the same sweep (the Lanczos
  * alpha = <v, H v>; what SLEPc does with MatMult + VecDot).  Single rank only. */
 int dnm_mat_mult_dot(dnm_mat *A, const void *x, void *y, double *dot /* [2], host */, void *stream);
-/* One Lanczos step's multiply: y = A x - b z (z may be NULL) and dot = <x, y>; the
- * beta term starts the accumulators of the first pass, the dot product closes the last. */
+/* One Lanczos step's multiply: y = A x - b z (z may be NULL), dot[0] + i dot[1] = <x, y> and
+ * dot[2] = |y|^2 (beta^2 = |y|^2 - |alpha|^2 without another sweep); the beta term starts the
+ * accumulators of the first pass, the sums close the last. */
 int dnm_mat_mult_lanczos(dnm_mat *A, const void *x, void *y, const void *z, double b,
-                         double *dot /* [2], host */, void *stream);
+                         double *dot /* [3], host */, void *stream);
 /* y = (masks that stay on this rank) x_local; y overwritten */
 int dnm_mat_mult_local(dnm_mat *A, const void *x_local, void *y, void *stream);
 /* y += (masks served by receive `recv_index`) x_recv, where x_recv holds the

@@ -560,9 +560,15 @@ def test_mult_dot_fused(monkeypatch, name, L, sub):
     # the whole Lanczos multiply: y = Hx - b z, <x, y>
     z = rand_state(s.get_dimension(), seed=9)
     zv, y3 = vec_from(z), backend.Vec(mat.M)
-    _lib.check(_lib.lib().dnm_mat_mult_lanczos(mat.handle, xv.ptr, y3.ptr, zv.ptr, 0.37, d, None))
+    d3 = (C.c_double * 3)()
+    _lib.check(_lib.lib().dnm_mat_mult_lanczos(mat.handle, xv.ptr, y3.ptr, zv.ptr, 0.37, d3, None))
     want = y1.local_numpy() - 0.37 * z
     assert np.max(np.abs(y3.local_numpy() - want)) <= 4e-16 * max(1.0, np.abs(want).max())
     ref = np.vdot(x, want)
-    assert abs(complex(d[0], d[1]) - ref) <= 1e-13 * max(1.0, abs(ref)) * np.sqrt(x.size)
+    assert abs(complex(d3[0], d3[1]) - ref) <= 1e-13 * max(1.0, abs(ref)) * np.sqrt(x.size)
+    assert abs(d3[2] - np.vdot(want, want).real) <= 1e-13 * np.vdot(want, want).real      # |y|^2 rides along
+    _lib.check(_lib.lib().dnm_mat_mult_lanczos(mat.handle, xv.ptr, y3.ptr, None, 0.0, d3, None))
+    assert np.array_equal(y1.local_numpy(), y3.local_numpy())
+    nn = np.vdot(y1.local_numpy(), y1.local_numpy()).real
+    assert abs(d3[2] - nn) <= 1e-13 * nn and abs(complex(d3[0], d3[1]) - np.vdot(x, y1.local_numpy())) <= 1e-12 * nn
     mat.destroy()

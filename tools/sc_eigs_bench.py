@@ -17,14 +17,16 @@ def main():
     H = models.heisenberg(L)
     sub = SpinConserve(L, L // 2)
     H.add_subspace(sub)
-    t0 = time.perf_counter()
-    ev = H.eigsolve(nev=1, tol=tol, subspace=sub)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    st = eigsolve.last_stats
-    print("SpinConserve(%d,%d) dim=%d eigsolve nev=1 tol=%g: %.2f s, %d restarts, %d matvecs, E0=%.10f (E0/L=%.6f), "
-          "measured relative residual %.1e" % (L, L // 2, sub.get_dimension(), tol, dt, st['its'], st['matvecs'], ev[0],
-                                               ev[0] / L, st['max_rel_residual']), flush=True)
+    reps = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+    for rep in range(reps):
+      t0 = time.perf_counter()
+      ev = H.eigsolve(nev=1, tol=tol, subspace=sub)
+      torch.cuda.synchronize()
+      dt = time.perf_counter() - t0
+      st = eigsolve.last_stats
+      print("SpinConserve(%d,%d) dim=%d eigsolve nev=1 tol=%g: %.2f s, %d restarts, %d matvecs, E0=%.10f (E0/L=%.6f), "
+            "measured relative residual %.1e" % (L, L // 2, sub.get_dimension(), tol, dt, st['its'], st['matvecs'], ev[0],
+                                                 ev[0] / L, st['max_rel_residual']), flush=True)
 
 
 if __name__ == "__main__":
