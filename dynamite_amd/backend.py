@@ -64,18 +64,14 @@ def exchange_window(x_local, owned, windows, me, window_buf=None):
     """Assemble this rank's column window from the owners' blocks with
     torch.distributed send/recv (RCCL over xGMI on GPUs, gloo in CPU tests)."""
     import torch
-    import torch.distributed as dist
+    from . import _comm
     wlo, whi = windows[me][0], windows[me][1] + 1
     if window_buf is None or window_buf.numel() != whi - wlo:
         window_buf = torch.empty(whi - wlo, dtype=x_local.dtype, device=x_local.device)
     my0, myn = owned[me]
     recvs, sends = window_exchange_ops(owned, windows, me)
-    ops = []
-    for q, lo, hi in sends:
-        ops.append(dist.P2POp(dist.isend, x_local[lo - my0:hi - my0], q))
-    for q, lo, hi in recvs:
-        ops.append(dist.P2POp(dist.irecv, window_buf[lo - wlo:hi - wlo], q))
-    reqs = dist.batch_isend_irecv(ops) if ops else []
+    reqs = _comm.batch_p2p([(x_local[lo - my0:hi - my0], q) for q, lo, hi in sends],
+                           [(window_buf[lo - wlo:hi - wlo], q) for q, lo, hi in recvs])
     a, b = max(wlo, my0), min(whi, my0 + myn)
     window_buf[a - wlo:b - wlo].copy_(x_local[a - my0:b - my0])
     for r in reqs:
@@ -114,10 +110,9 @@ def post_exchange(x_local, sends, recvs, recv_bufs):
     """Post every send/receive of one multiply as one batch (RCCL send/recv on a
     GPU, gloo on CPU).  Between a pair of ranks the sends of one side are listed in
     the order of the other side's receives, so in-order matching pairs them up."""
-    import torch.distributed as dist
-    ops = [dist.P2POp(dist.isend, x_local[off:off + cnt], p) for p, off, cnt in sends]
-    ops += [dist.P2POp(dist.irecv, buf, p) for (p, _, _), buf in zip(recvs, recv_bufs)]
-    return dist.batch_isend_irecv(ops) if ops else []
+    from . import _comm
+    return _comm.batch_p2p([(x_local[off:off + cnt], p) for p, off, cnt in sends],
+                           [(buf, p) for (p, _, _), buf in zip(recvs, recv_bufs)])
 
 
 class Vec:
@@ -216,18 +211,16 @@ class Vec:
         if d is None:
             return self.local_numpy()
         import torch
+        from . import _comm
         ws = config.world_size
         sizes = [split_ownership(self.size, ws, q)[1] for q in range(ws)]
         if len(set(sizes)) == 1:
-            parts = [torch.empty_like(self.array) for _ in range(ws)]
-            d.all_gather(parts, self.array)
+            parts = _comm.all_gather(self.array)
         else:   # uneven blocks: pad to the largest
             mx = max(sizes)
             pad = torch.zeros(mx, dtype=self.array.dtype, device=self.array.device)
             pad[:self.local_size] = self.array
-            got = [torch.empty_like(pad) for _ in range(ws)]
-            d.all_gather(got, pad)
-            parts = [g[:n] for g, n in zip(got, sizes)]
+            parts = [g[:n] for g, n in zip(_comm.all_gather(pad), sizes)]
         if not to_all and config.rank != 0:
             return None
         return torch.cat(parts).cpu().numpy()
@@ -449,14 +442,15 @@ def reduced_density_matrix(vec, subspace, keep):
     if d is not None and d.get_world_size() > 1:
         blk = rdm_block_subspace(subspace, config.rank, config.world_size, keep)
         if blk is not None:
+            from . import _comm
             rho = rdm_partial(x, blk, keep)
-            d.reduce(rho, dst=0)
+            _comm.reduce_sum(rho, dst=0)
             if config.rank != 0:
                 return np.array([[-1]], dtype=np.complex128)
             return rho.cpu().numpy().reshape(K, K)
-        parts = [torch.empty(split_ownership(vec.size, config.world_size, q)[1], dtype=x.dtype, device=x.device)
-                 for q in range(config.world_size)] if config.rank == 0 else None
-        d.gather(x, parts, dst=0)
+        from . import _comm
+        parts = _comm.gather_varied(x, [split_ownership(vec.size, config.world_size, q)[1]
+                                        for q in range(config.world_size)], dst=0)
         if config.rank != 0:
             return np.array([[-1]], dtype=np.complex128)
         x = torch.cat(parts)

@@ -1,0 +1,122 @@
+"""
+End-to-end runs of the partitioned path with several ranks on ONE GPU.
+
+RCCL refuses two ranks on one device, so these process groups use the gloo backend; dynamite_amd/_comm.py then
+stages the exchanged blocks through host memory.  Everything else is the production path: every rank builds
+its plan, runs the rank-local and partner passes of the HIP kernels on its block, the Krylov solvers reduce
+their scalars through the hooks, SpinConserve ranks assemble their column windows.  Results are compared on
+rank 0 with the oracle / scipy on the gathered vectors.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, case, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_RANK=str(rank), RANK=str(rank),
+                      WORLD_SIZE=str(world), DNM_TILE_BITS="8", DNM_LOG_ROWS="2", DNM_PLAN_MODE="2", DNM_GBITS="3",
+                      DNM_AMIN="3")
+    if case == "sc":
+        os.environ["DNM_SC_BLOCK"] = "10"
+    import faulthandler
+    faulthandler.dump_traceback_later(int(os.environ.get("DNM_TEST_HANG_S", "90")), exit=True)   # a stuck rank reports where
+    import datetime
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    import scipy.sparse.linalg as spla
+    from dynamite_amd import config, models
+    from dynamite_amd.states import State
+    from dynamite_amd.subspaces import Full, Parity, SpinConserve
+    from dynamite_amd.computations import reduced_density_matrix, entanglement_entropy
+    from oracle import oracle as orc
+    from gpu_util import orc_msc, orc_sub
+
+    L = 14
+    config.L = L
+    config._initialize()
+    if case == "full":
+        sub, H = Full(L=L), models.mbl(L)
+    elif case == "parity":
+        sub, H = Parity('even', L=L), models.mbl(L)
+    else:
+        sub, H = SpinConserve(L, L // 2), models.mbl(L)
+    H.add_subspace(sub)
+    dim = sub.get_dimension()
+
+    x = State(subspace=sub, state='random', seed=3)
+    start, end = x.vec.getOwnershipRange()
+    from dynamite_amd.backend import split_ownership
+    assert (start, end - start) == split_ownership(dim, world, rank)
+    xg = x.to_numpy(to_all=True)
+    assert xg.shape == (dim,) and abs(np.linalg.norm(xg) - 1) < 1e-12
+    assert abs(x.norm() - 1) < 1e-12
+
+    # multiply
+    y = H.dot(x)
+    yg = y.to_numpy(to_all=True)
+    ref = orc.matvec(orc_msc(H), orc_sub(sub), orc_sub(sub), xg, nthreads=2)
+    assert np.max(np.abs(yg - ref)) < 1e-12, "partitioned multiply"
+    assert abs(x.dot(y) - np.vdot(xg, yg)) < 1e-12           # <x|y> as Vec.dot (conjugates x)
+    assert abs(H.infinity_norm(subspaces=(sub, sub)) - orc.infnorm(orc_msc(H), orc_sub(sub), orc_sub(sub))) < 1e-12
+    # gather to rank 0 only
+    y0 = y.to_numpy()
+    assert (y0 is None) == (rank != 0)
+
+    # Krylov solvers through the hooks
+    Hs = H.to_numpy(subspaces=(sub, sub), sparse=True)
+    z = H.evolve(x, t=0.6)
+    zg = z.to_numpy(to_all=True)
+    want = spla.expm_multiply(-0.6j * Hs, xg)
+    assert np.max(np.abs(zg - want)) < 1e-8, "partitioned evolve"
+    evals, evecs = H.eigsolve(nev=2, getvecs=True, tol=1e-10, subspace=sub)
+    lowest = np.sort(spla.eigsh(Hs, k=2, which='SA', tol=1e-12, return_eigenvectors=False))
+    assert np.max(np.abs(np.array(evals[:2]) - lowest)) < 1e-8, "partitioned eigsolve"
+    v0 = evecs[0].to_numpy(to_all=True)
+    assert np.linalg.norm(Hs @ v0 - evals[0] * v0) < 1e-7
+
+    # reduced density matrix / entropy of the partitioned state
+    for keep in ([0, 1, 2], [L - 3, L - 2], [1, 5, L - 1]):
+        rho = reduced_density_matrix(z, keep)
+        if rank == 0:
+            want_rho = orc.rdm(orc_sub(sub), zg, np.array(keep, dtype=np.int64))
+            assert np.max(np.abs(rho - want_rho)) < 1e-12, "partitioned RDM"
+        else:
+            assert rho.shape == (1, 1)
+    s = entanglement_entropy(z, list(range(L // 2)))
+    if rank == 0:
+        assert s > 0
+
+    # files written by all ranks, read back
+    fn = os.path.join(out_dir, "state_" + case)
+    z.save(fn)
+    z2 = State.from_file(fn)
+    assert np.array_equal(z2.to_numpy(to_all=True), zg)
+
+    dist.barrier()
+    faulthandler.cancel_dump_traceback_later()
+    if rank == 0:
+        open(os.path.join(out_dir, "ok_%s_%d" % (case, world)), "w").write("ok")
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case,world", [("full", 2), ("full", 4), ("parity", 2), ("sc", 2), ("sc", 3)])
+def test_partitioned_end_to_end_one_gpu(tmp_path, case, world):
+    import torch.multiprocessing as mp
+    mp.spawn(_worker, args=(world, _free_port(), case, str(tmp_path)), nprocs=world, join=True)
+    assert os.path.exists(os.path.join(str(tmp_path), "ok_%s_%d" % (case, world)))
