@@ -71,9 +71,16 @@ def main():
         sys.exit(2)
     if world > 1:
         import torch.distributed as dist
-        local = int(os.environ.get("LOCAL_RANK", "0"))
+        # rank % device count, as the reference picks its GPU (bcuda_template_2.cu:64-67)
+        local = int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count())
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        # DNM_BENCH_BACKEND=gloo: dry run of the multi-rank flow with several ranks on one GPU (blocks staged
+        # through the host; RCCL refuses two ranks on one device) -- a plumbing check, not a measurement
+        backend_name = os.environ.get("DNM_BENCH_BACKEND", "nccl")
+        if backend_name == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend_name)
     from dynamite_amd import models, backend, _lib
     from dynamite_amd.config import config
     from dynamite_amd.subspaces import Full
