@@ -290,6 +290,29 @@ class ShellMat:
         for i in range(len(self.recvs)):
             _lib.check(L.dnm_mat_mult_remote(self.handle, i, C.c_void_p(bufs[i].data_ptr()), y.ptr, _stream()))
 
+    def prepare_exchange(self, like):
+        """Allocate the receive buffers / column window of the partitioned multiply now (they are
+        otherwise created by the first ``mult``), so that a solver sizing its Krylov basis to the
+        free device memory sees what is really left.  ``like``: a local vector (dtype / device)."""
+        if self.nranks == 1:
+            return
+        import torch
+        if not self.partners and self._is_windowed():
+            if self._windows is None:
+                import torch.distributed as dist
+                mine = self.column_window()
+                allw = [None] * self.nranks
+                dist.all_gather_object(allw, mine)
+                self._windows = allw
+                self._owned = [split_ownership(self.N, self.nranks, q) for q in range(self.nranks)]
+            lo, hi = self._windows[self.rank]
+            if self._window_buf is None or self._window_buf.numel() != hi - lo + 1:
+                self._window_buf = torch.empty(hi - lo + 1, dtype=like.dtype, device=like.device)
+            return
+        for i, (p, off, cnt) in enumerate(self.recvs):
+            if i not in self._recv:
+                self._recv[i] = torch.empty(cnt, dtype=like.dtype, device=like.device)
+
     def uses_cached_diagonal(self):
         """True for the kernels that read a cached diagonal: the SpinConserve kernel (also
         partitioned) and the generic row-gather kernel on one rank."""

@@ -103,6 +103,7 @@ def evolve(H, state, t, result=None, tol=None, ncv=None, algo=None, max_its=None
     hooks = _hooks(mat, keep)
     stats = _lib.SolverStats()
     import torch
+    mat.prepare_exchange(state.vec.array)
     free, _ = torch.cuda.mem_get_info()
     if free < 34 * 16 * mat.n_local:      # the default basis would not fit: hand torch's cached blocks back first
         torch.cuda.empty_cache()
@@ -157,6 +158,7 @@ def eigsolve(H, getvecs=False, nev=1, which='lowest', target=None, tol=None, sub
     hooks = _hooks(mat, keep)
     import torch
     vec_bytes = 16 * mat.n_local
+    mat.prepare_exchange(torch.empty(0, dtype=torch.complex128, device=config.device))
     # all converged pairs are returned (computations.py:259-281) -- but not at the price of a second basis:
     # large vectors are limited to the nev requested
     nev_max = max(nev, int(ncv) if ncv else max(2 * nev, nev + 15))
