@@ -61,6 +61,8 @@ struct ScBlock {
   int32_t lb;              // low bits per block
   int32_t swizzle;         // XCD-aware block order (needs h_first % 512 == 0)
   int64_t h_first, h_last; // high parts covered by the launch
+  const uint32_t *perm;    // optional block order: workgroup b owns high part h_first + perm[b] (0xffffffff: none)
+  int64_t nperm;
 };
 bool sc_block_supported(int lb);
 int sc_block_max_masks();

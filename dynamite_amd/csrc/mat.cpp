@@ -507,11 +507,13 @@ static int setup_sc_block(dnm_mat *A) {
   if (lb == 0) return 0;
   const bool forced = lb > 0;
   if (!forced) lb = 13;
-  if (!sc_block_supported(lb) || L <= lb || L - lb > 48 || (int64_t)A->masks.size() > sc_block_max_masks()) {
+  if ((int64_t)A->masks.size() > sc_block_max_masks()) return 0;     // one lane per mask in the block kernel
+  if (!sc_block_supported(lb) || L <= lb || L - lb > 48) {
     DNM_CHECK(!forced, "DNM_SC_BLOCK=%d not usable for L=%d, k=%d", lb, L, k);
     return 0;
   }
   if (!forced && (A->M >> (L - lb)) < 256) return 0;     // blocks too small on average: one row per thread instead
+  if (!forced && 2 * A->sc_nfast < (int)A->masks.size()) return 0;   // mostly non-chain masks: they take the per-row path anyway
   std::vector<uint16_t> tab((size_t)1 << lb);
   int cnt[18] = {0};
   for (int v = 0; v < (1 << lb); ++v) ++cnt[__builtin_popcount(v) + 1];
@@ -531,6 +533,55 @@ static int setup_sc_block(dnm_mat *A) {
   A->scblock.h_first = hf;
   A->scblock.h_last = hl;
   A->scblock.lb = lb;
+  A->scblock.perm = nullptr;
+  A->scblock.nperm = 0;
+  // Block order (DNM_SC_ORDER=g, 0 = ascending H): blocks of equal size run together -- ordered by the popcount
+  // of H, then by the bits of H above the lowest g -- so that the workgroups resident at one time do equal work
+  // and stay in step, and the blocks an XCD holds are siblings under the g-1 lowest high bonds; groups go
+  // round-robin to the XCDs.  Measured on MI355X, L=32 k=16: 17.6 ms ascending, 15.3 (g=1), 14.4 (g=6), 15.9 (g=8).
+  int g = (hl - hf + 1 >= 1024) ? 6 : 0;
+  if (const char *e = getenv("DNM_SC_ORDER")) g = atoi(e);
+  if (g > 0 && hl - hf + 1 < ((int64_t)1 << 31)) {
+    const int64_t span = hl - hf + 1;
+    const bool by_size = getenv("DNM_SC_ORDER_SIZE") && atoi(getenv("DNM_SC_ORDER_SIZE")) != 0;
+    std::vector<uint32_t> ord;
+    ord.reserve((size_t)span);
+    for (int64_t e = 0; e < span; ++e) {
+      const int kl = k - __builtin_popcountll((uint64_t)(hf + e));
+      if (kl >= 0 && kl <= lb) ord.push_back((uint32_t)e);
+    }
+    std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) {
+      const uint64_t ha = (uint64_t)(hf + a), hb = (uint64_t)(hf + b);
+      const int pa = __builtin_popcountll(ha), pb = __builtin_popcountll(hb);
+      if (pa != pb) {
+        if (!by_size) return pa < pb;
+        const int64_t sa = h.nchoosek[(size_t)(k - pa) * h.ld + lb], sb = h.nchoosek[(size_t)(k - pb) * h.ld + lb];
+        return sa != sb ? sa > sb : pa < pb;          // largest blocks first
+      }
+      if ((ha >> g) != (hb >> g)) return (ha >> g) < (hb >> g);
+      return ha < hb;
+    });
+    std::vector<std::vector<uint32_t>> lists(8);
+    size_t i = 0;
+    int64_t q = 0;
+    while (i < ord.size()) {
+      size_t j = i;
+      const uint64_t h0 = (uint64_t)(hf + ord[i]);
+      while (j < ord.size() && ((uint64_t)(hf + ord[j]) >> g) == (h0 >> g) &&
+             __builtin_popcountll((uint64_t)(hf + ord[j])) == __builtin_popcountll(h0)) ++j;
+      auto &dst = lists[(size_t)(q++ & 7)];
+      dst.insert(dst.end(), ord.begin() + i, ord.begin() + j);
+      i = j;
+    }
+    size_t longest = 0;
+    for (auto &l : lists) longest = std::max(longest, l.size());
+    std::vector<uint32_t> perm(longest * 8, 0xffffffffu);
+    for (size_t x = 0; x < 8; ++x)
+      for (size_t t = 0; t < lists[x].size(); ++t) perm[t * 8 + x] = lists[x][t];
+    DNM_TRY(A->d_scperm.upload(perm.data(), perm.size() * sizeof(uint32_t)));
+    A->scblock.perm = (const uint32_t *)A->d_scperm.p;
+    A->scblock.nperm = (int64_t)perm.size();
+  }
   return 0;
 }
 
@@ -639,6 +690,8 @@ int dnm_mat_create(int64_t nmasks, const int64_t *masks, const int64_t *mask_off
         (imag ? e.dn_im : e.dn_re) += dn;
       }
     }
+    A->sc_nfast = 0;
+    for (const ScMask &e : scm) A->sc_nfast += e.fast ? 1 : 0;
     DNM_TRY(A->d_scmasks.upload(scm.data(), scm.size() * sizeof(ScMask)));
     // 16-bit patterns grouped by popcount, ascending inside a group (colex order = numeric order)
     std::vector<uint16_t> low(65536);

@@ -71,7 +71,9 @@ struct dnm_mat {
   dnm::DevBuf d_sclow;            // SpinConserve kernel: 16-bit unranking table
   dnm::ScLow sclow{};
   dnm::DevBuf d_scblock;          // block kernel: lb-bit patterns grouped by popcount
+  dnm::DevBuf d_scperm;           // block kernel: optional block order
   dnm::ScBlock scblock{};         // lb == 0: block kernel not used
+  int sc_nfast = 0;               // masks that are chain bonds with local signs
   dnm::DevBuf d_scmasks;          // SpinConserve kernel: per-mask precomputation (ScMask[nmasks])
 
   dnm::DevBuf diag;              // cached diagonal (double[m_local]) if precomputed

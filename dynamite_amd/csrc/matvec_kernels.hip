@@ -718,7 +718,11 @@ sc_block_kernel(const DevMsc msc, const ScMask *__restrict__ scm, const ScBlock 
   int64_t hrel;
   {
     const uint32_t b = blockIdx.x;
-    if (blk.swizzle) {
+    if (blk.perm) {
+      const uint32_t e = blk.perm[b];
+      if (e == 0xffffffffu) return;
+      hrel = e;
+    } else if (blk.swizzle) {
       const uint32_t seq = b >> 3, xcd = b & 7u;
       hrel = ((int64_t)(seq >> 6) << 9) | (xcd << 6) | (seq & 63u);
     } else {
@@ -949,7 +953,7 @@ int launch_sc_block(const DevMsc &msc, const ScMask *scm, const ScBlock &blk, co
   DNM_CHECK(msc.nmasks <= SCB_MAXM, "too many masks for the block kernel");
   const int64_t span = blk.h_last - blk.h_first + 1;
   DNM_CHECK(span > 0 && span < (int64_t)1 << 31, "block range out of range");
-  const dim3 grid((unsigned)(blk.swizzle ? ((span + 511) & ~(int64_t)511) : span));
+  const dim3 grid((unsigned)(blk.perm ? blk.nperm : blk.swizzle ? ((span + 511) & ~(int64_t)511) : span));
 #define DNM_SCB(LB_, NT_)                                                                                      \
   hipLaunchKernelGGL((sc_block_kernel<LB_, NT_>), grid, dim3(NT_), 0, st, msc, scm, blk, sub, M, row0,           \
                      win_start, win_len, diag, (const c128 *)xw, (c128 *)y)

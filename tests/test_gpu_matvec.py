@@ -181,14 +181,16 @@ def test_spinconserve_kernel_general_masks():
         assert np.max(np.abs(y - ref)) <= tol_for(arrs, x)
 
 
+@pytest.mark.parametrize("order", [0, 3])
 @pytest.mark.parametrize("lb,L,k", [(10, 12, 6), (10, 16, 7), (10, 17, 3), (10, 18, 14), (13, 20, 10), (13, 20, 9),
                                     (13, 22, 11)])
-def test_spinconserve_block_kernel(monkeypatch, lb, L, k):
+def test_spinconserve_block_kernel(monkeypatch, lb, L, k, order):
     """Block form of the SpinConserve kernel (one workgroup per high part): chain bonds inside the low
     part (LDS), inside the high part (block runs), the bond across the boundary and long-range /
     four-spin masks (per-row path), with and without the cached diagonal, against the oracle."""
     from dynamite_amd.operators import sigmax, sigmay, sigmaz, op_sum
     monkeypatch.setenv("DNM_SC_BLOCK", str(lb))
+    monkeypatch.setenv("DNM_SC_ORDER", str(order))      # ascending high parts / equal-size groups
     rs = np.random.RandomState(L * 31 + k)
     hop = lambda i, j: sigmax(i) * sigmax(j) + sigmay(i) * sigmay(j)
     Hs = [models.mbl(L)]
@@ -217,6 +219,7 @@ def test_spinconserve_block_kernel(monkeypatch, lb, L, k):
 def test_spinconserve_block_kernel_windows(monkeypatch, P):
     """The block kernel on a partition: blocks cut by the ownership boundaries, x given as a column window."""
     monkeypatch.setenv("DNM_SC_BLOCK", "10")
+    monkeypatch.setenv("DNM_SC_ORDER", str(P % 2 * 2))   # both block orders
     L, k = 17, 8
     H = models.mbl(L)
     arrs = marshal(H)
