@@ -333,6 +333,27 @@ def test_xparity_golden_gpu(golden_xp, monkeypatch):
         H.destroy_mat()
 
 
+@pytest.mark.parametrize("sector", [+1, -1])
+def test_xparity_spinconserve_block_kernel(monkeypatch, sector):
+    """XParity(SpinConserve): the reduced operator (complemented many-spin masks next to the chain bonds) through
+    the block form of the SpinConserve kernel, the row kernel and the host-built sparse matrix."""
+    L = 16
+    sub = XParity(SpinConserve(L, L // 2), sector=sector)
+    outs = []
+    for blk in ("10", "0"):
+        monkeypatch.setenv("DNM_SC_BLOCK", blk)
+        H = models.heisenberg(L)
+        H.add_subspace(sub)
+        x = State(subspace=sub, state='random', seed=4)
+        assert ("block form" in H.get_mat().describe()) == (blk == "10")
+        outs.append(H.dot(x).to_numpy())
+        if blk == "10":
+            want = H.to_numpy().toarray() @ x.to_numpy()
+        H.destroy_mat()
+    assert np.max(np.abs(outs[0] - outs[1])) < 1e-13
+    assert np.max(np.abs(outs[0] - want)) < 1e-12
+
+
 @pytest.mark.parametrize("parent", ["full", "sc", "parity"])
 @pytest.mark.parametrize("sector", [+1, -1])
 def test_xparity_convert_state(parent, sector):
