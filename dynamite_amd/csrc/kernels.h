@@ -66,9 +66,12 @@ struct ScBlock {
 };
 bool sc_block_supported(int lb);
 int sc_block_max_masks();
+// zinit != null: y = A x - zscale * zinit (local vector); dot_out != null: per-workgroup partial sums of
+// conj(x_row) y_row (re, im) and |y_row|^2 -- 3 * sc_block_grid(blk) doubles, zeroed by the launch
+int64_t sc_block_grid(const ScBlock &blk);
 int launch_sc_block(const DevMsc &msc, const ScMask *scm, const ScBlock &blk, const SubView &sub, int64_t M, int64_t row0,
                     int64_t win_start, int64_t win_len, const double *diag, const void *xw, void *y,
-                    hipStream_t st);
+                    hipStream_t st, const void *zinit = nullptr, double zscale = 0.0, double *dot_out = nullptr);
 
 // diag[row] = sum over mask-0 terms (bcuda_template_1.cu:29-66)
 int launch_diag(const DevMsc &msc, const SubView &sub, int64_t M, int64_t row0, double *diag, hipStream_t st);

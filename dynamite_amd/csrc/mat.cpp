@@ -819,6 +819,19 @@ int dnm_mat_mult_lanczos(dnm_mat *A, const void *x, void *y, const void *z, doub
   DNM_CHECK(A->remote_passes.empty(), "operator couples different ranks: no fused Lanczos step");
   DNM_CHECK(z != y && x != y, "y must not alias x or z");
   const bool tiled = A->hypercube && A->plan.use_tiled && !A->local_passes.empty() && !A->host_only;
+  if (!tiled && A->sc_pair && A->scblock.lb && A->nranks == 1 && !A->host_only) {
+    // SpinConserve block kernel: the beta term starts the accumulators, the sums are taken while the block of x
+    // is still in LDS
+    const size_t nwg = (size_t)sc_block_grid(A->scblock);
+    double *part = nullptr;
+    DNM_TRY(vec_scratch((nwg + 1) * 3 * sizeof(double), &part));
+    DNM_TRY(launch_sc_block(A->dmsc, (const ScMask *)A->d_scmasks.p, A->scblock, A->right.dev, A->m_local, A->row0, 0,
+                            A->N, A->have_diag ? (const double *)A->diag.p : nullptr, x, y, S(stream), z, b, part));
+    DNM_TRY(vk_reduce_partials(part, (int)nwg, 3, part + 3 * nwg, S(stream)));
+    DNM_HIP(hipMemcpyAsync(dot, part + 3 * nwg, 3 * sizeof(double), hipMemcpyDeviceToHost, S(stream)));
+    DNM_HIP(hipStreamSynchronize(S(stream)));
+    return 0;
+  }
   if (!tiled) {
     DNM_TRY(dnm_mat_mult_local(A, x, y, stream));
     return vec_lanczos_dot_host(y, z, x, A->m_local, b, dot, S(stream));

@@ -701,7 +701,8 @@ template <int LB, int NT>
 __global__ void __launch_bounds__(NT, 4)
 sc_block_kernel(const DevMsc msc, const ScMask *__restrict__ scm, const ScBlock blk, const SubView sub_g, int64_t M,
                 int64_t row0, int64_t win_start, int64_t win_len, const double *__restrict__ diag,
-                const c128 *__restrict__ xw, c128 *__restrict__ y) {
+                const c128 *__restrict__ xw, c128 *__restrict__ y, const c128 *__restrict__ zinit, double zscale,
+                double *__restrict__ dot_out) {
   constexpr int MAXROWS = sc_binom(LB, LB / 2);
   constexpr int RPT = (MAXROWS + NT - 1) / NT;
   __shared__ c128 xs[MAXROWS];
@@ -825,6 +826,11 @@ sc_block_kernel(const DevMsc msc, const ScMask *__restrict__ scm, const ScBlock 
         accr[i] = dg * xv[i].x;
         acci[i] = dg * xv[i].y;
       }
+      if (zinit && ((live >> i) & 1u)) {       // Lanczos: y = A x - b z, the beta term starts the accumulators
+        const c128 zv = zinit[base + r - row0];
+        accr[i] = fma(-zscale, zv.x, accr[i]);
+        acci[i] = fma(-zscale, zv.y, acci[i]);
+      }
     }
   }
 
@@ -942,21 +948,65 @@ sc_block_kernel(const DevMsc msc, const ScMask *__restrict__ scm, const ScBlock 
     const int r = threadIdx.x + i * NT;
     if ((live >> i) & 1u) store_streaming(y + (base + r - row0), accr[i], acci[i]);
   }
+  // fused <x, y> and |y|^2 of this block's rows (the block of x is still in LDS); the slot of a workgroup that
+  // returned early keeps the zero the host put there
+  if (dot_out) {
+    double dr = 0.0, di = 0.0, dn = 0.0;
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+      const int r = threadIdx.x + i * NT;
+      if ((live >> i) & 1u) {
+        const c128 xo = xs[r];
+        dr = fma(xo.x, accr[i], dr);
+        dr = fma(xo.y, acci[i], dr);
+        di = fma(xo.x, acci[i], di);
+        di = fma(-xo.y, accr[i], di);
+        dn = fma(accr[i], accr[i], dn);
+        dn = fma(acci[i], acci[i], dn);
+      }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+      dr += __shfl_xor(dr, off, 64);
+      di += __shfl_xor(di, off, 64);
+      dn += __shfl_xor(dn, off, 64);
+    }
+    __syncthreads();                       // every wavefront is done with xs
+    double *red = (double *)xs;            // reuse the tile for the cross-wave sum
+    if (lane == 0) {
+      red[3 * (threadIdx.x >> 6)] = dr;
+      red[3 * (threadIdx.x >> 6) + 1] = di;
+      red[3 * (threadIdx.x >> 6) + 2] = dn;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double sr = 0.0, si = 0.0, sn = 0.0;
+      for (int w = 0; w < NT / 64; ++w) { sr += red[3 * w]; si += red[3 * w + 1]; sn += red[3 * w + 2]; }
+      dot_out[3 * (size_t)blockIdx.x] = sr;
+      dot_out[3 * (size_t)blockIdx.x + 1] = si;
+      dot_out[3 * (size_t)blockIdx.x + 2] = sn;
+    }
+  }
 }
 
 bool sc_block_supported(int lb) { return lb == 10 || lb == 13; }
 int sc_block_max_masks() { return SCB_MAXM; }
 
+int64_t sc_block_grid(const ScBlock &blk) {
+  const int64_t span = blk.h_last - blk.h_first + 1;
+  return blk.perm ? blk.nperm : blk.swizzle ? ((span + 511) & ~(int64_t)511) : span;
+}
+
 int launch_sc_block(const DevMsc &msc, const ScMask *scm, const ScBlock &blk, const SubView &sub, int64_t M, int64_t row0,
                     int64_t win_start, int64_t win_len, const double *diag, const void *xw, void *y,
-                    hipStream_t st) {
+                    hipStream_t st, const void *zinit, double zscale, double *dot_out) {
   DNM_CHECK(msc.nmasks <= SCB_MAXM, "too many masks for the block kernel");
   const int64_t span = blk.h_last - blk.h_first + 1;
   DNM_CHECK(span > 0 && span < (int64_t)1 << 31, "block range out of range");
-  const dim3 grid((unsigned)(blk.perm ? blk.nperm : blk.swizzle ? ((span + 511) & ~(int64_t)511) : span));
+  const dim3 grid((unsigned)sc_block_grid(blk));
+  if (dot_out) DNM_HIP(hipMemsetAsync(dot_out, 0, (size_t)grid.x * 3 * sizeof(double), st));
 #define DNM_SCB(LB_, NT_)                                                                                      \
   hipLaunchKernelGGL((sc_block_kernel<LB_, NT_>), grid, dim3(NT_), 0, st, msc, scm, blk, sub, M, row0,           \
-                     win_start, win_len, diag, (const c128 *)xw, (c128 *)y)
+                     win_start, win_len, diag, (const c128 *)xw, (c128 *)y, (const c128 *)zinit, zscale, dot_out)
   switch (blk.lb) {
     case 10: DNM_SCB(10, 64); break;
     case 13: DNM_SCB(13, 512); break;

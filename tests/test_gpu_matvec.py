@@ -542,15 +542,23 @@ def test_error_behaviour():
 
 
 @pytest.mark.parametrize("name,L,sub", [("mbl", 16, "full"), ("long_range", 12, "full"), ("ising", 14, "parity"),
-                                        ("mbl", 6, "full"), ("heisenberg", 12, "sc")])
+                                        ("mbl", 6, "full"), ("heisenberg", 12, "sc"), ("mbl", 15, "scblock"),
+                                        ("heisenberg", 13, "scblock")])
 def test_mult_dot_fused(monkeypatch, name, L, sub):
     """dnm_mat_mult_dot: y identical to dnm_mat_mult, <x, y> equal to the separate dot product
     (fused into the last tiled pass when x is staged there; separate sweep otherwise)."""
     import ctypes as C
     cfg(monkeypatch, B=8, logR=2, mode=2, amin=3, gbits=3)
     H = models.BY_NAME[name](L)
-    s = {"full": Full(L=L), "parity": Parity('even', L=L), "sc": SpinConserve(L, L // 2)}[sub]
+    if sub == "scblock":        # the block form of the SpinConserve kernel takes the sums while x is in LDS
+        monkeypatch.setenv("DNM_SC_BLOCK", "10")
+        monkeypatch.setenv("DNM_SC_ORDER", "2")
+    s = {"full": Full(L=L), "parity": Parity('even', L=L), "sc": SpinConserve(L, L // 2),
+         "scblock": SpinConserve(L, L // 2)}[sub]
     mat = shell(H, s)
+    if sub == "scblock":
+        assert "block form" in mat.describe()
+        mat.precompute_diagonal()
     x = rand_state(s.get_dimension(), seed=8)
     xv, y1, y2 = vec_from(x), backend.Vec(mat.M), backend.Vec(mat.M)
     mat.mult(xv, y1)
