@@ -587,7 +587,24 @@ sc_matvec_kernel(const DevMsc msc, const ScMask *__restrict__ scm, const ScLow l
     const uint64_t mask = (uint64_t)msc.masks[m];
     const uint64_t bra = ket ^ mask;
     int64_t delta = 0;
-    if (mask) {
+    if (mask && (mask & (mask + 1)) == 0) {
+      // the mask flips every spin below c (XParity's complemented terms): among the c-bit patterns with the same
+      // number of ones the complement reverses the order, so with hc the rank contribution of the ones at or
+      // above c:  row = hc + r,  col = hc + C(c, n1) - 1 - r
+      if (__popcll(bra) != kk) continue;
+      const int c = 64 - __clzll((long long)mask);
+      const int n1 = __popcll(ket & mask);
+      int64_t hc = 0;
+      uint64_t hb = ket >> c;
+      int o = n1;
+      while (hb) {
+        const int p = c + __ffsll((long long)hb) - 1;
+        ++o;
+        hc += SC_TAB(o * ld + p);
+        hb &= hb - 1;
+      }
+      delta = SC_TAB(n1 * ld + c) - 1 - 2 * (row - hc);
+    } else if (mask) {
       if (__popcll(bra) != kk) continue;             // leaves the subspace: projection semantics
       const int lo = __ffsll((long long)mask) - 1;    // wave-uniform
       const int hi = 63 - __clzll((long long)mask);
@@ -908,7 +925,22 @@ sc_block_kernel(const DevMsc msc, const ScMask *__restrict__ scm, const ScBlock 
       const uint64_t ket = (H << LB) | lowb[i];
       const uint64_t bra = ket ^ mask;
       int64_t delta = 0;
-      if (mask) {
+      if (mask && (mask & (mask + 1)) == 0) {
+        // every spin below c flipped: the order among the low patterns is reversed (see sc_matvec_kernel)
+        if (__popcll(bra) != kk) continue;
+        const int c = 64 - __clzll((long long)mask);
+        const int n1 = __popcll(ket & mask);
+        int64_t hc = 0;
+        uint64_t hb2 = ket >> c;
+        int o = n1;
+        while (hb2) {
+          const int p = c + __ffsll((long long)hb2) - 1;
+          ++o;
+          hc += gtab[o * ld + p];
+          hb2 &= hb2 - 1;
+        }
+        delta = gtab[n1 * ld + c] - 1 - 2 * (base + r - hc);
+      } else if (mask) {
         if (__popcll(bra) != kk) continue;             // leaves the subspace: projection semantics
         const int mlo_ = __ffsll((long long)mask) - 1;
         const int mhi = 63 - __clzll((long long)mask);
