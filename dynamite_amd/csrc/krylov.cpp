@@ -668,6 +668,10 @@ int dnm_eigsolve(dnm_mat *A, int64_t n_local, int nev, int which, double tol, in
   // Krylov-Schur does); default: partial re-orthogonalisation driven by the omega-recurrence
   const char *oenv = getenv("DNM_EIGS_ORTHO");
   const bool use_pro = !(oenv && oenv[0] == 'f');
+  // DNM_EIGS_BETA=sweep: beta from a norm sweep after the update (never the fused form); =rescale: always run the
+  // corrective rescaling sweep -- both only to exercise the rarely taken branches in tests
+  const char *benv = getenv("DNM_EIGS_BETA");
+  const int beta_mode = !benv ? 0 : (benv[0] == 's' ? 1 : (benv[0] == 'r' ? 2 : 0));
   RestartMonitor mon;
   mon.init(m, (double)Nglob, tol);
   std::vector<double> row_l;
@@ -696,7 +700,7 @@ int dnm_eigsolve(dnm_mat *A, int64_t n_local, int nev, int which, double tol, in
         // then writes q_{j+1} = (p - alpha q_j) / beta directly; its own sum of squares (1 up to the cancellation
         // in the difference) corrects beta and, if it is off, the vector
         const double b2 = pn2 - std::norm(d0);
-        const bool fused = b2 > 1e-4 * pn2 && pn2 > 0;
+        const bool fused = b2 > 1e-4 * pn2 && pn2 > 0 && beta_mode != 1;
         const double best = fused ? std::sqrt(b2) : 0.0;
         const bool reorth = fused ? mon.update(j, alpha[j], best) : false;
         double n2 = 0;
@@ -708,7 +712,8 @@ int dnm_eigsolve(dnm_mat *A, int64_t n_local, int nev, int which, double tol, in
           bn = best * nu;
           mon.beta[j + 1] = bn;
           normalised = true;
-          if (std::fabs(n2 - 1.0) > 1e-12 && nu > 0) DNM_TRY(vk_scale(p, n_local, 1.0 / nu, 0, st));
+          if ((std::fabs(n2 - 1.0) > 1e-12 || beta_mode == 2) && nu > 0)
+            DNM_TRY(vk_scale(p, n_local, 1.0 / nu, 0, st));
         } else {
           bn = std::sqrt(n2 > 0 ? n2 : 0.0);
           if (fused) mon.beta[j + 1] = bn;

@@ -333,6 +333,30 @@ def test_xparity_golden_gpu(golden_xp, monkeypatch):
         H.destroy_mat()
 
 
+@pytest.mark.parametrize("sub", ["full", "sc"])
+def test_eigsolve_beta_branches(monkeypatch, sub):
+    """The three ways a three-term step gets its beta (fused: |p|^2 - |alpha|^2 before the update; norm sweep
+    after it; fused plus the corrective rescaling) must give the same spectrum and residuals."""
+    L = 14
+    s = Full(L=L) if sub == "full" else SpinConserve(L, L // 2)
+    got = []
+    for mode in ("", "sweep", "rescale"):
+        if mode:
+            monkeypatch.setenv("DNM_EIGS_BETA", mode)
+        if sub == "sc":
+            monkeypatch.setenv("DNM_SC_BLOCK", "10")
+        H = models.mbl(L)
+        H.add_subspace(s)
+        evals, evecs = H.eigsolve(nev=3, getvecs=True, tol=1e-11, subspace=s)
+        for e, v in zip(evals[:3], evecs[:3]):
+            r = H.dot(v)
+            r.axpy(-e, v)
+            assert r.norm() < 1e-9
+        got.append(np.array(evals[:3]))
+        H.destroy_mat()
+    assert np.max(np.abs(got[0] - got[1])) < 1e-10 and np.max(np.abs(got[0] - got[2])) < 1e-10
+
+
 @pytest.mark.parametrize("sector", [+1, -1])
 def test_xparity_spinconserve_block_kernel(monkeypatch, sector):
     """XParity(SpinConserve): the reduced operator (complemented many-spin masks next to the chain bonds) through
