@@ -28,8 +28,8 @@ struct DevBuf {
 struct SubOwned {
   SubView host{};
   SubView dev{};
-  std::vector<int64_t> nck, smap, rind, rstates;
-  DevBuf d_nck, d_smap, d_rind, d_rstates;
+  std::vector<int64_t> nck, smap, rind, rstates, bucket;
+  DevBuf d_nck, d_smap, d_rind, d_rstates, d_bucket;
   int init(const dnm_subspace *s, bool want_device);
 };
 

@@ -27,6 +27,10 @@ struct SubView {
   const int64_t *state_map;
   const int64_t *rmap_indices;
   const int64_t *rmap_states;
+  // Explicit: optional bucket table over the sorted rmap_states -- the states with (state >> bucket_shift) == b
+  // are rmap_states[bucket[b] .. bucket[b+1]); the search of S2I starts inside one bucket
+  const int64_t *bucket;
+  int32_t bucket_shift;
 };
 
 #define DNM_HD __host__ __device__ __forceinline__
@@ -110,7 +114,13 @@ struct Sub<DNM_EXPLICIT> {
   static DNM_HD int64_t dim(const SubView &s) { return s.dim; }
   static DNM_HD int64_t i2s(int64_t idx, const SubView &s) { return s.state_map[idx]; }
   static DNM_HD int64_t s2i(int64_t st, const SubView &s) {
+    // binary search in the sorted reverse map (bsubspace_impl.h:306-338), narrowed to the state's bucket first
     int64_t lo = 0, hi = s.dim - 1;
+    if (s.bucket) {
+      const int64_t b = st >> s.bucket_shift;
+      lo = s.bucket[b];
+      hi = s.bucket[b + 1] - 1;
+    }
     while (lo <= hi) {
       int64_t mid = (lo + hi) / 2;
       int64_t v = s.rmap_states[mid];
