@@ -569,7 +569,6 @@ static int setup_sc_block(dnm_mat *A) {
   if (const char *e = getenv("DNM_SC_ORDER")) g = atoi(e);
   if (g > 0 && hl - hf + 1 < ((int64_t)1 << 31)) {
     const int64_t span = hl - hf + 1;
-    const bool by_size = getenv("DNM_SC_ORDER_SIZE") && atoi(getenv("DNM_SC_ORDER_SIZE")) != 0;
     std::vector<uint32_t> ord;
     ord.reserve((size_t)span);
     for (int64_t e = 0; e < span; ++e) {
@@ -579,11 +578,7 @@ static int setup_sc_block(dnm_mat *A) {
     std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) {
       const uint64_t ha = (uint64_t)(hf + a), hb = (uint64_t)(hf + b);
       const int pa = __builtin_popcountll(ha), pb = __builtin_popcountll(hb);
-      if (pa != pb) {
-        if (!by_size) return pa < pb;
-        const int64_t sa = h.nchoosek[(size_t)(k - pa) * h.ld + lb], sb = h.nchoosek[(size_t)(k - pb) * h.ld + lb];
-        return sa != sb ? sa > sb : pa < pb;          // largest blocks first
-      }
+      if (pa != pb) return pa < pb;
       if ((ha >> g) != (hb >> g)) return (ha >> g) < (hb >> g);
       return ha < hb;
     });
