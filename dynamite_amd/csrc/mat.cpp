@@ -534,10 +534,8 @@ static int setup_sc_block(dnm_mat *A) {
   const bool forced = lb > 0;
   if (!forced) lb = 13;
   if ((int64_t)A->masks.size() > sc_block_max_masks()) return 0;     // one lane per mask in the block kernel
-  if (!sc_block_supported(lb) || L <= lb || L - lb > 48) {
-    DNM_CHECK(!forced, "DNM_SC_BLOCK=%d not usable for L=%d, k=%d", lb, L, k);
-    return 0;
-  }
+  DNM_CHECK(sc_block_supported(lb), "DNM_SC_BLOCK=%d: no such kernel instance (0, 10, 13)", lb);
+  if (L <= lb || L - lb > 48) return 0;
   if (!forced && (A->M >> (L - lb)) < 256) return 0;     // blocks too small on average: one row per thread instead
   if (!forced && 2 * A->sc_nfast < (int)A->masks.size()) return 0;   // mostly non-chain masks: they take the per-row path anyway
   std::vector<uint16_t> tab((size_t)1 << lb);
