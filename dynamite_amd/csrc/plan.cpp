@@ -338,13 +338,13 @@ static int make_plan_with(const OpForm &op, int rank, int nranks, const PlanConf
 
 int make_plan(const OpForm &op, int rank, int nranks, const PlanConfig &cfg_in, Plan *out) {
   if (cfg_in.amin >= 0) return make_plan_with(op, rank, nranks, cfg_in, out);
-  // default run length of the window passes: 256 B (amin = 4); at >= 2^30 local amplitudes 1 KB runs (amin = 6)
-  // measured 2.5 % faster with the wide group (the L2 merges part of the window pass's gathers,
-  // profiles/r01_prof_multi16.txt) -- unless they cost a launch
+  // default run length of the window passes: 256 B (amin = 4); at >= 2^29 local amplitudes 1 KB runs (amin = 6)
+  // measured 2.5-4 % faster with the wide group (the L2 merges part of the window pass's gathers,
+  // profiles/r01_prof_multi16.txt; L=29: 10.2 against 10.6 ms, same time at L=28) -- unless they cost a launch
   PlanConfig c4 = cfg_in;
   c4.amin = 4;
   DNM_TRY(make_plan_with(op, rank, nranks, c4, out));
-  if (out->use_tiled && out->n_loc >= 30 && out->cfg.mode == 2) {
+  if (out->use_tiled && out->n_loc >= 29 && out->cfg.mode == 2) {
     PlanConfig c6 = cfg_in;
     c6.amin = 6;
     Plan p6;
