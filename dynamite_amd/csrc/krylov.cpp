@@ -192,6 +192,15 @@ struct Ops {
     if (nn) *nn = buf[2];
     return 0;
   }
+  // y = A x - b z (no inner products)
+  int mult_sub(const void *x, void *y, const void *z, double b) {
+    if (hooks && hooks->mult) {
+      DNM_TRY(mult(x, y));
+      return vk_axpby(y, z, n, -b, 0.0, 1.0, 0.0, st);
+    }
+    ++matvecs;
+    return dnm_mat_mult_sub(A, x, y, z, b, (void *)st);
+  }
   int sum(double *buf, int cnt) {
     if (hooks && hooks->allreduce_sum)
       DNM_CHECK(hooks->allreduce_sum(hooks->ctx, buf, cnt) == 0, "allreduce_sum hook failed");
@@ -441,6 +450,92 @@ int dnm_workspace_bytes(size_t *bytes) {
 int dnm_release_workspace(void) {
   g_basis.release();
   rdm_release_scratch();
+  return 0;
+}
+
+int dnm_expm_chebyshev(dnm_mat *A, const void *x, void *y, int64_t n_local, double t, double tol,
+                       const dnm_hooks *hooks, dnm_solver_stats *stats, void *stream) {
+  DNM_CHECK(A && x && y && stats, "null argument");
+  hipStream_t st = (hipStream_t)stream;
+  Ops ops{A, hooks, st, n_local};
+  stats->reason = 0; stats->its = 0; stats->matvecs = 0; stats->nconv = 0; stats->err_est = 0;
+  if (tol <= 0) tol = 1e-8;
+  if (x != y) DNM_HIP(hipMemcpyAsync(y, x, (size_t)n_local * 16, hipMemcpyDeviceToDevice, st));
+  if (t == 0.0) { stats->reason = DNM_CONVERGED_TOL; return 0; }
+  double r = 0;
+  DNM_TRY(dnm_mat_norm_inf(A, &r, stream));
+  DNM_TRY(ops.maxr(&r, 1));
+  if (hooks && hooks->allreduce_max) dnm_mat_set_norm(A, r);
+  if (r == 0.0) { stats->reason = DNM_CONVERGED_TOL; return 0; }
+
+  // steps of |r t| <= 64: the coefficients J_k(z) die out super-exponentially beyond k = z
+  const double ztot = std::fabs(r * t);
+  const int nsteps = std::max(1, (int)std::ceil(ztot / 64.0));
+  const double z = ztot / nsteps;
+  const double cut = tol / (100.0 * nsteps);
+  std::vector<double> J;
+  {
+    const int kmax = (int)(z + 30.0 * std::cbrt(z + 1.0) + 80.0);
+    J.resize((size_t)kmax + 1);
+    for (int k = 0; k <= kmax; ++k) J[(size_t)k] = std::cyl_bessel_j((double)k, z);
+    double tail = 0;
+    int K = kmax;
+    while (K > 1 && tail + 2.0 * std::fabs(J[(size_t)K]) < cut) { tail += 2.0 * std::fabs(J[(size_t)K]); --K; }
+    DNM_CHECK(K < kmax, "internal: Bessel coefficients have not decayed (z = %g)", z);
+    J.resize((size_t)K + 1);
+    stats->err_est = tail * nsteps;
+  }
+  const int K = (int)J.size() - 1;
+  // a_k = (2 - delta_k0) (-i sgn t)^k J_k(z)
+  const zc mi(0.0, t > 0 ? -1.0 : 1.0);
+  auto coef = [&](int k) {
+    const zc pw = (k & 3) == 0 ? zc(1, 0) : (k & 3) == 1 ? mi : (k & 3) == 2 ? zc(-1, 0) : -mi;
+    return (k == 0 ? 1.0 : 2.0) * J[(size_t)k] * pw;
+  };
+
+  // ring of four vectors U_k = T_k(A/r) x / gamma_k in slot k & 3, gamma_0 = 1, gamma_{k+1} = (2/r) gamma_k:
+  //   T_{k+1} = (2/r) A T_k - T_{k-1}   <=>   U_{k+1} = A U_k - (r/2)^2 U_{k-1}
+  void *W = nullptr;
+  DNM_TRY(basis_workspace((size_t)4 * (size_t)n_local * 16, &W));
+  const double beta = 0.25 * r * r;
+  auto slot = [&](int k) { return (void *)vecptr(W, n_local, k & 3); };
+  for (int step = 0; step < nsteps; ++step) {
+    double gam[4];
+    // U_0 = the state, U_1 = A U_0 / 2 (T_1 = A x / r = (2/r) U_1)
+    DNM_HIP(hipMemcpyAsync(slot(0), y, (size_t)n_local * 16, hipMemcpyDeviceToDevice, st));
+    DNM_TRY(ops.mult(slot(0), slot(1)));
+    DNM_TRY(vk_scale(slot(1), n_local, 0.5, 0.0, st));
+    gam[0] = 1.0;
+    gam[1] = 2.0 / r;
+    {   // y holds U_0 already: y += (a_0 - 1) U_0 + a_1 gamma_1 U_1
+      std::vector<zc> c = {coef(0) - 1.0, coef(1) * gam[1]};
+      DNM_TRY(ops.maxpy(y, slot(0), 2, c));
+    }
+    for (int k = 1; k < K; ++k) {
+      DNM_TRY(ops.mult_sub(slot(k), slot(k + 1), slot(k - 1), beta));
+      gam[(k + 1) & 3] = gam[k & 3] * (2.0 / r);
+      if (gam[(k + 1) & 3] < 1e-200) {
+        // bring the two live vectors back to O(1) by the same factor: the recurrence is unchanged
+        const double f = gam[(k + 1) & 3];
+        DNM_TRY(vk_scale(slot(k + 1), n_local, f, 0.0, st));
+        DNM_TRY(vk_scale(slot(k), n_local, f, 0.0, st));
+        gam[(k + 1) & 3] /= f;
+        gam[k & 3] /= f;
+      }
+      // terms k (even) and k + 1 sit side by side in the ring: one sweep adds both; an even K leaves its last
+      // term alone
+      if ((k + 1) & 1) {
+        std::vector<zc> c = {coef(k) * gam[k & 3], coef(k + 1) * gam[(k + 1) & 3]};
+        DNM_TRY(ops.maxpy(y, slot(k), 2, c));
+      } else if (k + 1 == K) {
+        std::vector<zc> c = {coef(K) * gam[K & 3]};
+        DNM_TRY(ops.maxpy(y, slot(K), 1, c));
+      }
+    }
+  }
+  stats->reason = DNM_CONVERGED_TOL;
+  stats->its = nsteps;
+  stats->matvecs = ops.matvecs;
   return 0;
 }
 

@@ -877,6 +877,33 @@ int dnm_mat_mult_lanczos(dnm_mat *A, const void *x, void *y, const void *z, doub
   return 0;
 }
 
+// y = A x - b z without the sums (Chebyshev recurrences): the beta term rides on the multiply where a kernel
+// can start its accumulators from it, otherwise one more sweep.
+int dnm_mat_mult_sub(dnm_mat *A, const void *x, void *y, const void *z, double b, void *stream) {
+  DNM_CHECK(A && x && y && z, "null argument");
+  DNM_CHECK(A->remote_passes.empty(), "operator couples different ranks: use the partitioned multiply");
+  DNM_CHECK(z != y && x != y, "y must not alias x or z");
+  DNM_CHECK(!A->host_only, "host-only handle cannot multiply");
+  if (A->hypercube && A->plan.use_tiled && !A->local_passes.empty()) {
+    for (size_t i = 0; i < A->local_passes.size(); ++i) {
+      DevPass d = A->local_passes[i]->desc;
+      if (i == 0) {
+        DNM_CHECK(!d.accumulate, "internal: first pass accumulates");
+        d.zinit = z;
+        d.zscale = b;
+      }
+      DNM_TRY(launch_tile_pass(d, d.tile_bits, d.log_rows, use_glds(A), A->local_passes[i]->n_eff, x, y,
+                               nullptr, S(stream)));
+    }
+    return 0;
+  }
+  if (A->sc_pair && A->scblock.lb && A->nranks == 1)
+    return launch_sc_block(A->dmsc, (const ScMask *)A->d_scmasks.p, A->scblock, A->right.dev, A->m_local, A->row0, 0,
+                           A->N, A->have_diag ? (const double *)A->diag.p : nullptr, x, y, S(stream), z, b, nullptr);
+  DNM_TRY(dnm_mat_mult_local(A, x, y, stream));
+  return vk_axpby(y, z, A->m_local, -b, 0.0, 1.0, 0.0, S(stream));
+}
+
 int dnm_mat_mult_dot(dnm_mat *A, const void *x, void *y, double *dot, void *stream) {
   DNM_CHECK(dot, "null argument");
   double d3[3];

@@ -186,6 +186,8 @@ int dnm_mat_mult_dot(dnm_mat *A, const void *x, void *y, double *dot /* [2], hos
  * accumulators of the first pass, the sums close the last. */
 int dnm_mat_mult_lanczos(dnm_mat *A, const void *x, void *y, const void *z, double b,
                          double *dot /* [3], host */, void *stream);
+/* y = A x - b z (three-term recurrences without inner products, e.g. Chebyshev).  Single rank only. */
+int dnm_mat_mult_sub(dnm_mat *A, const void *x, void *y, const void *z, double b, void *stream);
 /* y = (masks that stay on this rank) x_local; y overwritten */
 int dnm_mat_mult_local(dnm_mat *A, const void *x_local, void *y, void *stream);
 /* y += (masks served by receive `recv_index`) x_recv, where x_recv holds the
@@ -279,6 +281,18 @@ int dnm_expm_multiply(dnm_mat *A, const void *x, void *y, int64_t n_local,
                       double scale_re, double scale_im, double tol, int ncv,
                       int max_its, size_t work_limit_bytes, const dnm_hooks *hooks,
                       dnm_solver_stats *stats, void *stream);
+
+/* y = exp(-i t A) x for REAL t by the Chebyshev expansion
+ *   exp(-i t A) = sum_k (2 - delta_k0) (-i)^k J_k(r t) T_k(A / r),   r = ||A||_inf >= spectral radius,
+ * evaluated with the three-term recurrence on the fused multiply y = A x - b z: one multiply and
+ * two thirds of a vector sweep per term, four work vectors, no inner products and no basis --
+ * an alternative to dnm_expm_multiply when the Krylov basis is what limits the size or the speed
+ * (Operator.evolve(algo='chebyshev')).  The series is cut where the remaining Bessel coefficients sum to
+ * less than tol/100 (tol <= 0 -> 1e-8); long times are split into steps of r*t <= 64.  Costs about
+ * r*t + 6 (r*t)^(1/3) + 10 multiplies; loose norm bounds (r much larger than the spectral radius)
+ * cost proportionally more.  stats->its = number of steps, stats->matvecs = multiplies. */
+int dnm_expm_chebyshev(dnm_mat *A, const void *x, void *y, int64_t n_local, double t, double tol,
+                       const dnm_hooks *hooks, dnm_solver_stats *stats, void *stream);
 
 /* The solvers keep their Krylov-basis allocation between calls and the reduced
  * density matrix its tile scratch; this frees them.  (The library keeps such

@@ -130,6 +130,51 @@ def test_evolve_golden(golden_full, name, L, ts):
         _evolve_check(H, x0, t, g[k])
 
 
+@pytest.mark.parametrize("name,L,ts", [("mbl", 12, ["1", "5"]), ("mbl", 10, ["1"]), ("long_range", 8, ["1"]),
+                                       ("syk", 5, ["1"]), ("ising", 10, ["1"])])
+def test_evolve_chebyshev_golden(golden_full, name, L, ts):
+    """algo='chebyshev' (Chebyshev expansion on the fused multiply) against the same golden vectors, element-wise
+    agreement with the Krylov result, long times (several steps), negative times, tight tolerances."""
+    g = golden_full[f"{name}_L{L}"]
+    H = models.BY_NAME[name](L)
+    x0 = State(L=L, state='random', seed=0)
+    for key in ts:
+        t = float(key)
+        ynp = _evolve_check(H, x0, t, g["expm_t=" + key], algo='chebyshev')
+        ref = g["expm_t=" + key]
+        assert np.max(np.abs(ynp - ref)) < 1e-9
+        tight = H.evolve(x0, t=t, algo='chebyshev', tol=1e-13).to_numpy()
+        assert np.max(np.abs(tight - ref)) < 5e-12
+    back = H.evolve(H.evolve(x0, t=40.0, algo='chebyshev'), t=-40.0, algo='chebyshev')     # several steps each way
+    assert np.max(np.abs(back.to_numpy() - x0.to_numpy())) < 1e-8
+    from dynamite_amd.computations import evolve
+    assert evolve.last_stats['its'] >= 1 and evolve.last_stats['matvecs'] > 40
+    with pytest.raises(ValueError):
+        H.evolve(x0, t=1.0 - 0.5j, algo='chebyshev')
+
+
+def test_evolve_chebyshev_subspaces(monkeypatch):
+    """The recurrence on every kernel family: tiled (Full, Parity), SpinConserve row and block kernels, the
+    generic kernel (Explicit) -- against the Krylov result."""
+    L = 14
+    monkeypatch.setenv("DNM_TILE_BITS", "8")
+    monkeypatch.setenv("DNM_LOG_ROWS", "2")
+    sc = SpinConserve(L, L // 2)
+    cases = [("full", Full(L=L), {}), ("parity", Parity('odd', L=L), {}), ("sc", sc, {"DNM_SC_BLOCK": "0"}),
+             ("scblock", sc, {"DNM_SC_BLOCK": "10"}),
+             ("explicit", Explicit(sc.idx_to_state(np.arange(0, sc.get_dimension(), dtype=np.int64)), L=L), {})]
+    for name, sub, env in cases:
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        H = models.heisenberg(L)
+        H.add_subspace(sub)
+        x0 = State(subspace=sub, state='random', seed=2)
+        a = H.evolve(x0, t=2.5).to_numpy()
+        b = H.evolve(x0, t=2.5, algo='chebyshev').to_numpy()
+        assert np.max(np.abs(a - b)) < 1e-9, name
+        H.destroy_mat()
+
+
 def test_evolve_options_and_errors(golden_full):
     g = golden_full["mbl_L12"]
     H = models.mbl(12)
