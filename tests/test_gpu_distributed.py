@@ -84,6 +84,8 @@ def _worker(rank, world, port, case, out_dir):
     zg = z.to_numpy(to_all=True)
     want = spla.expm_multiply(-0.6j * Hs, xg)
     assert np.max(np.abs(zg - want)) < 1e-8, "partitioned evolve"
+    zc = H.evolve(x, t=0.6, algo='chebyshev').to_numpy(to_all=True)
+    assert np.max(np.abs(zc - want)) < 1e-8, "partitioned Chebyshev evolve"
     evals, evecs = H.eigsolve(nev=2, getvecs=True, tol=1e-10, subspace=sub)
     lowest = np.sort(spla.eigsh(Hs, k=2, which='SA', tol=1e-12, return_eigenvectors=False))
     assert np.max(np.abs(np.array(evals[:2]) - lowest)) < 1e-8, "partitioned eigsolve"
