@@ -127,7 +127,9 @@ def evolve(H, state, t, result=None, tol=None, ncv=None, algo=None, max_its=None
     _lib.check(_lib.lib().dnm_expm_multiply(
         mat.handle, state.vec.ptr, result.vec.ptr, mat.n_local, scale.real, scale.imag,
         0.0 if tol is None else float(tol), 0 if ncv is None else int(ncv),
-        0 if max_its is None else int(max_its), int(free * 0.9),
+        # an explicit algo='krylov' / 'expokit' keeps the Krylov scheme to the end (the driver hands the rest of a
+        # real-time interval to the Chebyshev expansion only under all-default parameters)
+        (100 if algo is not None else 0) if max_its is None else int(max_its), int(free * 0.9),
         C.byref(hooks) if hooks is not None else None, C.byref(stats), _stream()))
     evolve.last_stats = {'reason': stats.reason, 'its': stats.its, 'matvecs': stats.matvecs,
                          'err_est': stats.err_est}

@@ -276,7 +276,11 @@ typedef struct dnm_solver_stats {
  * with partial re-orthogonalisation (DNM_EXPM_ORTHO=full: against the whole
  * basis every step, as SLEPc's BV).  tol<=0 -> 1e-8; ncv<=0 -> min(30, N);
  * max_its<=0 -> 100 (SLEPc defaults).  work_limit_bytes bounds the basis
- * allocation (0 = no limit): ncv is reduced to fit. */
+ * allocation (0 = no limit): ncv is reduced to fit.  With ncv <= 0, max_its <= 0
+ * and scale_re == 0 (a real time) the driver compares, after every accepted step,
+ * what the rest of the interval costs at the step size the error control has
+ * settled on with what dnm_expm_chebyshev needs for it (known exactly) and hands
+ * the rest over when that is clearly cheaper (DNM_EXPM_HYBRID=0: never). */
 int dnm_expm_multiply(dnm_mat *A, const void *x, void *y, int64_t n_local,
                       double scale_re, double scale_im, double tol, int ncv,
                       int max_its, size_t work_limit_bytes, const dnm_hooks *hooks,
