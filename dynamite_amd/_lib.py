@@ -66,7 +66,7 @@ class DevPass(C.Structure):
                 ("sign_base", C.c_uint64), ("accumulate", C.c_int32), ("need_tile", C.c_int32),
                 ("has_diag", C.c_int32), ("cache_policy", C.c_int32), ("dext_begin", C.c_uint32), ("dext_end", C.c_uint32),
                 ("dbucket", C.c_uint32 * (MAXR + 1)), ("loop", C.c_uint32 * (LP_COUNT + 1)),
-                ("nquads", C.c_int32), ("n_eff", C.c_int32), ("quads", vp), ("dot_out", vp), ("zinit", vp), ("zscale", C.c_double),
+                ("nquads", C.c_int32), ("n_eff", C.c_int32), ("quads", vp), ("dot_out", vp), ("zinit", vp), ("zscale", C.c_double), ("zinit2", vp), ("z2re", C.c_double), ("z2im", C.c_double),
                 ("tile_bits", C.c_int32), ("log_rows", C.c_int32)]
 
 
@@ -134,6 +134,8 @@ SIGNATURES = {
     "dnm_expm_chebyshev": (C.c_int, [vp, vp, vp, C.c_int64, C.c_double, C.c_double, C.POINTER(Hooks),
                                      C.POINTER(SolverStats), vp]),
     "dnm_mat_mult_sub": (C.c_int, [vp, vp, vp, vp, C.c_double, vp]),
+    "dnm_mat_fuses_init": (C.c_int, [vp]),
+    "dnm_mat_mult_sub2": (C.c_int, [vp, vp, vp, vp, C.c_double, vp, C.c_double, C.c_double, vp]),
     "dnm_expm_multiply": (C.c_int, [vp, vp, vp, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_int,
                                     C.c_int, C.c_size_t, C.POINTER(Hooks), C.POINTER(SolverStats), vp]),
     "dnm_eigsolve": (C.c_int, [vp, C.c_int64, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int,

@@ -71,7 +71,8 @@ int sc_block_max_masks();
 int64_t sc_block_grid(const ScBlock &blk);
 int launch_sc_block(const DevMsc &msc, const ScMask *scm, const ScBlock &blk, const SubView &sub, int64_t M, int64_t row0,
                     int64_t win_start, int64_t win_len, const double *diag, const void *xw, void *y,
-                    hipStream_t st, const void *zinit = nullptr, double zscale = 0.0, double *dot_out = nullptr);
+                    hipStream_t st, const void *zinit = nullptr, double zscale = 0.0, double *dot_out = nullptr,
+                    const void *zinit2 = nullptr, double z2re = 0.0, double z2im = 0.0);
 
 // diag[row] = sum over mask-0 terms (bcuda_template_1.cu:29-66)
 int launch_diag(const DevMsc &msc, const SubView &sub, int64_t M, int64_t row0, double *diag, hipStream_t st);

@@ -201,6 +201,11 @@ struct Ops {
     ++matvecs;
     return dnm_mat_mult_sub(A, x, y, z, b, (void *)st);
   }
+  // y = A x - b z + c z2 (single rank: fused where the kernel allows)
+  int mult_sub2(const void *x, void *y, const void *z, double b, const void *z2, zc c) {
+    ++matvecs;
+    return dnm_mat_mult_sub2(A, x, y, z, b, z2, c.real(), c.imag(), (void *)st);
+  }
   int sum(double *buf, int cnt) {
     if (hooks && hooks->allreduce_sum)
       DNM_CHECK(hooks->allreduce_sum(hooks->ctx, buf, cnt) == 0, "allreduce_sum hook failed");
@@ -503,6 +508,45 @@ static int cheb_core(Ops &ops, void *y, int64_t n_local, double t, double tol, d
     const zc pw = (k & 3) == 0 ? zc(1, 0) : (k & 3) == 1 ? mi : (k & 3) == 2 ? zc(-1, 0) : -mi;
     return (k == 0 ? 1.0 : 2.0) * J[(size_t)k] * pw;
   };
+  if (steps_out) *steps_out = nsteps;
+  if (err_out) *err_out = tail * nsteps;
+
+  const char *cenv = getenv("DNM_CHEB_FORM");
+  const bool clenshaw = !(ops.hooks && ops.hooks->mult) && dnm_mat_fuses_init(ops.A) && !(cenv && cenv[0] == 'f');
+  if (clenshaw) {
+    // Clenshaw's backward recurrence, b_k = a_k x + (2/r) A b_{k+1} - b_{k+2}, result a_0 x + A b_1 / r - b_2:
+    // every term is ONE fused multiply (the a_k x term and the b_{k+2} term start the accumulators), three
+    // work vectors, x is the state itself.  Unnormalised: B_k = b_k / gamma_k, gamma_K = 1, gamma_k = (2/r) gamma_{k+1}:
+    //   B_k = A B_{k+1} - (r/2)^2 B_{k+2} + (a_k / gamma_k) x
+    const double beta2 = 0.25 * r * r;
+    auto sl = [&](int k) { return (void *)vecptr(W, n_local, k % 3); };
+    for (int step = 0; step < nsteps; ++step) {
+      double g[3];
+      const zc aK = coef(K);
+      DNM_TRY(vk_axpby(sl(K), y, n_local, aK.real(), aK.imag(), 0.0, 0.0, st));       // B_K = a_K x
+      g[K % 3] = 1.0;
+      for (int k = K - 1; k >= 1; --k) {
+        const double gk = g[(k + 1) % 3] * (2.0 / r);
+        const zc c = coef(k) / gk;
+        if (k == K - 1) DNM_TRY(ops.mult_sub2(sl(k + 1), sl(k), y, 0.0, y, c));          // b_{K+1} = 0
+        else DNM_TRY(ops.mult_sub2(sl(k + 1), sl(k), sl(k + 2), beta2, y, c));
+        g[k % 3] = gk;
+        if (gk < 1e-200) {      // bring the two live vectors back to O(1) by the same factor
+          DNM_TRY(vk_scale(sl(k), n_local, gk, 0.0, st));
+          DNM_TRY(vk_scale(sl(k + 1), n_local, gk, 0.0, st));
+          g[(k + 1) % 3] /= gk;
+          g[k % 3] = 1.0;
+        }
+      }
+      // result = a_0 x + (gamma_1 / r) [A B_1 - (r^2/2) B_2]  (gamma_2 / gamma_1 = r / 2)
+      const double g1 = g[1 % 3];
+      const zc c0 = coef(0) * (r / g1);
+      if (K >= 2) DNM_TRY(ops.mult_sub2(sl(1), sl(0), sl(2), 0.5 * r * r, y, c0));
+      else DNM_TRY(ops.mult_sub2(sl(1), sl(0), y, 0.0, y, c0));
+      DNM_TRY(vk_axpby(y, sl(0), n_local, g1 / r, 0.0, 0.0, 0.0, st));
+    }
+    return 0;
+  }
   // ring of four vectors U_k = T_k(A/r) x / gamma_k in slot k & 3, gamma_0 = 1, gamma_{k+1} = (2/r) gamma_k:
   //   T_{k+1} = (2/r) A T_k - T_{k-1}   <=>   U_{k+1} = A U_k - (r/2)^2 U_{k-1}
   const double beta = 0.25 * r * r;
@@ -541,8 +585,6 @@ static int cheb_core(Ops &ops, void *y, int64_t n_local, double t, double tol, d
       }
     }
   }
-  if (steps_out) *steps_out = nsteps;
-  if (err_out) *err_out = tail * nsteps;
   return 0;
 }
 
@@ -754,14 +796,14 @@ int dnm_expm_multiply(dnm_mat *A, const void *x, void *y, int64_t n_local, doubl
     s_error += err_loc;
     if (beta == 0.0) break;
     // With the caller's defaults (no ncv / max_its) and a real time, finish by the Chebyshev expansion when the
-    // step size the error control has settled on makes that clearly cheaper: it costs ~1.45 multiply-times per
+    // step size the error control has settled on makes that clearly cheaper: it costs ~1.25 multiply-times per
     // term against ~1.9 per Krylov multiply (measured), and its term count is known exactly.
     if (hybrid && m >= 2 && t_now < t_out) {
       const double t_left = t_out - t_now;
       int64_t terms = 0;
       DNM_TRY(cheb_cost(anorm * t_left, tol, &terms));
       const double kry = 1.9 * (double)m * std::ceil(t_left / t_new);
-      if (1.45 * (double)terms < 0.8 * kry) {
+      if (1.25 * (double)terms < 0.8 * kry) {
         int csteps = 0;
         double cerr = 0;
         DNM_TRY(cheb_core(ops, y, n_local, -dir.imag() * t_left, tol, anorm, V, &csteps, &cerr));

@@ -877,12 +877,20 @@ int dnm_mat_mult_lanczos(dnm_mat *A, const void *x, void *y, const void *z, doub
   return 0;
 }
 
-// y = A x - b z without the sums (Chebyshev recurrences): the beta term rides on the multiply where a kernel
-// can start its accumulators from it, otherwise one more sweep.
-int dnm_mat_mult_sub(dnm_mat *A, const void *x, void *y, const void *z, double b, void *stream) {
+// true when the multiply can start its accumulators from other vectors (dnm_mat_mult_sub2 costs no extra sweep)
+int dnm_mat_fuses_init(const dnm_mat *A) {
+  if (!A || A->host_only || !A->remote_passes.empty()) return 0;
+  if (A->hypercube && A->plan.use_tiled && !A->local_passes.empty()) return 1;
+  return (A->sc_pair && A->scblock.lb && A->nranks == 1) ? 1 : 0;
+}
+
+// y = A x - b z + c z2 without the sums (Chebyshev / Clenshaw recurrences; z2 may be null): the extra terms ride
+// on the multiply where a kernel can start its accumulators from them, otherwise one more sweep each.
+int dnm_mat_mult_sub2(dnm_mat *A, const void *x, void *y, const void *z, double b, const void *z2, double c_re,
+                      double c_im, void *stream) {
   DNM_CHECK(A && x && y && z, "null argument");
   DNM_CHECK(A->remote_passes.empty(), "operator couples different ranks: use the partitioned multiply");
-  DNM_CHECK(z != y && x != y, "y must not alias x or z");
+  DNM_CHECK(z != y && x != y && z2 != y, "y must not alias x, z or z2");
   DNM_CHECK(!A->host_only, "host-only handle cannot multiply");
   if (A->hypercube && A->plan.use_tiled && !A->local_passes.empty()) {
     for (size_t i = 0; i < A->local_passes.size(); ++i) {
@@ -891,6 +899,9 @@ int dnm_mat_mult_sub(dnm_mat *A, const void *x, void *y, const void *z, double b
         DNM_CHECK(!d.accumulate, "internal: first pass accumulates");
         d.zinit = z;
         d.zscale = b;
+        d.zinit2 = z2;
+        d.z2re = c_re;
+        d.z2im = c_im;
       }
       DNM_TRY(launch_tile_pass(d, d.tile_bits, d.log_rows, use_glds(A), A->local_passes[i]->n_eff, x, y,
                                nullptr, S(stream)));
@@ -899,9 +910,16 @@ int dnm_mat_mult_sub(dnm_mat *A, const void *x, void *y, const void *z, double b
   }
   if (A->sc_pair && A->scblock.lb && A->nranks == 1)
     return launch_sc_block(A->dmsc, (const ScMask *)A->d_scmasks.p, A->scblock, A->right.dev, A->m_local, A->row0, 0,
-                           A->N, A->have_diag ? (const double *)A->diag.p : nullptr, x, y, S(stream), z, b, nullptr);
+                           A->N, A->have_diag ? (const double *)A->diag.p : nullptr, x, y, S(stream), z, b, nullptr,
+                           z2, c_re, c_im);
   DNM_TRY(dnm_mat_mult_local(A, x, y, stream));
-  return vk_axpby(y, z, A->m_local, -b, 0.0, 1.0, 0.0, S(stream));
+  DNM_TRY(vk_axpby(y, z, A->m_local, -b, 0.0, 1.0, 0.0, S(stream)));
+  if (z2) DNM_TRY(vk_axpby(y, z2, A->m_local, c_re, c_im, 1.0, 0.0, S(stream)));
+  return 0;
+}
+
+int dnm_mat_mult_sub(dnm_mat *A, const void *x, void *y, const void *z, double b, void *stream) {
+  return dnm_mat_mult_sub2(A, x, y, z, b, nullptr, 0.0, 0.0, stream);
 }
 
 int dnm_mat_mult_dot(dnm_mat *A, const void *x, void *y, double *dot, void *stream) {

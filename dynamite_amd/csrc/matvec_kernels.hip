@@ -225,6 +225,18 @@ tile_pass_kernel(const DevPass P, const c128 *__restrict__ x, c128 *__restrict__
       ar[k] = zs * v.x;
       ai[k] = zs * v.y;
     }
+    if (P.zinit2) {
+      const c128 *__restrict__ z2 = (const c128 *)P.zinit2;
+      const double cr = P.z2re, ci = P.z2im;
+#pragma unroll
+      for (int k = 0; k < R; ++k) {
+        const c128 v = load_streaming(z2 + rows[k]);
+        ar[k] = fma(cr, v.x, ar[k]);
+        ar[k] = fma(-ci, v.y, ar[k]);
+        ai[k] = fma(cr, v.y, ai[k]);
+        ai[k] = fma(ci, v.x, ai[k]);
+      }
+    }
   } else {
 #pragma unroll
     for (int k = 0; k < R; ++k) ar[k] = ai[k] = 0.0;
@@ -719,7 +731,7 @@ __global__ void __launch_bounds__(NT, 4)
 sc_block_kernel(const DevMsc msc, const ScMask *__restrict__ scm, const ScBlock blk, const SubView sub_g, int64_t M,
                 int64_t row0, int64_t win_start, int64_t win_len, const double *__restrict__ diag,
                 const c128 *__restrict__ xw, c128 *__restrict__ y, const c128 *__restrict__ zinit, double zscale,
-                double *__restrict__ dot_out) {
+                double *__restrict__ dot_out, const c128 *__restrict__ zinit2, double z2re, double z2im) {
   constexpr int MAXROWS = sc_binom(LB, LB / 2);
   constexpr int RPT = (MAXROWS + NT - 1) / NT;
   __shared__ c128 xs[MAXROWS];
@@ -847,6 +859,13 @@ sc_block_kernel(const DevMsc msc, const ScMask *__restrict__ scm, const ScBlock 
         const c128 zv = zinit[base + r - row0];
         accr[i] = fma(-zscale, zv.x, accr[i]);
         acci[i] = fma(-zscale, zv.y, acci[i]);
+        if (zinit2) {
+          const c128 z2 = zinit2[base + r - row0];
+          accr[i] = fma(z2re, z2.x, accr[i]);
+          accr[i] = fma(-z2im, z2.y, accr[i]);
+          acci[i] = fma(z2re, z2.y, acci[i]);
+          acci[i] = fma(z2im, z2.x, acci[i]);
+        }
       }
     }
   }
@@ -1030,7 +1049,8 @@ int64_t sc_block_grid(const ScBlock &blk) {
 
 int launch_sc_block(const DevMsc &msc, const ScMask *scm, const ScBlock &blk, const SubView &sub, int64_t M, int64_t row0,
                     int64_t win_start, int64_t win_len, const double *diag, const void *xw, void *y,
-                    hipStream_t st, const void *zinit, double zscale, double *dot_out) {
+                    hipStream_t st, const void *zinit, double zscale, double *dot_out, const void *zinit2,
+                    double z2re, double z2im) {
   DNM_CHECK(msc.nmasks <= SCB_MAXM, "too many masks for the block kernel");
   const int64_t span = blk.h_last - blk.h_first + 1;
   DNM_CHECK(span > 0 && span < (int64_t)1 << 31, "block range out of range");
@@ -1038,7 +1058,8 @@ int launch_sc_block(const DevMsc &msc, const ScMask *scm, const ScBlock &blk, co
   if (dot_out) DNM_HIP(hipMemsetAsync(dot_out, 0, (size_t)grid.x * 3 * sizeof(double), st));
 #define DNM_SCB(LB_, NT_)                                                                                      \
   hipLaunchKernelGGL((sc_block_kernel<LB_, NT_>), grid, dim3(NT_), 0, st, msc, scm, blk, sub, M, row0,           \
-                     win_start, win_len, diag, (const c128 *)xw, (c128 *)y, (const c128 *)zinit, zscale, dot_out)
+                     win_start, win_len, diag, (const c128 *)xw, (c128 *)y, (const c128 *)zinit, zscale, dot_out,      \
+                     (const c128 *)zinit2, z2re, z2im)
   switch (blk.lb) {
     case 10: DNM_SCB(10, 64); break;
     case 13: DNM_SCB(13, 512); break;

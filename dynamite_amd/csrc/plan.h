@@ -106,6 +106,8 @@ struct DevPass {
   double *dot_out;      // non-null (last pass, tile staged): per-workgroup partial sums of conj(x_row) y_row (re, im) and |y_row|^2
   const void *zinit;    // non-null (first, non-accumulating pass): y starts from -zscale * zinit (Lanczos: the
   double zscale;        //   beta term of the three-term recurrence rides on the multiply)
+  const void *zinit2;   // with zinit: a second start vector with a complex factor, y += (z2re + i z2im) * zinit2
+  double z2re, z2im;    //   (Clenshaw's a_k x term)
   int32_t tile_bits;    // B and LOGR of the kernel instance this pass runs on (passes of one plan may differ)
   int32_t log_rows;
 };

@@ -188,6 +188,11 @@ int dnm_mat_mult_lanczos(dnm_mat *A, const void *x, void *y, const void *z, doub
                          double *dot /* [3], host */, void *stream);
 /* y = A x - b z (three-term recurrences without inner products, e.g. Chebyshev).  Single rank only. */
 int dnm_mat_mult_sub(dnm_mat *A, const void *x, void *y, const void *z, double b, void *stream);
+/* 1 if dnm_mat_mult_sub / _sub2 cost no extra vector sweep for this operator (tiled and SpinConserve block kernels) */
+int dnm_mat_fuses_init(const dnm_mat *A);
+/* y = A x - b z + (c_re + i c_im) z2 (Clenshaw's recurrence; z2 may be NULL).  Single rank only. */
+int dnm_mat_mult_sub2(dnm_mat *A, const void *x, void *y, const void *z, double b, const void *z2,
+                      double c_re, double c_im, void *stream);
 /* y = (masks that stay on this rank) x_local; y overwritten */
 int dnm_mat_mult_local(dnm_mat *A, const void *x_local, void *y, void *stream);
 /* y += (masks served by receive `recv_index`) x_recv, where x_recv holds the
