@@ -122,3 +122,25 @@ def test_partitioned_end_to_end_one_gpu(tmp_path, case, world):
     import torch.multiprocessing as mp
     mp.spawn(_worker, args=(world, _free_port(), case, str(tmp_path)), nprocs=world, join=True)
     assert os.path.exists(os.path.join(str(tmp_path), "ok_%s_%d" % (case, world)))
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_bench_multi_rank_flow_one_gpu(world):
+    """bench.py exactly as the driver launches it for N > 1 (torch.distributed.run, one rank per 'GPU'), with the
+    ranks sharing this GPU over gloo (DNM_BENCH_BACKEND): the exchange plan, barriers, max-over-ranks timing and
+    the JSON line -- a plumbing check of the multi-rank flow, not a measurement."""
+    import json
+    import subprocess
+    env = dict(os.environ, DNM_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
+           "--gpus", str(world), "--steps", "2", "--warmup", "1", "--L", "22"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == world and d["steps"] == 2 and d["warmup"] == 1 and d["unit"] == "Gamplitudes/s"
+    assert d["value"] > 0 and d["scaling"] == "weak" and d["config"]["L"] == 22
+    assert d["config"]["launches_per_step"] >= 3          # rank-local passes plus at least one partner pass
+    assert "cpu_baseline" not in d and d["roofline"]["bound"] == "hbm"
