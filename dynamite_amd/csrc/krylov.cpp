@@ -654,6 +654,27 @@ int dnm_expm_multiply(dnm_mat *A, const void *x, void *y, int64_t n_local, doubl
   DNM_TRY(ops.norm(y, &beta));
   if (beta == 0.0 || anorm == 0.0) { stats->reason = DNM_CONVERGED_TOL; return 0; }
 
+  if (hybrid && A->expm_tstep > 0.0) {
+    // an earlier solve with this operator ended in the Chebyshev expansion: if the Krylov step size seen then
+    // still makes the expansion the cheaper one for this interval, skip the Krylov probe
+    int64_t terms = 0;
+    DNM_TRY(cheb_cost(anorm * t_out, tol, &terms));
+    const double kry = 1.9 * (double)A->expm_m * std::ceil(t_out / A->expm_tstep);
+    if (1.25 * (double)terms < 0.8 * kry) {
+      void *W = nullptr;
+      DNM_TRY(basis_workspace((size_t)4 * (size_t)n_local * 16, &W));
+      int csteps = 0;
+      double cerr = 0;
+      DNM_TRY(cheb_core(ops, y, n_local, -dir.imag() * t_out, tol, anorm, W, &csteps, &cerr));
+      DNM_HIP(hipStreamSynchronize(st));
+      stats->reason = DNM_CONVERGED_TOL;
+      stats->its = csteps;
+      stats->matvecs = ops.matvecs;
+      stats->err_est = cerr;
+      return 0;
+    }
+  }
+
   void *V = nullptr;   // v_0..v_m plus one scratch vector
   DNM_TRY(basis_workspace((size_t)(m + 2) * (size_t)n_local * 16, &V));
   void *tmpv = vecptr(V, n_local, m + 1);
@@ -807,6 +828,8 @@ int dnm_expm_multiply(dnm_mat *A, const void *x, void *y, int64_t n_local, doubl
         int csteps = 0;
         double cerr = 0;
         DNM_TRY(cheb_core(ops, y, n_local, -dir.imag() * t_left, tol, anorm, V, &csteps, &cerr));
+        A->expm_tstep = t_new;
+        A->expm_m = m;
         nstep += csteps;
         s_error += cerr;
         break;

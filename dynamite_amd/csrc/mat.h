@@ -74,6 +74,10 @@ struct dnm_mat {
   dnm::DevBuf d_scperm;           // block kernel: optional block order
   dnm::ScBlock scblock{};         // lb == 0: block kernel not used
   int sc_nfast = 0;               // masks that are chain bonds with local signs
+  // evolve: the Krylov step size at which the driver last handed over to the Chebyshev expansion (0: never) and
+  // the basis size it belonged to -- later calls on this operator skip the Krylov probe when the estimate still holds
+  double expm_tstep = 0.0;
+  int expm_m = 0;
   dnm::DevBuf d_scmasks;          // SpinConserve kernel: per-mask precomputation (ScMask[nmasks])
 
   dnm::DevBuf diag;              // cached diagonal (double[m_local]) if precomputed

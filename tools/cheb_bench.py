@@ -30,9 +30,9 @@ for t in ts:
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
             print("  t=%-5g %-10s %s: %.3f s, %d multiplies, %d steps" %
-                  (t, algo or 'krylov', "first" if rep == 0 else "again", dt, evolve.last_stats['matvecs'],
+                  (t, algo or 'default', "first" if rep == 0 else "again", dt, evolve.last_stats['matvecs'],
                    evolve.last_stats['its']), flush=True)
         out[algo] = y
     d = out[None].copy()
     d.axpy(-1.0, out['chebyshev'])
-    print("  t=%-5g |krylov - chebyshev| = %.2e" % (t, d.norm()), flush=True)
+    print("  t=%-5g |default - chebyshev| = %.2e" % (t, d.norm()), flush=True)
