@@ -637,6 +637,13 @@ int dnm_expm_multiply(dnm_mat *A, const void *x, void *y, int64_t n_local, doubl
     if (fit < 2) fit = 2;
     if (m > fit) m = (int)fit;
   }
+  {
+    // a cached workspace of a useful size is reused as it is: growing it by a few vectors means handing back and
+    // re-acquiring the whole slab, which the driver clears at ~30 GB/s (seconds at these sizes) -- more than a
+    // slightly larger basis saves
+    const int64_t have = (int64_t)(g_basis.bytes / ((size_t)n_local * 16));
+    if (ncv <= 0 && have >= 12 && (int64_t)m + 2 > have) m = (int)(have - 2);
+  }
   if (m < 1) m = 1;
 
   const zc scale(scale_re, scale_im);
