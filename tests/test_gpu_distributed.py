@@ -47,9 +47,29 @@ def _worker(rank, world, port, case, out_dir):
     from oracle import oracle as orc
     from gpu_util import orc_msc, orc_sub
 
-    L = 14
+    L = 24 if case == "sc_big" else 14
     config.L = L
     config._initialize()
+    if case == "sc_big":
+        # the default SpinConserve path of BASELINE config 5: 13-bit blocks, equal-size block order, blocks cut by
+        # the ownership boundaries, column windows -- multiply only (2.7 M rows)
+        os.environ.pop("DNM_SC_BLOCK", None)
+        sub, H = SpinConserve(L, L // 2), models.heisenberg(L)
+        H.add_subspace(sub)
+        x = State(subspace=sub, state='random', seed=3)
+        assert "block form (13" in H.get_mat().describe()
+        y = H.dot(x)
+        xg, yg = x.to_numpy(to_all=True), y.to_numpy(to_all=True)
+        ref = orc.matvec(orc_msc(H), orc_sub(sub), orc_sub(sub), xg, nthreads=2)
+        assert np.max(np.abs(yg - ref)) < 1e-12, "partitioned SpinConserve multiply (default block kernel)"
+        z = H.evolve(x, t=0.3, algo='chebyshev')
+        assert abs(z.norm() - 1) < 1e-9 and abs(z.dot(H.dot(z)).imag) < 1e-9
+        dist.barrier()
+        faulthandler.cancel_dump_traceback_later()
+        if rank == 0:
+            open(os.path.join(out_dir, "ok_%s_%d" % (case, world)), "w").write("ok")
+        dist.destroy_process_group()
+        return
     if case == "full":
         sub, H = Full(L=L), models.mbl(L)
     elif case == "parity":
@@ -117,7 +137,8 @@ def _worker(rank, world, port, case, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("case,world", [("full", 2), ("full", 4), ("parity", 2), ("sc", 2), ("sc", 3)])
+@pytest.mark.parametrize("case,world", [("full", 2), ("full", 4), ("parity", 2), ("sc", 2), ("sc", 3),
+                                        ("sc_big", 3)])
 def test_partitioned_end_to_end_one_gpu(tmp_path, case, world):
     import torch.multiprocessing as mp
     mp.spawn(_worker, args=(world, _free_port(), case, str(tmp_path)), nprocs=world, join=True)
