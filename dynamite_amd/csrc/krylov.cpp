@@ -269,6 +269,31 @@ struct Ops {
     }
     return 0;
   }
+  // First vector of a thick-restart cycle, p = A q_l against [u_0..u_{l-1}, q_l]: the components along the kept
+  // Ritz vectors are the spikes s_i of the projected matrix (A u_i = theta_i u_i + s_i q_l), so the first
+  // Gram-Schmidt pass needs no inner products except <q_l, p>; a measured pass follows (the Ritz vectors of a
+  // semi-orthogonal basis are orthonormal to sqrt(eps) only) and its coefficients correct h.
+  int orthogonalize_known(void *p, const void *V, int nv, const std::vector<double> &spike, std::vector<zc> &h,
+                          double *nrm) {
+    std::vector<zc> h1, neg(nv);
+    h.assign(nv, zc(0));
+    const void *ql = (const char *)V + (size_t)(nv - 1) * (size_t)n * 16;
+    DNM_TRY(mdot(ql, 1, p, h1));
+    for (int i = 0; i + 1 < nv; ++i) h[i] = zc(spike[(size_t)i], 0.0);
+    h[nv - 1] = h1[0];
+    for (int i = 0; i < nv; ++i) neg[i] = -h[i];
+    DNM_TRY(maxpy(p, V, nv, neg));
+    for (int pass = 0; pass < 2; ++pass) {
+      DNM_TRY(mdot(V, nv, p, h1));
+      double hn2 = 0.0;
+      for (int j = 0; j < nv; ++j) { neg[j] = -h1[j]; h[j] += h1[j]; hn2 += std::norm(h1[j]); }
+      DNM_TRY(maxpy(p, V, nv, neg));
+      DNM_TRY(norm(p, nrm));
+      const double before = std::sqrt((*nrm) * (*nrm) + hn2);
+      if (*nrm >= 0.7071067811865476 * before) break;
+    }
+    return 0;
+  }
 };
 
 // Simon's omega-recurrence: a running estimate of |v_{j+1}^H v_k| for a Lanczos
@@ -892,6 +917,7 @@ int dnm_eigsolve(dnm_mat *A, int64_t n_local, int nev, int which, double tol, in
   const bool use_pro = !(oenv && oenv[0] == 'f');
   // DNM_EIGS_BETA=sweep: beta from a norm sweep after the update (never the fused form); =rescale: always run the
   // corrective rescaling sweep -- both only to exercise the rarely taken branches in tests
+  const bool known_off = getenv("DNM_EIGS_KNOWN") && getenv("DNM_EIGS_KNOWN")[0] == '0';   // A/B switch
   const char *benv = getenv("DNM_EIGS_BETA");
   const int beta_mode = !benv ? 0 : (benv[0] == 's' ? 1 : (benv[0] == 'r' ? 2 : 0));
   RestartMonitor mon;
@@ -913,7 +939,10 @@ int dnm_eigsolve(dnm_mat *A, int64_t n_local, int nev, int which, double tol, in
       if (!three_term) {
         // the first step of a cycle removes the spike components: whole basis, twice when Ritz vectors are
         // present (they are orthonormal to sqrt(eps) only under partial re-orthogonalisation)
-        DNM_TRY(ops.orthogonalize(p, V, j + 1, h, &bn, (use_pro && l > 0) ? 2 : 1));
+        if (use_pro && l > 0 && j == l && (int)spike.size() == l && !known_off)
+          DNM_TRY(ops.orthogonalize_known(p, V, j + 1, spike, h, &bn));
+        else
+          DNM_TRY(ops.orthogonalize(p, V, j + 1, h, &bn, (use_pro && l > 0) ? 2 : 1));
         alpha[j] = h[j].real();
         if (use_pro) mon.first_step(alpha[j], bn);
       } else {
