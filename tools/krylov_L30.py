@@ -24,9 +24,10 @@ for t in (0.2, 0.2):
     print("L=%d evolve t=%.2f: %.2f s, %d outer steps, %d matvecs (%.1f ms per matvec-equivalent), |y|=%.12f"
           % (L, t, dt, st['its'], st['matvecs'], dt / st['matvecs'] * 1e3, out.norm()), flush=True)
 del out
-torch.cuda.synchronize(); t0 = time.perf_counter()
-ev = H.eigsolve(nev=1, tol=1e-6)
-torch.cuda.synchronize(); dt = time.perf_counter() - t0
-st = eigsolve.last_stats
-print("L=%d eigsolve nev=1 tol=1e-6: %.2f s, %d restarts, %d matvecs, E0=%.8f, measured relative residual %.1e"
-      % (L, dt, st['its'], st['matvecs'], ev[0], st['max_rel_residual']), flush=True)
+for rep in range(2):      # the first solve pays for growing the cached workspace (cleared by the driver at ~30 GB/s)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    ev = H.eigsolve(nev=1, tol=1e-6)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    st = eigsolve.last_stats
+    print("L=%d eigsolve nev=1 tol=1e-6: %.2f s, %d restarts, %d matvecs, E0=%.8f, measured relative residual %.1e"
+          % (L, dt, st['its'], st['matvecs'], ev[0], st['max_rel_residual']), flush=True)
