@@ -11,6 +11,12 @@ amplitudes, 16 GiB per vector; BASELINE.json configs[2]).  N>1: the state is
 row-block partitioned, L = 30 + log2(N) so every GPU keeps 2^30 amplitudes
 (weak scaling); partner blocks travel over RCCL while the rank-local masks
 run.  Prints ONE JSON line on rank 0.
+
+Launch forms: under torch.distributed.run (RANK / WORLD_SIZE in the environment) every process is one
+rank; a bare `python bench.py --gpus N` (N > 1, no WORLD_SIZE) starts its own N rank processes BEFORE
+anything touches the GPU in the parent and forwards rank 0's line.  When fewer than N GPUs are visible the
+ranks share the devices over gloo with host-staged blocks (a plumbing check, flagged "transport": "gloo");
+with no GPU at all (`"dry_run": true`) only the plan, the exchange schedule and the gloo transport run.
 """
 import argparse
 import json
@@ -53,6 +59,116 @@ def cpu_baseline(sample_L=27, reps=3):
                       f"2^11-row blocks over {nt} OpenMP threads"}
 
 
+XGMI_LINK_GBS = 64.0      # assumed sustained one-direction rate of one xGMI link (spec 153 GB/s bidirectional per
+                          # link pair; RCCL send/recv reaches 60-77 GB/s per direction): used for the PREDICTION only
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(n):
+    """Parent of a bare `--gpus N` call: start N rank processes (this interpreter has not touched the GPU:
+    `torch.cuda.device_count()` does not initialise it) and exit with the worst return code."""
+    import subprocess
+    import torch
+    ndev = torch.cuda.device_count()
+    env = dict(os.environ)
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE=str(n),
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    if ndev < n:
+        env["DNM_BENCH_BACKEND"] = "gloo"      # ranks share devices (or there is none): host-staged transport
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    sys.exit(rc)
+
+
+def exchange_estimate(sends, recvs, n_gpus):
+    """Bytes this rank moves over xGMI per multiply and the time the busiest link needs for them."""
+    per_partner = {}
+    for p, _, cnt in recvs:
+        per_partner[p] = per_partner.get(p, 0) + 16 * cnt
+    out_bytes = sum(16 * cnt for _, _, cnt in sends)
+    in_bytes = sum(per_partner.values())
+    worst = max(per_partner.values()) if per_partner else 0
+    return {"xgmi_bytes_per_step": int(in_bytes), "xgmi_bytes_sent_per_step": int(out_bytes),
+            "xgmi_partners": len(per_partner), "xgmi_link_GBs_assumed": XGMI_LINK_GBS,
+            "xgmi_link_bound_ms": worst / (XGMI_LINK_GBS * 1e9) * 1e3}
+
+
+def dry_run(args, world, rank):
+    """No GPU: build every rank's plan on the host, run the exchange schedule over gloo with host tensors and
+    print the line with value = null.  Exercises launch, rendezvous, plan, schedule matching and transport."""
+    import torch
+    import torch.distributed as dist
+    from dynamite_amd import models, backend, msc_tools, _lib
+    from dynamite_amd.subspaces import Full
+    L = args.L or (18 + int(math.log2(world)))
+    H = models.BY_NAME[args.model](L)
+    H.establish_L()
+    H.reduce_msc()
+    masks, offs = msc_tools.get_mask_offsets(H.msc)
+    sub = Full(L=L)
+    lc, rc = sub._c(), sub._c()
+    h = backend.create_mat(masks, offs, H.msc['signs'], H.msc['coeffs'], lc, rc, False, _lib.MAT_HOST_ONLY, rank, world)
+    sends, recvs = backend.exchange_plan(h)
+    nloc = (1 << L) // world
+    x = torch.full((nloc,), complex(rank + 1, 0), dtype=torch.complex128)
+    bufs = [torch.empty(cnt, dtype=x.dtype) for _, _, cnt in recvs]
+    for _ in range(args.warmup):
+        for r in backend.post_exchange(x, sends, recvs, bufs):
+            r.wait()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        for r in backend.post_exchange(x, sends, recvs, bufs):
+            r.wait()
+    dist.barrier()
+    wall = time.perf_counter() - t0
+    ok = all(bool((b == complex(p + 1, 0)).all()) for (p, _, _), b in zip(recvs, bufs))
+    t = torch.tensor([wall, 0.0 if ok else 1.0], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        buf = C_describe(h)
+        est = exchange_estimate(sends, recvs, world)
+        print(json.dumps({
+            "metric": "matrix-free H|psi> Gamplitudes/s, random-field Heisenberg", "value": None,
+            "unit": "Gamplitudes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": float(t[0]) * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64 (complex128)", "data": "synthetic", "dry_run": True,
+            "transport": "gloo", "exchange_ok": bool(t[1] == 0.0),
+            "config": dict({"workload": f"DRY RUN (no GPU): plan + exchange schedule of the L={L} random-field "
+                                        f"Heisenberg chain on {world} ranks, no multiply executed",
+                            "L": L, "plan": buf.strip().replace("\n", " | ")}, **est)}))
+    _lib.check(_lib.lib().dnm_mat_destroy(h))
+    dist.destroy_process_group()
+    sys.exit(0 if t[1] == 0.0 else 1)
+
+
+def plan_signature(mat):
+    """Identifies the executed plan in profiles/latest_pmc.json (the counter run must be of the same plan)."""
+    import hashlib
+    return hashlib.sha256(mat.describe().strip().replace("\n", " | ").encode()).hexdigest()[:16]
+
+
+def C_describe(handle):
+    import ctypes as C
+    from dynamite_amd import _lib
+    buf = C.create_string_buffer(8192)
+    _lib.check(_lib.lib().dnm_mat_plan_describe(handle, buf, len(buf)))
+    return buf.value.decode()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -63,12 +179,15 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args.gpus)          # does not return
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    if args.gpus > 1 and world == 1:
-        print("bench.py: --gpus %d needs torch.distributed.run (one rank per GPU)" % args.gpus, file=sys.stderr)
-        sys.exit(2)
+    if world > 1 and torch.cuda.device_count() == 0:
+        import torch.distributed as dist
+        dist.init_process_group("gloo")
+        dry_run(args, world, rank)      # does not return
     if world > 1:
         import torch.distributed as dist
         # rank % device count, as the reference picks its GPU (bcuda_template_2.cu:64-67)
@@ -143,15 +262,20 @@ def main():
         dim_local = dim // n_gpus
         alg_bytes_launch = ALG_BYTES_PER_AMP * dim_local / launches
         achieved = alg_bytes_launch / (avg_launch_ms * 1e-3) / 1e9
-        traffic = None
+        # HBM traffic needs the PMC counters, i.e. a separate rocprofv3 --pmc run of this same command
+        # (tools/profile_bench.sh): the line carries the committed figure of that run, and says so, when it was
+        # taken for the same size / rank count / plan; otherwise null
+        traffic, traffic_source = None, None
         pmc = os.path.join(ROOT, "profiles", "latest_pmc.json")
         if os.path.exists(pmc):
             try:
                 p = json.load(open(pmc))
-                if p.get("L") == L and p.get("n_gpus") == n_gpus and p.get("plan") == os.environ.get("DNM_PLAN_MODE", "2"):
+                if p.get("L") == L and p.get("n_gpus") == n_gpus and p.get("plan_signature") == plan_signature(mat):
                     traffic = p.get("hbm_bytes_per_launch")
+                    traffic_source = ("profiles/latest_pmc.json: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE of "
+                                      "this command, separate run" + (", " + p["source"] if p.get("source") else ""))
             except Exception:
-                traffic = None
+                traffic, traffic_source = None, None
         out = {
             "metric": "matrix-free H|psi> Gamplitudes/s, random-field Heisenberg",
             "value": dim / (ms_per_step * 1e-3) / 1e9,
@@ -165,11 +289,14 @@ def main():
                        "L": L, "dim": dim, "nmasks": int(len(masks)), "nterms": int(H.msc.size),
                        "partition": f"{n_gpus} x 2^{L - int(math.log2(n_gpus))} contiguous blocks",
                        "launches_per_step": launches,
+                       "transport": (os.environ.get("DNM_BENCH_BACKEND", "nccl") if world > 1 else "none"),
+                       **exchange_estimate(mat.sends, mat.recvs, n_gpus),
                        "tile_bits": int(os.environ.get("DNM_TILE_BITS", "12")),
                        "plan_mode": int(os.environ.get("DNM_PLAN_MODE", "2")),
-                       "plan": mat.describe().strip().replace("\n", " | ")},
+                       "plan": mat.describe().strip().replace("\n", " | "),
+                       "plan_signature": plan_signature(mat)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "tile_pass_kernel", "avg_launch_ms": avg_launch_ms,
                          "alg_bytes_per_launch": alg_bytes_launch,
                          "read_only_frac": 0.5 * achieved / HBM_PEAK_GBS},

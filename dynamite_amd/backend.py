@@ -285,10 +285,22 @@ class ShellMat:
             bufs.append(self._recv[i])
         reqs = post_exchange(x.array, self.sends, self.recvs, bufs)     # runs on RCCL's stream
         _lib.check(L.dnm_mat_mult_local(self.handle, x.ptr, y.ptr, _stream()))   # overlaps
-        for r in reqs:
-            r.wait()
-        for i in range(len(self.recvs)):
-            _lib.check(L.dnm_mat_mult_remote(self.handle, i, C.c_void_p(bufs[i].data_ptr()), y.ptr, _stream()))
+        # one request per posted operation (sends first, then the receives in order): wait per received block and
+        # apply it at once, smallest first, so that a large block still in flight does not hold back the others;
+        # a transport that hands back one request for the whole batch is waited for as a whole
+        nr = len(self.recvs)
+        if len(reqs) == len(self.sends) + nr:
+            rreq = reqs[len(self.sends):]
+            for i in sorted(range(nr), key=lambda j: self.recvs[j][2]):
+                rreq[i].wait()
+                _lib.check(L.dnm_mat_mult_remote(self.handle, i, C.c_void_p(bufs[i].data_ptr()), y.ptr, _stream()))
+            for r in reqs[:len(self.sends)]:
+                r.wait()
+        else:
+            for r in reqs:
+                r.wait()
+            for i in range(nr):
+                _lib.check(L.dnm_mat_mult_remote(self.handle, i, C.c_void_p(bufs[i].data_ptr()), y.ptr, _stream()))
 
     def prepare_exchange(self, like):
         """Allocate the receive buffers / column window of the partitioned multiply now (they are

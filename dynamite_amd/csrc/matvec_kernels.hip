@@ -74,7 +74,8 @@ template <int R, int LOGNT, bool KVAR, bool CPLX, bool GATHER, bool K0>
 __device__ __forceinline__ void apply_records(const DevQuad *__restrict__ quads, uint32_t b, uint32_t e,
                                               double (&ar)[R], double (&ai)[R], const c128 *tile,
                                               const uint32_t (&rows)[R], const c128 *__restrict__ x,
-                                              const c128 *__restrict__ xr, uint32_t tid, uint64_t sbase) {
+                                              const c128 *__restrict__ xr, uint32_t tid, uint64_t sbase,
+                                              uint32_t skw = 0) {
   constexpr uint32_t NT = 1u << LOGNT;
   for (uint32_t qi = b; qi < e; ++qi) {
     const DevQuad &Q = quads[qi];
@@ -95,7 +96,10 @@ __device__ __forceinline__ void apply_records(const DevQuad *__restrict__ quads,
       const uint32_t mloc = Q.mask_loc;
       if (live) {
 #pragma unroll
-        for (int k = 0; k < R; ++k) xv[k] = src[rows[k] ^ mloc];
+        for (int k = 0; k < R; ++k) {
+          const uint32_t pr = rows[k] ^ mloc;
+          xv[k] = src[skw ? (pr ^ (((pr >> skw) & ((1u << (skw - 4)) - 1u)) << 4)) : pr];
+        }
       } else {
 #pragma unroll
         for (int k = 0; k < R; ++k) xv[k] = make_double2(0.0, 0.0);
@@ -178,22 +182,28 @@ tile_pass_kernel(const DevPass P, const c128 *__restrict__ x, c128 *__restrict__
   for (int k = 0; k < R; ++k)
     rows[k] = base | dep_t | deposit<MAXSEG>((uint32_t)k << LOGNT, P.nseg, P.seg_off, P.seg_len, P.seg_pos);
 
+  // experiment (cache_policy bits 8..13 = s): XOR-swizzled vector layout: index bits [s, 2s-4) folded onto bits [4, s)
+  const uint32_t skw = ((uint32_t)P.cache_policy >> 8) & 63u;
+  uint64_t arows[R];
+#pragma unroll
+  for (int k = 0; k < R; ++k) arows[k] = skw ? (uint64_t)(rows[k] ^ (((rows[k] >> skw) & ((1u << (skw - 4)) - 1u)) << 4)) : (uint64_t)rows[k];
+
   // ---- stage the tile: each wavefront moves 1 KB runs, lane = low 6 tile bits
   if (!P.need_tile) {
     // pure gather pass (remote partner vector): nothing to stage
   } else if constexpr (GLDS) {
 #pragma unroll
     for (int k = 0; k < R; ++k)
-      __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *)(x + rows[k]),
+      __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *)(x + arows[k]),
                                        (LDS_AS void *)(tile + (k * NT + (tid & ~63u))), 16, 0, 0);
   } else {
     c128 v[R];
     if (P.cache_policy & 4) {
 #pragma unroll
-      for (int k = 0; k < R; ++k) v[k] = load_streaming(x + rows[k]);
+      for (int k = 0; k < R; ++k) v[k] = load_streaming(x + arows[k]);
     } else {
 #pragma unroll
-      for (int k = 0; k < R; ++k) v[k] = x[rows[k]];
+      for (int k = 0; k < R; ++k) v[k] = x[arows[k]];
     }
 #pragma unroll
     for (int k = 0; k < R; ++k) tile[tid + k * NT] = v[k];
@@ -204,14 +214,14 @@ tile_pass_kernel(const DevPass P, const c128 *__restrict__ x, c128 *__restrict__
     if (P.cache_policy & 2) {
 #pragma unroll
       for (int k = 0; k < R; ++k) {
-        c128 v = load_streaming(y + rows[k]);
+        c128 v = load_streaming(y + arows[k]);
         ar[k] = v.x;
         ai[k] = v.y;
       }
     } else {
 #pragma unroll
       for (int k = 0; k < R; ++k) {
-        c128 v = y[rows[k]];
+        c128 v = y[arows[k]];
         ar[k] = v.x;
         ai[k] = v.y;
       }
@@ -221,7 +231,7 @@ tile_pass_kernel(const DevPass P, const c128 *__restrict__ x, c128 *__restrict__
     const double zs = -P.zscale;
 #pragma unroll
     for (int k = 0; k < R; ++k) {
-      const c128 v = load_streaming(z + rows[k]);      // read once
+      const c128 v = load_streaming(z + arows[k]);      // read once
       ar[k] = zs * v.x;
       ai[k] = zs * v.y;
     }
@@ -245,7 +255,7 @@ tile_pass_kernel(const DevPass P, const c128 *__restrict__ x, c128 *__restrict__
   const DevQuad *__restrict__ quads = P.quads;
 
 #define DNM_LOOP(LP, KV, CX, GA, KZ) \
-  apply_records<R, LOGNT, KV, CX, GA, KZ>(quads, P.loop[LP], P.loop[LP + 1], ar, ai, tile, rows, x, xr, tid, sbase)
+  apply_records<R, LOGNT, KV, CX, GA, KZ>(quads, P.loop[LP], P.loop[LP + 1], ar, ai, tile, rows, x, xr, tid, sbase, skw)
   if constexpr (GV >= 1) {
     DNM_LOOP(LP_GATHER_REAL, false, false, true, false);
     DNM_LOOP(LP_GATHER_CPLX, false, true, true, false);
@@ -316,7 +326,7 @@ tile_pass_kernel(const DevPass P, const c128 *__restrict__ x, c128 *__restrict__
 
   // ---- off-diagonal masks, one branch-free loop per record class
 #define DNM_LOOP(LP, KV, CX, GA, KZ) \
-  apply_records<R, LOGNT, KV, CX, GA, KZ>(quads, P.loop[LP], P.loop[LP + 1], ar, ai, tile, rows, x, xr, tid, sbase)
+  apply_records<R, LOGNT, KV, CX, GA, KZ>(quads, P.loop[LP], P.loop[LP + 1], ar, ai, tile, rows, x, xr, tid, sbase, skw)
   DNM_LOOP(LP_TILE_REAL_K0, false, false, false, true);
   DNM_LOOP(LP_TILE_REAL, false, false, false, false);
   DNM_LOOP(LP_TILE_CPLX, false, true, false, false);
@@ -331,13 +341,13 @@ tile_pass_kernel(const DevPass P, const c128 *__restrict__ x, c128 *__restrict__
 
   if (P.cache_policy & 64) {
 #pragma unroll
-    for (int k = 0; k < R; ++k) store_streaming(y + rows[k], ar[k], ai[k]);
+    for (int k = 0; k < R; ++k) store_streaming(y + arows[k], ar[k], ai[k]);
   } else if (P.cache_policy & 1) {
 #pragma unroll
-    for (int k = 0; k < R; ++k) store_through(y + rows[k], ar[k], ai[k]);
+    for (int k = 0; k < R; ++k) store_through(y + arows[k], ar[k], ai[k]);
   } else {
 #pragma unroll
-    for (int k = 0; k < R; ++k) y[rows[k]] = make_double2(ar[k], ai[k]);
+    for (int k = 0; k < R; ++k) y[arows[k]] = make_double2(ar[k], ai[k]);
   }
 
   // ---- fused <x, y> (Lanczos alpha) and |y|^2: the rows' own x values are still in the tile
