@@ -217,7 +217,7 @@ def main():
     if rank == 0:
         print(mat.describe(), file=sys.stderr)
     dim = 1 << L
-    x, y = backend.Vec(dim), backend.Vec(dim)
+    x, y = mat.createVecs()
     x.set_random(0)
     x.normalize()
 

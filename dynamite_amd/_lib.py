@@ -22,7 +22,7 @@ class Subspace(C.Structure):
     """dnm_subspace"""
     _fields_ = [("type", C.c_int32), ("L", C.c_int64), ("space", C.c_int64), ("k", C.c_int64),
                 ("ld_nchoosek", C.c_int64), ("nchoosek", i64p), ("dim", C.c_int64),
-                ("state_map", i64p), ("rmap_indices", i64p), ("rmap_states", i64p)]
+                ("state_map", i64p), ("rmap_indices", i64p), ("rmap_states", i64p), ("vec_swizzle", C.c_int32)]
 
 
 class Partition(C.Structure):
@@ -47,10 +47,10 @@ class SolverStats(C.Structure):
 MAXSEG, MAXBSEG, MAXR = 4, 8, 16
 
 
-LP_COUNT = 8
+LP_COUNT = 9
 LP_NAMES = ["tile_real_k0", "tile_real", "tile_cplx", "tile_kvar_real", "tile_kvar_cplx", "gather_real",
-            "gather_cplx", "gather_kvar"]
-LP_KVAR, LP_CPLX, LP_GATHER = (3, 4, 7), (2, 4, 6, 7), (5, 6, 7)
+            "gather_kvar_real", "gather_cplx", "gather_kvar_cplx"]
+LP_KVAR, LP_CPLX, LP_GATHER = (3, 4, 6, 8), (2, 4, 7, 8), (5, 6, 7, 8)
 
 
 class DevQuad(C.Structure):
@@ -67,7 +67,8 @@ class DevPass(C.Structure):
                 ("has_diag", C.c_int32), ("cache_policy", C.c_int32), ("dext_begin", C.c_uint32), ("dext_end", C.c_uint32),
                 ("dbucket", C.c_uint32 * (MAXR + 1)), ("loop", C.c_uint32 * (LP_COUNT + 1)),
                 ("nquads", C.c_int32), ("n_eff", C.c_int32), ("quads", vp), ("dot_out", vp), ("zinit", vp), ("zscale", C.c_double), ("zinit2", vp), ("z2re", C.c_double), ("z2im", C.c_double),
-                ("tile_bits", C.c_int32), ("log_rows", C.c_int32)]
+                ("tile_bits", C.c_int32), ("log_rows", C.c_int32),
+                ("swz_shift", C.c_int32), ("swz_xor_y", C.c_uint32), ("swz_xor_src", C.c_uint32)]
 
 
 class Xfer(C.Structure):
@@ -98,6 +99,8 @@ SIGNATURES = {
     "dnm_check_conserves": (C.c_int, [C.c_int64, i64p, i64p, i64p, f64p, C.POINTER(Subspace),
                                       C.POINTER(Subspace), C.c_int, C.POINTER(C.c_int), vp]),
     "dnm_reduced_density_matrix": (C.c_int, [vp, C.POINTER(Subspace), C.c_int, i64p, vp, vp]),
+    "dnm_vec_set_random_swz": (C.c_int, [vp, C.c_int64, C.c_uint64, C.c_int64, C.c_int, vp]),
+    "dnm_vec_swizzle_copy": (C.c_int, [vp, vp, C.c_int64, C.c_int, vp]),
     "dnm_mat_destroy": (C.c_int, [vp]),
     "dnm_mat_sizes": (C.c_int, [vp, i64p, i64p, i64p, i64p]),
     "dnm_mat_precompute_diagonal": (C.c_int, [vp, vp]),

@@ -117,16 +117,51 @@ def post_exchange(x_local, sends, recvs, recv_bufs):
 
 class Vec:
     """Distributed complex128 vector: this rank's block lives in ``self.array``
-    (a 1-D torch tensor on the rank's GPU)."""
+    (a 1-D torch tensor on the rank's GPU).  ``swz``: layout of the block (dnm_subspace.vec_swizzle): 0 = element
+    i at position i; S > 0 = XOR-swizzled (Full / Parity states).  Everything index-wise goes through
+    ``positions`` / ``get_local`` / ``set_local``; the BLAS-1 methods do not care."""
 
-    def __init__(self, size, array=None):
+    def __init__(self, size, array=None, swz=0):
         import torch
         config._initialize()
         self.size = int(size)
+        self.swz = int(swz)
         self.start, self.local_size = split_ownership(self.size, config.world_size, config.rank)
         if array is None:
             array = device_zeros(self.local_size)
         self.array = array
+
+    # -- layout ------------------------------------------------------------------
+    def positions(self, idx):
+        """Positions in ``self.array`` of the local elements ``idx`` (int64 tensor or int)."""
+        S = self.swz
+        if not S:
+            return idx
+        return idx ^ (((idx >> S) & ((1 << (S - 4)) - 1)) << 4)
+
+    def get_local(self, lo, hi):
+        """Device tensor of the local elements [lo, hi) in index order."""
+        import torch
+        if not self.swz:
+            return self.array[lo:hi]
+        return self.array[self.positions(torch.arange(lo, hi, device=self.array.device))]
+
+    def set_local(self, lo, hi, values):
+        import torch
+        if not self.swz:
+            self.array[lo:hi] = values
+        else:
+            self.array[self.positions(torch.arange(lo, hi, device=self.array.device))] = values
+
+    def local_natural(self):
+        """This rank's block in index order (a new device tensor when the layout is swizzled)."""
+        import torch
+        if not self.swz:
+            return self.array
+        out = torch.empty_like(self.array)
+        _lib.check(_lib.lib().dnm_vec_swizzle_copy(C.c_void_p(out.data_ptr()), self.ptr, self.local_size,
+                                                   self.swz, _stream()))
+        return out
 
     # -- petsc4py.Vec-like surface -------------------------------------------
     def getSize(self):
@@ -148,7 +183,9 @@ class Vec:
 
     def copy(self, result=None):
         if result is None:
-            result = Vec(self.size)
+            result = Vec(self.size, swz=self.swz)
+        if result.swz != self.swz:
+            raise ValueError('vectors of different layouts')
         _lib.check(_lib.lib().dnm_vec_copy(self.ptr, result.ptr, self.local_size, _stream()))
         return result
 
@@ -193,17 +230,32 @@ class Vec:
         self.array += complex(alpha)
 
     def set_random(self, seed):
-        _lib.check(_lib.lib().dnm_vec_set_random(self.ptr, self.local_size, seed & (2 ** 64 - 1),
-                                                 self.start, _stream()))
+        _lib.check(_lib.lib().dnm_vec_set_random_swz(self.ptr, self.local_size, seed & (2 ** 64 - 1),
+                                                     self.start, self.swz, _stream()))
+
+    _CHUNK = 1 << 24
 
     def set_local_from_numpy(self, arr):
         import torch
         arr = np.ascontiguousarray(arr, dtype=np.complex128)
         assert arr.size == self.local_size
-        self.array.copy_(torch.from_numpy(arr))
+        if not self.swz:
+            self.array.copy_(torch.from_numpy(arr))
+            return
+        for lo in range(0, self.local_size, self._CHUNK):      # chunked: no second full-size device buffer
+            hi = min(self.local_size, lo + self._CHUNK)
+            self.set_local(lo, hi, torch.from_numpy(arr[lo:hi]).to(self.array.device))
 
     def local_numpy(self):
-        return self.array.cpu().numpy()
+        if not self.swz:
+            return self.array.cpu().numpy()
+        if self.local_size <= self._CHUNK:
+            return self.local_natural().cpu().numpy()
+        out = np.empty(self.local_size, dtype=np.complex128)
+        for lo in range(0, self.local_size, self._CHUNK):
+            hi = min(self.local_size, lo + self._CHUNK)
+            out[lo:hi] = self.get_local(lo, hi).cpu().numpy()
+        return out
 
     def to_numpy(self, to_all=False):
         """Gather to rank 0 (or everywhere): State._to_numpy (states.py:403-447)."""
@@ -215,11 +267,11 @@ class Vec:
         ws = config.world_size
         sizes = [split_ownership(self.size, ws, q)[1] for q in range(ws)]
         if len(set(sizes)) == 1:
-            parts = _comm.all_gather(self.array)
+            parts = _comm.all_gather(self.local_natural())
         else:   # uneven blocks: pad to the largest
             mx = max(sizes)
             pad = torch.zeros(mx, dtype=self.array.dtype, device=self.array.device)
-            pad[:self.local_size] = self.array
+            pad[:self.local_size] = self.local_natural()
             parts = [g[:n] for g, n in zip(_comm.all_gather(pad), sizes)]
         if not to_all and config.rank != 0:
             return None
@@ -239,6 +291,7 @@ class ShellMat:
         M, N, m, n = (C.c_int64() for _ in range(4))
         _lib.check(_lib.lib().dnm_mat_sizes(handle, C.byref(M), C.byref(N), C.byref(m), C.byref(n)))
         self.M, self.N, self.m_local, self.n_local = M.value, N.value, m.value, n.value
+        self.swz_left, self.swz_right = int(left_c.vec_swizzle), int(right_c.vec_swizzle)   # layouts of y and x
         self.sends, self.recvs = exchange_plan(handle)
         self.partners = sorted({r[0] for r in self.recvs})
         self._recv = {}
@@ -258,7 +311,7 @@ class ShellMat:
         return self.M, self.N
 
     def createVecs(self):
-        return Vec(self.N), Vec(self.M)
+        return Vec(self.N, swz=self.swz_right), Vec(self.M, swz=self.swz_left)
 
     def describe(self):
         buf = C.create_string_buffer(8192)
@@ -272,6 +325,9 @@ class ShellMat:
         L = _lib.lib()
         if x.array.data_ptr() == y.array.data_ptr():
             raise ValueError('x and y must be different vectors')
+        if x.swz != self.swz_right or y.swz != self.swz_left:
+            raise ValueError('vector layout (swizzle %d -> %d) does not match the matrix (%d -> %d)'
+                             % (x.swz, y.swz, self.swz_right, self.swz_left))
         if self.nranks > 1 and not self.partners and self._is_windowed():
             return self._mult_window(x, y)
         if not self.recvs and not self.sends:
@@ -446,6 +502,7 @@ def rdm_block_subspace(subspace, rank, nranks, keep):
         return None
     out = _lib.Subspace()
     out.type, out.L = d.type, Lb
+    out.vec_swizzle = d.vec_swizzle        # the swizzle acts on the local index
     if subspace['type'] == 1:
         out.space = int(d.space) ^ (bin(rank).count('1') & 1)
     return out
@@ -484,11 +541,14 @@ def reduced_density_matrix(vec, subspace, keep):
                 return np.array([[-1]], dtype=np.complex128)
             return rho.cpu().numpy().reshape(K, K)
         from . import _comm
-        parts = _comm.gather_varied(x, [split_ownership(vec.size, config.world_size, q)[1]
-                                        for q in range(config.world_size)], dst=0)
+        parts = _comm.gather_varied(vec.local_natural(), [split_ownership(vec.size, config.world_size, q)[1]
+                                                          for q in range(config.world_size)], dst=0)
         if config.rank != 0:
             return np.array([[-1]], dtype=np.complex128)
-        x = torch.cat(parts)
+        x = torch.cat(parts)                 # the whole state in index order
+        sub_c = _lib.Subspace.from_buffer_copy(subspace['data'])
+        sub_c.vec_swizzle = 0
+        return rdm_partial(x, sub_c, keep).cpu().numpy().reshape(K, K)
     return rdm_partial(x, subspace['data'], keep).cpu().numpy().reshape(K, K)
 
 

@@ -36,8 +36,8 @@ def _hooks(mat, keep):
             n = mat.n_local
             # wrap raw device pointers as Vec views without copying
             x = Vec.__new__(Vec); y = Vec.__new__(Vec)
-            for v, p in ((x, xp), (y, yp)):
-                v.size, v.local_size, v.start = mat.N, n, mat.row0
+            for v, p, sw in ((x, xp, mat.swz_right), (y, yp, mat.swz_left)):
+                v.size, v.local_size, v.start, v.swz = mat.N, n, mat.row0, sw
                 v.array = _tensor_from_ptr(p, n)
             mat.mult(x, y)
             return 0
@@ -255,7 +255,7 @@ def eigsolve(H, getvecs=False, nev=1, which='lowest', target=None, tol=None, sub
     for i in range(nconv):
         v = State(L=H.L, subspace=subspace)
         # (views of one buffer: no second copy of the vectors)
-        v._vec = Vec(mat.N, array=evec_buf[i * mat.n_local:(i + 1) * mat.n_local])
+        v._vec = Vec(mat.N, array=evec_buf[i * mat.n_local:(i + 1) * mat.n_local], swz=mat.swz_right)
         v.set_initialized()
         evecs.append(v)
     return vals, evecs

@@ -17,6 +17,10 @@ class _Config:
         self._initialized = False
         self.gpu = True
         self.device = None           # torch.device of this rank
+        # layout of Full / Parity state vectors in device memory: XOR-swizzle shift (include/dynamite_amd.h,
+        # dnm_subspace.vec_swizzle); 0 = index order.  16 measured best on MI355X (profiles/r02_exp1_swz.txt).
+        # Fixed for the life of the process: vectors and matrices built under different values do not mix.
+        self.vec_swizzle = int(os.environ.get('DNM_SWZ', '16'))
 
     # -- L / subspace / shell: same validation as the reference --------------
     @property

@@ -24,6 +24,11 @@ bool tile_config_supported(int B, int logR);
 int launch_tile_pass(const DevPass &P, int B, int logR, bool glds, int n_loc,
                      const void *x, void *y, const void *xr, hipStream_t st);
 
+// The same pass on tile_pass2_kernel (tile_pass2.hip): lean addressing, scalar-evaluated gathers, pipelined records.
+bool tile2_config_supported(int B, int logR);
+int launch_tile_pass2(const DevPass &P, int B, int logR, int n_loc, const void *x, void *y, const void *xr,
+                      hipStream_t st);
+
 // y (+)= H x by one thread per row with index maps (MatMult semantics of
 // bcuda_template_2.cu:200-273 / bpetsc_template_2.c:371-412).
 int launch_gather_matvec(const DevMsc &msc, const SubView &left, const SubView &right,
@@ -106,7 +111,8 @@ int vk_set(void *x, int64_t n, double re, double im, hipStream_t st);
 int vk_scale(void *x, int64_t n, double re, double im, hipStream_t st);
 int vk_axpby(void *y, const void *x, int64_t n, double are, double aim, double bre, double bim,
              hipStream_t st);
-int vk_random(void *x, int64_t n, uint64_t seed, int64_t offset, hipStream_t st);
+int vk_random(void *x, int64_t n, uint64_t seed, int64_t offset, hipStream_t st, int swz = 0);
+int vk_swizzle_copy(void *dst, const void *src, int64_t n, int swz, hipStream_t st);
 // partial sums: out_dev[2*nv * nblocks]; reduce_blocks returns the block count
 int vk_mdot_blocks(int64_t n);
 int vk_mdot(const void *V, int64_t ldv, int nv, const void *w, int64_t n, double *partials_dev,

@@ -894,10 +894,11 @@ int dnm_eigsolve(dnm_mat *A, int64_t n_local, int nev, int which, double tol, in
   void *V = nullptr;
   DNM_TRY(basis_workspace((size_t)(m + 1) * (size_t)n_local * 16, &V));
 
-  // start vector: counter-based normal deviates keyed by the global index
-  int64_t offset = 0;
-  if (hooks) offset = (int64_t)A->rank * n_local;
-  DNM_TRY(vk_random(vecptr(V, n_local, 0), n_local, seed, offset, st));
+  // start vector: counter-based normal deviates keyed by the global index (the rank's first row: blocks may be
+  // uneven, PetscSplitOwnership), written in the vectors' layout
+  const int64_t offset = hooks ? A->row0 : 0;
+  const int vswz = A->right.host.swz;
+  DNM_TRY(vk_random(vecptr(V, n_local, 0), n_local, seed, offset, st, vswz));
   double nrm0 = 0;
   DNM_TRY(ops.norm(vecptr(V, n_local, 0), &nrm0));
   DNM_CHECK(nrm0 > 0, "zero start vector");
@@ -983,7 +984,7 @@ int dnm_eigsolve(dnm_mat *A, int64_t n_local, int nev, int which, double tol, in
       if (bn <= 1e-14 * std::max(1.0, anorm_est)) {
         // invariant subspace: continue with a fresh direction orthogonal to the basis
         betav[j] = 0.0;
-        DNM_TRY(vk_random(p, n_local, seed + 7919u * (uint64_t)(its * m + j + 1), offset, st));
+        DNM_TRY(vk_random(p, n_local, seed + 7919u * (uint64_t)(its * m + j + 1), offset, st, vswz));
         double rn = 0;
         DNM_TRY(ops.orthogonalize(p, V, j + 1, h, &rn, 2));
         DNM_CHECK(rn > 0, "Lanczos breakdown: could not extend the basis");

@@ -52,6 +52,9 @@ static int view_from_c(const dnm_subspace *s, SubView *v) {
   v->state_map = s->state_map;
   v->rmap_indices = s->rmap_indices;
   v->rmap_states = s->rmap_states;
+  v->swz = s->vec_swizzle;
+  DNM_CHECK(v->swz == 0 || ((s->type == DNM_FULL || s->type == DNM_PARITY) && v->swz >= 5 && v->swz <= 24),
+            "vec_swizzle %d: swizzled vectors need a Full or Parity subspace and a shift in [5, 24]", v->swz);
   if (s->type == DNM_PARITY) DNM_CHECK(s->space == 0 || s->space == 1, "parity space must be 0 or 1");
   if (s->type == DNM_SPIN_CONSERVE) {
     DNM_CHECK(s->nchoosek != nullptr && s->ld_nchoosek == s->L + 1 && s->k >= 0 && s->k <= s->L,
@@ -260,6 +263,16 @@ static int build_pass(const dnm_mat &A, const PassSpec &ps, PassOnDevice *out) {
   d.accumulate = ps.accumulate ? 1 : 0;
   d.has_diag = 0;
   d.cache_policy = pl.cfg.cache_policy;
+  {
+    const int S = pl.cfg.swz;
+    DNM_CHECK(S == 0 || (S >= 5 && S <= 24), "swizzle shift %d out of range", S);
+    d.swz_shift = S;
+    auto sw = [S](uint64_t v) -> uint32_t {
+      return S ? (uint32_t)(((v >> S) & (((uint64_t)1 << (S - 4)) - 1)) << 4) : 0u;
+    };
+    d.swz_xor_y = sw((uint64_t)ps.y_off);
+    d.swz_xor_src = sw((uint64_t)ps.src_off);
+  }
 
   std::vector<DevQuad> quads;
   auto empty_quad = [&]() {
@@ -335,7 +348,7 @@ static int build_pass(const dnm_mat &A, const PassSpec &ps, PassOnDevice *out) {
         cplx = true;
       }
       int loop;
-      if (gather) loop = kvar ? LP_GATHER_KVAR : (cplx ? LP_GATHER_CPLX : LP_GATHER_REAL);
+      if (gather) loop = kvar ? (cplx ? LP_GATHER_KVAR_CPLX : LP_GATHER_KVAR_REAL) : (cplx ? LP_GATHER_CPLX : LP_GATHER_REAL);
       else if (kvar) loop = cplx ? LP_TILE_KVAR_CPLX : LP_TILE_KVAR_REAL;
       else if (cplx) loop = LP_TILE_CPLX;
       else loop = (q.mask_tile >> lognt) == 0 ? LP_TILE_REAL_K0 : LP_TILE_REAL;
@@ -365,6 +378,26 @@ static int build_pass(const dnm_mat &A, const PassSpec &ps, PassOnDevice *out) {
 }
 
 static hipStream_t S(void *stream) { return (hipStream_t)stream; }
+
+// tile_pass2_kernel wherever it has an instance for the pass geometry and the thread part of the tile coordinate
+// stays below index bit 28 (its 32-bit byte offsets); tile_pass_kernel otherwise (and with DNM_KERNEL=1 / GLDS)
+static bool pass_runs_on_v2(const dnm_mat *A, const DevPass &d) {
+  if (A->plan.cfg.kernel != 2 || (A->flags & DNM_MAT_USE_GLDS)) return false;
+  if (!tile2_config_supported(d.tile_bits, d.log_rows)) return false;
+  const int lognt = d.tile_bits - d.log_rows;
+  for (int j = 0; j < d.nseg; ++j) {
+    if (d.seg_off[j] >= lognt) continue;
+    const int top_coord = std::min(d.seg_off[j] + d.seg_len[j], lognt) - 1;       // highest thread bit in this segment
+    if (d.seg_pos[j] + (top_coord - d.seg_off[j]) >= 28) return false;
+  }
+  return true;
+}
+
+static int launch_pass(const dnm_mat *A, const DevPass &d, int n_eff, const void *x, void *y, const void *xr,
+                       hipStream_t st) {
+  if (pass_runs_on_v2(A, d)) return launch_tile_pass2(d, d.tile_bits, d.log_rows, n_eff, x, y, xr, st);
+  return launch_tile_pass(d, d.tile_bits, d.log_rows, (A->flags & DNM_MAT_USE_GLDS) != 0, n_eff, x, y, xr, st);
+}
 
 }  // namespace dnm
 
@@ -739,10 +772,14 @@ int dnm_mat_create(int64_t nmasks, const int64_t *masks, const int64_t *mask_off
       A->op.n -= 1;
     }
     PlanConfig cfg = plan_config_from_env();
-    if (cfg.logR < 0) {   // measured (profiles/r01_sweep6.txt): 16 rows per thread pay from 2^26 local amplitudes on
+    DNM_CHECK(A->left.host.swz == A->right.host.swz, "left and right vectors of a Full/Parity pair must share a layout");
+    cfg.swz = A->left.host.swz;
+    if (cfg.logR < 0) {
+      // measured: in index order 16 rows per thread pay from 2^26 local amplitudes on (profiles/r01_sweep6.txt);
+      // with swizzled vectors 8 rows (16 waves per CU) are faster at every size (profiles/r02_exp3_v2.txt)
       int nl = A->op.n;
       for (int r = A->nranks; r > 1; r >>= 1) --nl;
-      cfg.logR = nl >= 26 ? 4 : 3;
+      cfg.logR = (nl >= 26 && !cfg.swz) ? 4 : 3;
     }
     if (!tile_config_supported(cfg.B, cfg.logR)) {
       set_error("unsupported tile configuration B=%d logR=%d", cfg.B, cfg.logR);
@@ -812,7 +849,7 @@ static int launch_sc(dnm_mat *A, int64_t win_start, int64_t win_len, const void 
                           win_start, dg, xw, y, nullptr, S(stream));
 }
 
-static bool use_glds(const dnm_mat *A) { return (A->flags & DNM_MAT_USE_GLDS) != 0; }
+
 
 int dnm_mat_mult_local(dnm_mat *A, const void *x, void *y, void *stream) {
   DNM_CHECK(A && x && y, "null argument");
@@ -820,8 +857,7 @@ int dnm_mat_mult_local(dnm_mat *A, const void *x, void *y, void *stream) {
   DNM_CHECK(x != y, "x and y must be different vectors");
   if (A->hypercube && A->plan.use_tiled) {
     for (auto &p : A->local_passes)
-      DNM_TRY(launch_tile_pass(p->desc, p->desc.tile_bits, p->desc.log_rows, use_glds(A), p->n_eff, x, y,
-                               nullptr, S(stream)));
+      DNM_TRY(launch_pass(A, p->desc, p->n_eff, x, y, nullptr, S(stream)));
     return 0;
   }
   DNM_CHECK(A->nranks == 1, "this subspace pair cannot run partitioned (use dnm_mat_mult_window)");
@@ -867,8 +903,7 @@ int dnm_mat_mult_lanczos(dnm_mat *A, const void *x, void *y, const void *z, doub
       d.zscale = b;
     }
     if (fused_dot && i + 1 == A->local_passes.size()) d.dot_out = part;
-    DNM_TRY(launch_tile_pass(d, d.tile_bits, d.log_rows, use_glds(A), A->local_passes[i]->n_eff, x, y,
-                             nullptr, S(stream)));
+    DNM_TRY(launch_pass(A, d, A->local_passes[i]->n_eff, x, y, nullptr, S(stream)));
   }
   if (!fused_dot) return vec_lanczos_dot_host(y, nullptr, x, A->m_local, 0.0, dot, S(stream));
   DNM_TRY(vk_reduce_partials(part, (int)nblk, 3, part + 3 * nblk, S(stream)));
@@ -903,8 +938,7 @@ int dnm_mat_mult_sub2(dnm_mat *A, const void *x, void *y, const void *z, double 
         d.z2re = c_re;
         d.z2im = c_im;
       }
-      DNM_TRY(launch_tile_pass(d, d.tile_bits, d.log_rows, use_glds(A), A->local_passes[i]->n_eff, x, y,
-                               nullptr, S(stream)));
+      DNM_TRY(launch_pass(A, d, A->local_passes[i]->n_eff, x, y, nullptr, S(stream)));
     }
     return 0;
   }
@@ -999,8 +1033,7 @@ int dnm_mat_mult_remote(dnm_mat *A, int32_t recv_index, const void *x_recv, void
   DNM_CHECK(recv_index >= 0 && recv_index < (int)A->remote_passes.size(), "rank %d has no receive %d", A->rank,
             recv_index);
   const auto &p = A->remote_passes[recv_index];
-  return launch_tile_pass(p->desc, p->desc.tile_bits, p->desc.log_rows, use_glds(A), p->n_eff, x_recv,
-                          (char *)y + (size_t)p->y_off * 16, x_recv, S(stream));
+  return launch_pass(A, p->desc, p->n_eff, x_recv, (char *)y + (size_t)p->y_off * 16, x_recv, S(stream));
 }
 
 int dnm_mat_norm_inf(dnm_mat *A, double *nrm, void *stream) {

@@ -75,7 +75,7 @@ __device__ __forceinline__ void apply_records(const DevQuad *__restrict__ quads,
                                               double (&ar)[R], double (&ai)[R], const c128 *tile,
                                               const uint32_t (&rows)[R], const c128 *__restrict__ x,
                                               const c128 *__restrict__ xr, uint32_t tid, uint64_t sbase,
-                                              uint32_t skw = 0) {
+                                              uint32_t skw = 0, uint32_t xrx = 0) {
   constexpr uint32_t NT = 1u << LOGNT;
   for (uint32_t qi = b; qi < e; ++qi) {
     const DevQuad &Q = quads[qi];
@@ -93,12 +93,13 @@ __device__ __forceinline__ void apply_records(const DevQuad *__restrict__ quads,
       const bool live = KVAR || (a0 + a1 != 0.0) || (CPLX && (a2 + a3 != 0.0));
       if (!__any(live)) continue;
       const c128 *__restrict__ src = Q.src ? xr : x;
+      const uint32_t sxor = Q.src ? xrx : 0u;
       const uint32_t mloc = Q.mask_loc;
       if (live) {
 #pragma unroll
         for (int k = 0; k < R; ++k) {
           const uint32_t pr = rows[k] ^ mloc;
-          xv[k] = src[skw ? (pr ^ (((pr >> skw) & ((1u << (skw - 4)) - 1u)) << 4)) : pr];
+          xv[k] = src[(skw ? (pr ^ (((pr >> skw) & ((1u << (skw - 4)) - 1u)) << 4)) : pr) ^ sxor];
         }
       } else {
 #pragma unroll
@@ -182,11 +183,15 @@ tile_pass_kernel(const DevPass P, const c128 *__restrict__ x, c128 *__restrict__
   for (int k = 0; k < R; ++k)
     rows[k] = base | dep_t | deposit<MAXSEG>((uint32_t)k << LOGNT, P.nseg, P.seg_off, P.seg_len, P.seg_pos);
 
-  // experiment (cache_policy bits 8..13 = s): XOR-swizzled vector layout: index bits [s, 2s-4) folded onto bits [4, s)
-  const uint32_t skw = ((uint32_t)P.cache_policy >> 8) & 63u;
-  uint64_t arows[R];
+  // XOR-swizzled vector layout: index bits [s, 2s-4) are folded onto bits [4, s); sub-block
+  // passes add the swizzle of the block's own offset (swz_xor_y for y, swz_xor_src for the partner's amplitudes)
+  const uint32_t skw = (uint32_t)P.swz_shift;
+  uint64_t arows[R], yrows[R];
 #pragma unroll
-  for (int k = 0; k < R; ++k) arows[k] = skw ? (uint64_t)(rows[k] ^ (((rows[k] >> skw) & ((1u << (skw - 4)) - 1u)) << 4)) : (uint64_t)rows[k];
+  for (int k = 0; k < R; ++k) {
+    arows[k] = skw ? (uint64_t)(rows[k] ^ (((rows[k] >> skw) & ((1u << (skw - 4)) - 1u)) << 4)) : (uint64_t)rows[k];
+    yrows[k] = arows[k] ^ P.swz_xor_y;
+  }
 
   // ---- stage the tile: each wavefront moves 1 KB runs, lane = low 6 tile bits
   if (!P.need_tile) {
@@ -214,14 +219,14 @@ tile_pass_kernel(const DevPass P, const c128 *__restrict__ x, c128 *__restrict__
     if (P.cache_policy & 2) {
 #pragma unroll
       for (int k = 0; k < R; ++k) {
-        c128 v = load_streaming(y + arows[k]);
+        c128 v = load_streaming(y + yrows[k]);
         ar[k] = v.x;
         ai[k] = v.y;
       }
     } else {
 #pragma unroll
       for (int k = 0; k < R; ++k) {
-        c128 v = y[arows[k]];
+        c128 v = y[yrows[k]];
         ar[k] = v.x;
         ai[k] = v.y;
       }
@@ -231,7 +236,7 @@ tile_pass_kernel(const DevPass P, const c128 *__restrict__ x, c128 *__restrict__
     const double zs = -P.zscale;
 #pragma unroll
     for (int k = 0; k < R; ++k) {
-      const c128 v = load_streaming(z + arows[k]);      // read once
+      const c128 v = load_streaming(z + yrows[k]);      // read once
       ar[k] = zs * v.x;
       ai[k] = zs * v.y;
     }
@@ -240,7 +245,7 @@ tile_pass_kernel(const DevPass P, const c128 *__restrict__ x, c128 *__restrict__
       const double cr = P.z2re, ci = P.z2im;
 #pragma unroll
       for (int k = 0; k < R; ++k) {
-        const c128 v = load_streaming(z2 + rows[k]);
+        const c128 v = load_streaming(z2 + yrows[k]);
         ar[k] = fma(cr, v.x, ar[k]);
         ar[k] = fma(-ci, v.y, ar[k]);
         ai[k] = fma(cr, v.y, ai[k]);
@@ -255,11 +260,12 @@ tile_pass_kernel(const DevPass P, const c128 *__restrict__ x, c128 *__restrict__
   const DevQuad *__restrict__ quads = P.quads;
 
 #define DNM_LOOP(LP, KV, CX, GA, KZ) \
-  apply_records<R, LOGNT, KV, CX, GA, KZ>(quads, P.loop[LP], P.loop[LP + 1], ar, ai, tile, rows, x, xr, tid, sbase, skw)
+  apply_records<R, LOGNT, KV, CX, GA, KZ>(quads, P.loop[LP], P.loop[LP + 1], ar, ai, tile, rows, x, xr, tid, sbase, skw, P.swz_xor_src)
   if constexpr (GV >= 1) {
     DNM_LOOP(LP_GATHER_REAL, false, false, true, false);
+    DNM_LOOP(LP_GATHER_KVAR_REAL, true, false, true, false);
     DNM_LOOP(LP_GATHER_CPLX, false, true, true, false);
-    DNM_LOOP(LP_GATHER_KVAR, true, true, true, false);
+    DNM_LOOP(LP_GATHER_KVAR_CPLX, true, true, true, false);
   }
 #undef DNM_LOOP
 
@@ -326,7 +332,7 @@ tile_pass_kernel(const DevPass P, const c128 *__restrict__ x, c128 *__restrict__
 
   // ---- off-diagonal masks, one branch-free loop per record class
 #define DNM_LOOP(LP, KV, CX, GA, KZ) \
-  apply_records<R, LOGNT, KV, CX, GA, KZ>(quads, P.loop[LP], P.loop[LP + 1], ar, ai, tile, rows, x, xr, tid, sbase, skw)
+  apply_records<R, LOGNT, KV, CX, GA, KZ>(quads, P.loop[LP], P.loop[LP + 1], ar, ai, tile, rows, x, xr, tid, sbase, skw, P.swz_xor_src)
   DNM_LOOP(LP_TILE_REAL_K0, false, false, false, true);
   DNM_LOOP(LP_TILE_REAL, false, false, false, false);
   DNM_LOOP(LP_TILE_CPLX, false, true, false, false);
@@ -334,20 +340,21 @@ tile_pass_kernel(const DevPass P, const c128 *__restrict__ x, c128 *__restrict__
   DNM_LOOP(LP_TILE_KVAR_CPLX, true, true, false, false);
   if constexpr (GV == 0) {
     DNM_LOOP(LP_GATHER_REAL, false, false, true, false);
+    DNM_LOOP(LP_GATHER_KVAR_REAL, true, false, true, false);
     DNM_LOOP(LP_GATHER_CPLX, false, true, true, false);
-    DNM_LOOP(LP_GATHER_KVAR, true, true, true, false);
+    DNM_LOOP(LP_GATHER_KVAR_CPLX, true, true, true, false);
   }
 #undef DNM_LOOP
 
   if (P.cache_policy & 64) {
 #pragma unroll
-    for (int k = 0; k < R; ++k) store_streaming(y + arows[k], ar[k], ai[k]);
+    for (int k = 0; k < R; ++k) store_streaming(y + yrows[k], ar[k], ai[k]);
   } else if (P.cache_policy & 1) {
 #pragma unroll
-    for (int k = 0; k < R; ++k) store_through(y + arows[k], ar[k], ai[k]);
+    for (int k = 0; k < R; ++k) store_through(y + yrows[k], ar[k], ai[k]);
   } else {
 #pragma unroll
-    for (int k = 0; k < R; ++k) y[arows[k]] = make_double2(ar[k], ai[k]);
+    for (int k = 0; k < R; ++k) y[yrows[k]] = make_double2(ar[k], ai[k]);
   }
 
   // ---- fused <x, y> (Lanczos alpha) and |y|^2: the rows' own x values are still in the tile
@@ -492,7 +499,7 @@ gather_matvec_kernel(const DevMsc msc, const SubView left_g, const SubView right
   double accr = 0.0, acci = 0.0;
   int m0 = 0;
   if (diag) {   // bcuda_template_2.cu:230-236
-    c128 xs = x[row];
+    c128 xs = x[vec_pos(row, right.swz)];
     accr = diag[row] * xs.x;
     acci = diag[row] * xs.y;
     m0 = 1;
@@ -508,13 +515,13 @@ gather_matvec_kernel(const DevMsc msc, const SubView left_g, const SubView right
       const double c = flip_sign(msc.real_coeffs[t], (uint32_t)__popcll((uint64_t)(bra & sg)) & 1u);
       if (__popcll((uint64_t)(mask & sg)) & 1) cim += c; else cre += c;   // TERM_REAL
     }
-    const c128 xv = x[col];
+    const c128 xv = x[vec_pos(col, right.swz)];
     accr = fma(cre, xv.x, accr);
     acci = fma(cre, xv.y, acci);
     accr = fma(-cim, xv.y, accr);
     acci = fma(cim, xv.x, acci);
   }
-  y[row] = make_double2(accr, acci);
+  y[vec_pos(row, left.swz)] = make_double2(accr, acci);
 }
 
 // ---------------------------------------------------------------------------

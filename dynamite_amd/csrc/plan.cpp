@@ -26,6 +26,7 @@ PlanConfig plan_config_from_env() {
   c.Bw = env_int("DNM_TILE_BITS_WINDOW", c.Bw);
   c.logRw = env_int("DNM_LOG_ROWS_WINDOW", c.logRw);
   c.cache_policy = env_int("DNM_CACHE_POLICY", c.cache_policy);
+  c.kernel = env_int("DNM_KERNEL", c.kernel);
   return c;
 }
 
@@ -187,7 +188,9 @@ static int make_plan_with(const OpForm &op, int rank, int nranks, const PlanConf
     // from LDS, masks that also touch the group bits are gathered (L2)
     // measured on MI355X (profiles/r01_sweep6.txt): with early gathers and streaming y traffic a wide group pays
     // from 2^26 local amplitudes on (9 bits at 2^30)
-    if (cfg.gbits < 0) cfg.gbits = nl >= 30 ? 9 : (nl >= 26 ? 8 : 6);
+    // with swizzled vectors the window passes' gathers merge in the L2 like the contiguous pass's, so the group
+    // stays at what an XCD's L2 holds (2^6 tiles of 64 KB): 83 B/amp against 115 (profiles/r02_exp1_swz.txt)
+    if (cfg.gbits < 0) cfg.gbits = cfg.swz ? 6 : (nl >= 30 ? 9 : (nl >= 26 ? 8 : 6));
     if (cfg.gbits > 10) cfg.gbits = 10;
     bool first = true;
     while (!remaining.empty() || first) {
@@ -344,7 +347,7 @@ int make_plan(const OpForm &op, int rank, int nranks, const PlanConfig &cfg_in, 
   PlanConfig c4 = cfg_in;
   c4.amin = 4;
   DNM_TRY(make_plan_with(op, rank, nranks, c4, out));
-  if (out->use_tiled && out->n_loc >= 29 && out->cfg.mode == 2) {
+  if (out->use_tiled && out->n_loc >= 29 && out->cfg.mode == 2 && !cfg_in.swz) {
     PlanConfig c6 = cfg_in;
     c6.amin = 6;
     Plan p6;

@@ -76,8 +76,9 @@ enum {
   LP_TILE_KVAR_REAL,     // LDS, real, sign reaches the k bits
   LP_TILE_KVAR_CPLX,
   LP_GATHER_REAL,        // global gather, real, k-invariant
-  LP_GATHER_CPLX,
-  LP_GATHER_KVAR,
+  LP_GATHER_KVAR_REAL,   // global gather, real, sign reaches the k bits
+  LP_GATHER_CPLX,        // global gather with an imaginary part, k-invariant
+  LP_GATHER_KVAR_CPLX,
   LP_COUNT
 };
 
@@ -110,6 +111,11 @@ struct DevPass {
   double z2re, z2im;    //   (Clenshaw's a_k x term)
   int32_t tile_bits;    // B and LOGR of the kernel instance this pass runs on (passes of one plan may differ)
   int32_t log_rows;
+  // XOR-swizzled vector layout: element i of a vector of this space lives at i ^ (((i >> swz_shift) &
+  // (2^(swz_shift-4) - 1)) << 4); 0 = natural order.  Sub-block (partner) passes address y relative to the
+  // sub-block and read a slice of the partner's block: the swizzle of the fixed offset bits is a constant XOR.
+  int32_t swz_shift;
+  uint32_t swz_xor_y, swz_xor_src;
 };
 
 // ---- host-side description --------------------------------------------------
@@ -153,6 +159,8 @@ struct PlanConfig {
   int gbits_window = -1; // mode 2: cap of the group bits of window-tile passes (-1: no cap)
   int cache_policy = 98; // DevPass::cache_policy for every pass; default: gathers right behind the tile loads (32) + streaming loads (2) and stores (64) of y
   int max_gather_span = 0;   // mode 0: masks the tiler cannot place are gathered
+  int swz = 0;               // XOR-swizzle shift of the vectors this plan multiplies (0: natural order)
+  int kernel = 1;            // 1: tile_pass_kernel; 2: tile_pass2_kernel where it has an instance for the pass
 };
 
 struct Plan {

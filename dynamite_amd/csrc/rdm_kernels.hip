@@ -22,7 +22,7 @@ constexpr int RDM_STAGE = 1024;   // amplitudes per operand per chunk
 template <int ST>
 __device__ __forceinline__ c128 rdm_fetch(const c128 *__restrict__ x, uint64_t state, const SubView &sub) {
   const int64_t idx = Sub<ST>::s2i((int64_t)state, sub);
-  return idx >= 0 ? x[idx] : make_double2(0.0, 0.0);
+  return idx >= 0 ? x[vec_pos(idx, sub.swz)] : make_double2(0.0, 0.0);
 }
 
 __device__ __forceinline__ uint64_t rdm_deposit(uint64_t v, const int8_t *len, const int8_t *pos, int nseg) {

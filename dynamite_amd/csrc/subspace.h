@@ -31,7 +31,13 @@ struct SubView {
   // are rmap_states[bucket[b] .. bucket[b+1]); the search of S2I starts inside one bucket
   const int64_t *bucket;
   int32_t bucket_shift;
+  int32_t swz;               // vector layout (dnm_subspace::vec_swizzle)
 };
+
+// position of element i of a vector in the XOR-swizzled layout (S = 0: index order)
+__host__ __device__ __forceinline__ int64_t vec_pos(int64_t i, int S) {
+  return S ? (i ^ (((i >> S) & (((int64_t)1 << (S - 4)) - 1)) << 4)) : i;
+}
 
 #define DNM_HD __host__ __device__ __forceinline__
 

@@ -103,6 +103,19 @@ int dnm_vec_norm2(const void *x, int64_t n, double *out, void *stream) {
   return 0;
 }
 
+int dnm_vec_set_random_swz(void *x, int64_t n, uint64_t seed, int64_t offset, int swizzle, void *stream) {
+  DNM_CHECK(x || n == 0, "null vector");
+  DNM_CHECK(swizzle == 0 || (swizzle >= 5 && swizzle <= 24), "swizzle shift %d out of range", swizzle);
+  return vk_random(x, n, seed, offset, S(stream), swizzle);
+}
+
+int dnm_vec_swizzle_copy(void *dst, const void *src, int64_t n, int swizzle, void *stream) {
+  DNM_CHECK((dst && src) || n == 0, "null vector");
+  DNM_CHECK(dst != src, "dnm_vec_swizzle_copy works out of place");
+  DNM_CHECK(swizzle == 0 || (swizzle >= 5 && swizzle <= 24), "swizzle shift %d out of range", swizzle);
+  return vk_swizzle_copy(dst, src, n, swizzle, S(stream));
+}
+
 int dnm_vec_set_random(void *x, int64_t n, uint64_t seed, int64_t offset, void *stream) {
   DNM_CHECK(x && n >= 0, "bad vector");
   return vk_random(x, n, seed, offset, S(stream));

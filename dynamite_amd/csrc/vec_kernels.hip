@@ -86,9 +86,9 @@ __device__ __forceinline__ void philox_round(uint32_t &c0, uint32_t &c1, uint32_
 }
 
 __global__ void __launch_bounds__(VNT)
-random_kernel(c128 *x, int64_t n, uint64_t seed, int64_t offset) {
+random_kernel(c128 *x, int64_t n, uint64_t seed, int64_t offset, int swz) {
   for (int64_t i = (int64_t)blockIdx.x * VNT + threadIdx.x; i < n; i += (int64_t)gridDim.x * VNT) {
-    uint64_t ctr = (uint64_t)(offset + i);
+    uint64_t ctr = (uint64_t)(offset + vec_pos(i, swz));     // the element stored at position i (involution)
     uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = 0x243F6A88u, c3 = 0x85A308D3u;
     uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
 #pragma unroll
@@ -107,8 +107,19 @@ random_kernel(c128 *x, int64_t n, uint64_t seed, int64_t offset) {
   }
 }
 
-int vk_random(void *x, int64_t n, uint64_t seed, int64_t offset, hipStream_t st) {
-  hipLaunchKernelGGL(random_kernel, dim3(vgrid(n)), dim3(VNT), 0, st, (c128 *)x, n, seed, offset);
+int vk_random(void *x, int64_t n, uint64_t seed, int64_t offset, hipStream_t st, int swz) {
+  hipLaunchKernelGGL(random_kernel, dim3(vgrid(n)), dim3(VNT), 0, st, (c128 *)x, n, seed, offset, swz);
+  DNM_HIP(hipGetLastError());
+  return 0;
+}
+
+// dst[i] = src[i ^ sw(i)]: 256-byte runs move as units, both sides coalesced
+__global__ void __launch_bounds__(VNT) swizzle_copy_kernel(c128 *dst, const c128 *__restrict__ src, int64_t n, int swz) {
+  for (int64_t i = (int64_t)blockIdx.x * VNT + threadIdx.x; i < n; i += (int64_t)gridDim.x * VNT)
+    st_stream(dst + i, ld_stream(src + vec_pos(i, swz)));
+}
+int vk_swizzle_copy(void *dst, const void *src, int64_t n, int swz, hipStream_t st) {
+  hipLaunchKernelGGL(swizzle_copy_kernel, dim3(vgrid(n)), dim3(VNT), 0, st, (c128 *)dst, (const c128 *)src, n, swz);
   DNM_HIP(hipGetLastError());
   return 0;
 }

@@ -58,7 +58,7 @@ class State:
         if self._vec is None:
             if self.L is None:
                 raise ValueError('must set L first')
-            self._vec = Vec(self.subspace.get_dimension())
+            self._vec = Vec(self.subspace.get_dimension(), swz=self.subspace.vec_swizzle)
         return self._vec
 
     @property
@@ -112,7 +112,7 @@ class State:
         v.set(0)
         istart, iend = v.getOwnershipRange()
         if istart <= idx < iend:
-            v.array[idx - istart] = 1
+            v.array[v.positions(int(idx - istart))] = 1
         self.repr_binary = isinstance(s, str) and any(c in '01' for c in s)
         self.set_initialized()
 
@@ -181,7 +181,8 @@ class State:
             else:
                 sts = self.subspace.idx_to_state(np.arange(b0, b1))
                 kill = torch.from_numpy(((sts >> index) & 1) != value).to(v.array.device)
-            v.array[b0 - istart:b1 - istart][kill] = 0
+            pos = v.positions(torch.arange(b0 - istart, b1 - istart, device=v.array.device))
+            v.array[pos[kill]] = 0
         v.normalize()
 
     def to_numpy(self, to_all=False):
@@ -216,7 +217,7 @@ class State:
             f.seek(2 * (int_size // 8) + 16 * start)
             for lo in range(0, end - start, self._IO_CHUNK):
                 hi = min(end - start, lo + self._IO_CHUNK)
-                f.write(self.vec.array[lo:hi].cpu().numpy().astype('>c16').tobytes())
+                f.write(self.vec.get_local(lo, hi).cpu().numpy().astype('>c16').tobytes())
         if d is not None:
             d.barrier()
 
@@ -247,7 +248,8 @@ class State:
                 buf = f.read(16 * (hi - lo))
                 if len(buf) != 16 * (hi - lo):
                     raise RuntimeError("corrupt data encountered when loading state from file")
-                rtn.vec.array[lo:hi] = torch.from_numpy(np.frombuffer(buf, dtype='>c16').astype(np.complex128))
+                rtn.vec.set_local(lo, hi, torch.from_numpy(np.frombuffer(buf, dtype='>c16').astype(np.complex128))
+                                  .to(rtn.vec.array.device))
         rtn.set_initialized()
         return rtn
 

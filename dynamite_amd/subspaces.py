@@ -114,6 +114,13 @@ class Subspace:
         """Mirror of Subspace._to_c (subspaces.py:200-213): what build_mat receives."""
         return {'type': self._enum, 'data': self._c()}
 
+    @property
+    def vec_swizzle(self):
+        """Layout of this subspace's state vectors in device memory (dnm_subspace.vec_swizzle): Full and Parity
+        vectors are XOR-swizzled by ``config.vec_swizzle``; every other subspace keeps index order."""
+        from .config import config
+        return config.vec_swizzle if self._enum in (FULL, PARITY) else 0
+
     # -- maps ----------------------------------------------------------------
     def get_dimension(self):
         import ctypes as C
@@ -166,6 +173,7 @@ class Full(Subspace):
     def _descriptor(self):
         d = _lib.Subspace()
         d.type, d.L = FULL, self.L
+        d.vec_swizzle = self.vec_swizzle
         return d
 
 
@@ -202,6 +210,7 @@ class Parity(Subspace):
     def _descriptor(self):
         d = _lib.Subspace()
         d.type, d.L, d.space = PARITY, self.L, self.space
+        d.vec_swizzle = self.vec_swizzle
         return d
 
 
@@ -489,3 +498,7 @@ class XParity(Subspace):
 
     def _to_c(self):
         return self.parent._to_c()
+
+    @property
+    def vec_swizzle(self):
+        return self.parent.vec_swizzle

@@ -70,6 +70,13 @@ typedef struct dnm_subspace {
   const int64_t *state_map;    /* Explicit: idx -> state */
   const int64_t *rmap_indices; /* Explicit: NULL when state_map is sorted */
   const int64_t *rmap_states;  /* Explicit: sorted states */
+  /* Layout of state vectors on this subspace in device memory (no counterpart in the reference: a PETSc Vec is
+   * opaque too).  0: element i of a rank's block is at position i.  S >= 5, Full / Parity only: XOR-swizzled,
+   * element i is at position  i ^ (((i >> S) & (2^(S-4) - 1)) << 4)  -- index bits [S, 2S-4) folded onto bits
+   * [4, S), an involution that keeps 256-byte runs together.  The far-apart runs of the tiled multiply's window
+   * passes then spread over the L2 sets.  Every dnm_* call that takes a vector of this
+   * subspace expects this layout; dnm_vec_swizzle_copy converts to and from index order. */
+  int32_t vec_swizzle;
 } dnm_subspace;
 
 /* get_dimension_* (bsubspace.pyx:144-162) -> Dim_* */
@@ -230,6 +237,10 @@ int dnm_vec_norm2(const void *x, int64_t n, double *out, void *stream);         
  * (seed, global index = offset + i): distribution of State.set_random
  * (states.py:292-316), not its MT19937 stream. */
 int dnm_vec_set_random(void *x, int64_t n, uint64_t seed, int64_t offset, void *stream);
+/* the same stream of numbers for a vector in the swizzled layout (element i gets what index order would give it) */
+int dnm_vec_set_random_swz(void *x, int64_t n, uint64_t seed, int64_t offset, int swizzle, void *stream);
+/* dst[i] = src[i ^ sw(i)]: swizzled <-> index order (the map is an involution); dst != src */
+int dnm_vec_swizzle_copy(void *dst, const void *src, int64_t n, int swizzle, void *stream);
 /* h[j] = V_j^H w for j < nv (BVDotVec); V = nv vectors of length n, stride ldv elements.
  * h_host: 2*nv doubles. */
 int dnm_vec_mdot(const void *V, int64_t ldv, int nv, const void *w, int64_t n,

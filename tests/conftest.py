@@ -14,6 +14,20 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "default_layout: run with the production vector layout (full-size tests)")
+
+
+@pytest.fixture(autouse=True)
+def _vector_layout(request):
+    """GPU tests run their (small) Full / Parity vectors in a swizzled layout whose shift is small enough to
+    permute them (DNM_TEST_SWZ, default 6: index bits [6, 8) folded onto bits [4, 6)); the production shift (16)
+    only moves amplitudes beyond 2^16.  Tests marked default_layout keep the production value."""
+    from dynamite_amd.config import config as dcfg
+    old = dcfg.vec_swizzle
+    if request.node.get_closest_marker("gpu") and not request.node.get_closest_marker("default_layout"):
+        dcfg.vec_swizzle = int(os.environ.get("DNM_TEST_SWZ", "6"))
+    yield
+    dcfg.vec_swizzle = old
 
 
 class Golden:

@@ -40,15 +40,22 @@ def shell(H, left, right=None, flags=0):
     return backend.build_mat(*m, left._to_c(), right._to_c(), flags=flags)
 
 
-def vec_from(arr):
-    v = backend.Vec(arr.size)
+def vec_from(arr, swz=0):
+    """Device vector holding ``arr`` (index order) in the layout ``swz`` (dnm_subspace.vec_swizzle)."""
+    v = backend.Vec(arr.size, swz=swz)
     v.set_local_from_numpy(arr)
     return v
 
 
+def partner_slice(xl, off, cnt):
+    """What a partner rank receives of the local vector ``xl``: the slice [off, off + cnt) of its device array
+    (the exchange of ShellMat.mult ships device memory as it lies)."""
+    return backend.Vec(cnt, array=xl.array[off:off + cnt], swz=xl.swz)
+
+
 def mult_numpy(mat, x):
-    xv = vec_from(x)
-    yv = backend.Vec(mat.M)
+    xv = vec_from(x, mat.swz_right)
+    yv = backend.Vec(mat.M, swz=mat.swz_left)
     yv.set(777.0)          # the multiply must overwrite, not accumulate
     mat.mult(xv, yv)
     return yv.local_numpy()

@@ -61,9 +61,28 @@ class HostMat:
             pass
 
 
+def vec_pos(i, S):
+    """Position of element i in the XOR-swizzled vector layout (dnm_subspace.vec_swizzle = S)."""
+    i = np.asarray(i, dtype=np.int64)
+    return i ^ (((i >> S) & ((1 << (S - 4)) - 1)) << 4) if S else i
+
+
 def run_pass(hm, p, x, y, xr=None):
-    """Apply one exported pass to the local vector x (numpy), updating y."""
+    """Apply one exported pass to the local vector x (numpy), updating y.  The arrays are device images: with a
+    swizzled layout (desc.swz_shift) element i of x sits at vec_pos(i), of y at vec_pos(i) ^ swz_xor_y and of the
+    partner slice xr at vec_pos(i) ^ swz_xor_src -- exactly the addresses the kernels form."""
     desc, quads = p
+    if desc.swz_shift:
+        n = 1 << desc.n_eff
+        pos = vec_pos(np.arange(n), desc.swz_shift)
+        assert np.array_equal(np.sort(pos), np.arange(n)) and desc.swz_xor_y < n and desc.swz_xor_src < n
+        nat = type(desc).from_buffer_copy(desc)
+        nat.swz_shift = 0
+        ylog = y[pos ^ desc.swz_xor_y].copy()
+        run_pass(hm, (nat, quads), x[pos] if desc.need_tile or xr is None else x,
+                 ylog, None if xr is None else xr[pos ^ desc.swz_xor_src])
+        y[pos ^ desc.swz_xor_y] = ylog
+        return
     B, logR, n_loc = desc.tile_bits, desc.log_rows, desc.n_eff
     assert x.shape[0] == 1 << n_loc and y.shape[0] == 1 << n_loc
     lognt = B - logR

@@ -968,16 +968,18 @@ def test_rdm_partitioned_blocks(kind, P):
     L = 12
     sub = {"full": Full(L=L), "even": Parity('even', L=L), "odd": Parity('odd', L=L)}[kind]
     st = State(L=L, subspace=sub, state='random', seed=6)
-    x = st.vec.array
     nloc = len(st) // P
     p = P.bit_length() - 1
+    # every rank's block in its own device layout (the swizzle acts on the local index)
+    nat = st.to_numpy()
+    blocks = [vec_from(nat[r * nloc:(r + 1) * nloc], sub.vec_swizzle) for r in range(P)]
     for keep in ([0], [1, 3, 4], list(range(6)), [2, L - p - 1]):
         keep = np.array(keep, dtype=np.int64)
         tot = 0
         for r in range(P):
             blk = backend.rdm_block_subspace(sub._to_c(), r, P, keep)
             assert blk is not None and blk.L == L - p
-            tot = tot + backend.rdm_partial(x[r * nloc:(r + 1) * nloc], blk, keep)
+            tot = tot + backend.rdm_partial(blocks[r].array, blk, keep)
         K = 1 << keep.size
         assert np.max(np.abs(tot.cpu().numpy().reshape(K, K) - reduced_density_matrix(st, keep))) < 1e-14
     assert backend.rdm_block_subspace(sub._to_c(), 0, P, np.array([L - p])) is None

@@ -11,7 +11,7 @@ import pytest
 from dynamite_amd import _lib, models, backend
 from dynamite_amd.subspaces import Full, Parity, SpinConserve, Explicit
 from oracle import oracle as orc
-from gpu_util import marshal, orc_msc, orc_sub, shell, vec_from, mult_numpy, rand_state
+from gpu_util import partner_slice, marshal, orc_msc, orc_sub, shell, vec_from, mult_numpy, rand_state
 
 pytestmark = pytest.mark.gpu
 EPS = 2.2e-16
@@ -260,14 +260,15 @@ def test_partitioned_kernels_on_one_gpu(monkeypatch):
     nloc = (1 << L) // P
     Lb = _lib.lib()
     y = np.empty(1 << L, dtype=complex)
+    xls = [vec_from(x[q * nloc:(q + 1) * nloc], sub.vec_swizzle) for q in range(P)]
     for r in range(P):
         h = backend.create_mat(*arrs, sub._c(), sub._c(), flags=0, rank=r, nranks=P)
         mat = backend.ShellMat(h, sub._c(), sub._c(), P, r)
-        xl = vec_from(x[r * nloc:(r + 1) * nloc])
-        yl = backend.Vec(nloc)
+        xl = xls[r]
+        yl = backend.Vec(nloc, swz=mat.swz_left)
         _lib.check(Lb.dnm_mat_mult_local(mat.handle, xl.ptr, yl.ptr, None))
         for i, (p, off, cnt) in enumerate(mat.recvs):
-            xr = vec_from(x[p * nloc + off:p * nloc + off + cnt])
+            xr = partner_slice(xls[p], off, cnt)
             _lib.check(Lb.dnm_mat_mult_remote(mat.handle, i, xr.ptr, yl.ptr, None))
         y[r * nloc:(r + 1) * nloc] = yl.local_numpy()
         mat.destroy()
@@ -327,12 +328,19 @@ def _sample_rows_check(H, L, xv, yv, nsamp=64, seed=0):
     import torch
     masks, offs, signs, coeffs = marshal(H)
     rs = np.random.RandomState(seed)
-    rows = np.unique(np.concatenate([[0, (1 << L) - 1], rs.randint(0, 1 << L, nsamp)])).astype(np.int64)
+    # random rows plus rows on both sides of every power-of-two boundary (tile, XCD group, window and swizzle
+    # field edges all sit on those), each with random low bits
+    edge = []
+    for b in range(1, L):
+        lowbits = int(rs.randint(0, 1 << b))
+        edge += [(1 << b) - 1, 1 << b, ((1 << L) - 1) ^ (1 << b), (int(rs.randint(0, 1 << (L - b))) << b) | lowbits,
+                 (((1 << (L - b)) - 1) << b) | lowbits]
+    rows = np.unique(np.concatenate([[0, (1 << L) - 1], edge, rs.randint(0, 1 << L, nsamp)])).astype(np.int64)
     worst = 0.0
-    ycheck = yv.array[torch.from_numpy(rows).to(yv.array.device)].cpu().numpy()
+    ycheck = yv.array[yv.positions(torch.from_numpy(rows).to(yv.array.device))].cpu().numpy()
     for i, r in enumerate(rows):
         cols = r ^ masks
-        xs = xv.array[torch.from_numpy(cols).to(xv.array.device)].cpu().numpy()
+        xs = xv.array[xv.positions(torch.from_numpy(cols).to(xv.array.device))].cpu().numpy()
         acc = 0j
         for m in range(len(masks)):
             c = 0j
@@ -343,6 +351,7 @@ def _sample_rows_check(H, L, xv, yv, nsamp=64, seed=0):
     return worst
 
 
+@pytest.mark.default_layout
 @pytest.mark.parametrize("L", [26, 30])
 def test_full_size_properties(monkeypatch, L):
     """BASELINE configs 2/3 (L=26 XXZ, L=30 random-field Heisenberg): sampled
@@ -355,7 +364,8 @@ def test_full_size_properties(monkeypatch, L):
     H = models.xxz(L) if L == 26 else models.mbl(L)
     sub = Full(L=L)
     n = 1 << L
-    a, b, Ha, Hb = (backend.Vec(n) for _ in range(4))
+    sw = sub.vec_swizzle
+    a, b, Ha, Hb = (backend.Vec(n, swz=sw) for _ in range(4))
     a.set_random(1); b.set_random(2)
     na, nb = a.normalize(), b.normalize()
     cfg(monkeypatch, 12, 4, 0)
@@ -369,7 +379,7 @@ def test_full_size_properties(monkeypatch, L):
     # second plan (single pass, gathers) must agree element-wise
     cfg(monkeypatch, 13, 4, 1)
     mat2 = shell(H, sub)
-    Ha2 = backend.Vec(n)
+    Ha2 = backend.Vec(n, swz=sw)
     mat2.mult(a, Ha2)
     Ha2.axpby(-1.0, 1.0, Ha)
     assert Ha2.norm() < 1e-12
@@ -382,6 +392,7 @@ def test_full_size_properties(monkeypatch, L):
     mat.destroy(); mat2.destroy()
 
 
+@pytest.mark.default_layout
 @pytest.mark.parametrize("L", [26, 30])
 def test_full_size_default_plan(monkeypatch, L):
     """The plan bench.py times (defaults: B=12, 8 rows per thread, LDS tiles + XCD-group gathers, fused
@@ -396,11 +407,11 @@ def test_full_size_default_plan(monkeypatch, L):
     H = models.xxz(L) if L == 26 else models.mbl(L)
     sub = Full(L=L)
     n = 1 << L
-    a, y0, y1 = (backend.Vec(n) for _ in range(3))
+    a, y0, y1 = (backend.Vec(n, swz=sub.vec_swizzle) for _ in range(3))
     a.set_random(4)
     a.normalize()
     mat = shell(H, sub)
-    assert "mode=2" in mat.describe() and "B=12 logR=4" in mat.describe()
+    assert "mode=2" in mat.describe() and "B=12 logR=3" in mat.describe() and len(mat.describe().splitlines()) == 3
     d = (C.c_double * 2)()
     _lib.check(_lib.lib().dnm_mat_mult_dot(mat.handle, a.ptr, y0.ptr, d, None))
     ref_dot = a.dot(y0)                        # sum a_i conj(y0_i) = conj(<a, y0>)
@@ -491,13 +502,14 @@ def test_fuzz_random_operators(monkeypatch, seed):
             Lb = _lib.lib()
             nloc = left.get_dimension() // P
             yp = np.empty(left.get_dimension(), dtype=complex)
+            xls = [vec_from(x[q * nloc:(q + 1) * nloc], right.vec_swizzle) for q in range(P)]
             for r in range(P):
                 h = backend.create_mat(*arrs, left._c(), right._c(), flags=0, rank=r, nranks=P)
                 m = backend.ShellMat(h, left._c(), right._c(), P, r)
-                xl, yl = vec_from(x[r * nloc:(r + 1) * nloc]), backend.Vec(nloc)
+                xl, yl = xls[r], backend.Vec(nloc, swz=m.swz_left)
                 _lib.check(Lb.dnm_mat_mult_local(m.handle, xl.ptr, yl.ptr, None))
                 for i, (p, off, cnt) in enumerate(m.recvs):
-                    xr = vec_from(x[p * nloc + off:p * nloc + off + cnt])
+                    xr = partner_slice(xls[p], off, cnt)
                     _lib.check(Lb.dnm_mat_mult_remote(m.handle, i, xr.ptr, yl.ptr, None))
                 yp[r * nloc:(r + 1) * nloc] = yl.local_numpy()
                 m.destroy()
@@ -526,14 +538,14 @@ def test_error_behaviour():
     H = models.mbl(12)
     sub = Full(L=12)
     mat = shell(H, sub)
-    x = vec_from(rand_state(1 << 12))
+    x = vec_from(rand_state(1 << 12), mat.swz_right)
     with pytest.raises(ValueError):
         mat.mult(x, x)
     with pytest.raises(ValueError):
         mat.norm('frobenius')
     mat.destroy()
     with pytest.raises(RuntimeError):
-        mat.mult(x, backend.Vec(1 << 12))
+        mat.mult(x, backend.Vec(1 << 12, swz=x.swz))
     # unsorted masks are rejected by the native layer
     arrs = marshal(H)
     bad = (arrs[0][::-1].copy(),) + arrs[1:]
@@ -560,7 +572,7 @@ def test_mult_dot_fused(monkeypatch, name, L, sub):
         assert "block form" in mat.describe()
         mat.precompute_diagonal()
     x = rand_state(s.get_dimension(), seed=8)
-    xv, y1, y2 = vec_from(x), backend.Vec(mat.M), backend.Vec(mat.M)
+    xv, y1, y2 = vec_from(x, mat.swz_right), backend.Vec(mat.M, swz=mat.swz_left), backend.Vec(mat.M, swz=mat.swz_left)
     mat.mult(xv, y1)
     d = (C.c_double * 2)()
     _lib.check(_lib.lib().dnm_mat_mult_dot(mat.handle, xv.ptr, y2.ptr, d, None))
@@ -570,7 +582,7 @@ def test_mult_dot_fused(monkeypatch, name, L, sub):
     assert abs(d[1]) <= 1e-12 * max(1.0, abs(ref))      # Hermitian operator: real expectation value
     # the whole Lanczos multiply: y = Hx - b z, <x, y>
     z = rand_state(s.get_dimension(), seed=9)
-    zv, y3 = vec_from(z), backend.Vec(mat.M)
+    zv, y3 = vec_from(z, mat.swz_left), backend.Vec(mat.M, swz=mat.swz_left)
     d3 = (C.c_double * 3)()
     _lib.check(_lib.lib().dnm_mat_mult_lanczos(mat.handle, xv.ptr, y3.ptr, zv.ptr, 0.37, d3, None))
     want = y1.local_numpy() - 0.37 * z

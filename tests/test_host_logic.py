@@ -201,7 +201,7 @@ def test_plan_shape_chain_L30(monkeypatch):
         assert hm.local[0][0].accumulate == 0 and all(p[0].accumulate for p in hm.local[1:])
         seen = set()
         for desc, quads in hm.local:
-            assert desc.loop[5] == desc.loop[8]       # no gathers
+            assert desc.loop[5] == desc.loop[_lib.LP_COUNT]       # no gathers
             for M in quads[desc.loop[0]:desc.loop[5]]:
                 # recover the global mask from its tile coordinates
                 g = 0
@@ -232,6 +232,46 @@ def test_partitioned_plan_other_models(monkeypatch, model, P):
         for i, (partner, off, cnt) in enumerate(hm.recvs):
             run_remote(hm, i, x[partner * nloc + off:partner * nloc + off + cnt], yl)
         y[r * nloc:(r + 1) * nloc] = yl
+    ref = orc.matvec(omsc, orc.full(L), orc.full(L), x)
+    assert np.max(np.abs(y - ref)) <= 64 * len(arrs[0]) * EPS * np.abs(x).max() * max(1.0, np.abs(arrs[3]).max())
+
+
+@pytest.mark.parametrize("S", [5, 7, 9])
+@pytest.mark.parametrize("P", [1, 2, 4])
+@pytest.mark.parametrize("model", ["mbl", "ising"])
+def test_swizzled_layout_plan(monkeypatch, model, P, S):
+    """Vectors in the XOR-swizzled layout (dnm_subspace.vec_swizzle = S): the pass tables carry the shift and, for
+    partner passes, the constants of the sub-block offsets; local blocks are device images, the exchange ships
+    slices of them as they lie.  Result, un-swizzled, must equal the oracle's."""
+    from dynamite_amd.config import config
+    from plan_emulator import vec_pos
+    monkeypatch.setattr(config, "vec_swizzle", S)
+    L = 14
+    _cfg(monkeypatch, 8, 2, 2)
+    monkeypatch.setenv("DNM_GBITS", "3")
+    H = models.BY_NAME[model](L)
+    omsc, arrs = _orc_msc(H)
+    sub = Full(L=L)
+    assert sub._c().vec_swizzle == S
+    x = _rand(1 << L, 9)
+    nloc = (1 << L) // P
+    pos = vec_pos(np.arange(nloc), S)
+    assert not np.array_equal(pos, np.arange(nloc))
+    dev = []                                     # every rank's block as it lies in device memory
+    for r in range(P):
+        img = np.empty(nloc, dtype=complex)
+        img[pos] = x[r * nloc:(r + 1) * nloc]
+        dev.append(img)
+    y = np.zeros(1 << L, dtype=complex)
+    for r in range(P):
+        hm = HostMat(*arrs, sub._c(), sub._c(), rank=r, nranks=P)
+        assert all(p[0].swz_shift == S for p in hm.local + hm.remote)
+        yl = np.full(nloc, np.nan + 0j)
+        for p in hm.local:
+            run_pass(hm, p, dev[r], yl)
+        for i, (partner, off, cnt) in enumerate(hm.recvs):
+            run_remote(hm, i, dev[partner][off:off + cnt], yl)
+        y[r * nloc:(r + 1) * nloc] = yl[pos]
     ref = orc.matvec(omsc, orc.full(L), orc.full(L), x)
     assert np.max(np.abs(y - ref)) <= 64 * len(arrs[0]) * EPS * np.abs(x).max() * max(1.0, np.abs(arrs[3]).max())
 

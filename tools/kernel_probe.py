@@ -46,7 +46,7 @@ def main():
     config._initialize()
     dim = 1 << L
     sub = Full(L=L)
-    x, y = backend.Vec(dim), backend.Vec(dim)
+    x, y = backend.Vec(dim, swz=sub.vec_swizzle), backend.Vec(dim, swz=sub.vec_swizzle)
     x.set_random(0)
     ms = timeit(lambda: y.array.copy_(x.array))
     print("torch copy            %8.3f ms  %7.1f GB/s (r+w)" % (ms, 32.0 * dim / ms / 1e6), flush=True)

@@ -16,7 +16,7 @@ for L in [int(a) for a in sys.argv[1:]] or list(range(16, 31, 2)):
     sub = Full(L=L)
     mat = backend.build_mat(masks, offs, H.msc['signs'], H.msc['coeffs'], sub._to_c(), sub._to_c())
     dim = 1 << L
-    x, y = backend.Vec(dim), backend.Vec(dim)
+    x, y = mat.createVecs()
     x.set_random(0)
     n = 20 if L >= 26 else 200
     for _ in range(3):

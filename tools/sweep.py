@@ -46,14 +46,14 @@ def main():
         H.reduce_msc()
         return H
     dim = 1 << L
-    x, y = backend.Vec(dim), backend.Vec(dim)
+    x, y = backend.Vec(dim, swz=sub.vec_swizzle), backend.Vec(dim, swz=sub.vec_swizzle)
     x.set_random(0)
     x.normalize()
     ref = None
     for c in cfgs:
         flags = 0
         for k in list(os.environ):
-            if k.startswith("DNM_") and k not in ("DNM_FUZZ_N",):
+            if k.startswith("DNM_") and k not in ("DNM_FUZZ_N", "DNM_SWZ"):
                 os.environ.pop(k)
         for k, v in c.get("env", {}).items():
             os.environ[k] = str(v)
@@ -69,6 +69,7 @@ def main():
             if c.get("glds", 0):
                 flags |= _lib.MAT_USE_GLDS
         H = operator_for(c)
+        assert int(c.get("env", {}).get("DNM_SWZ", config.vec_swizzle)) == config.vec_swizzle, "one layout per process: export DNM_SWZ"
         masks, offs = msc_tools.get_mask_offsets(H.msc)
         mat = backend.build_mat(masks, offs, H.msc['signs'], H.msc['coeffs'], sub._to_c(), sub._to_c(),
                                 flags=flags)
