@@ -9,7 +9,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdynamite_amd.so")
-SOURCES = ["matvec_kernels.hip", "tile_pass2.hip", "vec_kernels.hip", "rdm_kernels.hip", "plan.cpp", "mat.cpp", "vec_api.cpp", "krylov.cpp"]
+SOURCES = ["matvec_kernels.hip", "tile_persist.hip", "vec_kernels.hip", "rdm_kernels.hip", "plan.cpp", "mat.cpp", "vec_api.cpp", "krylov.cpp"]
 ARCH = "gfx950"
 
 

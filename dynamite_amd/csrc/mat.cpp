@@ -370,6 +370,7 @@ static int build_pass(const dnm_mat &A, const PassSpec &ps, PassOnDevice *out) {
   out->h_quads = quads;
   if (!A.host_only) DNM_TRY(out->quads.upload(quads.data(), quads.size() * sizeof(DevQuad)));
   d.quads = (const DevQuad *)out->quads.p;
+  if (!A.host_only) DNM_TRY(out->desc_dev.upload(&d, sizeof(d)));
   out->partner = ps.partner;
   out->n_eff = n_eff;
   out->y_off = ps.y_off;
@@ -381,9 +382,9 @@ static hipStream_t S(void *stream) { return (hipStream_t)stream; }
 
 // tile_pass2_kernel wherever it has an instance for the pass geometry and the thread part of the tile coordinate
 // stays below index bit 28 (its 32-bit byte offsets); tile_pass_kernel otherwise (and with DNM_KERNEL=1 / GLDS)
-static bool pass_runs_on_v2(const dnm_mat *A, const DevPass &d) {
+static bool pass_runs_persistent(const dnm_mat *A, const DevPass &d) {
   if (A->plan.cfg.kernel != 2 || (A->flags & DNM_MAT_USE_GLDS)) return false;
-  if (!tile2_config_supported(d.tile_bits, d.log_rows)) return false;
+  if (!tile_persist_supported(d.tile_bits, d.log_rows)) return false;
   const int lognt = d.tile_bits - d.log_rows;
   for (int j = 0; j < d.nseg; ++j) {
     if (d.seg_off[j] >= lognt) continue;
@@ -393,10 +394,20 @@ static bool pass_runs_on_v2(const dnm_mat *A, const DevPass &d) {
   return true;
 }
 
-static int launch_pass(const dnm_mat *A, const DevPass &d, int n_eff, const void *x, void *y, const void *xr,
-                       hipStream_t st) {
-  if (pass_runs_on_v2(A, d)) return launch_tile_pass2(d, d.tile_bits, d.log_rows, n_eff, x, y, xr, st);
-  return launch_tile_pass(d, d.tile_bits, d.log_rows, (A->flags & DNM_MAT_USE_GLDS) != 0, n_eff, x, y, xr, st);
+// d: the pass descriptor with this call's fields filled in; p: the pass it was copied from
+static int launch_pass(const dnm_mat *A, const PassOnDevice &p, const DevPass &d, const void *x, void *y,
+                       const void *xr, hipStream_t st) {
+  if (pass_runs_persistent(A, d)) {
+    const PassCall call{d.dot_out, d.zinit, d.zscale, d.zinit2, d.z2re, d.z2im};
+    return launch_tile_persist((const DevPass *)p.desc_dev.p, call, d.tile_bits, d.log_rows, p.n_eff, x, y, xr, st);
+  }
+  return launch_tile_pass(d, d.tile_bits, d.log_rows, (A->flags & DNM_MAT_USE_GLDS) != 0, p.n_eff, x, y, xr, st);
+}
+
+// partial sums a pass writes to dot_out: one per tile, or one per resident workgroup
+static size_t pass_dot_partials(const dnm_mat *A, const PassOnDevice &p) {
+  if (pass_runs_persistent(A, p.desc)) return tile_persist_dot_partials(p.n_eff, p.desc.tile_bits, p.desc.log_rows);
+  return (size_t)1 << (p.n_eff - p.desc.tile_bits);
 }
 
 }  // namespace dnm
@@ -857,7 +868,7 @@ int dnm_mat_mult_local(dnm_mat *A, const void *x, void *y, void *stream) {
   DNM_CHECK(x != y, "x and y must be different vectors");
   if (A->hypercube && A->plan.use_tiled) {
     for (auto &p : A->local_passes)
-      DNM_TRY(launch_pass(A, p->desc, p->n_eff, x, y, nullptr, S(stream)));
+      DNM_TRY(launch_pass(A, *p, p->desc, x, y, nullptr, S(stream)));
     return 0;
   }
   DNM_CHECK(A->nranks == 1, "this subspace pair cannot run partitioned (use dnm_mat_mult_window)");
@@ -892,7 +903,7 @@ int dnm_mat_mult_lanczos(dnm_mat *A, const void *x, void *y, const void *z, doub
     return vec_lanczos_dot_host(y, z, x, A->m_local, b, dot, S(stream));
   }
   const bool fused_dot = A->local_passes.back()->desc.need_tile != 0;
-  const size_t nblk = (size_t)1 << (A->local_passes.back()->n_eff - A->local_passes.back()->desc.tile_bits);
+  const size_t nblk = pass_dot_partials(A, *A->local_passes.back());
   double *part = nullptr;
   if (fused_dot) DNM_TRY(vec_scratch((nblk + 1) * 3 * sizeof(double), &part));
   for (size_t i = 0; i < A->local_passes.size(); ++i) {
@@ -903,7 +914,7 @@ int dnm_mat_mult_lanczos(dnm_mat *A, const void *x, void *y, const void *z, doub
       d.zscale = b;
     }
     if (fused_dot && i + 1 == A->local_passes.size()) d.dot_out = part;
-    DNM_TRY(launch_pass(A, d, A->local_passes[i]->n_eff, x, y, nullptr, S(stream)));
+    DNM_TRY(launch_pass(A, *A->local_passes[i], d, x, y, nullptr, S(stream)));
   }
   if (!fused_dot) return vec_lanczos_dot_host(y, nullptr, x, A->m_local, 0.0, dot, S(stream));
   DNM_TRY(vk_reduce_partials(part, (int)nblk, 3, part + 3 * nblk, S(stream)));
@@ -938,7 +949,7 @@ int dnm_mat_mult_sub2(dnm_mat *A, const void *x, void *y, const void *z, double 
         d.z2re = c_re;
         d.z2im = c_im;
       }
-      DNM_TRY(launch_pass(A, d, A->local_passes[i]->n_eff, x, y, nullptr, S(stream)));
+      DNM_TRY(launch_pass(A, *A->local_passes[i], d, x, y, nullptr, S(stream)));
     }
     return 0;
   }
@@ -1033,7 +1044,7 @@ int dnm_mat_mult_remote(dnm_mat *A, int32_t recv_index, const void *x_recv, void
   DNM_CHECK(recv_index >= 0 && recv_index < (int)A->remote_passes.size(), "rank %d has no receive %d", A->rank,
             recv_index);
   const auto &p = A->remote_passes[recv_index];
-  return launch_pass(A, p->desc, p->n_eff, x_recv, (char *)y + (size_t)p->y_off * 16, x_recv, S(stream));
+  return launch_pass(A, *p, p->desc, x_recv, (char *)y + (size_t)p->y_off * 16, x_recv, S(stream));
 }
 
 int dnm_mat_norm_inf(dnm_mat *A, double *nrm, void *stream) {

@@ -37,6 +37,7 @@ struct PassOnDevice {
   DevPass desc{};
   std::vector<DevQuad> h_quads;   // host copy (diagnostics / host-only handles)
   DevBuf quads;
+  DevBuf desc_dev;                // the descriptor in device memory (persistent kernel)
   int partner = -1;
   int n_eff = 0;                  // index bits the pass sweeps
   int64_t y_off = 0, src_off = 0; // partner passes: first local row / first partner amplitude
