@@ -32,31 +32,53 @@ HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 ALG_BYTES_PER_AMP = 32.0  # read x once + write y once
 
 
-def cpu_baseline(sample_L=27, reps=3):
-    """Oracle (C restatement of the reference's MatMult_CPU_Fast) timed on this
-    box's host cores; a reported baseline, not the target."""
+def cpu_baseline(sample_L=26, reps=3):
+    """Oracle (C restatement of the reference's MatMult_CPU_Fast: 2^11-row blocks, unswitched sum_term loops,
+    contiguous-run do_cache_product, bpetsc_template_2.c:598-683, 713-889) timed on this box's host cores; a
+    reported baseline, not the target.  Sample: L=26 (BASELINE.md section 5's CPU size) on all cores, plus a
+    one-thread run at L=24 so that the per-core rate can be set against SURVEY section 6's anchor for the genuine
+    reference C (4.3-6.8 Mamp/s per core); DNM_BENCH_CPU_L30=1 adds one multiply at the headline size."""
     import numpy as np
     from oracle import oracle as orc
     from dynamite_amd import models, msc_tools
-    H = models.mbl(sample_L)
-    H.reduce_msc()
-    masks, offs = msc_tools.get_mask_offsets(H.msc)
-    msc = orc.Msc(masks, offs, H.msc['signs'], H.msc['coeffs'])
-    sub = orc.full(sample_L)
-    n = 1 << sample_L
-    rs = np.random.RandomState(0)
-    x = rs.standard_normal(n) + 1j * rs.standard_normal(n)
-    out = np.empty(n, dtype=np.complex128)
+
+    def time_one(L, nt, reps):
+        H = models.mbl(L)
+        H.reduce_msc()
+        masks, offs = msc_tools.get_mask_offsets(H.msc)
+        msc = orc.Msc(masks, offs, H.msc['signs'], H.msc['coeffs'])
+        sub = orc.full(L)
+        n = 1 << L
+        x = np.empty(n, dtype=np.complex128)
+        x.real = (np.arange(n, dtype=np.int64) % 1021 - 510) * (1.0 / 512)        # cheap, non-trivial amplitudes
+        x.imag = (np.arange(n, dtype=np.int64) % 509 - 254) * (1.0 / 256)
+        out = np.zeros(n, dtype=np.complex128)          # pages touched before the clock starts
+        best = float('inf')
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            orc.matvec(msc, sub, sub, x, nthreads=nt, out=out)
+            best = min(best, time.perf_counter() - t0)
+        return n / best, best
+
     nt = orc.max_threads()
-    best = float('inf')
-    for _ in range(reps):
-        t0 = time.perf_counter()
-        orc.matvec(msc, sub, sub, x, nthreads=nt, out=out)
-        best = min(best, time.perf_counter() - t0)
-    return {"value": n / best / 1e9, "unit": "Gamplitudes/s", "cores": nt, "kind": "port",
-            "sample": f"L={sample_L} random-field Heisenberg, Full space, best of {reps} multiplies "
-                      f"({best:.2f} s each) of the oracle's MatMult_CPU_Fast restatement, "
-                      f"2^11-row blocks over {nt} OpenMP threads"}
+    rate, best = time_one(sample_L, nt, reps)
+    rate1, best1 = time_one(24, 1, 1)
+    out = {"value": rate / 1e9, "unit": "Gamplitudes/s", "cores": nt, "kind": "port",
+           "per_core_Mamp_s": rate / nt / 1e6, "one_thread_Mamp_s": rate1 / 1e6,
+           "reference_anchor_Mamp_s_per_core": [4.3, 6.8],
+           "sample": f"L={sample_L} random-field Heisenberg, Full space, best of {reps} multiplies ({best:.2f} s each) "
+                     f"of the oracle's MatMult_CPU_Fast restatement on {nt} OpenMP threads = {rate / nt / 1e6:.2f} "
+                     f"Mamp/s per thread; one thread at L=24: {best1:.2f} s = "
+                     f"{rate1 / 1e6:.2f} Mamp/s, against 4.3-6.8 Mamp/s per core measured for the reference's own C "
+                     f"(SURVEY section 6)"}
+    if os.environ.get("DNM_BENCH_CPU_L30"):
+        try:
+            r30, b30 = time_one(30, nt, 1)
+            out["L30_Gamp_s"] = r30 / 1e9
+            out["sample"] += f"; L=30, one multiply: {b30:.2f} s = {r30 / 1e9:.3f} Gamp/s"
+        except MemoryError:
+            pass
+    return out
 
 
 XGMI_LINK_GBS = 64.0      # assumed sustained one-direction rate of one xGMI link (spec 153 GB/s bidirectional per

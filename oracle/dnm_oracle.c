@@ -237,36 +237,64 @@ static void build_lookup(orc_int *tab, int with_parity, orc_int space)
     }
 }
 
-/* sum_term (:637-683): add +-coeff (as a real or an imaginary number) into
- * the per-row coefficient buffer; the sign of row `block_start+c` under sign
- * mask `s` is split into a 64x64 lookup on the low 6 bits and a parity on
- * the rest; check_parity adds the Parity-subspace dropped-bit correction. */
+/* sum_term (:637-683): add +-coeff (as a real or an imaginary number) into the per-row coefficient buffer.
+ * The sign of row `block_start + c` under sign mask `s` splits into a parity of the bits above the low 6
+ * (constant over a run of 64 rows) and a 64x64 lookup on the low 6; check_parity adds the Parity-subspace
+ * dropped-bit correction.  As in the reference the loop is unswitched by hand over (real | imaginary) x
+ * (lookup needed | sign mask clear on the low 6 bits | parity lookup): six loop nests whose inner loop over 64
+ * rows has no branch, so this leg is a fair stand-in for the reference's cost per term. */
+#define ORC_SUM_LOOP(SIGN_OF_J, ADD_STMT, WITH_PARITY)                          \
+  for (orc_int c = 0; c < BLK; c += LKP) {                                      \
+    const orc_int hi = (c + block_start) & ~LKPM;                               \
+    int flip = par64(hi & s);                                                   \
+    if (WITH_PARITY) flip ^= par64(hi);                                         \
+    const double v = flip ? -coeff : coeff;                                     \
+    orc_cplx *a = acc + c;                                                      \
+    for (orc_int j = 0; j < LKP; ++j) {                                         \
+      const double w = (double)(SIGN_OF_J) * v;                                 \
+      ADD_STMT;                                                                 \
+    }                                                                           \
+  }
+
 static void add_term(orc_int block_start, orc_int s, int is_real, double coeff,
                      int check_parity, const orc_int *tab, orc_cplx *acc)
 {
   const orc_int *row = tab + (s & LKPM) * LKP;
-  int trivial = !check_parity && !(s & LKPM);
-  for (orc_int c = 0; c < BLK; c += LKP) {
-    orc_int hi = (c + block_start) & ~LKPM;
-    int flip = par64(hi & s);
-    if (check_parity) flip ^= par64(hi);
-    double v = flip ? -coeff : coeff;
-    for (orc_int j = 0; j < LKP; ++j) {
-      double w = trivial ? v : (double)row[j] * v;
-      if (is_real) acc[c + j] += w; else acc[c + j] += I * w;
-    }
+  if (check_parity) {
+    if (is_real) { ORC_SUM_LOOP(row[j], a[j] += w, 1) }
+    else         { ORC_SUM_LOOP(row[j], a[j] += I * w, 1) }
+  } else if (s & LKPM) {
+    if (is_real) { ORC_SUM_LOOP(row[j], a[j] += w, 0) }
+    else         { ORC_SUM_LOOP(row[j], a[j] += I * w, 0) }
+  } else {
+    if (is_real) { ORC_SUM_LOOP(1, a[j] += w, 0) }
+    else         { ORC_SUM_LOOP(1, a[j] += I * w, 0) }
   }
 }
+#undef ORC_SUM_LOOP
 
-/* do_cache_product (:598-635): values[c] += acc[c] * x[(block_start+c)^m].
- * (The reference special-cases contiguous runs of 2^ctz(m); arithmetic is
- * identical element by element.) */
+/* do_cache_product (:598-635): values[c] += acc[c] * x[(block_start + c) ^ m].  XOR with m maps an aligned run
+ * of 2^ctz(m) consecutive rows onto consecutive columns, so for runs of at least ITER_CUTOFF (8, :515) the
+ * reference walks run by run with unit-stride inner loops; shorter runs take the element-wise loop. */
+#define ITER_CUTOFF 8
 static void apply_mask(orc_int m, orc_int block_start, orc_int x_start,
                        const orc_cplx *acc, const orc_cplx *xloc, orc_cplx *vals)
 {
-  for (orc_int c = 0; c < BLK; ++c) {
-    orc_int r = (block_start + c) ^ m;
-    vals[c] += acc[c] * xloc[r - x_start];
+  const orc_int run = m ? ((orc_int)1 << ctz64(m)) : BLK;
+  if (run < ITER_CUTOFF) {
+    for (orc_int c = 0; c < BLK; ++c) {
+      orc_int r = (block_start + c) ^ m;
+      vals[c] += acc[c] * xloc[r - x_start];
+    }
+    return;
+  }
+  for (orc_int c = 0; c < BLK;) {
+    const orc_int r = (block_start + c) ^ m;
+    orc_int stop = run - (r % run);
+    if (stop > BLK - c) stop = BLK - c;
+    const orc_cplx *xs = xloc + (r - x_start);
+    for (orc_int j = 0; j < stop; ++j) vals[c + j] += acc[c + j] * xs[j];
+    c += stop;
   }
 }
 

@@ -1,0 +1,175 @@
+"""
+BASELINE configs 4 and 5 at their full per-rank size on ONE GPU (the 8-GPU runs are the driver's):
+
+* config 4 -- L=34 Heisenberg, Full space, 8 ranks: one rank's share is a 2^31-amplitude block (32 GiB).  The
+  rank-local passes plus every partner pass (partner sub-blocks generated in place, as the exchange would ship
+  them) are checked on sampled rows -- on both sides of every power-of-two boundary of the local index, so tile,
+  XCD-group, window, swizzle-field and rank-bit edges are all hit -- against the MSC definition
+  (reference semantics: src/dynamite/_backend/bpetsc_template_2.c:371-412; the reference's own large-index
+  tests: tests/integration/test_matrices.py:183-232, int64 masks and signs above bit 31).
+* config 5 -- L=36 SpinConserve k=18, 8 ranks: rank 3's rows (1.13 G) through its 4.1x column window, block kernel
+  against the row kernel element-wise and against the MSC definition on sampled rows
+  (bsubspace_impl.h:187-245 maps, PetscSplitOwnership blocks).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from dynamite_amd import _lib, backend, models
+from dynamite_amd.subspaces import Full, SpinConserve
+from gpu_util import marshal
+
+pytestmark = [pytest.mark.gpu, pytest.mark.default_layout]
+
+
+def _need(nbytes):
+    import torch
+    free, _ = torch.cuda.mem_get_info()
+    if free < nbytes:
+        pytest.skip("needs %.0f GiB of free HBM" % (nbytes / 2**30))
+
+
+def _boundary_rows(nbits, rs, nrand=48):
+    rows = [0, (1 << nbits) - 1]
+    for b in range(1, nbits):
+        low = int(rs.randint(0, 1 << min(b, 30)))
+        rows += [(1 << b) - 1, 1 << b, ((1 << nbits) - 1) ^ (1 << b),
+                 (int(rs.randint(0, 1 << min(nbits - b, 30))) << b | low) & ((1 << nbits) - 1)]
+    rows += [int(v) for v in rs.randint(0, 1 << 30, nrand) * 2 + rs.randint(0, 2, nrand)]
+    return np.unique(np.array(rows, dtype=np.int64) & ((1 << nbits) - 1))
+
+
+@pytest.mark.parametrize("rank", [0, 5])
+def test_config4_one_rank_of_eight(rank):
+    """One rank of L=34 / P=8: n_loc = 31, masks and signs reach bit 33."""
+    import torch
+    L, P, seed = 34, 8, 11
+    nl = L - 3
+    nloc = 1 << nl
+    H = models.heisenberg(L)
+    arrs = marshal(H)
+    masks, offs, signs, coeffs = arrs
+    sub = Full(L=L)
+    h = backend.create_mat(*arrs, sub._c(), sub._c(), flags=0, rank=rank, nranks=P)
+    mat = backend.ShellMat(h, sub._c(), sub._c(), P, rank)
+    recv_bytes = sum(16 * cnt for _, _, cnt in mat.recvs)
+    _need(2 * 16 * nloc + recv_bytes + (4 << 30))
+    assert "n_loc=31" in mat.describe() and mat.swz_right == sub.vec_swizzle
+
+    # x is a function of the GLOBAL index (counter-based generator keyed by it): every rank's block and every
+    # shipped sub-block can be produced where it is needed
+    def block(n, first_global):
+        v = backend.Vec(n, swz=sub.vec_swizzle)
+        v.start = first_global
+        v.set_random(seed)
+        return v
+    xl = block(nloc, rank * nloc)
+    yl = backend.Vec(nloc, swz=sub.vec_swizzle)
+    Lb = _lib.lib()
+    _lib.check(Lb.dnm_mat_mult_local(mat.handle, xl.ptr, yl.ptr, None))
+    bufs = []
+    for i, (p, off, cnt) in enumerate(mat.recvs):
+        # the slice [off, off + cnt) of partner p's device array: its position j holds the partner's local
+        # element off + vec_pos(j) (the sub-block offset lies above the swizzle field)
+        assert off % cnt == 0 and cnt >= 1 << (2 * sub.vec_swizzle - 4)
+        b = block(cnt, p * nloc + off)
+        bufs.append(b)
+        _lib.check(Lb.dnm_mat_mult_remote(mat.handle, i, b.ptr, yl.ptr, None))
+    torch.cuda.synchronize()
+    # rank 5 = 101b: the boundary bond ships half a block, each rank-bit bond (bits differ) a whole one
+    want = {0: 1, 5: 5}[rank]
+    assert len(mat.recvs) == want, mat.recvs
+
+    def fetch(g):
+        r, loc = int(g) >> nl, int(g) & (nloc - 1)
+        if r == rank:
+            return complex(xl.array[xl.positions(loc)].item())
+        for (p, off, cnt), b in zip(mat.recvs, bufs):
+            if p == r and off <= loc < off + cnt:
+                return complex(b.array[b.positions(loc - off)].item())
+        return None
+
+    rs = np.random.RandomState(3 + rank)
+    rows = _boundary_rows(nl, rs)
+    worst, scale = 0.0, 0.0
+    ys = yl.array[yl.positions(torch.from_numpy(rows).to(yl.array.device))].cpu().numpy()
+    for yv, row in zip(ys, rows):
+        g = (rank << nl) | int(row)
+        acc = 0j
+        for m in range(len(masks)):
+            col = g ^ int(masks[m])
+            c = 0j
+            for t in range(offs[m], offs[m + 1]):
+                c += (1 - 2 * (bin(col & int(signs[t])).count("1") & 1)) * coeffs[t]
+            if c == 0:
+                continue
+            xv = fetch(col)
+            assert xv is not None, ("a column with a non-zero matrix element was not shipped", row, m)
+            acc += c * xv
+        worst = max(worst, abs(acc - yv))
+        scale = max(scale, abs(acc))
+    assert worst <= 1e-13 * max(1.0, scale) * len(masks), (worst, scale)
+    mat.destroy()
+
+
+def test_config5_rank3_of_eight(monkeypatch):
+    """One rank of L=36, k=18 on 8 ranks: uneven PETSc-style ownership, device-computed column window, block
+    kernel against the row kernel and against the definition."""
+    import torch
+    L, k, P, R = 36, 18, 8, 3
+    sub = SpinConserve(L, k)
+    dim = sub.get_dimension()
+    H = models.heisenberg(L)
+    arrs = marshal(H)
+    masks, offs, signs, coeffs = arrs
+    start, n = backend.split_ownership(dim, P, R)
+    _need(16 * (5 * n + 2 * n) + 8 * n + (6 << 30))
+    Lb = _lib.lib()
+    out = {}
+    xw = None
+    for blk in ("13", "0"):
+        monkeypatch.setenv("DNM_SC_BLOCK", blk)
+        h = backend.create_mat(*arrs, sub._c(), sub._c(), flags=0, rank=R, nranks=P)
+        mat = backend.ShellMat(h, sub._c(), sub._c(), P, R)
+        assert ("block form" in mat.describe()) == (blk == "13")
+        assert (mat.row0, mat.m_local) == (start, n)
+        mat.precompute_diagonal()
+        lo, hi = mat.column_window()
+        assert 0 <= lo <= start and start + n - 1 <= hi < dim
+        if xw is None:
+            xw = backend.Vec(hi - lo + 1)
+            xw.set_random(3)
+            win = (lo, hi)
+        assert (lo, hi) == win
+        y = backend.Vec(n)
+        _lib.check(Lb.dnm_mat_mult_window(mat.handle, xw.ptr, lo, hi - lo + 1, y.ptr, None))
+        torch.cuda.synchronize()
+        out[blk] = y
+        mat.destroy()
+    # sampled rows against the definition (maps from the C library on the host)
+    rs = np.random.RandomState(1)
+    rows = np.unique(np.concatenate([[0, n - 1], rs.randint(0, 1 << 30, 64) % n,
+                                     [(n >> s) for s in range(1, 30)]])).astype(np.int64)
+    kets = sub.idx_to_state(rows + start)
+    ys = out["13"].array[torch.from_numpy(rows).to(xw.array.device)].cpu().numpy()
+    worst, scale = 0.0, 0.0
+    for yv, ket in zip(ys, kets):
+        acc = 0j
+        bras = int(ket) ^ masks
+        cols = sub.state_to_idx(bras)
+        for m in range(len(masks)):
+            if cols[m] < 0:
+                continue
+            c = 0j
+            for t in range(offs[m], offs[m + 1]):
+                c += (1 - 2 * (bin(int(bras[m]) & int(signs[t])).count("1") & 1)) * coeffs[t]
+            assert lo <= cols[m] <= hi or c == 0
+            if c != 0:
+                acc += c * complex(xw.array[int(cols[m]) - lo].item())
+        worst = max(worst, abs(acc - yv))
+        scale = max(scale, abs(acc))
+    assert worst <= 1e-13 * max(1.0, scale) * len(masks), (worst, scale)
+    ynorm = out["13"].norm()
+    out["0"].axpby(-1.0, 1.0, out["13"])
+    assert out["0"].norm() <= 1e-13 * ynorm
