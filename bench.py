@@ -49,10 +49,8 @@ def cpu_baseline(sample_L=26, reps=3):
         msc = orc.Msc(masks, offs, H.msc['signs'], H.msc['coeffs'])
         sub = orc.full(L)
         n = 1 << L
-        x = np.empty(n, dtype=np.complex128)
-        x.real = (np.arange(n, dtype=np.int64) % 1021 - 510) * (1.0 / 512)        # cheap, non-trivial amplitudes
-        x.imag = (np.arange(n, dtype=np.int64) % 509 - 254) * (1.0 / 256)
-        out = np.zeros(n, dtype=np.complex128)          # pages touched before the clock starts
+        x, out = np.empty(n, dtype=np.complex128), np.empty(n, dtype=np.complex128)
+        orc.fill_test_vectors(x, out, nt)      # cheap non-trivial amplitudes; pages first touched by the workers
         best = float('inf')
         for _ in range(reps):
             t0 = time.perf_counter()

@@ -387,10 +387,12 @@ class ShellMat:
         d = self.describe()
         if 'SpinConserve kernel' in d:
             return True
-        return self.nranks == 1 and 'row-gather kernel' in d
+        return 'row-gather kernel' in d
 
     def _is_windowed(self):
-        return 'SpinConserve kernel' in self.describe()
+        """Partitions other than Full/Parity on 2^p ranks: rows split in index order (PetscSplitOwnership), the
+        columns a rank reads come through a window gathered from its neighbours."""
+        return 'tiled=1' not in self.describe()
 
     def column_window(self):
         lo, hi = C.c_int64(), C.c_int64()
@@ -406,7 +408,8 @@ class ShellMat:
             dist.all_gather_object(allw, mine)
             self._windows = allw
             self._owned = [split_ownership(self.N, self.nranks, q) for q in range(self.nranks)]
-        self._window_buf = exchange_window(x.array, self._owned, self._windows, self.rank, self._window_buf)
+        # the window is in index order: a swizzled block is straightened first (projection pairs)
+        self._window_buf = exchange_window(x.local_natural(), self._owned, self._windows, self.rank, self._window_buf)
         w0 = self._windows[self.rank][0]
         _lib.check(_lib.lib().dnm_mat_mult_window(self.handle, C.c_void_p(self._window_buf.data_ptr()), w0,
                                                   self._window_buf.numel(), y.ptr, _stream()))

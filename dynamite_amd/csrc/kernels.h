@@ -41,9 +41,13 @@ int launch_tile_persist(const DevPass *P_dev, const PassCall &call, int B, int l
 
 // y (+)= H x by one thread per row with index maps (MatMult semantics of
 // bcuda_template_2.cu:200-273 / bpetsc_template_2.c:371-412).
+// Rows [row0, row0 + M); x holds the columns [win_start, ...) in the layout xswz (-1: the right subspace's own);
+// colrange != null: no multiply, per-workgroup (min, max) of the columns touched (2 * gather_num_blocks(M) int64).
+int gather_num_blocks(int64_t M);
 int launch_gather_matvec(const DevMsc &msc, const SubView &left, const SubView &right,
                          int64_t M, const double *diag, const void *x, void *y,
-                         hipStream_t st);
+                         hipStream_t st, int64_t row0 = 0, int64_t win_start = 0, int xswz = -1,
+                         int64_t *colrange = nullptr);
 
 // Per-mask precomputation for the SpinConserve kernel.  fast != 0: the mask is a
 // bond of two adjacent spins (3 << lo) whose sign masks all lie inside the bond,

@@ -699,21 +699,24 @@ int dnm_mat_create(int64_t nmasks, const int64_t *masks, const int64_t *mask_off
   A->hypercube = (lt == rt) && (lt == DNM_FULL || lt == DNM_PARITY);
   A->sc_pair = lt == DNM_SPIN_CONSERVE && rt == DNM_SPIN_CONSERVE && A->left.host.k == A->right.host.k &&
                !(flags & DNM_MAT_FORCE_GATHER);
-  if (A->nranks > 1) {
-    DNM_CHECK(A->hypercube || A->sc_pair,
-              "partitioned multiply needs Full/Full, Parity/Parity or SpinConserve/SpinConserve subspaces");
-    if (A->hypercube) {
-      DNM_CHECK((A->nranks & (A->nranks - 1)) == 0, "nranks must be a power of two for Full/Parity");
-      DNM_CHECK(A->M % A->nranks == 0, "dimension not divisible by nranks");
-    }
+  if (A->nranks > 1 && A->hypercube && ((A->nranks & (A->nranks - 1)) != 0 || A->M % A->nranks != 0)) {
+    // Full / Parity on a rank count that is not a power of two: blocks are not subcubes, so the XOR-partner
+    // exchange does not apply -- rows are split as PetscSplitOwnership does and the generic row kernel reads
+    // its columns through a window (MatMult_CPU_General's MPI branch, bpetsc_template_2.c:413-504)
+    A->hypercube = false;
+  }
+  if (A->nranks > 1 && !A->hypercube) {
+    // rows of a window partition are index-ordered blocks of any size: swizzled blocks need power-of-two sizes
+    DNM_CHECK(A->left.host.swz == 0 || (A->M % A->nranks == 0 && ((A->M / A->nranks) & (A->M / A->nranks - 1)) == 0),
+              "swizzled left vectors need power-of-two blocks (use vec_swizzle = 0 for this partition)");
   }
   // PetscSplitOwnership: M / P rows each, the first M % P ranks one more
   {
     const int64_t q = A->M / A->nranks, rem = A->M % A->nranks;
     A->m_local = q + (A->rank < rem ? 1 : 0);
     A->row0 = (int64_t)A->rank * q + std::min<int64_t>(A->rank, rem);
-    A->n_local = A->m_local;
-    if (A->M != A->N) A->n_local = A->N / A->nranks;
+    const int64_t qn = A->N / A->nranks, remn = A->N % A->nranks;
+    A->n_local = qn + (A->rank < remn ? 1 : 0);
   }
 
   // tables for the generic kernels (always: norm and diagonal use them)
@@ -798,9 +801,11 @@ int dnm_mat_create(int64_t nmasks, const int64_t *masks, const int64_t *mask_off
     }
     DNM_TRY(make_plan(A->op, A->rank, A->nranks, cfg, &A->plan));
     if (flags & DNM_MAT_FORCE_GATHER) A->plan.use_tiled = false;
-    if (A->nranks > 1)
-      DNM_CHECK(A->plan.use_tiled, "local vector (2^%d) smaller than one tile (2^%d)", A->plan.n_loc,
-                A->plan.cfg.B);
+    if (A->nranks > 1 && !A->plan.use_tiled) {
+      // blocks smaller than one tile (or DNM_MAT_FORCE_GATHER): the window partition of the row kernel
+      A->plan.remote.clear();
+      A->plan.sends.clear();
+    }
     if (A->plan.use_tiled) {
       for (const PassSpec &ps : A->plan.local) {
         std::unique_ptr<PassOnDevice> p(new PassOnDevice());
@@ -837,7 +842,8 @@ int dnm_mat_precompute_diagonal(dnm_mat *A, void *stream) {
   // only when the first mask is the identity (bpetsc_template_1.c:177-180) and
   // left == right (operators.py:627-629; the caller guarantees it)
   if (A->masks.empty() || A->masks[0] != 0) return 0;
-  DNM_CHECK(A->nranks == 1 || A->sc_pair, "precomputed diagonal is not used by the partitioned tiled multiply");
+  DNM_CHECK(A->nranks == 1 || !(A->hypercube && A->plan.use_tiled),
+            "precomputed diagonal is not used by the partitioned tiled multiply");
   DNM_CHECK(A->M == A->N, "precompute_diagonal needs a square matrix");
   DNM_TRY(A->diag.alloc((size_t)A->m_local * sizeof(double)));
   DNM_TRY(launch_diag(A->dmsc, A->right.dev, A->m_local, A->row0, (double *)A->diag.p, S(stream)));
@@ -992,17 +998,23 @@ int dnm_mat_ownership(const dnm_mat *A, int64_t *row0, int64_t *m_local) {
 
 int dnm_mat_column_window(dnm_mat *A, int64_t *cmin, int64_t *cmax, void *stream) {
   DNM_CHECK(A && cmin && cmax && !A->host_only, "bad argument");
-  DNM_CHECK(A->sc_pair, "column windows are defined for SpinConserve/SpinConserve matrices");
+  DNM_CHECK(!(A->hypercube && A->plan.use_tiled), "Full/Parity partitions on 2^p ranks exchange partner blocks, not windows");
   if (A->win_max < A->win_min) {
-    const int nb = sc_num_blocks(A->m_local);
+    const int nb = A->sc_pair ? sc_num_blocks(A->m_local) : gather_num_blocks(A->m_local);
     DevBuf buf;
     DNM_TRY(buf.alloc((size_t)nb * 2 * sizeof(int64_t)));
-    DNM_TRY(launch_sc_matvec(A->dmsc, (const ScMask *)A->d_scmasks.p, A->sclow, A->right.dev, A->m_local, A->row0, 0,
-                             nullptr, nullptr, nullptr, (int64_t *)buf.p, S(stream)));
+    if (A->sc_pair)
+      DNM_TRY(launch_sc_matvec(A->dmsc, (const ScMask *)A->d_scmasks.p, A->sclow, A->right.dev, A->m_local, A->row0,
+                               0, nullptr, nullptr, nullptr, (int64_t *)buf.p, S(stream)));
+    else
+      DNM_TRY(launch_gather_matvec(A->dmsc, A->left.dev, A->right.dev, A->m_local, nullptr, nullptr, nullptr,
+                                   S(stream), A->row0, 0, 0, (int64_t *)buf.p));
     std::vector<int64_t> h((size_t)nb * 2);
     DNM_TRY(dnm_memcpy_d2h(h.data(), buf.p, h.size() * sizeof(int64_t), stream));
-    int64_t lo = A->row0, hi = A->row0 + A->m_local - 1;
+    // (a SpinConserve pair always reads its own rows' columns; a general pair reads what its masks reach)
+    int64_t lo = A->sc_pair ? A->row0 : INT64_MAX, hi = A->sc_pair ? A->row0 + A->m_local - 1 : INT64_MIN;
     for (int b = 0; b < nb; ++b) { lo = std::min(lo, h[2 * b]); hi = std::max(hi, h[2 * b + 1]); }
+    if (hi < lo) lo = hi = 0;          // no matrix element at all in these rows
     A->win_min = lo;
     A->win_max = hi;
   }
@@ -1014,13 +1026,16 @@ int dnm_mat_column_window(dnm_mat *A, int64_t *cmin, int64_t *cmax, void *stream
 int dnm_mat_mult_window(dnm_mat *A, const void *x_window, int64_t win_start, int64_t win_len, void *y_local,
                         void *stream) {
   DNM_CHECK(A && x_window && y_local && !A->host_only, "bad argument");
-  DNM_CHECK(A->sc_pair, "dnm_mat_mult_window needs a SpinConserve/SpinConserve matrix");
   int64_t lo, hi;
   DNM_TRY(dnm_mat_column_window(A, &lo, &hi, stream));
   DNM_CHECK(win_start <= lo && win_start + win_len > hi,
             "window [%lld, %lld) does not cover the columns [%lld, %lld] this rank reads", (long long)win_start,
             (long long)(win_start + win_len), (long long)lo, (long long)hi);
-  return launch_sc(A, win_start, win_len, x_window, y_local, stream);
+  if (A->sc_pair) return launch_sc(A, win_start, win_len, x_window, y_local, stream);
+  // any other subspace pair: one thread per row, columns read from the window (index order)
+  return launch_gather_matvec(A->dmsc, A->left.dev, A->right.dev, A->m_local,
+                              A->have_diag ? (const double *)A->diag.p : nullptr, x_window, y_local, S(stream),
+                              A->row0, win_start, 0, nullptr);
 }
 
 int dnm_mat_exchange_plan(const dnm_mat *A, int *nsend, dnm_xfer *sends, int *nrecv, dnm_xfer *recvs) {
@@ -1081,7 +1096,8 @@ int dnm_mat_plan_describe(const dnm_mat *A, char *buf, size_t buflen) {
     s = A->scblock.lb ? "SpinConserve kernel, block form (" + std::to_string(A->scblock.lb) +
                             " low bits per workgroup in LDS, high bonds as block runs)\n"
                       : std::string("SpinConserve kernel (one row per thread, incremental colex rank)\n");
-  else s = "generic row-gather kernel (non-hypercube subspace pair)\n";
+  else s = A->nranks > 1 ? "generic row-gather kernel (rows split in index order, columns through a window)\n"
+                         : "generic row-gather kernel (non-hypercube subspace pair)\n";
   if (A->hypercube && !A->plan.use_tiled) s += "generic row-gather kernel in use\n";
   snprintf(buf, buflen, "%s", s.c_str());
   return 0;

@@ -482,46 +482,78 @@ __device__ __forceinline__ SubView stage_sub(const SubView &s, int64_t *lds_tab,
 
 constexpr int GATHER_NT = 256;
 
+// Rows [row0, row0 + M) of the matrix (a rank's block); x holds the columns [win_start, ...) in the layout xswz
+// (one rank: the whole right vector in its own layout; partitioned: the rank's column window in index order);
+// y and diag are local (index row - row0).  colrange != nullptr: no multiply, only the min / max column each
+// workgroup touches (2 int64 per workgroup) -- how a partition finds its column window.
 template <int LT, int RT>
 __global__ void __launch_bounds__(GATHER_NT)
-gather_matvec_kernel(const DevMsc msc, const SubView left_g, const SubView right_g, int64_t M,
-                     const double *__restrict__ diag, const c128 *__restrict__ x,
-                     c128 *__restrict__ y) {
+gather_matvec_kernel(const DevMsc msc, const SubView left_g, const SubView right_g, int64_t M, int64_t row0,
+                     int64_t win_start, int xswz, const double *__restrict__ diag, const c128 *__restrict__ x,
+                     c128 *__restrict__ y, int64_t *__restrict__ colrange) {
   __shared__ int64_t nck[NCK_LDS_MAX];
   int used = 0;
   const SubView left = stage_sub<LT>(left_g, nck, used);
   const SubView right = stage_sub<RT>(right_g, nck, used);
   if (used) __syncthreads();
 
-  const int64_t row = (int64_t)blockIdx.x * GATHER_NT + threadIdx.x;
-  if (row >= M) return;
-  const int64_t ket = Sub<LT>::i2s(row, left);
-  double accr = 0.0, acci = 0.0;
-  int m0 = 0;
-  if (diag) {   // bcuda_template_2.cu:230-236
-    c128 xs = x[vec_pos(row, right.swz)];
-    accr = diag[row] * xs.x;
-    acci = diag[row] * xs.y;
-    m0 = 1;
-  }
-  for (int m = m0; m < msc.nmasks; ++m) {
-    const int64_t mask = msc.masks[m];
-    const int64_t bra = ket ^ mask;
-    const int64_t col = Sub<RT>::s2i(bra, right);
-    if (col < 0) continue;   // projection semantics
-    double cre = 0.0, cim = 0.0;
-    for (int64_t t = msc.mask_offsets[m]; t < msc.mask_offsets[m + 1]; ++t) {
-      const int64_t sg = msc.signs[t];
-      const double c = flip_sign(msc.real_coeffs[t], (uint32_t)__popcll((uint64_t)(bra & sg)) & 1u);
-      if (__popcll((uint64_t)(mask & sg)) & 1) cim += c; else cre += c;   // TERM_REAL
+  const int64_t lrow = (int64_t)blockIdx.x * GATHER_NT + threadIdx.x;
+  const bool active = lrow < M;
+  if (!active && !colrange) return;
+  const int64_t row = row0 + lrow;
+  int64_t cmin = INT64_MAX, cmax = INT64_MIN;
+  if (active) {
+    const int64_t ket = Sub<LT>::i2s(row, left);
+    double accr = 0.0, acci = 0.0;
+    int m0 = 0;
+    if (diag && !colrange) {   // bcuda_template_2.cu:230-236
+      c128 xs = x[vec_pos(row, xswz) - win_start];
+      accr = diag[lrow] * xs.x;
+      acci = diag[lrow] * xs.y;
+      m0 = 1;
     }
-    const c128 xv = x[vec_pos(col, right.swz)];
-    accr = fma(cre, xv.x, accr);
-    acci = fma(cre, xv.y, acci);
-    accr = fma(-cim, xv.y, accr);
-    acci = fma(cim, xv.x, acci);
+    for (int m = m0; m < msc.nmasks; ++m) {
+      const int64_t mask = msc.masks[m];
+      const int64_t bra = ket ^ mask;
+      const int64_t col = Sub<RT>::s2i(bra, right);
+      if (col < 0) continue;   // projection semantics
+      if (colrange) {
+        cmin = col < cmin ? col : cmin;
+        cmax = col > cmax ? col : cmax;
+        continue;
+      }
+      double cre = 0.0, cim = 0.0;
+      for (int64_t t = msc.mask_offsets[m]; t < msc.mask_offsets[m + 1]; ++t) {
+        const int64_t sg = msc.signs[t];
+        const double c = flip_sign(msc.real_coeffs[t], (uint32_t)__popcll((uint64_t)(bra & sg)) & 1u);
+        if (__popcll((uint64_t)(mask & sg)) & 1) cim += c; else cre += c;   // TERM_REAL
+      }
+      const c128 xv = x[vec_pos(col, xswz) - win_start];
+      accr = fma(cre, xv.x, accr);
+      acci = fma(cre, xv.y, acci);
+      accr = fma(-cim, xv.y, accr);
+      acci = fma(cim, xv.x, acci);
+    }
+    if (!colrange) y[vec_pos(lrow, left.swz)] = make_double2(accr, acci);
   }
-  y[vec_pos(row, left.swz)] = make_double2(accr, acci);
+  if (colrange) {
+    __shared__ int64_t smin[GATHER_NT / 64], smax[GATHER_NT / 64];
+    for (int off = 32; off > 0; off >>= 1) {
+      const int64_t a = __shfl_xor(cmin, off, 64), b2 = __shfl_xor(cmax, off, 64);
+      cmin = a < cmin ? a : cmin;
+      cmax = b2 > cmax ? b2 : cmax;
+    }
+    if ((threadIdx.x & 63) == 0) { smin[threadIdx.x >> 6] = cmin; smax[threadIdx.x >> 6] = cmax; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int i = 1; i < GATHER_NT / 64; ++i) {
+        cmin = smin[i] < cmin ? smin[i] : cmin;
+        cmax = smax[i] > cmax ? smax[i] : cmax;
+      }
+      colrange[2 * (int64_t)blockIdx.x] = cmin;
+      colrange[2 * (int64_t)blockIdx.x + 1] = cmax;
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -1209,13 +1241,14 @@ int launch_conserves(const DevMsc &msc, const double *coeffs_im, const SubView &
 }
 
 template <int LT>
-static int gather_dispatch_r(const DevMsc &msc, const SubView &l, const SubView &r, int64_t M,
-                             const double *diag, const void *x, void *y, hipStream_t st) {
+static int gather_dispatch_r(const DevMsc &msc, const SubView &l, const SubView &r, int64_t M, int64_t row0,
+                             int64_t win_start, int xswz, const double *diag, const void *x, void *y,
+                             int64_t *colrange, hipStream_t st) {
   const dim3 grid((unsigned)((M + GATHER_NT - 1) / GATHER_NT)), blk(GATHER_NT);
-#define DNM_G(RT)                                                                             \
-  case RT:                                                                                    \
-    hipLaunchKernelGGL((gather_matvec_kernel<LT, RT>), grid, blk, 0, st, msc, l, r, M, diag, \
-                       (const c128 *)x, (c128 *)y);                                           \
+#define DNM_G(RT)                                                                                         \
+  case RT:                                                                                                \
+    hipLaunchKernelGGL((gather_matvec_kernel<LT, RT>), grid, blk, 0, st, msc, l, r, M, row0, win_start,  \
+                       xswz, diag, (const c128 *)x, (c128 *)y, colrange);                                 \
     break;
   switch (r.type) {
     DNM_G(DNM_FULL) DNM_G(DNM_PARITY) DNM_G(DNM_SPIN_CONSERVE) DNM_G(DNM_EXPLICIT)
@@ -1226,14 +1259,18 @@ static int gather_dispatch_r(const DevMsc &msc, const SubView &l, const SubView 
   return 0;
 }
 
+int gather_num_blocks(int64_t M) { return (int)((M + GATHER_NT - 1) / GATHER_NT); }
+
 int launch_gather_matvec(const DevMsc &msc, const SubView &left, const SubView &right, int64_t M,
-                         const double *diag, const void *x, void *y, hipStream_t st) {
+                         const double *diag, const void *x, void *y, hipStream_t st, int64_t row0,
+                         int64_t win_start, int xswz, int64_t *colrange) {
   DNM_CHECK(M > 0 && (M + GATHER_NT - 1) / GATHER_NT < (int64_t)1 << 31, "row count out of range");
+  if (xswz < 0) xswz = right.swz;
   switch (left.type) {
-    case DNM_FULL: return gather_dispatch_r<DNM_FULL>(msc, left, right, M, diag, x, y, st);
-    case DNM_PARITY: return gather_dispatch_r<DNM_PARITY>(msc, left, right, M, diag, x, y, st);
-    case DNM_SPIN_CONSERVE: return gather_dispatch_r<DNM_SPIN_CONSERVE>(msc, left, right, M, diag, x, y, st);
-    case DNM_EXPLICIT: return gather_dispatch_r<DNM_EXPLICIT>(msc, left, right, M, diag, x, y, st);
+    case DNM_FULL: return gather_dispatch_r<DNM_FULL>(msc, left, right, M, row0, win_start, xswz, diag, x, y, colrange, st);
+    case DNM_PARITY: return gather_dispatch_r<DNM_PARITY>(msc, left, right, M, row0, win_start, xswz, diag, x, y, colrange, st);
+    case DNM_SPIN_CONSERVE: return gather_dispatch_r<DNM_SPIN_CONSERVE>(msc, left, right, M, row0, win_start, xswz, diag, x, y, colrange, st);
+    case DNM_EXPLICIT: return gather_dispatch_r<DNM_EXPLICIT>(msc, left, right, M, row0, win_start, xswz, diag, x, y, colrange, st);
   }
   set_error("bad left subspace type");
   return 1;

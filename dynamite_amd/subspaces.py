@@ -119,7 +119,15 @@ class Subspace:
         """Layout of this subspace's state vectors in device memory (dnm_subspace.vec_swizzle): Full and Parity
         vectors are XOR-swizzled by ``config.vec_swizzle``; every other subspace keeps index order."""
         from .config import config
-        return config.vec_swizzle if self._enum in (FULL, PARITY) else 0
+        if self._enum not in (FULL, PARITY) or not config.vec_swizzle:
+            return 0
+        # the swizzle acts on a rank's local index: it needs power-of-two blocks (any other partition of these
+        # spaces goes through the index-ordered window path)
+        ws = config.world_size
+        dim = 1 << (self.L if self._enum == FULL else self.L - 1)
+        if ws > 1 and (dim % ws or ((dim // ws) & (dim // ws - 1))):
+            return 0
+        return config.vec_swizzle
 
     # -- maps ----------------------------------------------------------------
     def get_dimension(self):

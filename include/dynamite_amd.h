@@ -101,10 +101,16 @@ enum {
                                  diagnostics and CPU tests) -- such a handle cannot multiply */
 };
 
-/* Row-block partition of the state vector over `nranks` devices
- * (PetscSplitOwnership in BuildGPUShell, bcuda_template_2.cu:24-27).
- * nranks must be a power of two and (for now) the subspace Full or Parity;
- * rank r owns indices [r*dim/nranks, (r+1)*dim/nranks). */
+/* Row-block partition of the state vector over `nranks` devices, as PetscSplitOwnership splits it
+ * (BuildGPUShell, bcuda_template_2.cu:24-27): dim / nranks rows each, the first dim % nranks ranks one more.
+ * Two exchange schemes, chosen by dnm_mat_create (dnm_mat_exchange_plan reports no transfers for the second):
+ *   - Full/Full or Parity/Parity on 2^p ranks with blocks of at least one tile: XOR-partner sub-blocks
+ *     (dnm_mat_exchange_plan + dnm_mat_mult_local + dnm_mat_mult_remote), MatMult_CPU_Fast's scheme
+ *     (bpetsc_template_2.c:787-879);
+ *   - every other case -- SpinConserve, Explicit / Auto, projections between different subspaces, Full / Parity
+ *     on any other rank count: rows in index order, each rank reads its columns through a window
+ *     (dnm_mat_column_window + dnm_mat_mult_window), in place of the scatter-add of MatMult_CPU_General's MPI
+ *     branch (bpetsc_template_2.c:413-504). */
 typedef struct dnm_partition {
   int32_t rank;
   int32_t nranks;
@@ -208,11 +214,12 @@ int dnm_mat_mult_local(dnm_mat *A, const void *x_local, void *y, void *stream);
 int dnm_mat_mult_remote(dnm_mat *A, int32_t recv_index, const void *x_recv,
                         void *y, void *stream);
 
-/* --- partitioned SpinConserve/SpinConserve multiply ("column window") ------
- * Basis indices are split as PetscSplitOwnership does (M / P rows each, the
- * first M % P ranks one more; any P).  The columns a rank's rows read form a
- * window around its own block (col = row +- binomials); the host
- * assembles that window from the owners' blocks (send/recv) and multiplies. */
+/* --- partitioned multiply through a column window -------------------------------------------------
+ * Basis indices are split as PetscSplitOwnership does (M / P rows each, the first M % P ranks one more; any P).
+ * The columns a rank's rows read lie in a window (SpinConserve: col = row +- binomials, a few blocks wide, see
+ * DESIGN.md; Explicit / projections: whatever the masks reach, found by one device sweep); the host assembles
+ * that window IN INDEX ORDER from the owners' blocks (send/recv) and multiplies.  y_local is the rank's block of
+ * the left vector in that subspace's own layout. */
 int dnm_mat_ownership(const dnm_mat *A, int64_t *row0, int64_t *m_local);
 /* inclusive column range this rank's rows read; one device sweep, then cached */
 int dnm_mat_column_window(dnm_mat *A, int64_t *cmin, int64_t *cmax, void *stream);

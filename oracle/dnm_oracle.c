@@ -26,6 +26,18 @@ int orc_max_threads(void)
 #endif
 }
 
+void orc_fill_test_vectors(orc_cplx *x, orc_cplx *y, orc_int n, int nthreads)
+{
+  if (nthreads < 1) nthreads = 1;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(nthreads)
+#endif
+  for (orc_int i = 0; i < n; ++i) {
+    x[i] = (double)(i % 1021 - 510) * (1.0 / 512) + I * ((double)(i % 509 - 254) * (1.0 / 256));
+    y[i] = 0;
+  }
+}
+
 /* ------------------------------------------------------------------ */
 /* Subspace maps                                                      */
 /* ------------------------------------------------------------------ */

@@ -123,6 +123,10 @@ int orc_check_conserves(const orc_msc *msc, const orc_subspace *left,
                         const orc_subspace *right, int *result);
 
 int orc_max_threads(void);
+/* bench support: x[i] = ((i % 1021) - 510)/512 + i ((i % 509) - 254)/256 and y = 0, written by the threads that
+ * will later work on those blocks (first touch places the pages on their NUMA nodes, as rank-local PETSc vectors
+ * would be) */
+void orc_fill_test_vectors(orc_cplx *x, orc_cplx *y, orc_int n, int nthreads);
 
 #ifdef __cplusplus
 }

@@ -315,6 +315,15 @@ def max_threads():
     return int(lib().orc_max_threads())
 
 
+def fill_test_vectors(x, y, nthreads=1):
+    """x = a cheap non-trivial pattern, y = 0, first-touched by the worker threads (bench.py's cpu_baseline)."""
+    assert x.dtype == np.complex128 and y.dtype == np.complex128 and x.size == y.size
+    L_ = lib()
+    L_.orc_fill_test_vectors.restype = None
+    L_.orc_fill_test_vectors.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int]
+    L_.orc_fill_test_vectors(x.ctypes.data, y.ctypes.data, x.size, nthreads)
+
+
 # ----------------------------------------------------------------------
 # numpy restatement of msc_tools.msc_to_numpy (msc_tools.py:19-92)
 # ----------------------------------------------------------------------

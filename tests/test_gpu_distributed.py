@@ -70,6 +70,46 @@ def _worker(rank, world, port, case, out_dir):
             open(os.path.join(out_dir, "ok_%s_%d" % (case, world)), "w").write("ok")
         dist.destroy_process_group()
         return
+    if case in ("explicit", "auto", "projection", "full_odd", "parity_odd"):
+        # partitions that are not XOR-partner exchanges: rows in index order, columns through a window
+        # (the reference runs these through MatMult_CPU_General's MPI branch, bpetsc_template_2.c:413-504,
+        # exercised at 3 ranks by tests/integration/run_all_tests.py:109-113)
+        from dynamite_amd.subspaces import Explicit, Auto
+        H = models.mbl(L) if case != "auto" else models.heisenberg(L)
+        if case == "explicit":
+            rs = np.random.RandomState(5)
+            left = right = Explicit(np.sort(rs.choice(1 << L, size=3001, replace=False)), L=L)
+        elif case == "auto":
+            left = right = Auto(H, 'U' * (L // 2) + 'D' * (L - L // 2))
+        elif case == "projection":
+            left, right = Parity('even', L=L), Full(L=L)
+        elif case == "full_odd":
+            left = right = Full(L=L)
+        else:
+            left = right = Parity('odd', L=L)
+        H.allow_projection = True
+        H.add_subspace(left, right)
+        x = State(subspace=right, state='random', seed=3)
+        y = H.dot(x, result=State(subspace=left))
+        assert y.subspace == left and "tiled=1" not in H.get_mat(subspaces=(left, right)).describe()
+        xg, yg = x.to_numpy(to_all=True), y.to_numpy(to_all=True)
+        ref = orc.matvec(orc_msc(H), orc_sub(left), orc_sub(right), xg)
+        assert np.max(np.abs(yg - ref)) < 1e-12, "partitioned multiply through a column window (%s)" % case
+        if left is right:
+            import scipy.sparse.linalg as spla2
+            Hs = H.to_numpy(subspaces=(left, right), sparse=True)
+            z = H.evolve(x, t=0.4)
+            want = spla2.expm_multiply(-0.4j * Hs, xg)
+            assert np.max(np.abs(z.to_numpy(to_all=True) - want)) < 1e-8, "evolve on a window partition"
+            ev = H.eigsolve(nev=1, tol=1e-10, subspace=left)
+            low = spla2.eigsh(Hs, k=1, which='SA', tol=1e-12, return_eigenvectors=False)
+            assert abs(ev[0] - low[0]) < 1e-8, "eigsolve on a window partition"
+        dist.barrier()
+        faulthandler.cancel_dump_traceback_later()
+        if rank == 0:
+            open(os.path.join(out_dir, "ok_%s_%d" % (case, world)), "w").write("ok")
+        dist.destroy_process_group()
+        return
     if case == "full":
         sub, H = Full(L=L), models.mbl(L)
     elif case == "parity":
@@ -138,7 +178,8 @@ def _worker(rank, world, port, case, out_dir):
 
 
 @pytest.mark.parametrize("case,world", [("full", 2), ("full", 4), ("parity", 2), ("sc", 2), ("sc", 3),
-                                        ("sc_big", 3)])
+                                        ("sc_big", 3), ("explicit", 3), ("auto", 2), ("projection", 3),
+                                        ("projection", 2), ("full_odd", 3), ("parity_odd", 3)])
 def test_partitioned_end_to_end_one_gpu(tmp_path, case, world):
     import torch.multiprocessing as mp
     mp.spawn(_worker, args=(world, _free_port(), case, str(tmp_path)), nprocs=world, join=True)

@@ -24,7 +24,11 @@ pytestmark = [pytest.mark.gpu, pytest.mark.default_layout]
 
 
 def _need(nbytes):
+    import gc
     import torch
+    gc.collect()
+    _lib.check(_lib.lib().dnm_release_workspace())      # Krylov workspace cached by earlier tests
+    torch.cuda.empty_cache()                            # and torch's own cache
     free, _ = torch.cuda.mem_get_info()
     if free < nbytes:
         pytest.skip("needs %.0f GiB of free HBM" % (nbytes / 2**30))
