@@ -68,7 +68,7 @@ class DevPass(C.Structure):
                 ("dbucket", C.c_uint32 * (MAXR + 1)), ("loop", C.c_uint32 * (LP_COUNT + 1)),
                 ("nquads", C.c_int32), ("n_eff", C.c_int32), ("quads", vp), ("dot_out", vp), ("zinit", vp), ("zscale", C.c_double), ("zinit2", vp), ("z2re", C.c_double), ("z2im", C.c_double),
                 ("tile_bits", C.c_int32), ("log_rows", C.c_int32),
-                ("swz_shift", C.c_int32), ("swz_xor_y", C.c_uint32), ("swz_xor_src", C.c_uint32)]
+                ("swz_shift", C.c_int32), ("swz_xor_y", C.c_uint32), ("swz_xor_src", C.c_uint32), ("dtile", vp)]
 
 
 class Xfer(C.Structure):
@@ -111,6 +111,7 @@ SIGNATURES = {
     "dnm_mat_plan_describe": (C.c_int, [vp, C.c_char_p, C.c_size_t]),
     "dnm_mat_plan_launches": (C.c_int, [vp, C.POINTER(C.c_int)]),
     "dnm_mat_plan_counts": (C.c_int, [vp] + [C.POINTER(C.c_int)] * 6),
+    "dnm_mat_export_dtile": (C.c_int, [vp, C.c_int, C.c_int, f64p, C.c_int64]),
     "dnm_mat_export_pass": (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_size_t, vp, C.c_size_t, C.c_int,
                                       C.POINTER(C.c_int)]),
     "dnm_mat_ownership": (C.c_int, [vp, i64p, i64p]),

@@ -67,6 +67,18 @@ def _hooks(mat, keep):
     return h
 
 
+def _min_over_ranks(*vals):
+    """The smallest of each value over the ranks (decisions taken from free device memory must agree)."""
+    d = _dist()
+    if d is None:
+        return vals if len(vals) > 1 else vals[0]
+    import torch
+    t = torch.tensor([float(v) for v in vals], dtype=torch.float64, device=config.device)
+    d.all_reduce(t, op=d.ReduceOp.MIN)
+    out = tuple(int(v) for v in t.tolist())
+    return out if len(out) > 1 else out[0]
+
+
 def _tensor_from_ptr(ptr, n):
     """torch complex128 tensor aliasing n amplitudes at a raw device pointer."""
     import torch
@@ -91,11 +103,11 @@ def evolve(H, state, t, result=None, tol=None, ncv=None, algo=None, max_its=None
         result = State(L=H.L, subspace=state.subspace)
     elif state.subspace != result.subspace:
         raise ValueError('input and result states are on different subspaces.')
+    if algo not in (None, 'expokit', 'krylov', 'chebyshev'):
+        raise ValueError("algo must be 'expokit', 'krylov' or 'chebyshev'")
     if t == 0.0:
         state.copy(result)
         return result
-    if algo not in (None, 'expokit', 'krylov', 'chebyshev'):
-        raise ValueError("algo must be 'expokit', 'krylov' or 'chebyshev'")
     if algo == 'chebyshev':
         return _evolve_chebyshev(H, state, t, result, tol)
 
@@ -115,6 +127,7 @@ def evolve(H, state, t, result=None, tol=None, ncv=None, algo=None, max_its=None
     cached = C.c_size_t()
     _lib.check(_lib.lib().dnm_workspace_bytes(C.byref(cached)))
     fit = int((free * 0.9 + cached.value) // (16 * mat.n_local)) - 2
+    fit, free = _min_over_ranks(fit, free)        # Krylov or Chebyshev, and the work limit: the same on every rank
     if ncv is None and fit < 10:
         if complex(t).imag == 0.0 and fit >= 2:
             warnings.warn('evolve: only %d Krylov vectors of %.1f GiB fit in device memory; using '
@@ -166,6 +179,8 @@ def _evolve_chebyshev(H, state, t, result, tol):
         _stream()))
     evolve.last_stats = {'reason': stats.reason, 'its': stats.its, 'matvecs': stats.matvecs,
                          'err_est': stats.err_est}
+    if stats.reason <= 0:
+        raise ConvergenceError('solver failed to converge.')
     result.set_initialized()
     return result
 
@@ -212,10 +227,10 @@ def eigsolve(H, getvecs=False, nev=1, which='lowest', target=None, tol=None, sub
         def fitting():
             free, _ = torch.cuda.mem_get_info()
             return int((free + cached.value) // vec_bytes) - 1 - (nev_max if getvecs else 0)
-        fit = fitting()
+        fit = _min_over_ranks(fitting())
         if fit < want:
             torch.cuda.empty_cache()        # memory torch holds for reuse counts as free
-            fit = fitting()
+            fit = _min_over_ranks(fitting())
         if fit < want:
             if fit < nev + 2:
                 raise RuntimeError('not enough device memory for a Krylov basis: %d vectors of %.1f GiB fit, '

@@ -556,7 +556,7 @@ static int cheb_core(Ops &ops, void *y, int64_t n_local, double t, double tol, d
         if (k == K - 1) DNM_TRY(ops.mult_sub2(sl(k + 1), sl(k), y, 0.0, y, c));          // b_{K+1} = 0
         else DNM_TRY(ops.mult_sub2(sl(k + 1), sl(k), sl(k + 2), beta2, y, c));
         g[k % 3] = gk;
-        if (gk < 1e-200) {      // bring the two live vectors back to O(1) by the same factor
+        if (gk < 1e-200 || gk > 1e200) {      // (tiny or huge norm bound r) bring the two live vectors back to O(1) by the same factor
           DNM_TRY(vk_scale(sl(k), n_local, gk, 0.0, st));
           DNM_TRY(vk_scale(sl(k + 1), n_local, gk, 0.0, st));
           g[(k + 1) % 3] /= gk;
@@ -591,7 +591,7 @@ static int cheb_core(Ops &ops, void *y, int64_t n_local, double t, double tol, d
     for (int k = 1; k < K; ++k) {
       DNM_TRY(ops.mult_sub(slot(k), slot(k + 1), slot(k - 1), beta));
       gam[(k + 1) & 3] = gam[k & 3] * (2.0 / r);
-      if (gam[(k + 1) & 3] < 1e-200) {
+      if (gam[(k + 1) & 3] < 1e-200 || gam[(k + 1) & 3] > 1e200) {
         // bring the two live vectors back to O(1) by the same factor: the recurrence is unchanged
         const double f = gam[(k + 1) & 3];
         DNM_TRY(vk_scale(slot(k + 1), n_local, f, 0.0, st));
@@ -670,6 +670,13 @@ int dnm_expm_multiply(dnm_mat *A, const void *x, void *y, int64_t n_local, doubl
     if (ncv <= 0 && have >= 12 && (int64_t)m + 2 > have) m = (int)(have - 2);
   }
   if (m < 1) m = 1;
+  {
+    // every rank sizes its basis from its own free memory and cached workspace: they must run the same m (the
+    // all-reduce lengths and the multiply counts depend on it), so take the smallest
+    double neg = -(double)m;
+    DNM_TRY(ops.maxr(&neg, 1));
+    m = (int)(-neg);
+  }
 
   const zc scale(scale_re, scale_im);
   const double t_out = std::abs(scale);
@@ -887,9 +894,14 @@ int dnm_eigsolve(dnm_mat *A, int64_t n_local, int nev, int which, double tol, in
   if (tol <= 0) tol = 1e-8;
   int m = ncv > 0 ? ncv : std::max(2 * nev, nev + 15);
   if ((int64_t)m > Nglob) m = (int)Nglob;
+  {
+    double neg = -(double)m;          // the same basis size on every rank (see dnm_expm_multiply)
+    DNM_TRY(ops.maxr(&neg, 1));
+    m = (int)(-neg);
+  }
   DNM_CHECK(m >= nev, "ncv smaller than nev");
   if (max_its <= 0) max_its = (int)std::max<int64_t>(100, 2 * Nglob / m);
-  DNM_CHECK((size_t)(m + 1) * 64 * 16 <= 160 * 1024, "ncv too large for the basis-rotation kernel");
+  DNM_CHECK((size_t)(m + 1) * 16 <= 160 * 1024, "ncv too large for the basis-rotation kernel");
 
   void *V = nullptr;
   DNM_TRY(basis_workspace((size_t)(m + 1) * (size_t)n_local * 16, &V));

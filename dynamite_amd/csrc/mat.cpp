@@ -308,11 +308,21 @@ static int build_pass(const dnm_mat &A, const PassSpec &ps, PassOnDevice *out) {
       d.dext_begin = (uint32_t)quads.size();
       push_diag_list(lst);
       d.dext_end = (uint32_t)quads.size();
+      // terms inside the tile only: tabulated per tile coordinate (DNM_DIAG_TABLE=0: bucket lists as before)
+      const char *dte = getenv("DNM_DIAG_TABLE");
+      const bool use_table = !(dte && dte[0] == '0') && B <= 13;
+      if (use_table) out->h_dtile.assign((size_t)1 << B, 0.0);
       for (int j = 0; j < R; ++j) {
         lst.clear();
         for (const RowTerm &t : dm->terms) {
           uint32_t st = compress_to_tile(t.sign & tb, ps);
-          if (st != 0 && (int)(st >> lognt) == j) lst.push_back(t);
+          if (st == 0 || (int)(st >> lognt) != j) continue;
+          if (use_table && (t.sign & ~tb) == 0) {
+            for (uint32_t tc = 0; tc < (1u << B); ++tc)
+              out->h_dtile[tc] += (__builtin_popcount(tc & st) & 1) ? -t.coeff : t.coeff;
+          } else {
+            lst.push_back(t);
+          }
         }
         d.dbucket[j] = (uint32_t)quads.size();
         push_diag_list(lst);
@@ -370,6 +380,11 @@ static int build_pass(const dnm_mat &A, const PassSpec &ps, PassOnDevice *out) {
   out->h_quads = quads;
   if (!A.host_only) DNM_TRY(out->quads.upload(quads.data(), quads.size() * sizeof(DevQuad)));
   d.quads = (const DevQuad *)out->quads.p;
+  d.dtile = nullptr;
+  if (!out->h_dtile.empty() && !A.host_only) {
+    DNM_TRY(out->dtile.upload(out->h_dtile.data(), out->h_dtile.size() * sizeof(double)));
+    d.dtile = (const double *)out->dtile.p;
+  }
   if (!A.host_only) DNM_TRY(out->desc_dev.upload(&d, sizeof(d)));
   out->partner = ps.partner;
   out->n_eff = n_eff;
@@ -1119,6 +1134,17 @@ int dnm_mat_export_pass(const dnm_mat *A, int remote, int idx, void *desc_out, s
     DNM_CHECK(max_quads >= *nquads, "record buffer too small");
     memcpy(quads_out, p.h_quads.data(), p.h_quads.size() * sizeof(DevQuad));
   }
+  return 0;
+}
+
+int dnm_mat_export_dtile(const dnm_mat *A, int remote, int idx, double *out, int64_t n) {
+  DNM_CHECK(A && out, "null argument");
+  const auto &v = remote ? A->remote_passes : A->local_passes;
+  DNM_CHECK(idx >= 0 && idx < (int)v.size(), "pass index out of range");
+  const PassOnDevice &p = *v[idx];
+  DNM_CHECK((int64_t)p.h_dtile.size() == n, "the pass has %zu tabulated diagonal entries, not %lld", p.h_dtile.size(),
+            (long long)n);
+  memcpy(out, p.h_dtile.data(), p.h_dtile.size() * sizeof(double));
   return 0;
 }
 

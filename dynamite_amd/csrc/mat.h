@@ -38,6 +38,8 @@ struct PassOnDevice {
   std::vector<DevQuad> h_quads;   // host copy (diagnostics / host-only handles)
   DevBuf quads;
   DevBuf desc_dev;                // the descriptor in device memory (persistent kernel)
+  std::vector<double> h_dtile;    // in-tile diagonal per tile coordinate (DevPass::dtile), host copy
+  DevBuf dtile;
   int partner = -1;
   int n_eff = 0;                  // index bits the pass sweeps
   int64_t y_off = 0, src_off = 0; // partner passes: first local row / first partner amplitude

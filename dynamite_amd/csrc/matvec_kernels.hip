@@ -93,14 +93,13 @@ __device__ __forceinline__ void apply_records(const DevQuad *__restrict__ quads,
       const bool live = KVAR || (a0 + a1 != 0.0) || (CPLX && (a2 + a3 != 0.0));
       if (!__any(live)) continue;
       const c128 *__restrict__ src = Q.src ? xr : x;
-      const uint32_t sxor = Q.src ? xrx : 0u;
+      // `rows` are positions (layout applied); the layout map is XOR-linear, so the partner of a mask sits at
+      // position(row) ^ position(mask): one scalar per record, one v_xor per load
       const uint32_t mloc = Q.mask_loc;
+      const uint32_t xm = (skw ? (mloc ^ (((mloc >> skw) & ((1u << (skw - 4)) - 1u)) << 4)) : mloc) ^ (Q.src ? xrx : 0u);
       if (live) {
 #pragma unroll
-        for (int k = 0; k < R; ++k) {
-          const uint32_t pr = rows[k] ^ mloc;
-          xv[k] = src[(skw ? (pr ^ (((pr >> skw) & ((1u << (skw - 4)) - 1u)) << 4)) : pr) ^ sxor];
-        }
+        for (int k = 0; k < R; ++k) xv[k] = src[rows[k] ^ xm];
       } else {
 #pragma unroll
         for (int k = 0; k < R; ++k) xv[k] = make_double2(0.0, 0.0);
@@ -186,10 +185,10 @@ tile_pass_kernel(const DevPass P, const c128 *__restrict__ x, c128 *__restrict__
   // XOR-swizzled vector layout: index bits [s, 2s-4) are folded onto bits [4, s); sub-block
   // passes add the swizzle of the block's own offset (swz_xor_y for y, swz_xor_src for the partner's amplitudes)
   const uint32_t skw = (uint32_t)P.swz_shift;
-  uint64_t arows[R], yrows[R];
+  uint32_t arows[R], yrows[R];
 #pragma unroll
   for (int k = 0; k < R; ++k) {
-    arows[k] = skw ? (uint64_t)(rows[k] ^ (((rows[k] >> skw) & ((1u << (skw - 4)) - 1u)) << 4)) : (uint64_t)rows[k];
+    arows[k] = skw ? (rows[k] ^ (((rows[k] >> skw) & ((1u << (skw - 4)) - 1u)) << 4)) : rows[k];
     yrows[k] = arows[k] ^ P.swz_xor_y;
   }
 
@@ -260,7 +259,7 @@ tile_pass_kernel(const DevPass P, const c128 *__restrict__ x, c128 *__restrict__
   const DevQuad *__restrict__ quads = P.quads;
 
 #define DNM_LOOP(LP, KV, CX, GA, KZ) \
-  apply_records<R, LOGNT, KV, CX, GA, KZ>(quads, P.loop[LP], P.loop[LP + 1], ar, ai, tile, rows, x, xr, tid, sbase, skw, P.swz_xor_src)
+  apply_records<R, LOGNT, KV, CX, GA, KZ>(quads, P.loop[LP], P.loop[LP + 1], ar, ai, tile, arows, x, xr, tid, sbase, skw, P.swz_xor_src)
   if constexpr (GV >= 1) {
     DNM_LOOP(LP_GATHER_REAL, false, false, true, false);
     DNM_LOOP(LP_GATHER_KVAR_REAL, true, false, true, false);
@@ -301,6 +300,11 @@ tile_pass_kernel(const DevPass P, const c128 *__restrict__ x, c128 *__restrict__
 #pragma unroll
     for (int j = 0; j < R; ++j) D[j] = 0.0;
     D[0] = dext;
+    double dtab[R];
+    if (P.dtile) {      // tile-only terms, tabulated per tile coordinate (L2-resident)
+#pragma unroll
+      for (int k = 0; k < R; ++k) dtab[k] = P.dtile[tid + k * NT];
+    }
 #pragma unroll
     for (int j = 0; j < R; ++j)
       for (uint32_t q = P.dbucket[j]; q < P.dbucket[j + 1]; ++q) {
@@ -322,6 +326,10 @@ tile_pass_kernel(const DevPass P, const c128 *__restrict__ x, c128 *__restrict__
         }
       }
     }
+    if (P.dtile) {
+#pragma unroll
+      for (int k = 0; k < R; ++k) D[k] += dtab[k];
+    }
 #pragma unroll
     for (int k = 0; k < R; ++k) {
       c128 xs = tile[tid + k * NT];
@@ -332,7 +340,7 @@ tile_pass_kernel(const DevPass P, const c128 *__restrict__ x, c128 *__restrict__
 
   // ---- off-diagonal masks, one branch-free loop per record class
 #define DNM_LOOP(LP, KV, CX, GA, KZ) \
-  apply_records<R, LOGNT, KV, CX, GA, KZ>(quads, P.loop[LP], P.loop[LP + 1], ar, ai, tile, rows, x, xr, tid, sbase, skw, P.swz_xor_src)
+  apply_records<R, LOGNT, KV, CX, GA, KZ>(quads, P.loop[LP], P.loop[LP + 1], ar, ai, tile, arows, x, xr, tid, sbase, skw, P.swz_xor_src)
   DNM_LOOP(LP_TILE_REAL_K0, false, false, false, true);
   DNM_LOOP(LP_TILE_REAL, false, false, false, false);
   DNM_LOOP(LP_TILE_CPLX, false, true, false, false);

@@ -27,6 +27,7 @@ PlanConfig plan_config_from_env() {
   c.logRw = env_int("DNM_LOG_ROWS_WINDOW", c.logRw);
   c.cache_policy = env_int("DNM_CACHE_POLICY", c.cache_policy);
   c.kernel = env_int("DNM_KERNEL", c.kernel);
+  if (const char *d = getenv("DNM_DIAG_PASS")) c.diag_last = (d[0] == 'l') ? 1 : 0;
   return c;
 }
 
@@ -306,6 +307,14 @@ static int make_plan_with(const OpForm &op, int rank, int nranks, const PlanConf
       pl.local[i].accumulate = i > 0;
       pl.local[i].has_diag = i == 0 && has_diag;
     }
+  }
+
+  // the diagonal rides on the pass with the most time per tile to spare: the last (window, accumulating) pass moves
+  // 48 B/amp against the first one's 32 and holds fewer masks (DNM_DIAG_PASS=first|last; measured in
+  // profiles/r02_exp13_diag.txt)
+  if (cfg.diag_last && pl.local.size() > 1 && has_diag) {
+    for (auto &ps : pl.local) ps.has_diag = false;
+    pl.local.back().has_diag = true;
   }
 
   // remote passes: what this rank receives and applies

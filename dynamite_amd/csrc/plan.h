@@ -116,6 +116,11 @@ struct DevPass {
   // sub-block and read a slice of the partner's block: the swizzle of the fixed offset bits is a constant XOR.
   int32_t swz_shift;
   uint32_t swz_xor_y, swz_xor_src;
+  // diagonal terms whose sign mask lies entirely inside the tile do not depend on the block: their sum per tile
+  // coordinate, 2^B doubles (32 KB at B = 12, L2-resident), computed once on the host -- one 8-byte load per
+  // amplitude instead of ~25 vector instructions.  Terms that see the tile AND bits outside it stay in the
+  // k-bucket lists; terms outside the tile in the dext list.  Null: every tile term is in the bucket lists.
+  const double *dtile;
 };
 
 // ---- host-side description --------------------------------------------------
@@ -159,6 +164,7 @@ struct PlanConfig {
   int gbits_window = -1; // mode 2: cap of the group bits of window-tile passes (-1: no cap)
   int cache_policy = 98; // DevPass::cache_policy for every pass; default: gathers right behind the tile loads (32) + streaming loads (2) and stores (64) of y
   int max_gather_span = 0;   // mode 0: masks the tiler cannot place are gathered
+  int diag_last = 0;         // mode 2: evaluate the diagonal in the last local pass instead of the first
   int swz = 0;               // XOR-swizzle shift of the vectors this plan multiplies (0: natural order)
   int kernel = 1;            // 1: tile_pass_kernel; 2: tile_pass2_kernel where it has an instance for the pass
 };

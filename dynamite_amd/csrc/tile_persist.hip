@@ -379,6 +379,7 @@ tile_persist_kernel(const DevPass *__restrict__ Pp, const PassCall C, const c128
 #pragma unroll
       for (int j = 0; j < R; ++j) D[j] = 0.0;
       D[0] = dext;
+      const double *__restrict__ dt = P.dtile;
 #pragma unroll
       for (int j = 0; j < R; ++j)
         for (uint32_t q = P.dbucket[j]; q < P.dbucket[j + 1]; ++q) {
@@ -399,6 +400,10 @@ tile_persist_kernel(const DevPass *__restrict__ Pp, const PassCall C, const c128
             D[i | h] = a - b;
           }
         }
+      }
+      if (dt) {
+#pragma unroll
+        for (int k = 0; k < R; ++k) D[k] += dt[tid + k * NT];
       }
 #pragma unroll
       for (int k = 0; k < R; ++k) {

@@ -245,20 +245,22 @@ constexpr int BU_ROWS = 64;
 
 __global__ void __launch_bounds__(VNT)
 basis_update_kernel(c128 *V, int64_t ldv, int nin, int nout, int64_t n,
-                    const double *__restrict__ S) {
+                    const double *__restrict__ S, int rows) {
+  // `rows` (a power of two <= BU_ROWS) rows of all nin vectors are staged per step: fewer rows when the basis is
+  // too wide for 64 of them (nin * rows * 16 B <= 160 KB)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  c128 *rowsbuf = reinterpret_cast<c128 *>(smem);   // [nin][BU_ROWS]
-  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
-  for (int64_t r0 = (int64_t)blockIdx.x * BU_ROWS; r0 < n; r0 += (int64_t)gridDim.x * BU_ROWS) {
+  c128 *rowsbuf = reinterpret_cast<c128 *>(smem);   // [nin][rows]
+  const int lane = threadIdx.x & (rows - 1), grp = threadIdx.x / rows, ngrp = VNT / rows;
+  for (int64_t r0 = (int64_t)blockIdx.x * rows; r0 < n; r0 += (int64_t)gridDim.x * rows) {
     const int64_t row = r0 + lane;
-    for (int j = grp; j < nin; j += VNT / 64)
-      if (row < n) rowsbuf[j * BU_ROWS + lane] = ld_stream(V + (int64_t)j * ldv + row);
+    for (int j = grp; j < nin; j += ngrp)
+      if (row < n) rowsbuf[j * rows + lane] = ld_stream(V + (int64_t)j * ldv + row);
     __syncthreads();
-    for (int o = grp; o < nout; o += VNT / 64) {
+    for (int o = grp; o < nout; o += ngrp) {
       double ar = 0.0, ai = 0.0;
       for (int j = 0; j < nin; ++j) {
         const double sr = S[2 * ((int64_t)o * nin + j)], si = S[2 * ((int64_t)o * nin + j) + 1];
-        const c128 v = rowsbuf[j * BU_ROWS + lane];
+        const c128 v = rowsbuf[j * rows + lane];
         ar = fma(sr, v.x, ar);
         ar = fma(-si, v.y, ar);
         ai = fma(sr, v.y, ai);
@@ -317,7 +319,9 @@ int vk_basis_update(void *V, int64_t ldv, int nin, int nout, int64_t n, const do
     DNM_HIP(hipGetLastError());
     return 0;
   }
-  const size_t lds = (size_t)nin * BU_ROWS * sizeof(c128);
+  int rows = BU_ROWS;
+  while (rows > 1 && (size_t)nin * rows * sizeof(c128) > 160 * 1024) rows >>= 1;
+  const size_t lds = (size_t)nin * rows * sizeof(c128);
   DNM_CHECK(lds <= 160 * 1024, "basis_update: too many vectors for one LDS stage");
   static size_t attr = 0;
   if (lds > attr) {
@@ -325,10 +329,10 @@ int vk_basis_update(void *V, int64_t ldv, int nin, int nout, int64_t n, const do
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr = lds;
   }
-  int64_t nb = (n + BU_ROWS - 1) / BU_ROWS;
+  int64_t nb = (n + rows - 1) / rows;
   if (nb > 4096) nb = 4096;
   hipLaunchKernelGGL(basis_update_kernel, dim3((unsigned)nb), dim3(VNT), lds, st, (c128 *)V, ldv, nin,
-                     nout, n, S_dev);
+                     nout, n, S_dev, rows);
   DNM_HIP(hipGetLastError());
   return 0;
 }

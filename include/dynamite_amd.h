@@ -169,6 +169,8 @@ int dnm_mat_plan_launches(const dnm_mat *A, int *n);
  * DevQuad; pointers inside the copied DevPass are meaningless). */
 int dnm_mat_plan_counts(const dnm_mat *A, int *n_local_passes, int *n_remote_passes, int *tiled,
                         int *B, int *logR, int *n_loc);
+/* the pass's tabulated in-tile diagonal (2^tile_bits doubles; an error when the pass has none) */
+int dnm_mat_export_dtile(const dnm_mat *A, int remote, int idx, double *out, int64_t n);
 int dnm_mat_export_pass(const dnm_mat *A, int remote, int idx, void *desc_out, size_t desc_bytes,
                         void *quads_out, size_t quad_bytes, int max_quads, int *nquads);
 

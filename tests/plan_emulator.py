@@ -22,6 +22,11 @@ def _popc(v):
     return c
 
 
+class _Quads(list):
+    """The records of a pass; ``dtile``: its tabulated in-tile diagonal (DevPass::dtile), if any."""
+    dtile = None
+
+
 class HostMat:
     """DNM_MAT_HOST_ONLY handle + exported pass tables."""
 
@@ -52,7 +57,12 @@ class HostMat:
         quads = (_lib.DevQuad * max(1, nq.value))()
         _lib.check(L.dnm_mat_export_pass(self.h, remote, idx, C.byref(desc), C.sizeof(desc), quads,
                                          C.sizeof(_lib.DevQuad), nq.value, C.byref(nq)))
-        return desc, [quads[i] for i in range(nq.value)]
+        out = _Quads(quads[i] for i in range(nq.value))
+        if desc.has_diag:
+            tab = np.empty(1 << desc.tile_bits, dtype=np.float64)
+            rc = L.dnm_mat_export_dtile(self.h, remote, idx, tab.ctypes.data_as(_lib.f64p), tab.size)
+            out.dtile = tab if rc == 0 else None
+        return desc, out
 
     def __del__(self):
         try:
@@ -154,6 +164,9 @@ def run_pass(hm, p, x, y, xr=None):
                         assert quads[q].sign_tile[j] != 0 and (quads[q].sign_tile[j] >> lognt) == b
                     D[b] = D[b] + amp(quads[q], j, tid)
         d = np.zeros(n, dtype=np.float64)      # Walsh-Hadamard over the k bits
+        if getattr(quads, "dtile", None) is not None:     # tile-only terms, tabulated per tile coordinate
+            assert quads.dtile.shape == (1 << B,)
+            d += quads.dtile[tt.astype(np.int64)]
         for b in range(R):
             d += np.where(_popc(kk & np.uint64(b)) & 1, -D[b], D[b])
         acc += d * x

@@ -26,12 +26,10 @@ def phys_index(n, S, dev):
 def main():
     Ls = [int(a) for a in sys.argv[1:]] or [20, 24]
     config._initialize()
-    cfgs = [dict(DNM_KERNEL=1), dict(DNM_KERNEL=2, DNM_GATHER_INFLIGHT=1, DNM_TILE_DMA=0),
-            dict(DNM_KERNEL=2, DNM_GATHER_INFLIGHT=2, DNM_TILE_DMA=0), dict(DNM_KERNEL=2, DNM_GATHER_INFLIGHT=1, DNM_TILE_DMA=1),
-            dict(DNM_KERNEL=2), dict(DNM_KERNEL=1, DNM_SWZ=12), dict(DNM_KERNEL=2, DNM_SWZ=12), dict(DNM_KERNEL=2, DNM_SWZ=16),
-            dict(DNM_KERNEL=2, DNM_SWZ=10, DNM_LOG_ROWS=4), dict(DNM_KERNEL=2, DNM_SWZ=9, DNM_AMIN=4, DNM_GBITS=4),
-            dict(DNM_KERNEL=2, DNM_SWZ=9, DNM_TILE_BITS=10, DNM_LOG_ROWS=2, DNM_PLAN_MODE=0),
-            dict(DNM_KERNEL=2, DNM_SWZ=9, DNM_TILE_BITS=11, DNM_LOG_ROWS=3, DNM_PLAN_MODE=1)]
+    cfgs = [dict(DNM_PLAN_MODE=0, DNM_KERNEL=1), dict(DNM_KERNEL=1), dict(DNM_KERNEL=2), dict(DNM_KERNEL=1, DNM_LOG_ROWS=4),
+            dict(DNM_KERNEL=1, DNM_AMIN=4, DNM_GBITS=4), dict(DNM_KERNEL=2, DNM_AMIN=4, DNM_GBITS=4),
+            dict(DNM_KERNEL=1, DNM_TILE_BITS=10, DNM_LOG_ROWS=2, DNM_PLAN_MODE=0),
+            dict(DNM_KERNEL=1, DNM_TILE_BITS=11, DNM_LOG_ROWS=3, DNM_PLAN_MODE=1)]
     worst = 0.0
     for L in Ls:
         for name in ("mbl", "xxz", "ising", "long_range", "syk", "xsum"):
@@ -43,22 +41,22 @@ def main():
             masks, offs = msc_tools.get_mask_offsets(H.msc)
             sub = Full(L=L)
             dim = 1 << L
-            x = backend.Vec(dim)
+            x = backend.Vec(dim)          # index order: the logical vector
             x.set_random(3)
             xn = x.array.clone()
             ref = None
             for c in cfgs:
                 for k in list(os.environ):
-                    if k.startswith("DNM_"):
+                    if k.startswith("DNM_") and k != "DNM_SWZ":
                         os.environ.pop(k)
                 for k, v in c.items():
                     os.environ[k] = str(v)
-                S = int(c.get("DNM_SWZ", 0))
+                S = config.vec_swizzle
                 mat = backend.build_mat(masks, offs, H.msc['signs'], H.msc['coeffs'], sub._to_c(), sub._to_c())
                 p = phys_index(dim, S, xn.device)
-                xs = backend.Vec(dim)
+                xs = backend.Vec(dim, swz=S)
                 xs.array[p] = xn                  # element i lives at p[i]
-                y = backend.Vec(dim)
+                y = backend.Vec(dim, swz=S)
                 mat.mult(xs, y)
                 torch.cuda.synchronize()
                 yl = y.array[p]
