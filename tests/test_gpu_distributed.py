@@ -206,3 +206,65 @@ def test_bench_multi_rank_flow_one_gpu(world):
     assert d["value"] > 0 and d["scaling"] == "weak" and d["config"]["L"] == 22
     assert d["config"]["launches_per_step"] >= 3          # rank-local passes plus at least one partner pass
     assert "cpu_baseline" not in d and d["roofline"]["bound"] == "hbm"
+
+
+def _rccl_worker(rank, world, port, out_dir):
+    """One rank per GPU over RCCL: the device-to-device branch of _comm.batch_p2p (no host staging)."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_RANK=str(rank), RANK=str(rank),
+                      WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import faulthandler
+    faulthandler.dump_traceback_later(int(os.environ.get("DNM_TEST_HANG_S", "120")), exit=True)
+    import datetime
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank),
+                            timeout=datetime.timedelta(seconds=90))
+    from dynamite_amd import config, models, _comm
+    from dynamite_amd.states import State
+    from dynamite_amd.subspaces import Full
+    from oracle import oracle as orc
+    from gpu_util import orc_msc, orc_sub
+    L = 20
+    config.L = L
+    config._initialize()
+    # the transport on its own: every rank sends a tagged block to every other rank, device to device
+    mine = torch.full((1 << 12,), complex(rank + 1, -rank), dtype=torch.complex128, device=config.device)
+    bufs = {q: torch.empty(1 << 12, dtype=torch.complex128, device=config.device) for q in range(world) if q != rank}
+    assert not _comm._staged(mine)
+    for r in _comm.batch_p2p([(mine, q) for q in bufs], [(b, q) for q, b in bufs.items()]):
+        r.wait()
+    torch.cuda.synchronize()
+    for q, b in bufs.items():
+        assert bool((b == complex(q + 1, -q)).all()), "RCCL p2p block from rank %d" % q
+    # and the partitioned multiply through it (partner blocks over xGMI, overlapped with the local passes)
+    sub, H = Full(L=L), models.mbl(L)
+    H.add_subspace(sub)
+    x = State(subspace=sub, state='random', seed=3)
+    y = H.dot(x)
+    xg, yg = x.to_numpy(to_all=True), y.to_numpy(to_all=True)
+    ref = orc.matvec(orc_msc(H), orc_sub(sub), orc_sub(sub), xg, nthreads=2)
+    assert np.max(np.abs(yg - ref)) < 1e-12, "partitioned multiply over RCCL"
+    z = H.evolve(x, t=0.3)
+    assert abs(z.norm() - 1) < 1e-9
+    dist.barrier()
+    faulthandler.cancel_dump_traceback_later()
+    if rank == 0:
+        open(os.path.join(out_dir, "ok_rccl_%d" % world), "w").write("ok")
+    dist.destroy_process_group()
+
+
+def test_rccl_transport_when_several_gpus(tmp_path):
+    """The production transport (one rank per GPU, RCCL send/recv of device memory -- what replaces the all-gather of
+    bcuda_template_2.cu:161-171): runs wherever at least two GPUs are visible, so that the first multi-GPU
+    benchmark is not also its first execution.  Skipped on one-GPU boxes."""
+    import torch
+    import torch.multiprocessing as mp
+    n = torch.cuda.device_count()
+    if n < 2:
+        pytest.skip("needs at least two GPUs (this box has %d)" % n)
+    world = 2 if n < 4 else 4
+    mp.spawn(_rccl_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert os.path.exists(os.path.join(str(tmp_path), "ok_rccl_%d" % world))
