@@ -163,6 +163,8 @@ def lib():
         # and torch's streams / allocations are valid handles for our launches.
         import torch  # noqa: F401
         path = _build.build()       # no-op when the in-tree .so is current
+        import os
+        path = os.environ.get("DNM_LIB", path)      # A/B experiments: another build of the same ABI
         L = C.CDLL(path)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)   # AttributeError if the library lacks a declared symbol
