@@ -218,7 +218,13 @@ def eigsolve(H, getvecs=False, nev=1, which='lowest', target=None, tol=None, sub
     nev_max = max(nev, int(ncv) if ncv else max(2 * nev, nev + 15))
     if getvecs and vec_bytes * nev_max > (1 << 30):
         nev_max = nev
-    if ncv is None:
+    # one extremal pair of a large operator: the native driver runs Lanczos without a stored basis (four work
+    # vectors; DNM_EIGS_BASISFREE=0/1 forces the choice) -- nothing to fit into memory then
+    import os
+    bf = os.environ.get('DNM_EIGS_BASISFREE')
+    basis_free = (ncv is None and nev == 1 and mat.N > 64 and
+                  (bf[:1] == '1' if bf else _min_over_ranks(mat.n_local) >= (1 << 22)))
+    if ncv is None and not basis_free:
         # SLEPc's default max(2 nev, nev + 15) (+1 for the residual vector), reduced to what fits in HBM
         cached = C.c_size_t()
         _lib.check(_lib.lib().dnm_workspace_bytes(C.byref(cached)))

@@ -613,6 +613,185 @@ static int cheb_core(Ops &ops, void *y, int64_t n_local, double t, double tol, d
   return 0;
 }
 
+// ---------------------------------------------------------------------------
+// Basis-free Lanczos for ONE extremal eigenpair (memory-bound sizes)
+// ---------------------------------------------------------------------------
+// A symmetric tridiagonal matrix T (diagonal a[0..n), off-diagonal b[0..n-1)): number of eigenvalues below x
+static int sturm_count(const std::vector<double> &a, const std::vector<double> &b, int n, double x) {
+  int cnt = 0;
+  double q = a[0] - x;
+  if (q < 0) ++cnt;
+  for (int i = 1; i < n; ++i) {
+    const double den = std::fabs(q) > 1e-300 ? q : (q < 0 ? -1e-300 : 1e-300);
+    q = a[i] - x - b[i - 1] * b[i - 1] / den;
+    if (q < 0) ++cnt;
+  }
+  return cnt;
+}
+
+// k-th smallest eigenvalue of T by bisection, its eigenvector (unit norm) by inverse iteration
+static double tridiag_eigpair(const std::vector<double> &a, const std::vector<double> &b, int n, int k,
+                              std::vector<double> &z) {
+  double lo = a[0], hi = a[0], nrm = 0;
+  for (int i = 0; i < n; ++i) {
+    const double r = (i > 0 ? std::fabs(b[i - 1]) : 0.0) + (i + 1 < n ? std::fabs(b[i]) : 0.0);
+    lo = std::min(lo, a[i] - r);
+    hi = std::max(hi, a[i] + r);
+    nrm = std::max(nrm, std::fabs(a[i]) + r);
+  }
+  for (int it = 0; it < 200 && hi - lo > 4e-16 * std::max(nrm, 1e-300); ++it) {
+    const double mid = 0.5 * (lo + hi);
+    if (sturm_count(a, b, n, mid) > k) hi = mid; else lo = mid;
+  }
+  const double theta = 0.5 * (lo + hi);
+  z.assign(n, 0.0);
+  if (n == 1) { z[0] = 1.0; return theta; }
+  // (T - theta') z = rhs by Gaussian elimination with partial pivoting on the tridiagonal (theta' a hair off the
+  // eigenvalue); three sweeps from a generic start
+  const double shift = theta + 1e-13 * std::max(nrm, 1e-300);
+  std::vector<double> rhs(n);
+  for (int i = 0; i < n; ++i) rhs[i] = 1.0 / std::sqrt((double)n) * ((i & 1) ? 0.7 : 1.0);
+  std::vector<double> d(n), du(n), du2(n), dl(n);
+  for (int sweep = 0; sweep < 3; ++sweep) {
+    for (int i = 0; i < n; ++i) { d[i] = a[i] - shift; du[i] = i + 1 < n ? b[i] : 0.0; dl[i] = i + 1 < n ? b[i] : 0.0; du2[i] = 0.0; }
+    z = rhs;
+    for (int i = 0; i + 1 < n; ++i) {
+      if (std::fabs(dl[i]) > std::fabs(d[i])) {          // swap rows i and i+1
+        std::swap(d[i], dl[i]);
+        const double t = du[i]; du[i] = d[i + 1]; d[i + 1] = t;
+        du2[i] = du[i + 1]; du[i + 1] = 0.0;
+        std::swap(z[i], z[i + 1]);
+        // after the swap: row i = (d[i], du[i], du2[i]), row i+1 = (dl[i], d[i+1], du[i+1])
+      }
+      const double piv = std::fabs(d[i]) > 1e-300 ? d[i] : 1e-300;
+      const double f = dl[i] / piv;
+      d[i + 1] -= f * du[i];
+      du[i + 1] -= f * du2[i];
+      z[i + 1] -= f * z[i];
+    }
+    for (int i = n - 1; i >= 0; --i) {
+      double v = z[i];
+      if (i + 1 < n) v -= du[i] * z[i + 1];
+      if (i + 2 < n) v -= du2[i] * z[i + 2];
+      const double piv = std::fabs(d[i]) > 1e-300 ? d[i] : 1e-300;
+      z[i] = v / piv;
+    }
+    double nn = 0;
+    for (int i = 0; i < n; ++i) nn += z[i] * z[i];
+    nn = std::sqrt(nn);
+    for (int i = 0; i < n; ++i) z[i] /= nn;
+    rhs = z;
+  }
+  return theta;
+}
+
+// Lanczos without a stored basis: three work vectors, the three-term recurrence only, the tridiagonal matrix on
+// the host.  The extremal Ritz value converges regardless of the loss of orthogonality (Paige); copies of it that
+// appear later do not matter because the iteration stops at convergence.  The Ritz vector, if wanted, is built
+// in a second run of the same recurrence with the recorded coefficients.  At 16 GiB per vector a step is the
+// multiply plus one sweep -- no restarts, no re-orthogonalisation passes over a 240 GiB basis.
+static int eigsolve_basis_free(Ops &ops, dnm_mat *A, int64_t n_local, int which, double tol, int max_steps,
+                               uint64_t seed, const dnm_hooks *hooks, double *evals, void *evecs,
+                               dnm_solver_stats *stats, hipStream_t st) {
+  void *W = nullptr;
+  DNM_TRY(basis_workspace((size_t)4 * (size_t)n_local * 16, &W));
+  const int64_t offset = hooks ? A->row0 : 0;
+  const int vswz = A->right.host.swz;
+  std::vector<double> al, be, svec;
+  double theta = 0, res = 0;
+  bool converged = false;
+  int steps = 0;
+  auto slot = [&](int k) { return (void *)vecptr(W, n_local, k % 3); };
+  auto start = [&]() -> int {
+    DNM_TRY(vk_random(slot(0), n_local, seed, offset, st, vswz));
+    double n0 = 0;
+    DNM_TRY(ops.norm(slot(0), &n0));
+    DNM_CHECK(n0 > 0, "zero start vector");
+    return vk_scale(slot(0), n_local, 1.0 / n0, 0, st);
+  };
+  auto pick = [&](int n, std::vector<double> &z) {
+    if (which == DNM_WHICH_LOWEST) return tridiag_eigpair(al, be, n, 0, z);
+    if (which == DNM_WHICH_HIGHEST) return tridiag_eigpair(al, be, n, n - 1, z);
+    std::vector<double> z2;
+    const double lo = tridiag_eigpair(al, be, n, 0, z), hi = tridiag_eigpair(al, be, n, n - 1, z2);
+    if (std::fabs(hi) > std::fabs(lo)) { z = z2; return hi; }
+    return lo;
+  };
+  DNM_TRY(start());
+  for (int j = 0; j < max_steps; ++j) {
+    void *q = slot(j), *p = slot(j + 1), *qm = slot(j + 2);     // (j + 2) % 3 == (j - 1) % 3
+    zc d(0);
+    double pn2 = 0;
+    DNM_TRY(ops.mult_dot(q, p, &d, j > 0 ? qm : nullptr, j > 0 ? be[j - 1] : 0.0, &pn2));
+    al.push_back(d.real());
+    const double b2 = pn2 - std::norm(d);
+    const bool fused = b2 > 1e-4 * pn2 && pn2 > 0;
+    double n2 = 0, bn;
+    DNM_TRY(vec_lanczos_update_host(p, q, nullptr, n_local, d.real(), d.imag(), 0.0, &n2, st,
+                                    fused ? 1.0 / std::sqrt(b2) : 1.0));
+    DNM_TRY(ops.sum(&n2, 1));
+    if (fused) {
+      const double nu = std::sqrt(n2 > 0 ? n2 : 0.0);
+      bn = std::sqrt(b2) * nu;
+      if (std::fabs(n2 - 1.0) > 1e-12 && nu > 0) DNM_TRY(vk_scale(p, n_local, 1.0 / nu, 0, st));
+    } else {
+      bn = std::sqrt(n2 > 0 ? n2 : 0.0);
+      if (bn > 0) DNM_TRY(vk_scale(p, n_local, 1.0 / bn, 0, st));
+    }
+    be.push_back(bn);
+    steps = j + 1;
+    double scale = 0;
+    for (int i = 0; i < steps; ++i) scale = std::max(scale, std::fabs(al[i]) + be[i]);
+    const bool breakdown = bn <= 1e-14 * std::max(1.0, scale);
+    if (steps >= 8 || breakdown || steps == max_steps) {
+      theta = pick(steps, svec);
+      res = std::fabs(bn * svec[steps - 1]);
+      if (breakdown || res <= tol * std::max(std::fabs(theta), 1e-300)) { converged = true; break; }
+    }
+  }
+  evals[0] = theta;
+  stats->err_est = res / std::max(std::fabs(theta), 1e-300);
+  const int matvecs_solve = ops.matvecs;
+  const char *venv = getenv("DNM_EIGS_VERIFY");
+  if ((evecs || (venv && venv[0] == '1')) && steps > 0) {
+    // second run: the same vectors from the same start, v = sum_j s_j q_j accumulated in the fourth slot
+    void *v = vecptr(W, n_local, 3);
+    DNM_TRY(start());
+    DNM_TRY(vk_axpby(v, slot(0), n_local, svec[0], 0.0, 0.0, 0.0, st));
+    for (int j = 0; j + 1 < steps; ++j) {
+      void *q = slot(j), *p = slot(j + 1), *qm = slot(j + 2);
+      if (j > 0) DNM_TRY(ops.mult_sub(q, p, qm, be[j - 1]));
+      else DNM_TRY(ops.mult(q, p));
+      double n2 = 0;
+      DNM_TRY(vec_lanczos_update_host(p, q, nullptr, n_local, al[j], 0.0, 0.0, &n2, st, 1.0 / be[j]));
+      DNM_TRY(vk_axpby(v, p, n_local, svec[j + 1], 0.0, 1.0, 0.0, st));
+    }
+    double vn = 0;
+    DNM_TRY(ops.norm(v, &vn));
+    DNM_CHECK(vn > 0, "zero Ritz vector");
+    DNM_TRY(vk_scale(v, n_local, 1.0 / vn, 0, st));
+    // what was promised, measured: |H v - <v, H v> v| / |theta|
+    zc d(0);
+    void *hv = slot(0);
+    DNM_TRY(ops.mult_dot(v, hv, &d));
+    double n2 = 0;
+    DNM_TRY(vec_lanczos_update_host(hv, v, nullptr, n_local, d.real(), d.imag(), 0.0, &n2, st));
+    DNM_TRY(ops.sum(&n2, 1));
+    evals[0] = d.real();
+    stats->err_est = std::sqrt(n2 > 0 ? n2 : 0.0) / std::max(std::fabs(evals[0]), 1e-300);
+    if (evecs) DNM_HIP(hipMemcpyAsync(evecs, v, (size_t)n_local * 16, hipMemcpyDeviceToDevice, st));
+  }
+  if (getenv("DNM_KRYLOV_DEBUG"))
+    fprintf(stderr, "dnm_eigsolve (basis-free Lanczos): %d steps, %d matvecs in all, theta = %.12g, relative residual %.2e (%s)\n",
+            steps, ops.matvecs, evals[0], stats->err_est, evecs ? "measured" : "Lanczos estimate");
+  DNM_HIP(hipStreamSynchronize(st));
+  stats->its = 1;
+  stats->matvecs = evecs ? ops.matvecs : matvecs_solve;
+  stats->nconv = converged ? 1 : 0;
+  stats->reason = converged ? DNM_CONVERGED_TOL : DNM_DIVERGED_ITS;
+  return 0;
+}
+
 extern "C" {
 
 int dnm_expm_chebyshev(dnm_mat *A, const void *x, void *y, int64_t n_local, double t, double tol,
@@ -901,6 +1080,20 @@ int dnm_eigsolve(dnm_mat *A, int64_t n_local, int nev, int which, double tol, in
   }
   DNM_CHECK(m >= nev, "ncv smaller than nev");
   if (max_its <= 0) max_its = (int)std::max<int64_t>(100, 2 * Nglob / m);
+  {
+    // one extremal pair of a large operator under default parameters: Lanczos without a stored basis (a step is
+    // the multiply plus one sweep; the restarted scheme below spends two thirds of its time on basis traffic at
+    // these sizes).  DNM_EIGS_BASISFREE=0 / 1 forces the choice; an explicit ncv keeps the restarted scheme.
+    const char *bf = getenv("DNM_EIGS_BASISFREE");
+    double negn = -(double)n_local;       // the smallest block decides, so that every rank takes the same path
+    DNM_TRY(ops.maxr(&negn, 1));
+    const bool want = bf ? bf[0] == '1' : (-negn >= (double)((int64_t)1 << 22));
+    if (want && nev == 1 && ncv <= 0 && Nglob > 64) {
+      const int64_t steps64 = std::min<int64_t>((int64_t)max_its * m, Nglob);
+      return eigsolve_basis_free(ops, A, n_local, which, tol, (int)std::min<int64_t>(steps64, 100000), seed, hooks,
+                                 evals, evecs, stats, st);
+    }
+  }
   DNM_CHECK((size_t)(m + 1) * 16 <= 160 * 1024, "ncv too large for the basis-rotation kernel");
 
   void *V = nullptr;

@@ -151,6 +151,12 @@ def _worker(rank, world, port, case, out_dir):
     assert np.max(np.abs(np.array(evals[:2]) - lowest)) < 1e-8, "partitioned eigsolve"
     v0 = evecs[0].to_numpy(to_all=True)
     assert np.linalg.norm(Hs @ v0 - evals[0] * v0) < 1e-7
+    os.environ["DNM_EIGS_BASISFREE"] = "1"        # one extremal pair without a stored basis, through the hooks
+    e1, v1 = H.eigsolve(nev=1, getvecs=True, tol=1e-10, subspace=sub)
+    os.environ.pop("DNM_EIGS_BASISFREE")
+    assert abs(e1[0] - lowest[0]) < 1e-8
+    v1g = v1[0].to_numpy(to_all=True)
+    assert np.linalg.norm(Hs @ v1g - e1[0] * v1g) < 1e-7
 
     # reduced density matrix / entropy of the partitioned state
     for keep in ([0, 1, 2], [L - 3, L - 2], [1, 5, L - 1]):

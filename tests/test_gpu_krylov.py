@@ -1022,3 +1022,29 @@ def test_eigsolve_many_pairs():
     ev = H.eigsolve(nev=90, tol=1e-9)
     want = np.linalg.eigvalsh(H.to_numpy(sparse=False))[:90]
     assert len(ev) >= 90 and np.max(np.abs(np.sort(ev)[:90] - want)) < 1e-7
+
+
+@pytest.mark.parametrize("which", ["lowest", "highest", "exterior"])
+@pytest.mark.parametrize("name,L,sub", [("mbl", 12, "full"), ("heisenberg", 12, "sc"), ("xxz", 11, "parity"),
+                                        ("long_range", 10, "full")])
+def test_eigsolve_basis_free(monkeypatch, name, L, sub, which):
+    """The basis-free Lanczos path (one extremal pair; the default from 2^22 local amplitudes on, forced here):
+    eigenvalue against dense diagonalisation, and with getvecs the reference's residual / Rayleigh-quotient bars
+    (tests/integration/test_eigsolve.py:17-88)."""
+    monkeypatch.setenv("DNM_EIGS_BASISFREE", "1")
+    H = models.BY_NAME[name](L)
+    s = {"full": Full(L=L), "sc": SpinConserve(L, L // 2), "parity": Parity('even', L=L)}[sub]
+    H.add_subspace(s)
+    dense = H.to_numpy(subspaces=(s, s), sparse=False)
+    w = np.linalg.eigvalsh(dense)
+    want = {"lowest": w[0], "highest": w[-1], "exterior": w[0] if abs(w[0]) > abs(w[-1]) else w[-1]}[which]
+    from dynamite_amd.computations import eigsolve
+    ev = H.eigsolve(nev=1, which=which, tol=1e-10, subspace=s)
+    assert len(ev) == 1 and abs(ev[0] - want) < 1e-8 * max(1.0, abs(want))
+    assert eigsolve.last_stats['max_rel_residual'] < 1e-9
+    ev2, vecs = H.eigsolve(nev=1, which=which, tol=1e-10, subspace=s, getvecs=True)
+    v = vecs[0].to_numpy()
+    assert abs(np.linalg.norm(v) - 1) < 1e-12
+    assert abs(ev2[0] - want) < 1e-8 * max(1.0, abs(want))
+    assert np.linalg.norm(dense @ v - ev2[0] * v) < 1e-8 * max(1.0, abs(want))      # measured, as promised
+    assert eigsolve.last_stats['max_rel_residual'] < 1e-9
