@@ -11,6 +11,10 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdynamite_amd.so")
 SOURCES = ["matvec_kernels.hip", "tile_persist.hip", "vec_kernels.hip", "rdm_kernels.hip", "plan.cpp", "mat.cpp", "vec_api.cpp", "krylov.cpp"]
 ARCH = "gfx950"
+# tile_pass_kernel sits at the 128-VGPR edge of 4 waves per SIMD; these two scheduler options of the AMDGPU backend
+# measured -2.1 % on the L=30 multiply, same box (profiles/r02_exp22_sched.txt; max-ilp / iterative-minreg: +12...17 %)
+PER_FILE_FLAGS = {"matvec_kernels.hip": ["-mllvm", "-amdgpu-schedule-relaxed-occupancy=true",
+                                         "-mllvm", "-amdgpu-sched-strategy=max-memory-clause"]}
 
 
 def _hipcc():
@@ -35,12 +39,13 @@ def build(force=False, verbose=False):
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
     flags = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+    flags += os.environ.get("DNM_HIPCC_EXTRA", "").split()        # experiments (scheduler options ...)
     procs = []
     objs = []
     for s in SOURCES:
         o = os.path.join(objdir, s + ".o")
         objs.append(o)
-        cmd = [_hipcc()] + flags + ["-x", "hip", "-c", os.path.join(CSRC, s), "-o", o]
+        cmd = [_hipcc()] + flags + PER_FILE_FLAGS.get(s, []) + ["-x", "hip", "-c", os.path.join(CSRC, s), "-o", o]
         if verbose:
             print(" ".join(cmd))
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
