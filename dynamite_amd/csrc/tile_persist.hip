@@ -202,32 +202,47 @@ __device__ __forceinline__ void slot_apply(const GSlot<R> &g, double (&ar)[R], d
   }
 }
 
-// records [gb, ge): four slots, record j+4 is issued when record j has been multiplied
-template <int R, int LOGNT>
+// records [gb, ge): NS slots (2 or 4), record j+NS is issued when record j has been multiplied
+template <int R, int LOGNT, int NS>
 __device__ __forceinline__ void gather_pipeline(const DevQuad *__restrict__ quads, uint32_t gb, uint32_t ge,
                                                 double (&ar)[R], double (&ai)[R], const c128 *__restrict__ x,
                                                 const c128 *__restrict__ xr, uint32_t xr_xor, const Swz &z,
                                                 uint32_t pt4, const uint32_t (&ps)[R], uint32_t tid, uint64_t sbase) {
-  GSlot<R> g0, g1, g2, g3;
-  g0.live = g1.live = g2.live = g3.live = false;
 #define DNM_ISSUE(G, Q) if ((Q) < ge) slot_issue<R, LOGNT>(G, quads[(Q)], x, xr, xr_xor, z, pt4, ps, tid, sbase); else G.live = false
-  for (uint32_t q = gb; q < ge; q += 8u) {
-    DNM_ISSUE(g0, q);
-    DNM_ISSUE(g1, q + 1u);
-    DNM_ISSUE(g2, q + 2u);
-    DNM_ISSUE(g3, q + 3u);
-    slot_apply<R>(g0, ar, ai);
-    DNM_ISSUE(g0, q + 4u);
-    slot_apply<R>(g1, ar, ai);
-    DNM_ISSUE(g1, q + 5u);
-    slot_apply<R>(g2, ar, ai);
-    DNM_ISSUE(g2, q + 6u);
-    slot_apply<R>(g3, ar, ai);
-    DNM_ISSUE(g3, q + 7u);
-    slot_apply<R>(g0, ar, ai);
-    slot_apply<R>(g1, ar, ai);
-    slot_apply<R>(g2, ar, ai);
-    slot_apply<R>(g3, ar, ai);
+  if constexpr (NS == 2) {
+    GSlot<R> g0, g1;
+    g0.live = g1.live = false;
+    for (uint32_t q = gb; q < ge; q += 4u) {
+      DNM_ISSUE(g0, q);
+      DNM_ISSUE(g1, q + 1u);
+      slot_apply<R>(g0, ar, ai);
+      DNM_ISSUE(g0, q + 2u);
+      slot_apply<R>(g1, ar, ai);
+      DNM_ISSUE(g1, q + 3u);
+      slot_apply<R>(g0, ar, ai);
+      slot_apply<R>(g1, ar, ai);
+    }
+  } else {
+    GSlot<R> g0, g1, g2, g3;
+    g0.live = g1.live = g2.live = g3.live = false;
+    for (uint32_t q = gb; q < ge; q += 8u) {
+      DNM_ISSUE(g0, q);
+      DNM_ISSUE(g1, q + 1u);
+      DNM_ISSUE(g2, q + 2u);
+      DNM_ISSUE(g3, q + 3u);
+      slot_apply<R>(g0, ar, ai);
+      DNM_ISSUE(g0, q + 4u);
+      slot_apply<R>(g1, ar, ai);
+      DNM_ISSUE(g1, q + 5u);
+      slot_apply<R>(g2, ar, ai);
+      DNM_ISSUE(g2, q + 6u);
+      slot_apply<R>(g3, ar, ai);
+      DNM_ISSUE(g3, q + 7u);
+      slot_apply<R>(g0, ar, ai);
+      slot_apply<R>(g1, ar, ai);
+      slot_apply<R>(g2, ar, ai);
+      slot_apply<R>(g3, ar, ai);
+    }
   }
 #undef DNM_ISSUE
 }
@@ -237,7 +252,9 @@ __device__ __forceinline__ void gather_pipeline(const DevQuad *__restrict__ quad
 #define GLOBAL_AS __attribute__((address_space(1)))
 #define LDS_AS __attribute__((address_space(3)))
 
-template <int B, int LOGR>
+// REGS: the next tile is prefetched into registers (and written to the other LDS buffer at the top of its
+// iteration) instead of by DMA
+template <int B, int LOGR, bool REGS>
 __global__ void __launch_bounds__(1 << (B - LOGR))
 tile_persist_kernel(const DevPass *__restrict__ Pp, const PassCall C, const c128 *__restrict__ x,
                     c128 *__restrict__ y, const c128 *__restrict__ xr, uint32_t nblocks) {
@@ -270,12 +287,18 @@ tile_persist_kernel(const DevPass *__restrict__ Pp, const PassCall C, const c128
   double dsum_r = 0.0, dsum_i = 0.0, dsum_n = 0.0;     // fused <x, y>, |y|^2 over this workgroup's tiles
   uint32_t cur = 0;
   const uint32_t wave_base = tid & ~63u;               // LDS-DMA: the wave's 64 lanes land on consecutive slots
+  d2v pre[R];
   if (need_tile) {
     const uint32_t pb = z.phys(deposit<MAXBSEG>(bid, P0.nbseg, P0.bseg_off, P0.bseg_len, P0.bseg_pos));
+    if constexpr (REGS) {
 #pragma unroll
-    for (int k = 0; k < R; ++k)
-      __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *)elem(x, pt4, pk[k] ^ pb),
-                                       (LDS_AS void *)(bufs + (k * NT + wave_base)), 16, 0, 0);
+      for (int k = 0; k < R; ++k) pre[k] = *elem(x, pt4, pk[k] ^ pb);
+    } else {
+#pragma unroll
+      for (int k = 0; k < R; ++k)
+        __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *)elem(x, pt4, pk[k] ^ pb),
+                                         (LDS_AS void *)(bufs + (k * NT + wave_base)), 16, 0, 0);
+    }
   }
 
   for (; bid < nblocks; bid += gridDim.x) {
@@ -294,6 +317,12 @@ tile_persist_kernel(const DevPass *__restrict__ Pp, const PassCall C, const c128
     const bool has_diag = P.has_diag != 0, accumulate = P.accumulate != 0;
     const DevQuad *__restrict__ quads = P.quads;
     const c128 *tile = bufs + cur * TILE;
+    if constexpr (REGS) {
+      if (need_tile) {      // (the waves still reading are on the OTHER buffer: no barrier needed before these writes)
+#pragma unroll
+        for (int k = 0; k < R; ++k) *reinterpret_cast<d2v *>(bufs + cur * TILE + (tid + k * NT)) = pre[k];
+      }
+    }
 
     // ---- accumulator start values (streamed: read once)
     double ar[R], ai[R];
@@ -334,7 +363,7 @@ tile_persist_kernel(const DevPass *__restrict__ Pp, const PassCall C, const c128
     // within the same microseconds, so the L2 merges the requests
 #define DNM_GLOOP(LP, KV, CX) \
   records<R, LOGNT, KV, CX, true, false>(quads, P.loop[LP], P.loop[LP + 1], ar, ai, tile, x, xr, xrx, z, pt4, ps, tid, sbase)
-    gather_pipeline<R, LOGNT>(quads, P.loop[LP_GATHER_REAL], P.loop[LP_GATHER_KVAR_REAL + 1], ar, ai, x, xr, xrx, z, pt4,
+    gather_pipeline<R, LOGNT, (NT >= 1024 || REGS) ? 2 : 4>(quads, P.loop[LP_GATHER_REAL], P.loop[LP_GATHER_KVAR_REAL + 1], ar, ai, x, xr, xrx, z, pt4,
                               ps, tid, sbase);
     DNM_GLOOP(LP_GATHER_CPLX, false, true);
     DNM_GLOOP(LP_GATHER_KVAR_CPLX, true, true);
@@ -360,16 +389,21 @@ tile_persist_kernel(const DevPass *__restrict__ Pp, const PassCall C, const c128
       for (int off = 32; off > 0; off >>= 1) dext += __shfl_xor(dext, off, 64);
     }
     if (need_tile) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's rows of the tile have landed
+      if constexpr (!REGS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's rows of the tile have landed
       __syncthreads();                                   // tile `bid` is complete; the other buffer is free
       const uint32_t nb = bid + gridDim.x;
-      if (nb < nblocks) {                                // tile t+1 -> the other buffer, under the LDS phase of tile t
+      if (nb < nblocks) {                                // tile t+1 is requested under the LDS phase of tile t
         const uint32_t pbn = z.phys(deposit<MAXBSEG>(nb, P.nbseg, P.bseg_off, P.bseg_len, P.bseg_pos));
-        c128 *dst = bufs + (cur ^ 1u) * TILE;
+        if constexpr (REGS) {
 #pragma unroll
-        for (int k = 0; k < R; ++k)
-          __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *)elem(x, pt4, pk[k] ^ pbn),
-                                           (LDS_AS void *)(dst + (k * NT + wave_base)), 16, 0, 0);
+          for (int k = 0; k < R; ++k) pre[k] = *elem(x, pt4, pk[k] ^ pbn);
+        } else {
+          c128 *dst = bufs + (cur ^ 1u) * TILE;
+#pragma unroll
+          for (int k = 0; k < R; ++k)
+            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *)elem(x, pt4, pk[k] ^ pbn),
+                                             (LDS_AS void *)(dst + (k * NT + wave_base)), 16, 0, 0);
+        }
       }
     }
 
@@ -498,7 +532,8 @@ static int launch_persist_cfg(const DevPass *P_dev, const PassCall &call, int n_
   const size_t lds = (size_t)32 << B;              // double-buffered tile
   const unsigned nblocks = 1u << (n_loc - B);
   const unsigned grid = tile_persist_grid(n_loc, B);
-  auto k = tile_persist_kernel<B, LOGR>;
+  static const bool regs = []() { const char *e = getenv("DNM_PERSIST_STAGE"); return !(e && e[0] == 'd'); }();
+  auto k = regs ? tile_persist_kernel<B, LOGR, true> : tile_persist_kernel<B, LOGR, false>;
   static bool attr_done = false;
   if (!attr_done) {
     DNM_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
