@@ -61,14 +61,19 @@ def cpu_baseline(sample_L=26, reps=3):
     nt = orc.max_threads()
     rate, best = time_one(sample_L, nt, reps)
     rate1, best1 = time_one(24, 1, 1)
+    n16 = min(16, nt)
+    rate16, _ = time_one(24, n16, 2)
     out = {"value": rate / 1e9, "unit": "Gamplitudes/s", "cores": nt, "kind": "port",
            "per_core_Mamp_s": rate / nt / 1e6, "one_thread_Mamp_s": rate1 / 1e6,
+           "threads_%d_Mamp_s_per_thread" % n16: rate16 / n16 / 1e6,
            "reference_anchor_Mamp_s_per_core": [4.3, 6.8],
            "sample": f"L={sample_L} random-field Heisenberg, Full space, best of {reps} multiplies ({best:.2f} s each) "
                      f"of the oracle's MatMult_CPU_Fast restatement on {nt} OpenMP threads = {rate / nt / 1e6:.2f} "
                      f"Mamp/s per thread; one thread at L=24: {best1:.2f} s = "
-                     f"{rate1 / 1e6:.2f} Mamp/s, against 4.3-6.8 Mamp/s per core measured for the reference's own C "
-                     f"(SURVEY section 6)"}
+                     f"{rate1 / 1e6:.2f} Mamp/s, {n16} threads at L=24: {rate16 / n16 / 1e6:.2f} Mamp/s per thread, against "
+                     f"4.3-6.8 Mamp/s per core measured for the reference's own C (SURVEY section 6); the rate per "
+                     f"thread falls with the thread count because every mask re-reads x from host memory "
+                     f"(30 x 16 B per amplitude)"}
     if os.environ.get("DNM_BENCH_CPU_L30"):
         try:
             r30, b30 = time_one(30, nt, 1)

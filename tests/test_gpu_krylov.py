@@ -1048,3 +1048,32 @@ def test_eigsolve_basis_free(monkeypatch, name, L, sub, which):
     assert abs(ev2[0] - want) < 1e-8 * max(1.0, abs(want))
     assert np.linalg.norm(dense @ v - ev2[0] * v) < 1e-8 * max(1.0, abs(want))      # measured, as promised
     assert eigsolve.last_stats['max_rel_residual'] < 1e-9
+
+
+@pytest.mark.default_layout
+def test_vec_layout_conversions_chunked():
+    """Vec index operations under the production layout on a block larger than the conversion chunk (2^24):
+    numpy round trip (chunked both ways), single positions, ranges, the one-kernel conversion and the RNG stream
+    (a swizzled vector holds the numbers index order would)."""
+    import torch
+    n = (1 << 25) + 0
+    S = 16
+    a = rand_state(n, seed=4)
+    v = vec_from(a, S)
+    assert v.swz == S
+    back = v.local_numpy()
+    assert np.array_equal(back, a)
+    idx = torch.tensor([0, 15, 16, (1 << 16) - 1, 1 << 16, (1 << 16) + 17, (1 << 24) + 12345, n - 1], device=v.array.device)
+    assert np.array_equal(v.array[v.positions(idx)].cpu().numpy(), a[idx.cpu().numpy()])
+    assert not np.array_equal(v.array[idx].cpu().numpy(), a[idx.cpu().numpy()])      # the layout does permute
+    lo, hi = (1 << 20) - 5, (1 << 20) + 70000
+    assert np.array_equal(v.get_local(lo, hi).cpu().numpy(), a[lo:hi])
+    nat = v.local_natural()
+    assert np.array_equal(nat.cpu().numpy(), a)
+    w = backend.Vec(n, swz=S)
+    w.set_local(lo, hi, torch.from_numpy(a[lo:hi]).to(w.array.device))
+    assert np.array_equal(w.get_local(lo, hi).cpu().numpy(), a[lo:hi]) and float(w.norm()) > 0
+    r0, r1 = backend.Vec(n), backend.Vec(n, swz=S)
+    r0.set_random(77)
+    r1.set_random(77)
+    assert np.array_equal(r1.local_numpy(), r0.local_numpy())
