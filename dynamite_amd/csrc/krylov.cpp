@@ -872,13 +872,20 @@ int dnm_expm_multiply(dnm_mat *A, const void *x, void *y, int64_t n_local, doubl
   DNM_TRY(ops.norm(y, &beta));
   if (beta == 0.0 || anorm == 0.0) { stats->reason = DNM_CONVERGED_TOL; return 0; }
 
-  if (hybrid && A->expm_tstep > 0.0) {
-    // an earlier solve with this operator ended in the Chebyshev expansion: if the Krylov step size seen then
-    // still makes the expansion the cheaper one for this interval, skip the Krylov probe
+  if (hybrid) {
+    // skip the Krylov probe when the expansion -- whose term count is known exactly -- is the cheaper one: an
+    // earlier solve with this operator ended in it and the Krylov step size seen then still says so for this
+    // interval; or the whole expansion costs less than ONE outer Krylov step of m multiplies (short time steps:
+    // no basis, and none of the seconds a 200 GiB workspace takes to acquire)
     int64_t terms = 0;
     DNM_TRY(cheb_cost(anorm * t_out, tol, &terms));
-    const double kry = 1.9 * (double)A->expm_m * std::ceil(t_out / A->expm_tstep);
-    if (1.25 * (double)terms < 0.8 * kry) {
+    bool go = false;
+    if (A->expm_tstep > 0.0) {
+      const double kry = 1.9 * (double)A->expm_m * std::ceil(t_out / A->expm_tstep);
+      go = 1.25 * (double)terms < 0.8 * kry;
+    }
+    if (!go) go = 1.25 * (double)terms <= 1.9 * (double)m;
+    if (go) {
       void *W = nullptr;
       DNM_TRY(basis_workspace((size_t)4 * (size_t)n_local * 16, &W));
       int csteps = 0;

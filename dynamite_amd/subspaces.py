@@ -365,52 +365,54 @@ class XParity(Subspace):
 
     _product_state_basis = False
 
+    _SECTORS = {'+': +1, '-': -1, +1: +1, -1: -1}
+
     def __init__(self, parent=None, sector='+', L=None):
-        if parent is None:
-            parent = Full()
-        self._parent = parent
+        self._parent = Full() if parent is None else parent
         self._chksum = None
         self._cdesc = None
         if L is not None:
-            self.parent.L = L
-        self._validate_parent(self.parent)
-        if sector in ['+', +1]:
-            self._sector = +1
-        elif sector in ['-', -1]:
-            self._sector = -1
-        else:
-            raise ValueError('invalid value for sector')
+            self._parent.L = L
+        self._validate_parent(self._parent)
+        try:
+            self._sector = self._SECTORS[sector]
+        except (KeyError, TypeError):
+            raise ValueError('invalid value for sector') from None
+
+    @staticmethod
+    def _flip_closed(parent):
+        """Reason (text) why ``parent`` cannot carry the global flip, or None.  The closed-form spaces are
+        decided from their parameters; a listed space (Explicit, Auto) from its states: the first half of the
+        basis must be the representatives (spin L-1 up) and the complement of each must be listed too -- the
+        second half then holds exactly those complements, since the states are distinct (subspaces.py:566-617)."""
+        if isinstance(parent, Parity):
+            return None if parent.L % 2 == 0 else 'Parity is only compatible with XParity when L is even'
+        if isinstance(parent, SpinConserve):
+            return None if parent.L == 2 * parent.k else \
+                'SpinConserve is only compatible with XParity when k=L/2'
+        half, odd = divmod(parent.get_dimension(), 2)
+        if odd:
+            return 'parent subspace must have even dimension'
+        everything = (1 << parent.L) - 1
+        for first in range(0, half, 1 << 16):
+            reps = parent.idx_to_state(np.arange(first, min(first + (1 << 16), half)))
+            if (reps >> (parent.L - 1)).any():
+                return 'first dim/2 basis states must have spin L-1 up (0 in integer notation)'
+            if (parent.state_to_idx(reps ^ everything) < 0).any():
+                return 'the complement of every state in subspace (all spins flipped) must also be in subspace'
+        return None
 
     @classmethod
     def _validate_parent(cls, parent):
-        """What subspaces.py:566-617 requires of a parent: a product-state basis, closed under the
-        global flip, whose first half is exactly the configurations with spin L-1 up."""
         if not parent.product_state_basis:
             raise ValueError('parent must be a product state subspace')
         if isinstance(parent, Full):
-            return
+            return                                   # any L, set or not
         if parent.L is None:
             raise ValueError('L must be set for the parent subspace')
-        if isinstance(parent, Parity):
-            if parent.L % 2:
-                raise ValueError('Parity is only compatible with XParity when L is even')
-            return
-        if isinstance(parent, SpinConserve):
-            if parent.L != 2 * parent.k:
-                raise ValueError('SpinConserve is only compatible with XParity when k=L/2')
-            return
-        # anything else (Explicit, Auto): look at the states themselves
-        dim = parent.get_dimension()
-        if dim % 2:
-            raise ValueError('parent subspace must have even dimension')
-        reps = parent.idx_to_state(np.arange(dim // 2))
-        if np.any(reps >> (parent.L - 1)):
-            raise ValueError('first dim/2 basis states must have spin L-1 up '
-                             '(0 in integer notation)')
-        partners = parent.state_to_idx(reps ^ ((1 << parent.L) - 1))
-        if np.any(partners < 0):
-            raise ValueError('the complement of every state in subspace (all spins flipped) '
-                             'must also be in subspace')
+        why = cls._flip_closed(parent)
+        if why is not None:
+            raise ValueError(why)
 
     @property
     def parent(self):
