@@ -6,7 +6,8 @@ BASELINE configs 4 and 5 at their full per-rank size on ONE GPU (the 8-GPU runs 
   them) are checked on sampled rows -- on both sides of every power-of-two boundary of the local index, so tile,
   XCD-group, window, swizzle-field and rank-bit edges are all hit -- against the MSC definition
   (reference semantics: src/dynamite/_backend/bpetsc_template_2.c:371-412; the reference's own large-index
-  tests: tests/integration/test_matrices.py:183-232, int64 masks and signs above bit 31).
+  tests: tests/integration/test_matrices.py:183-232, int64 masks and signs above bit 31); and with two ranks'
+  shares resident, the off-diagonal blocks H_rs and H_sr are checked to be adjoint to each other.
 * config 5 -- L=36 SpinConserve k=18, 8 ranks: rank 3's rows (1.13 G) through its 4.1x column window, block kernel
   against the row kernel element-wise and against the MSC definition on sampled rows
   (bsubspace_impl.h:187-245 maps, PetscSplitOwnership blocks).
@@ -177,3 +178,58 @@ def test_config5_rank3_of_eight(monkeypatch):
     ynorm = out["13"].norm()
     out["0"].axpby(-1.0, 1.0, out["13"])
     assert out["0"].norm() <= 1e-13 * ynorm
+
+
+def test_config4_hermiticity_between_ranks():
+    """<u_r, H_rs v_s> = conj(<v_s, H_sr u_r>) with both ranks' shares of L=34 / P=8 resident: the remote passes of
+    rank 5 fed from slices of rank s's block, those of rank s fed from rank 5's -- for the partner across the
+    boundary bond (4: half blocks travel) and one across a rank-bit bond (6: whole blocks)."""
+    import torch
+    L, P, r = 34, 8, 5
+    nl = L - 3
+    nloc = 1 << nl
+    _need(4 * 16 * nloc + (6 << 30))
+    H = models.heisenberg(L)
+    arrs = marshal(H)
+    sub = Full(L=L)
+    Lb = _lib.lib()
+
+    def shell(rank):
+        h = backend.create_mat(*arrs, sub._c(), sub._c(), flags=0, rank=rank, nranks=P)
+        return backend.ShellMat(h, sub._c(), sub._c(), P, rank)
+
+    def block(rank, seed):
+        v = backend.Vec(nloc, swz=sub.vec_swizzle)
+        v.start = rank * nloc
+        v.set_random(seed)
+        return v
+
+    def off_diagonal(mat, partner, src):
+        """H_(mat.rank, partner) applied to the partner's block ``src``: every remote pass fed by that partner."""
+        out = backend.Vec(nloc, swz=sub.vec_swizzle)
+        out.array.zero_()
+        fed = 0
+        for i, (p, off, cnt) in enumerate(mat.recvs):
+            if p != partner:
+                continue
+            piece = C.c_void_p(src.array.data_ptr() + 16 * off)
+            _lib.check(Lb.dnm_mat_mult_remote(mat.handle, i, piece, out.ptr, None))
+            fed += cnt
+        torch.cuda.synchronize()
+        return out, fed
+
+    mr = shell(r)
+    u = block(r, 21)
+    for s, whole in ((4, False), (6, True)):
+        ms = shell(s)
+        v = block(s, 22 + s)
+        y, fed_r = off_diagonal(mr, s, v)          # rows of rank r, columns of rank s
+        w, fed_s = off_diagonal(ms, r, u)          # rows of rank s, columns of rank r
+        assert fed_r == fed_s and (fed_r == nloc) == whole and fed_r >= nloc // 2
+        a = u.dot(y)
+        b = v.dot(w)
+        assert abs(a) > 1e-3, "the two shares do not couple"
+        assert abs(a - b.conjugate()) <= 1e-10 * abs(a), (a, b)     # 2^31-term sums of O(1) products
+        ms.destroy()
+        del v, y, w
+    mr.destroy()
