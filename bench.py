@@ -9,8 +9,9 @@ Full space, complex128, on N MI355X GPUs of one node.
 A "step" is one multiply y = H x with x, y resident in HBM.  N=1: L=30 (2^30
 amplitudes, 16 GiB per vector; BASELINE.json configs[2]).  N>1: the state is
 row-block partitioned, L = 30 + log2(N) so every GPU keeps 2^30 amplitudes
-(weak scaling); partner blocks travel over RCCL while the rank-local masks
-run.  Prints ONE JSON line on rank 0.
+(weak scaling); the rank exchange (partner blocks on 2 ranks, an all-to-all
+between two layouts from 4 on -- DESIGN.md section 6) travels over RCCL while
+the rank-local masks run.  Prints ONE JSON line on rank 0.
 
 Launch forms: under torch.distributed.run (RANK / WORLD_SIZE in the environment) every process is one
 rank; a bare `python bench.py --gpus N` (N > 1, no WORLD_SIZE) starts its own N rank processes BEFORE
@@ -137,17 +138,13 @@ def spawn_ranks(n):
     sys.exit(rc)
 
 
-def exchange_estimate(sends, recvs, n_gpus):
-    """Bytes this rank moves over xGMI per multiply and the time the busiest link needs for them."""
-    per_partner = {}
-    for p, _, cnt in recvs:
-        per_partner[p] = per_partner.get(p, 0) + 16 * cnt
-    out_bytes = sum(16 * cnt for _, _, cnt in sends)
-    in_bytes = sum(per_partner.values())
-    worst = max(per_partner.values()) if per_partner else 0
-    return {"xgmi_bytes_per_step": int(in_bytes), "xgmi_bytes_sent_per_step": int(out_bytes),
-            "xgmi_partners": len(per_partner), "xgmi_link_GBs_assumed": XGMI_LINK_GBS,
-            "xgmi_link_bound_ms": worst / (XGMI_LINK_GBS * 1e9) * 1e3}
+def exchange_estimate(summary):
+    """Bytes this rank moves over xGMI per multiply (ShellMat.exchange_summary) and the time the busiest link
+    needs for them."""
+    return {"exchange": summary["scheme"], "xgmi_bytes_per_step": int(summary["bytes_in"]),
+            "xgmi_bytes_sent_per_step": int(summary["bytes_out"]), "xgmi_partners": int(summary["peers"]),
+            "xgmi_busiest_link_bytes": int(summary["busiest_link_bytes"]), "xgmi_link_GBs_assumed": XGMI_LINK_GBS,
+            "xgmi_link_bound_ms": summary["busiest_link_bytes"] / (XGMI_LINK_GBS * 1e9) * 1e3}
 
 
 def dry_run(args, world, rank):
@@ -165,26 +162,70 @@ def dry_run(args, world, rank):
     sub = Full(L=L)
     lc, rc = sub._c(), sub._c()
     h = backend.create_mat(masks, offs, H.msc['signs'], H.msc['coeffs'], lc, rc, False, _lib.MAT_HOST_ONLY, rank, world)
-    sends, recvs = backend.exchange_plan(h)
     nloc = (1 << L) // world
-    x = torch.full((nloc,), complex(rank + 1, 0), dtype=torch.complex128)
-    bufs = [torch.empty(cnt, dtype=x.dtype) for _, _, cnt in recvs]
+    nbits = nloc.bit_length() - 1
+    split = None
+    if backend.use_transposed_exchange(world):
+        split = backend.transpose_split(masks, offs, H.msc['signs'], H.msc['coeffs'], L, world, int(lc.vec_swizzle))
+    if split is not None:
+        # transposed exchange: both operators must plan without partner passes; the all-to-all runs both ways
+        lo, hi, f = split
+        plans = []
+        for part in (lo, hi):
+            hp = backend.create_mat(*part, lc, rc, False, _lib.MAT_HOST_ONLY, rank, world)
+            assert backend.exchange_plan(hp) == ([], [])
+            plans.append(C_describe(hp).strip().replace("\n", " | "))
+            _lib.check(_lib.lib().dnm_mat_destroy(hp))
+        pieces, own, cnt = backend.transpose_pieces(nbits, world.bit_length() - 1, f, rank)
+        gidx = torch.arange(nloc, dtype=torch.float64) + float(rank * nloc)
+        x = gidx.to(torch.complex128)
+        xb = torch.empty_like(x)
+
+        def one_step():
+            for src, dst in ((x, xb), (xb, x)):          # there and back: x must come home unchanged
+                if dst is x:
+                    dst.fill_(-1.0)
+                for r in backend.post_transpose(src, dst, pieces):
+                    r.wait()
+                for off in own:
+                    dst[off:off + cnt] = src[off:off + cnt]
+        summary = {"scheme": "transpose", "bytes_in": 2 * 16 * cnt * len(pieces), "bytes_out": 2 * 16 * cnt * len(pieces),
+                   "peers": world - 1, "busiest_link_bytes": 2 * 16 * cnt * len(pieces) // (world - 1)}
+    else:
+        plans = None
+        sends, recvs = backend.exchange_plan(h)
+        x = torch.full((nloc,), complex(rank + 1, 0), dtype=torch.complex128)
+        bufs = [torch.empty(cnt, dtype=x.dtype) for _, _, cnt in recvs]
+
+        def one_step():
+            for r in backend.post_exchange(x, sends, recvs, bufs):
+                r.wait()
+        per = {}
+        for p_, _, c_ in recvs:
+            per[p_] = per.get(p_, 0) + 16 * c_
+        summary = {"scheme": "partner", "bytes_in": sum(per.values()), "bytes_out": sum(16 * c_ for _, _, c_ in sends),
+                   "peers": len(per), "busiest_link_bytes": max(per.values()) if per else 0}
     for _ in range(args.warmup):
-        for r in backend.post_exchange(x, sends, recvs, bufs):
-            r.wait()
+        one_step()
     dist.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        for r in backend.post_exchange(x, sends, recvs, bufs):
-            r.wait()
+        one_step()
     dist.barrier()
     wall = time.perf_counter() - t0
-    ok = all(bool((b == complex(p + 1, 0)).all()) for (p, _, _), b in zip(recvs, bufs))
+    if split is not None:
+        # layout B holds, at local index i' of rank q, the element whose global index has the two fields swapped
+        g = torch.arange(nloc, dtype=torch.int64) + rank * nloc
+        d = ((g >> f) ^ (g >> nbits)) & (world - 1)
+        want_b = (g ^ (d << f) ^ (d << nbits)).to(torch.float64)
+        ok = bool((xb.real == want_b).all()) and bool((x.real == gidx).all())
+    else:
+        ok = all(bool((b == complex(p + 1, 0)).all()) for (p, _, _), b in zip(recvs, bufs))
     t = torch.tensor([wall, 0.0 if ok else 1.0], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     if rank == 0:
-        buf = C_describe(h)
-        est = exchange_estimate(sends, recvs, world)
+        buf = C_describe(h) if plans is None else "transposed exchange | A: " + plans[0] + " | B: " + plans[1]
+        est = exchange_estimate(summary)
         print(json.dumps({
             "metric": "matrix-free H|psi> Gamplitudes/s, random-field Heisenberg", "value": None,
             "unit": "Gamplitudes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -265,10 +306,7 @@ def main():
     x.set_random(0)
     x.normalize()
 
-    import ctypes as C
-    nl = C.c_int()
-    _lib.check(_lib.lib().dnm_mat_plan_launches(mat.handle, C.byref(nl)))
-    launches = nl.value + len(mat.recvs)
+    launches = mat.launches_per_mult()
 
     def barrier():
         torch.cuda.synchronize()
@@ -293,6 +331,12 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall, dev_ms = float(t[0]), float(t[1])
     ms_per_step = wall * 1e3 / args.steps
+    summary = mat.exchange_summary()
+    if world > 1:       # the heaviest rank (partner blocks differ from rank to rank: rank 0 needs the least)
+        t = torch.tensor([summary["bytes_in"], summary["bytes_out"], summary["busiest_link_bytes"], summary["peers"]],
+                         dtype=torch.float64, device=config.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        summary.update(bytes_in=int(t[0]), bytes_out=int(t[1]), busiest_link_bytes=int(t[2]), peers=int(t[3]))
 
     # sanity: the timed multiply produced a finite vector of the expected size
     ynorm = y.norm()
@@ -334,7 +378,7 @@ def main():
                        "partition": f"{n_gpus} x 2^{L - int(math.log2(n_gpus))} contiguous blocks",
                        "launches_per_step": launches,
                        "transport": (os.environ.get("DNM_BENCH_BACKEND", "nccl") if world > 1 else "none"),
-                       **exchange_estimate(mat.sends, mat.recvs, n_gpus),
+                       **exchange_estimate(summary),
                        "tile_bits": int(os.environ.get("DNM_TILE_BITS", "12")),
                        "plan_mode": int(os.environ.get("DNM_PLAN_MODE", "2")),
                        "plan": mat.describe().strip().replace("\n", " | "),

@@ -110,10 +110,11 @@ def gather_varied(tensor, sizes, dst=0):
 
 def reduce_sum(tensor, dst=0):
     """Sum over the ranks, in place on rank ``dst`` (other ranks' tensors are left unspecified)."""
+    flat = torch.view_as_real(tensor) if tensor.is_complex() else tensor     # shares the memory
     if _staged(tensor):
-        dist.all_reduce(tensor)          # gloo reduces device tensors only through all_reduce
+        dist.all_reduce(flat)            # gloo reduces device tensors only through all_reduce
     else:
-        dist.reduce(tensor, dst=dst)
+        dist.reduce(flat, dst=dst)
 
 
 def barrier():

@@ -115,6 +115,72 @@ def post_exchange(x_local, sends, recvs, recv_bufs):
                            [(buf, p) for (p, _, _), buf in zip(recvs, recv_bufs)])
 
 
+def transpose_split(masks, mask_offsets, signs, coeffs, L, nranks, swizzle=0):
+    """Split a Full-space operator on P = 2^p ranks for the transposed exchange, or None if it does not apply.
+
+    A rank's block holds the n = L - p low spins; the rank number is the p top spins.  A mask that flips a top
+    spin couples blocks of different ranks.  Instead of shipping a partner block per such mask
+    (bpetsc_template_2.c:787-879 scatters the needed entries), the state is redistributed ONCE so that the top
+    spins become local: layout B swaps spins [n, n+p) with the local spins F = [f, f+p), f = n - 1 - p (right
+    below the top local spin, which the boundary bond touches).  In layout B every mask that flips a top spin is
+    rank-local provided it leaves F alone; it is the same MSC term with the two bit fields swapped.  One
+    all-to-all of the state, one local pass, one all-to-all of the result: every xGMI link carries
+    2 * 2^n / P amplitudes per multiply instead of up to 2^n on one link.
+
+    Returns (lo, hi, f): ``lo`` = (masks, offsets, signs, coeffs) of the terms that flip no top spin (layout A),
+    ``hi`` = the others with bits permuted (layout B)."""
+    p = nranks.bit_length() - 1
+    n = L - p
+    f = n - 1 - p
+    if nranks != 1 << p or p < 1 or f < 0:
+        return None
+    if swizzle and f < 2 * swizzle - 4:
+        return None                    # pieces of 2^f amplitudes must keep their internal order in both layouts
+    masks = np.asarray(masks, dtype=np.int64)
+    offs = np.asarray(mask_offsets, dtype=np.int64)
+    signs = np.asarray(signs, dtype=np.int64)
+    coeffs = np.asarray(coeffs, dtype=np.complex128)
+    tm = np.repeat(masks, np.diff(offs))
+    top = (tm >> n) != 0
+    fld = np.int64(nranks - 1)
+    if not top.any() or top.all() or ((tm[top] >> f) & fld).any():
+        return None
+
+    def swap(v):
+        d = ((v >> f) ^ (v >> n)) & fld
+        return v ^ (d << f) ^ (d << n)
+
+    def csr(m, sg, c):
+        order = np.argsort(m, kind='stable')
+        m, sg, c = m[order], sg[order], c[order]
+        um, first = np.unique(m, return_index=True)
+        return um, np.append(first, m.size).astype(np.int64), sg, c
+
+    lo = csr(tm[~top], signs[~top], coeffs[~top])
+    hi = csr(swap(tm[top]), swap(signs[top]), coeffs[top])
+    return lo, hi, f
+
+
+def transpose_pieces(n, p, f, rank):
+    """The all-to-all between layouts A and B as (peer, offset, count) pieces: the piece at ``offset`` of the
+    source vector goes to ``peer`` and the piece received from ``peer`` lands at the same ``offset`` of the
+    destination vector (the map is its own inverse).  Pieces for one peer are listed in the same order on both
+    sides.  Returns (pieces, own): ``own`` = offsets that stay on this rank."""
+    P = 1 << p
+    nb = 1 << (n - f - p)
+    cnt = 1 << f
+    pieces = [(q, (b * P + q) << f, cnt) for q in range(P) if q != rank for b in range(nb)]
+    own = [(b * P + rank) << f for b in range(nb)]
+    return pieces, own, cnt
+
+
+def post_transpose(src, dst, pieces):
+    """Post one all-to-all between the layouts (see ``transpose_pieces``) as one batch."""
+    from . import _comm
+    return _comm.batch_p2p([(src[off:off + cnt], q) for q, off, cnt in pieces],
+                           [(dst[off:off + cnt], q) for q, off, cnt in pieces])
+
+
 class Vec:
     """Distributed complex128 vector: this rank's block lives in ``self.array``
     (a 1-D torch tensor on the rank's GPU).  ``swz``: layout of the block (dnm_subspace.vec_swizzle): 0 = element
@@ -300,6 +366,8 @@ class ShellMat:
         self.row0 = r0.value
         self._windows = None      # partitioned SpinConserve: every rank's column window
         self._window_buf = None
+        self._tr = None           # transposed exchange (set_transposed): (lo handle, hi handle, pieces, own, cnt)
+        self._tr_bufs = None
 
     @property
     def handle(self):
@@ -328,6 +396,8 @@ class ShellMat:
         if x.swz != self.swz_right or y.swz != self.swz_left:
             raise ValueError('vector layout (swizzle %d -> %d) does not match the matrix (%d -> %d)'
                              % (x.swz, y.swz, self.swz_right, self.swz_left))
+        if self._tr is not None:
+            return self._mult_transposed(x, y)
         if self.nranks > 1 and not self.partners and self._is_windowed():
             return self._mult_window(x, y)
         if not self.recvs and not self.sends:
@@ -358,6 +428,91 @@ class ShellMat:
             for i in range(nr):
                 _lib.check(L.dnm_mat_mult_remote(self.handle, i, C.c_void_p(bufs[i].data_ptr()), y.ptr, _stream()))
 
+    def set_transposed(self, split, left_c, right_c, flags=0):
+        """Switch the partitioned multiply to the transposed exchange (``transpose_split``): two operators with
+        rank-local passes only -- the masks that flip no top spin in the state's own layout, the others in the
+        redistributed layout -- and the piece list of the all-to-all between the layouts."""
+        lo, hi, f = split
+        p = self.nranks.bit_length() - 1
+        n = (self.n_local - 1).bit_length()
+        hs = []
+        try:
+            for arrs in (lo, hi):
+                h = create_mat(*arrs, left_c, right_c, False, flags, self.rank, self.nranks)
+                hs.append(h)
+                snd, rcv = exchange_plan(h)
+                if snd or rcv:
+                    raise RuntimeError('transposed exchange: a pass is not rank-local')
+        except Exception:
+            for h in hs:
+                _lib.lib().dnm_mat_destroy(h)
+            raise
+        pieces, own, cnt = transpose_pieces(n, p, f, self.rank)
+        self._tr = (hs[0], hs[1], pieces, own, cnt)
+
+    def launches_per_mult(self):
+        """Kernel launches of one multiply on this rank (rank-local passes, partner passes / the pass in the
+        transposed layout and the sum of its result)."""
+        def count(h):
+            nl = C.c_int()
+            _lib.check(_lib.lib().dnm_mat_plan_launches(h, C.byref(nl)))
+            return nl.value
+        if self._tr is not None:
+            return count(self._tr[0]) + count(self._tr[1]) + 1
+        return count(self.handle) + len(self.recvs)
+
+    def exchange_summary(self):
+        """What one multiply moves between ranks: bytes received, sent, peers, and the bytes on the busiest
+        link (peer) -- for the link-bound estimate of bench.py."""
+        if self._tr is not None:
+            pieces, cnt = self._tr[2], self._tr[4]
+            per_peer = {}
+            for q, _, c in pieces:
+                per_peer[q] = per_peer.get(q, 0) + 2 * 16 * c        # state out and result back
+            tot = sum(per_peer.values())
+            return {'scheme': 'transpose', 'bytes_in': tot, 'bytes_out': tot, 'peers': len(per_peer),
+                    'busiest_link_bytes': max(per_peer.values()) if per_peer else 0}
+        per_peer = {}
+        for q, _, c in self.recvs:
+            per_peer[q] = per_peer.get(q, 0) + 16 * c
+        return {'scheme': 'window' if (self.nranks > 1 and not self.partners and self._is_windowed()) else 'partner',
+                'bytes_in': sum(per_peer.values()), 'bytes_out': sum(16 * c for _, _, c in self.sends),
+                'peers': len(per_peer), 'busiest_link_bytes': max(per_peer.values()) if per_peer else 0}
+
+    def _transpose_buffers(self, like):
+        import torch
+        if self._tr_bufs is None:
+            self._tr_bufs = (torch.empty(self.n_local, dtype=like.dtype, device=like.device),
+                             torch.empty(self.n_local, dtype=like.dtype, device=like.device))
+        return self._tr_bufs
+
+    def _mult_transposed(self, x, y):
+        """y = A x with the transposed exchange: the state goes to layout B (all-to-all, every link at once) while
+        the masks that flip no top spin run here; the others are one rank-local pass in layout B, and its result
+        comes back through the same all-to-all and is added."""
+        L = _lib.lib()
+        lo, hi, pieces, own, cnt = self._tr
+        xb, wb = self._transpose_buffers(x.array)
+        vp = lambda t: C.c_void_p(t.data_ptr())
+        reqs = post_transpose(x.array, xb, pieces)                              # runs on RCCL's stream
+        for off in own:
+            _lib.check(L.dnm_vec_copy(vp(x.array[off:off + cnt]), vp(xb[off:off + cnt]), cnt, _stream()))
+        _lib.check(L.dnm_mat_mult_local(lo, x.ptr, y.ptr, _stream()))           # overlaps the all-to-all
+        for r in reqs:
+            r.wait()
+        _lib.check(L.dnm_mat_mult_local(hi, vp(xb), vp(wb), _stream()))
+        reqs = post_transpose(wb, xb, pieces)                                   # xb is free again: the way back
+        for off in own:
+            _lib.check(L.dnm_vec_axpby(vp(y.array[off:off + cnt]), vp(wb[off:off + cnt]), cnt, 1.0, 0.0, 1.0, 0.0,
+                                       _stream()))
+        for r in reqs:
+            r.wait()
+        # everything that came back, in runs between this rank's own pieces
+        edges = [0] + [e for off in own for e in (off, off + cnt)] + [self.n_local]
+        for a, b in zip(edges[0::2], edges[1::2]):
+            if b > a:
+                _lib.check(L.dnm_vec_axpby(vp(y.array[a:b]), vp(xb[a:b]), b - a, 1.0, 0.0, 1.0, 0.0, _stream()))
+
     def prepare_exchange(self, like):
         """Allocate the receive buffers / column window of the partitioned multiply now (they are
         otherwise created by the first ``mult``), so that a solver sizing its Krylov basis to the
@@ -365,6 +520,9 @@ class ShellMat:
         if self.nranks == 1:
             return
         import torch
+        if self._tr is not None:
+            self._transpose_buffers(like)
+            return
         if not self.partners and self._is_windowed():
             if self._windows is None:
                 import torch.distributed as dist
@@ -436,6 +594,10 @@ class ShellMat:
             _lib.check(_lib.lib().dnm_mat_destroy(self._h))
             self._h = None
             self._recv = {}
+            if self._tr is not None:
+                for h in self._tr[:2]:
+                    _lib.check(_lib.lib().dnm_mat_destroy(h))
+                self._tr, self._tr_bufs = None, None
 
     def __del__(self):
         try:
@@ -472,7 +634,25 @@ def build_mat(masks, mask_offsets, signs, coeffs, left_subspace, right_subspace,
     lc, rc = left_subspace['data'], right_subspace['data']
     h = create_mat(masks, mask_offsets, signs, coeffs, lc, rc, xparity, flags,
                    rank=config.rank, nranks=config.world_size)
-    return ShellMat(h, lc, rc, config.world_size, config.rank)
+    mat = ShellMat(h, lc, rc, config.world_size, config.rank)
+    if use_transposed_exchange(config.world_size) and lc.type == 0 and rc.type == 0 and not xparity \
+            and 'tiled=1' in mat.describe():
+        split = transpose_split(masks, mask_offsets, signs, coeffs, int(lc.L), config.world_size,
+                                int(lc.vec_swizzle))
+        if split is not None:
+            mat.set_transposed(split, lc, rc, flags)
+    return mat
+
+
+def use_transposed_exchange(nranks):
+    """Exchange scheme of a partitioned Full-space multiply: with four or more ranks the all-to-all of the
+    transposed scheme puts less on the busiest link than the partner blocks (two ranks: the partner block is
+    half of what two transposes move).  DNM_EXCHANGE=partner / transpose overrides."""
+    import os
+    mode = os.environ.get('DNM_EXCHANGE', 'auto')
+    if mode == 'partner' or nranks < 2:
+        return False
+    return mode == 'transpose' or nranks >= 4
 
 
 def check_conserves(masks, mask_offsets, signs, coeffs, left_subspace, right_subspace, xparity=False):

@@ -30,7 +30,15 @@ def test_bench_spawns_its_ranks(n):
     assert out["n_gpus"] == n and out["dry_run"] is True and out["exchange_ok"] is True
     assert out["value"] is None and out["scaling"] == "weak"
     cfg = out["config"]
-    # rank 0 (all rank bits 0) receives half a block across the block boundary and nothing for the bonds
-    # inside the rank bits (its rows are annihilated there): 2^(L - log2 n - 1) amplitudes of 16 B
-    assert cfg["xgmi_bytes_per_step"] == 16 * ((1 << 16) // n // 2)
-    assert cfg["xgmi_partners"] == 1 and cfg["xgmi_link_bound_ms"] > 0
+    nloc = (1 << 16) // n
+    if n < 4:
+        # partner blocks: rank 0 (all rank bits 0) receives half a block across the block boundary and nothing for
+        # the bonds inside the rank bits (its rows are annihilated there): 2^(L - log2 n - 1) amplitudes of 16 B
+        assert cfg["exchange"] == "partner"
+        assert cfg["xgmi_bytes_per_step"] == 16 * (nloc // 2)
+        assert cfg["xgmi_partners"] == 1 and cfg["xgmi_link_bound_ms"] > 0
+    else:
+        # transposed exchange: (n-1)/n of the block goes out and comes back, the same share on every link
+        assert cfg["exchange"] == "transpose" and cfg["plan"].startswith("transposed exchange")
+        assert cfg["xgmi_bytes_per_step"] == 2 * 16 * nloc * (n - 1) // n
+        assert cfg["xgmi_partners"] == n - 1 and cfg["xgmi_busiest_link_bytes"] == 2 * 16 * nloc // n

@@ -45,7 +45,13 @@ def _worker(rank, world, port, L, out_dir):
     nloc = (1 << L) // world
     rs = np.random.RandomState(11)          # same global vector on every rank, each keeps its block
     xg = rs.standard_normal(1 << L) + 1j * rs.standard_normal(1 << L)
-    x = torch.from_numpy(xg[rank * nloc:(rank + 1) * nloc].copy())
+    # the block as it sits in device memory: the subspace's vector layout on the local index (with four ranks the
+    # shift is the smaller one the transposed exchange asks for, subspaces.Subspace.vec_swizzle)
+    from plan_emulator import vec_pos
+    pos = vec_pos(np.arange(nloc), sub.vec_swizzle)
+    xl = np.empty(nloc, dtype=complex)
+    xl[pos] = xg[rank * nloc:(rank + 1) * nloc]
+    x = torch.from_numpy(xl)
 
     # the exchange of ShellMat.mult: post all sends/recvs, do local work, wait, partner passes
     bufs = [torch.empty(cnt, dtype=x.dtype) for _, _, cnt in hm.recvs]
@@ -58,6 +64,8 @@ def _worker(rank, world, port, L, out_dir):
     for i in range(len(hm.recvs)):
         run_remote(hm, i, bufs[i].numpy(), y)
     sent = sum(c for _, _, c in hm.sends)
+    y = y[pos]                                  # back to index order
+    x = torch.from_numpy(xg[rank * nloc:(rank + 1) * nloc].copy())
 
     # Krylov-style reductions: global <x|y> and max |y|
     t = torch.tensor([np.vdot(x.numpy(), y).real, np.vdot(x.numpy(), y).imag], dtype=torch.float64)

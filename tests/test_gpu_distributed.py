@@ -34,6 +34,12 @@ def _worker(rank, world, port, case, out_dir):
                       DNM_AMIN="3")
     if case == "sc":
         os.environ["DNM_SC_BLOCK"] = "10"
+    # small vectors: a swizzle shift that really permutes them (conftest's choice for the one-process GPU tests)
+    os.environ.setdefault("DNM_SWZ", os.environ.get("DNM_TEST_SWZ", "6"))
+    if case == "full_partner":
+        os.environ["DNM_EXCHANGE"] = "partner"          # four ranks would take the transposed exchange
+    elif case == "full_transpose":
+        os.environ["DNM_EXCHANGE"] = "transpose"        # two ranks would take the partner blocks
     import faulthandler
     faulthandler.dump_traceback_later(int(os.environ.get("DNM_TEST_HANG_S", "90")), exit=True)   # a stuck rank reports where
     import datetime
@@ -110,7 +116,7 @@ def _worker(rank, world, port, case, out_dir):
             open(os.path.join(out_dir, "ok_%s_%d" % (case, world)), "w").write("ok")
         dist.destroy_process_group()
         return
-    if case == "full":
+    if case in ("full", "full_partner", "full_transpose"):
         sub, H = Full(L=L), models.mbl(L)
     elif case == "parity":
         sub, H = Parity('even', L=L), models.mbl(L)
@@ -128,6 +134,11 @@ def _worker(rank, world, port, case, out_dir):
     assert abs(x.norm() - 1) < 1e-12
 
     # multiply
+    if sub.__class__ is Full:
+        # exchange scheme: partner blocks on two ranks, the transposed all-to-all from four on (backend.py)
+        want_scheme = {"full": "transpose" if world >= 4 else "partner", "full_partner": "partner",
+                       "full_transpose": "transpose"}[case]
+        assert H.get_mat().exchange_summary()["scheme"] == want_scheme
     y = H.dot(x)
     yg = y.to_numpy(to_all=True)
     ref = orc.matvec(orc_msc(H), orc_sub(sub), orc_sub(sub), xg, nthreads=2)
@@ -183,7 +194,8 @@ def _worker(rank, world, port, case, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("case,world", [("full", 2), ("full", 4), ("parity", 2), ("sc", 2), ("sc", 3),
+@pytest.mark.parametrize("case,world", [("full", 2), ("full", 4), ("full_partner", 4), ("full_transpose", 2),
+                                        ("parity", 2), ("sc", 2), ("sc", 3),
                                         ("sc_big", 3), ("explicit", 3), ("auto", 2), ("projection", 3),
                                         ("projection", 2), ("full_odd", 3), ("parity_odd", 3)])
 def test_partitioned_end_to_end_one_gpu(tmp_path, case, world):
@@ -210,7 +222,9 @@ def test_bench_multi_rank_flow_one_gpu(world):
     d = json.loads(lines[0])
     assert d["n_gpus"] == world and d["steps"] == 2 and d["warmup"] == 1 and d["unit"] == "Gamplitudes/s"
     assert d["value"] > 0 and d["scaling"] == "weak" and d["config"]["L"] == 22
-    assert d["config"]["launches_per_step"] >= 3          # rank-local passes plus at least one partner pass
+    assert d["config"]["launches_per_step"] >= 3          # rank-local passes plus partner / transposed-layout passes
+    assert d["config"]["exchange"] == ("transpose" if world >= 4 else "partner")
+    assert d["config"]["xgmi_busiest_link_bytes"] > 0
     assert "cpu_baseline" not in d and d["roofline"]["bound"] == "hbm"
 
 
