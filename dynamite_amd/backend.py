@@ -115,8 +115,10 @@ def post_exchange(x_local, sends, recvs, recv_bufs):
                            [(buf, p) for (p, _, _), buf in zip(recvs, recv_bufs)])
 
 
-def transpose_split(masks, mask_offsets, signs, coeffs, L, nranks, swizzle=0):
-    """Split a Full-space operator on P = 2^p ranks for the transposed exchange, or None if it does not apply.
+def transpose_split(masks, mask_offsets, signs, coeffs, L, nranks, swizzle=0, shift=0):
+    """Split a Full-space (``shift`` = 0) or Parity (``shift`` = 1: basis index = configuration >> 1, so index bit
+    j is spin j + 1 and ``L`` counts the index bits) operator on P = 2^p ranks for the transposed exchange, or None
+    if it does not apply.
 
     A rank's block holds the n = L - p low spins; the rank number is the p top spins.  A mask that flips a top
     spin couples blocks of different ranks.  Instead of shipping a partner block per such mask
@@ -141,14 +143,15 @@ def transpose_split(masks, mask_offsets, signs, coeffs, L, nranks, swizzle=0):
     signs = np.asarray(signs, dtype=np.int64)
     coeffs = np.asarray(coeffs, dtype=np.complex128)
     tm = np.repeat(masks, np.diff(offs))
-    top = (tm >> n) != 0
+    fs, ns = f + shift, n + shift             # the two fields as spins
+    top = (tm >> ns) != 0
     fld = np.int64(nranks - 1)
-    if not top.any() or top.all() or ((tm[top] >> f) & fld).any():
+    if not top.any() or top.all() or ((tm[top] >> fs) & fld).any():
         return None
 
     def swap(v):
-        d = ((v >> f) ^ (v >> n)) & fld
-        return v ^ (d << f) ^ (d << n)
+        d = ((v >> fs) ^ (v >> ns)) & fld
+        return v ^ (d << fs) ^ (d << ns)
 
     def csr(m, sg, c):
         order = np.argsort(m, kind='stable')
@@ -635,17 +638,18 @@ def build_mat(masks, mask_offsets, signs, coeffs, left_subspace, right_subspace,
     h = create_mat(masks, mask_offsets, signs, coeffs, lc, rc, xparity, flags,
                    rank=config.rank, nranks=config.world_size)
     mat = ShellMat(h, lc, rc, config.world_size, config.rank)
-    if use_transposed_exchange(config.world_size) and lc.type == 0 and rc.type == 0 and not xparity \
-            and 'tiled=1' in mat.describe():
-        split = transpose_split(masks, mask_offsets, signs, coeffs, int(lc.L), config.world_size,
-                                int(lc.vec_swizzle))
+    same = lc.type == rc.type and lc.L == rc.L and (lc.type == 0 or (lc.type == 1 and lc.space == rc.space))
+    if use_transposed_exchange(config.world_size) and same and not xparity and 'tiled=1' in mat.describe():
+        shift = int(lc.type)                   # Full: index = configuration; Parity: index = configuration >> 1
+        split = transpose_split(masks, mask_offsets, signs, coeffs, int(lc.L) - shift, config.world_size,
+                                int(lc.vec_swizzle), shift)
         if split is not None:
             mat.set_transposed(split, lc, rc, flags)
     return mat
 
 
 def use_transposed_exchange(nranks):
-    """Exchange scheme of a partitioned Full-space multiply: with four or more ranks the all-to-all of the
+    """Exchange scheme of a partitioned Full-space or Parity multiply: with four or more ranks the all-to-all of the
     transposed scheme puts less on the busiest link than the partner blocks (two ranks: the partner block is
     half of what two transposes move).  DNM_EXCHANGE=partner / transpose overrides."""
     import os

@@ -134,10 +134,10 @@ def _worker(rank, world, port, case, out_dir):
     assert abs(x.norm() - 1) < 1e-12
 
     # multiply
-    if sub.__class__ is Full:
+    if case != "sc":
         # exchange scheme: partner blocks on two ranks, the transposed all-to-all from four on (backend.py)
         want_scheme = {"full": "transpose" if world >= 4 else "partner", "full_partner": "partner",
-                       "full_transpose": "transpose"}[case]
+                       "full_transpose": "transpose", "parity": "transpose" if world >= 4 else "partner"}[case]
         assert H.get_mat().exchange_summary()["scheme"] == want_scheme
     y = H.dot(x)
     yg = y.to_numpy(to_all=True)
@@ -195,7 +195,7 @@ def _worker(rank, world, port, case, out_dir):
 
 
 @pytest.mark.parametrize("case,world", [("full", 2), ("full", 4), ("full_partner", 4), ("full_transpose", 2),
-                                        ("parity", 2), ("sc", 2), ("sc", 3),
+                                        ("parity", 2), ("parity", 4), ("sc", 2), ("sc", 3),
                                         ("sc_big", 3), ("explicit", 3), ("auto", 2), ("projection", 3),
                                         ("projection", 2), ("full_odd", 3), ("parity_odd", 3)])
 def test_partitioned_end_to_end_one_gpu(tmp_path, case, world):

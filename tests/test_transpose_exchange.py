@@ -57,6 +57,29 @@ def test_split_reproduces_the_operator(name, L, P):
     assert np.max(np.abs(y - ref)) <= 1e-13 * max(1.0, np.abs(ref).max())
 
 
+@pytest.mark.parametrize("name,L,P,space", [("mbl", 11, 4, 0), ("heisenberg", 12, 8, 1), ("long_range", 10, 2, 1)])
+def test_split_reproduces_the_operator_parity(name, L, P, space):
+    """The same on a Parity subspace: index bit j is spin j + 1, the fields move as spins."""
+    from oracle import oracle as orc
+    from dynamite_amd.backend import transpose_split
+    arrs = _arrays(name, L)
+    nb = L - 1
+    split = transpose_split(*arrs, nb, P, shift=1)
+    assert split is not None
+    lo, hi, f = split
+    p = P.bit_length() - 1
+    n = nb - p
+    rs = np.random.RandomState(6)
+    x = rs.standard_normal(1 << nb) + 1j * rs.standard_normal(1 << nb)
+    sub = orc.parity(L, space)
+    ref = orc.matvec(orc.Msc(*arrs), sub, sub, x)
+    perm = _swap_index(np.arange(1 << nb, dtype=np.int64), n, p, f)
+    y = orc.matvec(orc.Msc(*lo), sub, sub, x)
+    wb = orc.matvec(orc.Msc(*hi), sub, sub, x[perm])
+    y = y + wb[perm]
+    assert np.max(np.abs(y - ref)) <= 1e-13 * max(1.0, np.abs(ref).max())
+
+
 def test_split_refuses_what_it_cannot_do():
     from dynamite_amd.backend import transpose_split
     from dynamite_amd import msc_tools
