@@ -504,17 +504,20 @@ class ShellMat:
         for r in reqs:
             r.wait()
         _lib.check(L.dnm_mat_mult_local(hi, vp(xb), vp(wb), _stream()))
-        reqs = post_transpose(wb, xb, pieces)                                   # xb is free again: the way back
+        # the way back (xb is free again), one batch per own piece: what a batch brought is added while the next
+        # one is on the links
+        span = self.n_local // len(own)               # P pieces: one per peer around this rank's own
+        batches = [post_transpose(wb, xb, [pc for pc in pieces if pc[1] // span == b]) for b in range(len(own))]
         for off in own:
             _lib.check(L.dnm_vec_axpby(vp(y.array[off:off + cnt]), vp(wb[off:off + cnt]), cnt, 1.0, 0.0, 1.0, 0.0,
                                        _stream()))
-        for r in reqs:
-            r.wait()
-        # everything that came back, in runs between this rank's own pieces
-        edges = [0] + [e for off in own for e in (off, off + cnt)] + [self.n_local]
-        for a, b in zip(edges[0::2], edges[1::2]):
-            if b > a:
-                _lib.check(L.dnm_vec_axpby(vp(y.array[a:b]), vp(xb[a:b]), b - a, 1.0, 0.0, 1.0, 0.0, _stream()))
+        for b, (reqs, off) in enumerate(zip(batches, own)):
+            for r in reqs:
+                r.wait()
+            for lo_, hi_ in ((b * span, off), (off + cnt, (b + 1) * span)):
+                if hi_ > lo_:
+                    _lib.check(L.dnm_vec_axpby(vp(y.array[lo_:hi_]), vp(xb[lo_:hi_]), hi_ - lo_, 1.0, 0.0, 1.0, 0.0,
+                                               _stream()))
 
     def prepare_exchange(self, like):
         """Allocate the receive buffers / column window of the partitioned multiply now (they are
