@@ -233,3 +233,55 @@ def test_config4_hermiticity_between_ranks():
         ms.destroy()
         del v, y, w
     mr.destroy()
+
+
+@pytest.mark.parametrize("rank", [5])
+def test_config4_transposed_exchange_layouts(rank, monkeypatch):
+    """The two operators of the transposed exchange (backend.transpose_split) for one rank of L=34 / P=8 at full
+    size: the masks that flip no rank bit in the state's own layout, and the others with the rank bits and the
+    field [27, 30) exchanged -- rank-local passes only, n_loc = 31, signs above bit 31 as rank constants.  Sampled
+    rows on every power-of-two boundary against the definition of each part."""
+    import torch
+    L, P = 34, 8
+    nl = L - 3
+    nloc = 1 << nl
+    _need(2 * 16 * nloc + (4 << 30))
+    monkeypatch.setenv("DNM_EXCHANGE", "transpose")
+    H = models.heisenberg(L)
+    arrs = marshal(H)
+    S = 14                              # what Subspace.vec_swizzle picks on 8 ranks (pieces of 2^27 amplitudes)
+    sc = Full(L=L)._c()
+    sc.vec_swizzle = S
+    split = backend.transpose_split(*arrs, L, P, S)
+    assert split is not None and split[2] == 27
+    Lb = _lib.lib()
+    xl = backend.Vec(nloc, swz=S)
+    xl.start = rank * nloc
+    xl.set_random(5)
+    yl = backend.Vec(nloc, swz=S)
+    rs = np.random.RandomState(17)
+    rows = _boundary_rows(nl, rs, nrand=24)
+    dev_rows = torch.from_numpy(rows).to(xl.array.device)
+    for part, name in ((split[0], "layout A"), (split[1], "layout B")):
+        masks, offs, signs, coeffs = part
+        assert not (np.asarray(masks) >> nl).any(), name          # nothing leaves the rank
+        h = backend.create_mat(*part, sc, sc, flags=0, rank=rank, nranks=P)
+        assert backend.exchange_plan(h) == ([], [])
+        _lib.check(Lb.dnm_mat_mult_local(h, xl.ptr, yl.ptr, None))
+        torch.cuda.synchronize()
+        ys = yl.array[yl.positions(dev_rows)].cpu().numpy()
+        worst, scale = 0.0, 0.0
+        for yv, row in zip(ys, rows):
+            g = (rank << nl) | int(row)
+            acc = 0j
+            for m in range(len(masks)):
+                col = g ^ int(masks[m])
+                c = 0j
+                for t in range(offs[m], offs[m + 1]):
+                    c += (1 - 2 * (bin(col & int(signs[t])).count("1") & 1)) * coeffs[t]
+                if c != 0:
+                    acc += c * complex(xl.array[xl.positions(col & (nloc - 1))].item())
+            worst = max(worst, abs(acc - yv))
+            scale = max(scale, abs(acc))
+        assert scale > 0 and worst <= 1e-13 * max(1.0, scale) * max(1, len(masks)), (name, worst, scale)
+        _lib.check(Lb.dnm_mat_destroy(h))
