@@ -116,6 +116,7 @@ SIGNATURES = {
                                       C.POINTER(C.c_int)]),
     "dnm_mat_ownership": (C.c_int, [vp, i64p, i64p]),
     "dnm_mat_column_window": (C.c_int, [vp, i64p, i64p, vp]),
+    "dnm_mat_column_chunks": (C.c_int, [vp, C.c_int, C.POINTER(C.c_uint8), C.c_int64, vp]),
     "dnm_mat_mult_window": (C.c_int, [vp, vp, C.c_int64, C.c_int64, vp, vp]),
     "dnm_mat_exchange_plan": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(Xfer), C.POINTER(C.c_int),
                                         C.POINTER(Xfer)]),

@@ -39,37 +39,55 @@ def split_ownership(size, world, rank):
     return rank * q + min(rank, rem), q + (1 if rank < rem else 0)
 
 
-def window_exchange_ops(owned, windows, me):
+def window_exchange_ops(owned, windows, me, needs=None):
     """Who sends what to whom so that every rank holds the columns of its window.
-    owned[q] = (start, n) of rank q's block; windows[q] = inclusive (cmin, cmax) rank q reads.
+    owned[q] = (start, n) of rank q's block; windows[q] = inclusive (cmin, cmax) rank q reads; needs[q] (optional)
+    = the ascending, disjoint [lo, hi) ranges inside that window rank q really reads (``needed_ranges``) --
+    without it the whole window travels.
     Returns (recvs, sends): recvs = [(src, lo, hi)] global index ranges [lo, hi) to receive from
-    src, sends = [(dst, lo, hi)] ranges of MY block to send."""
+    src, sends = [(dst, lo, hi)] ranges of MY block to send; between a pair of ranks both lists ascend."""
+    def wanted(q):
+        return needs[q] if needs is not None else [(windows[q][0], windows[q][1] + 1)]
     recvs, sends = [], []
     my0, myn = owned[me]
-    wlo, whi = windows[me][0], windows[me][1] + 1
     for q, (q0, qn) in enumerate(owned):
         if q == me:
             continue
-        lo, hi = max(wlo, q0), min(whi, q0 + qn)
-        if lo < hi:
-            recvs.append((q, lo, hi))
-        qlo, qhi = windows[q][0], windows[q][1] + 1
-        lo, hi = max(qlo, my0), min(qhi, my0 + myn)
-        if lo < hi:
-            sends.append((q, lo, hi))
+        for wlo, whi in wanted(me):
+            lo, hi = max(wlo, q0), min(whi, q0 + qn)
+            if lo < hi:
+                recvs.append((q, lo, hi))
+        for qlo, qhi in wanted(q):
+            lo, hi = max(qlo, my0), min(qhi, my0 + myn)
+            if lo < hi:
+                sends.append((q, lo, hi))
     return recvs, sends
 
 
-def exchange_window(x_local, owned, windows, me, window_buf=None):
+def needed_ranges(chunk_map, shift, window):
+    """[lo, hi) column ranges covering the marked chunks of ``dnm_mat_column_chunks`` (clipped to the window)."""
+    wlo, whi = window[0], window[1] + 1
+    first = wlo >> shift
+    marked = np.flatnonzero(np.asarray(chunk_map, dtype=np.uint8))
+    if marked.size == 0:
+        return []
+    cuts = np.flatnonzero(np.diff(marked) > 1)
+    starts = np.concatenate(([marked[0]], marked[cuts + 1]))
+    ends = np.concatenate((marked[cuts], [marked[-1]]))
+    return [(max(wlo, int(first + a) << shift), min(whi, int(first + b + 1) << shift)) for a, b in zip(starts, ends)]
+
+
+def exchange_window(x_local, owned, windows, me, window_buf=None, needs=None):
     """Assemble this rank's column window from the owners' blocks with
-    torch.distributed send/recv (RCCL over xGMI on GPUs, gloo in CPU tests)."""
+    torch.distributed send/recv (RCCL over xGMI on GPUs, gloo in CPU tests).  With ``needs`` only the ranges a
+    rank reads are moved; the rest of its window buffer keeps whatever it held (zeros from the allocation)."""
     import torch
     from . import _comm
     wlo, whi = windows[me][0], windows[me][1] + 1
     if window_buf is None or window_buf.numel() != whi - wlo:
-        window_buf = torch.empty(whi - wlo, dtype=x_local.dtype, device=x_local.device)
+        window_buf = torch.zeros(whi - wlo, dtype=x_local.dtype, device=x_local.device)
     my0, myn = owned[me]
-    recvs, sends = window_exchange_ops(owned, windows, me)
+    recvs, sends = window_exchange_ops(owned, windows, me, needs)
     reqs = _comm.batch_p2p([(x_local[lo - my0:hi - my0], q) for q, lo, hi in sends],
                            [(window_buf[lo - wlo:hi - wlo], q) for q, lo, hi in recvs])
     a, b = max(wlo, my0), min(whi, my0 + myn)
@@ -368,6 +386,7 @@ class ShellMat:
         _lib.check(_lib.lib().dnm_mat_ownership(handle, C.byref(r0), C.byref(ml)))
         self.row0 = r0.value
         self._windows = None      # partitioned SpinConserve: every rank's column window
+        self._needs = None        # ... and the ranges of it each rank really reads
         self._window_buf = None
         self._tr = None           # transposed exchange (set_transposed): (lo handle, hi handle, pieces, own, cnt)
         self._tr_bufs = None
@@ -478,6 +497,15 @@ class ShellMat:
         per_peer = {}
         for q, _, c in self.recvs:
             per_peer[q] = per_peer.get(q, 0) + 16 * c
+        if self.nranks > 1 and not self.partners and self._is_windowed():
+            self._setup_windows()
+            rcv, snd = window_exchange_ops(self._owned, self._windows, self.rank, self._needs)
+            for q, lo, hi in rcv:
+                per_peer[q] = per_peer.get(q, 0) + 16 * (hi - lo)
+            return {'scheme': 'window', 'bytes_in': sum(per_peer.values()),
+                    'bytes_out': sum(16 * (hi - lo) for _, lo, hi in snd), 'peers': len(per_peer),
+                    'busiest_link_bytes': max(per_peer.values()) if per_peer else 0,
+                    'window_bytes': 16 * (self._windows[self.rank][1] - self._windows[self.rank][0] + 1)}
         return {'scheme': 'window' if (self.nranks > 1 and not self.partners and self._is_windowed()) else 'partner',
                 'bytes_in': sum(per_peer.values()), 'bytes_out': sum(16 * c for _, _, c in self.sends),
                 'peers': len(per_peer), 'busiest_link_bytes': max(per_peer.values()) if per_peer else 0}
@@ -530,16 +558,10 @@ class ShellMat:
             self._transpose_buffers(like)
             return
         if not self.partners and self._is_windowed():
-            if self._windows is None:
-                import torch.distributed as dist
-                mine = self.column_window()
-                allw = [None] * self.nranks
-                dist.all_gather_object(allw, mine)
-                self._windows = allw
-                self._owned = [split_ownership(self.N, self.nranks, q) for q in range(self.nranks)]
+            self._setup_windows()
             lo, hi = self._windows[self.rank]
             if self._window_buf is None or self._window_buf.numel() != hi - lo + 1:
-                self._window_buf = torch.empty(hi - lo + 1, dtype=like.dtype, device=like.device)
+                self._window_buf = torch.zeros(hi - lo + 1, dtype=like.dtype, device=like.device)
             return
         for i, (p, off, cnt) in enumerate(self.recvs):
             if i not in self._recv:
@@ -563,17 +585,40 @@ class ShellMat:
         _lib.check(_lib.lib().dnm_mat_column_window(self.handle, C.byref(lo), C.byref(hi), _stream()))
         return lo.value, hi.value
 
+    WINDOW_CHUNKS = 1024          # resolution of the needed-columns map over a rank's window
+
+    def column_needs(self, window):
+        """The [lo, hi) ranges of the window this rank's rows read (one device sweep), at a resolution of
+        ``WINDOW_CHUNKS`` chunks over the window."""
+        lo, hi = window
+        shift = max(0, int(hi - lo + 1).bit_length() - self.WINDOW_CHUNKS.bit_length())
+        n = (hi >> shift) - (lo >> shift) + 1
+        cmap = np.zeros(n, dtype=np.uint8)
+        _lib.check(_lib.lib().dnm_mat_column_chunks(self.handle, shift, cmap.ctypes.data_as(C.POINTER(C.c_uint8)), n,
+                                                    _stream()))
+        return needed_ranges(cmap, shift, window)
+
+    def _setup_windows(self):
+        """Every rank's column window and, inside it, the ranges it really reads (DNM_WINDOW_RANGES=0: the whole
+        window travels)."""
+        if self._windows is not None:
+            return
+        import os
+        import torch.distributed as dist
+        mine = self.column_window()
+        needs = self.column_needs(mine) if os.environ.get('DNM_WINDOW_RANGES', '1') != '0' else None
+        allw = [None] * self.nranks
+        dist.all_gather_object(allw, (mine, needs))
+        self._windows = [w for w, _ in allw]
+        self._needs = [nd for _, nd in allw] if needs is not None else None
+        self._owned = [split_ownership(self.N, self.nranks, q) for q in range(self.nranks)]
+
     def _mult_window(self, x, y):
         """Partitioned SpinConserve: gather the column window, then one kernel."""
-        import torch.distributed as dist
-        if self._windows is None:
-            mine = self.column_window()
-            allw = [None] * self.nranks
-            dist.all_gather_object(allw, mine)
-            self._windows = allw
-            self._owned = [split_ownership(self.N, self.nranks, q) for q in range(self.nranks)]
+        self._setup_windows()
         # the window is in index order: a swizzled block is straightened first (projection pairs)
-        self._window_buf = exchange_window(x.local_natural(), self._owned, self._windows, self.rank, self._window_buf)
+        self._window_buf = exchange_window(x.local_natural(), self._owned, self._windows, self.rank, self._window_buf,
+                                           self._needs)
         w0 = self._windows[self.rank][0]
         _lib.check(_lib.lib().dnm_mat_mult_window(self.handle, C.c_void_p(self._window_buf.data_ptr()), w0,
                                                   self._window_buf.numel(), y.ptr, _stream()))

@@ -43,11 +43,18 @@ int launch_tile_persist(const DevPass *P_dev, const PassCall &call, int B, int l
 // bcuda_template_2.cu:200-273 / bpetsc_template_2.c:371-412).
 // Rows [row0, row0 + M); x holds the columns [win_start, ...) in the layout xswz (-1: the right subspace's own);
 // colrange != null: no multiply, per-workgroup (min, max) of the columns touched (2 * gather_num_blocks(M) int64).
+// column-range sweeps, optional: which chunks of 2^shift columns are read (map[(col >> shift) - first] = 1) -- what a
+// partition really has to receive of its column window
+struct ColMark {
+  uint8_t *map = nullptr;
+  int32_t shift = 0;
+  int64_t first = 0;
+};
 int gather_num_blocks(int64_t M);
 int launch_gather_matvec(const DevMsc &msc, const SubView &left, const SubView &right,
                          int64_t M, const double *diag, const void *x, void *y,
                          hipStream_t st, int64_t row0 = 0, int64_t win_start = 0, int xswz = -1,
-                         int64_t *colrange = nullptr);
+                         int64_t *colrange = nullptr, ColMark mark = ColMark());
 
 // Per-mask precomputation for the SpinConserve kernel.  fast != 0: the mask is a
 // bond of two adjacent spins (3 << lo) whose sign masks all lie inside the bond,
@@ -71,7 +78,7 @@ struct ScLow {
 int sc_num_blocks(int64_t M);
 int launch_sc_matvec(const DevMsc &msc, const ScMask *scm, const ScLow &low, const SubView &sub, int64_t M, int64_t row0,
                      int64_t win_start, const double *diag, const void *xw, void *y, int64_t *colrange,
-                     hipStream_t st);
+                     hipStream_t st, ColMark mark = ColMark());
 
 // Block form of the same product (sc_block_kernel): one workgroup per high part H = state >> lb.
 struct ScBlock {

@@ -1038,6 +1038,32 @@ int dnm_mat_column_window(dnm_mat *A, int64_t *cmin, int64_t *cmax, void *stream
   return 0;
 }
 
+int dnm_mat_column_chunks(dnm_mat *A, int chunk_shift, uint8_t *map, int64_t nchunks, void *stream) {
+  DNM_CHECK(A && map && chunk_shift >= 0 && chunk_shift < 62, "bad argument");
+  int64_t lo, hi;
+  DNM_TRY(dnm_mat_column_window(A, &lo, &hi, stream));
+  const int64_t first = lo >> chunk_shift;
+  DNM_CHECK(nchunks == (hi >> chunk_shift) - first + 1, "the window [%lld, %lld] has %lld chunks of 2^%d columns",
+            (long long)lo, (long long)hi, (long long)((hi >> chunk_shift) - first + 1), chunk_shift);
+  const int nb = A->sc_pair ? sc_num_blocks(A->m_local) : gather_num_blocks(A->m_local);
+  DevBuf range, dmap;
+  DNM_TRY(range.alloc((size_t)nb * 2 * sizeof(int64_t)));
+  DNM_TRY(dmap.alloc((size_t)nchunks));
+  DNM_HIP(hipMemsetAsync(dmap.p, 0, (size_t)nchunks, S(stream)));
+  ColMark mark;
+  mark.map = (uint8_t *)dmap.p;
+  mark.shift = chunk_shift;
+  mark.first = first;
+  if (A->sc_pair)
+    DNM_TRY(launch_sc_matvec(A->dmsc, (const ScMask *)A->d_scmasks.p, A->sclow, A->right.dev, A->m_local, A->row0,
+                             0, nullptr, nullptr, nullptr, (int64_t *)range.p, S(stream), mark));
+  else
+    DNM_TRY(launch_gather_matvec(A->dmsc, A->left.dev, A->right.dev, A->m_local, nullptr, nullptr, nullptr,
+                                 S(stream), A->row0, 0, 0, (int64_t *)range.p, mark));
+  DNM_TRY(dnm_memcpy_d2h(map, dmap.p, (size_t)nchunks, stream));
+  return 0;
+}
+
 int dnm_mat_mult_window(dnm_mat *A, const void *x_window, int64_t win_start, int64_t win_len, void *y_local,
                         void *stream) {
   DNM_CHECK(A && x_window && y_local && !A->host_only, "bad argument");

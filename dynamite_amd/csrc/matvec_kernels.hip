@@ -490,6 +490,18 @@ __device__ __forceinline__ SubView stage_sub(const SubView &s, int64_t *lds_tab,
 
 constexpr int GATHER_NT = 256;
 
+// column-range sweeps: note the chunk a column lies in (one store per wavefront when the lanes agree)
+__device__ __forceinline__ void mark_column(const ColMark &cm, int64_t col) {
+  if (!cm.map) return;
+  const int64_t c = (col >> cm.shift) - cm.first;
+  const int c32 = (int)c;
+  if (__all(c32 == __builtin_amdgcn_readfirstlane(c32))) {
+    if ((int)(threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) cm.map[c] = 1;
+  } else {
+    cm.map[c] = 1;
+  }
+}
+
 // Rows [row0, row0 + M) of the matrix (a rank's block); x holds the columns [win_start, ...) in the layout xswz
 // (one rank: the whole right vector in its own layout; partitioned: the rank's column window in index order);
 // y and diag are local (index row - row0).  colrange != nullptr: no multiply, only the min / max column each
@@ -498,7 +510,7 @@ template <int LT, int RT>
 __global__ void __launch_bounds__(GATHER_NT)
 gather_matvec_kernel(const DevMsc msc, const SubView left_g, const SubView right_g, int64_t M, int64_t row0,
                      int64_t win_start, int xswz, const double *__restrict__ diag, const c128 *__restrict__ x,
-                     c128 *__restrict__ y, int64_t *__restrict__ colrange) {
+                     c128 *__restrict__ y, int64_t *__restrict__ colrange, const ColMark mark) {
   __shared__ int64_t nck[NCK_LDS_MAX];
   int used = 0;
   const SubView left = stage_sub<LT>(left_g, nck, used);
@@ -528,6 +540,7 @@ gather_matvec_kernel(const DevMsc msc, const SubView left_g, const SubView right
       if (colrange) {
         cmin = col < cmin ? col : cmin;
         cmax = col > cmax ? col : cmax;
+        mark_column(mark, col);
         continue;
       }
       double cre = 0.0, cim = 0.0;
@@ -583,7 +596,8 @@ template <bool IN_LDS>
 __global__ void __launch_bounds__(SC_NT)
 sc_matvec_kernel(const DevMsc msc, const ScMask *__restrict__ scm, const ScLow low, const SubView sub_g, int64_t M,
                  int64_t row0, int64_t win_start, const double *__restrict__ diag,
-                 const c128 *__restrict__ xw, c128 *__restrict__ y, int64_t *__restrict__ colrange) {
+                 const c128 *__restrict__ xw, c128 *__restrict__ y, int64_t *__restrict__ colrange,
+                 const ColMark mark) {
   // rows [row0, row0 + M) of the matrix; xw holds columns [win_start, ...); y and diag are
   // local (index row - row0).  colrange != nullptr: only record min/max column per workgroup.
   __shared__ int64_t nck[NCK_LDS_MAX];
@@ -641,6 +655,7 @@ sc_matvec_kernel(const DevMsc msc, const ScMask *__restrict__ scm, const ScLow l
           const int64_t c = up ? row + d : row - d;
           cmin = c < cmin ? c : cmin;
           cmax = c > cmax ? c : cmax;
+          mark_column(mark, c);
           continue;
         }
         const c128 xv = x[up ? row + d : row - d];
@@ -699,6 +714,7 @@ sc_matvec_kernel(const DevMsc msc, const ScMask *__restrict__ scm, const ScLow l
       const int64_t c = row + delta;
       cmin = c < cmin ? c : cmin;
       cmax = c > cmax ? c : cmax;
+      mark_column(mark, c);
       continue;
     }
     double cre = 0.0, cim = 0.0;
@@ -743,15 +759,15 @@ int sc_num_blocks(int64_t M) { return (int)((M + SC_NT - 1) / SC_NT); }
 
 int launch_sc_matvec(const DevMsc &msc, const ScMask *scm, const ScLow &low, const SubView &sub, int64_t M, int64_t row0,
                      int64_t win_start, const double *diag, const void *xw, void *y, int64_t *colrange,
-                     hipStream_t st) {
+                     hipStream_t st, ColMark mark) {
   DNM_CHECK(M > 0 && (M + SC_NT - 1) / SC_NT < (int64_t)1 << 31, "row count out of range");
   const dim3 grid((unsigned)sc_num_blocks(M)), blk(SC_NT);
   if ((sub.k + 1) * sub.ld <= NCK_LDS_MAX)
     hipLaunchKernelGGL(sc_matvec_kernel<true>, grid, blk, 0, st, msc, scm, low, sub, M, row0, win_start, diag,
-                       (const c128 *)xw, (c128 *)y, colrange);
+                       (const c128 *)xw, (c128 *)y, colrange, mark);
   else
     hipLaunchKernelGGL(sc_matvec_kernel<false>, grid, blk, 0, st, msc, scm, low, sub, M, row0, win_start, diag,
-                       (const c128 *)xw, (c128 *)y, colrange);
+                       (const c128 *)xw, (c128 *)y, colrange, mark);
   DNM_HIP(hipGetLastError());
   return 0;
 }
@@ -1251,12 +1267,12 @@ int launch_conserves(const DevMsc &msc, const double *coeffs_im, const SubView &
 template <int LT>
 static int gather_dispatch_r(const DevMsc &msc, const SubView &l, const SubView &r, int64_t M, int64_t row0,
                              int64_t win_start, int xswz, const double *diag, const void *x, void *y,
-                             int64_t *colrange, hipStream_t st) {
+                             int64_t *colrange, hipStream_t st, ColMark mark) {
   const dim3 grid((unsigned)((M + GATHER_NT - 1) / GATHER_NT)), blk(GATHER_NT);
 #define DNM_G(RT)                                                                                         \
   case RT:                                                                                                \
     hipLaunchKernelGGL((gather_matvec_kernel<LT, RT>), grid, blk, 0, st, msc, l, r, M, row0, win_start,  \
-                       xswz, diag, (const c128 *)x, (c128 *)y, colrange);                                 \
+                       xswz, diag, (const c128 *)x, (c128 *)y, colrange, mark);                           \
     break;
   switch (r.type) {
     DNM_G(DNM_FULL) DNM_G(DNM_PARITY) DNM_G(DNM_SPIN_CONSERVE) DNM_G(DNM_EXPLICIT)
@@ -1271,14 +1287,14 @@ int gather_num_blocks(int64_t M) { return (int)((M + GATHER_NT - 1) / GATHER_NT)
 
 int launch_gather_matvec(const DevMsc &msc, const SubView &left, const SubView &right, int64_t M,
                          const double *diag, const void *x, void *y, hipStream_t st, int64_t row0,
-                         int64_t win_start, int xswz, int64_t *colrange) {
+                         int64_t win_start, int xswz, int64_t *colrange, ColMark mark) {
   DNM_CHECK(M > 0 && (M + GATHER_NT - 1) / GATHER_NT < (int64_t)1 << 31, "row count out of range");
   if (xswz < 0) xswz = right.swz;
   switch (left.type) {
-    case DNM_FULL: return gather_dispatch_r<DNM_FULL>(msc, left, right, M, row0, win_start, xswz, diag, x, y, colrange, st);
-    case DNM_PARITY: return gather_dispatch_r<DNM_PARITY>(msc, left, right, M, row0, win_start, xswz, diag, x, y, colrange, st);
-    case DNM_SPIN_CONSERVE: return gather_dispatch_r<DNM_SPIN_CONSERVE>(msc, left, right, M, row0, win_start, xswz, diag, x, y, colrange, st);
-    case DNM_EXPLICIT: return gather_dispatch_r<DNM_EXPLICIT>(msc, left, right, M, row0, win_start, xswz, diag, x, y, colrange, st);
+    case DNM_FULL: return gather_dispatch_r<DNM_FULL>(msc, left, right, M, row0, win_start, xswz, diag, x, y, colrange, st, mark);
+    case DNM_PARITY: return gather_dispatch_r<DNM_PARITY>(msc, left, right, M, row0, win_start, xswz, diag, x, y, colrange, st, mark);
+    case DNM_SPIN_CONSERVE: return gather_dispatch_r<DNM_SPIN_CONSERVE>(msc, left, right, M, row0, win_start, xswz, diag, x, y, colrange, st, mark);
+    case DNM_EXPLICIT: return gather_dispatch_r<DNM_EXPLICIT>(msc, left, right, M, row0, win_start, xswz, diag, x, y, colrange, st, mark);
   }
   set_error("bad left subspace type");
   return 1;

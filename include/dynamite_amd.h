@@ -225,6 +225,12 @@ int dnm_mat_mult_remote(dnm_mat *A, int32_t recv_index, const void *x_recv,
 int dnm_mat_ownership(const dnm_mat *A, int64_t *row0, int64_t *m_local);
 /* inclusive column range this rank's rows read; one device sweep, then cached */
 int dnm_mat_column_window(dnm_mat *A, int64_t *cmin, int64_t *cmax, void *stream);
+/* which chunks of 2^chunk_shift columns inside that window the rank's rows really read:
+ * map[(col >> chunk_shift) - (cmin >> chunk_shift)] = 1, nchunks = (cmax >> chunk_shift) - (cmin >> chunk_shift) + 1
+ * bytes on the host.  The window is mostly holes for the far hops of a SpinConserve chain (L=24, k=12 on 8
+ * ranks: 1.5 blocks needed of a 4.2-block window): only marked chunks have to be received, the multiply never
+ * reads the others (the reference scatters exactly the entries it needs, bpetsc_template_2.c:413-504) */
+int dnm_mat_column_chunks(dnm_mat *A, int chunk_shift, uint8_t *map, int64_t nchunks, void *stream);
 /* y_local = A[own rows, :] x, x_window holding columns [win_start, win_start + win_len) */
 int dnm_mat_mult_window(dnm_mat *A, const void *x_window, int64_t win_start, int64_t win_len,
                         void *y_local, void *stream);

@@ -124,6 +124,16 @@ def _window_worker(rank, world, port, out_dir):
     buf = exchange_window(xg[s:s + n].clone(), owned, windows, rank)
     lo, hi = windows[rank]
     ok = torch.equal(buf, xg[lo:hi + 1])
+    # only the ranges a rank reads (backend.needed_ranges of the device's chunk map): holes stay as allocated
+    needs = []
+    for q, (wlo, whi) in enumerate(windows):
+        third = (whi + 1 - wlo) // 3
+        needs.append([(wlo, wlo + third - 5 * q), (whi + 1 - third, whi + 1)])
+    buf2 = exchange_window(xg[s:s + n].clone(), owned, windows, rank, None, needs)
+    want = torch.zeros_like(buf2)
+    for a, b in needs[rank] + [(max(lo, s), min(hi + 1, s + n))]:
+        want[a - lo:b - lo] = xg[a:b]
+    ok = ok and torch.equal(buf2, want)
     flag = torch.tensor([1.0 if ok else 0.0])
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     if rank == 0:

@@ -68,6 +68,10 @@ def _worker(rank, world, port, case, out_dir):
         xg, yg = x.to_numpy(to_all=True), y.to_numpy(to_all=True)
         ref = orc.matvec(orc_msc(H), orc_sub(sub), orc_sub(sub), xg, nthreads=2)
         assert np.max(np.abs(yg - ref)) < 1e-12, "partitioned SpinConserve multiply (default block kernel)"
+        summ = H.get_mat().exchange_summary()          # only the ranges of the window that are read travel
+        assert summ["scheme"] == "window" and 0 < summ["bytes_in"] < summ["window_bytes"]
+        # (three ranks: the middle rank's window has no holes; config 5's 8-rank share in test_gpu_fullsize.py has)
+        assert summ["bytes_in"] <= summ["window_bytes"] - 16 * H.get_mat().m_local, summ
         z = H.evolve(x, t=0.3, algo='chebyshev')
         assert abs(z.norm() - 1) < 1e-9 and abs(z.dot(H.dot(z)).imag) < 1e-9
         dist.barrier()

@@ -146,6 +146,11 @@ def test_config5_rank3_of_eight(monkeypatch):
             xw = backend.Vec(hi - lo + 1)
             xw.set_random(3)
             win = (lo, hi)
+            # the ranges of the window this rank really reads (what the exchange ships): a few long runs
+            needs = mat.column_needs(win)
+            covered = sum(b - a for a, b in needs)
+            assert len(needs) <= 16 and n < covered < 0.75 * (hi - lo + 1), (needs, n, hi - lo + 1)
+            assert any(a <= start and start + n <= b for a, b in needs)       # its own rows among them
         assert (lo, hi) == win
         y = backend.Vec(n)
         _lib.check(Lb.dnm_mat_mult_window(mat.handle, xw.ptr, lo, hi - lo + 1, y.ptr, None))
@@ -170,6 +175,7 @@ def test_config5_rank3_of_eight(monkeypatch):
             for t in range(offs[m], offs[m + 1]):
                 c += (1 - 2 * (bin(int(bras[m]) & int(signs[t])).count("1") & 1)) * coeffs[t]
             assert lo <= cols[m] <= hi or c == 0
+            assert c == 0 or any(a <= cols[m] < b for a, b in needs), "a column that is read was not marked"
             if c != 0:
                 acc += c * complex(xw.array[int(cols[m]) - lo].item())
         worst = max(worst, abs(acc - yv))

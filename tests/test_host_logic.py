@@ -456,3 +456,43 @@ def test_global_config_L():
             sigmax(9).L = 9
     finally:
         config.L = old
+
+
+def test_window_needed_ranges_and_schedule():
+    """backend.needed_ranges turns the device's chunk map into column ranges; window_exchange_ops schedules only
+    those, consistently on every rank (what q sends to r is what r expects from q, in the same order)."""
+    from dynamite_amd.backend import needed_ranges, window_exchange_ops, split_ownership
+    cmap = np.zeros(10, dtype=np.uint8)
+    cmap[[0, 1, 2, 5, 9]] = 1
+    assert needed_ranges(cmap, 4, (37, 187)) == [(37, 80), (112, 128), (176, 188)]
+    assert needed_ranges(np.zeros(4, dtype=np.uint8), 3, (8, 30)) == []
+    assert needed_ranges(np.ones(3, dtype=np.uint8), 0, (5, 7)) == [(5, 8)]
+    rs = np.random.RandomState(3)
+    N, P = 5000, 5
+    owned = [split_ownership(N, P, q) for q in range(P)]
+    windows, needs = [], []
+    for q, (s0, n) in enumerate(owned):
+        lo, hi = max(0, s0 - rs.randint(0, 1500)), min(N - 1, s0 + n - 1 + rs.randint(0, 1500))
+        windows.append((lo, hi))
+        cuts = np.sort(rs.choice(np.arange(lo, hi + 2), size=6, replace=False))
+        needs.append([(int(cuts[i]), int(cuts[i + 1])) for i in (0, 2, 4)])
+    ops = [window_exchange_ops(owned, windows, q, needs) for q in range(P)]
+    for q in range(P):
+        recvs, sends = ops[q]
+        for r in range(P):
+            if r == q:
+                continue
+            assert [(lo, hi) for (src, lo, hi) in recvs if src == r] == \
+                   [(lo, hi) for (dst, lo, hi) in ops[r][1] if dst == q]
+        got = sorted((lo, hi) for _, lo, hi in recvs)
+        # everything needed that others own arrives, nothing else
+        want = []
+        for a, b in needs[q]:
+            for r, (r0, rn) in enumerate(owned):
+                if r != q and max(a, r0) < min(b, r0 + rn):
+                    want.append((max(a, r0), min(b, r0 + rn)))
+        assert got == sorted(want)
+    # without the ranges the whole window travels
+    full = window_exchange_ops(owned, windows, 2)
+    assert sum(hi - lo for _, lo, hi in full[0]) == windows[2][1] + 1 - windows[2][0] - \
+        (min(windows[2][1] + 1, owned[2][0] + owned[2][1]) - max(windows[2][0], owned[2][0]))
