@@ -792,6 +792,37 @@ static int eigsolve_basis_free(Ops &ops, dnm_mat *A, int64_t n_local, int which,
   return 0;
 }
 
+// Spectral extent of A as the vector x sees it: k Lanczos steps from x (three work vectors in W, x untouched), the
+// larger magnitude of the extreme Ritz values -- a lower bound of the spectral radius that is close after a few
+// steps.  0 if the recurrence breaks down (x lies in a small invariant subspace: a Krylov method is exact there).
+static int lanczos_extent(Ops &ops, const void *x, double xnorm, int64_t n_local, void *W, int k, double *rho,
+                          hipStream_t st) {
+  std::vector<double> al, be, z;
+  auto slot = [&](int j) { return (void *)vecptr(W, n_local, j % 3); };
+  DNM_TRY(vk_axpby(slot(0), x, n_local, 1.0 / xnorm, 0.0, 0.0, 0.0, st));
+  *rho = 0.0;
+  for (int j = 0; j < k; ++j) {
+    void *q = slot(j), *p = slot(j + 1), *qm = slot(j + 2);
+    zc d(0);
+    double pn2 = 0;
+    DNM_TRY(ops.mult_dot(q, p, &d, j > 0 ? qm : nullptr, j > 0 ? be[j - 1] : 0.0, &pn2));
+    al.push_back(d.real());
+    double n2 = 0;
+    DNM_TRY(vec_lanczos_update_host(p, q, nullptr, n_local, d.real(), d.imag(), 0.0, &n2, st, 1.0));
+    DNM_TRY(ops.sum(&n2, 1));
+    const double bn = std::sqrt(n2 > 0 ? n2 : 0.0);
+    double scale = 0;
+    for (size_t i = 0; i < al.size(); ++i) scale = std::max(scale, std::fabs(al[i]) + (i < be.size() ? be[i] : 0.0));
+    if (bn <= 1e-10 * std::max(1.0, scale)) return 0;
+    DNM_TRY(vk_scale(p, n_local, 1.0 / bn, 0, st));
+    be.push_back(bn);
+  }
+  const int n = (int)al.size();
+  const double lo = tridiag_eigpair(al, be, n, 0, z), hi = tridiag_eigpair(al, be, n, n - 1, z);
+  *rho = std::max(std::fabs(lo), std::fabs(hi));
+  return 0;
+}
+
 extern "C" {
 
 int dnm_expm_chebyshev(dnm_mat *A, const void *x, void *y, int64_t n_local, double t, double tol,
@@ -885,9 +916,36 @@ int dnm_expm_multiply(dnm_mat *A, const void *x, void *y, int64_t n_local, doubl
       go = 1.25 * (double)terms < 0.8 * kry;
     }
     if (!go) go = 1.25 * (double)terms <= 1.9 * (double)m;
+    void *W = nullptr;
+    if (!go) {
+      // the Krylov probe would have to acquire a large workspace first (seconds, see basis_workspace) for a basis
+      // that memory keeps short -- where the expansion wins unless the norm bound is loose (m = 11 at L = 30: 144
+      // Krylov multiplies against 56 terms for t = 1, i.e. the bound may exceed the spectral radius about
+      // threefold before the expansion loses).  Ten Lanczos steps from x (the expansion's own four vectors
+      // suffice) tell: their extreme Ritz values reach roughly half the radius (random-field Heisenberg chain:
+      // 0.3 of the infinity norm; SYK at L = 8, where ten steps see all of it: 0.18), so 0.2 of the bound is the line.
+      const double need = (double)(m + 2) * (double)n_local * 16.0;
+      double want = (need > (double)g_basis.bytes && need >= 48.0 * 1073741824.0 && m < 30 && Nglob > 64) ? 1.0 : 0.0;
+      DNM_TRY(ops.maxr(&want, 1));
+      const char *penv = getenv("DNM_EXPM_PROBE");
+      if (penv) want = penv[0] == '1' && Nglob > 64 ? 1.0 : 0.0;
+      if (want > 0.0 && A->expm_bound != 0) {       // probed before with this operator
+        go = A->expm_bound > 0;
+        want = 0.0;
+      }
+      if (want > 0.0) {
+        DNM_TRY(basis_workspace((size_t)4 * (size_t)n_local * 16, &W));
+        double rho = 0;
+        DNM_TRY(lanczos_extent(ops, y, beta, n_local, W, 10, &rho, st));
+        go = rho >= 0.2 * anorm;
+        A->expm_bound = go ? 1 : -1;
+        if (getenv("DNM_KRYLOV_DEBUG"))
+          fprintf(stderr, "dnm_expm_multiply: spectral extent seen by x %.4g of the bound %.4g -> %s\n", rho, anorm,
+                  go ? "Chebyshev expansion" : "Krylov");
+      }
+    }
     if (go) {
-      void *W = nullptr;
-      DNM_TRY(basis_workspace((size_t)4 * (size_t)n_local * 16, &W));
+      if (!W) DNM_TRY(basis_workspace((size_t)4 * (size_t)n_local * 16, &W));
       int csteps = 0;
       double cerr = 0;
       DNM_TRY(cheb_core(ops, y, n_local, -dir.imag() * t_out, tol, anorm, W, &csteps, &cerr));

@@ -81,6 +81,7 @@ struct dnm_mat {
   // the basis size it belonged to -- later calls on this operator skip the Krylov probe when the estimate still holds
   double expm_tstep = 0.0;
   int expm_m = 0;
+  int expm_bound = 0;             // what the Lanczos probe of the norm bound found: +1 tight, -1 loose, 0 not probed
   dnm::DevBuf d_scmasks;          // SpinConserve kernel: per-mask precomputation (ScMask[nmasks])
 
   dnm::DevBuf diag;              // cached diagonal (double[m_local]) if precomputed

@@ -312,8 +312,10 @@ typedef struct dnm_solver_stats {
  * what the rest of the interval costs at the step size the error control has
  * settled on with what dnm_expm_chebyshev needs for it (known exactly) and hands
  * the rest over when that is clearly cheaper; the expansion is taken from the
- * start when all of it costs less than one outer step of ncv multiplies or when
- * an earlier hand-over on this operator still applies (DNM_EXPM_HYBRID=0: never). */
+ * start when all of it costs less than one outer step of ncv multiplies, when
+ * an earlier hand-over on this operator still applies, or when the basis
+ * workspace would have to be acquired for a memory-limited basis and ten Lanczos
+ * steps from x show that the norm bound is not loose (DNM_EXPM_HYBRID=0: never). */
 int dnm_expm_multiply(dnm_mat *A, const void *x, void *y, int64_t n_local,
                       double scale_re, double scale_im, double tol, int ncv,
                       int max_its, size_t work_limit_bytes, const dnm_hooks *hooks,

@@ -1077,3 +1077,24 @@ def test_vec_layout_conversions_chunked():
     r0.set_random(77)
     r1.set_random(77)
     assert np.array_equal(r1.local_numpy(), r0.local_numpy())
+
+
+def test_evolve_probe_of_the_norm_bound(monkeypatch, capfd):
+    """Memory-bound sizes: before acquiring a large Krylov workspace, evolve looks at the spectrum x sees (ten
+    Lanczos steps) and takes the Chebyshev expansion unless the norm bound is loose -- forced on here at a small
+    size (DNM_EXPM_PROBE): tight bound (random-field Heisenberg) -> expansion, loose bound (SYK) -> Krylov; results
+    agree with scipy either way."""
+    import scipy.sparse.linalg as spla
+    from dynamite_amd import models
+    from dynamite_amd.states import State
+    monkeypatch.setenv("DNM_EXPM_PROBE", "1")
+    monkeypatch.setenv("DNM_KRYLOV_DEBUG", "1")
+    for name, L, t, want in (("mbl", 12, 3.0, "Chebyshev expansion"), ("syk", 8, 0.3, "Krylov")):
+        H = models.BY_NAME[name](L)
+        H.establish_L()
+        x = State(L=H.L, state='random', seed=4)
+        y = H.evolve(x, t=t)
+        err = capfd.readouterr().err
+        assert "spectral extent seen by x" in err and ("-> " + want) in err, err
+        ref = spla.expm_multiply(-1j * t * H.to_numpy(sparse=True), x.to_numpy())
+        assert np.max(np.abs(y.to_numpy() - ref)) < 1e-8
