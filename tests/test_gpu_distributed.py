@@ -198,7 +198,7 @@ def _worker(rank, world, port, case, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("case,world", [("full", 2), ("full", 4), ("full_partner", 4), ("full_transpose", 2),
+@pytest.mark.parametrize("case,world", [("full", 2), ("full", 4), ("full", 8), ("full_partner", 4), ("full_transpose", 2),
                                         ("parity", 2), ("parity", 4), ("sc", 2), ("sc", 3),
                                         ("sc_big", 3), ("explicit", 3), ("auto", 2), ("projection", 3),
                                         ("projection", 2), ("full_odd", 3), ("parity_odd", 3)])
