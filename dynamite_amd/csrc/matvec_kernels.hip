@@ -149,13 +149,20 @@ __device__ __forceinline__ void apply_records(const DevQuad *__restrict__ quads,
   }
 }
 
+// 4 rows per thread need 76 registers as compiled for 4 waves per SIMD -- one 1024-thread workgroup per CU at B=12
+// (19.1 ms at L=30); asked for 8 waves they fit in 64 and two workgroups run: 17.35 ms, level with 8 rows per thread
+// at half the waves (17.45; profiles/r02_exp37_waves8.txt) -- occupancy is not what the passes wait for
+#ifndef DNM_WAVES_4ROWS
+#define DNM_WAVES_4ROWS 8
+#endif
 // waves per SIMD the launch bounds ask for: what LDS lets be resident, capped at 4
 constexpr int tile_waves_per_simd(int B, int LOGR) {
   int nt = 1 << (B - LOGR);
   int blocks = (160 * 1024) / (16 << B);
   if (blocks < 1) blocks = 1;
   int w = blocks * nt / 256;
-  return w < 1 ? 1 : (w > 4 ? 4 : w);
+  const int cap = LOGR <= 2 ? DNM_WAVES_4ROWS : 4;
+  return w < 1 ? 1 : (w > cap ? cap : w);
 }
 
 // GV (gather variant): 0 = gathers after the LDS masks; 1 = right behind the tile loads, before the barrier
