@@ -810,6 +810,17 @@ int dnm_mat_create(int64_t nmasks, const int64_t *masks, const int64_t *mask_off
       for (int r = A->nranks; r > 1; r >>= 1) --nl;
       cfg.logR = (nl >= 26 && !cfg.swz) ? 4 : 3;
     }
+    if (cfg.window_first < 0) {
+      // which pass writes y and which adds to it: the window pass is bound by its bytes (48 B/amp when it
+      // accumulates, at the streaming rate), the contiguous pass by its records (8.0 ms for 32.9 B/amp) -- so the y
+      // read belongs to the latter.  With swizzled vectors (in index order the window pass's gathers do not merge
+      // and it is the slow one either way, profiles/r01_prof_multi18.txt): L=30 17.5 -> 17.0 ms, L=28 4.43 -> 4.22,
+      // L=26 1.09 -> 1.07; level or worse while both vectors fit in the Infinity Cache
+      // (profiles/r02_exp41_pass_order.txt, r02_exp42_window_first_wide.txt)
+      int nl = A->op.n;
+      for (int r = A->nranks; r > 1; r >>= 1) --nl;
+      cfg.window_first = (cfg.swz && nl >= 25) ? 1 : 0;
+    }
     if (!tile_config_supported(cfg.B, cfg.logR)) {
       set_error("unsupported tile configuration B=%d logR=%d", cfg.B, cfg.logR);
       return 1;

@@ -297,10 +297,9 @@ static int make_plan_with(const OpForm &op, int rank, int nranks, const PlanConf
     }
   }
 
-  // Execution order (experiment, DNM_WINDOW_FIRST=1): window passes first, the contiguous pass accumulating
-  // last -- the idea being that the bandwidth-bound window pass then need not read y.  Measured slower: a
-  // window pass that only writes y takes 13.9 ms for 35 B/amp (profiles/r01_prof_multi18.txt).
-  if (cfg.window_first && pl.local.size() > 1) {
+  // Execution order (DNM_WINDOW_FIRST; the default is set where the plan is requested, mat.cpp): window passes
+  // first, the contiguous pass accumulating last -- the bandwidth-bound window pass then need not read y.
+  if (cfg.window_first > 0 && pl.local.size() > 1) {
     std::stable_sort(pl.local.begin(), pl.local.end(),
                      [](const PassSpec &a, const PassSpec &b) { return (a.nseg > 1) > (b.nseg > 1); });
     for (size_t i = 0; i < pl.local.size(); ++i) {

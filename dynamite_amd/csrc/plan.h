@@ -160,7 +160,8 @@ struct PlanConfig {
                        // 2: multi-pass LDS tiles + L2-served gathers over an XCD group
   int gbits = -1;      // mode 2: bits per XCD group (-1: 9 / 8 / 6 for local vectors of >= 2^30 / >= 2^26 / fewer amplitudes)
   int Bw = 0, logRw = 0; // mode 2 experiment: tile bits / rows per thread of the window passes (0: as B / logR)
-  int window_first = 0; // mode 2 experiment: run the window passes before the contiguous one (measured slower)
+  int window_first = -1; // run the window passes before the contiguous one, which then accumulates (-1: with swizzled
+                         // vectors of >= 2^25 local amplitudes; DNM_WINDOW_FIRST)
   int gbits_window = -1; // mode 2: cap of the group bits of window-tile passes (-1: no cap)
   int cache_policy = 98; // DevPass::cache_policy for every pass; default: gathers right behind the tile loads (32) + streaming loads (2) and stores (64) of y
   int max_gather_span = 0;   // mode 0: masks the tiler cannot place are gathered
