@@ -221,7 +221,10 @@ tile_pass_kernel(const DevPass P, const c128 *__restrict__ x, c128 *__restrict__
   }
 
   double ar[R], ai[R];
-  if (P.accumulate) {
+  // cache_policy bit 7: an accumulating pass adds its y at the END (loaded right before the stores) instead of
+  // starting from it -- y then crosses the L2 after the gathers of the workgroup, not before them
+  const bool late_y = P.accumulate && (P.cache_policy & 128);
+  if (P.accumulate && !late_y) {
     if (P.cache_policy & 2) {
 #pragma unroll
       for (int k = 0; k < R; ++k) {
@@ -361,6 +364,16 @@ tile_pass_kernel(const DevPass P, const c128 *__restrict__ x, c128 *__restrict__
   }
 #undef DNM_LOOP
 
+  if (late_y) {
+    c128 w[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) w[k] = load_streaming(y + yrows[k]);
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      ar[k] += w[k].x;
+      ai[k] += w[k].y;
+    }
+  }
   if (P.cache_policy & 64) {
 #pragma unroll
     for (int k = 0; k < R; ++k) store_streaming(y + yrows[k], ar[k], ai[k]);

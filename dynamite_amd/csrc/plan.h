@@ -96,7 +96,9 @@ struct DevPass {
   int32_t cache_policy; // bit0: write y through L2 (sc1 stores, line not kept); bit1: non-temporal y loads;
                         // bit2: non-temporal x tile loads; bit6: non-temporal y stores;
                         // bit5: gathers before the barrier, right behind
-                        // the tile loads (default)
+                        // the tile loads (default); bit7: an accumulating pass loads its y right before the
+                        // stores and adds it, instead of starting from it (default: y then crosses the L2 after
+                        // the workgroup's gathers -- L=30: 16.90 -> 16.74 ms, profiles/r02_exp44_late_y.txt)
   // diagonal records: tile-external terms, then one list per k-bucket
   uint32_t dext_begin, dext_end;
   uint32_t dbucket[MAXR + 1];
@@ -163,7 +165,7 @@ struct PlanConfig {
   int window_first = -1; // run the window passes before the contiguous one, which then accumulates (-1: with swizzled
                          // vectors of >= 2^25 local amplitudes; DNM_WINDOW_FIRST)
   int gbits_window = -1; // mode 2: cap of the group bits of window-tile passes (-1: no cap)
-  int cache_policy = 98; // DevPass::cache_policy for every pass; default: gathers right behind the tile loads (32) + streaming loads (2) and stores (64) of y
+  int cache_policy = 226; // DevPass::cache_policy for every pass; default: gathers right behind the tile loads (32) + streaming loads (2) and stores (64) of y + an accumulating pass adds its y at the end (128)
   int max_gather_span = 0;   // mode 0: masks the tiler cannot place are gathered
   int diag_last = 0;         // mode 2: evaluate the diagonal in the last local pass instead of the first
   int swz = 0;               // XOR-swizzle shift of the vectors this plan multiplies (0: natural order)

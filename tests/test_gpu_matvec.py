@@ -475,7 +475,7 @@ def test_fuzz_random_operators(monkeypatch, seed):
     B, logR = [(8, 2), (10, 2), (10, 3), (11, 3), (12, 3), (12, 4)][rs.randint(6)]
     mode = int(rs.randint(3))
     cfg(monkeypatch, B=B, logR=logR, mode=mode, amin=int(rs.randint(3, 6)), gbits=int(rs.randint(0, 7)))
-    monkeypatch.setenv("DNM_CACHE_POLICY", str([0, 32][rs.randint(2)]))
+    monkeypatch.setenv("DNM_CACHE_POLICY", str([0, 32, 226][rs.randint(3)]))
     H = _random_hermitian(L, int(rs.randint(3, 40)), rs)
     arrs = marshal(H)
     kind = ["full", "full", "parity", "sc", "explicit"][rs.randint(5)]
