@@ -805,11 +805,15 @@ int dnm_mat_create(int64_t nmasks, const int64_t *masks, const int64_t *mask_off
     cfg.swz = A->left.host.swz;
     if (cfg.logR < 0) {
       // measured: in index order 16 rows per thread pay from 2^26 local amplitudes on (profiles/r01_sweep6.txt);
-      // with swizzled vectors 8 rows (16 waves per CU) are faster at every size (profiles/r02_exp3_v2.txt)
+      // with swizzled vectors 8 rows beat 16 at every size (profiles/r02_exp3_v2.txt), and once the window pass
+      // runs first and the accumulating pass carries the diagonal, 4 rows per thread (two 1024-thread workgroups,
+      // 32 waves per CU) beat 8: L=30 16.9 -> 16.5 ms, 2-3 % from 2^26 amplitudes on
+      // (profiles/r02_exp46_rows4_series.txt, r02_exp47_rows4_sizes.txt)
       int nl = A->op.n;
       for (int r = A->nranks; r > 1; r >>= 1) --nl;
-      cfg.logR = (nl >= 26 && !cfg.swz) ? 4 : 3;
+      cfg.logR = cfg.swz ? 2 : (nl >= 26 ? 4 : 3);
     }
+    if (cfg.diag_last < 0) cfg.diag_last = cfg.swz ? 1 : 0;
     if (cfg.window_first < 0) {
       // which pass writes y and which adds to it: the window pass is bound by its bytes (48 B/amp when it
       // accumulates, at the streaming rate), the contiguous pass by its records (8.0 ms for 32.9 B/amp) -- so the y

@@ -308,10 +308,10 @@ static int make_plan_with(const OpForm &op, int rank, int nranks, const PlanConf
     }
   }
 
-  // the diagonal rides on the pass with the most time per tile to spare: the last (window, accumulating) pass moves
-  // 48 B/amp against the first one's 32 and holds fewer masks (DNM_DIAG_PASS=first|last; measured in
-  // profiles/r02_exp13_diag.txt)
-  if (cfg.diag_last && pl.local.size() > 1 && has_diag) {
+  // the diagonal rides on the last, accumulating pass (DNM_DIAG_PASS=first|last; the default is set where the plan
+  // is requested, mat.cpp): that pass is bound by its 48 B/amp, the first one by its records
+  // (profiles/r02_exp13_diag.txt, r02_exp45_after_order.txt, r02_exp46_rows4_series.txt)
+  if (cfg.diag_last > 0 && pl.local.size() > 1 && has_diag) {
     for (auto &ps : pl.local) ps.has_diag = false;
     pl.local.back().has_diag = true;
   }

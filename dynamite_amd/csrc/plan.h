@@ -167,7 +167,8 @@ struct PlanConfig {
   int gbits_window = -1; // mode 2: cap of the group bits of window-tile passes (-1: no cap)
   int cache_policy = 226; // DevPass::cache_policy for every pass; default: gathers right behind the tile loads (32) + streaming loads (2) and stores (64) of y + an accumulating pass adds its y at the end (128)
   int max_gather_span = 0;   // mode 0: masks the tiler cannot place are gathered
-  int diag_last = 0;         // mode 2: evaluate the diagonal in the last local pass instead of the first
+  int diag_last = -1;        // mode 2: evaluate the diagonal in the last local pass instead of the first (-1: with
+                             // swizzled vectors; DNM_DIAG_PASS=first|last)
   int swz = 0;               // XOR-swizzle shift of the vectors this plan multiplies (0: natural order)
   int kernel = 1;            // 1: tile_pass_kernel; 2: tile_pass2_kernel where it has an instance for the pass
 };

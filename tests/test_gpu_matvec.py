@@ -411,7 +411,7 @@ def test_full_size_default_plan(monkeypatch, L):
     a.set_random(4)
     a.normalize()
     mat = shell(H, sub)
-    assert "mode=2" in mat.describe() and "B=12 logR=3" in mat.describe() and len(mat.describe().splitlines()) == 3
+    assert "mode=2" in mat.describe() and "B=12 logR=2" in mat.describe() and len(mat.describe().splitlines()) == 3
     d = (C.c_double * 2)()
     _lib.check(_lib.lib().dnm_mat_mult_dot(mat.handle, a.ptr, y0.ptr, d, None))
     ref_dot = a.dot(y0)                        # sum a_i conj(y0_i) = conj(<a, y0>)
