@@ -811,6 +811,10 @@ constexpr int sc_binom(int n, int k) {
   return (int)r;
 }
 constexpr int SCB_MAXM = 64;    // masks per operator: one lane of a wavefront each
+#ifndef DNM_SC_NB
+#define DNM_SC_NB 2
+#endif
+constexpr int SC_NB = DNM_SC_NB;   // high bonds whose partner blocks are requested together
 
 __device__ __forceinline__ int64_t rl_i64(int64_t v, int l) {
   const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(v & 0xffffffff), l);
@@ -967,33 +971,38 @@ sc_block_kernel(const DevMsc msc, const ScMask *__restrict__ scm, const ScBlock 
   // bonds are resident on this XCD and were requested by their owners a moment ago.  Two bonds at a time:
   // 2 * RPT independent coalesced loads in flight per thread.
   while (hb) {
-    const int ma = __ffsll((long long)hb) - 1;
-    hb &= hb - 1;
-    const bool two = hb != 0;
-    const int mb = two ? __ffsll((long long)hb) - 1 : ma;
-    hb &= hb - 1;
-    const c128 *__restrict__ p0 = x + (base + rl_i64(delta_v, ma));
-    const c128 *__restrict__ p1 = x + (base + rl_i64(delta_v, mb));
-    const double c0r = rl_f64(c0, ma), c0i = rl_f64(c1, ma);
-    const double c1r = two ? rl_f64(c0, mb) : 0.0, c1i = two ? rl_f64(c1, mb) : 0.0;
-    c128 v0[RPT], v1[RPT];
+    // SC_NB bonds at a time: SC_NB * RPT independent coalesced loads in flight per thread
+    const c128 *__restrict__ pp[SC_NB];
+    double cr[SC_NB], ci[SC_NB];
+#pragma unroll
+    for (int j = 0; j < SC_NB; ++j) {
+      const bool have = hb != 0;
+      const int m = have ? __ffsll((long long)hb) - 1 : 0;
+      hb &= hb - 1;
+      pp[j] = x + (base + rl_i64(delta_v, m));
+      cr[j] = have ? rl_f64(c0, m) : 0.0;
+      ci[j] = have ? rl_f64(c1, m) : 0.0;
+      if (!have) pp[j] = pp[0];
+    }
+    c128 v[SC_NB][RPT];
 #pragma unroll
     for (int i = 0; i < RPT; ++i) {
       const int r = threadIdx.x + i * NT;
-      v0[i] = make_double2(0.0, 0.0);
-      v1[i] = make_double2(0.0, 0.0);
-      if ((live >> i) & 1u) { v0[i] = p0[r]; v1[i] = p1[r]; }
+#pragma unroll
+      for (int j = 0; j < SC_NB; ++j) {
+        v[j][i] = make_double2(0.0, 0.0);
+        if ((live >> i) & 1u) v[j][i] = pp[j][r];
+      }
     }
 #pragma unroll
-    for (int i = 0; i < RPT; ++i) {
-      accr[i] = fma(c0r, v0[i].x, accr[i]);
-      acci[i] = fma(c0r, v0[i].y, acci[i]);
-      accr[i] = fma(-c0i, v0[i].y, accr[i]);
-      acci[i] = fma(c0i, v0[i].x, acci[i]);
-      accr[i] = fma(c1r, v1[i].x, accr[i]);
-      acci[i] = fma(c1r, v1[i].y, acci[i]);
-      accr[i] = fma(-c1i, v1[i].y, accr[i]);
-      acci[i] = fma(c1i, v1[i].x, acci[i]);
+    for (int j = 0; j < SC_NB; ++j) {
+#pragma unroll
+      for (int i = 0; i < RPT; ++i) {
+        accr[i] = fma(cr[j], v[j][i].x, accr[i]);
+        acci[i] = fma(cr[j], v[j][i].y, acci[i]);
+        accr[i] = fma(-ci[j], v[j][i].y, accr[i]);
+        acci[i] = fma(ci[j], v[j][i].x, acci[i]);
+      }
     }
   }
   __syncthreads();
