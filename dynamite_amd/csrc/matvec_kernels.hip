@@ -814,6 +814,9 @@ constexpr int SCB_MAXM = 64;    // masks per operator: one lane of a wavefront e
 #ifndef DNM_SC_NB
 #define DNM_SC_NB 2
 #endif
+#ifndef DNM_SC_NT
+#define DNM_SC_NT 512
+#endif
 constexpr int SC_NB = DNM_SC_NB;   // high bonds whose partner blocks are requested together
 
 __device__ __forceinline__ int64_t rl_i64(int64_t v, int l) {
@@ -824,7 +827,7 @@ __device__ __forceinline__ int64_t rl_i64(int64_t v, int l) {
 __device__ __forceinline__ double rl_f64(double v, int l) { return __longlong_as_double(rl_i64(__double_as_longlong(v), l)); }
 
 template <int LB, int NT>
-__global__ void __launch_bounds__(NT, 4)
+__global__ void __launch_bounds__(NT, NT >= 1024 ? 8 : 4)
 sc_block_kernel(const DevMsc msc, const ScMask *__restrict__ scm, const ScBlock blk, const SubView sub_g, int64_t M,
                 int64_t row0, int64_t win_start, int64_t win_len, const double *__restrict__ diag,
                 const c128 *__restrict__ xw, c128 *__restrict__ y, const c128 *__restrict__ zinit, double zscale,
@@ -1164,7 +1167,7 @@ int launch_sc_block(const DevMsc &msc, const ScMask *scm, const ScBlock &blk, co
                      (const c128 *)zinit2, z2re, z2im)
   switch (blk.lb) {
     case 10: DNM_SCB(10, 64); break;
-    case 13: DNM_SCB(13, 512); break;
+    case 13: DNM_SCB(13, DNM_SC_NT); break;
     default: DNM_CHECK(false, "unsupported block size %d", blk.lb);
   }
 #undef DNM_SCB
