@@ -624,6 +624,11 @@ static int setup_sc_block(dnm_mat *A) {
   // round-robin to the XCDs.  Measured on MI355X, L=32 k=16: 17.6 ms ascending, 15.3 (g=1), 14.4 (g=6), 15.9 (g=8).
   int g = (hl - hf + 1 >= 1024) ? 6 : 0;
   if (const char *e = getenv("DNM_SC_ORDER")) g = atoi(e);
+  // DNM_SC_CHUNK=c (experiment): the order above inside chunks of 2^c consecutive high parts, chunk after chunk --
+  // partners under the c-1 lowest high bonds then lie in the same chunk, i.e. within what the Infinity Cache holds
+  int chunk = 0;
+  if (const char *e = getenv("DNM_SC_CHUNK")) chunk = atoi(e);
+  if (chunk <= 0 || chunk > 40) chunk = 62;
   if (g > 0 && hl - hf + 1 < ((int64_t)1 << 31)) {
     const int64_t span = hl - hf + 1;
     std::vector<uint32_t> ord;
@@ -635,6 +640,7 @@ static int setup_sc_block(dnm_mat *A) {
     std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) {
       const uint64_t ha = (uint64_t)(hf + a), hb = (uint64_t)(hf + b);
       const int pa = __builtin_popcountll(ha), pb = __builtin_popcountll(hb);
+      if ((ha >> chunk) != (hb >> chunk)) return (ha >> chunk) < (hb >> chunk);
       if (pa != pb) return pa < pb;
       if ((ha >> g) != (hb >> g)) return (ha >> g) < (hb >> g);
       return ha < hb;
