@@ -485,7 +485,8 @@ class ShellMat:
 
     def exchange_summary(self):
         """What one multiply moves between ranks: bytes received, sent, peers, and the bytes on the busiest
-        link (peer) -- for the link-bound estimate of bench.py."""
+        link (peer) -- for the link-bound estimate of bench.py.  On a window partition the first call sets the
+        windows up, which is collective: call it on every rank."""
         if self._tr is not None:
             pieces, cnt = self._tr[2], self._tr[4]
             per_peer = {}
