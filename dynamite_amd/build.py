@@ -12,7 +12,9 @@ LIB = os.path.join(HERE, "libdynamite_amd.so")
 SOURCES = ["matvec_kernels.hip", "tile_persist.hip", "vec_kernels.hip", "rdm_kernels.hip", "plan.cpp", "mat.cpp", "vec_api.cpp", "krylov.cpp"]
 ARCH = "gfx950"
 # tile_pass_kernel sits at the 128-VGPR edge of 4 waves per SIMD; these two scheduler options of the AMDGPU backend
-# measured -2.1 % on the L=30 multiply, same box (profiles/r02_exp22_sched.txt; max-ilp / iterative-minreg: +12...17 %)
+# measured -2.1 % on the L=30 multiply, same box (profiles/r02_exp22_sched.txt; max-ilp / iterative-minreg: +12...17 %);
+# re-measured for the 4-rows-per-thread default (64 registers): 16.31-16.67 ms with them (the memory-clause strategy is
+# the one that counts), 16.55-17.0 without or with max-ilp (profiles/r02_exp55_sched_rows4.txt)
 PER_FILE_FLAGS = {"matvec_kernels.hip": ["-mllvm", "-amdgpu-schedule-relaxed-occupancy=true",
                                          "-mllvm", "-amdgpu-sched-strategy=max-memory-clause"]}
 
