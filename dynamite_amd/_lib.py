@@ -165,7 +165,8 @@ def lib():
         import torch  # noqa: F401
         path = _build.build()       # no-op when the in-tree .so is current
         import os
-        path = os.environ.get("DNM_LIB", path)      # A/B experiments: another build of the same ABI
+        if os.environ.get("DNM_EXPERIMENTAL") == "1":       # A/B experiments: another build of the same ABI
+            path = os.environ.get("DNM_LIB", path)
         L = C.CDLL(path)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)   # AttributeError if the library lacks a declared symbol

@@ -19,7 +19,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from .config import config
+from .config import config, knob
 
 
 def _stream():
@@ -607,7 +607,7 @@ class ShellMat:
         import os
         import torch.distributed as dist
         mine = self.column_window()
-        needs = self.column_needs(mine) if os.environ.get('DNM_WINDOW_RANGES', '1') != '0' else None
+        needs = self.column_needs(mine) if knob('DNM_WINDOW_RANGES', '1') != '0' else None
         allw = [None] * self.nranks
         dist.all_gather_object(allw, (mine, needs))
         self._windows = [w for w, _ in allw]
@@ -702,7 +702,7 @@ def use_transposed_exchange(nranks):
     transposed scheme puts less on the busiest link than the partner blocks (two ranks: the partner block is
     half of what two transposes move).  DNM_EXCHANGE=partner / transpose overrides."""
     import os
-    mode = os.environ.get('DNM_EXCHANGE', 'auto')
+    mode = knob('DNM_EXCHANGE', 'auto')
     if mode == 'partner' or nranks < 2:
         return False
     return mode == 'transpose' or nranks >= 4

@@ -11,7 +11,7 @@ import numpy as np
 
 from . import _lib
 from .backend import _stream, _dist
-from .config import config
+from .config import config, knob
 
 
 class ConvergenceError(Exception):
@@ -221,7 +221,7 @@ def eigsolve(H, getvecs=False, nev=1, which='lowest', target=None, tol=None, sub
     # one extremal pair of a large operator: the native driver runs Lanczos without a stored basis (four work
     # vectors; DNM_EIGS_BASISFREE=0/1 forces the choice) -- nothing to fit into memory then
     import os
-    bf = os.environ.get('DNM_EIGS_BASISFREE')
+    bf = knob('DNM_EIGS_BASISFREE')
     basis_free = (ncv is None and nev == 1 and mat.N > 64 and
                   (bf[:1] == '1' if bf else _min_over_ranks(mat.n_local) >= (1 << 22)))
     if ncv is None and not basis_free:

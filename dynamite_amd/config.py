@@ -9,6 +9,15 @@ rank this process drives.  One process per GPU; ranks come from
 import os
 
 
+def knob(name, default=None):
+    """Experiment knobs (DNM_* environment variables) count only under DNM_EXPERIMENTAL=1, as in the native
+    library (csrc/dnm_common.h: knob); tests and the A/B tools set the gate, production runs ignore them."""
+    if os.environ.get('DNM_EXPERIMENTAL') != '1':
+        return default
+    v = os.environ.get(name)
+    return v if v else default
+
+
 class _Config:
     def __init__(self):
         self._L = None
@@ -20,7 +29,7 @@ class _Config:
         # layout of Full / Parity state vectors in device memory: XOR-swizzle shift (include/dynamite_amd.h,
         # dnm_subspace.vec_swizzle); 0 = index order.  16 measured best on MI355X (profiles/r02_exp1_swz.txt).
         # Fixed for the life of the process: vectors and matrices built under different values do not mix.
-        self.vec_swizzle = int(os.environ.get('DNM_SWZ', '16'))
+        self.vec_swizzle = int(knob('DNM_SWZ', '16'))
 
     # -- L / subspace / shell: same validation as the reference --------------
     @property

@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -38,6 +39,15 @@ void set_error(const char *fmt, ...);
     int rc_ = (call);                                                              \
     if (rc_) return rc_;                                                           \
   } while (0)
+
+// Experiment knobs (DNM_* environment variables that change plans, kernels or solver internals) are honoured
+// only under DNM_EXPERIMENTAL=1; a production process ignores them.  Tests and the A/B tools set the gate.
+static inline const char *knob(const char *name) {
+  const char *g = getenv("DNM_EXPERIMENTAL");
+  if (!g || g[0] != '1') return nullptr;
+  const char *v = getenv(name);
+  return (v && *v) ? v : nullptr;
+}
 
 struct cplx {
   double re, im;

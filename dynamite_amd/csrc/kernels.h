@@ -24,21 +24,6 @@ bool tile_config_supported(int B, int logR);
 int launch_tile_pass(const DevPass &P, int B, int logR, bool glds, int n_loc,
                      const void *x, void *y, const void *xr, hipStream_t st);
 
-// The same pass on the persistent kernel (tile_persist.hip): resident workgroups walk the tiles and prefetch the
-// next one.  P_dev: the descriptor in device memory; the fields that change from call to call travel by value.
-struct PassCall {
-  double *dot_out;
-  const void *zinit;
-  double zscale;
-  const void *zinit2;
-  double z2re, z2im;
-};
-bool tile_persist_supported(int B, int logR);
-unsigned tile_persist_grid(int n_loc, int B);      // workgroups
-size_t tile_persist_dot_partials(int n_loc, int B, int logR);   // partial sums written to dot_out (one per compute wave)
-int launch_tile_persist(const DevPass *P_dev, const PassCall &call, int B, int logR, int n_loc, const void *x, void *y,
-                        const void *xr, hipStream_t st);
-
 // y (+)= H x by one thread per row with index maps (MatMult semantics of
 // bcuda_template_2.cu:200-273 / bpetsc_template_2.c:371-412).
 // Rows [row0, row0 + M); x holds the columns [win_start, ...) in the layout xswz (-1: the right subspace's own);

@@ -311,7 +311,7 @@ static double pro_threshold(double eps1, double tol) {
   double t = std::sqrt(2.220446049250313e-16);
   if (tol > 0 && 0.1 * tol < t) t = 0.1 * tol;
   if (t < 4.0 * eps1) t = 4.0 * eps1;
-  if (getenv("DNM_PRO_THRESH")) t = atof(getenv("DNM_PRO_THRESH"));
+  if (knob("DNM_PRO_THRESH")) t = atof(knob("DNM_PRO_THRESH"));
   return t;
 }
 
@@ -536,7 +536,7 @@ static int cheb_core(Ops &ops, void *y, int64_t n_local, double t, double tol, d
   if (steps_out) *steps_out = nsteps;
   if (err_out) *err_out = tail * nsteps;
 
-  const char *cenv = getenv("DNM_CHEB_FORM");
+  const char *cenv = knob("DNM_CHEB_FORM");
   const bool clenshaw = !(ops.hooks && ops.hooks->mult) && dnm_mat_fuses_init(ops.A) && !(cenv && cenv[0] == 'f');
   if (clenshaw) {
     // Clenshaw's backward recurrence, b_k = a_k x + (2/r) A b_{k+1} - b_{k+2}, result a_0 x + A b_1 / r - b_2:
@@ -752,7 +752,7 @@ static int eigsolve_basis_free(Ops &ops, dnm_mat *A, int64_t n_local, int which,
   evals[0] = theta;
   stats->err_est = res / std::max(std::fabs(theta), 1e-300);
   const int matvecs_solve = ops.matvecs;
-  const char *venv = getenv("DNM_EIGS_VERIFY");
+  const char *venv = knob("DNM_EIGS_VERIFY");
   if ((evecs || (venv && venv[0] == '1')) && steps > 0) {
     // second run: the same vectors from the same start, v = sum_j s_j q_j accumulated in the fourth slot
     void *v = vecptr(W, n_local, 3);
@@ -781,7 +781,7 @@ static int eigsolve_basis_free(Ops &ops, dnm_mat *A, int64_t n_local, int which,
     stats->err_est = std::sqrt(n2 > 0 ? n2 : 0.0) / std::max(std::fabs(evals[0]), 1e-300);
     if (evecs) DNM_HIP(hipMemcpyAsync(evecs, v, (size_t)n_local * 16, hipMemcpyDeviceToDevice, st));
   }
-  if (getenv("DNM_KRYLOV_DEBUG"))
+  if (knob("DNM_KRYLOV_DEBUG"))
     fprintf(stderr, "dnm_eigsolve (basis-free Lanczos): %d steps, %d matvecs in all, theta = %.12g, relative residual %.2e (%s)\n",
             steps, ops.matvecs, evals[0], stats->err_est, evecs ? "measured" : "Lanczos estimate");
   DNM_HIP(hipStreamSynchronize(st));
@@ -860,7 +860,7 @@ int dnm_expm_multiply(dnm_mat *A, const void *x, void *y, int64_t n_local, doubl
   int64_t Nglob = A->N;
   // defaults everywhere and a real time: the driver may hand the rest of the interval to the Chebyshev expansion
   // (DNM_EXPM_HYBRID=0 keeps it Krylov throughout)
-  const char *henv = getenv("DNM_EXPM_HYBRID");
+  const char *henv = knob("DNM_EXPM_HYBRID");
   const bool hybrid = ncv <= 0 && max_its <= 0 && scale_re == 0.0 && !(henv && henv[0] == '0');
   if (tol <= 0) tol = 1e-8;
   if (max_its <= 0) max_its = 100;
@@ -927,7 +927,7 @@ int dnm_expm_multiply(dnm_mat *A, const void *x, void *y, int64_t n_local, doubl
       const double need = (double)(m + 2) * (double)n_local * 16.0;
       double want = (need > (double)g_basis.bytes && need >= 48.0 * 1073741824.0 && m < 30 && Nglob > 64) ? 1.0 : 0.0;
       DNM_TRY(ops.maxr(&want, 1));
-      const char *penv = getenv("DNM_EXPM_PROBE");
+      const char *penv = knob("DNM_EXPM_PROBE");
       if (penv) want = penv[0] == '1' && Nglob > 64 ? 1.0 : 0.0;
       if (want > 0.0 && A->expm_bound != 0) {       // probed before with this operator
         go = A->expm_bound > 0;
@@ -939,7 +939,7 @@ int dnm_expm_multiply(dnm_mat *A, const void *x, void *y, int64_t n_local, doubl
         DNM_TRY(lanczos_extent(ops, y, beta, n_local, W, 10, &rho, st));
         go = rho >= 0.2 * anorm;
         A->expm_bound = go ? 1 : -1;
-        if (getenv("DNM_KRYLOV_DEBUG"))
+        if (knob("DNM_KRYLOV_DEBUG"))
           fprintf(stderr, "dnm_expm_multiply: spectral extent seen by x %.4g of the bound %.4g -> %s\n", rho, anorm,
                   go ? "Chebyshev expansion" : "Krylov");
       }
@@ -976,7 +976,7 @@ int dnm_expm_multiply(dnm_mat *A, const void *x, void *y, int64_t n_local, doubl
   int nstep = 0;
   // DNM_EXPM_ORTHO=full: orthogonalise every Krylov vector against the whole basis (what
   // SLEPc's BV does); default: Lanczos with partial re-orthogonalisation
-  const char *oenv = getenv("DNM_EXPM_ORTHO");
+  const char *oenv = knob("DNM_EXPM_ORTHO");
   const bool use_pro = !(oenv && oenv[0] == 'f');
   LanczosMonitor mon;
   while (t_now < t_out) {
@@ -1149,7 +1149,7 @@ int dnm_eigsolve(dnm_mat *A, int64_t n_local, int nev, int which, double tol, in
     // one extremal pair of a large operator under default parameters: Lanczos without a stored basis (a step is
     // the multiply plus one sweep; the restarted scheme below spends two thirds of its time on basis traffic at
     // these sizes).  DNM_EIGS_BASISFREE=0 / 1 forces the choice; an explicit ncv keeps the restarted scheme.
-    const char *bf = getenv("DNM_EIGS_BASISFREE");
+    const char *bf = knob("DNM_EIGS_BASISFREE");
     double negn = -(double)n_local;       // the smallest block decides, so that every rank takes the same path
     DNM_TRY(ops.maxr(&negn, 1));
     const bool want = bf ? bf[0] == '1' : (-negn >= (double)((int64_t)1 << 22));
@@ -1184,12 +1184,12 @@ int dnm_eigsolve(dnm_mat *A, int64_t n_local, int nev, int which, double tol, in
 
   // DNM_EIGS_ORTHO=full: orthogonalise every Lanczos vector against the whole basis (what SLEPc's
   // Krylov-Schur does); default: partial re-orthogonalisation driven by the omega-recurrence
-  const char *oenv = getenv("DNM_EIGS_ORTHO");
+  const char *oenv = knob("DNM_EIGS_ORTHO");
   const bool use_pro = !(oenv && oenv[0] == 'f');
   // DNM_EIGS_BETA=sweep: beta from a norm sweep after the update (never the fused form); =rescale: always run the
   // corrective rescaling sweep -- both only to exercise the rarely taken branches in tests
-  const bool known_off = getenv("DNM_EIGS_KNOWN") && getenv("DNM_EIGS_KNOWN")[0] == '0';   // A/B switch
-  const char *benv = getenv("DNM_EIGS_BETA");
+  const bool known_off = knob("DNM_EIGS_KNOWN") && knob("DNM_EIGS_KNOWN")[0] == '0';   // A/B switch
+  const char *benv = knob("DNM_EIGS_BETA");
   const int beta_mode = !benv ? 0 : (benv[0] == 's' ? 1 : (benv[0] == 'r' ? 2 : 0));
   RestartMonitor mon;
   mon.init(m, (double)Nglob, tol);
@@ -1354,7 +1354,7 @@ int dnm_eigsolve(dnm_mat *A, int64_t n_local, int nev, int which, double tol, in
     ops.matvecs = matvecs_solve;      // reported separately from the iteration's multiplies
     stats->err_est = worst;
   }
-  if (getenv("DNM_KRYLOV_DEBUG"))
+  if (knob("DNM_KRYLOV_DEBUG"))
     fprintf(stderr, "dnm_eigsolve: %d restarts, %d matvecs, %d three-term steps, %d full re-orthogonalisations, "
             "largest true relative residual %.2e\n", its, ops.matvecs, mon.steps, mon.reorths, stats->err_est);
   DNM_HIP(hipStreamSynchronize(st));

@@ -85,7 +85,7 @@ int SubOwned::init(const dnm_subspace *s, bool want_device) {
     // bucket table: about two buckets per state (at most 2^26: 512 MB), so a search touches one or two entries
     int tb = 1;
     int tb_max = 26;         // measured at 40 M states: 8.2 ms (2^20 buckets), 6.5 (2^22), 4.9 (2^24), 4.2 (2^26); binary search: 22.9
-    if (const char *e = getenv("DNM_BUCKET_BITS")) tb_max = atoi(e);
+    if (const char *e = knob("DNM_BUCKET_BITS")) tb_max = atoi(e);
     while (tb < v.L && tb < tb_max && ((int64_t)1 << tb) < 2 * v.dim) ++tb;
     host.bucket_shift = v.L - tb;
     const int64_t nb = (int64_t)1 << tb;
@@ -226,7 +226,7 @@ static int build_pass(const dnm_mat &A, const PassSpec &ps, PassOnDevice *out) {
     for (size_t i = 0; i < nsel; ++i) order.push_back(rest[i]);
     for (int pos = ps.gpos; pos < ps.gpos + ps.glen; ++pos) order.push_back(pos);
     for (size_t i = nsel; i < rest.size(); ++i) order.push_back(rest[i]);
-    if (const char *e = getenv("DNM_ORDER_WINDOW")) {     // experiments: explicit block-id bit order (low to high)
+    if (const char *e = knob("DNM_ORDER_WINDOW")) {     // experiments: explicit block-id bit order (low to high)
       if (ps.nseg > 1 && ps.partner < 0) {
         std::vector<int> o;
         for (const char *q = e; *q;) {
@@ -309,7 +309,7 @@ static int build_pass(const dnm_mat &A, const PassSpec &ps, PassOnDevice *out) {
       push_diag_list(lst);
       d.dext_end = (uint32_t)quads.size();
       // terms inside the tile only: tabulated per tile coordinate (DNM_DIAG_TABLE=0: bucket lists as before)
-      const char *dte = getenv("DNM_DIAG_TABLE");
+      const char *dte = knob("DNM_DIAG_TABLE");
       const bool use_table = !(dte && dte[0] == '0') && B <= 13;
       if (use_table) out->h_dtile.assign((size_t)1 << B, 0.0);
       for (int j = 0; j < R; ++j) {
@@ -385,7 +385,6 @@ static int build_pass(const dnm_mat &A, const PassSpec &ps, PassOnDevice *out) {
     DNM_TRY(out->dtile.upload(out->h_dtile.data(), out->h_dtile.size() * sizeof(double)));
     d.dtile = (const double *)out->dtile.p;
   }
-  if (!A.host_only) DNM_TRY(out->desc_dev.upload(&d, sizeof(d)));
   out->partner = ps.partner;
   out->n_eff = n_eff;
   out->y_off = ps.y_off;
@@ -395,33 +394,14 @@ static int build_pass(const dnm_mat &A, const PassSpec &ps, PassOnDevice *out) {
 
 static hipStream_t S(void *stream) { return (hipStream_t)stream; }
 
-// tile_pass2_kernel wherever it has an instance for the pass geometry and the thread part of the tile coordinate
-// stays below index bit 28 (its 32-bit byte offsets); tile_pass_kernel otherwise (and with DNM_KERNEL=1 / GLDS)
-static bool pass_runs_persistent(const dnm_mat *A, const DevPass &d) {
-  if (A->plan.cfg.kernel != 2 || (A->flags & DNM_MAT_USE_GLDS)) return false;
-  if (!tile_persist_supported(d.tile_bits, d.log_rows)) return false;
-  const int lognt = d.tile_bits - d.log_rows;
-  for (int j = 0; j < d.nseg; ++j) {
-    if (d.seg_off[j] >= lognt) continue;
-    const int top_coord = std::min(d.seg_off[j] + d.seg_len[j], lognt) - 1;       // highest thread bit in this segment
-    if (d.seg_pos[j] + (top_coord - d.seg_off[j]) >= 28) return false;
-  }
-  return true;
-}
-
 // d: the pass descriptor with this call's fields filled in; p: the pass it was copied from
 static int launch_pass(const dnm_mat *A, const PassOnDevice &p, const DevPass &d, const void *x, void *y,
                        const void *xr, hipStream_t st) {
-  if (pass_runs_persistent(A, d)) {
-    const PassCall call{d.dot_out, d.zinit, d.zscale, d.zinit2, d.z2re, d.z2im};
-    return launch_tile_persist((const DevPass *)p.desc_dev.p, call, d.tile_bits, d.log_rows, p.n_eff, x, y, xr, st);
-  }
   return launch_tile_pass(d, d.tile_bits, d.log_rows, (A->flags & DNM_MAT_USE_GLDS) != 0, p.n_eff, x, y, xr, st);
 }
 
-// partial sums a pass writes to dot_out: one per tile, or one per resident workgroup
-static size_t pass_dot_partials(const dnm_mat *A, const PassOnDevice &p) {
-  if (pass_runs_persistent(A, p.desc)) return tile_persist_dot_partials(p.n_eff, p.desc.tile_bits, p.desc.log_rows);
+// partial sums a pass writes to dot_out: one per tile
+static size_t pass_dot_partials(const dnm_mat *, const PassOnDevice &p) {
   return (size_t)1 << (p.n_eff - p.desc.tile_bits);
 }
 
@@ -588,7 +568,7 @@ static int setup_sc_block(dnm_mat *A) {
   const SubView &h = A->left.host;
   const int L = h.L, k = h.k;
   int lb = -1;
-  if (const char *e = getenv("DNM_SC_BLOCK")) lb = atoi(e);
+  if (const char *e = knob("DNM_SC_BLOCK")) lb = atoi(e);
   if (lb == 0) return 0;
   const bool forced = lb > 0;
   if (!forced) lb = 13;
@@ -623,11 +603,11 @@ static int setup_sc_block(dnm_mat *A) {
   // and stay in step, and the blocks an XCD holds are siblings under the g-1 lowest high bonds; groups go
   // round-robin to the XCDs.  Measured on MI355X, L=32 k=16: 17.6 ms ascending, 15.3 (g=1), 14.4 (g=6), 15.9 (g=8).
   int g = (hl - hf + 1 >= 1024) ? 6 : 0;
-  if (const char *e = getenv("DNM_SC_ORDER")) g = atoi(e);
+  if (const char *e = knob("DNM_SC_ORDER")) g = atoi(e);
   // DNM_SC_CHUNK=c (experiment): the order above inside chunks of 2^c consecutive high parts, chunk after chunk --
   // partners under the c-1 lowest high bonds then lie in the same chunk, i.e. within what the Infinity Cache holds
   int chunk = 0;
-  if (const char *e = getenv("DNM_SC_CHUNK")) chunk = atoi(e);
+  if (const char *e = knob("DNM_SC_CHUNK")) chunk = atoi(e);
   if (chunk <= 0 || chunk > 40) chunk = 62;
   if (g > 0 && hl - hf + 1 < ((int64_t)1 << 31)) {
     const int64_t span = hl - hf + 1;

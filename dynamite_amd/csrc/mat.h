@@ -37,7 +37,6 @@ struct PassOnDevice {
   DevPass desc{};
   std::vector<DevQuad> h_quads;   // host copy (diagnostics / host-only handles)
   DevBuf quads;
-  DevBuf desc_dev;                // the descriptor in device memory (persistent kernel)
   std::vector<double> h_dtile;    // in-tile diagonal per tile coordinate (DevPass::dtile), host copy
   DevBuf dtile;
   int partner = -1;

@@ -433,7 +433,7 @@ static int launch_cfg(const DevPass &P, bool glds, int n_loc, const void *x, voi
   // DNM_LDS_KB (experiments): request more LDS than the tile needs to cap the
   // number of resident workgroups per CU
   static const size_t lds_req = []() {
-    const char *e = getenv("DNM_LDS_KB");
+    const char *e = knob("DNM_LDS_KB");
     return e ? (size_t)atoi(e) * 1024 : (size_t)0;
   }();
   const size_t lds = std::max((size_t)16 << B, lds_req);

@@ -9,8 +9,8 @@
 namespace dnm {
 
 static int env_int(const char *name, int dflt) {
-  const char *v = getenv(name);
-  if (!v || !*v) return dflt;
+  const char *v = knob(name);
+  if (!v) return dflt;
   return atoi(v);
 }
 
@@ -26,8 +26,7 @@ PlanConfig plan_config_from_env() {
   c.Bw = env_int("DNM_TILE_BITS_WINDOW", c.Bw);
   c.logRw = env_int("DNM_LOG_ROWS_WINDOW", c.logRw);
   c.cache_policy = env_int("DNM_CACHE_POLICY", c.cache_policy);
-  c.kernel = env_int("DNM_KERNEL", c.kernel);
-  if (const char *d = getenv("DNM_DIAG_PASS")) c.diag_last = (d[0] == 'l') ? 1 : 0;
+  if (const char *d = knob("DNM_DIAG_PASS")) c.diag_last = (d[0] == 'l') ? 1 : 0;
   return c;
 }
 

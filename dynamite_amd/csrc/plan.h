@@ -170,7 +170,6 @@ struct PlanConfig {
   int diag_last = -1;        // mode 2: evaluate the diagonal in the last local pass instead of the first (-1: with
                              // swizzled vectors; DNM_DIAG_PASS=first|last)
   int swz = 0;               // XOR-swizzle shift of the vectors this plan multiplies (0: natural order)
-  int kernel = 1;            // 1: tile_pass_kernel; 2: tile_pass2_kernel where it has an instance for the pass
 };
 
 struct Plan {

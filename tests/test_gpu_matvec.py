@@ -395,7 +395,7 @@ def test_full_size_properties(monkeypatch, L):
 @pytest.mark.default_layout
 @pytest.mark.parametrize("L", [26, 30])
 def test_full_size_default_plan(monkeypatch, L):
-    """The plan bench.py times (defaults: B=12, 8 rows per thread, LDS tiles + XCD-group gathers, fused
+    """The plan bench.py times (defaults: B=12, 4 rows per thread, LDS tiles + XCD-group gathers, fused
     dot product) against the plain multi-pass LDS plan, element-wise, at the BASELINE sizes."""
     import ctypes as C
     import torch

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Time of large device allocations (hipMalloc / hipFree): single slabs against many pieces."""
 import os, sys, time, ctypes as C
+os.environ.setdefault("DNM_EXPERIMENTAL", "1")   # tools drive experiment knobs
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402

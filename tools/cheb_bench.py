@@ -2,6 +2,7 @@
 """evolve(): the default Krylov (Expokit-style Lanczos) against algo='chebyshev' -- time, multiplies, agreement.
 usage: cheb_bench.py L [model] [t ...]"""
 import os, sys, time
+os.environ.setdefault("DNM_EXPERIMENTAL", "1")   # tools drive experiment knobs
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402

@@ -2,6 +2,7 @@
 """eigsolve on a named model: prints every returned pair with its explicitly computed residual, norm and
 overlaps (usage: eig_debug.py MODEL L NEV [TOL]); with DNM_KRYLOV_DEBUG=1 the solver adds its statistics."""
 import os, sys
+os.environ.setdefault("DNM_EXPERIMENTAL", "1")   # tools drive experiment knobs
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np

@@ -2,6 +2,7 @@
 """Multiply in an Explicit subspace (the states of SpinConserve(L, L/2) listed explicitly): what Auto / Explicit
 subspaces cost against the dedicated SpinConserve kernel."""
 import os, sys, time
+os.environ.setdefault("DNM_EXPERIMENTAL", "1")   # tools drive experiment knobs
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402

@@ -5,6 +5,7 @@ plain device copy."""
 import ctypes as C
 import json
 import os
+os.environ.setdefault("DNM_EXPERIMENTAL", "1")   # tools drive experiment knobs
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -2,6 +2,7 @@
 """The Krylov loops at the headline size: L=30 random-field Heisenberg, 2^30 amplitudes (16 GiB per vector),
 basis sizes chosen by what fits in HBM."""
 import os, sys, time
+os.environ.setdefault("DNM_EXPERIMENTAL", "1")   # tools drive experiment knobs
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402

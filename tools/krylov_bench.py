@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Times Operator.evolve / Operator.eigsolve (BASELINE config 2: L=26 XXZ, Full space, one GPU)."""
 import os
+os.environ.setdefault("DNM_EXPERIMENTAL", "1")   # tools drive experiment knobs
 import sys
 import time
 

@@ -1,6 +1,7 @@
 """Does the relative placement of x and y in HBM matter for the L=30 multiply?  y is placed at a byte offset inside a
 larger allocation (channel / bank interleaving of reads against writes).   python tools/offset_probe.py [L=30]"""
 import os
+os.environ.setdefault("DNM_EXPERIMENTAL", "1")   # tools drive experiment knobs
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Times reduced_density_matrix (GPU) for several cuts; prints effective FMA rate and bytes/s."""
 import os, sys, time
+os.environ.setdefault("DNM_EXPERIMENTAL", "1")   # tools drive experiment knobs
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402

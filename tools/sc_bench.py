@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Times the multiply in SpinConserve subspaces (generic row-gather kernel)."""
 import os
+os.environ.setdefault("DNM_EXPERIMENTAL", "1")   # tools drive experiment knobs
 import sys
 import time
 

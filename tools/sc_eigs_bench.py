@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """BASELINE config 5 on one GPU: lowest eigenvalue of the Heisenberg chain in the SpinConserve(L, L/2) sector."""
 import os, sys, time
+os.environ.setdefault("DNM_EXPERIMENTAL", "1")   # tools drive experiment knobs
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """evolve in SpinConserve(L, L/2) (Heisenberg chain): pure Krylov, default (hand-over) and Chebyshev."""
 import os, sys, time
+os.environ.setdefault("DNM_EXPERIMENTAL", "1")   # tools drive experiment knobs
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402

@@ -5,6 +5,7 @@
      block kernel against the row kernel, with the time per multiply.
 usage: sc_fullsize_check.py [single|rank R]"""
 import os
+os.environ.setdefault("DNM_EXPERIMENTAL", "1")   # tools drive experiment knobs
 import sys
 import time
 

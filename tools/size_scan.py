@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """y = Hx with the default plan over a range of sizes (random-field Heisenberg, Full space)."""
 import os, sys
+os.environ.setdefault("DNM_EXPERIMENTAL", "1")   # tools drive experiment knobs
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402

@@ -5,6 +5,7 @@ import ctypes as C
 import itertools
 import json
 import os
+os.environ.setdefault("DNM_EXPERIMENTAL", "1")   # tools drive experiment knobs
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

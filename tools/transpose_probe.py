@@ -6,6 +6,7 @@ the operator of the redistributed layout, the sum.  What is left of a multi-GPU 
 """
 import ctypes as C
 import os
+os.environ.setdefault("DNM_EXPERIMENTAL", "1")   # tools drive experiment knobs
 import sys
 import time
 

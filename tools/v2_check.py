@@ -6,6 +6,7 @@ usage: python tools/v2_check.py [L ...]"""
 import ctypes as C
 import json
 import os
+os.environ.setdefault("DNM_EXPERIMENTAL", "1")   # tools drive experiment knobs
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

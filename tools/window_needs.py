@@ -4,6 +4,7 @@ L=36, k=18, rank R of 8), on one GPU: window, needed ranges, time of the sweeps.
     python tools/window_needs.py [L=36] [k=18] [P=8]
 """
 import os
+os.environ.setdefault("DNM_EXPERIMENTAL", "1")   # tools drive experiment knobs
 import sys
 import time
 

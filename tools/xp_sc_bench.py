@@ -2,6 +2,7 @@
 """Multiply in XParity(SpinConserve(L, L/2)) (Heisenberg chain): the reduced operator carries one complemented
 many-spin mask next to the chain bonds."""
 import os, sys
+os.environ.setdefault("DNM_EXPERIMENTAL", "1")   # tools drive experiment knobs
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402
