@@ -7,11 +7,18 @@ Full space, complex128, on N MI355X GPUs of one node.
     python bench.py [--gpus N] [--steps K] [--warmup W] [--L L]
 
 A "step" is one multiply y = H x with x, y resident in HBM.  N=1: L=30 (2^30
-amplitudes, 16 GiB per vector; BASELINE.json configs[2]).  N>1: the state is
+amplitudes, 16 GiB per vector; BASELINE.json configs[2]).  N=2, 4: the state is
 row-block partitioned, L = 30 + log2(N) so every GPU keeps 2^30 amplitudes
-(weak scaling); the rank exchange (partner blocks on 2 ranks, an all-to-all
-between two layouts from 4 on -- DESIGN.md section 6) travels over RCCL while
-the rank-local masks run.  Prints ONE JSON line on rank 0.
+(weak scaling); N=8: L=34, the size of BASELINE.json configs[3] (2^31 amplitudes,
+32 GiB per vector and GPU).  The rank exchange (partner blocks on 2 ranks, an
+all-to-all between two layouts from 4 on -- DESIGN.md section 6) travels over
+RCCL while the rank-local masks run.  Prints ONE JSON line on rank 0.
+
+Every N > 1 line also carries the link rate MEASURED in the same run (the multiply's exchange posted alone,
+`xgmi_link_GBs_measured`) next to the assumed one the prediction uses.  Every rank runs a watchdog thread: a
+phase that makes no progress for `--watchdog` seconds prints the plan and the phase and ends the process with a
+non-zero code (so a hung collective cannot hold the node); the parent of a self-launched run ends the other
+ranks as soon as one fails.
 
 Launch forms: under torch.distributed.run (RANK / WORLD_SIZE in the environment) every process is one
 rank; a bare `python bench.py --gpus N` (N > 1, no WORLD_SIZE) starts its own N rank processes BEFORE
@@ -31,6 +38,23 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 ALG_BYTES_PER_AMP = 32.0  # read x once + write y once
+# what a two-launch plan must move per amplitude whatever the kernels do
+FLOOR_BYTES_PER_AMP = 80.0
+FLOOR_DERIVATION = ("two launches: x is read by both (2 x 16 B), y is written by the first, read back and written by "
+                    "the second (3 x 16 B); one launch would have to keep all 29 bond exchanges of the 2^30 hypercube "
+                    "on chip (DESIGN.md 4.2)")
+
+
+def default_L(n_gpus):
+    """N=1: BASELINE.json configs[2] (L=30).  N=2, 4: 2^30 amplitudes per GPU.  N=8: configs[3], L=34 (2^31 per GPU)."""
+    return 34 if n_gpus == 8 else 30 + int(math.log2(n_gpus))
+
+
+BASELINE_CONFIG = {(1, 30, "mbl"): "BASELINE.json configs[2]: L=30 random-field Heisenberg, 1 GPU",
+                   (8, 34, "mbl"): "BASELINE.json configs[3] at its size (L=34, 2^34 amplitudes on 8 GPUs) with the "
+                                   "headline's random fields kept: the same 33 bond masks and exchange as the plain "
+                                   "Heisenberg chain, L more diagonal terms (--model heisenberg runs it without them)",
+                   (8, 34, "heisenberg"): "BASELINE.json configs[3]: L=34 Heisenberg, 8 GPUs"}
 
 
 def cpu_baseline(sample_L=26, reps=3):
@@ -117,12 +141,32 @@ def _free_port():
     return p
 
 
-def spawn_ranks(n):
-    """Parent of a bare `--gpus N` call: start N rank processes (this interpreter has not touched the GPU:
-    `torch.cuda.device_count()` does not initialise it) and exit with the worst return code."""
+def visible_gpus():
+    """Number of GPUs this process could use, WITHOUT initialising the HIP runtime (the parent of a self-launched
+    run must stay clean of it: its children are the ones that touch the GPU).  KFD topology nodes with SIMDs are
+    GPUs; *_VISIBLE_DEVICES narrows the set."""
+    import glob
+    n = 0
+    for f in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            for ln in open(f):
+                if ln.startswith("simd_count") and int(ln.split()[1]) > 0:
+                    n += 1
+        except OSError:
+            pass
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([t for t in v.split(",") if t.strip() != ""]))
+    return n
+
+
+def spawn_ranks(n, timeout_s):
+    """Parent of a bare `--gpus N` call: start N rank processes (this interpreter never touches the GPU) and
+    supervise them: the first rank that fails, or the overall time limit, ends the others; exits with the worst
+    return code."""
     import subprocess
-    import torch
-    ndev = torch.cuda.device_count()
+    ndev = visible_gpus()
     env = dict(os.environ)
     env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE=str(n),
                HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
@@ -132,22 +176,79 @@ def spawn_ranks(n):
     for r in range(n):
         e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e))
-    rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
+    t0 = time.monotonic()
+    rc, why = 0, None
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            rc, why = abs(bad[0][1]) or 1, "rank %d exited with code %d" % bad[0]
+            break
+        if all(c == 0 for c in codes):
+            break
+        if timeout_s and time.monotonic() - t0 > timeout_s:
+            rc, why = 124, "time limit of %d s reached" % timeout_s
+            break
+        time.sleep(0.2)
+    if why:
+        sys.stderr.write("[bench] %s: ending the other ranks\n" % why)
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        t1 = time.monotonic()
+        while any(p.poll() is None for p in procs) and time.monotonic() - t1 < 10:
+            time.sleep(0.1)
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
     sys.exit(rc)
 
 
-def exchange_estimate(summary):
-    """Bytes this rank moves over xGMI per multiply (ShellMat.exchange_summary) and the time the busiest link
-    needs for them."""
-    return {"exchange": summary["scheme"], "xgmi_bytes_per_step": int(summary["bytes_in"]),
-            "xgmi_bytes_sent_per_step": int(summary["bytes_out"]), "xgmi_partners": int(summary["peers"]),
-            "xgmi_busiest_link_bytes": int(summary["busiest_link_bytes"]), "xgmi_link_GBs_assumed": XGMI_LINK_GBS,
-            "xgmi_link_bound_ms": summary["busiest_link_bytes"] / (XGMI_LINK_GBS * 1e9) * 1e3}
+class Watchdog:
+    """A rank's own guard against a hang (a collective whose peer never arrives, a kernel that does not return):
+    `phase(name)` marks progress; a phase older than `limit_s` prints what the rank was doing and the plan, then
+    ends the process with code 3 -- termination only, never a re-exec of a process that holds the GPU."""
+
+    def __init__(self, limit_s, rank):
+        import threading
+        self.limit, self.rank = limit_s, rank
+        self.name, self.t, self.info = "start", time.monotonic(), ""
+        self.done = []
+        if limit_s > 0:
+            threading.Thread(target=self._run, daemon=True).start()
+
+    def phase(self, name):
+        self.done.append(self.name)
+        self.name, self.t = name, time.monotonic()
+
+    def _run(self):
+        while True:
+            time.sleep(min(1.0, self.limit / 4))
+            if time.monotonic() - self.t > self.limit:
+                sys.stderr.write("[bench watchdog] rank %d: no progress in phase '%s' for %.0f s; last completed: %s\n"
+                                 "[bench watchdog] %s\n" % (self.rank, self.name, self.limit,
+                                                            self.done[-1] if self.done else "-", self.info))
+                sys.stderr.flush()
+                os._exit(3)
 
 
-def dry_run(args, world, rank):
+def exchange_estimate(summary, exchange_only_s=None):
+    """Bytes this rank moves over xGMI per multiply (ShellMat.exchange_summary), the time the busiest link needs
+    for them at the ASSUMED rate, and -- when the run timed the multiply's exchange on its own -- the rate the
+    busiest link really reached (bytes on that link / time of the exchange alone): the number that confirms or
+    refutes the prediction of DESIGN.md section 6."""
+    out = {"exchange": summary["scheme"], "xgmi_bytes_per_step": int(summary["bytes_in"]),
+           "xgmi_bytes_sent_per_step": int(summary["bytes_out"]), "xgmi_partners": int(summary["peers"]),
+           "xgmi_busiest_link_bytes": int(summary["busiest_link_bytes"]), "xgmi_link_GBs_assumed": XGMI_LINK_GBS,
+           "xgmi_link_bound_ms": summary["busiest_link_bytes"] / (XGMI_LINK_GBS * 1e9) * 1e3,
+           "xgmi_exchange_only_ms": None, "xgmi_link_GBs_measured": None}
+    if exchange_only_s and summary["busiest_link_bytes"]:
+        out["xgmi_exchange_only_ms"] = exchange_only_s * 1e3
+        out["xgmi_link_GBs_measured"] = summary["busiest_link_bytes"] / exchange_only_s / 1e9
+    return out
+
+
+def dry_run(args, world, rank, wd=None):
     """No GPU: build every rank's plan on the host, run the exchange schedule over gloo with host tensors and
     print the line with value = null.  Exercises launch, rendezvous, plan, schedule matching and transport."""
     import torch
@@ -155,6 +256,8 @@ def dry_run(args, world, rank):
     from dynamite_amd import models, backend, msc_tools, _lib
     from dynamite_amd.subspaces import Full
     L = args.L or (18 + int(math.log2(world)))
+    if wd:
+        wd.phase("dry run: plan L=%d" % L)
     H = models.BY_NAME[args.model](L)
     H.establish_L()
     H.reduce_msc()
@@ -205,6 +308,12 @@ def dry_run(args, world, rank):
             per[p_] = per.get(p_, 0) + 16 * c_
         summary = {"scheme": "partner", "bytes_in": sum(per.values()), "bytes_out": sum(16 * c_ for _, _, c_ in sends),
                    "peers": len(per), "busiest_link_bytes": max(per.values()) if per else 0}
+    if wd:
+        wd.info = "plan: " + C_describe(h).strip().replace("\n", " | ")
+        wd.phase("dry run: exchange steps")
+    hang = float(os.environ.get("DNM_BENCH_TEST_HANG_RANK", "-1"))
+    if hang == rank:            # tests: one rank never posts its exchange (what a lost peer looks like)
+        time.sleep(10 ** 6)
     for _ in range(args.warmup):
         one_step()
     dist.barrier()
@@ -225,7 +334,7 @@ def dry_run(args, world, rank):
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     if rank == 0:
         buf = C_describe(h) if plans is None else "transposed exchange | A: " + plans[0] + " | B: " + plans[1]
-        est = exchange_estimate(summary)
+        est = exchange_estimate(summary, float(t[0]) / args.steps)
         print(json.dumps({
             "metric": "matrix-free H|psi> Gamplitudes/s, random-field Heisenberg", "value": None,
             "unit": "Gamplitudes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -262,17 +371,22 @@ def main():
     ap.add_argument("--L", type=int, default=0)
     ap.add_argument("--model", default="mbl")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--watchdog", type=int, default=900, help="seconds a phase may take before the rank gives up (0: off)")
+    ap.add_argument("--timeout", type=int, default=3600, help="time limit of a self-launched multi-rank run (0: none)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        spawn_ranks(args.gpus)          # does not return
-    import torch
+        spawn_ranks(args.gpus, args.timeout)          # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    wd = Watchdog(args.watchdog if world > 1 else 0, rank)
+    wd.phase("import torch")
+    import torch
     if world > 1 and torch.cuda.device_count() == 0:
         import torch.distributed as dist
+        wd.phase("init_process_group(gloo)")
         dist.init_process_group("gloo")
-        dry_run(args, world, rank)      # does not return
+        dry_run(args, world, rank, wd)      # does not return
     if world > 1:
         import torch.distributed as dist
         # rank % device count, as the reference picks its GPU (bcuda_template_2.cu:64-67)
@@ -281,6 +395,7 @@ def main():
         # DNM_BENCH_BACKEND=gloo: dry run of the multi-rank flow with several ranks on one GPU (blocks staged
         # through the host; RCCL refuses two ranks on one device) -- a plumbing check, not a measurement
         backend_name = os.environ.get("DNM_BENCH_BACKEND", "nccl")
+        wd.phase("init_process_group(%s)" % backend_name)
         if backend_name == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
@@ -291,7 +406,8 @@ def main():
     config._initialize()
 
     n_gpus = world
-    L = args.L or (30 + int(math.log2(n_gpus)))
+    L = args.L or default_L(n_gpus)
+    wd.phase("build_mat L=%d" % L)
     H = models.BY_NAME[args.model](L)
     H.establish_L()
     H.reduce_msc()
@@ -301,7 +417,9 @@ def main():
     mat = backend.build_mat(masks, offs, H.msc['signs'], H.msc['coeffs'], sub._to_c(), sub._to_c())
     if rank == 0:
         print(mat.describe(), file=sys.stderr)
+    wd.info = "plan: " + mat.describe().strip().replace("\n", " | ")
     dim = 1 << L
+    wd.phase("allocate and fill the vectors")
     x, y = mat.createVecs()
     x.set_random(0)
     x.normalize()
@@ -314,9 +432,14 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for i in range(args.warmup):
+        wd.phase("warm-up multiply %d of %d" % (i + 1, args.warmup))
         mat.mult(x, y)
+        if world > 1:
+            torch.cuda.synchronize()        # so that the watchdog names the multiply that hangs
+    wd.phase("barrier before the timed steps")
     barrier()
+    wd.phase("%d timed multiplies" % args.steps)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
@@ -332,11 +455,25 @@ def main():
         wall, dev_ms = float(t[0]), float(t[1])
     ms_per_step = wall * 1e3 / args.steps
     summary = mat.exchange_summary()
+    exchange_only_s = None
     if world > 1:       # the heaviest rank (partner blocks differ from rank to rank: rank 0 needs the least)
         t = torch.tensor([summary["bytes_in"], summary["bytes_out"], summary["busiest_link_bytes"], summary["peers"]],
                          dtype=torch.float64, device=config.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         summary.update(bytes_in=int(t[0]), bytes_out=int(t[1]), busiest_link_bytes=int(t[2]), peers=int(t[3]))
+        # the multiply's exchange on its own (no kernels): what the links really carry per second
+        wd.phase("exchange alone (link rate)")
+        mat.exchange_only(x)
+        barrier()
+        t1 = time.perf_counter()
+        nrep = max(1, min(3, args.steps))
+        for _ in range(nrep):
+            mat.exchange_only(x)
+        barrier()
+        t = torch.tensor([(time.perf_counter() - t1) / nrep], dtype=torch.float64, device=config.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        exchange_only_s = float(t[0])
+    wd.phase("result line")
 
     # sanity: the timed multiply produced a finite vector of the expected size
     ynorm = y.norm()
@@ -376,20 +513,27 @@ def main():
                                    f"2^{L} complex128 amplitudes, matrix-free y=Hx",
                        "L": L, "dim": dim, "nmasks": int(len(masks)), "nterms": int(H.msc.size),
                        "partition": f"{n_gpus} x 2^{L - int(math.log2(n_gpus))} contiguous blocks",
+                       "baseline_config": BASELINE_CONFIG.get((n_gpus, L, args.model)),
                        "launches_per_step": launches,
                        "transport": (os.environ.get("DNM_BENCH_BACKEND", "nccl") if world > 1 else "none"),
-                       **exchange_estimate(summary),
-                       "tile_bits": int(os.environ.get("DNM_TILE_BITS", "12")),
-                       "plan_mode": int(os.environ.get("DNM_PLAN_MODE", "2")),
+                       "amplitudes_per_gpu": dim_local,
+                       **exchange_estimate(summary, exchange_only_s),
                        "plan": mat.describe().strip().replace("\n", " | "),
                        "plan_signature": plan_signature(mat)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                         # what the memory system really sustained: counter bytes per launch / launch time / peak
+                         "hbm_util": (traffic / (avg_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                         "traffic_bytes_per_amp": (traffic * launches / dim_local) if traffic else None,
+                         "floor_bytes_per_amp": FLOOR_BYTES_PER_AMP if launches == 2 else None,
+                         "floor_derivation": FLOOR_DERIVATION if launches == 2 else None,
+                         "frac_of_floor": (FLOOR_BYTES_PER_AMP * dim_local / launches / traffic) if (traffic and launches == 2) else None,
                          "kernel": "tile_pass_kernel", "avg_launch_ms": avg_launch_ms,
                          "alg_bytes_per_launch": alg_bytes_launch,
                          "read_only_frac": 0.5 * achieved / HBM_PEAK_GBS},
         }
         if n_gpus == 1 and not args.no_cpu_baseline:
+            wd.phase("cpu baseline")
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
     mat.destroy()

@@ -415,9 +415,7 @@ class ShellMat:
         L = _lib.lib()
         if x.array.data_ptr() == y.array.data_ptr():
             raise ValueError('x and y must be different vectors')
-        if x.swz != self.swz_right or y.swz != self.swz_left:
-            raise ValueError('vector layout (swizzle %d -> %d) does not match the matrix (%d -> %d)'
-                             % (x.swz, y.swz, self.swz_right, self.swz_left))
+        self.check_layout(x, y)
         if self._tr is not None:
             return self._mult_transposed(x, y)
         if self.nranks > 1 and not self.partners and self._is_windowed():
@@ -449,6 +447,19 @@ class ShellMat:
                 r.wait()
             for i in range(nr):
                 _lib.check(L.dnm_mat_mult_remote(self.handle, i, C.c_void_p(bufs[i].data_ptr()), y.ptr, _stream()))
+
+    def check_layout(self, x, y):
+        """Raise unless the vectors are laid out as this matrix expects them (x: right subspace, y: left).  Every
+        caller that hands raw vector pointers to the native library -- ``mult`` and the Krylov solvers -- goes
+        through here: the layout of a vector is fixed when it is created, the matrix's when it is built, and
+        process state in between (``config.vec_swizzle``, the number of ranks) may have changed."""
+        for v, want, n, name in ((x, self.swz_right, self.n_local, 'input'), (y, self.swz_left, self.m_local, 'result')):
+            if v.swz != want:
+                raise ValueError('%s vector layout (swizzle %d) does not match the matrix (%d): the state was '
+                                 'created under a different vector layout or rank count than the operator'
+                                 % (name, v.swz, want))
+            if v.local_size != n:
+                raise ValueError('%s vector holds %d local elements, the matrix expects %d' % (name, v.local_size, n))
 
     def set_transposed(self, split, left_c, right_c, flags=0):
         """Switch the partitioned multiply to the transposed exchange (``transpose_split``): two operators with
@@ -547,6 +558,32 @@ class ShellMat:
                 if hi_ > lo_:
                     _lib.check(L.dnm_vec_axpby(vp(y.array[lo_:hi_]), vp(xb[lo_:hi_]), hi_ - lo_, 1.0, 0.0, 1.0, 0.0,
                                                _stream()))
+
+    def exchange_only(self, x):
+        """Post and complete the rank exchange of ONE multiply without running any kernel: the same messages over
+        the same transport, for measuring what the links sustain (bench.py's ``xgmi_link_GBs_measured``).
+        Collective: every rank calls it."""
+        if self.nranks == 1:
+            return
+        import torch
+        if self._tr is not None:
+            _, _, pieces, own, cnt = self._tr
+            xb, wb = self._transpose_buffers(x.array)
+            for r in post_transpose(x.array, xb, pieces):        # the state goes out ...
+                r.wait()
+            for r in post_transpose(wb, xb, pieces):             # ... and a result of the same size comes back
+                r.wait()
+        elif not self.partners and self._is_windowed():
+            self._setup_windows()
+            self._window_buf = exchange_window(x.local_natural(), self._owned, self._windows, self.rank,
+                                               self._window_buf, self._needs)
+        else:
+            self.prepare_exchange(x.array)
+            bufs = [self._recv[i] for i in range(len(self.recvs))]
+            for r in post_exchange(x.array, self.sends, self.recvs, bufs):
+                r.wait()
+        if x.array.is_cuda:
+            torch.cuda.synchronize()
 
     def prepare_exchange(self, like):
         """Allocate the receive buffers / column window of the partitioned multiply now (they are

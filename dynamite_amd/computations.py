@@ -117,6 +117,7 @@ def evolve(H, state, t, result=None, tol=None, ncv=None, algo=None, max_its=None
     hooks = _hooks(mat, keep)
     stats = _lib.SolverStats()
     import torch
+    mat.check_layout(state.vec, result.vec)
     mat.prepare_exchange(state.vec.array)
     free, _ = torch.cuda.mem_get_info()
     if free < 34 * 16 * mat.n_local:      # the default basis would not fit: hand torch's cached blocks back first
@@ -172,6 +173,7 @@ def _evolve_chebyshev(H, state, t, result, tol):
     keep = []
     hooks = _hooks(mat, keep)
     stats = _lib.SolverStats()
+    mat.check_layout(state.vec, result.vec)
     mat.prepare_exchange(state.vec.array)
     _lib.check(_lib.lib().dnm_expm_chebyshev(
         mat.handle, state.vec.ptr, result.vec.ptr, mat.n_local, float(complex(t).real),

@@ -698,11 +698,15 @@ static int eigsolve_basis_free(Ops &ops, dnm_mat *A, int64_t n_local, int which,
   const int64_t offset = hooks ? A->row0 : 0;
   const int vswz = A->right.host.swz;
   std::vector<double> al, be, svec;
+  struct Step { double are, aim, s1, s2; };      // what the update of a step did, so that the second run repeats it
+  std::vector<Step> rec;
   double theta = 0, res = 0;
   bool converged = false;
-  int steps = 0;
+  int steps = 0, rounds = 0, matvecs_solve = 0;
   auto slot = [&](int k) { return (void *)vecptr(W, n_local, k % 3); };
-  auto start = [&]() -> int {
+  // start vector: seeded normal deviates, or (later rounds) the Ritz vector of the round before, kept in `evecs`
+  auto start = [&](bool from_prev) -> int {
+    if (from_prev) return vk_axpby(slot(0), evecs, n_local, 1.0, 0.0, 0.0, 0.0, st);
     DNM_TRY(vk_random(slot(0), n_local, seed, offset, st, vswz));
     double n0 = 0;
     DNM_TRY(ops.norm(slot(0), &n0));
@@ -717,53 +721,63 @@ static int eigsolve_basis_free(Ops &ops, dnm_mat *A, int64_t n_local, int which,
     if (std::fabs(hi) > std::fabs(lo)) { z = z2; return hi; }
     return lo;
   };
-  DNM_TRY(start());
-  for (int j = 0; j < max_steps; ++j) {
-    void *q = slot(j), *p = slot(j + 1), *qm = slot(j + 2);     // (j + 2) % 3 == (j - 1) % 3
-    zc d(0);
-    double pn2 = 0;
-    DNM_TRY(ops.mult_dot(q, p, &d, j > 0 ? qm : nullptr, j > 0 ? be[j - 1] : 0.0, &pn2));
-    al.push_back(d.real());
-    const double b2 = pn2 - std::norm(d);
-    const bool fused = b2 > 1e-4 * pn2 && pn2 > 0;
-    double n2 = 0, bn;
-    DNM_TRY(vec_lanczos_update_host(p, q, nullptr, n_local, d.real(), d.imag(), 0.0, &n2, st,
-                                    fused ? 1.0 / std::sqrt(b2) : 1.0));
-    DNM_TRY(ops.sum(&n2, 1));
-    if (fused) {
-      const double nu = std::sqrt(n2 > 0 ? n2 : 0.0);
-      bn = std::sqrt(b2) * nu;
-      if (std::fabs(n2 - 1.0) > 1e-12 && nu > 0) DNM_TRY(vk_scale(p, n_local, 1.0 / nu, 0, st));
-    } else {
-      bn = std::sqrt(n2 > 0 ? n2 : 0.0);
-      if (bn > 0) DNM_TRY(vk_scale(p, n_local, 1.0 / bn, 0, st));
-    }
-    be.push_back(bn);
-    steps = j + 1;
-    double scale = 0;
-    for (int i = 0; i < steps; ++i) scale = std::max(scale, std::fabs(al[i]) + be[i]);
-    const bool breakdown = bn <= 1e-14 * std::max(1.0, scale);
-    if (steps >= 8 || breakdown || steps == max_steps) {
-      theta = pick(steps, svec);
-      res = std::fabs(bn * svec[steps - 1]);
-      if (breakdown || res <= tol * std::max(std::fabs(theta), 1e-300)) { converged = true; break; }
-    }
-  }
-  evals[0] = theta;
-  stats->err_est = res / std::max(std::fabs(theta), 1e-300);
-  const int matvecs_solve = ops.matvecs;
   const char *venv = knob("DNM_EIGS_VERIFY");
-  if ((evecs || (venv && venv[0] == '1')) && steps > 0) {
-    // second run: the same vectors from the same start, v = sum_j s_j q_j accumulated in the fourth slot
+  const bool verify = venv && venv[0] == '1';
+  bool measured = false;
+  while (true) {
+    al.clear(); be.clear(); rec.clear();
+    converged = false;
+    steps = 0;
+    DNM_TRY(start(rounds > 0));
+    for (int j = 0; j < max_steps; ++j) {
+      void *q = slot(j), *p = slot(j + 1), *qm = slot(j + 2);     // (j + 2) % 3 == (j - 1) % 3
+      zc d(0);
+      double pn2 = 0;
+      DNM_TRY(ops.mult_dot(q, p, &d, j > 0 ? qm : nullptr, j > 0 ? be[j - 1] : 0.0, &pn2));
+      al.push_back(d.real());
+      const double b2 = pn2 - std::norm(d);
+      const bool fused = b2 > 1e-4 * pn2 && pn2 > 0;
+      double n2 = 0, bn;
+      Step sr{d.real(), d.imag(), fused ? 1.0 / std::sqrt(b2) : 1.0, 0.0};
+      DNM_TRY(vec_lanczos_update_host(p, q, nullptr, n_local, sr.are, sr.aim, 0.0, &n2, st, sr.s1));
+      DNM_TRY(ops.sum(&n2, 1));
+      if (fused) {
+        const double nu = std::sqrt(n2 > 0 ? n2 : 0.0);
+        bn = std::sqrt(b2) * nu;
+        if (std::fabs(n2 - 1.0) > 1e-12 && nu > 0) sr.s2 = 1.0 / nu;
+      } else {
+        bn = std::sqrt(n2 > 0 ? n2 : 0.0);
+        if (bn > 0) sr.s2 = 1.0 / bn;
+      }
+      if (sr.s2 != 0.0) DNM_TRY(vk_scale(p, n_local, sr.s2, 0, st));
+      rec.push_back(sr);
+      be.push_back(bn);
+      steps = j + 1;
+      double scale = 0;
+      for (int i = 0; i < steps; ++i) scale = std::max(scale, std::fabs(al[i]) + be[i]);
+      const bool breakdown = bn <= 1e-14 * std::max(1.0, scale);
+      if (steps >= 8 || breakdown || steps == max_steps) {
+        theta = pick(steps, svec);
+        res = std::fabs(bn * svec[steps - 1]);
+        if (breakdown || res <= tol * std::max(std::fabs(theta), 1e-300)) { converged = true; break; }
+      }
+    }
+    evals[0] = theta;
+    stats->err_est = res / std::max(std::fabs(theta), 1e-300);
+    matvecs_solve = ops.matvecs;
+    if (!(evecs || verify) || steps == 0) break;
+    // second run: the same vectors from the same start by the same arithmetic (recorded coefficients and scales),
+    // v = sum_j s_j q_j accumulated in the fourth slot
     void *v = vecptr(W, n_local, 3);
-    DNM_TRY(start());
+    DNM_TRY(start(rounds > 0));
     DNM_TRY(vk_axpby(v, slot(0), n_local, svec[0], 0.0, 0.0, 0.0, st));
     for (int j = 0; j + 1 < steps; ++j) {
       void *q = slot(j), *p = slot(j + 1), *qm = slot(j + 2);
       if (j > 0) DNM_TRY(ops.mult_sub(q, p, qm, be[j - 1]));
       else DNM_TRY(ops.mult(q, p));
       double n2 = 0;
-      DNM_TRY(vec_lanczos_update_host(p, q, nullptr, n_local, al[j], 0.0, 0.0, &n2, st, 1.0 / be[j]));
+      DNM_TRY(vec_lanczos_update_host(p, q, nullptr, n_local, rec[j].are, rec[j].aim, 0.0, &n2, st, rec[j].s1));
+      if (rec[j].s2 != 0.0) DNM_TRY(vk_scale(p, n_local, rec[j].s2, 0, st));
       DNM_TRY(vk_axpby(v, p, n_local, svec[j + 1], 0.0, 1.0, 0.0, st));
     }
     double vn = 0;
@@ -779,14 +793,21 @@ static int eigsolve_basis_free(Ops &ops, dnm_mat *A, int64_t n_local, int which,
     DNM_TRY(ops.sum(&n2, 1));
     evals[0] = d.real();
     stats->err_est = std::sqrt(n2 > 0 ? n2 : 0.0) / std::max(std::fabs(evals[0]), 1e-300);
+    measured = true;
     if (evecs) DNM_HIP(hipMemcpyAsync(evecs, v, (size_t)n_local * 16, hipMemcpyDeviceToDevice, st));
+    // the contract is a residual below tol (computations.py:274-275 raises otherwise): the estimate of the first
+    // run is not the vector's residual once rounding has crept into a long recurrence.  Polish: Lanczos again from
+    // the Ritz vector itself (a handful of steps); a vector that still misses tol is reported as not converged.
+    if (!converged || !evecs || stats->err_est <= tol) break;
+    if (++rounds >= 3) { converged = false; break; }
   }
   if (knob("DNM_KRYLOV_DEBUG"))
     fprintf(stderr, "dnm_eigsolve (basis-free Lanczos): %d steps, %d matvecs in all, theta = %.12g, relative residual %.2e (%s)\n",
-            steps, ops.matvecs, evals[0], stats->err_est, evecs ? "measured" : "Lanczos estimate");
+            steps, ops.matvecs, evals[0], stats->err_est, measured ? "measured" : "Lanczos estimate");
+  (void)rounds;
   DNM_HIP(hipStreamSynchronize(st));
   stats->its = 1;
-  stats->matvecs = evecs ? ops.matvecs : matvecs_solve;
+  stats->matvecs = measured ? ops.matvecs : matvecs_solve;
   stats->nconv = converged ? 1 : 0;
   stats->reason = converged ? DNM_CONVERGED_TOL : DNM_DIVERGED_ITS;
   return 0;

@@ -42,3 +42,92 @@ def test_bench_spawns_its_ranks(n):
         assert cfg["exchange"] == "transpose" and cfg["plan"].startswith("transposed exchange")
         assert cfg["xgmi_bytes_per_step"] == 2 * 16 * nloc * (n - 1) // n
         assert cfg["xgmi_partners"] == n - 1 and cfg["xgmi_busiest_link_bytes"] == 2 * 16 * nloc // n
+
+
+def _run_bench(argv, extra_env=None, timeout=600):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(extra_env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, capture_output=True, text=True,
+                          timeout=timeout, env=env)
+
+
+def test_bench_eight_ranks_dry_run():
+    """The 8-rank launch the driver's SCALE run uses, at a size eight CPU processes can hold: transposed exchange,
+    every link carrying 2 * block / 8 there and back, and the link rate measured in the run next to the assumed."""
+    import torch
+    if torch.cuda.device_count() > 0:
+        pytest.skip("dry-run flow is the no-GPU path")
+    p = _run_bench(["--gpus", "8", "--steps", "2", "--warmup", "1", "--L", "23"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    cfg = out["config"]
+    nloc = (1 << 23) // 8
+    assert out["n_gpus"] == 8 and out["exchange_ok"] is True
+    assert cfg["exchange"] == "transpose" and cfg["xgmi_partners"] == 7
+    assert cfg["xgmi_busiest_link_bytes"] == 2 * 16 * nloc // 8
+    assert cfg["xgmi_link_GBs_assumed"] == 64.0
+    assert cfg["xgmi_exchange_only_ms"] > 0 and cfg["xgmi_link_GBs_measured"] > 0
+
+
+def test_bench_default_sizes():
+    """N=1 is BASELINE configs[2] (L=30), N=8 is configs[3] (L=34); 2 and 4 keep 2^30 amplitudes per GPU."""
+    sys.path.insert(0, ROOT)
+    import bench
+    assert [bench.default_L(n) for n in (1, 2, 4, 8)] == [30, 31, 32, 34]
+    assert "configs[3]" in bench.BASELINE_CONFIG[(8, 34, "mbl")]
+    assert "configs[2]" in bench.BASELINE_CONFIG[(1, 30, "mbl")]
+
+
+@pytest.mark.parametrize("rank", [0, 5])
+def test_config4_plan_on_the_host(rank):
+    """BASELINE configs[3] -- L=34 on 8 ranks, 2^31 amplitudes per rank -- planned with a host-only handle: the
+    transposed exchange applies, both of its operators are rank-local, the layout-A operator runs the two-launch
+    plan on n_loc = 31 and every link carries 2 * 2^31 / 8 amplitudes of 16 B per multiply."""
+    from dynamite_amd import models, backend, msc_tools, _lib
+    from dynamite_amd.subspaces import Full
+    import bench
+    L, world = 34, 8
+    H = models.mbl(L)
+    H.establish_L()
+    H.reduce_msc()
+    masks, offs = msc_tools.get_mask_offsets(H.msc)
+    assert len(masks) == 34
+    sub = Full(L=L)
+    lc, rc = sub._c(), sub._c()
+    # the layout the 8-rank run takes: the swizzle field must end below the pieces of the all-to-all
+    lc.vec_swizzle = rc.vec_swizzle = 14
+    split = backend.transpose_split(masks, offs, H.msc['signs'], H.msc['coeffs'], L, world, int(lc.vec_swizzle))
+    assert split is not None
+    lo, hi, f = split
+    assert f == 31 - 1 - 3
+    descr = []
+    for part in (lo, hi):
+        h = backend.create_mat(*part, lc, rc, False, _lib.MAT_HOST_ONLY, rank, world)
+        assert backend.exchange_plan(h) == ([], [])
+        descr.append(bench.C_describe(h))
+        _lib.check(_lib.lib().dnm_mat_destroy(h))
+    assert "n=34 n_loc=31" in descr[0] and "tiled=1" in descr[0] and descr[0].count("local pass") == 2
+    assert "tiled=1" in descr[1] and descr[1].count("local pass") == 1        # layout B: one LDS-only window launch
+    pieces, own, cnt = backend.transpose_pieces(31, 3, f, rank)
+    per_peer = {}
+    for q, _, c in pieces:
+        per_peer[q] = per_peer.get(q, 0) + 16 * c
+    assert len(per_peer) == 7 and set(per_peer.values()) == {16 * (1 << 31) // 8}
+
+
+def test_bench_watchdog_ends_a_hung_run():
+    """One rank never posts its exchange: the others' watchdogs give up with the phase and the plan printed, the
+    parent ends what is left and returns non-zero -- nothing waits forever."""
+    import time
+    import torch
+    if torch.cuda.device_count() > 0:
+        pytest.skip("dry-run flow is the no-GPU path")
+    t0 = time.time()
+    p = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "1", "--L", "14", "--watchdog", "4"],
+                   {"DNM_BENCH_TEST_HANG_RANK": "1"}, timeout=300)
+    assert p.returncode != 0
+    assert time.time() - t0 < 120
+    assert "[bench watchdog] rank" in p.stderr and "no progress in phase" in p.stderr and "plan:" in p.stderr
+    assert "ending the other ranks" in p.stderr
