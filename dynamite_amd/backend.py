@@ -205,18 +205,34 @@ def post_transpose(src, dst, pieces):
 class Vec:
     """Distributed complex128 vector: this rank's block lives in ``self.array``
     (a 1-D torch tensor on the rank's GPU).  ``swz``: layout of the block (dnm_subspace.vec_swizzle): 0 = element
-    i at position i; S > 0 = XOR-swizzled (Full / Parity states).  Everything index-wise goes through
-    ``positions`` / ``get_local`` / ``set_local``; the BLAS-1 methods do not care."""
+    i at position i; 5 <= S <= 24 = XOR-swizzled (Full / Parity states); a | w << 8 = the three-field internal
+    layout of a SpinConserve subspace (csrc/sc3.h; ``sub_c`` is then that subspace's descriptor, one rank): rows in
+    another order plus zero padding, so ``local_size`` (what the vector kernels sweep) exceeds ``rows``.
+    Everything index-wise goes through ``positions`` / ``get_local`` / ``set_local``; the BLAS-1 methods do not
+    care."""
 
-    def __init__(self, size, array=None, swz=0):
+    def __init__(self, size, array=None, swz=0, sub_c=None):
         import torch
         config._initialize()
         self.size = int(size)
         self.swz = int(swz)
+        self.sub_c = sub_c
         self.start, self.local_size = split_ownership(self.size, config.world_size, config.rank)
+        self.rows = self.local_size              # elements of the vector this rank holds
+        if self.internal:
+            if sub_c is None or config.world_size != 1:
+                raise ValueError('a vector in the SpinConserve internal layout needs its subspace descriptor (one rank)')
+            n = C.c_int64()
+            _lib.check(_lib.lib().dnm_vec_layout_size(C.byref(sub_c), C.byref(n)))
+            self.local_size = n.value           # rows + padding
         if array is None:
             array = device_zeros(self.local_size)
         self.array = array
+
+    @property
+    def internal(self):
+        """True for the SpinConserve internal layout (rows reordered and padded)."""
+        return self.swz >= 256
 
     # -- layout ------------------------------------------------------------------
     def positions(self, idx):
@@ -224,6 +240,18 @@ class Vec:
         S = self.swz
         if not S:
             return idx
+        if self.internal:
+            import torch
+            if not torch.is_tensor(idx):
+                a = np.ascontiguousarray([int(idx)], dtype=np.int64)
+                out = np.empty_like(a)
+                _lib.check(_lib.lib().dnm_vec_layout_positions_host(C.byref(self.sub_c), 1, _lib.p64(a), _lib.p64(out)))
+                return int(out[0])
+            idx = idx.to(device=self.array.device, dtype=torch.int64).contiguous()
+            pos = torch.empty_like(idx)
+            _lib.check(_lib.lib().dnm_vec_layout_positions(C.byref(self.sub_c), idx.numel(), C.c_void_p(idx.data_ptr()),
+                                                           C.c_void_p(pos.data_ptr()), _stream()))
+            return pos
         return idx ^ (((idx >> S) & ((1 << (S - 4)) - 1)) << 4)
 
     def get_local(self, lo, hi):
@@ -241,14 +269,32 @@ class Vec:
             self.array[self.positions(torch.arange(lo, hi, device=self.array.device))] = values
 
     def local_natural(self):
-        """This rank's block in index order (a new device tensor when the layout is swizzled)."""
+        """This rank's block in index order (a new device tensor when the layout is not index order)."""
         import torch
         if not self.swz:
             return self.array
+        if self.internal:
+            out = torch.empty(self.rows, dtype=self.array.dtype, device=self.array.device)
+            _lib.check(_lib.lib().dnm_vec_layout_copy(C.byref(self.sub_c), C.c_void_p(out.data_ptr()), self.ptr, 0,
+                                                      _stream()))
+            return out
         out = torch.empty_like(self.array)
         _lib.check(_lib.lib().dnm_vec_swizzle_copy(C.c_void_p(out.data_ptr()), self.ptr, self.local_size,
                                                    self.swz, _stream()))
         return out
+
+    def set_local_natural(self, t):
+        """Fill this rank's block from a device tensor in index order."""
+        if self.internal:
+            t = t.contiguous()
+            _lib.check(_lib.lib().dnm_vec_layout_copy(C.byref(self.sub_c), self.ptr, C.c_void_p(t.data_ptr()), 1,
+                                                      _stream()))
+        else:
+            self.set_local(0, self.rows, t)
+
+    def _zero_padding(self):
+        if self.internal:
+            _lib.check(_lib.lib().dnm_vec_layout_zero_padding(C.byref(self.sub_c), self.ptr, _stream()))
 
     # -- petsc4py.Vec-like surface -------------------------------------------
     def getSize(self):
@@ -258,7 +304,7 @@ class Vec:
         return self.local_size
 
     def getOwnershipRange(self):
-        return self.start, self.start + self.local_size
+        return self.start, self.start + self.rows
 
     @property
     def ptr(self):
@@ -267,10 +313,12 @@ class Vec:
     def set(self, value):
         v = complex(value)
         _lib.check(_lib.lib().dnm_vec_set(self.ptr, self.local_size, v.real, v.imag, _stream()))
+        if v != 0:
+            self._zero_padding()
 
     def copy(self, result=None):
         if result is None:
-            result = Vec(self.size, swz=self.swz)
+            result = Vec(self.size, swz=self.swz, sub_c=self.sub_c)
         if result.swz != self.swz:
             raise ValueError('vectors of different layouts')
         _lib.check(_lib.lib().dnm_vec_copy(self.ptr, result.ptr, self.local_size, _stream()))
@@ -315,8 +363,13 @@ class Vec:
 
     def shift(self, alpha):
         self.array += complex(alpha)
+        self._zero_padding()
 
     def set_random(self, seed):
+        if self.internal:
+            _lib.check(_lib.lib().dnm_vec_layout_set_random(C.byref(self.sub_c), self.ptr, seed & (2 ** 64 - 1),
+                                                            _stream()))
+            return
         _lib.check(_lib.lib().dnm_vec_set_random_swz(self.ptr, self.local_size, seed & (2 ** 64 - 1),
                                                      self.start, self.swz, _stream()))
 
@@ -325,9 +378,12 @@ class Vec:
     def set_local_from_numpy(self, arr):
         import torch
         arr = np.ascontiguousarray(arr, dtype=np.complex128)
-        assert arr.size == self.local_size
+        assert arr.size == self.rows
         if not self.swz:
             self.array.copy_(torch.from_numpy(arr))
+            return
+        if self.internal:
+            self.set_local_natural(torch.from_numpy(arr).to(self.array.device))
             return
         for lo in range(0, self.local_size, self._CHUNK):      # chunked: no second full-size device buffer
             hi = min(self.local_size, lo + self._CHUNK)
@@ -336,7 +392,7 @@ class Vec:
     def local_numpy(self):
         if not self.swz:
             return self.array.cpu().numpy()
-        if self.local_size <= self._CHUNK:
+        if self.local_size <= self._CHUNK or self.internal:
             return self.local_natural().cpu().numpy()
         out = np.empty(self.local_size, dtype=np.complex128)
         for lo in range(0, self.local_size, self._CHUNK):
@@ -378,7 +434,11 @@ class ShellMat:
         M, N, m, n = (C.c_int64() for _ in range(4))
         _lib.check(_lib.lib().dnm_mat_sizes(handle, C.byref(M), C.byref(N), C.byref(m), C.byref(n)))
         self.M, self.N, self.m_local, self.n_local = M.value, N.value, m.value, n.value
-        self.swz_left, self.swz_right = int(left_c.vec_swizzle), int(right_c.vec_swizzle)   # layouts of y and x
+        # layouts of y and x the matrix works in: the descriptors' where it supports them (Full / Parity swizzle, the
+        # SpinConserve internal layout of a same-subspace pair on one rank), reference order otherwise
+        ll, lr = C.c_int(), C.c_int()
+        _lib.check(_lib.lib().dnm_mat_layouts(handle, C.byref(ll), C.byref(lr)))
+        self.swz_left, self.swz_right = ll.value, lr.value
         self.sends, self.recvs = exchange_plan(handle)
         self.partners = sorted({r[0] for r in self.recvs})
         self._recv = {}
@@ -401,7 +461,24 @@ class ShellMat:
         return self.M, self.N
 
     def createVecs(self):
-        return Vec(self.N, swz=self.swz_right), Vec(self.M, swz=self.swz_left)
+        return (Vec(self.N, swz=self.swz_right, sub_c=self._keep[1]), Vec(self.M, swz=self.swz_left, sub_c=self._keep[0]))
+
+    def _mult_converted(self, x, y):
+        """A vector in the SpinConserve internal layout meets a matrix that works in reference order (a projection
+        onto / from another subspace, XParity ...): multiply on reference-order copies."""
+        xn, yn = x, y
+        if x.swz != self.swz_right:
+            if not (x.internal and self.swz_right == 0):
+                return False
+            xn = Vec(x.size, array=x.local_natural(), swz=0)
+        if y.swz != self.swz_left:
+            if not (y.internal and self.swz_left == 0):
+                return False
+            yn = Vec(y.size, swz=0)
+        self.mult(xn, yn)
+        if yn is not y:
+            y.set_local_natural(yn.array)
+        return True
 
     def describe(self):
         buf = C.create_string_buffer(8192)
@@ -415,6 +492,8 @@ class ShellMat:
         L = _lib.lib()
         if x.array.data_ptr() == y.array.data_ptr():
             raise ValueError('x and y must be different vectors')
+        if (x.swz != self.swz_right or y.swz != self.swz_left) and self._mult_converted(x, y):
+            return
         self.check_layout(x, y)
         if self._tr is not None:
             return self._mult_transposed(x, y)
@@ -609,7 +688,7 @@ class ShellMat:
         """True for the kernels that read a cached diagonal: the SpinConserve kernel (also
         partitioned) and the generic row-gather kernel on one rank."""
         d = self.describe()
-        if 'SpinConserve kernel' in d:
+        if 'SpinConserve kernel' in d or 'SpinConserve row kernel' in d or 'diagonal cached' in d:
             return True
         return 'row-gather kernel' in d
 
@@ -822,7 +901,13 @@ def reduced_density_matrix(vec, subspace, keep):
         sub_c = _lib.Subspace.from_buffer_copy(subspace['data'])
         sub_c.vec_swizzle = 0
         return rdm_partial(x, sub_c, keep).cpu().numpy().reshape(K, K)
-    return rdm_partial(x, subspace['data'], keep).cpu().numpy().reshape(K, K)
+    sub_c = subspace['data']
+    if vec.internal:
+        # the kernel gathers by reference index: hand it the state in that order
+        x = vec.local_natural()
+        sub_c = _lib.Subspace.from_buffer_copy(sub_c)
+        sub_c.vec_swizzle = 0
+    return rdm_partial(x, sub_c, keep).cpu().numpy().reshape(K, K)
 
 
 def precompute_diagonal(mat):

@@ -223,6 +223,7 @@ def eigsolve(H, getvecs=False, nev=1, which='lowest', target=None, tol=None, sub
     # one extremal pair of a large operator: the native driver runs Lanczos without a stored basis (four work
     # vectors; DNM_EIGS_BASISFREE=0/1 forces the choice) -- nothing to fit into memory then
     import os
+    ncv_native = 0 if ncv is None else int(ncv)
     bf = knob('DNM_EIGS_BASISFREE')
     basis_free = (ncv is None and nev == 1 and mat.N > 64 and
                   (bf[:1] == '1' if bf else _min_over_ranks(mat.n_local) >= (1 << 22)))
@@ -244,7 +245,9 @@ def eigsolve(H, getvecs=False, nev=1, which='lowest', target=None, tol=None, sub
                 raise RuntimeError('not enough device memory for a Krylov basis: %d vectors of %.1f GiB fit, '
                                    'eigsolve(nev=%d) needs at least %d' % (max(fit, 0), vec_bytes / 2 ** 30, nev,
                                                                             nev + 2))
-            ncv = fit
+            # the default basis, capped at what fits (fit + 1 vectors in all): the native driver keeps its automatic
+            # choices -- a Chebyshev filter for several pairs of a large operator -- inside that budget
+            ncv_native = -(fit + 1)
     evals = np.zeros(nev_max, dtype=np.float64)
     evec_buf = None
     if getvecs:
@@ -253,7 +256,7 @@ def eigsolve(H, getvecs=False, nev=1, which='lowest', target=None, tol=None, sub
     stats = _lib.SolverStats()
     _lib.check(_lib.lib().dnm_eigsolve(
         mat.handle, mat.n_local, int(nev), _lib.WHICH[which], 0.0 if tol is None else float(tol),
-        0 if ncv is None else int(ncv), 0 if max_its is None else int(max_its), int(seed),
+        ncv_native, 0 if max_its is None else int(max_its), int(seed),
         C.byref(hooks) if hooks is not None else None, nev_max, _lib.pf64(evals),
         C.c_void_p(evec_buf.data_ptr()) if evec_buf is not None else None, C.byref(stats), _stream()))
     eigsolve.last_stats = {'reason': stats.reason, 'its': stats.its, 'matvecs': stats.matvecs,
@@ -278,7 +281,8 @@ def eigsolve(H, getvecs=False, nev=1, which='lowest', target=None, tol=None, sub
     for i in range(nconv):
         v = State(L=H.L, subspace=subspace)
         # (views of one buffer: no second copy of the vectors)
-        v._vec = Vec(mat.N, array=evec_buf[i * mat.n_local:(i + 1) * mat.n_local], swz=mat.swz_right)
+        v._vec = Vec(mat.N, array=evec_buf[i * mat.n_local:(i + 1) * mat.n_local], swz=mat.swz_right,
+                     sub_c=mat._keep[1])
         v.set_initialized()
         evecs.append(v)
     return vals, evecs

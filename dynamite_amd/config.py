@@ -30,6 +30,13 @@ class _Config:
         # dnm_subspace.vec_swizzle); 0 = index order.  16 measured best on MI355X (profiles/r02_exp1_swz.txt).
         # Fixed for the life of the process: vectors and matrices built under different values do not mix.
         self.vec_swizzle = int(knob('DNM_SWZ', '16'))
+        # layout of SpinConserve state vectors on one rank: (a, w) = low bits / window bits of the three-field
+        # internal layout (csrc/sc3.h) the two-pass SpinConserve multiply works in, or None for reference order;
+        # used from sc_layout_min_dim states on (smaller subspaces keep reference order and the row kernels).
+        # (14, 10): 55 KB and 63 KB LDS tiles, two workgroups per CU (profiles/r03_exp3_sc3_v2.txt).
+        lay = knob('DNM_SC_LAYOUT', '14,10')
+        self.sc_layout = None if lay in ('0', '') else tuple(int(v) for v in lay.split(','))
+        self.sc_layout_min_dim = 1 << 22
 
     # -- L / subspace / shell: same validation as the reference --------------
     @property

@@ -161,14 +161,82 @@ static void jacobi_eig(int n, std::vector<double> &A, std::vector<double> &w, st
 // ---------------------------------------------------------------------------
 // distributed plumbing
 // ---------------------------------------------------------------------------
+// Chebyshev filter p(A) = T_d((A - c) / h) / T_d((ref - c) / h): on the interval [c - h, c + h] |p| <= 1 / |T_d(ref)|,
+// outside it p grows exponentially with the distance -- Lanczos on p(A) sees the few eigenvalues beyond one end of
+// the interval as huge, well separated ones.  Evaluated by the three-term recurrence on unnormalised vectors
+// s_j = h^j T_j: s_{j+1} = 2 (A - c) s_j - h^2 s_{j-1} (s_1 = (A - c) s_0), every term ONE fused multiply
+// y = A x - b z + c2 z2 (dnm_mat_mult_sub2); the scale that brings s_d back to O(1) is known on the host.
+// seeded start vector in the layout of A's vectors (padding of an internal SpinConserve layout stays zero)
+static int random_start(dnm_mat *A, void *x, int64_t n_local, uint64_t seed, int64_t offset, hipStream_t st) {
+  if (A->use_sc3) return sc3_random(*A->sc3->ly, x, seed, st);
+  return vk_random(x, n_local, seed, offset, st, A->right.host.swz);
+}
+
+struct ChebFilter {
+  int d = 0;
+  double c = 0, h = 0, ref = 0;
+  void *ta = nullptr, *tb = nullptr;       // two work vectors
+  bool on = false;
+  double log_tref() const {                // log |T_d((ref - c) / h)|
+    const double at = std::fabs((ref - c) / h);
+    return at > 1.0 ? d * std::log(at + std::sqrt(at * at - 1.0)) - std::log(2.0) : 0.0;
+  }
+  // A Ritz pair (mu, absolute residual res_p) of p(A) seen from A: mu = p(lambda) inverted on the wanted side and
+  // the residual divided by the slope |p'(lambda)| -- what the residual in A is when the error lies along
+  // neighbouring eigenvectors (components deep inside the damped interval count with |mu| / 2h instead; the
+  // measured residual decides in the end).  Returns the relative residual estimate, *lam the eigenvalue estimate.
+  double seen_from_a(double mu, double res_p, bool low_side, double *lam) const {
+    const double a = std::fabs(mu) * std::exp(log_tref());
+    if (!(a > 1.0)) { *lam = c; return 1e300; }              // inside the damped interval: not a wanted pair
+    const double th = std::acosh(a) / d;
+    *lam = low_side ? c - h * std::cosh(th) : c + h * std::cosh(th);
+    const double slope = d * std::tanh(d * th) / (h * std::sinh(th)) * std::fabs(mu);
+    return res_p / slope / std::max(std::fabs(*lam), 1e-300);
+  }
+};
+
 struct Ops {
   dnm_mat *A;
   const dnm_hooks *hooks;
   hipStream_t st;
   int64_t n;
   int matvecs = 0;
+  ChebFilter *flt = nullptr;
+
+  // y = A x - b z + c2 x, the filter's step (z may be null when b == 0); 2 A x is avoided by halving the
+  // recurrence: u_j = s_j / 2^(j-1)  =>  u_{j+1} = (A - c) u_j - (h/2)^2 u_{j-1}, u_1 = (A - c) u_0, u_2 = (A - c) u_1 - (h^2/2) u_0
+  int filter_step(const void *x, void *y, const void *z, double b, double c2) {
+    if (hooks && hooks->mult) {
+      ++matvecs;
+      DNM_CHECK(hooks->mult(hooks->ctx, x, y) == 0, "mult hook failed");
+      if (b != 0.0) DNM_TRY(vk_axpby(y, z, n, -b, 0.0, 1.0, 0.0, st));
+      return vk_axpby(y, x, n, c2, 0.0, 1.0, 0.0, st);
+    }
+    ++matvecs;
+    return dnm_mat_mult_sub2(A, x, y, z ? z : x, b, x, c2, 0.0, (void *)st);
+  }
+  // y = p(A) x; y must differ from x and from the two work vectors
+  int apply_filter(const void *x, void *y) {
+    const ChebFilter &F = *flt;
+    // rotate through {ta, tb, y} so that the last term lands in y
+    void *buf[3] = {F.ta, F.tb, y};
+    const int first = (3 - (F.d % 3)) % 3;              // index of the buffer that takes u_1
+    // u_j goes to buf[(first + j - 1) % 3]: u_d -> (first + d - 1) % 3 == 2
+    const void *um = nullptr, *uc = x;
+    for (int j = 1; j <= F.d; ++j) {
+      void *out = buf[(first + j - 1) % 3];
+      const double b = j == 1 ? 0.0 : (j == 2 ? 0.5 * F.h * F.h : 0.25 * F.h * F.h);
+      DNM_TRY(filter_step(uc, out, um, b, -F.c));
+      um = uc;
+      uc = out;
+    }
+    // u_d = h^d T_d / 2^(d-1); normalise by the value at the reference point so that the wanted end is O(1..)
+    const double logscale = -(F.d * std::log(F.h) - (F.d - 1) * std::log(2.0)) - F.log_tref();
+    return vk_scale(y, n, std::exp(logscale), 0, st);
+  }
 
   int mult(const void *x, void *y) {
+    if (flt && flt->on) return apply_filter(x, y);
     ++matvecs;
     if (hooks && hooks->mult) {
       DNM_CHECK(hooks->mult(hooks->ctx, x, y) == 0, "mult hook failed");
@@ -180,7 +248,7 @@ struct Ops {
   // Lanczos step
   int mult_dot(const void *x, void *y, zc *d, const void *z = nullptr, double b = 0.0, double *nn = nullptr) {
     double buf[3];
-    if (hooks && hooks->mult) {
+    if ((flt && flt->on) || (hooks && hooks->mult)) {
       DNM_TRY(mult(x, y));
       DNM_TRY(vec_lanczos_dot_host(y, z, x, n, b, buf, st));
       DNM_TRY(sum(buf, 3));
@@ -696,7 +764,6 @@ static int eigsolve_basis_free(Ops &ops, dnm_mat *A, int64_t n_local, int which,
   void *W = nullptr;
   DNM_TRY(basis_workspace((size_t)4 * (size_t)n_local * 16, &W));
   const int64_t offset = hooks ? A->row0 : 0;
-  const int vswz = A->right.host.swz;
   std::vector<double> al, be, svec;
   struct Step { double are, aim, s1, s2; };      // what the update of a step did, so that the second run repeats it
   std::vector<Step> rec;
@@ -707,7 +774,7 @@ static int eigsolve_basis_free(Ops &ops, dnm_mat *A, int64_t n_local, int which,
   // start vector: seeded normal deviates, or (later rounds) the Ritz vector of the round before, kept in `evecs`
   auto start = [&](bool from_prev) -> int {
     if (from_prev) return vk_axpby(slot(0), evecs, n_local, 1.0, 0.0, 0.0, 0.0, st);
-    DNM_TRY(vk_random(slot(0), n_local, seed, offset, st, vswz));
+    DNM_TRY(random_start(A, slot(0), n_local, seed, offset, st));
     double n0 = 0;
     DNM_TRY(ops.norm(slot(0), &n0));
     DNM_CHECK(n0 > 0, "zero start vector");
@@ -1157,7 +1224,11 @@ int dnm_eigsolve(dnm_mat *A, int64_t n_local, int nev, int which, double tol, in
   stats->reason = 0; stats->its = 0; stats->matvecs = 0; stats->nconv = 0; stats->err_est = 0;
   const int64_t Nglob = A->N;
   if (tol <= 0) tol = 1e-8;
+  // ncv < 0: the default basis, but at most -ncv vectors in all (what fits in device memory: the caller's limit)
+  int cap = 0;
+  if (ncv < 0) { cap = -ncv; ncv = 0; }
   int m = ncv > 0 ? ncv : std::max(2 * nev, nev + 15);
+  if (cap > 0 && m + 1 > cap) m = cap - 1;
   if ((int64_t)m > Nglob) m = (int)Nglob;
   {
     double neg = -(double)m;          // the same basis size on every rank (see dnm_expm_multiply)
@@ -1166,6 +1237,7 @@ int dnm_eigsolve(dnm_mat *A, int64_t n_local, int nev, int which, double tol, in
   }
   DNM_CHECK(m >= nev, "ncv smaller than nev");
   if (max_its <= 0) max_its = (int)std::max<int64_t>(100, 2 * Nglob / m);
+  bool filtered = false;
   {
     // one extremal pair of a large operator under default parameters: Lanczos without a stored basis (a step is
     // the multiply plus one sweep; the restarted scheme below spends two thirds of its time on basis traffic at
@@ -1173,31 +1245,128 @@ int dnm_eigsolve(dnm_mat *A, int64_t n_local, int nev, int which, double tol, in
     const char *bf = knob("DNM_EIGS_BASISFREE");
     double negn = -(double)n_local;       // the smallest block decides, so that every rank takes the same path
     DNM_TRY(ops.maxr(&negn, 1));
-    const bool want = bf ? bf[0] == '1' : (-negn >= (double)((int64_t)1 << 22));
+    const bool large = -negn >= (double)((int64_t)1 << 22);
+    const bool want = bf ? bf[0] == '1' : large;
     if (want && nev == 1 && ncv <= 0 && Nglob > 64) {
       const int64_t steps64 = std::min<int64_t>((int64_t)max_its * m, Nglob);
       return eigsolve_basis_free(ops, A, n_local, which, tol, (int)std::min<int64_t>(steps64, 100000), seed, hooks,
                                  evals, evecs, stats, st);
     }
+    // several pairs at one end of the spectrum of a large operator: thick-restart Lanczos on a Chebyshev filter
+    // p(H) -- d fused multiplies per Lanczos vector, so the orthogonalisation and restart traffic per multiply
+    // drops by d (at 4-16 GiB per vector the plain scheme spends 80 % of its time there).  DNM_EIGS_FILTER=0 / 1
+    // forces the choice; an explicit ncv keeps the plain scheme.
+    const char *fe = knob("DNM_EIGS_FILTER");
+    filtered = (fe ? fe[0] == '1' : (large && nev > 1)) && which != DNM_WHICH_EXTERIOR && ncv <= 0 &&
+               Nglob > 8 * (int64_t)m;
+    if (filtered && cap > 0 && m + 3 > cap) {        // the filter's two work vectors come out of the same budget
+      if (cap - 3 >= nev + 2) m = cap - 3;
+      else filtered = false;
+    }
   }
   DNM_CHECK((size_t)(m + 1) * 16 <= 160 * 1024, "ncv too large for the basis-rotation kernel");
 
   void *V = nullptr;
-  DNM_TRY(basis_workspace((size_t)(m + 1) * (size_t)n_local * 16, &V));
+  DNM_TRY(basis_workspace((size_t)(m + 1 + (filtered ? 2 : 0)) * (size_t)n_local * 16, &V));
 
   // start vector: counter-based normal deviates keyed by the global index (the rank's first row: blocks may be
   // uneven, PetscSplitOwnership), written in the vectors' layout
   const int64_t offset = hooks ? A->row0 : 0;
-  const int vswz = A->right.host.swz;
-  DNM_TRY(vk_random(vecptr(V, n_local, 0), n_local, seed, offset, st, vswz));
+  DNM_TRY(random_start(A, vecptr(V, n_local, 0), n_local, seed, offset, st));
   double nrm0 = 0;
   DNM_TRY(ops.norm(vecptr(V, n_local, 0), &nrm0));
   DNM_CHECK(nrm0 > 0, "zero start vector");
   DNM_TRY(vk_scale(vecptr(V, n_local, 0), n_local, 1.0 / nrm0, 0, st));
 
+  ChebFilter flt;
+  int which_p = which;                     // the end of p(H)'s spectrum the wanted pairs sit at
+  double tol_p = tol, tol_h = 0.5 * tol;   // on a filter: its own relative residual / the estimate of H's
+  if (filtered) {
+    // where to cut: a few steps of plain Lanczos (three rotating vectors) give Ritz values theta_i >= lambda_i
+    // (from below at the other end) and the last residual norm; |H|_inf bounds the far end rigorously
+    const int k0 = (int)std::min<int64_t>(Nglob - 1, std::max(40, 10 * nev));
+    std::vector<double> al, be;
+    auto slot = [&](int k) { return (void *)vecptr(V, n_local, k % 3); };
+    for (int j = 0; j < k0; ++j) {
+      void *q = slot(j), *pq = slot(j + 1), *qm = slot(j + 2);
+      zc dd(0);
+      double pn2 = 0;
+      DNM_TRY(ops.mult_dot(q, pq, &dd, j > 0 ? qm : nullptr, j > 0 ? be[j - 1] : 0.0, &pn2));
+      al.push_back(dd.real());
+      double n2 = 0;
+      DNM_TRY(vec_lanczos_update_host(pq, q, nullptr, n_local, dd.real(), dd.imag(), 0.0, &n2, st, 1.0));
+      DNM_TRY(ops.sum(&n2, 1));
+      const double bn = std::sqrt(n2 > 0 ? n2 : 0.0);
+      be.push_back(bn);
+      if (bn <= 1e-12 * (std::fabs(dd.real()) + 1.0)) break;        // invariant subspace: the plain scheme copes
+      DNM_TRY(vk_scale(pq, n_local, 1.0 / bn, 0, st));
+    }
+    const int kk = (int)al.size();
+    const int margin = std::max(2, (nev + 1) / 2);
+    if (kk < nev + margin + 2) {
+      filtered = false;
+    } else {
+      std::vector<double> Tm((size_t)kk * kk, 0.0), wv, Sv;
+      for (int i = 0; i < kk; ++i) {
+        Tm[(size_t)i * kk + i] = al[i];
+        if (i + 1 < kk) Tm[(size_t)(i + 1) * kk + i] = Tm[(size_t)i * kk + i + 1] = be[i];
+      }
+      jacobi_eig(kk, Tm, wv, Sv);
+      std::sort(wv.begin(), wv.end());
+      double nrmH = 0;
+      DNM_TRY(dnm_mat_norm_inf(A, &nrmH, (void *)st));
+      DNM_TRY(ops.maxr(&nrmH, 1));
+      const double blast = be[kk - 1];
+      double a_cut, far, near_t, gam;
+      if (which == DNM_WHICH_LOWEST) {
+        far = std::min(nrmH, wv[kk - 1] + blast);
+        a_cut = wv[nev + margin - 1];
+        near_t = wv[nev - 1];
+        gam = (a_cut - near_t) / (far - a_cut);
+        flt.ref = wv[0];
+        which_p = DNM_WHICH_LOWEST;           // odd degree: p < 0 below the interval, ordered as H
+      } else {
+        far = std::max(-nrmH, wv[0] - blast);
+        a_cut = wv[kk - nev - margin];
+        near_t = wv[kk - nev];
+        gam = (near_t - a_cut) / (a_cut - far);
+        flt.ref = wv[kk - 1];
+        which_p = DNM_WHICH_HIGHEST;
+      }
+      if (!(gam > 1e-9) || !(std::fabs(far - a_cut) > 0)) {
+        filtered = false;                      // no usable gap estimate (degenerate Ritz values): plain scheme
+      } else {
+        // amplification of the nev-th wanted value over the unwanted interval ~ cosh(2 d sqrt(gam)): about 10^3
+        // (a basis that memory keeps short gets a proportionally stronger filter: the number of Lanczos vectors to
+        // convergence falls with the degree, and every restart throws part of the Krylov space away)
+        int d = (int)std::ceil(7.6 / (2.0 * std::sqrt(gam)) * std::max(1.0, 18.0 / m));
+        d = std::max(5, std::min(d, 99));
+        if (const char *de = knob("DNM_EIGS_FILTER_DEGREE")) d = std::max(1, atoi(de));
+        d |= 1;
+        flt.d = d;
+        flt.c = 0.5 * (a_cut + far);
+        flt.h = 0.5 * std::fabs(far - a_cut);
+        flt.ta = vecptr(V, n_local, m + 1);
+        flt.tb = vecptr(V, n_local, m + 2);
+        flt.on = true;
+        ops.flt = &flt;
+        tol_p = 0.25 * tol;
+        if (knob("DNM_KRYLOV_DEBUG"))
+          fprintf(stderr, "dnm_eigsolve (filtered): %d probe steps, cut %.6g, far end %.6g (|H|_inf %.6g), nev-th estimate "
+                  "%.6g, relative gap %.3g, degree %d\n", kk, a_cut, far, nrmH, near_t, gam, d);
+      }
+    }
+    // the probe used the first three slots: the start vector again
+    DNM_TRY(random_start(A, vecptr(V, n_local, 0), n_local, seed, offset, st));
+    DNM_TRY(vk_scale(vecptr(V, n_local, 0), n_local, 1.0 / nrm0, 0, st));
+  }
   std::vector<double> theta, spike;        // kept Ritz values and their coupling to v_l
   std::vector<double> alpha(m, 0.0), betav(m, 0.0);
   int l = 0, its = 0, nconv = 0;
+  int extra_matvecs = 0;
+  int nok = 0;                             // filtered: leading Ritz pairs whose MEASURED residual passes
+  std::vector<double> rq;                  // ... and their Rayleigh quotients in H
+  double worst_true = 0.0;
   std::vector<double> T, w, Sm;
   std::vector<int> order(m);
   std::vector<zc> h;
@@ -1206,14 +1375,15 @@ int dnm_eigsolve(dnm_mat *A, int64_t n_local, int nev, int which, double tol, in
   // DNM_EIGS_ORTHO=full: orthogonalise every Lanczos vector against the whole basis (what SLEPc's
   // Krylov-Schur does); default: partial re-orthogonalisation driven by the omega-recurrence
   const char *oenv = knob("DNM_EIGS_ORTHO");
-  const bool use_pro = !(oenv && oenv[0] == 'f');
+  // (on a filter the basis work is a small share of a step and p(H) has a huge dynamic range: every step in full)
+  const bool use_pro = !(oenv && oenv[0] == 'f') && !filtered;
   // DNM_EIGS_BETA=sweep: beta from a norm sweep after the update (never the fused form); =rescale: always run the
   // corrective rescaling sweep -- both only to exercise the rarely taken branches in tests
   const bool known_off = knob("DNM_EIGS_KNOWN") && knob("DNM_EIGS_KNOWN")[0] == '0';   // A/B switch
   const char *benv = knob("DNM_EIGS_BETA");
   const int beta_mode = !benv ? 0 : (benv[0] == 's' ? 1 : (benv[0] == 'r' ? 2 : 0));
   RestartMonitor mon;
-  mon.init(m, (double)Nglob, tol);
+  mon.init(m, (double)Nglob, filtered ? tol_p : tol);
   std::vector<double> row_l;
   while (true) {
     ++its;
@@ -1275,7 +1445,7 @@ int dnm_eigsolve(dnm_mat *A, int64_t n_local, int nev, int which, double tol, in
       if (bn <= 1e-14 * std::max(1.0, anorm_est)) {
         // invariant subspace: continue with a fresh direction orthogonal to the basis
         betav[j] = 0.0;
-        DNM_TRY(vk_random(p, n_local, seed + 7919u * (uint64_t)(its * m + j + 1), offset, st, vswz));
+        DNM_TRY(random_start(A, p, n_local, seed + 7919u * (uint64_t)(its * m + j + 1), offset, st));
         double rn = 0;
         DNM_TRY(ops.orthogonalize(p, V, j + 1, h, &rn, 2));
         DNM_CHECK(rn > 0, "Lanczos breakdown: could not extend the basis");
@@ -1301,8 +1471,8 @@ int dnm_eigsolve(dnm_mat *A, int64_t n_local, int nev, int which, double tol, in
     jacobi_eig(m, T, w, Sm);
     for (int i = 0; i < m; ++i) order[i] = i;
     std::sort(order.begin(), order.end(), [&](int a, int b) {
-      if (which == DNM_WHICH_LOWEST) return w[a] < w[b];
-      if (which == DNM_WHICH_HIGHEST) return w[a] > w[b];
+      if (which_p == DNM_WHICH_LOWEST) return w[a] < w[b];
+      if (which_p == DNM_WHICH_HIGHEST) return w[a] > w[b];
       return std::fabs(w[a]) > std::fabs(w[b]);
     });
     const double bm = betav[m - 1];
@@ -1310,12 +1480,20 @@ int dnm_eigsolve(dnm_mat *A, int64_t n_local, int nev, int which, double tol, in
     for (int i = 0; i < m; ++i) {
       const int c = order[i];
       const double res = std::fabs(bm * Sm[(size_t)c * m + (m - 1)]);
-      // relative to the eigenvalue (SLEPc EPS_CONV_REL)
-      if (res <= tol * std::max(std::fabs(w[c]), 1e-300)) ++nconv; else break;
+      // relative to the eigenvalue (SLEPc EPS_CONV_REL); on a filter: the residual as H would see it (the measured
+      // residual of the restarted vectors has the last word)
+      bool ok = res <= (filtered ? tol_p : tol) * std::max(std::fabs(w[c]), 1e-300);
+      if (filtered && !ok) {
+        double lam;
+        ok = flt.seen_from_a(w[c], res, which == DNM_WHICH_LOWEST, &lam) <= tol_h;
+      }
+      if (ok) ++nconv; else break;
     }
-    if (nconv >= nev || its >= max_its) break;
+    const bool stop = nconv >= nev || its >= max_its;
+    if (stop && !filtered) break;
     // thick restart: keep the converged pairs plus half of the rest
     int keep = nconv + std::max(1, (m - nconv) / 2);
+    if (filtered && keep < nev) keep = nev;
     if (keep > m - 1) keep = m - 1;
     std::vector<double> Ssel((size_t)2 * m * keep, 0.0);
     theta.assign(keep, 0.0);
@@ -1338,8 +1516,69 @@ int dnm_eigsolve(dnm_mat *A, int64_t n_local, int nev, int which, double tol, in
         for (int k = 0; k < m; ++k) row_l[o] += std::fabs(Sm[(size_t)order[o] * m + k]) * std::fabs(mon.wcur[k]);
     }
     l = keep;
+    if (filtered && stop) {
+      // the filter's estimates say the wanted pairs have converged (or the iteration limit is reached): the kept
+      // Ritz vectors now sit in the first slots -- measure what the contract is about, |H u - <u,Hu> u| / |<u,Hu>|
+      // in H itself (one multiply and one sweep each; the filter's work vectors are free in between)
+      const int nchk = std::min(std::min(keep, nev_max), std::max(nev, nconv));
+      flt.on = false;
+      const int mv0 = ops.matvecs;
+      rq.assign(nchk, 0.0);
+      nok = 0;
+      worst_true = 0.0;
+      bool chain = true;
+      for (int o = 0; o < nchk; ++o) {
+        void *u = vecptr(V, n_local, o), *hu = flt.ta;
+        zc dd(0);
+        DNM_TRY(ops.mult_dot(u, hu, &dd));
+        double n2 = 0;
+        DNM_TRY(vec_lanczos_update_host(hu, u, nullptr, n_local, dd.real(), dd.imag(), 0.0, &n2, st));
+        DNM_TRY(ops.sum(&n2, 1));
+        rq[o] = dd.real();
+        const double rel = std::sqrt(n2 > 0 ? n2 : 0.0) / std::max(std::fabs(rq[o]), 1e-300);
+        if (chain && rel <= tol) { ++nok; worst_true = std::max(worst_true, rel); }
+        else {
+          if (chain && o < nev) worst_true = std::max(worst_true, rel);
+          chain = false;
+        }
+      }
+      extra_matvecs += ops.matvecs - mv0;
+      ops.matvecs = mv0;
+      flt.on = true;
+      if (knob("DNM_KRYLOV_DEBUG"))
+        fprintf(stderr, "dnm_eigsolve (filtered): restart %d, %d pairs converged on the filter (tol %.1e, estimate for H "
+                "%.1e), %d pass in H (worst of the wanted %.2e)\n", its, nconv, tol_p, tol_h, nok, worst_true);
+      if (nok >= nev || its >= max_its) break;
+      // the estimates were satisfied too early: ask for more, by what the measurement missed
+      const double f = std::max(1e-3, std::min(0.3, 0.3 * tol / std::max(worst_true, 1e-300)));
+      tol_p *= f;
+      tol_h *= f;
+    }
   }
 
+  if (filtered) {
+    // the Ritz vectors are in place (thick restart) and measured in H: ordered by their Rayleigh quotients
+    flt.on = false;
+    const int nout = std::min(nok, nev_max);
+    std::vector<int> ord(nout);
+    for (int i = 0; i < nout; ++i) ord[i] = i;
+    std::sort(ord.begin(), ord.end(), [&](int a, int b) { return which == DNM_WHICH_LOWEST ? rq[a] < rq[b] : rq[a] > rq[b]; });
+    for (int i = 0; i < nout; ++i) evals[i] = rq[ord[i]];
+    if (evecs)
+      for (int i = 0; i < nout; ++i)
+        DNM_HIP(hipMemcpyAsync((char *)evecs + (size_t)i * (size_t)n_local * 16, vecptr(V, n_local, ord[i]),
+                               (size_t)n_local * 16, hipMemcpyDeviceToDevice, st));
+    if (knob("DNM_KRYLOV_DEBUG"))
+      fprintf(stderr, "dnm_eigsolve (filtered): %d restarts, %d matvecs (+%d for the checks), degree %d, largest true "
+              "relative residual %.2e\n", its, ops.matvecs, extra_matvecs, flt.d, worst_true);
+    DNM_HIP(hipStreamSynchronize(st));
+    stats->its = its;
+    stats->matvecs = ops.matvecs;
+    stats->nconv = nout;
+    stats->err_est = worst_true;
+    stats->reason = (nout >= nev) ? DNM_CONVERGED_TOL : DNM_DIVERGED_ITS;
+    return 0;
+  }
   const int nout = std::min(nconv, nev_max);
   for (int i = 0; i < nout; ++i) evals[i] = w[order[i]];
   if (nout > 0) {

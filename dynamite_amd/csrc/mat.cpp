@@ -53,6 +53,13 @@ static int view_from_c(const dnm_subspace *s, SubView *v) {
   v->rmap_indices = s->rmap_indices;
   v->rmap_states = s->rmap_states;
   v->swz = s->vec_swizzle;
+  v->sc3 = 0;
+  if (s->type == DNM_SPIN_CONSERVE && v->swz != 0) {       // the internal layout of sc3.h: a | w << 8
+    v->sc3 = v->swz;
+    v->swz = 0;
+    DNM_CHECK(sc3_valid((int)s->L, (int)s->k, sc3_code_a(v->sc3), sc3_code_w(v->sc3)),
+              "vec_swizzle %d: no such SpinConserve layout for L=%d k=%d", v->sc3, (int)s->L, (int)s->k);
+  }
   DNM_CHECK(v->swz == 0 || ((s->type == DNM_FULL || s->type == DNM_PARITY) && v->swz >= 5 && v->swz <= 24),
             "vec_swizzle %d: swizzled vectors need a Full or Parity subspace and a shift in [5, 24]", v->swz);
   if (s->type == DNM_PARITY) DNM_CHECK(s->space == 0 || s->space == 1, "parity space must be 0 or 1");
@@ -718,21 +725,17 @@ int dnm_mat_create(int64_t nmasks, const int64_t *masks, const int64_t *mask_off
     A->row0 = (int64_t)A->rank * q + std::min<int64_t>(A->rank, rem);
     const int64_t qn = A->N / A->nranks, remn = A->N % A->nranks;
     A->n_local = qn + (A->rank < remn ? 1 : 0);
+    A->rows_local = A->m_local;
   }
+  // SpinConserve pair whose vectors are in the internal layout: the two-pass / row kernels of sc3_kernels.hip.  Any
+  // other use of such a subspace (another partner, XParity, several ranks) works in reference order: the caller
+  // converts (dnm_mat_layouts tells).
+  A->use_sc3 = A->sc_pair && A->left.host.sc3 != 0 && A->left.host.sc3 == A->right.host.sc3 && A->nranks == 1 &&
+               !A->xparity && A->left.host.L == A->right.host.L;
 
-  // tables for the generic kernels (always: norm and diagonal use them)
-  if (!A->host_only) {
-  DNM_TRY(A->d_masks.upload(A->masks.data(), A->masks.size() * 8));
-  DNM_TRY(A->d_offsets.upload(A->mask_offsets.data(), A->mask_offsets.size() * 8));
-  DNM_TRY(A->d_signs.upload(A->signs.data(), A->signs.size() * 8));
-  DNM_TRY(A->d_rcoeffs.upload(A->real_coeffs.data(), A->real_coeffs.size() * 8));
-  A->dmsc.nmasks = (int32_t)nmasks;
-  A->dmsc.masks = (const int64_t *)A->d_masks.p;
-  A->dmsc.mask_offsets = (const int64_t *)A->d_offsets.p;
-  A->dmsc.signs = (const int64_t *)A->d_signs.p;
-  A->dmsc.real_coeffs = (const double *)A->d_rcoeffs.p;
+  std::vector<ScMask> scm;
   if (lt == DNM_SPIN_CONSERVE && rt == DNM_SPIN_CONSERVE) {
-    std::vector<ScMask> scm((size_t)nmasks);
+    scm.resize((size_t)nmasks);
     for (int64_t mi = 0; mi < nmasks; ++mi) {
       ScMask &e = scm[mi];
       memset(&e, 0, sizeof(e));
@@ -757,6 +760,19 @@ int dnm_mat_create(int64_t nmasks, const int64_t *masks, const int64_t *mask_off
         (imag ? e.dn_im : e.dn_re) += dn;
       }
     }
+  }
+  // tables for the generic kernels (always: norm and diagonal use them)
+  if (!A->host_only) {
+  DNM_TRY(A->d_masks.upload(A->masks.data(), A->masks.size() * 8));
+  DNM_TRY(A->d_offsets.upload(A->mask_offsets.data(), A->mask_offsets.size() * 8));
+  DNM_TRY(A->d_signs.upload(A->signs.data(), A->signs.size() * 8));
+  DNM_TRY(A->d_rcoeffs.upload(A->real_coeffs.data(), A->real_coeffs.size() * 8));
+  A->dmsc.nmasks = (int32_t)nmasks;
+  A->dmsc.masks = (const int64_t *)A->d_masks.p;
+  A->dmsc.mask_offsets = (const int64_t *)A->d_offsets.p;
+  A->dmsc.signs = (const int64_t *)A->d_signs.p;
+  A->dmsc.real_coeffs = (const double *)A->d_rcoeffs.p;
+  if (lt == DNM_SPIN_CONSERVE && rt == DNM_SPIN_CONSERVE) {
     A->sc_nfast = 0;
     for (const ScMask &e : scm) A->sc_nfast += e.fast ? 1 : 0;
     DNM_TRY(A->d_scmasks.upload(scm.data(), scm.size() * sizeof(ScMask)));
@@ -771,8 +787,18 @@ int dnm_mat_create(int64_t nmasks, const int64_t *masks, const int64_t *mask_off
     for (int v = 0; v < 65536; ++v) low[fill[__builtin_popcount(v)]++] = (uint16_t)v;
     DNM_TRY(A->d_sclow.upload(low.data(), low.size() * sizeof(uint16_t)));
     A->sclow.tab = (const uint16_t *)A->d_sclow.p;
-    DNM_TRY(setup_sc_block(A.get()));
+    if (!A->use_sc3) DNM_TRY(setup_sc_block(A.get()));
   }
+  }
+  if (A->use_sc3) {
+    const SubView &h = A->left.host;
+    const Sc3Layout *ly = sc3_get(h.L, h.k, sc3_code_a(h.sc3), sc3_code_w(h.sc3), !A->host_only);
+    DNM_CHECK(ly, "could not build the SpinConserve vector layout");
+    A->sc3.reset(new Sc3Mat());
+    DNM_TRY(A->sc3->init(ly, A->masks, A->mask_offsets, A->signs, A->real_coeffs, scm, !A->host_only));
+    if (const char *e = knob("DNM_SC3_TILED")) if (e[0] == '0') A->sc3->tiled = false;     // tests: the row kernel
+    if (const char *e = knob("DNM_SC3_DIAG")) if (e[0] == 'c' && A->sc3->diag_mode == 2) A->sc3->diag_mode = 1;
+    A->m_local = A->n_local = ly->host.nint;
   }
 
   if (A->hypercube) {
@@ -853,6 +879,35 @@ int dnm_mat_sizes(const dnm_mat *A, int64_t *M, int64_t *N, int64_t *m_local, in
   return 0;
 }
 
+int dnm_mat_layouts(const dnm_mat *A, int *left, int *right) {
+  DNM_CHECK(A, "null matrix");
+  if (left) *left = A->use_sc3 ? A->left.host.sc3 : A->left.host.swz;
+  if (right) *right = A->use_sc3 ? A->right.host.sc3 : A->right.host.swz;
+  return 0;
+}
+
+// y = A x (- b z + c z2) in the SpinConserve internal layout; dot3 != null: the fused sums (device partials reduced here)
+static int sc3_mult(dnm_mat *A, const void *x, void *y, const void *z, double b, const void *z2, double c_re, double c_im,
+                    double *dot3_host, void *stream) {
+  Sc3Call call;
+  call.zinit = (const double2 *)z;
+  call.zscale = b;
+  call.zinit2 = (const double2 *)z2;
+  call.z2re = c_re;
+  call.z2im = c_im;
+  const double *dg = A->have_diag ? (const double *)A->diag.p : nullptr;
+  if (!dot3_host) return launch_sc3(*A->sc3, A->dmsc, call, dg, x, y, S(stream));
+  const size_t nwg = sc3_dot_partials(*A->sc3);
+  double *part = nullptr;
+  DNM_TRY(vec_scratch((nwg + 1) * 3 * sizeof(double), &part));
+  call.dot_out = part;
+  DNM_TRY(launch_sc3(*A->sc3, A->dmsc, call, dg, x, y, S(stream)));
+  DNM_TRY(vk_reduce_partials(part, (int)nwg, 3, part + 3 * nwg, S(stream)));
+  DNM_HIP(hipMemcpyAsync(dot3_host, part + 3 * nwg, 3 * sizeof(double), hipMemcpyDeviceToHost, S(stream)));
+  DNM_HIP(hipStreamSynchronize(S(stream)));
+  return 0;
+}
+
 int dnm_mat_precompute_diagonal(dnm_mat *A, void *stream) {
   DNM_CHECK(A && !A->host_only, "null or host-only matrix");
   // only when the first mask is the identity (bpetsc_template_1.c:177-180) and
@@ -861,6 +916,17 @@ int dnm_mat_precompute_diagonal(dnm_mat *A, void *stream) {
   DNM_CHECK(A->nranks == 1 || !(A->hypercube && A->plan.use_tiled),
             "precomputed diagonal is not used by the partitioned tiled multiply");
   DNM_CHECK(A->M == A->N, "precompute_diagonal needs a square matrix");
+  if (A->use_sc3) {
+    // computed row by row in reference order, kept in the vectors' layout
+    DevBuf nat;
+    DNM_TRY(nat.alloc((size_t)A->rows_local * sizeof(double)));
+    DNM_TRY(launch_diag(A->dmsc, A->right.dev, A->rows_local, A->row0, (double *)nat.p, S(stream)));
+    DNM_TRY(A->diag.alloc((size_t)A->m_local * sizeof(double)));
+    DNM_TRY(sc3_layout_copy_f64(*A->sc3->ly, (double *)A->diag.p, (const double *)nat.p, true, S(stream)));
+    DNM_HIP(hipStreamSynchronize(S(stream)));      // `nat` is released on return
+    A->have_diag = true;
+    return 0;
+  }
   DNM_TRY(A->diag.alloc((size_t)A->m_local * sizeof(double)));
   DNM_TRY(launch_diag(A->dmsc, A->right.dev, A->m_local, A->row0, (double *)A->diag.p, S(stream)));
   A->have_diag = true;
@@ -869,6 +935,12 @@ int dnm_mat_precompute_diagonal(dnm_mat *A, void *stream) {
 
 int dnm_mat_get_diagonal(dnm_mat *A, double *diag_host, void *stream) {
   DNM_CHECK(A && A->have_diag, "no precomputed diagonal");
+  if (A->use_sc3) {       // handed out in reference order (row r of the matrix)
+    DevBuf nat;
+    DNM_TRY(nat.alloc((size_t)A->rows_local * sizeof(double)));
+    DNM_TRY(sc3_layout_copy_f64(*A->sc3->ly, (double *)nat.p, (const double *)A->diag.p, false, S(stream)));
+    return dnm_memcpy_d2h(diag_host, nat.p, (size_t)A->rows_local * sizeof(double), stream);
+  }
   return dnm_memcpy_d2h(diag_host, A->diag.p, (size_t)A->m_local * sizeof(double), stream);
 }
 
@@ -894,6 +966,7 @@ int dnm_mat_mult_local(dnm_mat *A, const void *x, void *y, void *stream) {
     return 0;
   }
   DNM_CHECK(A->nranks == 1, "this subspace pair cannot run partitioned (use dnm_mat_mult_window)");
+  if (A->use_sc3) return sc3_mult(A, x, y, nullptr, 0.0, nullptr, 0.0, 0.0, nullptr, stream);
   if (A->sc_pair) return launch_sc(A, 0, A->N, x, y, stream);
   return launch_gather_matvec(A->dmsc, A->left.dev, A->right.dev, A->M,
                               A->have_diag ? (const double *)A->diag.p : nullptr, x, y, S(stream));
@@ -907,6 +980,11 @@ int dnm_mat_mult_lanczos(dnm_mat *A, const void *x, void *y, const void *z, doub
   DNM_CHECK(A->remote_passes.empty(), "operator couples different ranks: no fused Lanczos step");
   DNM_CHECK(z != y && x != y, "y must not alias x or z");
   const bool tiled = A->hypercube && A->plan.use_tiled && !A->local_passes.empty() && !A->host_only;
+  if (A->use_sc3 && !A->host_only) {
+    if (A->sc3->tiled) return sc3_mult(A, x, y, z, b, nullptr, 0.0, 0.0, dot, stream);
+    DNM_TRY(sc3_mult(A, x, y, z, b, nullptr, 0.0, 0.0, nullptr, stream));       // the row kernel takes the start vector
+    return vec_lanczos_dot_host(y, nullptr, x, A->m_local, 0.0, dot, S(stream));
+  }
   if (!tiled && A->sc_pair && A->scblock.lb && A->nranks == 1 && !A->host_only) {
     // SpinConserve block kernel: the beta term starts the accumulators, the sums are taken while the block of x
     // is still in LDS
@@ -949,6 +1027,7 @@ int dnm_mat_mult_lanczos(dnm_mat *A, const void *x, void *y, const void *z, doub
 int dnm_mat_fuses_init(const dnm_mat *A) {
   if (!A || A->host_only || !A->remote_passes.empty()) return 0;
   if (A->hypercube && A->plan.use_tiled && !A->local_passes.empty()) return 1;
+  if (A->use_sc3) return 1;
   return (A->sc_pair && A->scblock.lb && A->nranks == 1) ? 1 : 0;
 }
 
@@ -975,6 +1054,7 @@ int dnm_mat_mult_sub2(dnm_mat *A, const void *x, void *y, const void *z, double 
     }
     return 0;
   }
+  if (A->use_sc3) return sc3_mult(A, x, y, z, b, z2, c_re, c_im, nullptr, stream);
   if (A->sc_pair && A->scblock.lb && A->nranks == 1)
     return launch_sc_block(A->dmsc, (const ScMask *)A->d_scmasks.p, A->scblock, A->right.dev, A->m_local, A->row0, 0,
                            A->N, A->have_diag ? (const double *)A->diag.p : nullptr, x, y, S(stream), z, b, nullptr,
@@ -1111,9 +1191,9 @@ int dnm_mat_norm_inf(dnm_mat *A, double *nrm, void *stream) {
     *nrm = A->nrm;
     return 0;
   }
-  const int nb = norm_num_blocks(A->m_local);
+  const int nb = norm_num_blocks(A->rows_local);
   DNM_TRY(A->scratch.alloc((size_t)nb * sizeof(double)));
-  DNM_TRY(launch_norm(A->dmsc, A->left.dev, A->right.dev, A->m_local, A->row0,
+  DNM_TRY(launch_norm(A->dmsc, A->left.dev, A->right.dev, A->rows_local, A->row0,
                       (double *)A->scratch.p, S(stream)));
   std::vector<double> h(nb);
   DNM_TRY(dnm_memcpy_d2h(h.data(), A->scratch.p, (size_t)nb * sizeof(double), stream));
@@ -1134,7 +1214,22 @@ int dnm_mat_plan_describe(const dnm_mat *A, char *buf, size_t buflen) {
   DNM_CHECK(A && buf && buflen, "null argument");
   std::string s;
   if (A->hypercube) s = A->plan.describe(A->op);
-  else if (A->sc_pair)
+  else if (A->use_sc3) {
+    const Sc3Tab &T = A->sc3->ly->host;
+    char tmp[512];
+    if (A->sc3->tiled)
+      snprintf(tmp, sizeof tmp, "SpinConserve two-pass kernels, internal layout [T %d | W %d | Lo %d]: window pass (%zu "
+               "workgroups, %d bonds in LDS, %d gathered) then lo pass (%zu workgroups, %d bonds in LDS, %d gathered), "
+               "diagonal %s, coefficients %s\n", T.t, T.w, T.a, A->sc3->permB.size(), T.w - 1,
+               __builtin_popcountll(A->sc3->op.bondsB), A->sc3->permA.size(), T.a - 1,
+               __builtin_popcountll(A->sc3->op.bondsA),
+               A->sc3->diag_mode == 2 ? "on the fly" : (A->sc3->diag_mode == 1 ? "cached" : "none"),
+               A->sc3->sym ? "real symmetric" : "complex");
+    else
+      snprintf(tmp, sizeof tmp, "SpinConserve row kernel, internal layout [T %d | W %d | Lo %d] (positions by table)\n",
+               T.t, T.w, T.a);
+    s = tmp;
+  } else if (A->sc_pair)
     s = A->scblock.lb ? "SpinConserve kernel, block form (" + std::to_string(A->scblock.lb) +
                             " low bits per workgroup in LDS, high bonds as block runs)\n"
                       : std::string("SpinConserve kernel (one row per thread, incremental colex rank)\n");

@@ -7,6 +7,7 @@
 
 #include "kernels.h"
 #include "plan.h"
+#include "sc3.h"
 #include "subspace.h"
 
 namespace dnm {
@@ -56,6 +57,11 @@ struct dnm_mat {
   int64_t M = 0, N = 0, m_local = 0, n_local = 0;
   int64_t row0 = 0;               // first row / column this rank owns
   bool sc_pair = false;           // SpinConserve(L,k) on both sides: incremental-rank kernel
+  // SpinConserve(L,k) on both sides with vectors in the internal layout (sc3.h): m_local / n_local then count the
+  // padding too (they are what the vector kernels sweep), rows_local the rows
+  bool use_sc3 = false;
+  std::unique_ptr<dnm::Sc3Mat> sc3;
+  int64_t rows_local = 0;
   int64_t win_min = 0, win_max = -1;   // partitioned SpinConserve: columns this rank reads (cached)
   int rank = 0, nranks = 1;
   int flags = 0;

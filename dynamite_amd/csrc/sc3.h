@@ -1,0 +1,153 @@
+// Three-field internal layout of SpinConserve(L, k) state vectors ("sc3") and the tables of its kernels.
+//
+//   state = [ T : t top bits | W : w window bits | Lo : a low bits ],  t = L - a - w >= 1
+//
+// The reference orders the basis by ascending state (bsubspace_impl.h:187-245): blocks of equal T, inside a block
+// ascending W, inside that ascending Lo.  Rows (T, W) -- the C(a, kl) states that share T and W, kl = k - |T| - |W| --
+// are contiguous in that order.  The internal layout keeps the T blocks where they are and, inside a block,
+//   * groups the rows by cw = |W| (classes), ascending,
+//   * orders the rows of a class by the rank wr of W among the w-bit patterns with cw ones,
+//   * pads every row to a multiple of 8 amplitudes (128-byte lines); padding holds zeros.
+// A class is then a dense matrix [wr][lr] with a fixed pitch: a bond inside Lo couples columns of one row, a bond
+// inside W couples rows of one class at the same column, every other chain bond couples a row to ONE other row at a
+// uniform offset.  Two tiled passes cover a nearest-neighbour chain (sc3_kernels.hip):
+//   lo pass     one workgroup per row: the a-1 bonds inside Lo from LDS, the Lo/W boundary bond gathered;
+//   window pass one workgroup per (T, cw, run of columns): all C(w, cw) rows of the class x R columns in LDS: the w-1
+//               bonds inside W from LDS, the W/T boundary and the bonds inside T gathered at uniform offsets.
+// Nothing like this exists in the reference (a PETSc Vec is opaque there as well); the maps to and from the
+// reference order are dnm_vec_layout_copy / dnm_vec_layout_positions.
+#pragma once
+
+#include <array>
+#include <cstdint>
+#include <vector>
+
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+
+namespace dnm {
+
+constexpr int SC3_MAXA = 16, SC3_MAXW = 12;
+
+// vec_swizzle code of a SpinConserve subspace: a | w << 8 (0: reference order)
+static inline int sc3_code(int a, int w) { return a | (w << 8); }
+static inline int sc3_code_a(int code) { return code & 0xff; }
+static inline int sc3_code_w(int code) { return (code >> 8) & 0xff; }
+
+struct Sc3Tab {
+  int32_t L, k, a, w, t;
+  int64_t nint;                    // length of a vector in this layout (rows + padding)
+  const int64_t *ibase;            // [1 << t]  internal offset of the T block (-1: the block is empty)
+  const int64_t *nbase;            // [1 << t]  reference index of the first state of the T block
+  const int64_t *icoff;            // [(a+w+1) * (w+1)]  offset of class cw inside a T block with kr ones left
+  const int64_t *ncoff;            // [(a+w+1) * (1 << w)]  reference offset of row W inside such a block
+  int32_t nl[SC3_MAXA + 2], pitch[SC3_MAXA + 2];   // by kl: C(a, kl), padded row length
+  int32_t lo_off[SC3_MAXA + 3];                    // lo_pat group offsets by kl
+  int32_t nw[SC3_MAXW + 2], w_off[SC3_MAXW + 3];   // by cw: C(w, cw), w_pat group offsets
+  int32_t rs[SC3_MAXW + 2];                        // window pass: log2(R / 16) by cw
+  const uint16_t *lo_pat, *w_pat;  // patterns grouped by popcount, ascending inside a group
+  const uint16_t *lo_rank, *w_rank;   // [1 << a], [1 << w]: rank of a pattern inside its group
+  const int32_t *cbin;             // [17 * 17] C(n, j)
+  const int64_t *nck;              // [(k+1) * (L+1)] C(LL, kk) at kk * (L+1) + LL: the reference's unranking table
+};
+
+// position of a state of the subspace in the internal layout
+__host__ __device__ __forceinline__ int64_t sc3_pos(uint64_t state, const Sc3Tab &S) {
+  const uint32_t T = (uint32_t)(state >> (S.a + S.w));
+  const uint32_t W = (uint32_t)(state >> S.a) & ((1u << S.w) - 1u);
+  const uint32_t Lo = (uint32_t)state & ((1u << S.a) - 1u);
+#if defined(__HIP_DEVICE_COMPILE__)
+  const int cw = __popc(W), kr = S.k - __popc(T);
+#else
+  const int cw = __builtin_popcount(W), kr = S.k - __builtin_popcount(T);
+#endif
+  return S.ibase[T] + S.icoff[kr * (S.w + 1) + cw] + (int64_t)S.w_rank[W] * S.pitch[kr - cw] + S.lo_rank[Lo];
+}
+
+// Host side: owns the tables (and, optionally, their device mirrors)
+struct Sc3Layout {
+  Sc3Tab host{}, dev{};
+  int64_t dim = 0;                 // C(L, k)
+  bool on_device = false;
+  std::vector<int64_t> ibase, nbase, icoff, ncoff, nck;
+  std::vector<uint16_t> lo_pat, w_pat, lo_rank, w_rank;
+  std::vector<int32_t> cbin;
+  std::vector<uint32_t> rows;      // every row (T << w | W) of the layout, in reference order
+  void *d_ibase = nullptr, *d_nbase = nullptr, *d_icoff = nullptr, *d_ncoff = nullptr, *d_lo_pat = nullptr,
+       *d_w_pat = nullptr, *d_lo_rank = nullptr, *d_w_rank = nullptr, *d_cbin = nullptr, *d_rows = nullptr, *d_nck = nullptr;
+  Sc3Layout() = default;
+  Sc3Layout(const Sc3Layout &) = delete;
+  Sc3Layout &operator=(const Sc3Layout &) = delete;
+  ~Sc3Layout();
+  // 0 on success; want_device: upload the tables
+  int init(int L, int k, int a, int w, bool want_device);
+};
+
+// does a (L, k, a, w) combination describe a usable layout?
+bool sc3_valid(int L, int k, int a, int w);
+// shared, cached layouts (a process uses a handful): the pointer stays valid for the life of the process
+const Sc3Layout *sc3_get(int L, int k, int a, int w, bool want_device);
+
+// ---- vector-level operations (sc3_kernels.hip) --------------------------------------------------------------
+// dst (internal) <- src (reference order) when to_internal, else dst (reference order) <- src (internal);
+// padding of an internal destination is zeroed
+int sc3_layout_copy(const Sc3Layout &Ly, void *dst, const void *src, bool to_internal, hipStream_t st);
+// same for a real array (the cached diagonal)
+int sc3_layout_copy_f64(const Sc3Layout &Ly, double *dst, const double *src, bool to_internal, hipStream_t st);
+int sc3_zero_padding(const Sc3Layout &Ly, void *x, hipStream_t st);
+// pos[i] = internal position of the reference index idx[i] (device arrays)
+int sc3_positions(const Sc3Layout &Ly, int64_t n, const int64_t *idx, int64_t *pos, hipStream_t st);
+// counter-based normal deviates keyed by the reference index (the numbers reference order would get), padding zero
+int sc3_random(const Sc3Layout &Ly, void *x, uint64_t seed, hipStream_t st);
+
+// ---- the operator in this layout ---------------------------------------------------------------------------------
+// Per-operator device data of the tiled passes.  A chain bond b couples spins b, b+1 with the two matrix elements of
+// ScMask (kernels.h): `up` when the ket has bit b set and bit b+1 clear, `dn` for the opposite hop.
+struct Sc3Op {
+  const double *bond = nullptr;    // [(L-1) * 4] up_re, up_im, dn_re, dn_im
+  uint64_t present = 0;            // bonds the operator has
+  uint64_t bondsA = 0, bondsB = 0; // bonds outside the LDS tile gathered by the lo pass / the window pass
+  const double *diag = nullptr;    // cached diagonal, internal order (DIAGM 1)
+  const double *dlo = nullptr;     // DIAGM 2: the diagonal terms that see Lo only, by (kl, lr) like lo_pat
+  const uint64_t *dt_sign = nullptr;   // DIAGM 2: the other terms: sign mask >> a, coefficient, group (0: the term
+  const double *dt_coef = nullptr;     //   sees (T, W) only; j >= 1: it also sees Lo through glo[j-1])
+  const int32_t *dt_group = nullptr;
+  int32_t ndt = 0, ngroups = 0;
+  uint32_t glo[4] = {0, 0, 0, 0};
+};
+// Per-call data: partition offsets (x holds the internal positions [win_start, ...), y / diag / z are this rank's
+// vectors starting at internal position row0), start vectors and fused sums as in launch_sc_block
+struct Sc3Call {
+  int64_t row0 = 0, win_start = 0;
+  const double2 *zinit = nullptr;
+  double zscale = 0.0;
+  const double2 *zinit2 = nullptr;
+  double z2re = 0.0, z2im = 0.0;
+  double *dot_out = nullptr;       // 3 * sc3_dot_partials() doubles: per-workgroup <x,y> (re, im) and |y|^2
+};
+
+struct Sc3Mat {
+  const Sc3Layout *ly = nullptr;
+  bool tiled = false;              // two tiled passes (every off-diagonal mask is a chain bond); else the row kernel
+  bool sym = false;                // every bond real and direction-independent
+  int diag_mode = 0;               // 0: no diagonal terms; 2: on the fly; 1: needs the cached diagonal
+  Sc3Op op{};
+  std::vector<uint32_t> permA, permB;
+  void *d_permA = nullptr, *d_permB = nullptr, *d_bond = nullptr, *d_dlo = nullptr, *d_dt_sign = nullptr,
+       *d_dt_coef = nullptr, *d_dt_group = nullptr;
+  Sc3Mat() = default;
+  Sc3Mat(const Sc3Mat &) = delete;
+  Sc3Mat &operator=(const Sc3Mat &) = delete;
+  ~Sc3Mat();
+  int init(const Sc3Layout *layout, const std::vector<int64_t> &masks, const std::vector<int64_t> &mask_offsets,
+           const std::vector<int64_t> &signs, const std::vector<double> &rcoef, const std::vector<ScMask> &scm,
+           bool want_device);
+};
+bool sc3_instance(int a, int w);           // kernel instances exist for this field split
+size_t sc3_dot_partials(const Sc3Mat &M);
+// y = A x (- zscale zinit + z2 zinit2), fused sums if asked for; cached_diag: internal order or null
+int launch_sc3(const Sc3Mat &M, const DevMsc &msc, const Sc3Call &call, const double *cached_diag, const void *xw,
+               void *y, hipStream_t st);
+
+}  // namespace dnm

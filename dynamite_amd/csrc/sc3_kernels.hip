@@ -1,0 +1,930 @@
+// SpinConserve(L,k) x SpinConserve(L,k) multiply in the three-field internal layout (sc3.h): two tiled passes for
+// nearest-neighbour chains, a row kernel for any other operator, and the layout's vector utilities.
+// Semantics: MatMult_CPU_General (src/dynamite/_backend/bpetsc_template_2.c:371-412) with the index maps of
+// bsubspace_impl.h:187-245; the cached-diagonal variant follows bpetsc_template_1.c:186-199.
+#include "sc3.h"
+
+#include <algorithm>
+#include <map>
+#include <memory>
+#include <mutex>
+
+#include "dnm_common.h"
+#include "kernels.h"
+#include "philox.h"
+
+namespace dnm {
+
+typedef double2 c128;
+typedef double d2v __attribute__((ext_vector_type(2)));
+
+namespace {
+
+__device__ __forceinline__ int64_t rl_i64(int64_t v, int l) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(v & 0xffffffff), l);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(v >> 32), l);
+  return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ double rl_f64(double v, int l) { return __longlong_as_double(rl_i64(__double_as_longlong(v), l)); }
+__device__ __forceinline__ int rl_i32(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ void store_nt(c128 *p, double re, double im) {
+  d2v v = {re, im};
+  __builtin_nontemporal_store(v, reinterpret_cast<d2v *>(p));
+}
+__device__ __forceinline__ c128 load_nt(const c128 *p) {
+  d2v v = __builtin_nontemporal_load(reinterpret_cast<const d2v *>(p));
+  return make_double2(v.x, v.y);
+}
+__device__ __forceinline__ double wave_sum(double v) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ double flip(double c, uint32_t parity_bit) {
+  int hi = __double2hiint(c) ^ (int)(parity_bit << 31);
+  return __hiloint2double(hi, __double2loint(c));
+}
+
+constexpr int cbinom(int n, int k) {
+  long long r = 1;
+  for (int i = 1; i <= k; ++i) r = r * (n - k + i) / i;
+  return (int)r;
+}
+
+// row (T, W) of a workgroup: everything the kernels derive from the perm entry
+struct RowId {
+  uint32_t T, W;
+  int cw, kr, kl, nrows, pitch;
+  int64_t tb, base;        // internal offset of the T block / of the row
+};
+__device__ __forceinline__ RowId decode_row(uint32_t e, const Sc3Tab &S) {
+  RowId r;
+  r.T = e >> S.w;
+  r.W = e & ((1u << S.w) - 1u);
+  r.cw = __popc(r.W);
+  r.kr = S.k - __popc(r.T);
+  r.kl = r.kr - r.cw;
+  r.nrows = S.nl[r.kl];
+  r.pitch = S.pitch[r.kl];
+  r.tb = S.ibase[r.T];
+  r.base = r.tb + S.icoff[r.kr * (S.w + 1) + r.cw] + (int64_t)S.w_rank[r.W] * r.pitch;
+  return r;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// lo pass (the second, accumulating pass): y += (bonds inside Lo, the Lo/W boundary, whatever else bondsA names
+// and the diagonal) x.  One workgroup per row (T, W).
+//   DIAGM 0: no diagonal; 1: cached (internal order, 8 B/row); 2: on the fly -- terms that see Lo only from a table
+//   over (kl, lr) (L2-resident), terms that see (T, W) only as one number per row, terms that see both as at most
+//   four (Lo sign mask, per-row coefficient) pairs.
+//   SYM: every bond coefficient is real and the same in both directions (Heisenberg, XXZ, XX chains).
+template <int A, int NT, int DIAGM, bool SYM>
+__global__ void __launch_bounds__(NT, (2048 / NT) * NT / 256 > 8 ? 8 : (2048 / NT) * NT / 256)
+sc3_lo_pass(const Sc3Tab S, const Sc3Op O, const uint32_t *__restrict__ perm, const Sc3Call C,
+            const c128 *__restrict__ xw, c128 *__restrict__ y) {
+  constexpr int MAXROWS = cbinom(A, A / 2);
+  constexpr int RPT = (MAXROWS + NT - 1) / NT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  c128 *xs = reinterpret_cast<c128 *>(smem);
+  __shared__ int32_t cl[A * (A + 1)];
+  __shared__ double red[3 * (NT / 64)];
+  const uint32_t e = perm[blockIdx.x];
+  if (e == 0xffffffffu) return;
+  const int lane = threadIdx.x & 63;
+  const int w = S.w;
+  const RowId R = decode_row(e, S);
+  const uint32_t T = R.T, W = R.W;
+  const int cw = R.cw, kr = R.kr, kl = R.kl, nrows = R.nrows, p = R.pitch;
+  const int64_t tb = R.tb, base = R.base;
+  const c128 *__restrict__ x = xw - C.win_start;
+  const int64_t lbase = base - C.row0;                 // position of the row in this rank's vectors
+
+  uint32_t lowb[RPT];
+  c128 xv[RPT];
+  const uint16_t *__restrict__ pat = S.lo_pat + S.lo_off[kl];
+#pragma unroll
+  for (int i = 0; i < RPT; ++i) {
+    const int r = threadIdx.x + i * NT;
+    lowb[i] = 0;
+    xv[i] = make_double2(0.0, 0.0);
+    if (r < nrows) {
+      lowb[i] = pat[r];
+      xv[i] = x[base + r];
+    }
+  }
+  // bonds outside Lo, one per lane: l = 0 the Lo/W boundary, 1..w-1 inside W, w the W/T boundary, above inside T.
+  // Each couples this row to one other row at a uniform offset (the boundary bond: a contiguous part of it).
+  int act = 0, r0 = 0, r1 = nrows;
+  int64_t delta = 0;
+  double c0 = 0.0, c1 = 0.0;
+  {
+    const int b = A - 1 + lane;
+    if (b < S.L - 1 && ((O.bondsA >> b) & 1ull)) {
+      bool up = false;
+      if (lane == 0) {
+        const int cut = S.cbin[(A - 1) * 17 + kl];                   // rows below: top bit of Lo clear
+        if (W & 1u) {                                                // the one comes down into Lo
+          if (cut > 0) {
+            act = 1; r0 = 0; r1 = cut; up = false;
+            delta = tb + S.icoff[kr * (w + 1) + cw - 1] + (int64_t)S.w_rank[W & ~1u] * S.pitch[kl + 1] +
+                    S.cbin[(A - 1) * 17 + kl + 1] - base;
+          }
+        } else if (cut < nrows) {                                    // the one goes up into W
+          act = 1; r0 = cut; r1 = nrows; up = true;
+          delta = tb + S.icoff[kr * (w + 1) + cw + 1] + (int64_t)S.w_rank[W | 1u] * S.pitch[kl - 1] - cut - base;
+        }
+      } else if (lane < w) {
+        const int bw = lane - 1;
+        const uint32_t pair = (W >> bw) & 3u;
+        if (pair == 1u || pair == 2u) {
+          act = 1; up = pair == 1u;
+          delta = ((int64_t)S.w_rank[W ^ (3u << bw)] - (int64_t)S.w_rank[W]) * p;
+        }
+      } else if (lane == w) {
+        const uint32_t pair = ((W >> (w - 1)) & 1u) | ((T & 1u) << 1);
+        if (pair == 1u) {
+          act = 1; up = true;
+          delta = S.ibase[T | 1u] + S.icoff[(kr - 1) * (w + 1) + cw - 1] +
+                  (int64_t)S.w_rank[W & ~(1u << (w - 1))] * p - base;
+        } else if (pair == 2u) {
+          act = 1; up = false;
+          delta = S.ibase[T & ~1u] + S.icoff[(kr + 1) * (w + 1) + cw + 1] +
+                  (int64_t)S.w_rank[W | (1u << (w - 1))] * p - base;
+        }
+      } else {
+        const int bt = lane - w - 1;
+        const uint32_t pair = (T >> bt) & 3u;
+        if (pair == 1u || pair == 2u) {
+          act = 1; up = pair == 1u;
+          delta = S.ibase[T ^ (3u << bt)] - tb;
+        }
+      }
+      if (act) {
+        c0 = O.bond[4 * b + (up ? 0 : 2)];
+        c1 = O.bond[4 * b + (up ? 1 : 3)];
+      }
+    }
+  }
+  uint64_t hb = __ballot(act);
+
+  for (int tt = threadIdx.x; tt < A * (A + 1); tt += NT) {
+    const int lo = tt / (A + 1), o = tt % (A + 1);
+    cl[tt] = S.cbin[lo * 17 + o];
+  }
+  // on-the-fly diagonal: what the row (T, W) contributes -- group 0 to every state of the row, groups 1..4 with the
+  // sign of a Lo pattern; one term per lane, wave sums (every wavefront computes them: no exchange needed)
+  double dg0 = 0.0, dgm[4] = {0.0, 0.0, 0.0, 0.0};
+  if (DIAGM == 2) {
+    const uint64_t hi = ((uint64_t)T << w) | W;
+    double v0 = 0.0, vm[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int t0 = 0; t0 < O.ndt; t0 += 64) {
+      const int t = t0 + lane;
+      if (t < O.ndt) {
+        const double c = flip(O.dt_coef[t], (uint32_t)__popcll(hi & O.dt_sign[t]) & 1u);
+        const int g = O.dt_group[t];
+        if (g == 0) v0 += c;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (g == j + 1) vm[j] += c;
+      }
+    }
+    dg0 = rl_f64(wave_sum(v0), 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) if (j < O.ngroups) dgm[j] = rl_f64(wave_sum(vm[j]), 0);
+  }
+  double accr[RPT], acci[RPT];
+#pragma unroll
+  for (int i = 0; i < RPT; ++i) {
+    const int r = threadIdx.x + i * NT;
+    accr[i] = 0.0;
+    acci[i] = 0.0;
+    if (r < nrows) {
+      xs[r] = xv[i];
+      if (DIAGM == 1) {
+        const double dg = __builtin_nontemporal_load(O.diag + lbase + r);
+        accr[i] = dg * xv[i].x;
+        acci[i] = dg * xv[i].y;
+      } else if (DIAGM == 2) {
+        double dg = O.dlo[S.lo_off[kl] + r] + dg0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (j < O.ngroups) dg += flip(dgm[j], (uint32_t)__popc(lowb[i] & O.glo[j]) & 1u);
+        accr[i] = dg * xv[i].x;
+        acci[i] = dg * xv[i].y;
+      }
+    }
+  }
+  while (hb) {
+    const int m = __ffsll((long long)hb) - 1;
+    hb &= hb - 1;
+    const c128 *__restrict__ pp = x + (base + rl_i64(delta, m));
+    const double cr = rl_f64(c0, m), ci = rl_f64(c1, m);
+    const int q0 = rl_i32(r0, m), q1 = rl_i32(r1, m);
+    c128 v[RPT];
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+      const int r = threadIdx.x + i * NT;
+      v[i] = make_double2(0.0, 0.0);
+      if (r >= q0 && r < q1) v[i] = pp[r];
+    }
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+      accr[i] = fma(cr, v[i].x, accr[i]);
+      acci[i] = fma(cr, v[i].y, acci[i]);
+      if (!SYM) {
+        accr[i] = fma(-ci, v[i].y, accr[i]);
+        acci[i] = fma(ci, v[i].x, acci[i]);
+      }
+    }
+  }
+  __syncthreads();
+  for (int lo = 0; lo < A - 1; ++lo) {
+    if (!((O.present >> lo) & 1ull)) continue;
+    const double ure = O.bond[4 * lo], uim = O.bond[4 * lo + 1], dre = O.bond[4 * lo + 2], dim_ = O.bond[4 * lo + 3];
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+      const int r = threadIdx.x + i * NT;
+      const uint32_t pair = (lowb[i] >> lo) & 3u;
+      if (r < nrows && (pair == 1u || pair == 2u)) {
+        const bool up = pair == 1u;
+        const int ord0 = __popc(lowb[i] & ((1u << lo) - 1u));
+        const int d = cl[lo * (A + 1) + ord0];
+        const c128 xp = xs[up ? r + d : r - d];
+        if (SYM) {
+          accr[i] = fma(ure, xp.x, accr[i]);
+          acci[i] = fma(ure, xp.y, acci[i]);
+        } else {
+          const double cre = up ? ure : dre, cim = up ? uim : dim_;
+          accr[i] = fma(cre, xp.x, accr[i]);
+          acci[i] = fma(cre, xp.y, acci[i]);
+          accr[i] = fma(-cim, xp.y, accr[i]);
+          acci[i] = fma(cim, xp.x, acci[i]);
+        }
+      }
+    }
+  }
+  double dr = 0.0, di = 0.0, dn = 0.0;
+#pragma unroll
+  for (int i = 0; i < RPT; ++i) {
+    const int r = threadIdx.x + i * NT;
+    if (r < p) {                                  // the padding of a row is written too (zeros)
+      double ar = accr[i], ai = acci[i];
+      if (r < nrows) {
+        const c128 yo = load_nt(y + lbase + r);
+        ar += yo.x;
+        ai += yo.y;
+        if (C.dot_out) {                          // <x, y> and |y|^2 of the finished rows (the row of x is in LDS)
+          const c128 xo = xs[r];
+          dr = fma(xo.x, ar, dr);
+          dr = fma(xo.y, ai, dr);
+          di = fma(xo.x, ai, di);
+          di = fma(-xo.y, ar, di);
+          dn = fma(ar, ar, dn);
+          dn = fma(ai, ai, dn);
+        }
+      }
+      store_nt(y + lbase + r, ar, ai);
+    }
+  }
+  if (C.dot_out) {
+    dr = wave_sum(dr); di = wave_sum(di); dn = wave_sum(dn);
+    if (lane == 0) {
+      red[3 * (threadIdx.x >> 6)] = dr;
+      red[3 * (threadIdx.x >> 6) + 1] = di;
+      red[3 * (threadIdx.x >> 6) + 2] = dn;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double sr = 0.0, si = 0.0, sn = 0.0;
+      for (int wv = 0; wv < NT / 64; ++wv) { sr += red[3 * wv]; si += red[3 * wv + 1]; sn += red[3 * wv + 2]; }
+      C.dot_out[3 * (size_t)blockIdx.x] = sr;
+      C.dot_out[3 * (size_t)blockIdx.x + 1] = si;
+      C.dot_out[3 * (size_t)blockIdx.x + 2] = sn;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// window pass (the first pass: writes y): one workgroup per (T, cw, run of R = 16 << s columns): all window
+// patterns of the class x R columns in LDS; the accumulators start from -zscale * zinit + z2 * zinit2 if given.
+template <int WB, int NT, bool SYM>
+__global__ void __launch_bounds__(NT, (2048 / NT) * NT / 256 > 8 ? 8 : (2048 / NT) * NT / 256)
+sc3_win_pass(const Sc3Tab S, const Sc3Op O, const uint32_t *__restrict__ perm, const Sc3Call C,
+             const c128 *__restrict__ xw, c128 *__restrict__ y) {
+  constexpr int MAXE = cbinom(WB, WB / 2) * 16;
+  constexpr int RPT = (MAXE + NT - 1) / NT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  c128 *xs = reinterpret_cast<c128 *>(smem);
+  __shared__ int32_t cl[WB * (WB + 1)];
+  const uint32_t e = perm[blockIdx.x];
+  if (e == 0xffffffffu) return;
+  const int lane = threadIdx.x & 63;
+  const uint32_t T = e >> 16;
+  const int cw = (e >> 12) & 15, run = e & 0xfff;
+  const int kr = S.k - __popc(T), kl = kr - cw;
+  const int nwp = S.nw[cw], p = S.pitch[kl];
+  const int sh = 4 + S.rs[cw];
+  const int lr0 = run << sh;
+  const int ncols = min(1 << sh, p - lr0);
+  const int64_t tb = S.ibase[T];
+  const int64_t own = tb + S.icoff[kr * (WB + 1) + cw];
+  const int64_t cbase = own + lr0;
+  const int64_t lcb = cbase - C.row0;
+  const int nent = nwp << sh;
+  const c128 *__restrict__ x = xw - C.win_start;
+
+  uint32_t wpat[RPT];
+  int32_t off[RPT];          // offset of the entry from cbase, -1: not an entry
+  c128 xv[RPT];
+  const uint16_t *__restrict__ pat = S.w_pat + S.w_off[cw];
+#pragma unroll
+  for (int i = 0; i < RPT; ++i) {
+    const int en = threadIdx.x + i * NT;
+    wpat[i] = 0;
+    off[i] = -1;
+    xv[i] = make_double2(0.0, 0.0);
+    if (en < nent) {
+      const int wrr = en >> sh, j = en & ((1 << sh) - 1);
+      wpat[i] = pat[wrr] | ((uint32_t)wrr << 16);
+      if (j < ncols) {
+        off[i] = wrr * p + j;
+        xv[i] = x[cbase + off[i]];
+      }
+    }
+  }
+  // gathered bonds, one per lane: l = 0 the W/T boundary, above inside T
+  int act = 0, r0 = 0, r1 = nwp;
+  int64_t delta = 0;
+  double c0 = 0.0, c1 = 0.0;
+  {
+    const int b = S.a + WB - 1 + lane;
+    if (b < S.L - 1 && ((O.bondsB >> b) & 1ull)) {
+      bool up = false;
+      if (lane == 0) {
+        const int cut = S.cbin[(WB - 1) * 17 + cw];                // rows below: top bit of W clear
+        if (T & 1u) {                                              // the one comes down into W
+          if (cut > 0) {
+            act = 1; r0 = 0; r1 = cut; up = false;
+            delta = S.ibase[T & ~1u] + S.icoff[(kr + 1) * (WB + 1) + cw + 1] +
+                    (int64_t)S.cbin[(WB - 1) * 17 + cw + 1] * p - own;
+          }
+        } else if (cut < nwp) {                                    // the one goes up into T
+          act = 1; r0 = cut; r1 = nwp; up = true;
+          delta = S.ibase[T | 1u] + S.icoff[(kr - 1) * (WB + 1) + cw - 1] - (int64_t)cut * p - own;
+        }
+      } else {
+        const int bt = lane - 1;
+        const uint32_t pair = (T >> bt) & 3u;
+        if (pair == 1u || pair == 2u) {
+          act = 1; up = pair == 1u;
+          delta = S.ibase[T ^ (3u << bt)] - tb;
+        }
+      }
+      if (act) {
+        c0 = O.bond[4 * b + (up ? 0 : 2)];
+        c1 = O.bond[4 * b + (up ? 1 : 3)];
+      }
+    }
+  }
+  uint64_t hb = __ballot(act);
+  for (int tt = threadIdx.x; tt < WB * (WB + 1); tt += NT) {
+    const int lo = tt / (WB + 1), o = tt % (WB + 1);
+    cl[tt] = S.cbin[lo * 17 + o];
+  }
+  double accr[RPT], acci[RPT];
+#pragma unroll
+  for (int i = 0; i < RPT; ++i) {
+    const int en = threadIdx.x + i * NT;
+    accr[i] = 0.0;
+    acci[i] = 0.0;
+    if (en < nent) {
+      xs[en] = xv[i];
+      if (C.zinit && off[i] >= 0) {        // y = A x - b z (+ c z2): the start vectors open the accumulators
+        const c128 zv = C.zinit[lcb + off[i]];
+        accr[i] = -C.zscale * zv.x;
+        acci[i] = -C.zscale * zv.y;
+        if (C.zinit2) {
+          const c128 z2 = C.zinit2[lcb + off[i]];
+          accr[i] = fma(C.z2re, z2.x, accr[i]);
+          accr[i] = fma(-C.z2im, z2.y, accr[i]);
+          acci[i] = fma(C.z2re, z2.y, acci[i]);
+          acci[i] = fma(C.z2im, z2.x, acci[i]);
+        }
+      }
+    }
+  }
+  while (hb) {
+    const int m = __ffsll((long long)hb) - 1;
+    hb &= hb - 1;
+    const c128 *__restrict__ pp = x + (cbase + rl_i64(delta, m));
+    const double cr = rl_f64(c0, m), ci = rl_f64(c1, m);
+    const int q0 = rl_i32(r0, m), q1 = rl_i32(r1, m);
+    c128 v[RPT];
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+      const int wrr = (int)(wpat[i] >> 16);
+      v[i] = make_double2(0.0, 0.0);
+      if (off[i] >= 0 && wrr >= q0 && wrr < q1) v[i] = pp[off[i]];
+    }
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+      accr[i] = fma(cr, v[i].x, accr[i]);
+      acci[i] = fma(cr, v[i].y, acci[i]);
+      if (!SYM) {
+        accr[i] = fma(-ci, v[i].y, accr[i]);
+        acci[i] = fma(ci, v[i].x, acci[i]);
+      }
+    }
+  }
+  __syncthreads();
+  for (int lo = 0; lo < WB - 1; ++lo) {
+    const int b = S.a + lo;
+    if (!((O.present >> b) & 1ull)) continue;
+    const double ure = O.bond[4 * b], uim = O.bond[4 * b + 1], dre = O.bond[4 * b + 2], dim_ = O.bond[4 * b + 3];
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+      const int en = threadIdx.x + i * NT;
+      const uint32_t pair = (wpat[i] >> lo) & 3u;
+      if (off[i] >= 0 && (pair == 1u || pair == 2u)) {
+        const bool up = pair == 1u;
+        const int ord0 = __popc(wpat[i] & ((1u << lo) - 1u));
+        const int d = cl[lo * (WB + 1) + ord0] << sh;
+        const c128 xp = xs[up ? en + d : en - d];
+        if (SYM) {
+          accr[i] = fma(ure, xp.x, accr[i]);
+          acci[i] = fma(ure, xp.y, acci[i]);
+        } else {
+          const double cre = up ? ure : dre, cim = up ? uim : dim_;
+          accr[i] = fma(cre, xp.x, accr[i]);
+          acci[i] = fma(cre, xp.y, acci[i]);
+          accr[i] = fma(-cim, xp.y, accr[i]);
+          acci[i] = fma(cim, xp.x, acci[i]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < RPT; ++i)
+    if (off[i] >= 0) store_nt(y + lcb + off[i], accr[i], acci[i]);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Row kernel: any operator between SpinConserve(L,k) and itself in the internal layout.  One workgroup per row
+// (T, W); a state's position is three table lookups (sc3_pos), so a column costs no unranking.  The matrix element
+// follows bpetsc_template_2.c:396-405 (sign on the column state, TERM_REAL decides real / imaginary).
+constexpr int SC3_ROW_NT = 256;
+__global__ void __launch_bounds__(SC3_ROW_NT)
+sc3_row_kernel(const Sc3Tab S, const DevMsc msc, const uint32_t *__restrict__ rows, const Sc3Call C,
+               const double *__restrict__ diag, const c128 *__restrict__ xw, c128 *__restrict__ y) {
+  const uint32_t e = rows[blockIdx.x];
+  if (e == 0xffffffffu) return;
+  const RowId R = decode_row(e, S);
+  const c128 *__restrict__ x = xw - C.win_start;
+  const int64_t lbase = R.base - C.row0;
+  const uint64_t hi = (((uint64_t)R.T << S.w) | R.W) << S.a;
+  const uint16_t *__restrict__ pat = S.lo_pat + S.lo_off[R.kl];
+  for (int r = threadIdx.x; r < R.pitch; r += SC3_ROW_NT) {
+    double accr = 0.0, acci = 0.0;
+    if (r < R.nrows) {
+      const uint64_t ket = hi | pat[r];
+      if (C.zinit) {
+        const c128 zv = C.zinit[lbase + r];
+        accr = -C.zscale * zv.x;
+        acci = -C.zscale * zv.y;
+        if (C.zinit2) {
+          const c128 z2 = C.zinit2[lbase + r];
+          accr = fma(C.z2re, z2.x, accr);
+          accr = fma(-C.z2im, z2.y, accr);
+          acci = fma(C.z2re, z2.y, acci);
+          acci = fma(C.z2im, z2.x, acci);
+        }
+      }
+      int m0 = 0;
+      if (diag) {
+        const c128 xo = x[R.base + r];
+        const double dg = diag[lbase + r];
+        accr = fma(dg, xo.x, accr);
+        acci = fma(dg, xo.y, acci);
+        m0 = 1;
+      }
+      for (int m = m0; m < msc.nmasks; ++m) {
+        const uint64_t mask = (uint64_t)msc.masks[m];
+        const uint64_t bra = ket ^ mask;
+        if (__popcll(bra) != S.k) continue;               // leaves the subspace: no such column
+        double cre = 0.0, cim = 0.0;
+        for (int64_t t = msc.mask_offsets[m]; t < msc.mask_offsets[m + 1]; ++t) {
+          const uint64_t sg = (uint64_t)msc.signs[t];
+          const double c = flip(msc.real_coeffs[t], (uint32_t)__popcll(bra & sg) & 1u);
+          if (__popcll(mask & sg) & 1) cim += c; else cre += c;   // TERM_REAL (bpetsc_impl.h:34)
+        }
+        const c128 xv = x[sc3_pos(bra, S)];
+        accr = fma(cre, xv.x, accr);
+        acci = fma(cre, xv.y, acci);
+        accr = fma(-cim, xv.y, accr);
+        acci = fma(cim, xv.x, acci);
+      }
+    }
+    store_nt(y + lbase + r, accr, acci);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// layout utilities: one workgroup per row (T, W)
+template <typename V>
+__global__ void __launch_bounds__(256)
+sc3_copy_kernel(const Sc3Tab S, const uint32_t *__restrict__ rows, V *__restrict__ dst, const V *__restrict__ src,
+                int to_internal) {
+  const uint32_t e = rows[blockIdx.x];
+  const RowId R = decode_row(e, S);
+  const int64_t nat = S.nbase[R.T] + S.ncoff[(int64_t)R.kr * ((int64_t)1 << S.w) + R.W];
+  V zero{};
+  for (int r = threadIdx.x; r < R.pitch; r += 256) {
+    if (to_internal) dst[R.base + r] = r < R.nrows ? src[nat + r] : zero;
+    else if (r < R.nrows) dst[nat + r] = src[R.base + r];
+  }
+}
+__global__ void __launch_bounds__(64)
+sc3_zero_pad_kernel(const Sc3Tab S, const uint32_t *__restrict__ rows, c128 *__restrict__ x) {
+  const RowId R = decode_row(rows[blockIdx.x], S);
+  for (int r = R.nrows + threadIdx.x; r < R.pitch; r += 64) x[R.base + r] = make_double2(0.0, 0.0);
+}
+__global__ void __launch_bounds__(256)
+sc3_random_kernel(const Sc3Tab S, const uint32_t *__restrict__ rows, c128 *__restrict__ x, uint64_t seed) {
+  const RowId R = decode_row(rows[blockIdx.x], S);
+  const int64_t nat = S.nbase[R.T] + S.ncoff[(int64_t)R.kr * ((int64_t)1 << S.w) + R.W];
+  for (int r = threadIdx.x; r < R.pitch; r += 256)
+    x[R.base + r] = r < R.nrows ? philox_normal((uint64_t)(nat + r), seed) : make_double2(0.0, 0.0);
+}
+// reference index -> internal position: unrank (bsubspace_impl.h:210-228), then the tables
+__global__ void __launch_bounds__(256)
+sc3_positions_kernel(const Sc3Tab S, int64_t n, const int64_t *__restrict__ idx, int64_t *__restrict__ pos) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int64_t *__restrict__ nck = S.nck;
+  const int ld = S.L + 1;
+  int64_t id = idx[i];
+  uint64_t st = 0;
+  int k = S.k;
+  for (int b = S.L; b > 0; --b) {
+    const int64_t here = (k > b - 1) ? 0 : nck[(int64_t)k * ld + (b - 1)];
+    st <<= 1;
+    if (id >= here) { id -= here; --k; st |= 1; }
+  }
+  pos[i] = sc3_pos(st, S);
+}
+
+}  // namespace
+
+// ===========================================================================================================
+// host side
+// ===========================================================================================================
+static int64_t hbinom(int n, int k) {
+  if (k < 0 || k > n) return 0;
+  long double r = 1;
+  for (int i = 1; i <= k; ++i) r = r * (n - k + i) / i;
+  return (int64_t)llroundl(r);
+}
+
+bool sc3_valid(int L, int k, int a, int w) {
+  const int t = L - a - w;
+  return a >= 2 && a <= SC3_MAXA && w >= 2 && w <= SC3_MAXW && t >= 1 && t <= 15 && k >= 0 && k <= L;
+}
+
+Sc3Layout::~Sc3Layout() {
+  for (void *p : {d_ibase, d_nbase, d_icoff, d_ncoff, d_lo_pat, d_w_pat, d_lo_rank, d_w_rank, d_cbin, d_rows, d_nck})
+    if (p) (void)hipFree(p);
+}
+
+template <class T_>
+static int up(const std::vector<T_> &v, void **d) {
+  DNM_HIP(hipMalloc(d, std::max<size_t>(1, v.size()) * sizeof(T_)));
+  DNM_HIP(hipMemcpy(*d, v.data(), v.size() * sizeof(T_), hipMemcpyHostToDevice));
+  return 0;
+}
+
+int Sc3Layout::init(int L, int k, int a, int w, bool want_device) {
+  DNM_CHECK(sc3_valid(L, k, a, w), "no such vector layout: L=%d k=%d a=%d w=%d", L, k, a, w);
+  Sc3Tab &S = host;
+  S = Sc3Tab{};
+  S.L = L; S.k = k; S.a = a; S.w = w; S.t = L - a - w;
+  const int t = S.t;
+  cbin.assign(17 * 17, 0);
+  for (int n = 0; n < 17; ++n) for (int j = 0; j < 17; ++j) cbin[n * 17 + j] = (int32_t)hbinom(n, j);
+  nck.assign((size_t)(k + 1) * (L + 1), 0);
+  for (int kk = 0; kk <= k; ++kk) for (int LL = 0; LL <= L; ++LL) nck[(size_t)kk * (L + 1) + LL] = hbinom(LL, kk);
+  lo_rank.assign((size_t)1 << a, 0);
+  w_rank.assign((size_t)1 << w, 0);
+  lo_pat.clear();
+  w_pat.clear();
+  for (int j = 0; j <= a; ++j) {
+    S.lo_off[j] = (int32_t)lo_pat.size();
+    S.nl[j] = (int32_t)hbinom(a, j);
+    S.pitch[j] = (S.nl[j] + 7) / 8 * 8;
+    int r = 0;
+    for (uint32_t v = 0; v < (1u << a); ++v)
+      if (__builtin_popcount(v) == j) { lo_rank[v] = (uint16_t)r++; lo_pat.push_back((uint16_t)v); }
+  }
+  S.lo_off[a + 1] = (int32_t)lo_pat.size();
+  const int wmax = (int)hbinom(w, w / 2);
+  for (int j = 0; j <= w; ++j) {
+    S.w_off[j] = (int32_t)w_pat.size();
+    S.nw[j] = (int32_t)hbinom(w, j);
+    int r = 0;
+    for (uint32_t v = 0; v < (1u << w); ++v)
+      if (__builtin_popcount(v) == j) { w_rank[v] = (uint16_t)r++; w_pat.push_back((uint16_t)v); }
+    int s = 0;
+    while ((S.nw[j] << (s + 1)) <= wmax && s < 8) ++s;      // R = 16 << s keeps nw * R within the largest tile
+    S.rs[j] = s;
+  }
+  S.w_off[w + 1] = (int32_t)w_pat.size();
+  icoff.assign((size_t)(a + w + 1) * (w + 1), 0);
+  ncoff.assign((size_t)(a + w + 1) << w, 0);
+  std::vector<int64_t> isize(a + w + 1, 0);
+  for (int kr = 0; kr <= a + w; ++kr) {
+    int64_t o = 0;
+    for (int cw = 0; cw <= w; ++cw) {
+      icoff[(size_t)kr * (w + 1) + cw] = o;
+      const int kl = kr - cw;
+      if (kl >= 0 && kl <= a) o += hbinom(w, cw) * S.pitch[kl];
+    }
+    isize[kr] = o;
+    int64_t no = 0;
+    for (uint32_t W = 0; W < (1u << w); ++W) {
+      ncoff[((size_t)kr << w) + W] = no;
+      const int kl = kr - __builtin_popcount(W);
+      if (kl >= 0 && kl <= a) no += hbinom(a, kl);
+    }
+  }
+  ibase.assign((size_t)1 << t, -1);
+  nbase.assign((size_t)1 << t, -1);
+  rows.clear();
+  int64_t ni = 0, nn = 0;
+  for (uint32_t T = 0; T < (1u << t); ++T) {
+    const int kr = k - __builtin_popcount(T);
+    if (kr < 0 || kr > a + w) continue;
+    ibase[T] = ni;
+    nbase[T] = nn;
+    ni += isize[kr];
+    nn += hbinom(a + w, kr);
+    for (uint32_t W = 0; W < (1u << w); ++W) {
+      const int kl = kr - __builtin_popcount(W);
+      if (kl >= 0 && kl <= a) rows.push_back((T << w) | W);
+    }
+  }
+  S.nint = ni;
+  dim = nn;
+  DNM_CHECK(nn == hbinom(L, k), "internal: layout does not cover the subspace");
+  S.ibase = ibase.data(); S.nbase = nbase.data(); S.icoff = icoff.data(); S.ncoff = ncoff.data();
+  S.lo_pat = lo_pat.data(); S.w_pat = w_pat.data(); S.lo_rank = lo_rank.data(); S.w_rank = w_rank.data();
+  S.cbin = cbin.data();
+  S.nck = nck.data();
+  dev = S;
+  if (want_device) {
+    DNM_TRY(up(ibase, &d_ibase)); DNM_TRY(up(nbase, &d_nbase)); DNM_TRY(up(icoff, &d_icoff));
+    DNM_TRY(up(ncoff, &d_ncoff)); DNM_TRY(up(lo_pat, &d_lo_pat)); DNM_TRY(up(w_pat, &d_w_pat));
+    DNM_TRY(up(lo_rank, &d_lo_rank)); DNM_TRY(up(w_rank, &d_w_rank)); DNM_TRY(up(cbin, &d_cbin));
+    DNM_TRY(up(rows, &d_rows));
+    DNM_TRY(up(nck, &d_nck));
+    dev.ibase = (const int64_t *)d_ibase; dev.nbase = (const int64_t *)d_nbase;
+    dev.icoff = (const int64_t *)d_icoff; dev.ncoff = (const int64_t *)d_ncoff;
+    dev.lo_pat = (const uint16_t *)d_lo_pat; dev.w_pat = (const uint16_t *)d_w_pat;
+    dev.lo_rank = (const uint16_t *)d_lo_rank; dev.w_rank = (const uint16_t *)d_w_rank;
+    dev.cbin = (const int32_t *)d_cbin;
+    dev.nck = (const int64_t *)d_nck;
+    on_device = true;
+  }
+  return 0;
+}
+
+const Sc3Layout *sc3_get(int L, int k, int a, int w, bool want_device) {
+  static std::mutex mu;
+  static std::map<std::array<int, 5>, std::unique_ptr<Sc3Layout>> cache;
+  std::lock_guard<std::mutex> g(mu);
+  const std::array<int, 5> key{L, k, a, w, want_device ? 1 : 0};
+  auto it = cache.find(key);
+  if (it != cache.end()) return it->second.get();
+  std::unique_ptr<Sc3Layout> lay(new Sc3Layout());
+  if (lay->init(L, k, a, w, want_device)) return nullptr;
+  return (cache[key] = std::move(lay)).get();
+}
+
+// ---- utilities ------------------------------------------------------------------------------------------
+int sc3_layout_copy(const Sc3Layout &Ly, void *dst, const void *src, bool to_internal, hipStream_t st) {
+  DNM_CHECK(Ly.on_device, "layout tables are not on the device");
+  hipLaunchKernelGGL(sc3_copy_kernel<c128>, dim3((unsigned)Ly.rows.size()), dim3(256), 0, st, Ly.dev,
+                     (const uint32_t *)Ly.d_rows, (c128 *)dst, (const c128 *)src, to_internal ? 1 : 0);
+  DNM_HIP(hipGetLastError());
+  return 0;
+}
+int sc3_layout_copy_f64(const Sc3Layout &Ly, double *dst, const double *src, bool to_internal, hipStream_t st) {
+  DNM_CHECK(Ly.on_device, "layout tables are not on the device");
+  hipLaunchKernelGGL(sc3_copy_kernel<double>, dim3((unsigned)Ly.rows.size()), dim3(256), 0, st, Ly.dev,
+                     (const uint32_t *)Ly.d_rows, dst, src, to_internal ? 1 : 0);
+  DNM_HIP(hipGetLastError());
+  return 0;
+}
+int sc3_zero_padding(const Sc3Layout &Ly, void *x, hipStream_t st) {
+  DNM_CHECK(Ly.on_device, "layout tables are not on the device");
+  hipLaunchKernelGGL(sc3_zero_pad_kernel, dim3((unsigned)Ly.rows.size()), dim3(64), 0, st, Ly.dev,
+                     (const uint32_t *)Ly.d_rows, (c128 *)x);
+  DNM_HIP(hipGetLastError());
+  return 0;
+}
+int sc3_random(const Sc3Layout &Ly, void *x, uint64_t seed, hipStream_t st) {
+  DNM_CHECK(Ly.on_device, "layout tables are not on the device");
+  hipLaunchKernelGGL(sc3_random_kernel, dim3((unsigned)Ly.rows.size()), dim3(256), 0, st, Ly.dev,
+                     (const uint32_t *)Ly.d_rows, (c128 *)x, seed);
+  DNM_HIP(hipGetLastError());
+  return 0;
+}
+int sc3_positions(const Sc3Layout &Ly, int64_t n, const int64_t *idx, int64_t *pos, hipStream_t st) {
+  DNM_CHECK(Ly.on_device, "layout tables are not on the device");
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(sc3_positions_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, Ly.dev, n, idx, pos);
+  DNM_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---- the operator ---------------------------------------------------------------------------------------
+// deal groups of workgroups to the 8 XCDs (workgroup b runs on XCD b % 8): the next group goes to the shortest stream
+static std::vector<uint32_t> deal(const std::vector<std::vector<uint32_t>> &groups) {
+  std::vector<std::vector<uint32_t>> st(8);
+  for (auto &g : groups) {
+    int best = 0;
+    for (int s = 1; s < 8; ++s) if (st[s].size() < st[best].size()) best = s;
+    st[best].insert(st[best].end(), g.begin(), g.end());
+  }
+  size_t n = 0;
+  for (auto &s : st) n = std::max(n, s.size());
+  std::vector<uint32_t> out(8 * n, 0xffffffffu);
+  for (int s = 0; s < 8; ++s)
+    for (size_t i = 0; i < st[s].size(); ++i) out[8 * i + s] = st[s][i];
+  return out;
+}
+
+bool sc3_instance(int a, int w) { return (a == 14 && w == 10) || (a == 6 && w == 4); }
+
+Sc3Mat::~Sc3Mat() {
+  for (void *p : {d_permA, d_permB, d_bond, d_dlo, d_dt_sign, d_dt_coef, d_dt_group})
+    if (p) (void)hipFree(p);
+}
+
+int Sc3Mat::init(const Sc3Layout *layout, const std::vector<int64_t> &masks, const std::vector<int64_t> &mask_offsets,
+                 const std::vector<int64_t> &signs, const std::vector<double> &rcoef, const std::vector<ScMask> &scm,
+                 bool want_device) {
+  ly = layout;
+  const Sc3Tab &S = ly->host;
+  const int L = S.L, a = S.a, w = S.w, t = S.t, k = S.k;
+  const int64_t nmasks = (int64_t)masks.size();
+  // two tiled passes need every off-diagonal mask to be a chain bond with local signs (ScMask::fast)
+  tiled = sc3_instance(a, w);
+  for (int64_t m = 0; m < nmasks; ++m)
+    if (masks[m] != 0 && !scm[m].fast) tiled = false;
+  if (!tiled) return 0;
+  std::vector<double> bond(4 * (size_t)std::max(1, L - 1), 0.0);
+  op.present = 0;
+  sym = true;
+  for (int64_t m = 0; m < nmasks; ++m) {
+    if (masks[m] == 0) continue;
+    const int b = scm[m].lo;
+    bond[4 * b] = scm[m].up_re; bond[4 * b + 1] = scm[m].up_im;
+    bond[4 * b + 2] = scm[m].dn_re; bond[4 * b + 3] = scm[m].dn_im;
+    op.present |= 1ull << b;
+    if (scm[m].up_im != 0.0 || scm[m].dn_im != 0.0 || scm[m].up_re != scm[m].dn_re) sym = false;
+  }
+  // which pass gathers which bond outside its LDS tile: the Lo/W boundary in the lo pass, the W/T boundary and the
+  // bonds inside T in the window pass (measured, profiles/r03_exp3_sc3_v2.txt)
+  op.bondsA = op.present & (1ull << (a - 1));
+  op.bondsB = 0;
+  for (int b = a + w - 1; b < L - 1; ++b) op.bondsB |= op.present & (1ull << b);
+  // diagonal on the fly: split the mask-0 terms by what their sign masks see
+  diag_mode = 0;
+  std::vector<double> dlo;
+  std::vector<uint64_t> dt_sign;
+  std::vector<double> dt_coef;
+  std::vector<int32_t> dt_group;
+  op.ngroups = 0;
+  if (nmasks > 0 && masks[0] == 0) {
+    diag_mode = 2;
+    const uint64_t lom = ((uint64_t)1 << a) - 1;
+    dlo.assign(ly->lo_pat.size(), 0.0);
+    std::vector<uint64_t> groups;
+    for (int64_t tt = mask_offsets[0]; tt < mask_offsets[1]; ++tt) {
+      const uint64_t sg = (uint64_t)signs[tt];
+      const double c = rcoef[tt];
+      if ((sg & ~lom) == 0) {
+        for (size_t i = 0; i < ly->lo_pat.size(); ++i)
+          dlo[i] += (__builtin_popcountll(ly->lo_pat[i] & sg) & 1) ? -c : c;
+        continue;
+      }
+      int g = 0;
+      if (sg & lom) {
+        size_t j = 0;
+        while (j < groups.size() && groups[j] != (sg & lom)) ++j;
+        if (j == groups.size()) groups.push_back(sg & lom);
+        g = (int)j + 1;
+      }
+      dt_sign.push_back(sg >> a);
+      dt_coef.push_back(c);
+      dt_group.push_back(g);
+    }
+    if (groups.size() > 4) diag_mode = 1;      // too many mixed patterns: the cached diagonal instead
+    else {
+      op.ngroups = (int32_t)groups.size();
+      for (size_t j = 0; j < groups.size(); ++j) op.glo[j] = (uint32_t)groups[j];
+    }
+  }
+  op.ndt = diag_mode == 2 ? (int32_t)dt_sign.size() : 0;
+  // dispatch order: workgroups that gather from each other run on one XCD at one time (their requests meet in that
+  // XCD's L2).  lo pass: groups (kt, cw, wr) over the T's of a popcount class; window pass: (kt, cw, run) likewise.
+  std::vector<std::vector<uint32_t>> Tby(t + 1), gA, gB;
+  for (uint32_t T = 0; T < (1u << t); ++T) if (ly->ibase[T] >= 0) Tby[__builtin_popcount(T)].push_back(T);
+  for (int kt = 0; kt <= t; ++kt) {
+    if (Tby[kt].empty()) continue;
+    const int kr = k - kt;
+    for (int cw = 0; cw <= w; ++cw) {
+      const int kl = kr - cw;
+      if (kl < 0 || kl > a) continue;
+      for (int wr = 0; wr < S.nw[cw]; ++wr) {
+        std::vector<uint32_t> g;
+        for (uint32_t T : Tby[kt]) g.push_back((T << w) | ly->w_pat[S.w_off[cw] + wr]);
+        gA.push_back(g);
+      }
+      const int Rr = 16 << S.rs[cw], nrun = (S.pitch[kl] + Rr - 1) / Rr;
+      DNM_CHECK(nrun < 4096, "internal: too many runs");
+      for (int run = 0; run < nrun; ++run) {
+        std::vector<uint32_t> g;
+        for (uint32_t T : Tby[kt]) g.push_back((T << 16) | (cw << 12) | run);
+        gB.push_back(g);
+      }
+    }
+  }
+  permA = deal(gA);
+  permB = deal(gB);
+  if (want_device) {
+    DNM_TRY(up(permA, &d_permA)); DNM_TRY(up(permB, &d_permB)); DNM_TRY(up(bond, &d_bond));
+    op.bond = (const double *)d_bond;
+    if (diag_mode == 2) {
+      DNM_TRY(up(dlo, &d_dlo)); DNM_TRY(up(dt_sign, &d_dt_sign)); DNM_TRY(up(dt_coef, &d_dt_coef));
+      DNM_TRY(up(dt_group, &d_dt_group));
+      op.dlo = (const double *)d_dlo; op.dt_sign = (const uint64_t *)d_dt_sign;
+      op.dt_coef = (const double *)d_dt_coef; op.dt_group = (const int32_t *)d_dt_group;
+    }
+  }
+  return 0;
+}
+
+template <int A, int W, int NT>
+static int launch_two_pass(const Sc3Mat &M, const Sc3Call &call, const double *cached_diag, const void *xw, void *y,
+                           hipStream_t st) {
+  const Sc3Tab &S = M.ly->dev;
+  constexpr size_t ldsA = (size_t)cbinom(A, A / 2) * 16, ldsB = (size_t)cbinom(W, W / 2) * 16 * 16;
+  Sc3Op op = M.op;
+  const int dm = M.diag_mode;       // 2: on the fly whether or not a cached copy exists (8 B/row less to read)
+  if (dm == 1) op.diag = cached_diag;
+  DNM_CHECK(dm != 1 || op.diag, "this operator needs its diagonal precomputed (dnm_mat_precompute_diagonal)");
+  using kern_t = void (*)(const Sc3Tab, const Sc3Op, const uint32_t *, const Sc3Call, const c128 *, c128 *);
+  const kern_t kB = M.sym ? sc3_win_pass<W, NT, true> : sc3_win_pass<W, NT, false>;
+  kern_t kA = nullptr;
+  switch (dm * 2 + (M.sym ? 1 : 0)) {
+    case 0: kA = sc3_lo_pass<A, NT, 0, false>; break;
+    case 1: kA = sc3_lo_pass<A, NT, 0, true>; break;
+    case 2: kA = sc3_lo_pass<A, NT, 1, false>; break;
+    case 3: kA = sc3_lo_pass<A, NT, 1, true>; break;
+    case 4: kA = sc3_lo_pass<A, NT, 2, false>; break;
+    default: kA = sc3_lo_pass<A, NT, 2, true>; break;
+  }
+  static std::map<const void *, bool> attr_done;
+  for (auto kp : {std::make_pair((const void *)kA, ldsA), std::make_pair((const void *)kB, ldsB)})
+    if (!attr_done[kp.first]) {
+      DNM_HIP(hipFuncSetAttribute(kp.first, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kp.second));
+      attr_done[kp.first] = true;
+    }
+  Sc3Call first = call, second = call;
+  first.dot_out = nullptr;
+  second.zinit = nullptr;
+  second.zinit2 = nullptr;
+  hipLaunchKernelGGL(kB, dim3((unsigned)M.permB.size()), dim3(NT), ldsB, st, S, op, (const uint32_t *)M.d_permB, first,
+                     (const c128 *)xw, (c128 *)y);
+  hipLaunchKernelGGL(kA, dim3((unsigned)M.permA.size()), dim3(NT), ldsA, st, S, op, (const uint32_t *)M.d_permA, second,
+                     (const c128 *)xw, (c128 *)y);
+  DNM_HIP(hipGetLastError());
+  return 0;
+}
+
+size_t sc3_dot_partials(const Sc3Mat &M) { return M.permA.size(); }
+
+int launch_sc3(const Sc3Mat &M, const DevMsc &msc, const Sc3Call &call, const double *cached_diag, const void *xw,
+               void *y, hipStream_t st) {
+  DNM_CHECK(M.ly && M.ly->on_device, "layout tables are not on the device");
+  if (M.tiled) {
+    if (call.dot_out) DNM_HIP(hipMemsetAsync(call.dot_out, 0, M.permA.size() * 3 * sizeof(double), st));
+    if (M.ly->host.a == 14) return launch_two_pass<14, 10, 1024>(M, call, cached_diag, xw, y, st);
+    return launch_two_pass<6, 4, 64>(M, call, cached_diag, xw, y, st);
+  }
+  DNM_CHECK(!call.dot_out, "internal: the row kernel has no fused sums");
+  hipLaunchKernelGGL(sc3_row_kernel, dim3((unsigned)M.ly->rows.size()), dim3(SC3_ROW_NT), 0, st, M.ly->dev, msc,
+                     (const uint32_t *)M.ly->d_rows, call, cached_diag, (const c128 *)xw, (c128 *)y);
+  DNM_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace dnm

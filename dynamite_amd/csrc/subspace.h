@@ -31,7 +31,8 @@ struct SubView {
   // are rmap_states[bucket[b] .. bucket[b+1]); the search of S2I starts inside one bucket
   const int64_t *bucket;
   int32_t bucket_shift;
-  int32_t swz;               // vector layout (dnm_subspace::vec_swizzle)
+  int32_t swz;               // vector layout of Full / Parity (dnm_subspace::vec_swizzle): XOR-swizzle shift
+  int32_t sc3;               // vector layout of SpinConserve: a | w << 8 (sc3.h), 0 = reference order
 };
 
 // position of element i of a vector in the XOR-swizzled layout (S = 0: index order)

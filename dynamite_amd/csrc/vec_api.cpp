@@ -1,5 +1,6 @@
 // C ABI for the vector kernels (PETSc Vec / SLEPc BV replacements).
 #include "vec_api.h"
+#include "sc3.h"
 
 #include <vector>
 
@@ -114,6 +115,80 @@ int dnm_vec_swizzle_copy(void *dst, const void *src, int64_t n, int swizzle, voi
   DNM_CHECK(dst != src, "dnm_vec_swizzle_copy works out of place");
   DNM_CHECK(swizzle == 0 || (swizzle >= 5 && swizzle <= 24), "swizzle shift %d out of range", swizzle);
   return vk_swizzle_copy(dst, src, n, swizzle, S(stream));
+}
+
+// ---- SpinConserve internal layout (sc3.h) ----------------------------------------------------------------
+static const Sc3Layout *layout_of(const dnm_subspace *s, bool device) {
+  if (!s || s->type != DNM_SPIN_CONSERVE || s->vec_swizzle == 0) {
+    set_error("not a SpinConserve subspace with an internal vector layout");
+    return nullptr;
+  }
+  const int a = sc3_code_a(s->vec_swizzle), w = sc3_code_w(s->vec_swizzle);
+  if (!sc3_valid((int)s->L, (int)s->k, a, w)) {
+    set_error("no such vector layout: L=%d k=%d a=%d w=%d", (int)s->L, (int)s->k, a, w);
+    return nullptr;
+  }
+  return sc3_get((int)s->L, (int)s->k, a, w, device);
+}
+
+int dnm_vec_layout_size(const dnm_subspace *s, int64_t *n) {
+  DNM_CHECK(n, "null argument");
+  const Sc3Layout *ly = layout_of(s, false);
+  if (!ly) return 1;
+  *n = ly->host.nint;
+  return 0;
+}
+
+int dnm_vec_layout_copy(const dnm_subspace *s, void *dst, const void *src, int to_internal, void *stream) {
+  DNM_CHECK(dst && src && dst != src, "dnm_vec_layout_copy works out of place on non-null vectors");
+  const Sc3Layout *ly = layout_of(s, true);
+  if (!ly) return 1;
+  return sc3_layout_copy(*ly, dst, src, to_internal != 0, S(stream));
+}
+
+int dnm_vec_layout_copy_f64(const dnm_subspace *s, double *dst, const double *src, int to_internal, void *stream) {
+  DNM_CHECK(dst && src && dst != src, "dnm_vec_layout_copy_f64 works out of place on non-null arrays");
+  const Sc3Layout *ly = layout_of(s, true);
+  if (!ly) return 1;
+  return sc3_layout_copy_f64(*ly, dst, src, to_internal != 0, S(stream));
+}
+
+int dnm_vec_layout_zero_padding(const dnm_subspace *s, void *x, void *stream) {
+  DNM_CHECK(x, "null vector");
+  const Sc3Layout *ly = layout_of(s, true);
+  if (!ly) return 1;
+  return sc3_zero_padding(*ly, x, S(stream));
+}
+
+int dnm_vec_layout_positions(const dnm_subspace *s, int64_t n, const int64_t *idx, int64_t *pos, void *stream) {
+  DNM_CHECK(n == 0 || (idx && pos), "null argument");
+  const Sc3Layout *ly = layout_of(s, true);
+  if (!ly) return 1;
+  return sc3_positions(*ly, n, idx, pos, S(stream));
+}
+
+int dnm_vec_layout_positions_host(const dnm_subspace *s, int64_t n, const int64_t *idx, int64_t *pos) {
+  DNM_CHECK(n == 0 || (idx && pos), "null argument");
+  const Sc3Layout *ly = layout_of(s, false);
+  if (!ly) return 1;
+  SubView v{};
+  v.type = DNM_SPIN_CONSERVE;
+  v.L = ly->host.L;
+  v.k = ly->host.k;
+  v.ld = ly->host.L + 1;
+  v.nchoosek = ly->host.nck;
+  for (int64_t i = 0; i < n; ++i) {
+    DNM_CHECK(idx[i] >= 0 && idx[i] < ly->dim, "index %lld out of range", (long long)idx[i]);
+    pos[i] = sc3_pos((uint64_t)Sub<DNM_SPIN_CONSERVE>::i2s(idx[i], v), ly->host);
+  }
+  return 0;
+}
+
+int dnm_vec_layout_set_random(const dnm_subspace *s, void *x, uint64_t seed, void *stream) {
+  DNM_CHECK(x, "null vector");
+  const Sc3Layout *ly = layout_of(s, true);
+  if (!ly) return 1;
+  return sc3_random(*ly, x, seed, S(stream));
 }
 
 int dnm_vec_set_random(void *x, int64_t n, uint64_t seed, int64_t offset, void *stream) {

@@ -4,6 +4,7 @@
 // counter-based normal generator.  All are HBM-streaming; 16 B per lane,
 // grid-stride, deterministic two-stage reductions (no atomics).
 #include "kernels.h"
+#include "philox.h"
 
 namespace dnm {
 
@@ -75,35 +76,12 @@ int vk_axpby(void *y, const void *x, int64_t n, double are, double aim, double b
   return 0;
 }
 
-// ---- Philox-4x32-10 counter-based generator --------------------------------
-__device__ __forceinline__ void philox_round(uint32_t &c0, uint32_t &c1, uint32_t &c2, uint32_t &c3,
-                                             uint32_t k0, uint32_t k1) {
-  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
-  uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
-  uint32_t hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
-  uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
-  c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-}
-
+// ---- Philox-4x32-10 counter-based generator (philox.h) -----------------------
 __global__ void __launch_bounds__(VNT)
 random_kernel(c128 *x, int64_t n, uint64_t seed, int64_t offset, int swz) {
   for (int64_t i = (int64_t)blockIdx.x * VNT + threadIdx.x; i < n; i += (int64_t)gridDim.x * VNT) {
     uint64_t ctr = (uint64_t)(offset + vec_pos(i, swz));     // the element stored at position i (involution)
-    uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = 0x243F6A88u, c3 = 0x85A308D3u;
-    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-      philox_round(c0, c1, c2, c3, k0, k1);
-      k0 += 0x9E3779B9u;
-      k1 += 0xBB67AE85u;
-    }
-    // two uniforms in (0,1] and [0,1) from 53 bits each -> Box-Muller pair
-    double u1 = ((double)((((uint64_t)c0 << 32) | c1) >> 11) + 1.0) * (1.0 / 9007199254740992.0);
-    double u2 = (double)((((uint64_t)c2 << 32) | c3) >> 11) * (1.0 / 9007199254740992.0);
-    double rad = sqrt(-2.0 * log(u1));
-    double s, c;
-    sincospi(2.0 * u2, &s, &c);
-    x[i] = make_double2(rad * c, rad * s);
+    x[i] = philox_normal(ctr, seed);
   }
 }
 

@@ -58,7 +58,8 @@ class State:
         if self._vec is None:
             if self.L is None:
                 raise ValueError('must set L first')
-            self._vec = Vec(self.subspace.get_dimension(), swz=self.subspace.vec_swizzle)
+            swz = self.subspace.vec_swizzle
+            self._vec = Vec(self.subspace.get_dimension(), swz=swz, sub_c=self.subspace._c() if swz >= 256 else None)
         return self._vec
 
     @property
@@ -133,13 +134,13 @@ class State:
             except NotImplementedError:
                 seed = int(time())
         if device_rng is None:
-            device_rng = v.local_size > (1 << 26)
+            device_rng = v.rows > (1 << 26)
         if device_rng:
             v.set_random(seed)
         else:
             R = np.random.RandomState()
             R.seed((seed + config.rank) % 2 ** 32)
-            n = v.local_size
+            n = v.rows
             v.set_local_from_numpy(R.standard_normal(n) + 1j * R.standard_normal(n))
         if normalize:
             v.normalize()

@@ -106,7 +106,8 @@ class Subspace:
         """ctypes dnm_subspace (kept alive together with its numpy buffers)."""
         if self.L is None:
             raise ValueError('L has not been set for this subspace')
-        if self._cdesc is None:
+        if self._cdesc is None or self._cdesc.vec_swizzle != self.vec_swizzle:
+            # (the layout is part of the descriptor: rebuilt if the process state it derives from has changed)
             self._cdesc = self._descriptor()
         return self._cdesc
 
@@ -274,7 +275,21 @@ class SpinConserve(Subspace):
         d.type, d.L, d.k = SPIN_CONSERVE, self.L, self.k
         d.ld_nchoosek = self.L + 1
         d.nchoosek = _lib.p64(self._nchoosek)
+        d.vec_swizzle = self.vec_swizzle
         return d
+
+    @property
+    def vec_swizzle(self):
+        """Layout of this subspace's state vectors (dnm_subspace.vec_swizzle): a | w << 8 for the three-field
+        internal layout of csrc/sc3.h (one rank, large subspaces), 0 for the reference's index order."""
+        from .config import config
+        lay = config.sc_layout
+        if not lay or config.world_size > 1 or self.L is None:
+            return 0
+        a, w = lay
+        if self.L - a - w < 1 or math.comb(self.L, self.k) < config.sc_layout_min_dim:
+            return 0
+        return a | (w << 8)
 
 
 class Explicit(Subspace):
@@ -524,4 +539,6 @@ class XParity(Subspace):
 
     @property
     def vec_swizzle(self):
-        return self.parent.vec_swizzle
+        # an XParity vector is the first half of the parent's in reference order: Full / Parity parents keep their
+        # swizzle (it acts on the local index), a SpinConserve parent's internal layout does not apply
+        return 0 if isinstance(self.parent, SpinConserve) else self.parent.vec_swizzle

@@ -75,7 +75,12 @@ typedef struct dnm_subspace {
    * element i is at position  i ^ (((i >> S) & (2^(S-4) - 1)) << 4)  -- index bits [S, 2S-4) folded onto bits
    * [4, S), an involution that keeps 256-byte runs together.  The far-apart runs of the tiled multiply's window
    * passes then spread over the L2 sets.  Every dnm_* call that takes a vector of this
-   * subspace expects this layout; dnm_vec_swizzle_copy converts to and from index order. */
+   * subspace expects this layout; dnm_vec_swizzle_copy converts to and from index order.
+   * SpinConserve: 0 or a | w << 8 (a low bits, w window bits): the three-field internal layout of
+   * dynamite_amd/csrc/sc3.h -- the blocks of equal top bits T = state >> (a + w) stay where the reference order has
+   * them, inside a block the rows (T, W) are grouped by popcount(W), ordered by the rank of W, and padded to 128-byte
+   * lines (padding holds zeros): a vector then has dnm_vec_layout_size() elements instead of C(L, k).  The two-pass
+   * SpinConserve multiply works in this layout; dnm_vec_layout_copy / _positions convert.  One rank only. */
   int32_t vec_swizzle;
 } dnm_subspace;
 
@@ -159,6 +164,11 @@ int dnm_mat_mult(dnm_mat *A, const void *x, void *y, void *stream);
  * max-reduces over ranks (MPIU_Allreduce(MAX), bpetsc_template_2.c:975) and
  * stores it back with dnm_mat_set_norm. */
 int dnm_mat_norm_inf(dnm_mat *A, double *nrm, void *stream);
+/* The vector layouts the matrix works in (dnm_subspace.vec_swizzle codes): what the descriptors asked for when the
+ * matrix supports it, 0 (reference order) otherwise -- e.g. a SpinConserve descriptor with the internal layout paired
+ * with another subspace, under XParity, or on several ranks.  The caller converts (dnm_vec_layout_copy) when a
+ * vector's layout differs.  With an internal layout dnm_mat_sizes reports the local lengths incl. padding. */
+int dnm_mat_layouts(const dnm_mat *A, int *left, int *right);
 int dnm_mat_set_norm(dnm_mat *A, double nrm);
 /* human-readable description of the execution plan (passes, tiles) */
 int dnm_mat_plan_describe(const dnm_mat *A, char *buf, size_t buflen);
@@ -256,6 +266,19 @@ int dnm_vec_set_random(void *x, int64_t n, uint64_t seed, int64_t offset, void *
 int dnm_vec_set_random_swz(void *x, int64_t n, uint64_t seed, int64_t offset, int swizzle, void *stream);
 /* dst[i] = src[i ^ sw(i)]: swizzled <-> index order (the map is an involution); dst != src */
 int dnm_vec_swizzle_copy(void *dst, const void *src, int64_t n, int swizzle, void *stream);
+/* Vectors of a SpinConserve subspace in the internal layout (dnm_subspace.vec_swizzle = a | w << 8).  No counterpart
+ * in the reference: what a petsc4py Vec of that subspace holds, element by element, is reached through these.
+ * size: elements of a vector (rows + padding); copy: to_internal != 0: dst (internal) <- src (reference order, C(L,k)
+ * elements), else dst (reference order) <- src (internal), dst != src; zero_padding: after an operation that wrote
+ * the padding (VecSet, VecShift); positions: pos[i] = where reference index idx[i] lives (device arrays of n int64);
+ * set_random: the numbers dnm_vec_set_random gives reference order, padding zero. */
+int dnm_vec_layout_size(const dnm_subspace *s, int64_t *n);
+int dnm_vec_layout_copy(const dnm_subspace *s, void *dst, const void *src, int to_internal, void *stream);
+int dnm_vec_layout_copy_f64(const dnm_subspace *s, double *dst, const double *src, int to_internal, void *stream);
+int dnm_vec_layout_zero_padding(const dnm_subspace *s, void *x, void *stream);
+int dnm_vec_layout_positions(const dnm_subspace *s, int64_t n, const int64_t *idx, int64_t *pos, void *stream);
+int dnm_vec_layout_positions_host(const dnm_subspace *s, int64_t n, const int64_t *idx, int64_t *pos);  /* host arrays */
+int dnm_vec_layout_set_random(const dnm_subspace *s, void *x, uint64_t seed, void *stream);
 /* h[j] = V_j^H w for j < nv (BVDotVec); V = nv vectors of length n, stride ldv elements.
  * h_host: 2*nv doubles. */
 int dnm_vec_mdot(const void *V, int64_t ldv, int nv, const void *w, int64_t n,

@@ -40,11 +40,18 @@ def shell(H, left, right=None, flags=0):
     return backend.build_mat(*m, left._to_c(), right._to_c(), flags=flags)
 
 
-def vec_from(arr, swz=0):
-    """Device vector holding ``arr`` (index order) in the layout ``swz`` (dnm_subspace.vec_swizzle)."""
-    v = backend.Vec(arr.size, swz=swz)
+def vec_from(arr, swz=0, sub_c=None):
+    """Device vector holding ``arr`` (index order) in the layout ``swz`` (dnm_subspace.vec_swizzle; the SpinConserve
+    internal layout also needs the subspace descriptor)."""
+    v = backend.Vec(arr.size, swz=swz, sub_c=sub_c)
     v.set_local_from_numpy(arr)
     return v
+
+
+def vec_for(sub):
+    """Zero vector of the subspace in the layout its states take."""
+    swz = sub.vec_swizzle
+    return backend.Vec(sub.get_dimension(), swz=swz, sub_c=sub._c() if swz >= 256 else None)
 
 
 def partner_slice(xl, off, cnt):
@@ -54,8 +61,8 @@ def partner_slice(xl, off, cnt):
 
 
 def mult_numpy(mat, x):
-    xv = vec_from(x, mat.swz_right)
-    yv = backend.Vec(mat.M, swz=mat.swz_left)
+    xv, yv = mat.createVecs()
+    xv.set_local_from_numpy(x)
     yv.set(777.0)          # the multiply must overwrite, not accumulate
     mat.mult(xv, yv)
     return yv.local_numpy()

@@ -431,13 +431,13 @@ def test_spinconserve_large_properties():
     L, k = 28, 14
     H = models.mbl(L)
     sub = SpinConserve(L, k)
-    n = sub.get_dimension()
-    a, b, Ha, Hb, Hg = (backend.Vec(n) for _ in range(5))
+    from gpu_util import vec_for
+    a, b, Ha, Hb, Hg = (vec_for(sub) for _ in range(5))      # in the layout the subspace's states take
     a.set_random(1); b.set_random(2)
     a.normalize(); b.normalize()
     mat = shell(H, sub)
-    matg = shell(H, sub, flags=_lib.MAT_FORCE_GATHER)
-    assert "SpinConserve kernel" in mat.describe() and "row-gather" in matg.describe()
+    matg = shell(H, sub, flags=_lib.MAT_FORCE_GATHER)        # works in reference order: vectors are converted
+    assert "SpinConserve" in mat.describe() and "row-gather" in matg.describe()
     mat.mult(a, Ha)
     matg.mult(a, Hg)
     Hg.axpby(-1.0, 1.0, Ha)

@@ -16,7 +16,7 @@
 //   Which pass gathers which of the non-LDS bonds is a bit mask (bondsA / bondsB).
 //
 // Build / run (GPU box):  hipcc --offload-arch=gfx950 -O3 tools/experiments/sc3_proto.hip -o /tmp/sc3_proto
-//                         /tmp/sc3_proto L k [a w orderA orderB tInA accA reps ntA ntB nbA nbB t1]
+//                         /tmp/sc3_proto L k [a w orderA orderB tInA accA reps ntA ntB nbA nbB t1 variant]
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -46,6 +46,9 @@ struct Sc3 {
   const int32_t *cbin;             // [17 * 17] C(n, j)
   const double *bond;              // [(L-1) * 4] up_re, up_im, dn_re, dn_im
   const double *diag;              // internal layout, or null
+  const double *dlo;               // on-the-fly diagonal: the part that depends on Lo only, indexed like lo_pat
+  const double *hfield;            // [L] field term of a site (+h for a zero bit, -h for a one)
+  double zz;                       // ZZ coupling of every bond
   uint64_t bondsA, bondsB;         // non-LDS bonds gathered by the lo pass / the window pass
 };
 
@@ -74,8 +77,11 @@ constexpr int cbinom(int n, int k) {
 
 // ---------------------------------------------------------------------------------------------------------
 // lo pass: one workgroup per row (T, W)
-template <int A, int NT, int NB, bool ACC, bool DIAG>
-__global__ void __launch_bounds__(NT, NT >= 1024 ? 8 : 4)
+// DIAGM: 0 no diagonal, 1 cached (8 B/row), 2 on the fly (table over Lo + per-row scalar + boundary bond)
+// SYM: every bond coefficient is real and the same in both directions; EARLY: first gathers issued before the tile
+// is waited for
+template <int A, int NT, int NB, bool ACC, int DIAGM, bool SYM, bool EARLY>
+__global__ void __launch_bounds__(NT, (2048 / NT) * NT / 256)
 sc3_lo_pass(const Sc3 S, const uint32_t *__restrict__ perm, const c128 *__restrict__ x, c128 *__restrict__ y) {
   constexpr int MAXROWS = cbinom(A, A / 2);
   constexpr int RPT = (MAXROWS + NT - 1) / NT;
@@ -165,24 +171,11 @@ sc3_lo_pass(const Sc3 S, const uint32_t *__restrict__ perm, const c128 *__restri
     cl[tt] = S.cbin[lo * 17 + o];
   }
   double accr[RPT], acci[RPT];
-#pragma unroll
-  for (int i = 0; i < RPT; ++i) {
-    const int r = threadIdx.x + i * NT;
-    accr[i] = 0.0;
-    acci[i] = 0.0;
-    if (r < nrows) {
-      xs[r] = xv[i];
-      if (DIAG) {
-        const double dg = __builtin_nontemporal_load(S.diag + base + r);
-        accr[i] = dg * xv[i].x;
-        acci[i] = dg * xv[i].y;
-      }
-    }
-  }
-  while (hb) {
-    const c128 *__restrict__ pp[NB];
-    double cr[NB], ci[NB];
-    int q0[NB], q1[NB];
+  const c128 *__restrict__ pp[NB];
+  double cr[NB], ci[NB];
+  int q0[NB], q1[NB];
+  c128 v[NB][RPT];
+  auto setup = [&]() {
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       const bool have = hb != 0;
@@ -194,7 +187,8 @@ sc3_lo_pass(const Sc3 S, const uint32_t *__restrict__ perm, const c128 *__restri
       q0[j] = rl_i32(r0, m);
       q1[j] = have ? rl_i32(r1, m) : 0;
     }
-    c128 v[NB][RPT];
+  };
+  auto issue = [&]() {
 #pragma unroll
     for (int i = 0; i < RPT; ++i) {
       const int r = threadIdx.x + i * NT;
@@ -204,17 +198,58 @@ sc3_lo_pass(const Sc3 S, const uint32_t *__restrict__ perm, const c128 *__restri
         if (r >= q0[j] && r < q1[j]) v[j][i] = pp[j][r];
       }
     }
+  };
+  auto consume = [&]() {
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
 #pragma unroll
       for (int i = 0; i < RPT; ++i) {
         accr[i] = fma(cr[j], v[j][i].x, accr[i]);
         acci[i] = fma(cr[j], v[j][i].y, acci[i]);
-        accr[i] = fma(-ci[j], v[j][i].y, accr[i]);
-        acci[i] = fma(ci[j], v[j][i].x, acci[i]);
+        if (!SYM) {
+          accr[i] = fma(-ci[j], v[j][i].y, accr[i]);
+          acci[i] = fma(ci[j], v[j][i].x, acci[i]);
+        }
+      }
+    }
+  };
+  const bool any = hb != 0;
+  if (EARLY && any) { setup(); issue(); }
+  // on-the-fly diagonal: the part of the row (T, W): fields and bonds above Lo, one site per lane
+  double dhi = 0.0;
+  if (DIAGM == 2) {
+    const uint64_t hi = ((uint64_t)T << w) | W;
+    const int site = A + lane;
+    double term = 0.0;
+    if (site < S.L) {
+      const uint32_t bit = (uint32_t)(hi >> lane) & 1u;
+      term = bit ? -S.hfield[site] : S.hfield[site];
+      if (site + 1 < S.L) term += (bit ^ ((uint32_t)(hi >> (lane + 1)) & 1u)) ? -S.zz : S.zz;
+    }
+    for (int off = 32; off > 0; off >>= 1) term += __shfl_xor(term, off, 64);
+    dhi = rl_f64(term, 0);
+  }
+#pragma unroll
+  for (int i = 0; i < RPT; ++i) {
+    const int r = threadIdx.x + i * NT;
+    accr[i] = 0.0;
+    acci[i] = 0.0;
+    if (r < nrows) {
+      xs[r] = xv[i];
+      if (DIAGM == 1) {
+        const double dg = __builtin_nontemporal_load(S.diag + base + r);
+        accr[i] = dg * xv[i].x;
+        acci[i] = dg * xv[i].y;
+      } else if (DIAGM == 2) {
+        // Lo part from the table (L2-resident), the bond across the boundary from the top bit of Lo and bit 0 of W
+        const double dg = S.dlo[S.lo_off[kl] + r] + dhi + ((((lowb[i] >> (A - 1)) ^ W) & 1u) ? -S.zz : S.zz);
+        accr[i] = dg * xv[i].x;
+        acci[i] = dg * xv[i].y;
       }
     }
   }
+  if (EARLY && any) consume();
+  while (hb) { setup(); issue(); consume(); }
   __syncthreads();
   for (int lo = 0; lo < A - 1; ++lo) {
     const double ure = S.bond[4 * lo], uim = S.bond[4 * lo + 1], dre = S.bond[4 * lo + 2], dim_ = S.bond[4 * lo + 3];
@@ -227,11 +262,16 @@ sc3_lo_pass(const Sc3 S, const uint32_t *__restrict__ perm, const c128 *__restri
         const int ord0 = __popc(lowb[i] & ((1u << lo) - 1u));
         const int d = cl[lo * (A + 1) + ord0];
         const c128 xp = xs[up ? r + d : r - d];
-        const double cre = up ? ure : dre, cim = up ? uim : dim_;
-        accr[i] = fma(cre, xp.x, accr[i]);
-        acci[i] = fma(cre, xp.y, acci[i]);
-        accr[i] = fma(-cim, xp.y, accr[i]);
-        acci[i] = fma(cim, xp.x, acci[i]);
+        if (SYM) {
+          accr[i] = fma(ure, xp.x, accr[i]);
+          acci[i] = fma(ure, xp.y, acci[i]);
+        } else {
+          const double cre = up ? ure : dre, cim = up ? uim : dim_;
+          accr[i] = fma(cre, xp.x, accr[i]);
+          acci[i] = fma(cre, xp.y, acci[i]);
+          accr[i] = fma(-cim, xp.y, accr[i]);
+          acci[i] = fma(cim, xp.x, acci[i]);
+        }
       }
     }
   }
@@ -252,8 +292,8 @@ sc3_lo_pass(const Sc3 S, const uint32_t *__restrict__ perm, const c128 *__restri
 
 // ---------------------------------------------------------------------------------------------------------
 // window pass: one workgroup per (T, cw, run of R = 16 << s columns): all window patterns of the class
-template <int WB, int NT, int NB, bool ACC, bool DIAG>
-__global__ void __launch_bounds__(NT, NT >= 1024 ? 8 : 4)
+template <int WB, int NT, int NB, bool ACC, int DIAGM, bool SYM, bool EARLY>
+__global__ void __launch_bounds__(NT, (2048 / NT) * NT / 256)
 sc3_win_pass(const Sc3 S, const uint32_t *__restrict__ perm, const c128 *__restrict__ x, c128 *__restrict__ y) {
   constexpr int MAXE = cbinom(WB, WB / 2) * 16;
   constexpr int RPT = (MAXE + NT - 1) / NT;
@@ -334,24 +374,11 @@ sc3_win_pass(const Sc3 S, const uint32_t *__restrict__ perm, const c128 *__restr
     cl[tt] = S.cbin[lo * 17 + o];
   }
   double accr[RPT], acci[RPT];
-#pragma unroll
-  for (int i = 0; i < RPT; ++i) {
-    const int en = threadIdx.x + i * NT;
-    accr[i] = 0.0;
-    acci[i] = 0.0;
-    if (en < nent) {
-      xs[en] = xv[i];
-      if (DIAG && off[i] >= 0) {
-        const double dg = __builtin_nontemporal_load(S.diag + cbase + off[i]);
-        accr[i] = dg * xv[i].x;
-        acci[i] = dg * xv[i].y;
-      }
-    }
-  }
-  while (hb) {
-    const c128 *__restrict__ pp[NB];
-    double cr[NB], ci[NB];
-    int q0[NB], q1[NB];
+  const c128 *__restrict__ pp[NB];
+  double cr[NB], ci[NB];
+  int q0[NB], q1[NB];
+  c128 v[NB][RPT];
+  auto setup = [&]() {
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       const bool have = hb != 0;
@@ -363,7 +390,8 @@ sc3_win_pass(const Sc3 S, const uint32_t *__restrict__ perm, const c128 *__restr
       q0[j] = rl_i32(r0, m);
       q1[j] = have ? rl_i32(r1, m) : 0;
     }
-    c128 v[NB][RPT];
+  };
+  auto issue = [&]() {
 #pragma unroll
     for (int i = 0; i < RPT; ++i) {
       const int wrr = (int)(wpat[i] >> 16);
@@ -373,17 +401,39 @@ sc3_win_pass(const Sc3 S, const uint32_t *__restrict__ perm, const c128 *__restr
         if (off[i] >= 0 && wrr >= q0[j] && wrr < q1[j]) v[j][i] = pp[j][off[i]];
       }
     }
+  };
+  auto consume = [&]() {
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
 #pragma unroll
       for (int i = 0; i < RPT; ++i) {
         accr[i] = fma(cr[j], v[j][i].x, accr[i]);
         acci[i] = fma(cr[j], v[j][i].y, acci[i]);
-        accr[i] = fma(-ci[j], v[j][i].y, accr[i]);
-        acci[i] = fma(ci[j], v[j][i].x, acci[i]);
+        if (!SYM) {
+          accr[i] = fma(-ci[j], v[j][i].y, accr[i]);
+          acci[i] = fma(ci[j], v[j][i].x, acci[i]);
+        }
+      }
+    }
+  };
+  const bool any = hb != 0;
+  if (EARLY && any) { setup(); issue(); }
+#pragma unroll
+  for (int i = 0; i < RPT; ++i) {
+    const int en = threadIdx.x + i * NT;
+    accr[i] = 0.0;
+    acci[i] = 0.0;
+    if (en < nent) {
+      xs[en] = xv[i];
+      if (DIAGM == 1 && off[i] >= 0) {
+        const double dg = __builtin_nontemporal_load(S.diag + cbase + off[i]);
+        accr[i] = dg * xv[i].x;
+        acci[i] = dg * xv[i].y;
       }
     }
   }
+  if (EARLY && any) consume();
+  while (hb) { setup(); issue(); consume(); }
   __syncthreads();
   for (int lo = 0; lo < WB - 1; ++lo) {
     const int b = S.a + lo;
@@ -397,11 +447,16 @@ sc3_win_pass(const Sc3 S, const uint32_t *__restrict__ perm, const c128 *__restr
         const int ord0 = __popc(wpat[i] & ((1u << lo) - 1u));
         const int d = cl[lo * (WB + 1) + ord0] << sh;
         const c128 xp = xs[up ? en + d : en - d];
-        const double cre = up ? ure : dre, cim = up ? uim : dim_;
-        accr[i] = fma(cre, xp.x, accr[i]);
-        acci[i] = fma(cre, xp.y, acci[i]);
-        accr[i] = fma(-cim, xp.y, accr[i]);
-        acci[i] = fma(cim, xp.x, acci[i]);
+        if (SYM) {
+          accr[i] = fma(ure, xp.x, accr[i]);
+          acci[i] = fma(ure, xp.y, acci[i]);
+        } else {
+          const double cre = up ? ure : dre, cim = up ? uim : dim_;
+          accr[i] = fma(cre, xp.x, accr[i]);
+          acci[i] = fma(cre, xp.y, acci[i]);
+          accr[i] = fma(-cim, xp.y, accr[i]);
+          acci[i] = fma(cim, xp.x, acci[i]);
+        }
       }
     }
   }
@@ -416,6 +471,25 @@ sc3_win_pass(const Sc3 S, const uint32_t *__restrict__ perm, const c128 *__restr
       }
       store_nt(y + cbase + off[i], ar, ai);
     }
+  }
+}
+
+// timing runs: x and a stand-in diagonal filled on the device, row by row (padding zero)
+__global__ void __launch_bounds__(256) sc3_fill(const Sc3 S, const uint32_t *__restrict__ perm, c128 *__restrict__ x,
+                                                double *__restrict__ diag) {
+  const uint32_t e = perm[blockIdx.x];
+  if (e == 0xffffffffu) return;
+  const int w = S.w;
+  const uint32_t T = e >> w, W = e & ((1u << w) - 1u);
+  const int cw = __popc(W), kr = S.k - __popc(T), kl = kr - cw;
+  const int nrows = S.nl[kl], p = S.pitch[kl];
+  const int64_t base = S.ibase[T] + S.icoff[kr * (w + 1) + cw] + (int64_t)S.w_rank[W] * p;
+  for (int r = threadIdx.x; r < p; r += 256) {
+    const uint64_t z = ((uint64_t)(base + r) * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)(base + r) >> 17);
+    const bool live = r < nrows;
+    x[base + r] = live ? make_double2((double)(z & 0xffff) / 65536.0 - 0.5, (double)((z >> 16) & 0xffff) / 65536.0 - 0.5)
+                       : make_double2(0.0, 0.0);
+    diag[base + r] = live ? (double)((z >> 32) & 0xff) / 64.0 - 2.0 : 0.0;
   }
 }
 
@@ -681,13 +755,12 @@ int main(int argc, char **argv) {
     for (int pbit = 0; pbit < a; ++pbit) if ((Lo >> pbit) & 1) { ++o; lr += binom(pbit, o); }
     return ibase[T] + icoff[kr * (w + 1) + cw] + (int64_t)w_rank[W] * S.pitch[kl] + lr;
   };
-  {
+  if (check) {
     hx.assign(nint, make_double2(0.0, 0.0));
     hdiag.assign(nint, 0.0);
-    if (check) state_of.assign(nint, ~0ull);
+    state_of.assign(nint, ~0ull);
     std::mt19937_64 r2(7);
     std::normal_distribution<double> N01(0.0, 1.0);
-    const auto t0 = std::chrono::steady_clock::now();
     for (uint32_t T = 0; T < (1u << t); ++T) {
       if (ibase[T] < 0) continue;
       const int kr = k - __builtin_popcount(T);
@@ -696,41 +769,60 @@ int main(int argc, char **argv) {
         if (kl < 0 || kl > a) continue;
         const int64_t rb = ibase[T] + icoff[kr * (w + 1) + cw] + (int64_t)w_rank[W] * S.pitch[kl];
         const uint64_t hi = ((uint64_t)T << (a + w)) | ((uint64_t)W << a);
-        // diagonal of the high part and of the boundary bond, then per row
         for (int r = 0; r < S.nl[kl]; ++r) {
           const uint64_t s = hi | lo_pat[S.lo_off[kl] + r];
-          if (check) {
-            hx[rb + r] = make_double2(N01(r2), N01(r2));
-            state_of[rb + r] = s;
-            hdiag[rb + r] = diag_of(s);
-          } else {
-            // large sizes: cheap pseudo-random fill, the diagonal from an incremental form is not needed for timing
-            const uint64_t z = (s * 0x9E3779B97F4A7C15ull) ^ (s >> 17);
-            hx[rb + r] = make_double2((double)(z & 0xffff) / 65536.0 - 0.5, (double)((z >> 16) & 0xffff) / 65536.0 - 0.5);
-            hdiag[rb + r] = (double)((z >> 32) & 0xff) / 64.0 - 2.0;
-          }
+          hx[rb + r] = make_double2(N01(r2), N01(r2));
+          state_of[rb + r] = s;
+          hdiag[rb + r] = diag_of(s);
         }
       }
     }
-    printf("host fill %.1f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     CK(hipMemcpy(dx, hx.data(), nint * sizeof(c128), hipMemcpyHostToDevice));
     CK(hipMemcpy(ddiag, hdiag.data(), nint * sizeof(double), hipMemcpyHostToDevice));
-    CK(hipMemset(dy, 0xff, nint * sizeof(c128)));
   }
+  CK(hipMemset(dy, 0xff, nint * sizeof(c128)));
   S.ibase = upload(ibase); S.icoff = upload(icoff);
   S.lo_pat = upload(lo_pat); S.w_pat = upload(w_pat); S.w_rank = upload(w_rank);
   S.cbin = upload(cbin); S.bond = upload(bond); S.diag = ddiag;
+  {
+    std::vector<double> dlo(lo_pat.size());
+    for (size_t i = 0; i < lo_pat.size(); ++i) {
+      const uint32_t v = lo_pat[i];
+      double d = 0.0;
+      for (int b = 0; b + 1 < a; ++b) d += (((v >> b) ^ (v >> (b + 1))) & 1) ? -0.25 : 0.25;
+      for (int i2 = 0; i2 < a; ++i2) d += ((v >> i2) & 1) ? -h[i2] : h[i2];
+      dlo[i] = d;
+    }
+    S.dlo = upload(dlo);
+    S.hfield = upload(h);
+    S.zz = 0.25;
+  }
   uint32_t *dpA = upload(permA), *dpB = upload(permB);
+  if (!check) {
+    hipLaunchKernelGGL(sc3_fill, dim3((unsigned)permA.size()), dim3(256), 0, 0, S, dpA, dx, ddiag);
+    CK(hipDeviceSynchronize());
+  }
 
   const int ntA = argc > 10 ? atoi(argv[10]) : 512, ntB = argc > 11 ? atoi(argv[11]) : 512;
   const int nbA = argc > 12 ? atoi(argv[12]) : 2, nbB = argc > 13 ? atoi(argv[13]) : 2;
   const size_t ldsA = (size_t)cbinom(14, 7) * 16, ldsB = (size_t)cbinom(10, 5) * 16 * 16;
   using kern_t = void (*)(const Sc3, const uint32_t *, const c128 *, c128 *);
   kern_t kA_acc = nullptr, kA_first = nullptr, kB_acc = nullptr, kB_first = nullptr;
-#define PICKA(NT_, NB_) if (ntA == NT_ && nbA == NB_) { kA_acc = sc3_lo_pass<14, NT_, NB_, true, true>; kA_first = sc3_lo_pass<14, NT_, NB_, false, false>; }
-#define PICKB(NT_, NB_) if (ntB == NT_ && nbB == NB_) { kB_acc = sc3_win_pass<10, NT_, NB_, true, true>; kB_first = sc3_win_pass<10, NT_, NB_, false, false>; }
-  PICKA(512, 1) PICKA(512, 2) PICKA(1024, 1) PICKA(1024, 2)
-  PICKB(512, 1) PICKB(512, 2) PICKB(1024, 1) PICKB(1024, 2)
+  // variant (argv[15]): bit 0 = on-the-fly diagonal instead of the cached one, bit 1 = SYM, bit 2 = EARLY
+  const int variant = argc > 15 ? atoi(argv[15]) : 0;
+#define PICKV(NT_, NB_, DM_, SY_, EA_)                                                                             \
+  if (ntA == NT_ && nbA == NB_ && variant == ((DM_ == 2 ? 1 : 0) | (SY_ ? 2 : 0) | (EA_ ? 4 : 0))) {                 \
+    kA_acc = sc3_lo_pass<14, NT_, NB_, true, DM_, SY_, EA_>;                                                        \
+    kA_first = sc3_lo_pass<14, NT_, NB_, false, (DM_ == 2 ? 2 : 0), SY_, EA_>;                                                       \
+  }                                                                                                                \
+  if (ntB == NT_ && nbB == NB_ && variant == ((DM_ == 2 ? 1 : 0) | (SY_ ? 2 : 0) | (EA_ ? 4 : 0))) {                 \
+    kB_acc = sc3_win_pass<10, NT_, NB_, true, (DM_ == 2 ? 0 : 1), SY_, EA_>;                                        \
+    kB_first = sc3_win_pass<10, NT_, NB_, false, 0, SY_, EA_>;                                                      \
+  }
+#define PICKALL(NT_, NB_) PICKV(NT_, NB_, 1, false, false) PICKV(NT_, NB_, 2, false, false) PICKV(NT_, NB_, 1, true, false) \
+  PICKV(NT_, NB_, 2, true, false) PICKV(NT_, NB_, 1, false, true) PICKV(NT_, NB_, 2, false, true) PICKV(NT_, NB_, 1, true, true) \
+  PICKV(NT_, NB_, 2, true, true)
+  PICKALL(512, 1) PICKALL(512, 2) PICKALL(1024, 1) PICKALL(1024, 2)
   if (!kA_acc || !kB_acc) { printf("no such kernel instance\n"); return 1; }
   CK(hipFuncSetAttribute((const void *)kA_acc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsA));
   CK(hipFuncSetAttribute((const void *)kA_first, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsA));
@@ -787,7 +879,7 @@ int main(int argc, char **argv) {
     if (accA) { tB += m1; tA += m2; } else { tA += m1; tB += m2; }
   }
   tA /= reps; tB /= reps;
-  printf("L=%d k=%d a=%d w=%d orderA=%d orderB=%d tInA=%d accA=%d ntA=%d ntB=%d nbA=%d nbB=%d: lo pass %.3f ms, window pass %.3f ms, multiply %.3f ms = %.2f Gamp/s, %.1f GB/s at 40 B/row\n",
-         L, k, a, w, orderA, orderB, tInA, accA, ntA, ntB, nbA, nbB, tA, tB, tA + tB, dim / (tA + tB) / 1e6, 40.0 * dim / (tA + tB) / 1e6);
+  printf("L=%d k=%d a=%d w=%d orderA=%d orderB=%d tInA=%d accA=%d ntA=%d ntB=%d nbA=%d nbB=%d t1=%d variant=%d: lo pass %.3f ms, window pass %.3f ms, multiply %.3f ms = %.2f Gamp/s, %.1f GB/s at 40 B/row\n",
+         L, k, a, w, orderA, orderB, tInA, accA, ntA, ntB, nbA, nbB, t1, variant, tA, tB, tA + tB, dim / (tA + tB) / 1e6, 40.0 * dim / (tA + tB) / 1e6);
   return 0;
 }

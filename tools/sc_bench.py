@@ -23,7 +23,8 @@ def main():
         sub = SpinConserve(L, k)
         dim = sub.get_dimension()
         mat = backend.build_mat(masks, offs, H.msc['signs'], H.msc['coeffs'], sub._to_c(), sub._to_c())
-        x, y = backend.Vec(dim), backend.Vec(dim)
+        x, y = mat.createVecs()
+        print(mat.describe().strip(), flush=True)
         x.set_random(0)
         for diag in (False, True):
             if diag:
