@@ -102,12 +102,13 @@ SIGNATURES = {
     "dnm_vec_set_random_swz": (C.c_int, [vp, C.c_int64, C.c_uint64, C.c_int64, C.c_int, vp]),
     "dnm_vec_swizzle_copy": (C.c_int, [vp, vp, C.c_int64, C.c_int, vp]),
     "dnm_vec_layout_size": (C.c_int, [C.POINTER(Subspace), C.POINTER(C.c_int64)]),
-    "dnm_vec_layout_copy": (C.c_int, [C.POINTER(Subspace), vp, vp, C.c_int, vp]),
-    "dnm_vec_layout_copy_f64": (C.c_int, [C.POINTER(Subspace), vp, vp, C.c_int, vp]),
-    "dnm_vec_layout_zero_padding": (C.c_int, [C.POINTER(Subspace), vp, vp]),
-    "dnm_vec_layout_positions": (C.c_int, [C.POINTER(Subspace), C.c_int64, vp, vp, vp]),
-    "dnm_vec_layout_positions_host": (C.c_int, [C.POINTER(Subspace), C.c_int64, i64p, i64p]),
-    "dnm_vec_layout_set_random": (C.c_int, [C.POINTER(Subspace), vp, C.c_uint64, vp]),
+    "dnm_vec_layout_partition": (C.c_int, [C.POINTER(Subspace), C.c_int, C.c_int, i64p, i64p, i64p, i64p]),
+    "dnm_vec_layout_copy": (C.c_int, [C.POINTER(Subspace), C.POINTER(Partition), vp, vp, C.c_int, vp]),
+    "dnm_vec_layout_copy_f64": (C.c_int, [C.POINTER(Subspace), C.POINTER(Partition), vp, vp, C.c_int, vp]),
+    "dnm_vec_layout_zero_padding": (C.c_int, [C.POINTER(Subspace), C.POINTER(Partition), vp, vp]),
+    "dnm_vec_layout_positions": (C.c_int, [C.POINTER(Subspace), C.POINTER(Partition), C.c_int64, vp, vp, vp]),
+    "dnm_vec_layout_positions_host": (C.c_int, [C.POINTER(Subspace), C.POINTER(Partition), C.c_int64, i64p, i64p]),
+    "dnm_vec_layout_set_random": (C.c_int, [C.POINTER(Subspace), C.POINTER(Partition), vp, C.c_uint64, vp]),
     "dnm_mat_layouts": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "dnm_mat_destroy": (C.c_int, [vp]),
     "dnm_mat_sizes": (C.c_int, [vp, i64p, i64p, i64p, i64p]),

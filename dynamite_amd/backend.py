@@ -39,6 +39,14 @@ def split_ownership(size, world, rank):
     return rank * q + min(rank, rem), q + (1 if rank < rem else 0)
 
 
+def layout_partition(sub_c, nranks, rank):
+    """(istart, ilen, nstart, nlen) of rank's part of a SpinConserve vector in the internal layout: positions
+    [istart, istart + ilen) of the layout = indices [nstart, nstart + nlen) of the reference order."""
+    v = [C.c_int64() for _ in range(4)]
+    _lib.check(_lib.lib().dnm_vec_layout_partition(C.byref(sub_c), int(nranks), int(rank), *[C.byref(x) for x in v]))
+    return tuple(x.value for x in v)
+
+
 def window_exchange_ops(owned, windows, me, needs=None):
     """Who sends what to whom so that every rank holds the columns of its window.
     owned[q] = (start, n) of rank q's block; windows[q] = inclusive (cmin, cmax) rank q reads; needs[q] (optional)
@@ -202,6 +210,11 @@ def post_transpose(src, dst, pieces):
                            [(dst[off:off + cnt], q) for q, off, cnt in pieces])
 
 
+class ExchangeCheckError(RuntimeError):
+    """The first multiply of a transposed-exchange operator disagreed with rows recomputed from the operator's
+    definition (``ShellMat.selfcheck``)."""
+
+
 class Vec:
     """Distributed complex128 vector: this rank's block lives in ``self.array``
     (a 1-D torch tensor on the rank's GPU).  ``swz``: layout of the block (dnm_subspace.vec_swizzle): 0 = element
@@ -219,12 +232,14 @@ class Vec:
         self.sub_c = sub_c
         self.start, self.local_size = split_ownership(self.size, config.world_size, config.rank)
         self.rows = self.local_size              # elements of the vector this rank holds
+        self.istart = self.start                 # where this rank's part starts in the layout's own index space
+        self._part = None
         if self.internal:
-            if sub_c is None or config.world_size != 1:
-                raise ValueError('a vector in the SpinConserve internal layout needs its subspace descriptor (one rank)')
-            n = C.c_int64()
-            _lib.check(_lib.lib().dnm_vec_layout_size(C.byref(sub_c), C.byref(n)))
-            self.local_size = n.value           # rows + padding
+            if sub_c is None:
+                raise ValueError('a vector in the SpinConserve internal layout needs its subspace descriptor')
+            # whole blocks of equal top bits per rank: a contiguous range of the layout and of the reference order
+            self._part = _lib.Partition(config.rank, config.world_size)
+            self.istart, self.local_size, self.start, self.rows = layout_partition(sub_c, config.world_size, config.rank)
         if array is None:
             array = device_zeros(self.local_size)
         self.array = array
@@ -245,12 +260,14 @@ class Vec:
             if not torch.is_tensor(idx):
                 a = np.ascontiguousarray([int(idx)], dtype=np.int64)
                 out = np.empty_like(a)
-                _lib.check(_lib.lib().dnm_vec_layout_positions_host(C.byref(self.sub_c), 1, _lib.p64(a), _lib.p64(out)))
+                _lib.check(_lib.lib().dnm_vec_layout_positions_host(C.byref(self.sub_c), C.byref(self._part), 1,
+                                                                    _lib.p64(a), _lib.p64(out)))
                 return int(out[0])
             idx = idx.to(device=self.array.device, dtype=torch.int64).contiguous()
             pos = torch.empty_like(idx)
-            _lib.check(_lib.lib().dnm_vec_layout_positions(C.byref(self.sub_c), idx.numel(), C.c_void_p(idx.data_ptr()),
-                                                           C.c_void_p(pos.data_ptr()), _stream()))
+            _lib.check(_lib.lib().dnm_vec_layout_positions(C.byref(self.sub_c), C.byref(self._part), idx.numel(),
+                                                           C.c_void_p(idx.data_ptr()), C.c_void_p(pos.data_ptr()),
+                                                           _stream()))
             return pos
         return idx ^ (((idx >> S) & ((1 << (S - 4)) - 1)) << 4)
 
@@ -275,8 +292,8 @@ class Vec:
             return self.array
         if self.internal:
             out = torch.empty(self.rows, dtype=self.array.dtype, device=self.array.device)
-            _lib.check(_lib.lib().dnm_vec_layout_copy(C.byref(self.sub_c), C.c_void_p(out.data_ptr()), self.ptr, 0,
-                                                      _stream()))
+            _lib.check(_lib.lib().dnm_vec_layout_copy(C.byref(self.sub_c), C.byref(self._part),
+                                                      C.c_void_p(out.data_ptr()), self.ptr, 0, _stream()))
             return out
         out = torch.empty_like(self.array)
         _lib.check(_lib.lib().dnm_vec_swizzle_copy(C.c_void_p(out.data_ptr()), self.ptr, self.local_size,
@@ -287,14 +304,15 @@ class Vec:
         """Fill this rank's block from a device tensor in index order."""
         if self.internal:
             t = t.contiguous()
-            _lib.check(_lib.lib().dnm_vec_layout_copy(C.byref(self.sub_c), self.ptr, C.c_void_p(t.data_ptr()), 1,
-                                                      _stream()))
+            _lib.check(_lib.lib().dnm_vec_layout_copy(C.byref(self.sub_c), C.byref(self._part), self.ptr,
+                                                      C.c_void_p(t.data_ptr()), 1, _stream()))
         else:
             self.set_local(0, self.rows, t)
 
     def _zero_padding(self):
         if self.internal:
-            _lib.check(_lib.lib().dnm_vec_layout_zero_padding(C.byref(self.sub_c), self.ptr, _stream()))
+            _lib.check(_lib.lib().dnm_vec_layout_zero_padding(C.byref(self.sub_c), C.byref(self._part), self.ptr,
+                                                              _stream()))
 
     # -- petsc4py.Vec-like surface -------------------------------------------
     def getSize(self):
@@ -367,8 +385,8 @@ class Vec:
 
     def set_random(self, seed):
         if self.internal:
-            _lib.check(_lib.lib().dnm_vec_layout_set_random(C.byref(self.sub_c), self.ptr, seed & (2 ** 64 - 1),
-                                                            _stream()))
+            _lib.check(_lib.lib().dnm_vec_layout_set_random(C.byref(self.sub_c), C.byref(self._part), self.ptr,
+                                                            seed & (2 ** 64 - 1), _stream()))
             return
         _lib.check(_lib.lib().dnm_vec_set_random_swz(self.ptr, self.local_size, seed & (2 ** 64 - 1),
                                                      self.start, self.swz, _stream()))
@@ -408,7 +426,10 @@ class Vec:
         import torch
         from . import _comm
         ws = config.world_size
-        sizes = [split_ownership(self.size, ws, q)[1] for q in range(ws)]
+        if self.internal:
+            sizes = [layout_partition(self.sub_c, ws, q)[3] for q in range(ws)]
+        else:
+            sizes = [split_ownership(self.size, ws, q)[1] for q in range(ws)]
         if len(set(sizes)) == 1:
             parts = _comm.all_gather(self.local_natural())
         else:   # uneven blocks: pad to the largest
@@ -450,6 +471,8 @@ class ShellMat:
         self._window_buf = None
         self._tr = None           # transposed exchange (set_transposed): (lo handle, hi handle, pieces, own, cnt)
         self._tr_bufs = None
+        self._msc = None          # (masks, mask_offsets, signs, coeffs, left subspace dict, right subspace dict): selfcheck
+        self._check_pending = False
 
     @property
     def handle(self):
@@ -496,7 +519,17 @@ class ShellMat:
             return
         self.check_layout(x, y)
         if self._tr is not None:
-            return self._mult_transposed(x, y)
+            self._mult_transposed(x, y)
+            if self._check_pending:
+                # The transposed exchange is the scheme with the most asynchronous traffic (buffers shared between
+                # the RCCL stream and the compute stream, batched returns): its first result on a transport is
+                # checked against rows recomputed from the MSC definition before anything is built on it.
+                self._check_pending = False
+                err, scale = self.selfcheck(x, y)
+                if not err <= 1e-9 * max(scale, 1e-300):
+                    raise ExchangeCheckError('transposed exchange: sampled rows of the first multiply are off by %.3e '
+                                             '(scale %.3e); build the operator with exchange="partner"' % (err, scale))
+            return
         if self.nranks > 1 and not self.partners and self._is_windowed():
             return self._mult_window(x, y)
         if not self.recvs and not self.sends:
@@ -539,6 +572,79 @@ class ShellMat:
                                  % (name, v.swz, want))
             if v.local_size != n:
                 raise ValueError('%s vector holds %d local elements, the matrix expects %d' % (name, v.local_size, n))
+
+    def selfcheck(self, x, y, nsample=24):
+        """Collective: recompute ``nsample`` rows per rank of y = A x on the host from the operator's definition
+        (A.3 of SURVEY.md: H[r, col] = sum_t (1 - 2 parity(bra & sign_t)) c_t over the terms of every mask, bra the
+        column state) with the x values fetched from the ranks that own them, and return (largest absolute
+        deviation over all ranks, largest |y| sampled).  Independent of every kernel and of the exchange scheme."""
+        import torch
+        from . import _comm
+        if self._msc is None:
+            raise RuntimeError('selfcheck needs the operator arrays (matrices built by build_mat have them)')
+        masks, offs, signs, coeffs, lsub, rsub = self._msc
+        lib = _lib.lib()
+
+        def maps(sub, fn, vals):
+            vals = np.ascontiguousarray(vals, dtype=np.int64)
+            out = np.empty_like(vals)
+            _lib.check(fn(C.byref(sub['data']), vals.size, _lib.p64(vals), _lib.p64(out)))
+            return out
+        nloc = y.rows
+        # rows: both ends, the middle and the neighbourhood of every power of two of the local index
+        cand = {0, nloc - 1, nloc // 2}
+        b = 1
+        while b < nloc:
+            cand.update((b - 1, b))
+            b <<= 1
+        rs = np.random.RandomState(1234 + self.rank)
+        rows = sorted(cand)[:max(0, nsample // 2)]
+        rows = np.unique(np.concatenate([np.asarray(rows, dtype=np.int64), rs.randint(0, nloc, size=nsample - len(rows))]))
+        grow = rows + y.start
+        kets = maps(lsub, lib.dnm_idx_to_state, grow)
+        bras = kets[:, None] ^ np.asarray(masks, dtype=np.int64)[None, :]
+        cols = maps(rsub, lib.dnm_state_to_idx, bras.reshape(-1)).reshape(bras.shape)
+        # fetch x[col] from the owners
+        d = _dist()
+        ws = self.nranks
+        owned = [split_ownership(self.N, ws, q) for q in range(ws)]
+        need = np.unique(cols[cols >= 0])
+        allneed = [None] * ws
+        if d is not None:
+            d.all_gather_object(allneed, need)
+        else:
+            allneed = [need]
+        s0, sn = owned[self.rank]
+        answers = []
+        for q in range(ws):
+            mine = allneed[q][(allneed[q] >= s0) & (allneed[q] < s0 + sn)]
+            pos = x.positions(torch.from_numpy(mine - s0).to(x.array.device))
+            answers.append((mine, x.array[pos].cpu().numpy()))
+        allans = [None] * ws
+        if d is not None:
+            d.all_gather_object(allans, answers)
+        else:
+            allans = [answers]
+        xval = {}
+        for q in range(ws):
+            idx, val = allans[q][self.rank]
+            xval.update(zip(idx.tolist(), val.tolist()))
+        tm = np.repeat(np.arange(len(masks)), np.diff(offs))
+        want = np.zeros(rows.size, dtype=np.complex128)
+        for i in range(rows.size):
+            for m in range(len(masks)):
+                c = cols[i, m]
+                if c < 0:
+                    continue
+                t = np.flatnonzero(tm == m)
+                par = np.array([bin(int(bras[i, m]) & int(signs[j])).count('1') & 1 for j in t])
+                want[i] += np.sum(np.where(par == 1, -1.0, 1.0) * coeffs[t]) * xval[int(c)]
+        got = y.array[y.positions(torch.from_numpy(rows).to(y.array.device))].cpu().numpy()
+        out = torch.tensor([float(np.abs(got - want).max()), float(np.abs(want).max())], dtype=torch.float64,
+                           device=x.array.device)
+        if d is not None:
+            d.all_reduce(out, op=d.ReduceOp.MAX)
+        return float(out[0]), float(out[1])
 
     def set_transposed(self, split, left_c, right_c, flags=0):
         """Switch the partitioned multiply to the transposed exchange (``transpose_split``): two operators with
@@ -623,20 +729,31 @@ class ShellMat:
         for r in reqs:
             r.wait()
         _lib.check(L.dnm_mat_mult_local(hi, vp(xb), vp(wb), _stream()))
-        # the way back (xb is free again), one batch per own piece: what a batch brought is added while the next
-        # one is on the links
+        # the way back (xb is free again) in TR_SUB * len(own) batches -- every piece travels as TR_SUB contiguous parts,
+        # part by part over all peers: what a batch brought is added to y while the next ones are on the links, so the
+        # only addition that is not hidden under a transfer is the last batch's (1 / (TR_SUB * len(own)) of the sweep)
         span = self.n_local // len(own)               # P pieces: one per peer around this rank's own
-        batches = [post_transpose(wb, xb, [pc for pc in pieces if pc[1] // span == b]) for b in range(len(own))]
+        sub = self.TR_SUB if cnt % self.TR_SUB == 0 and cnt // self.TR_SUB >= 1024 else 1
+        part = cnt // sub
+        batches = []
+        for b in range(len(own)):
+            mine = [pc for pc in pieces if pc[1] // span == b]
+            for k in range(sub):
+                batches.append((b, k, post_transpose(wb, xb, [(q, off + k * part, part) for q, off, _ in mine])))
         for off in own:
             _lib.check(L.dnm_vec_axpby(vp(y.array[off:off + cnt]), vp(wb[off:off + cnt]), cnt, 1.0, 0.0, 1.0, 0.0,
                                        _stream()))
-        for b, (reqs, off) in enumerate(zip(batches, own)):
+        for b, k, reqs in batches:
             for r in reqs:
                 r.wait()
-            for lo_, hi_ in ((b * span, off), (off + cnt, (b + 1) * span)):
-                if hi_ > lo_:
-                    _lib.check(L.dnm_vec_axpby(vp(y.array[lo_:hi_]), vp(xb[lo_:hi_]), hi_ - lo_, 1.0, 0.0, 1.0, 0.0,
-                                               _stream()))
+            off = own[b]
+            # the parts k of the pieces on either side of this rank's own piece: two strided groups of equal runs
+            for q, poff, _ in [pc for pc in pieces if pc[1] // span == b]:
+                lo_ = poff + k * part
+                _lib.check(L.dnm_vec_axpby(vp(y.array[lo_:lo_ + part]), vp(xb[lo_:lo_ + part]), part, 1.0, 0.0, 1.0, 0.0,
+                                           _stream()))
+
+    TR_SUB = 4     # parts a piece of the returning all-to-all travels in (_mult_transposed)
 
     def exchange_only(self, x):
         """Post and complete the rank exchange of ONE multiply without running any kernel: the same messages over
@@ -654,8 +771,8 @@ class ShellMat:
                 r.wait()
         elif not self.partners and self._is_windowed():
             self._setup_windows()
-            self._window_buf = exchange_window(x.local_natural(), self._owned, self._windows, self.rank,
-                                               self._window_buf, self._needs)
+            self._window_buf = exchange_window(x.array if x.internal else x.local_natural(), self._owned, self._windows,
+                                               self.rank, self._window_buf, self._needs)
         else:
             self.prepare_exchange(x.array)
             bufs = [self._recv[i] for i in range(len(self.recvs))]
@@ -728,14 +845,18 @@ class ShellMat:
         dist.all_gather_object(allw, (mine, needs))
         self._windows = [w for w, _ in allw]
         self._needs = [nd for _, nd in allw] if needs is not None else None
-        self._owned = [split_ownership(self.N, self.nranks, q) for q in range(self.nranks)]
+        if self.swz_right >= 256:      # internal SpinConserve layout: ownership and windows are positions of the layout
+            self._owned = [layout_partition(self._keep[1], self.nranks, q)[:2] for q in range(self.nranks)]
+        else:
+            self._owned = [split_ownership(self.N, self.nranks, q) for q in range(self.nranks)]
 
     def _mult_window(self, x, y):
         """Partitioned SpinConserve: gather the column window, then one kernel."""
         self._setup_windows()
-        # the window is in index order: a swizzled block is straightened first (projection pairs)
-        self._window_buf = exchange_window(x.local_natural(), self._owned, self._windows, self.rank, self._window_buf,
-                                           self._needs)
+        # the window is in index order: a swizzled block is straightened first (projection pairs); vectors in the
+        # internal SpinConserve layout travel as they lie (the window is a range of the layout)
+        xl = x.array if x.internal else x.local_natural()
+        self._window_buf = exchange_window(xl, self._owned, self._windows, self.rank, self._window_buf, self._needs)
         w0 = self._windows[self.rank][0]
         _lib.check(_lib.lib().dnm_mat_mult_window(self.handle, C.c_void_p(self._window_buf.data_ptr()), w0,
                                                   self._window_buf.numel(), y.ptr, _stream()))
@@ -791,9 +912,10 @@ def create_mat(masks, mask_offsets, signs, coeffs, left_c, right_c, xparity=Fals
 
 
 def build_mat(masks, mask_offsets, signs, coeffs, left_subspace, right_subspace, xparity=False,
-              shell=True, gpu=True, flags=0):
+              shell=True, gpu=True, flags=0, exchange=None):
     """Mirror of ``bpetsc.build_mat`` (bpetsc.pyx:78-138).  ``left_subspace`` /
-    ``right_subspace`` are the dicts ``Subspace._to_c()`` returns."""
+    ``right_subspace`` are the dicts ``Subspace._to_c()`` returns.  ``exchange`` (not in the reference):
+    'partner' / 'transpose' picks the scheme of a partitioned Full / Parity multiply, None decides by rank count."""
     if not shell:
         raise ValueError('this engine builds matrix-free (shell) operators only')
     if not gpu:
@@ -803,22 +925,25 @@ def build_mat(masks, mask_offsets, signs, coeffs, left_subspace, right_subspace,
     h = create_mat(masks, mask_offsets, signs, coeffs, lc, rc, xparity, flags,
                    rank=config.rank, nranks=config.world_size)
     mat = ShellMat(h, lc, rc, config.world_size, config.rank)
+    if not xparity:
+        mat._msc = (np.array(masks, dtype=np.int64), np.array(mask_offsets, dtype=np.int64),
+                    np.array(signs, dtype=np.int64), np.array(coeffs, dtype=np.complex128), left_subspace, right_subspace)
     same = lc.type == rc.type and lc.L == rc.L and (lc.type == 0 or (lc.type == 1 and lc.space == rc.space))
-    if use_transposed_exchange(config.world_size) and same and not xparity and 'tiled=1' in mat.describe():
+    if use_transposed_exchange(config.world_size, exchange) and same and not xparity and 'tiled=1' in mat.describe():
         shift = int(lc.type)                   # Full: index = configuration; Parity: index = configuration >> 1
         split = transpose_split(masks, mask_offsets, signs, coeffs, int(lc.L) - shift, config.world_size,
                                 int(lc.vec_swizzle), shift)
         if split is not None:
             mat.set_transposed(split, lc, rc, flags)
+            mat._check_pending = knob('DNM_EXCHANGE_SELFCHECK', '1') != '0'
     return mat
 
 
-def use_transposed_exchange(nranks):
+def use_transposed_exchange(nranks, mode=None):
     """Exchange scheme of a partitioned Full-space or Parity multiply: with four or more ranks the all-to-all of the
     transposed scheme puts less on the busiest link than the partner blocks (two ranks: the partner block is
     half of what two transposes move).  DNM_EXCHANGE=partner / transpose overrides."""
-    import os
-    mode = knob('DNM_EXCHANGE', 'auto')
+    mode = mode or knob('DNM_EXCHANGE', 'auto')
     if mode == 'partner' or nranks < 2:
         return False
     return mode == 'transpose' or nranks >= 4
@@ -893,8 +1018,11 @@ def reduced_density_matrix(vec, subspace, keep):
                 return np.array([[-1]], dtype=np.complex128)
             return rho.cpu().numpy().reshape(K, K)
         from . import _comm
-        parts = _comm.gather_varied(vec.local_natural(), [split_ownership(vec.size, config.world_size, q)[1]
-                                                          for q in range(config.world_size)], dst=0)
+        if vec.internal:
+            sizes = [layout_partition(vec.sub_c, config.world_size, q)[3] for q in range(config.world_size)]
+        else:
+            sizes = [split_ownership(vec.size, config.world_size, q)[1] for q in range(config.world_size)]
+        parts = _comm.gather_varied(vec.local_natural(), sizes, dst=0)
         if config.rank != 0:
             return np.array([[-1]], dtype=np.complex128)
         x = torch.cat(parts)                 # the whole state in index order

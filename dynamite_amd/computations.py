@@ -35,10 +35,8 @@ def _hooks(mat, keep):
         try:
             n = mat.n_local
             # wrap raw device pointers as Vec views without copying
-            x = Vec.__new__(Vec); y = Vec.__new__(Vec)
-            for v, p, sw in ((x, xp, mat.swz_right), (y, yp, mat.swz_left)):
-                v.size, v.local_size, v.start, v.swz = mat.N, n, mat.row0, sw
-                v.array = _tensor_from_ptr(p, n)
+            x = Vec(mat.N, array=_tensor_from_ptr(xp, n), swz=mat.swz_right, sub_c=mat._keep[1])
+            y = Vec(mat.M, array=_tensor_from_ptr(yp, n), swz=mat.swz_left, sub_c=mat._keep[0])
             mat.mult(x, y)
             return 0
         except Exception as e:   # pragma: no cover

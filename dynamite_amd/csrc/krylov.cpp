@@ -168,7 +168,7 @@ static void jacobi_eig(int n, std::vector<double> &A, std::vector<double> &w, st
 // y = A x - b z + c2 z2 (dnm_mat_mult_sub2); the scale that brings s_d back to O(1) is known on the host.
 // seeded start vector in the layout of A's vectors (padding of an internal SpinConserve layout stays zero)
 static int random_start(dnm_mat *A, void *x, int64_t n_local, uint64_t seed, int64_t offset, hipStream_t st) {
-  if (A->use_sc3) return sc3_random(*A->sc3->ly, x, seed, st);
+  if (A->use_sc3) return sc3_random(*A->sc3->ly, x, seed, st, A->sc3->T0, A->sc3->T1);
   return vk_random(x, n_local, seed, offset, st, A->right.host.swz);
 }
 
@@ -1336,11 +1336,15 @@ int dnm_eigsolve(dnm_mat *A, int64_t n_local, int nev, int which, double tol, in
       if (!(gam > 1e-9) || !(std::fabs(far - a_cut) > 0)) {
         filtered = false;                      // no usable gap estimate (degenerate Ritz values): plain scheme
       } else {
-        // amplification of the nev-th wanted value over the unwanted interval ~ cosh(2 d sqrt(gam)): about 10^3
-        // (a basis that memory keeps short gets a proportionally stronger filter: the number of Lanczos vectors to
-        // convergence falls with the degree, and every restart throws part of the Krylov space away)
-        int d = (int)std::ceil(7.6 / (2.0 * std::sqrt(gam)) * std::max(1.0, 18.0 / m));
-        d = std::max(5, std::min(d, 99));
+        // Degree: the filter cannot separate the wanted values from EACH OTHER (their images stay as close,
+        // relatively, as d times their distance in acosh), so that work stays with the outer Lanczos process at d
+        // multiplies per vector: a strong filter needs fewer vectors but more multiplies in all.  With a step costing
+        // d multiplies plus two orthogonalisation passes over the basis (about 7 multiply-times at m = 20) the
+        // measured optimum is an amplification of the nev-th value of about cosh(3.3) = 14 over the damped interval
+        // -- degree 9 for the chains at L = 26...30: L=28, nev=5, tol 1e-10: d = 5 / 9 / 13 / 17 / 21 take
+        // 6.2 / 5.6 / 5.9 / 6.1 / 7.3 s (plain restarted scheme: 12.1 s; profiles/r03_exp5_eigs_degree.txt)
+        int d = (int)std::ceil(3.3 / (2.0 * std::sqrt(gam)));
+        d = std::max(5, std::min(d, 49));
         if (const char *de = knob("DNM_EIGS_FILTER_DEGREE")) d = std::max(1, atoi(de));
         d |= 1;
         flt.d = d;
@@ -1376,7 +1380,7 @@ int dnm_eigsolve(dnm_mat *A, int64_t n_local, int nev, int which, double tol, in
   // Krylov-Schur does); default: partial re-orthogonalisation driven by the omega-recurrence
   const char *oenv = knob("DNM_EIGS_ORTHO");
   // (on a filter the basis work is a small share of a step and p(H) has a huge dynamic range: every step in full)
-  const bool use_pro = !(oenv && oenv[0] == 'f') && !filtered;
+  const bool use_pro = !(oenv && oenv[0] == 'f') && (!filtered || knob("DNM_EIGS_FILTER_PRO") != nullptr);
   // DNM_EIGS_BETA=sweep: beta from a norm sweep after the update (never the fused form); =rescale: always run the
   // corrective rescaling sweep -- both only to exercise the rarely taken branches in tests
   const bool known_off = knob("DNM_EIGS_KNOWN") && knob("DNM_EIGS_KNOWN")[0] == '0';   // A/B switch

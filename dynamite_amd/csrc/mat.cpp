@@ -730,8 +730,8 @@ int dnm_mat_create(int64_t nmasks, const int64_t *masks, const int64_t *mask_off
   // SpinConserve pair whose vectors are in the internal layout: the two-pass / row kernels of sc3_kernels.hip.  Any
   // other use of such a subspace (another partner, XParity, several ranks) works in reference order: the caller
   // converts (dnm_mat_layouts tells).
-  A->use_sc3 = A->sc_pair && A->left.host.sc3 != 0 && A->left.host.sc3 == A->right.host.sc3 && A->nranks == 1 &&
-               !A->xparity && A->left.host.L == A->right.host.L;
+  A->use_sc3 = A->sc_pair && A->left.host.sc3 != 0 && A->left.host.sc3 == A->right.host.sc3 && !A->xparity &&
+               A->left.host.L == A->right.host.L;
 
   std::vector<ScMask> scm;
   if (lt == DNM_SPIN_CONSERVE && rt == DNM_SPIN_CONSERVE) {
@@ -795,10 +795,17 @@ int dnm_mat_create(int64_t nmasks, const int64_t *masks, const int64_t *mask_off
     const Sc3Layout *ly = sc3_get(h.L, h.k, sc3_code_a(h.sc3), sc3_code_w(h.sc3), !A->host_only);
     DNM_CHECK(ly, "could not build the SpinConserve vector layout");
     A->sc3.reset(new Sc3Mat());
-    DNM_TRY(A->sc3->init(ly, A->masks, A->mask_offsets, A->signs, A->real_coeffs, scm, !A->host_only));
+    // partitioned: whole T blocks per rank (a contiguous range of both the internal layout and the reference order)
+    const std::vector<uint32_t> Tb = sc3_partition(*ly, A->nranks);
+    DNM_TRY(A->sc3->init(ly, A->masks, A->mask_offsets, A->signs, A->real_coeffs, scm, !A->host_only, Tb[A->rank],
+                         Tb[A->rank + 1]));
     if (const char *e = knob("DNM_SC3_TILED")) if (e[0] == '0') A->sc3->tiled = false;     // tests: the row kernel
     if (const char *e = knob("DNM_SC3_DIAG")) if (e[0] == 'c' && A->sc3->diag_mode == 2) A->sc3->diag_mode = 1;
-    A->m_local = A->n_local = ly->host.nint;
+    int64_t is, il, ns, nl;
+    sc3_range(*ly, Tb[A->rank], Tb[A->rank + 1], &is, &il, &ns, &nl);
+    A->m_local = A->n_local = il;          // what the vector kernels sweep: rows + padding
+    A->rows_local = nl;
+    A->row0 = ns;                          // first row in reference order (norm / diagonal kernels)
   }
 
   if (A->hypercube) {
@@ -888,8 +895,10 @@ int dnm_mat_layouts(const dnm_mat *A, int *left, int *right) {
 
 // y = A x (- b z + c z2) in the SpinConserve internal layout; dot3 != null: the fused sums (device partials reduced here)
 static int sc3_mult(dnm_mat *A, const void *x, void *y, const void *z, double b, const void *z2, double c_re, double c_im,
-                    double *dot3_host, void *stream) {
+                    double *dot3_host, void *stream, int64_t win_start = -1) {
   Sc3Call call;
+  call.row0 = A->sc3->row0;
+  call.win_start = win_start >= 0 ? win_start : A->sc3->row0;     // one rank: x is the whole vector
   call.zinit = (const double2 *)z;
   call.zscale = b;
   call.zinit2 = (const double2 *)z2;
@@ -922,7 +931,8 @@ int dnm_mat_precompute_diagonal(dnm_mat *A, void *stream) {
     DNM_TRY(nat.alloc((size_t)A->rows_local * sizeof(double)));
     DNM_TRY(launch_diag(A->dmsc, A->right.dev, A->rows_local, A->row0, (double *)nat.p, S(stream)));
     DNM_TRY(A->diag.alloc((size_t)A->m_local * sizeof(double)));
-    DNM_TRY(sc3_layout_copy_f64(*A->sc3->ly, (double *)A->diag.p, (const double *)nat.p, true, S(stream)));
+    DNM_TRY(sc3_layout_copy_f64(*A->sc3->ly, (double *)A->diag.p, (const double *)nat.p, true, S(stream), A->sc3->T0,
+                                A->sc3->T1));
     DNM_HIP(hipStreamSynchronize(S(stream)));      // `nat` is released on return
     A->have_diag = true;
     return 0;
@@ -938,7 +948,8 @@ int dnm_mat_get_diagonal(dnm_mat *A, double *diag_host, void *stream) {
   if (A->use_sc3) {       // handed out in reference order (row r of the matrix)
     DevBuf nat;
     DNM_TRY(nat.alloc((size_t)A->rows_local * sizeof(double)));
-    DNM_TRY(sc3_layout_copy_f64(*A->sc3->ly, (double *)nat.p, (const double *)A->diag.p, false, S(stream)));
+    DNM_TRY(sc3_layout_copy_f64(*A->sc3->ly, (double *)nat.p, (const double *)A->diag.p, false, S(stream), A->sc3->T0,
+                                A->sc3->T1));
     return dnm_memcpy_d2h(diag_host, nat.p, (size_t)A->rows_local * sizeof(double), stream);
   }
   return dnm_memcpy_d2h(diag_host, A->diag.p, (size_t)A->m_local * sizeof(double), stream);
@@ -1087,13 +1098,19 @@ int dnm_mat_mult(dnm_mat *A, const void *x, void *y, void *stream) {
 
 int dnm_mat_ownership(const dnm_mat *A, int64_t *row0, int64_t *m_local) {
   DNM_CHECK(A, "null matrix");
-  if (row0) *row0 = A->row0;
+  // (internal SpinConserve layout: the rank's range of the layout -- the index space its windows are expressed in)
+  if (row0) *row0 = A->use_sc3 ? A->sc3->row0 : A->row0;
   if (m_local) *m_local = A->m_local;
   return 0;
 }
 
 int dnm_mat_column_window(dnm_mat *A, int64_t *cmin, int64_t *cmax, void *stream) {
-  DNM_CHECK(A && cmin && cmax && !A->host_only, "bad argument");
+  DNM_CHECK(A && cmin && cmax, "bad argument");
+  if (A->use_sc3) {          // positions of the internal layout, from the T blocks the rank's rows reach (host tables)
+    A->sc3->window(cmin, cmax);
+    return 0;
+  }
+  DNM_CHECK(!A->host_only, "bad argument");
   DNM_CHECK(!(A->hypercube && A->plan.use_tiled), "Full/Parity partitions on 2^p ranks exchange partner blocks, not windows");
   if (A->win_max < A->win_min) {
     const int nb = A->sc_pair ? sc_num_blocks(A->m_local) : gather_num_blocks(A->m_local);
@@ -1126,6 +1143,10 @@ int dnm_mat_column_chunks(dnm_mat *A, int chunk_shift, uint8_t *map, int64_t nch
   const int64_t first = lo >> chunk_shift;
   DNM_CHECK(nchunks == (hi >> chunk_shift) - first + 1, "the window [%lld, %lld] has %lld chunks of 2^%d columns",
             (long long)lo, (long long)hi, (long long)((hi >> chunk_shift) - first + 1), chunk_shift);
+  if (A->use_sc3) {
+    A->sc3->chunks(chunk_shift, first, nchunks, map);
+    return 0;
+  }
   const int nb = A->sc_pair ? sc_num_blocks(A->m_local) : gather_num_blocks(A->m_local);
   DevBuf range, dmap;
   DNM_TRY(range.alloc((size_t)nb * 2 * sizeof(int64_t)));
@@ -1153,6 +1174,7 @@ int dnm_mat_mult_window(dnm_mat *A, const void *x_window, int64_t win_start, int
   DNM_CHECK(win_start <= lo && win_start + win_len > hi,
             "window [%lld, %lld) does not cover the columns [%lld, %lld] this rank reads", (long long)win_start,
             (long long)(win_start + win_len), (long long)lo, (long long)hi);
+  if (A->use_sc3) return sc3_mult(A, x_window, y_local, nullptr, 0.0, nullptr, 0.0, 0.0, nullptr, stream, win_start);
   if (A->sc_pair) return launch_sc(A, win_start, win_len, x_window, y_local, stream);
   // any other subspace pair: one thread per row, columns read from the window (index order)
   return launch_gather_matvec(A->dmsc, A->left.dev, A->right.dev, A->m_local,

@@ -90,16 +90,21 @@ bool sc3_valid(int L, int k, int a, int w);
 const Sc3Layout *sc3_get(int L, int k, int a, int w, bool want_device);
 
 // ---- vector-level operations (sc3_kernels.hip) --------------------------------------------------------------
+// All of them act on the part of a vector that covers the T blocks [T0, T1) (default: everything): the vectors
+// start at that range's first position of the internal layout / first index of the reference order.
 // dst (internal) <- src (reference order) when to_internal, else dst (reference order) <- src (internal);
 // padding of an internal destination is zeroed
-int sc3_layout_copy(const Sc3Layout &Ly, void *dst, const void *src, bool to_internal, hipStream_t st);
+int sc3_layout_copy(const Sc3Layout &Ly, void *dst, const void *src, bool to_internal, hipStream_t st, uint32_t T0 = 0,
+                    uint32_t T1 = 0xffffffffu);
 // same for a real array (the cached diagonal)
-int sc3_layout_copy_f64(const Sc3Layout &Ly, double *dst, const double *src, bool to_internal, hipStream_t st);
-int sc3_zero_padding(const Sc3Layout &Ly, void *x, hipStream_t st);
-// pos[i] = internal position of the reference index idx[i] (device arrays)
-int sc3_positions(const Sc3Layout &Ly, int64_t n, const int64_t *idx, int64_t *pos, hipStream_t st);
-// counter-based normal deviates keyed by the reference index (the numbers reference order would get), padding zero
-int sc3_random(const Sc3Layout &Ly, void *x, uint64_t seed, hipStream_t st);
+int sc3_layout_copy_f64(const Sc3Layout &Ly, double *dst, const double *src, bool to_internal, hipStream_t st,
+                        uint32_t T0 = 0, uint32_t T1 = 0xffffffffu);
+int sc3_zero_padding(const Sc3Layout &Ly, void *x, hipStream_t st, uint32_t T0 = 0, uint32_t T1 = 0xffffffffu);
+// pos[i] = local internal position of the local reference index idx[i] (device arrays)
+int sc3_positions(const Sc3Layout &Ly, int64_t n, const int64_t *idx, int64_t *pos, hipStream_t st, uint32_t T0 = 0,
+                  uint32_t T1 = 0xffffffffu);
+// counter-based normal deviates keyed by the global reference index (the numbers reference order would get), padding zero
+int sc3_random(const Sc3Layout &Ly, void *x, uint64_t seed, hipStream_t st, uint32_t T0 = 0, uint32_t T1 = 0xffffffffu);
 
 // ---- the operator in this layout ---------------------------------------------------------------------------------
 // Per-operator device data of the tiled passes.  A chain bond b couples spins b, b+1 with the two matrix elements of
@@ -127,8 +132,19 @@ struct Sc3Call {
   double *dot_out = nullptr;       // 3 * sc3_dot_partials() doubles: per-workgroup <x,y> (re, im) and |y|^2
 };
 
+// Partition of the layout over ranks: rank r owns the T blocks [Tb[r], Tb[r+1]) (whole blocks, balanced by internal
+// length), i.e. a contiguous range of the internal layout AND of the reference order.  Tb has nranks + 1 entries.
+std::vector<uint32_t> sc3_partition(const Sc3Layout &ly, int nranks);
+// internal / reference offsets of the block range [T0, T1): start and length
+void sc3_range(const Sc3Layout &ly, uint32_t T0, uint32_t T1, int64_t *istart, int64_t *ilen, int64_t *nstart, int64_t *nlen);
+
 struct Sc3Mat {
   const Sc3Layout *ly = nullptr;
+  uint32_t T0 = 0, T1 = 0;         // the T blocks this rank's rows cover
+  int64_t row0 = 0;                // internal position of its first row
+  std::vector<uint32_t> rowsel;    // its rows (T << w | W), for the row kernel
+  void *d_rowsel = nullptr;
+  std::vector<char> needT;         // T blocks its rows read (own blocks included)
   bool tiled = false;              // two tiled passes (every off-diagonal mask is a chain bond); else the row kernel
   bool sym = false;                // every bond real and direction-independent
   int diag_mode = 0;               // 0: no diagonal terms; 2: on the fly; 1: needs the cached diagonal
@@ -142,7 +158,10 @@ struct Sc3Mat {
   ~Sc3Mat();
   int init(const Sc3Layout *layout, const std::vector<int64_t> &masks, const std::vector<int64_t> &mask_offsets,
            const std::vector<int64_t> &signs, const std::vector<double> &rcoef, const std::vector<ScMask> &scm,
-           bool want_device);
+           bool want_device, uint32_t T0, uint32_t T1);
+  // the internal positions [lo, hi] this rank's rows read; marks the chunks of 2^shift positions among them
+  void window(int64_t *lo, int64_t *hi) const;
+  void chunks(int shift, int64_t first_chunk, int64_t nchunks, uint8_t *map) const;
 };
 bool sc3_instance(int a, int w);           // kernel instances exist for this field split
 size_t sc3_dot_partials(const Sc3Mat &M);

@@ -87,6 +87,7 @@ sc3_lo_pass(const Sc3Tab S, const Sc3Op O, const uint32_t *__restrict__ perm, co
   c128 *xs = reinterpret_cast<c128 *>(smem);
   __shared__ int32_t cl[A * (A + 1)];
   __shared__ double red[3 * (NT / 64)];
+  __shared__ double dsh[5];
   const uint32_t e = perm[blockIdx.x];
   if (e == 0xffffffffu) return;
   const int lane = threadIdx.x & 63;
@@ -171,24 +172,30 @@ sc3_lo_pass(const Sc3Tab S, const Sc3Op O, const uint32_t *__restrict__ perm, co
     cl[tt] = S.cbin[lo * 17 + o];
   }
   // on-the-fly diagonal: what the row (T, W) contributes -- group 0 to every state of the row, groups 1..4 with the
-  // sign of a Lo pattern; one term per lane, wave sums (every wavefront computes them: no exchange needed)
-  double dg0 = 0.0, dgm[4] = {0.0, 0.0, 0.0, 0.0};
-  if (DIAGM == 2) {
+  // sign of a Lo pattern.  The first wavefront evaluates the terms, one per lane, and leaves the sums in LDS; they
+  // are applied after the barrier the tile needs anyway.
+  if (DIAGM == 2 && threadIdx.x < 64) {
     const uint64_t hi = ((uint64_t)T << w) | W;
     double v0 = 0.0, vm[4] = {0.0, 0.0, 0.0, 0.0};
     for (int t0 = 0; t0 < O.ndt; t0 += 64) {
       const int t = t0 + lane;
       if (t < O.ndt) {
-        const double c = flip(O.dt_coef[t], (uint32_t)__popcll(hi & O.dt_sign[t]) & 1u);
-        const int g = O.dt_group[t];
+        const uint64_t sg = O.dt_sign[t];                       // bits 61..63: the group
+        const double c = flip(O.dt_coef[t], (uint32_t)__popcll(hi & sg & 0x1fffffffffffffffull) & 1u);
+        const int g = (int)(sg >> 61);
         if (g == 0) v0 += c;
 #pragma unroll
         for (int j = 0; j < 4; ++j) if (g == j + 1) vm[j] += c;
       }
     }
-    dg0 = rl_f64(wave_sum(v0), 0);
+    v0 = wave_sum(v0);
+    if (lane == 0) dsh[0] = v0;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) if (j < O.ngroups) dgm[j] = rl_f64(wave_sum(vm[j]), 0);
+    for (int j = 0; j < 4; ++j)
+      if (j < O.ngroups) {
+        const double s = wave_sum(vm[j]);
+        if (lane == 0) dsh[j + 1] = s;
+      }
   }
   double accr[RPT], acci[RPT];
 #pragma unroll
@@ -200,13 +207,6 @@ sc3_lo_pass(const Sc3Tab S, const Sc3Op O, const uint32_t *__restrict__ perm, co
       xs[r] = xv[i];
       if (DIAGM == 1) {
         const double dg = __builtin_nontemporal_load(O.diag + lbase + r);
-        accr[i] = dg * xv[i].x;
-        acci[i] = dg * xv[i].y;
-      } else if (DIAGM == 2) {
-        double dg = O.dlo[S.lo_off[kl] + r] + dg0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (j < O.ngroups) dg += flip(dgm[j], (uint32_t)__popc(lowb[i] & O.glo[j]) & 1u);
         accr[i] = dg * xv[i].x;
         acci[i] = dg * xv[i].y;
       }
@@ -236,6 +236,20 @@ sc3_lo_pass(const Sc3Tab S, const Sc3Op O, const uint32_t *__restrict__ perm, co
     }
   }
   __syncthreads();
+  if (DIAGM == 2) {
+    const double dg0 = dsh[0];
+    const double *__restrict__ dl = O.dlo + S.lo_off[kl];
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+      const int r = threadIdx.x + i * NT;
+      if (r < nrows) {
+        double dg = dl[r] + dg0;
+        for (int j = 0; j < O.ngroups; ++j) dg += flip(dsh[j + 1], (uint32_t)__popc(lowb[i] & O.glo[j]) & 1u);
+        accr[i] = fma(dg, xv[i].x, accr[i]);
+        acci[i] = fma(dg, xv[i].y, acci[i]);
+      }
+    }
+  }
   for (int lo = 0; lo < A - 1; ++lo) {
     if (!((O.present >> lo) & 1ull)) continue;
     const double ure = O.bond[4 * lo], uim = O.bond[4 * lo + 1], dre = O.bond[4 * lo + 2], dim_ = O.bond[4 * lo + 3];
@@ -531,36 +545,39 @@ sc3_row_kernel(const Sc3Tab S, const DevMsc msc, const uint32_t *__restrict__ ro
 template <typename V>
 __global__ void __launch_bounds__(256)
 sc3_copy_kernel(const Sc3Tab S, const uint32_t *__restrict__ rows, V *__restrict__ dst, const V *__restrict__ src,
-                int to_internal) {
+                int to_internal, int64_t ioff, int64_t noff) {
+  // ioff / noff: where the (partitioned) vectors start in the internal layout / the reference order
   const uint32_t e = rows[blockIdx.x];
   const RowId R = decode_row(e, S);
-  const int64_t nat = S.nbase[R.T] + S.ncoff[(int64_t)R.kr * ((int64_t)1 << S.w) + R.W];
+  const int64_t nat = S.nbase[R.T] + S.ncoff[(int64_t)R.kr * ((int64_t)1 << S.w) + R.W] - noff;
+  const int64_t base = R.base - ioff;
   V zero{};
   for (int r = threadIdx.x; r < R.pitch; r += 256) {
-    if (to_internal) dst[R.base + r] = r < R.nrows ? src[nat + r] : zero;
-    else if (r < R.nrows) dst[nat + r] = src[R.base + r];
+    if (to_internal) dst[base + r] = r < R.nrows ? src[nat + r] : zero;
+    else if (r < R.nrows) dst[nat + r] = src[base + r];
   }
 }
 __global__ void __launch_bounds__(64)
-sc3_zero_pad_kernel(const Sc3Tab S, const uint32_t *__restrict__ rows, c128 *__restrict__ x) {
+sc3_zero_pad_kernel(const Sc3Tab S, const uint32_t *__restrict__ rows, c128 *__restrict__ x, int64_t ioff) {
   const RowId R = decode_row(rows[blockIdx.x], S);
-  for (int r = R.nrows + threadIdx.x; r < R.pitch; r += 64) x[R.base + r] = make_double2(0.0, 0.0);
+  for (int r = R.nrows + threadIdx.x; r < R.pitch; r += 64) x[R.base - ioff + r] = make_double2(0.0, 0.0);
 }
 __global__ void __launch_bounds__(256)
-sc3_random_kernel(const Sc3Tab S, const uint32_t *__restrict__ rows, c128 *__restrict__ x, uint64_t seed) {
+sc3_random_kernel(const Sc3Tab S, const uint32_t *__restrict__ rows, c128 *__restrict__ x, uint64_t seed, int64_t ioff) {
   const RowId R = decode_row(rows[blockIdx.x], S);
   const int64_t nat = S.nbase[R.T] + S.ncoff[(int64_t)R.kr * ((int64_t)1 << S.w) + R.W];
   for (int r = threadIdx.x; r < R.pitch; r += 256)
-    x[R.base + r] = r < R.nrows ? philox_normal((uint64_t)(nat + r), seed) : make_double2(0.0, 0.0);
+    x[R.base - ioff + r] = r < R.nrows ? philox_normal((uint64_t)(nat + r), seed) : make_double2(0.0, 0.0);
 }
 // reference index -> internal position: unrank (bsubspace_impl.h:210-228), then the tables
 __global__ void __launch_bounds__(256)
-sc3_positions_kernel(const Sc3Tab S, int64_t n, const int64_t *__restrict__ idx, int64_t *__restrict__ pos) {
+sc3_positions_kernel(const Sc3Tab S, int64_t n, const int64_t *__restrict__ idx, int64_t *__restrict__ pos, int64_t ioff,
+                     int64_t noff) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const int64_t *__restrict__ nck = S.nck;
   const int ld = S.L + 1;
-  int64_t id = idx[i];
+  int64_t id = idx[i] + noff;
   uint64_t st = 0;
   int k = S.k;
   for (int b = S.L; b > 0; --b) {
@@ -568,7 +585,7 @@ sc3_positions_kernel(const Sc3Tab S, int64_t n, const int64_t *__restrict__ idx,
     st <<= 1;
     if (id >= here) { id -= here; --k; st |= 1; }
   }
-  pos[i] = sc3_pos(st, S);
+  pos[i] = sc3_pos(st, S) - ioff;
 }
 
 }  // namespace
@@ -707,38 +724,65 @@ const Sc3Layout *sc3_get(int L, int k, int a, int w, bool want_device) {
 }
 
 // ---- utilities ------------------------------------------------------------------------------------------
-int sc3_layout_copy(const Sc3Layout &Ly, void *dst, const void *src, bool to_internal, hipStream_t st) {
+// the rows of the T blocks [T0, T1) inside Ly.rows (sorted by T, then W) and the offsets of that range
+struct RowRange { size_t first, count; int64_t ioff, noff; };
+static RowRange row_range(const Sc3Layout &Ly, uint32_t T0, uint32_t T1) {
+  const int w = Ly.host.w;
+  const auto lo = std::lower_bound(Ly.rows.begin(), Ly.rows.end(), (uint64_t)T0 << w,
+                                   [](uint32_t e, uint64_t v) { return (uint64_t)e < v; });
+  const auto hi = std::lower_bound(Ly.rows.begin(), Ly.rows.end(), (uint64_t)T1 << w,
+                                   [](uint32_t e, uint64_t v) { return (uint64_t)e < v; });
+  RowRange r;
+  r.first = (size_t)(lo - Ly.rows.begin());
+  r.count = (size_t)(hi - lo);
+  int64_t il, nl;
+  sc3_range(Ly, T0, T1, &r.ioff, &il, &r.noff, &nl);
+  return r;
+}
+
+int sc3_layout_copy(const Sc3Layout &Ly, void *dst, const void *src, bool to_internal, hipStream_t st, uint32_t T0, uint32_t T1) {
   DNM_CHECK(Ly.on_device, "layout tables are not on the device");
-  hipLaunchKernelGGL(sc3_copy_kernel<c128>, dim3((unsigned)Ly.rows.size()), dim3(256), 0, st, Ly.dev,
-                     (const uint32_t *)Ly.d_rows, (c128 *)dst, (const c128 *)src, to_internal ? 1 : 0);
+  const RowRange r = row_range(Ly, T0, T1);
+  if (!r.count) return 0;
+  hipLaunchKernelGGL(sc3_copy_kernel<c128>, dim3((unsigned)r.count), dim3(256), 0, st, Ly.dev,
+                     (const uint32_t *)Ly.d_rows + r.first, (c128 *)dst, (const c128 *)src, to_internal ? 1 : 0, r.ioff, r.noff);
   DNM_HIP(hipGetLastError());
   return 0;
 }
-int sc3_layout_copy_f64(const Sc3Layout &Ly, double *dst, const double *src, bool to_internal, hipStream_t st) {
+int sc3_layout_copy_f64(const Sc3Layout &Ly, double *dst, const double *src, bool to_internal, hipStream_t st, uint32_t T0,
+                        uint32_t T1) {
   DNM_CHECK(Ly.on_device, "layout tables are not on the device");
-  hipLaunchKernelGGL(sc3_copy_kernel<double>, dim3((unsigned)Ly.rows.size()), dim3(256), 0, st, Ly.dev,
-                     (const uint32_t *)Ly.d_rows, dst, src, to_internal ? 1 : 0);
+  const RowRange r = row_range(Ly, T0, T1);
+  if (!r.count) return 0;
+  hipLaunchKernelGGL(sc3_copy_kernel<double>, dim3((unsigned)r.count), dim3(256), 0, st, Ly.dev,
+                     (const uint32_t *)Ly.d_rows + r.first, dst, src, to_internal ? 1 : 0, r.ioff, r.noff);
   DNM_HIP(hipGetLastError());
   return 0;
 }
-int sc3_zero_padding(const Sc3Layout &Ly, void *x, hipStream_t st) {
+int sc3_zero_padding(const Sc3Layout &Ly, void *x, hipStream_t st, uint32_t T0, uint32_t T1) {
   DNM_CHECK(Ly.on_device, "layout tables are not on the device");
-  hipLaunchKernelGGL(sc3_zero_pad_kernel, dim3((unsigned)Ly.rows.size()), dim3(64), 0, st, Ly.dev,
-                     (const uint32_t *)Ly.d_rows, (c128 *)x);
+  const RowRange r = row_range(Ly, T0, T1);
+  if (!r.count) return 0;
+  hipLaunchKernelGGL(sc3_zero_pad_kernel, dim3((unsigned)r.count), dim3(64), 0, st, Ly.dev,
+                     (const uint32_t *)Ly.d_rows + r.first, (c128 *)x, r.ioff);
   DNM_HIP(hipGetLastError());
   return 0;
 }
-int sc3_random(const Sc3Layout &Ly, void *x, uint64_t seed, hipStream_t st) {
+int sc3_random(const Sc3Layout &Ly, void *x, uint64_t seed, hipStream_t st, uint32_t T0, uint32_t T1) {
   DNM_CHECK(Ly.on_device, "layout tables are not on the device");
-  hipLaunchKernelGGL(sc3_random_kernel, dim3((unsigned)Ly.rows.size()), dim3(256), 0, st, Ly.dev,
-                     (const uint32_t *)Ly.d_rows, (c128 *)x, seed);
+  const RowRange r = row_range(Ly, T0, T1);
+  if (!r.count) return 0;
+  hipLaunchKernelGGL(sc3_random_kernel, dim3((unsigned)r.count), dim3(256), 0, st, Ly.dev,
+                     (const uint32_t *)Ly.d_rows + r.first, (c128 *)x, seed, r.ioff);
   DNM_HIP(hipGetLastError());
   return 0;
 }
-int sc3_positions(const Sc3Layout &Ly, int64_t n, const int64_t *idx, int64_t *pos, hipStream_t st) {
+int sc3_positions(const Sc3Layout &Ly, int64_t n, const int64_t *idx, int64_t *pos, hipStream_t st, uint32_t T0, uint32_t T1) {
   DNM_CHECK(Ly.on_device, "layout tables are not on the device");
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(sc3_positions_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, Ly.dev, n, idx, pos);
+  const RowRange r = row_range(Ly, T0, T1);
+  hipLaunchKernelGGL(sc3_positions_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, Ly.dev, n, idx, pos, r.ioff,
+                     r.noff);
   DNM_HIP(hipGetLastError());
   return 0;
 }
@@ -763,17 +807,92 @@ static std::vector<uint32_t> deal(const std::vector<std::vector<uint32_t>> &grou
 bool sc3_instance(int a, int w) { return (a == 14 && w == 10) || (a == 6 && w == 4); }
 
 Sc3Mat::~Sc3Mat() {
-  for (void *p : {d_permA, d_permB, d_bond, d_dlo, d_dt_sign, d_dt_coef, d_dt_group})
+  for (void *p : {d_permA, d_permB, d_bond, d_dlo, d_dt_sign, d_dt_coef, d_dt_group, d_rowsel})
     if (p) (void)hipFree(p);
+}
+
+static int64_t block_len(const Sc3Layout &ly, uint32_t T) {        // internal length of the T block
+  if (ly.ibase[T] < 0) return 0;
+  for (uint32_t U = T + 1; U < (1u << ly.host.t); ++U)
+    if (ly.ibase[U] >= 0) return ly.ibase[U] - ly.ibase[T];
+  return ly.host.nint - ly.ibase[T];
+}
+
+std::vector<uint32_t> sc3_partition(const Sc3Layout &ly, int nranks) {
+  const uint32_t nT = 1u << ly.host.t;
+  std::vector<uint32_t> Tb((size_t)nranks + 1, nT);
+  Tb[0] = 0;
+  uint32_t T = 0;
+  for (int r = 1; r < nranks; ++r) {
+    const int64_t target = (int64_t)((__int128)ly.host.nint * r / nranks);
+    while (T < nT && (ly.ibase[T] < 0 || ly.ibase[T] < target)) ++T;
+    Tb[r] = T;
+  }
+  return Tb;
+}
+
+void sc3_range(const Sc3Layout &ly, uint32_t T0, uint32_t T1, int64_t *istart, int64_t *ilen, int64_t *nstart, int64_t *nlen) {
+  const uint32_t nT = 1u << ly.host.t;
+  auto first_valid = [&](uint32_t T) { while (T < nT && ly.ibase[T] < 0) ++T; return T; };
+  const uint32_t A = first_valid(T0), B = first_valid(T1);
+  const int64_t i0 = A < nT ? ly.ibase[A] : ly.host.nint, i1 = B < nT ? ly.ibase[B] : ly.host.nint;
+  const int64_t n0 = A < nT ? ly.nbase[A] : ly.dim, n1 = B < nT ? ly.nbase[B] : ly.dim;
+  *istart = i0; *ilen = i1 - i0; *nstart = n0; *nlen = n1 - n0;
+}
+
+void Sc3Mat::window(int64_t *lo, int64_t *hi) const {
+  int64_t a = INT64_MAX, b = INT64_MIN;
+  for (uint32_t T = 0; T < (uint32_t)needT.size(); ++T)
+    if (needT[T] && ly->ibase[T] >= 0) {
+      a = std::min(a, ly->ibase[T]);
+      b = std::max(b, ly->ibase[T] + block_len(*ly, T) - 1);
+    }
+  if (b < a) a = b = row0;
+  *lo = a;
+  *hi = b;
+}
+
+void Sc3Mat::chunks(int shift, int64_t first_chunk, int64_t nchunks, uint8_t *map) const {
+  for (int64_t c = 0; c < nchunks; ++c) map[c] = 0;
+  for (uint32_t T = 0; T < (uint32_t)needT.size(); ++T)
+    if (needT[T] && ly->ibase[T] >= 0) {
+      const int64_t c0 = (ly->ibase[T] >> shift) - first_chunk, c1 = ((ly->ibase[T] + block_len(*ly, T) - 1) >> shift) - first_chunk;
+      for (int64_t c = std::max<int64_t>(c0, 0); c <= c1 && c < nchunks; ++c) map[c] = 1;
+    }
 }
 
 int Sc3Mat::init(const Sc3Layout *layout, const std::vector<int64_t> &masks, const std::vector<int64_t> &mask_offsets,
                  const std::vector<int64_t> &signs, const std::vector<double> &rcoef, const std::vector<ScMask> &scm,
-                 bool want_device) {
+                 bool want_device, uint32_t T0_, uint32_t T1_) {
   ly = layout;
+  T0 = T0_;
+  T1 = T1_;
   const Sc3Tab &S = ly->host;
   const int L = S.L, a = S.a, w = S.w, t = S.t, k = S.k;
   const int64_t nmasks = (int64_t)masks.size();
+  {
+    int64_t il, ns, nl;
+    sc3_range(*ly, T0, T1, &row0, &il, &ns, &nl);
+  }
+  rowsel.clear();
+  for (uint32_t e : ly->rows) if ((e >> w) >= T0 && (e >> w) < T1) rowsel.push_back(e);
+  if (rowsel.empty()) rowsel.push_back(0xffffffffu);
+  if (want_device) DNM_TRY(up(rowsel, &d_rowsel));
+  // the T blocks these rows read: their own and, for every mask that flips bits of T, the partner's
+  needT.assign((size_t)1 << t, 0);
+  for (uint32_t T = T0; T < T1; ++T) {
+    if (ly->ibase[T] < 0) continue;
+    needT[T] = 1;
+    for (int64_t m = 0; m < nmasks; ++m) {
+      const uint64_t hm = (uint64_t)masks[m] >> (a + w);
+      const uint32_t U = T ^ (uint32_t)hm;
+      if (!hm || U >= (1u << t) || ly->ibase[U] < 0) continue;     // (a mask that leaves T alone reads T itself)
+      // a mask that flips bits of T only keeps the state in the subspace only if it keeps T's popcount
+      const bool inside_T = ((uint64_t)masks[m] & (((uint64_t)1 << (a + w)) - 1)) == 0;
+      if (inside_T && __builtin_popcount(U) != __builtin_popcount(T)) continue;
+      needT[U] = 1;
+    }
+  }
   // two tiled passes need every off-diagonal mask to be a chain bond with local signs (ScMask::fast)
   tiled = sc3_instance(a, w);
   for (int64_t m = 0; m < nmasks; ++m)
@@ -822,7 +941,7 @@ int Sc3Mat::init(const Sc3Layout *layout, const std::vector<int64_t> &masks, con
         if (j == groups.size()) groups.push_back(sg & lom);
         g = (int)j + 1;
       }
-      dt_sign.push_back(sg >> a);
+      dt_sign.push_back((sg >> a) | ((uint64_t)g << 61));
       dt_coef.push_back(c);
       dt_group.push_back(g);
     }
@@ -836,7 +955,7 @@ int Sc3Mat::init(const Sc3Layout *layout, const std::vector<int64_t> &masks, con
   // dispatch order: workgroups that gather from each other run on one XCD at one time (their requests meet in that
   // XCD's L2).  lo pass: groups (kt, cw, wr) over the T's of a popcount class; window pass: (kt, cw, run) likewise.
   std::vector<std::vector<uint32_t>> Tby(t + 1), gA, gB;
-  for (uint32_t T = 0; T < (1u << t); ++T) if (ly->ibase[T] >= 0) Tby[__builtin_popcount(T)].push_back(T);
+  for (uint32_t T = T0; T < T1 && T < (1u << t); ++T) if (ly->ibase[T] >= 0) Tby[__builtin_popcount(T)].push_back(T);
   for (int kt = 0; kt <= t; ++kt) {
     if (Tby[kt].empty()) continue;
     const int kr = k - kt;
@@ -859,6 +978,8 @@ int Sc3Mat::init(const Sc3Layout *layout, const std::vector<int64_t> &masks, con
   }
   permA = deal(gA);
   permB = deal(gB);
+  if (permA.empty()) permA.assign(8, 0xffffffffu);
+  if (permB.empty()) permB.assign(8, 0xffffffffu);
   if (want_device) {
     DNM_TRY(up(permA, &d_permA)); DNM_TRY(up(permB, &d_permB)); DNM_TRY(up(bond, &d_bond));
     op.bond = (const double *)d_bond;
@@ -921,8 +1042,8 @@ int launch_sc3(const Sc3Mat &M, const DevMsc &msc, const Sc3Call &call, const do
     return launch_two_pass<6, 4, 64>(M, call, cached_diag, xw, y, st);
   }
   DNM_CHECK(!call.dot_out, "internal: the row kernel has no fused sums");
-  hipLaunchKernelGGL(sc3_row_kernel, dim3((unsigned)M.ly->rows.size()), dim3(SC3_ROW_NT), 0, st, M.ly->dev, msc,
-                     (const uint32_t *)M.ly->d_rows, call, cached_diag, (const c128 *)xw, (c128 *)y);
+  hipLaunchKernelGGL(sc3_row_kernel, dim3((unsigned)M.rowsel.size()), dim3(SC3_ROW_NT), 0, st, M.ly->dev, msc,
+                     (const uint32_t *)M.d_rowsel, call, cached_diag, (const c128 *)xw, (c128 *)y);
   DNM_HIP(hipGetLastError());
   return 0;
 }

@@ -131,6 +131,18 @@ static const Sc3Layout *layout_of(const dnm_subspace *s, bool device) {
   return sc3_get((int)s->L, (int)s->k, a, w, device);
 }
 
+// the T blocks of a partition's rank (null: one rank)
+static int part_range(const Sc3Layout &ly, const dnm_partition *part, uint32_t *T0, uint32_t *T1) {
+  *T0 = 0;
+  *T1 = 0xffffffffu;
+  if (!part || part->nranks <= 1) return 0;
+  DNM_CHECK(part->rank >= 0 && part->rank < part->nranks, "bad partition (rank %d of %d)", part->rank, part->nranks);
+  const std::vector<uint32_t> Tb = sc3_partition(ly, part->nranks);
+  *T0 = Tb[part->rank];
+  *T1 = Tb[part->rank + 1];
+  return 0;
+}
+
 int dnm_vec_layout_size(const dnm_subspace *s, int64_t *n) {
   DNM_CHECK(n, "null argument");
   const Sc3Layout *ly = layout_of(s, false);
@@ -139,38 +151,64 @@ int dnm_vec_layout_size(const dnm_subspace *s, int64_t *n) {
   return 0;
 }
 
-int dnm_vec_layout_copy(const dnm_subspace *s, void *dst, const void *src, int to_internal, void *stream) {
+int dnm_vec_layout_partition(const dnm_subspace *s, int nranks, int rank, int64_t *istart, int64_t *ilen,
+                             int64_t *nstart, int64_t *nlen) {
+  DNM_CHECK(istart && ilen && nstart && nlen && nranks >= 1 && rank >= 0 && rank < nranks, "bad argument");
+  const Sc3Layout *ly = layout_of(s, false);
+  if (!ly) return 1;
+  const std::vector<uint32_t> Tb = sc3_partition(*ly, nranks);
+  sc3_range(*ly, Tb[rank], Tb[rank + 1], istart, ilen, nstart, nlen);
+  return 0;
+}
+
+int dnm_vec_layout_copy(const dnm_subspace *s, const dnm_partition *part, void *dst, const void *src, int to_internal,
+                        void *stream) {
   DNM_CHECK(dst && src && dst != src, "dnm_vec_layout_copy works out of place on non-null vectors");
   const Sc3Layout *ly = layout_of(s, true);
   if (!ly) return 1;
-  return sc3_layout_copy(*ly, dst, src, to_internal != 0, S(stream));
+  uint32_t T0, T1;
+  DNM_TRY(part_range(*ly, part, &T0, &T1));
+  return sc3_layout_copy(*ly, dst, src, to_internal != 0, S(stream), T0, T1);
 }
 
-int dnm_vec_layout_copy_f64(const dnm_subspace *s, double *dst, const double *src, int to_internal, void *stream) {
+int dnm_vec_layout_copy_f64(const dnm_subspace *s, const dnm_partition *part, double *dst, const double *src,
+                            int to_internal, void *stream) {
   DNM_CHECK(dst && src && dst != src, "dnm_vec_layout_copy_f64 works out of place on non-null arrays");
   const Sc3Layout *ly = layout_of(s, true);
   if (!ly) return 1;
-  return sc3_layout_copy_f64(*ly, dst, src, to_internal != 0, S(stream));
+  uint32_t T0, T1;
+  DNM_TRY(part_range(*ly, part, &T0, &T1));
+  return sc3_layout_copy_f64(*ly, dst, src, to_internal != 0, S(stream), T0, T1);
 }
 
-int dnm_vec_layout_zero_padding(const dnm_subspace *s, void *x, void *stream) {
+int dnm_vec_layout_zero_padding(const dnm_subspace *s, const dnm_partition *part, void *x, void *stream) {
   DNM_CHECK(x, "null vector");
   const Sc3Layout *ly = layout_of(s, true);
   if (!ly) return 1;
-  return sc3_zero_padding(*ly, x, S(stream));
+  uint32_t T0, T1;
+  DNM_TRY(part_range(*ly, part, &T0, &T1));
+  return sc3_zero_padding(*ly, x, S(stream), T0, T1);
 }
 
-int dnm_vec_layout_positions(const dnm_subspace *s, int64_t n, const int64_t *idx, int64_t *pos, void *stream) {
+int dnm_vec_layout_positions(const dnm_subspace *s, const dnm_partition *part, int64_t n, const int64_t *idx,
+                             int64_t *pos, void *stream) {
   DNM_CHECK(n == 0 || (idx && pos), "null argument");
   const Sc3Layout *ly = layout_of(s, true);
   if (!ly) return 1;
-  return sc3_positions(*ly, n, idx, pos, S(stream));
+  uint32_t T0, T1;
+  DNM_TRY(part_range(*ly, part, &T0, &T1));
+  return sc3_positions(*ly, n, idx, pos, S(stream), T0, T1);
 }
 
-int dnm_vec_layout_positions_host(const dnm_subspace *s, int64_t n, const int64_t *idx, int64_t *pos) {
+int dnm_vec_layout_positions_host(const dnm_subspace *s, const dnm_partition *part, int64_t n, const int64_t *idx,
+                                  int64_t *pos) {
   DNM_CHECK(n == 0 || (idx && pos), "null argument");
   const Sc3Layout *ly = layout_of(s, false);
   if (!ly) return 1;
+  uint32_t T0, T1;
+  DNM_TRY(part_range(*ly, part, &T0, &T1));
+  int64_t is, il, ns, nl;
+  sc3_range(*ly, T0, T1, &is, &il, &ns, &nl);
   SubView v{};
   v.type = DNM_SPIN_CONSERVE;
   v.L = ly->host.L;
@@ -178,17 +216,19 @@ int dnm_vec_layout_positions_host(const dnm_subspace *s, int64_t n, const int64_
   v.ld = ly->host.L + 1;
   v.nchoosek = ly->host.nck;
   for (int64_t i = 0; i < n; ++i) {
-    DNM_CHECK(idx[i] >= 0 && idx[i] < ly->dim, "index %lld out of range", (long long)idx[i]);
-    pos[i] = sc3_pos((uint64_t)Sub<DNM_SPIN_CONSERVE>::i2s(idx[i], v), ly->host);
+    DNM_CHECK(idx[i] >= 0 && idx[i] < nl, "index %lld out of range", (long long)idx[i]);
+    pos[i] = sc3_pos((uint64_t)Sub<DNM_SPIN_CONSERVE>::i2s(idx[i] + ns, v), ly->host) - is;
   }
   return 0;
 }
 
-int dnm_vec_layout_set_random(const dnm_subspace *s, void *x, uint64_t seed, void *stream) {
+int dnm_vec_layout_set_random(const dnm_subspace *s, const dnm_partition *part, void *x, uint64_t seed, void *stream) {
   DNM_CHECK(x, "null vector");
   const Sc3Layout *ly = layout_of(s, true);
   if (!ly) return 1;
-  return sc3_random(*ly, x, seed, S(stream));
+  uint32_t T0, T1;
+  DNM_TRY(part_range(*ly, part, &T0, &T1));
+  return sc3_random(*ly, x, seed, S(stream), T0, T1);
 }
 
 int dnm_vec_set_random(void *x, int64_t n, uint64_t seed, int64_t offset, void *stream) {

@@ -281,10 +281,11 @@ class SpinConserve(Subspace):
     @property
     def vec_swizzle(self):
         """Layout of this subspace's state vectors (dnm_subspace.vec_swizzle): a | w << 8 for the three-field
-        internal layout of csrc/sc3.h (one rank, large subspaces), 0 for the reference's index order."""
+        internal layout of csrc/sc3.h (large subspaces; partitions give whole blocks of equal top bits to a rank),
+        0 for the reference's index order."""
         from .config import config
         lay = config.sc_layout
-        if not lay or config.world_size > 1 or self.L is None:
+        if not lay or self.L is None:
             return 0
         a, w = lay
         if self.L - a - w < 1 or math.comb(self.L, self.k) < config.sc_layout_min_dim:

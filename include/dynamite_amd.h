@@ -80,7 +80,8 @@ typedef struct dnm_subspace {
    * dynamite_amd/csrc/sc3.h -- the blocks of equal top bits T = state >> (a + w) stay where the reference order has
    * them, inside a block the rows (T, W) are grouped by popcount(W), ordered by the rank of W, and padded to 128-byte
    * lines (padding holds zeros): a vector then has dnm_vec_layout_size() elements instead of C(L, k).  The two-pass
-   * SpinConserve multiply works in this layout; dnm_vec_layout_copy / _positions convert.  One rank only. */
+   * SpinConserve multiply works in this layout; dnm_vec_layout_copy / _positions convert.  Partitions hand whole
+   * T blocks to a rank (dnm_vec_layout_partition). */
   int32_t vec_swizzle;
 } dnm_subspace;
 
@@ -166,7 +167,7 @@ int dnm_mat_mult(dnm_mat *A, const void *x, void *y, void *stream);
 int dnm_mat_norm_inf(dnm_mat *A, double *nrm, void *stream);
 /* The vector layouts the matrix works in (dnm_subspace.vec_swizzle codes): what the descriptors asked for when the
  * matrix supports it, 0 (reference order) otherwise -- e.g. a SpinConserve descriptor with the internal layout paired
- * with another subspace, under XParity, or on several ranks.  The caller converts (dnm_vec_layout_copy) when a
+ * with another subspace or under XParity.  The caller converts (dnm_vec_layout_copy) when a
  * vector's layout differs.  With an internal layout dnm_mat_sizes reports the local lengths incl. padding. */
 int dnm_mat_layouts(const dnm_mat *A, int *left, int *right);
 int dnm_mat_set_norm(dnm_mat *A, double nrm);
@@ -233,6 +234,10 @@ int dnm_mat_mult_remote(dnm_mat *A, int32_t recv_index, const void *x_recv,
  * that window IN INDEX ORDER from the owners' blocks (send/recv) and multiplies.  y_local is the rank's block of
  * the left vector in that subspace's own layout. */
 int dnm_mat_ownership(const dnm_mat *A, int64_t *row0, int64_t *m_local);
+/* SpinConserve pairs in the internal layout (dnm_mat_layouts) partition differently: a rank owns whole blocks of equal
+ * top bits T -- a contiguous range of the internal layout (dnm_vec_layout_partition; balanced to within one block)
+ * that is also a contiguous range of the reference order -- and ownership, windows and chunks are expressed in
+ * positions of the internal layout: ranks exchange ranges of their vectors as they lie. */
 /* inclusive column range this rank's rows read; one device sweep, then cached */
 int dnm_mat_column_window(dnm_mat *A, int64_t *cmin, int64_t *cmax, void *stream);
 /* which chunks of 2^chunk_shift columns inside that window the rank's rows really read:
@@ -273,12 +278,22 @@ int dnm_vec_swizzle_copy(void *dst, const void *src, int64_t n, int swizzle, voi
  * the padding (VecSet, VecShift); positions: pos[i] = where reference index idx[i] lives (device arrays of n int64);
  * set_random: the numbers dnm_vec_set_random gives reference order, padding zero. */
 int dnm_vec_layout_size(const dnm_subspace *s, int64_t *n);
-int dnm_vec_layout_copy(const dnm_subspace *s, void *dst, const void *src, int to_internal, void *stream);
-int dnm_vec_layout_copy_f64(const dnm_subspace *s, double *dst, const double *src, int to_internal, void *stream);
-int dnm_vec_layout_zero_padding(const dnm_subspace *s, void *x, void *stream);
-int dnm_vec_layout_positions(const dnm_subspace *s, int64_t n, const int64_t *idx, int64_t *pos, void *stream);
-int dnm_vec_layout_positions_host(const dnm_subspace *s, int64_t n, const int64_t *idx, int64_t *pos);  /* host arrays */
-int dnm_vec_layout_set_random(const dnm_subspace *s, void *x, uint64_t seed, void *stream);
+/* the part of such a vector rank `rank` of `nranks` owns: [istart, istart + ilen) of the internal layout =
+ * [nstart, nstart + nlen) of the reference order */
+int dnm_vec_layout_partition(const dnm_subspace *s, int nranks, int rank, int64_t *istart, int64_t *ilen,
+                             int64_t *nstart, int64_t *nlen);
+/* `part` (null: one rank) selects the rank whose part of the vector the pointers hold; indices and positions are
+ * then local to that part */
+int dnm_vec_layout_copy(const dnm_subspace *s, const dnm_partition *part, void *dst, const void *src, int to_internal,
+                        void *stream);
+int dnm_vec_layout_copy_f64(const dnm_subspace *s, const dnm_partition *part, double *dst, const double *src,
+                            int to_internal, void *stream);
+int dnm_vec_layout_zero_padding(const dnm_subspace *s, const dnm_partition *part, void *x, void *stream);
+int dnm_vec_layout_positions(const dnm_subspace *s, const dnm_partition *part, int64_t n, const int64_t *idx,
+                             int64_t *pos, void *stream);
+int dnm_vec_layout_positions_host(const dnm_subspace *s, const dnm_partition *part, int64_t n, const int64_t *idx,
+                                  int64_t *pos);  /* host arrays */
+int dnm_vec_layout_set_random(const dnm_subspace *s, const dnm_partition *part, void *x, uint64_t seed, void *stream);
 /* h[j] = V_j^H w for j < nv (BVDotVec); V = nv vectors of length n, stride ldv elements.
  * h_host: 2*nv doubles. */
 int dnm_vec_mdot(const void *V, int64_t ldv, int nv, const void *w, int64_t n,

@@ -56,6 +56,10 @@ def _worker(rank, world, port, case, out_dir):
     L = 24 if case == "sc_big" else 14
     config.L = L
     config._initialize()
+    if case == "sc3":
+        # SpinConserve states in the internal three-field layout (csrc/sc3.h): ranks own whole blocks of equal top
+        # bits, windows and the exchange are expressed in positions of the layout (small kernel instances (6, 4))
+        config.sc_layout, config.sc_layout_min_dim = (6, 4), 0
     if case == "sc_big":
         # the default SpinConserve path of BASELINE config 5: 13-bit blocks, equal-size block order, blocks cut by
         # the ownership boundaries, column windows -- multiply only (2.7 M rows)
@@ -132,13 +136,22 @@ def _worker(rank, world, port, case, out_dir):
     x = State(subspace=sub, state='random', seed=3)
     start, end = x.vec.getOwnershipRange()
     from dynamite_amd.backend import split_ownership
-    assert (start, end - start) == split_ownership(dim, world, rank)
+    if case == "sc3":
+        assert x.vec.internal and "internal layout" in H.get_mat().describe()
+        import torch
+        t = torch.tensor([start, end], dtype=torch.int64)
+        allr = [torch.zeros(2, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(allr, t)
+        assert int(allr[0][0]) == 0 and int(allr[-1][1]) == dim
+        assert all(int(allr[q][1]) == int(allr[q + 1][0]) for q in range(world - 1))     # contiguous in reference order
+    else:
+        assert (start, end - start) == split_ownership(dim, world, rank)
     xg = x.to_numpy(to_all=True)
     assert xg.shape == (dim,) and abs(np.linalg.norm(xg) - 1) < 1e-12
     assert abs(x.norm() - 1) < 1e-12
 
     # multiply
-    if case != "sc":
+    if case not in ("sc", "sc3"):
         # exchange scheme: partner blocks on two ranks, the transposed all-to-all from four on (backend.py)
         want_scheme = {"full": "transpose" if world >= 4 else "partner", "full_partner": "partner",
                        "full_transpose": "transpose", "parity": "transpose" if world >= 4 else "partner"}[case]
@@ -199,7 +212,7 @@ def _worker(rank, world, port, case, out_dir):
 
 
 @pytest.mark.parametrize("case,world", [("full", 2), ("full", 4), ("full", 8), ("full_partner", 4), ("full_transpose", 2),
-                                        ("parity", 2), ("parity", 4), ("sc", 2), ("sc", 3),
+                                        ("parity", 2), ("parity", 4), ("sc", 2), ("sc", 3), ("sc3", 2), ("sc3", 3),
                                         ("sc_big", 3), ("explicit", 3), ("auto", 2), ("projection", 3),
                                         ("projection", 2), ("full_odd", 3), ("parity_odd", 3)])
 def test_partitioned_end_to_end_one_gpu(tmp_path, case, world):

@@ -1050,6 +1050,60 @@ def test_eigsolve_basis_free(monkeypatch, name, L, sub, which):
     assert eigsolve.last_stats['max_rel_residual'] < 1e-9
 
 
+@pytest.mark.parametrize("which", ["lowest", "highest"])
+@pytest.mark.parametrize("name,L,sub,nev", [("mbl", 13, "full", 5), ("heisenberg", 14, "sc", 3), ("xxz", 12, "parity", 4),
+                                            ("long_range", 11, "full", 3)])
+def test_eigsolve_filtered(monkeypatch, name, L, sub, nev, which):
+    """Thick-restart Lanczos on a Chebyshev filter of H (several pairs at one end of the spectrum; the default from 2^22
+    local amplitudes on, forced here): eigenvalues against dense diagonalisation -- every returned value must be an
+    eigenvalue and the extremal one must be found (degenerate levels may be missed by a Krylov solver,
+    computations.py:137-139) -- and the reference's Rayleigh-quotient / residual / orthogonality bars
+    (tests/integration/test_eigsolve.py:17-88, 127-137) at tol = 1e-12."""
+    monkeypatch.setenv("DNM_EIGS_FILTER", "1")
+    H = models.BY_NAME[name](L)
+    s = {"full": Full(L=L), "sc": SpinConserve(L, L // 2), "parity": Parity('even', L=L)}[sub]
+    H.add_subspace(s)
+    w = np.linalg.eigvalsh(H.to_numpy(subspaces=(s, s), sparse=False))
+    if which == "highest":
+        w = w[::-1]
+    from dynamite_amd.computations import eigsolve
+    ev, vecs = H.eigsolve(nev=nev, which=which, tol=1e-12, subspace=s, getvecs=True)
+    assert len(ev) >= nev
+    assert abs(ev[0] - w[0]) < 1e-9 * max(1.0, abs(w[0]))
+    for e in ev[:nev]:
+        assert np.min(np.abs(w - e)) < 1e-9 * max(1.0, abs(e))
+    assert all((ev[i] <= ev[i + 1] + 1e-12) if which == "lowest" else (ev[i] >= ev[i + 1] - 1e-12) for i in range(nev - 1))
+    assert eigsolve.last_stats['max_rel_residual'] <= 1e-12
+    for i, (e, v) in enumerate(zip(ev[:nev], vecs[:nev])):
+        Hv = H.dot(v)
+        assert abs(v.norm() - 1) < 1e-10
+        assert abs(Hv.dot(v).real - e) < max(1e-12, abs(e) * 1e-12) * 10
+        r = Hv.copy()
+        r.axpy(-e, v)
+        assert r.norm() < 1e-11 * max(1.0, abs(e))
+        for j in range(i):
+            assert abs(v.dot(vecs[j])) < 1e-12 * 10
+
+
+def test_eigsolve_filtered_default_at_size():
+    """L = 24 XXZ (2^24 amplitudes): eigsolve(nev=4) takes the filtered scheme on its own; its values agree with the
+    plain restarted scheme and the residuals hold the requested tolerance."""
+    import os
+    from dynamite_amd.computations import eigsolve
+    L = 24
+    H = models.xxz(L)
+    ev = H.eigsolve(nev=4, tol=1e-9)
+    st = dict(eigsolve.last_stats)
+    assert st['nconv'] >= 4 and st['max_rel_residual'] <= 1e-9
+    os.environ["DNM_EIGS_FILTER"] = "0"
+    try:
+        ev0 = H.eigsolve(nev=4, tol=1e-9)
+    finally:
+        del os.environ["DNM_EIGS_FILTER"]
+    assert np.abs(np.asarray(ev[:4]) - np.asarray(ev0[:4])).max() < 1e-7
+    assert st['matvecs'] != eigsolve.last_stats['matvecs']          # two different schemes ran
+
+
 @pytest.mark.default_layout
 def test_vec_layout_conversions_chunked():
     """Vec index operations under the production layout on a block larger than the conversion chunk (2^24):

@@ -1,0 +1,117 @@
+"""
+Host logic of the SpinConserve internal vector layout (dynamite_amd/csrc/sc3.h) -- no GPU needed: the position map
+is a bijection onto the non-padding slots that keeps the reference order (bsubspace_impl.h:187-245) at the level of
+the top-bit blocks and inside every row, partitions hand whole blocks to the ranks, and a host-only handle of
+BASELINE config 5 (SpinConserve(36, 18) on 8 ranks) plans the two tiled passes and its column windows.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+from dynamite_amd import _lib, backend, models, msc_tools
+from dynamite_amd.subspaces import SpinConserve
+
+
+def _desc(L, k, a, w):
+    sub = SpinConserve(L, k)
+    d = _lib.Subspace.from_buffer_copy(sub._c())
+    d.vec_swizzle = a | (w << 8)
+    return sub, d
+
+
+def _positions(d, n, part=None):
+    idx = np.arange(n, dtype=np.int64)
+    pos = np.empty_like(idx)
+    _lib.check(_lib.lib().dnm_vec_layout_positions_host(C.byref(d), C.byref(part) if part is not None else None, n,
+                                                        _lib.p64(idx), _lib.p64(pos)))
+    return pos
+
+
+@pytest.mark.parametrize("L,k,a,w", [(11, 5, 6, 4), (12, 6, 6, 4), (13, 3, 6, 4), (14, 7, 5, 4), (12, 0, 6, 4), (12, 12, 6, 4)])
+def test_positions_are_a_bijection_that_keeps_rows_together(L, k, a, w):
+    sub, d = _desc(L, k, a, w)
+    n = sub.get_dimension()
+    nint = C.c_int64()
+    _lib.check(_lib.lib().dnm_vec_layout_size(C.byref(d), C.byref(nint)))
+    pos = _positions(d, n)
+    assert len(np.unique(pos)) == n and pos.min() >= 0 and pos.max() < nint.value
+    assert nint.value >= n and nint.value % 8 == 0
+    states = sub.idx_to_state(np.arange(n))
+    # inside a row (equal bits above Lo) consecutive states sit at consecutive positions, rows start on 128-byte lines
+    hi = states >> a
+    same_row = hi[1:] == hi[:-1]
+    assert np.all(pos[1:][same_row] == pos[:-1][same_row] + 1)
+    first = np.concatenate(([True], ~same_row))
+    assert np.all(pos[first] % 8 == 0)
+    # blocks of equal top bits stay in the reference's order and are contiguous
+    T = states >> (a + w)
+    for t in np.unique(T):
+        p = pos[T == t]
+        later = pos[T > t]
+        assert later.size == 0 or p.max() < later.min()
+    # inside a block the rows are grouped by popcount(W), ascending
+    W = (states >> a) & ((1 << w) - 1)
+    cw = np.array([bin(int(v)).count('1') for v in W])
+    for t in np.unique(T):
+        sel = T == t
+        order = np.argsort(pos[sel], kind='stable')
+        assert np.all(np.diff(cw[sel][order]) >= 0)
+
+
+@pytest.mark.parametrize("P", [2, 3, 8])
+def test_partition_gives_whole_blocks(P):
+    L, k, a, w = 14, 7, 6, 4
+    sub, d = _desc(L, k, a, w)
+    n = sub.get_dimension()
+    nint = C.c_int64()
+    _lib.check(_lib.lib().dnm_vec_layout_size(C.byref(d), C.byref(nint)))
+    states = sub.idx_to_state(np.arange(n))
+    gpos = _positions(d, n)
+    i_end = n_end = 0
+    for r in range(P):
+        istart, ilen, nstart, nlen = backend.layout_partition(d, P, r)
+        assert istart == i_end and nstart == n_end          # contiguous in both index spaces
+        i_end, n_end = istart + ilen, nstart + nlen
+        if nlen:
+            T = states[nstart:nstart + nlen] >> (a + w)
+            others = np.concatenate((states[:nstart], states[nstart + nlen:])) >> (a + w)
+            assert not np.intersect1d(T, others).size       # whole blocks of equal top bits
+            part = _lib.Partition(r, P)
+            lp = _positions(d, nlen, part)
+            assert np.array_equal(lp + istart, gpos[nstart:nstart + nlen])
+    assert i_end == nint.value and n_end == n
+
+
+def test_config5_plan_on_the_host():
+    """SpinConserve(36, 18) on 8 ranks (BASELINE configs[4]) in the (14, 10) layout: 0.2 % padding, ranks balanced to a
+    block, the two tiled passes planned, and what a rank reads beyond its own part."""
+    L, k, a, w, P = 36, 18, 14, 10, 8
+    sub, d = _desc(L, k, a, w)
+    dim = math.comb(L, k)
+    nint = C.c_int64()
+    _lib.check(_lib.lib().dnm_vec_layout_size(C.byref(d), C.byref(nint)))
+    assert dim < nint.value < dim * 1.004
+    H = models.heisenberg(L)
+    H.establish_L()
+    H.reduce_msc()
+    masks, offs = msc_tools.get_mask_offsets(H.msc)
+    parts = [backend.layout_partition(d, P, r) for r in range(P)]
+    lens = [p[1] for p in parts]
+    assert max(lens) - min(lens) < 0.01 * nint.value / P
+    assert sum(p[3] for p in parts) == dim
+    for r in (0, 3, 7):
+        h = backend.create_mat(masks, offs, H.msc['signs'], H.msc['coeffs'], d, d, False, _lib.MAT_HOST_ONLY, r, P)
+        buf = C.create_string_buffer(4096)
+        _lib.check(_lib.lib().dnm_mat_plan_describe(h, buf, len(buf)))
+        s = buf.value.decode()
+        assert "two-pass" in s and "[T 12 | W 10 | Lo 14]" in s and "13 gathered" not in s
+        row0, ml = C.c_int64(), C.c_int64()
+        _lib.check(_lib.lib().dnm_mat_ownership(h, C.byref(row0), C.byref(ml)))
+        assert (row0.value, ml.value) == parts[r][:2]
+        lo, hi = C.c_int64(), C.c_int64()
+        _lib.check(_lib.lib().dnm_mat_column_window(h, C.byref(lo), C.byref(hi), None))
+        assert lo.value <= row0.value and hi.value >= row0.value + ml.value - 1
+        assert hi.value - lo.value + 1 <= nint.value
+        _lib.check(_lib.lib().dnm_mat_destroy(h))

@@ -54,6 +54,54 @@ lds_kernel(const d2v *__restrict__ x, d2v *__restrict__ y) {
   }
 }
 
+// the tile skeleton with the loads of a thread issued G at a time (G = R: all at once, as lds_kernel): fewer bytes in
+// flight per wavefront, more round trips per tile
+template <int NT, int R, int G>
+__global__ void __launch_bounds__(NT, (2048 / NT >= 8 ? 8 : 2048 / NT) * NT / 256)
+lds_serial_kernel(const d2v *__restrict__ x, d2v *__restrict__ y) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  d2v *tile = reinterpret_cast<d2v *>(smem);
+  const size_t base = (size_t)blockIdx.x * (NT * R);
+  const uint32_t tid = threadIdx.x;
+#pragma unroll
+  for (int k0 = 0; k0 < R; k0 += G) {
+    d2v v[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) v[g] = x[base + tid + (k0 + g) * NT];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int g = 0; g < G; ++g) tile[tid + (k0 + g) * NT] = v[g];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    const d2v a = tile[(tid ^ 1u) + k * NT], b = tile[(tid ^ 5u) + k * NT];
+    __builtin_nontemporal_store(a + b, y + base + tid + k * NT);
+  }
+}
+// ... and with the stores also spaced: store row k, then wait, before the next
+template <int NT, int R>
+__global__ void __launch_bounds__(NT, (2048 / NT >= 8 ? 8 : 2048 / NT) * NT / 256)
+lds_serial2_kernel(const d2v *__restrict__ x, d2v *__restrict__ y) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  d2v *tile = reinterpret_cast<d2v *>(smem);
+  const size_t base = (size_t)blockIdx.x * (NT * R);
+  const uint32_t tid = threadIdx.x;
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    const d2v v = x[base + tid + k * NT];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    tile[tid + k * NT] = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    const d2v a = tile[(tid ^ 1u) + k * NT], b = tile[(tid ^ 5u) + k * NT];
+    __builtin_nontemporal_store(a + b, y + base + tid + k * NT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+}
+
 static hipEvent_t e0, e1;
 template <class F>
 static double time_ms(F f, int reps) {
@@ -85,6 +133,27 @@ static void run_lds() {
   CK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const double t = time_ms([&] { hipLaunchKernelGGL(k, dim3((unsigned)(N / (NT * R))), dim3(NT), lds, 0, X, Y); }, 10);
   printf("lds    NT=%4d R=%d (tile %3zu KB)         stores=%-5s  %7.3f ms  %7.1f GB/s\n", NT, R, lds >> 10, NTS ? "nt" : "plain", t,
+         32.0 * N / 1e9 / t * 1e3);
+  fflush(stdout);
+}
+
+template <int NT, int R, int G>
+static void run_lds_serial() {
+  auto k = lds_serial_kernel<NT, R, G>;
+  const size_t lds = (size_t)NT * R * 16;
+  CK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const double t = time_ms([&] { hipLaunchKernelGGL(k, dim3((unsigned)(N / (NT * R))), dim3(NT), lds, 0, X, Y); }, 10);
+  printf("lds    NT=%4d R=%d (tile %3zu KB) loads %d at a time     %7.3f ms  %7.1f GB/s\n", NT, R, lds >> 10, G, t,
+         32.0 * N / 1e9 / t * 1e3);
+  fflush(stdout);
+}
+template <int NT, int R>
+static void run_lds_serial2() {
+  auto k = lds_serial2_kernel<NT, R>;
+  const size_t lds = (size_t)NT * R * 16;
+  CK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const double t = time_ms([&] { hipLaunchKernelGGL(k, dim3((unsigned)(N / (NT * R))), dim3(NT), lds, 0, X, Y); }, 10);
+  printf("lds    NT=%4d R=%d (tile %3zu KB) loads and stores 1 at a time %7.3f ms  %7.1f GB/s\n", NT, R, lds >> 10, t,
          32.0 * N / 1e9 / t * 1e3);
   fflush(stdout);
 }
@@ -127,5 +196,13 @@ int main(int argc, char **argv) {
   run_lds<1024, 2, true>();
   run_lds<1024, 4, true>();
   run_lds<1024, 4, false>();
+  run_lds_serial<1024, 4, 1>();
+  run_lds_serial<1024, 4, 2>();
+  run_lds_serial<1024, 4, 4>();
+  run_lds_serial<512, 8, 1>();
+  run_lds_serial<512, 8, 2>();
+  run_lds_serial<512, 8, 4>();
+  run_lds_serial2<1024, 4>();
+  run_lds_serial2<512, 8>();
   return 0;
 }

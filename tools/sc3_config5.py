@@ -1,0 +1,90 @@
+#!/usr/bin/env python
+"""BASELINE config 5 (SpinConserve(36, 18) Heisenberg chain on 8 ranks) in the internal three-field layout:
+what every rank owns and reads (host tables only, runs anywhere), and -- with a GPU -- one rank's share of the
+multiply at full size: its window of x in device memory, the two tiled passes, time per multiply.
+usage: sc3_config5.py [L k P] [--rank R]"""
+import os
+os.environ.setdefault("DNM_EXPERIMENTAL", "1")   # tools drive experiment knobs
+import ctypes as C
+import math
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+from dynamite_amd import _lib, backend, models, msc_tools  # noqa: E402
+from dynamite_amd.subspaces import SpinConserve  # noqa: E402
+
+
+def main():
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    L, k, P = (int(args[0]), int(args[1]), int(args[2])) if len(args) >= 3 else (36, 18, 8)
+    rank = int(sys.argv[sys.argv.index("--rank") + 1]) if "--rank" in sys.argv else None
+    a, w = 14, 10
+    sub = SpinConserve(L, k)
+    d = _lib.Subspace.from_buffer_copy(sub._c())
+    d.vec_swizzle = a | (w << 8)
+    dim = math.comb(L, k)
+    H = models.heisenberg(L)
+    H.establish_L()
+    H.reduce_msc()
+    masks, offs = msc_tools.get_mask_offsets(H.msc)
+    nint = C.c_int64()
+    _lib.check(_lib.lib().dnm_vec_layout_size(C.byref(d), C.byref(nint)))
+    print("SpinConserve(%d,%d): dim %d, internal length %d (+%.3f%%), %d ranks" % (L, k, dim, nint.value,
+                                                                                 100.0 * (nint.value - dim) / dim, P))
+    tot_need = 0
+    for r in range(P):
+        h = backend.create_mat(masks, offs, H.msc['signs'], H.msc['coeffs'], d, d, False, _lib.MAT_HOST_ONLY, r, P)
+        istart, ilen, nstart, nlen = backend.layout_partition(d, P, r)
+        lo, hi = C.c_int64(), C.c_int64()
+        _lib.check(_lib.lib().dnm_mat_column_window(h, C.byref(lo), C.byref(hi), None))
+        shift = max(0, int(hi.value - lo.value + 1).bit_length() - 11)
+        n = (hi.value >> shift) - (lo.value >> shift) + 1
+        cmap = np.zeros(n, dtype=np.uint8)
+        _lib.check(_lib.lib().dnm_mat_column_chunks(h, shift, cmap.ctypes.data_as(C.POINTER(C.c_uint8)), n, None))
+        need = backend.needed_ranges(cmap, shift, (lo.value, hi.value))
+        remote = sum(max(0, min(b, istart) - a_) + max(0, b - max(a_, istart + ilen)) for a_, b in need)
+        tot_need += remote
+        print("  rank %d: rows %d (%.2f GiB), window %.2f GiB, reads %.2f GiB from other ranks in %d ranges"
+              % (r, nlen, 16 * ilen / 2 ** 30, 16 * (hi.value - lo.value + 1) / 2 ** 30, 16 * remote / 2 ** 30, len(need)))
+        _lib.check(_lib.lib().dnm_mat_destroy(h))
+    print("  received per multiply, mean over the ranks: %.2f GiB" % (16 * tot_need / P / 2 ** 30))
+    if rank is None:
+        return
+    import torch
+    from dynamite_amd.config import config
+    config._initialize()
+    h = backend.create_mat(masks, offs, H.msc['signs'], H.msc['coeffs'], d, d, False, 0, rank, P)
+    mat = backend.ShellMat(h, d, d, P, rank)
+    print(mat.describe().strip())
+    lo, hi = mat.column_window()
+    wlen = hi - lo + 1
+    print("rank %d: window of %.1f GiB, rows %.1f GiB" % (rank, 16 * wlen / 2 ** 30, 16 * mat.m_local / 2 ** 30), flush=True)
+    xw = torch.empty(wlen, dtype=torch.complex128, device=config.device)
+    # any finite content does for the timing; normal deviates by chunks
+    for c0 in range(0, wlen, 1 << 28):
+        c1 = min(wlen, c0 + (1 << 28))
+        _lib.check(_lib.lib().dnm_vec_set_random(C.c_void_p(xw[c0:c1].data_ptr()), c1 - c0, 7, c0, backend._stream()))
+    y = torch.empty(mat.m_local, dtype=torch.complex128, device=config.device)
+    for _ in range(2):
+        _lib.check(_lib.lib().dnm_mat_mult_window(mat.handle, C.c_void_p(xw.data_ptr()), lo, wlen, C.c_void_p(y.data_ptr()),
+                                                  backend._stream()))
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    n = 5
+    for _ in range(n):
+        _lib.check(_lib.lib().dnm_mat_mult_window(mat.handle, C.c_void_p(xw.data_ptr()), lo, wlen, C.c_void_p(y.data_ptr()),
+                                                  backend._stream()))
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / n
+    rows = backend.layout_partition(d, P, rank)[3]
+    print("rank %d of %d, SpinConserve(%d,%d): %.2f ms per multiply for %d rows = %.2f Grows/s" % (rank, P, L, k, ms, rows,
+                                                                                                 rows / ms / 1e6))
+    assert torch.isfinite(torch.view_as_real(y)).all()
+
+
+if __name__ == "__main__":
+    main()
