@@ -435,7 +435,7 @@ class Vec:
         else:   # uneven blocks: pad to the largest
             mx = max(sizes)
             pad = torch.zeros(mx, dtype=self.array.dtype, device=self.array.device)
-            pad[:self.local_size] = self.local_natural()
+            pad[:self.rows] = self.local_natural()
             parts = [g[:n] for g, n in zip(_comm.all_gather(pad), sizes)]
         if not to_all and config.rank != 0:
             return None
@@ -717,18 +717,24 @@ class ShellMat:
     def _mult_transposed(self, x, y):
         """y = A x with the transposed exchange: the state goes to layout B (all-to-all, every link at once) while
         the masks that flip no top spin run here; the others are one rank-local pass in layout B, and its result
-        comes back through the same all-to-all and is added."""
+        comes back through the same all-to-all and is added.  ``self.trace`` (a list, tools/transpose_timeline.py):
+        every phase appends (name, seconds since the call began) after the device has finished it."""
         L = _lib.lib()
         lo, hi, pieces, own, cnt = self._tr
         xb, wb = self._transpose_buffers(x.array)
         vp = lambda t: C.c_void_p(t.data_ptr())
+        mark = self._trace_marker()
         reqs = post_transpose(x.array, xb, pieces)                              # runs on RCCL's stream
+        mark('forward all-to-all posted')
         for off in own:
             _lib.check(L.dnm_vec_copy(vp(x.array[off:off + cnt]), vp(xb[off:off + cnt]), cnt, _stream()))
         _lib.check(L.dnm_mat_mult_local(lo, x.ptr, y.ptr, _stream()))           # overlaps the all-to-all
+        mark('layout-A passes (masks that flip no rank bit)')
         for r in reqs:
             r.wait()
+        mark('forward all-to-all complete')
         _lib.check(L.dnm_mat_mult_local(hi, vp(xb), vp(wb), _stream()))
+        mark('layout-B pass (masks that flip rank bits)')
         # the way back (xb is free again) in TR_SUB * len(own) batches -- every piece travels as TR_SUB contiguous parts,
         # part by part over all peers: what a batch brought is added to y while the next ones are on the links, so the
         # only addition that is not hidden under a transfer is the last batch's (1 / (TR_SUB * len(own)) of the sweep)
@@ -740,18 +746,35 @@ class ShellMat:
             mine = [pc for pc in pieces if pc[1] // span == b]
             for k in range(sub):
                 batches.append((b, k, post_transpose(wb, xb, [(q, off + k * part, part) for q, off, _ in mine])))
+        mark('return all-to-all posted in %d batches' % len(batches))
         for off in own:
             _lib.check(L.dnm_vec_axpby(vp(y.array[off:off + cnt]), vp(wb[off:off + cnt]), cnt, 1.0, 0.0, 1.0, 0.0,
                                        _stream()))
-        for b, k, reqs in batches:
+        mark('own pieces added')
+        for i, (b, k, reqs) in enumerate(batches):
             for r in reqs:
                 r.wait()
-            off = own[b]
-            # the parts k of the pieces on either side of this rank's own piece: two strided groups of equal runs
+            # the parts k of the pieces on either side of this rank's own piece
             for q, poff, _ in [pc for pc in pieces if pc[1] // span == b]:
                 lo_ = poff + k * part
                 _lib.check(L.dnm_vec_axpby(vp(y.array[lo_:lo_ + part]), vp(xb[lo_:lo_ + part]), part, 1.0, 0.0, 1.0, 0.0,
                                            _stream()))
+            mark('return batch %d of %d received and added' % (i + 1, len(batches)))
+
+    trace = None   # set to a list to record the phases of _mult_transposed
+
+    def _trace_marker(self):
+        if self.trace is None:
+            return lambda name: None
+        import time
+        import torch
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+
+        def mark(name):
+            torch.cuda.synchronize()
+            self.trace.append((name, time.perf_counter() - t0))
+        return mark
 
     TR_SUB = 4     # parts a piece of the returning all-to-all travels in (_mult_transposed)
 

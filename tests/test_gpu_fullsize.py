@@ -119,9 +119,11 @@ def test_config4_one_rank_of_eight(rank):
 
 
 def test_config5_rank3_of_eight(monkeypatch):
-    """One rank of L=36, k=18 on 8 ranks: uneven PETSc-style ownership, device-computed column window, block
-    kernel against the row kernel and against the definition."""
+    """One rank of L=36, k=18 on 8 ranks in REFERENCE ORDER (config.sc_layout = None): uneven PETSc-style
+    ownership, device-computed column window, block kernel against the row kernel and against the definition."""
     import torch
+    from dynamite_amd.config import config
+    monkeypatch.setattr(config, "sc_layout", None)
     L, k, P, R = 36, 18, 8, 3
     sub = SpinConserve(L, k)
     dim = sub.get_dimension()
@@ -184,6 +186,73 @@ def test_config5_rank3_of_eight(monkeypatch):
     ynorm = out["13"].norm()
     out["0"].axpby(-1.0, 1.0, out["13"])
     assert out["0"].norm() <= 1e-13 * ynorm
+
+
+def test_config5_rank3_of_eight_internal_layout():
+    """The same share of BASELINE config 5 in the internal three-field layout (the default for a subspace of this
+    size): rank 3 owns whole blocks of equal top bits, its window is a range of the layout (only the blocks its
+    rows reach are marked as needed), the two tiled passes run on it, and sampled rows -- both ends, the middle,
+    powers of two, random -- are recomputed on the host from the definition."""
+    import ctypes as C
+    import torch
+    L, k, P, R = 36, 18, 8, 3
+    sub = SpinConserve(L, k)
+    d = sub._c()
+    assert d.vec_swizzle == (14 | (10 << 8))
+    H = models.heisenberg(L)
+    arrs = marshal(H)
+    masks, offs, signs, coeffs = arrs
+    istart, ilen, nstart, nlen = backend.layout_partition(d, P, R)
+    h = backend.create_mat(*arrs, d, d, flags=0, rank=R, nranks=P)
+    mat = backend.ShellMat(h, d, d, P, R)
+    assert "two-pass" in mat.describe() and mat.swz_right == d.vec_swizzle
+    assert (mat.row0, mat.m_local) == (istart, ilen)
+    lo, hi = mat.column_window()
+    assert lo <= istart and istart + ilen - 1 <= hi
+    _need(16 * (hi - lo + 1 + ilen) + (4 << 30))
+    needs = mat.column_needs((lo, hi))
+    covered = sum(b - a for a, b in needs)
+    assert len(needs) <= 16 and ilen < covered < 0.8 * (hi - lo + 1), (needs, ilen, hi - lo + 1)
+    Lb = _lib.lib()
+    xw = backend.Vec(hi - lo + 1)
+    xw.set_random(3)                  # (padding positions hold numbers too: rows must not depend on them)
+    y = backend.Vec(ilen)
+    _lib.check(Lb.dnm_mat_mult_window(mat.handle, xw.ptr, lo, hi - lo + 1, y.ptr, None))
+    torch.cuda.synchronize()
+
+    def positions(idx, part):
+        idx = np.ascontiguousarray(idx, dtype=np.int64)
+        out = np.empty_like(idx)
+        _lib.check(Lb.dnm_vec_layout_positions_host(C.byref(d), C.byref(part) if part is not None else None, idx.size,
+                                                    _lib.p64(idx), _lib.p64(out)))
+        return out
+    rs = np.random.RandomState(1)
+    rows = np.unique(np.concatenate([[0, nlen - 1], rs.randint(0, 1 << 30, 64) % nlen,
+                                     [(nlen >> s) for s in range(1, 30)]])).astype(np.int64)
+    kets = sub.idx_to_state(rows + nstart)
+    lpos = positions(rows, _lib.Partition(R, P))
+    ys = y.array[torch.from_numpy(lpos).to(y.array.device)].cpu().numpy()
+    worst, scale = 0.0, 0.0
+    for yv, ket in zip(ys, kets):
+        acc = 0j
+        bras = int(ket) ^ masks
+        cols = sub.state_to_idx(bras)
+        live = cols >= 0
+        gpos = np.full(cols.shape, -1, dtype=np.int64)
+        gpos[live] = positions(cols[live], None)
+        for m in range(len(masks)):
+            if cols[m] < 0:
+                continue
+            c = 0j
+            for t in range(offs[m], offs[m + 1]):
+                c += (1 - 2 * (bin(int(bras[m]) & int(signs[t])).count("1") & 1)) * coeffs[t]
+            if c != 0:
+                assert lo <= gpos[m] <= hi and any(a <= gpos[m] < b for a, b in needs), "a column that is read was not marked"
+                acc += c * complex(xw.array[int(gpos[m]) - lo].item())
+        worst = max(worst, abs(acc - yv))
+        scale = max(scale, abs(acc))
+    assert worst <= 1e-13 * max(1.0, scale) * len(masks), (worst, scale)
+    mat.destroy()
 
 
 def test_config4_hermiticity_between_ranks():

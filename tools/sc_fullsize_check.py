@@ -15,6 +15,7 @@ import torch  # noqa: E402
 from dynamite_amd import models, backend, msc_tools, _lib  # noqa: E402
 from dynamite_amd.config import config  # noqa: E402
 from dynamite_amd.subspaces import SpinConserve  # noqa: E402
+config.sc_layout = None      # this tool measures the reference-order kernels (tools/sc3_config5.py: the internal layout)
 
 
 def arrays(L):

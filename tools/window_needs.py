@@ -14,6 +14,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 from dynamite_amd import backend, models
 from dynamite_amd.subspaces import SpinConserve
+from dynamite_amd.config import config
+config.sc_layout = None      # this tool measures the reference-order kernels (tools/sc3_config5.py: the internal layout)
 from gpu_util import marshal
 
 L = int(sys.argv[1]) if len(sys.argv) > 1 else 36
