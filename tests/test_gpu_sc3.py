@@ -282,3 +282,51 @@ def test_production_instances_against_reference_order(L, k, name):
     y.axpby(-1.0, 1.0, Ha)
     assert y.norm() < 1e-13
     mat.destroy()
+
+
+def _random_chain(L, rs):
+    """Nearest-neighbour chain with random complex hopping per bond (some bonds missing), random ZZ couplings at
+    distance 1..3 and random fields: exercises absent bonds, direction-dependent complex matrix elements and several
+    diagonal patterns that see both Lo and the fields above it."""
+    from dynamite_amd.operators import sigmax, sigmay, sigmaz, op_sum
+    terms = []
+    for i in range(L - 1):
+        if rs.rand() < 0.2:
+            continue                                     # no hopping on this bond
+        a, b = rs.uniform(-1, 1), rs.uniform(-1, 1)
+        terms.append(a * (sigmax(i) * sigmax(i + 1) + sigmay(i) * sigmay(i + 1)))
+        if rs.rand() < 0.6:
+            terms.append(b * (sigmax(i) * sigmay(i + 1) - sigmay(i) * sigmax(i + 1)))
+    for i in range(L):
+        terms.append(rs.uniform(-1, 1) * sigmaz(i))
+        for dist in (1, 2, 3):
+            if i + dist < L and rs.rand() < 0.5:
+                terms.append(rs.uniform(-1, 1) * sigmaz(i) * sigmaz(i + dist))
+    H = op_sum(terms)
+    H.L = L
+    return H
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fuzz_internal_layout(small_layout, seed):
+    """Random chains (two tiled passes) and random Pauli-string sums (row kernel) on random SpinConserve sectors in the
+    internal layout, against the oracle."""
+    from test_gpu_matvec import _random_hermitian
+    rs = np.random.RandomState(1000 + seed)
+    L = int(rs.randint(11, 15))
+    k = int(rs.randint(1, L))
+    H = _random_chain(L, rs) if seed % 3 else _random_hermitian(L, 12, rs)
+    sub = SpinConserve(L, k)
+    n = sub.get_dimension()
+    x = rand_state(n, seed=seed)
+    want = orc.matvec(orc_msc(H), orc_sub(sub), orc_sub(sub), x)
+    mat = shell(H, sub)
+    assert "internal layout" in mat.describe()
+    if seed % 3:
+        assert "two-pass" in mat.describe()
+    if mat.uses_cached_diagonal():
+        mat.precompute_diagonal()
+    got = mult_numpy(mat, x)
+    scale = max(1.0, np.abs(H.msc['coeffs']).sum()) * np.abs(x).max()
+    assert np.abs(got - want).max() <= 64 * 2.2e-16 * scale, (L, k, mat.describe())
+    mat.destroy()

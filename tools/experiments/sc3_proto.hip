@@ -16,7 +16,7 @@
 //   Which pass gathers which of the non-LDS bonds is a bit mask (bondsA / bondsB).
 //
 // Build / run (GPU box):  hipcc --offload-arch=gfx950 -O3 tools/experiments/sc3_proto.hip -o /tmp/sc3_proto
-//                         /tmp/sc3_proto L k [a w orderA orderB tInA accA reps ntA ntB nbA nbB t1 variant]
+//                         /tmp/sc3_proto L k [a w orderA orderB tInA accA reps ntA ntB nbA nbB t1 variant shb]
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -49,6 +49,7 @@ struct Sc3 {
   const double *dlo;               // on-the-fly diagonal: the part that depends on Lo only, indexed like lo_pat
   const double *hfield;            // [L] field term of a site (+h for a zero bit, -h for a one)
   double zz;                       // ZZ coupling of every bond
+  int32_t shb;                     // window pass: log2 of the shortest run (4: 256-byte runs, 3: 128-byte runs)
   uint64_t bondsA, bondsB;         // non-LDS bonds gathered by the lo pass / the window pass
 };
 
@@ -292,10 +293,10 @@ sc3_lo_pass(const Sc3 S, const uint32_t *__restrict__ perm, const c128 *__restri
 
 // ---------------------------------------------------------------------------------------------------------
 // window pass: one workgroup per (T, cw, run of R = 16 << s columns): all window patterns of the class
-template <int WB, int NT, int NB, bool ACC, int DIAGM, bool SYM, bool EARLY>
+template <int WB, int NT, int NB, bool ACC, int DIAGM, bool SYM, bool EARLY, int SHB = 4>
 __global__ void __launch_bounds__(NT, (2048 / NT) * NT / 256)
 sc3_win_pass(const Sc3 S, const uint32_t *__restrict__ perm, const c128 *__restrict__ x, c128 *__restrict__ y) {
-  constexpr int MAXE = cbinom(WB, WB / 2) * 16;
+  constexpr int MAXE = cbinom(WB, WB / 2) * (1 << SHB);
   constexpr int RPT = (MAXE + NT - 1) / NT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   c128 *xs = reinterpret_cast<c128 *>(smem);
@@ -307,7 +308,7 @@ sc3_win_pass(const Sc3 S, const uint32_t *__restrict__ perm, const c128 *__restr
   const int cw = (e >> 12) & 15, run = e & 0xfff;
   const int kr = S.k - __popc(T), kl = kr - cw;
   const int nwp = S.nw[cw], p = S.pitch[kl];
-  const int sh = 4 + S.rs[cw];
+  const int sh = S.shb + S.rs[cw];
   const int lr0 = run << sh;
   const int ncols = min(1 << sh, p - lr0);
   const int64_t tb = S.ibase[T];
@@ -542,12 +543,14 @@ int main(int argc, char **argv) {
   // t1 (argv[14]): split of the T bonds between the passes when tInA == 2: the window pass gathers the W/T boundary
   // and the bonds inside the low t1 bits of T, the lo pass the bonds above (and the Lo/W boundary)
   const int t1 = argc > 14 ? atoi(argv[14]) : t / 2;
+  const int shb = argc > 16 ? atoi(argv[16]) : 4;
   if (t < 1 || t > 15 || a != 14 || w != 10) { printf("prototype instances: a=14 w=10, 1 <= t <= 15\n"); return 1; }
 
   // ---- tables
   Sc3 S;
   memset(&S, 0, sizeof S);
   S.L = L; S.k = k; S.a = a; S.w = w; S.t = t;
+  S.shb = shb;
   std::vector<int32_t> cbin(17 * 17);
   for (int n = 0; n < 17; ++n) for (int j = 0; j < 17; ++j) cbin[n * 17 + j] = (int32_t)binom(n, j);
   std::vector<uint16_t> lo_pat, w_pat, w_rank(1 << w);
@@ -693,7 +696,7 @@ int main(int argc, char **argv) {
           for (int cw = 0; cw <= w; ++cw) {
             const int kl = kr - cw;
             if (kl < 0 || kl > a) continue;
-            const int R = 16 << S.rs[cw], nrun = (S.pitch[kl] + R - 1) / R;
+            const int R = (1 << S.shb) << S.rs[cw], nrun = (S.pitch[kl] + R - 1) / R;
             for (int run = 0; run < nrun; ++run) {
               std::vector<uint32_t> g;
               for (uint32_t T : Ts) g.push_back((T << 16) | (cw << 12) | run);
@@ -709,7 +712,7 @@ int main(int argc, char **argv) {
         for (int cw = 0; cw <= w; ++cw) {
           const int kl = kr - cw;
           if (kl < 0 || kl > a) continue;
-          const int R = 16 << S.rs[cw], nrun = (S.pitch[kl] + R - 1) / R;
+          const int R = (1 << S.shb) << S.rs[cw], nrun = (S.pitch[kl] + R - 1) / R;
           for (int run = 0; run < nrun; ++run) {
             std::vector<uint32_t> g;
             for (uint32_t T : Tby[kt]) g.push_back((T << 16) | (cw << 12) | run);
@@ -724,7 +727,7 @@ int main(int argc, char **argv) {
         for (int cw = 0; cw <= w; ++cw) {
           const int kl = kr - cw;
           if (kl < 0 || kl > a) continue;
-          const int R = 16 << S.rs[cw], nrun = (S.pitch[kl] + R - 1) / R;
+          const int R = (1 << S.shb) << S.rs[cw], nrun = (S.pitch[kl] + R - 1) / R;
           std::vector<uint32_t> g;
           for (int run = 0; run < nrun; ++run) g.push_back((T << 16) | (cw << 12) | run);
           gB.push_back(g);
@@ -805,7 +808,7 @@ int main(int argc, char **argv) {
 
   const int ntA = argc > 10 ? atoi(argv[10]) : 512, ntB = argc > 11 ? atoi(argv[11]) : 512;
   const int nbA = argc > 12 ? atoi(argv[12]) : 2, nbB = argc > 13 ? atoi(argv[13]) : 2;
-  const size_t ldsA = (size_t)cbinom(14, 7) * 16, ldsB = (size_t)cbinom(10, 5) * 16 * 16;
+  const size_t ldsA = (size_t)cbinom(14, 7) * 16, ldsB = (size_t)cbinom(10, 5) * 16 * ((size_t)1 << S.shb);
   using kern_t = void (*)(const Sc3, const uint32_t *, const c128 *, c128 *);
   kern_t kA_acc = nullptr, kA_first = nullptr, kB_acc = nullptr, kB_first = nullptr;
   // variant (argv[15]): bit 0 = on-the-fly diagonal instead of the cached one, bit 1 = SYM, bit 2 = EARLY
@@ -823,6 +826,11 @@ int main(int argc, char **argv) {
   PICKV(NT_, NB_, 2, true, false) PICKV(NT_, NB_, 1, false, true) PICKV(NT_, NB_, 2, false, true) PICKV(NT_, NB_, 1, true, true) \
   PICKV(NT_, NB_, 2, true, true)
   PICKALL(512, 1) PICKALL(512, 2) PICKALL(1024, 1) PICKALL(1024, 2)
+  if (shb == 3) {          // 128-byte runs: 31.5 KB tiles, 512 threads x 4 entries, four workgroups per CU
+    const bool sy = (variant & 2) != 0;
+    kB_acc = sy ? sc3_win_pass<10, 512, 1, true, 0, true, false, 3> : sc3_win_pass<10, 512, 1, true, 0, false, false, 3>;
+    kB_first = sy ? sc3_win_pass<10, 512, 1, false, 0, true, false, 3> : sc3_win_pass<10, 512, 1, false, 0, false, false, 3>;
+  }
   if (!kA_acc || !kB_acc) { printf("no such kernel instance\n"); return 1; }
   CK(hipFuncSetAttribute((const void *)kA_acc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsA));
   CK(hipFuncSetAttribute((const void *)kA_first, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsA));
