@@ -154,6 +154,15 @@ def visible_gpus():
                     n += 1
         except OSError:
             pass
+    if n == 0:
+        # no readable KFD topology (or really no GPU): ask a short-lived child, which may initialise HIP and exit
+        import subprocess
+        try:
+            out = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"],
+                                 capture_output=True, text=True, timeout=300)
+            return int(out.stdout.strip().splitlines()[-1])
+        except Exception:
+            return 0
     for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
         v = os.environ.get(var)
         if v is not None:
