@@ -110,6 +110,9 @@ SIGNATURES = {
     "dnm_vec_layout_positions_host": (C.c_int, [C.POINTER(Subspace), C.POINTER(Partition), C.c_int64, i64p, i64p]),
     "dnm_vec_layout_set_random": (C.c_int, [C.POINTER(Subspace), C.POINTER(Partition), vp, C.c_uint64, vp]),
     "dnm_mat_layouts": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "dnm_mat_window_split": (C.c_int, [vp, C.POINTER(C.c_int)]),
+    "dnm_mat_mult_window_local": (C.c_int, [vp, vp, vp, vp]),
+    "dnm_mat_mult_window_remote": (C.c_int, [vp, vp, C.c_int64, C.c_int64, vp, vp]),
     "dnm_mat_destroy": (C.c_int, [vp]),
     "dnm_mat_sizes": (C.c_int, [vp, i64p, i64p, i64p, i64p]),
     "dnm_mat_precompute_diagonal": (C.c_int, [vp, vp]),

@@ -85,10 +85,11 @@ def needed_ranges(chunk_map, shift, window):
     return [(max(wlo, int(first + a) << shift), min(whi, int(first + b + 1) << shift)) for a, b in zip(starts, ends)]
 
 
-def exchange_window(x_local, owned, windows, me, window_buf=None, needs=None):
-    """Assemble this rank's column window from the owners' blocks with
-    torch.distributed send/recv (RCCL over xGMI on GPUs, gloo in CPU tests).  With ``needs`` only the ranges a
-    rank reads are moved; the rest of its window buffer keeps whatever it held (zeros from the allocation)."""
+def post_window_exchange(x_local, owned, windows, me, window_buf=None, needs=None):
+    """Post the transfers that assemble this rank's column window from the owners' blocks (torch.distributed
+    send/recv: RCCL over xGMI on GPUs, gloo in CPU tests) and copy the rank's own part in.  With ``needs`` only
+    the ranges a rank reads are moved; the rest of its window buffer keeps whatever it held (zeros from the
+    allocation).  Returns (window buffer, requests to wait for)."""
     import torch
     from . import _comm
     wlo, whi = windows[me][0], windows[me][1] + 1
@@ -100,6 +101,12 @@ def exchange_window(x_local, owned, windows, me, window_buf=None, needs=None):
                            [(window_buf[lo - wlo:hi - wlo], q) for q, lo, hi in recvs])
     a, b = max(wlo, my0), min(whi, my0 + myn)
     window_buf[a - wlo:b - wlo].copy_(x_local[a - my0:b - my0])
+    return window_buf, reqs
+
+
+def exchange_window(x_local, owned, windows, me, window_buf=None, needs=None):
+    """``post_window_exchange`` and the wait for its transfers."""
+    window_buf, reqs = post_window_exchange(x_local, owned, windows, me, window_buf, needs)
     for r in reqs:
         r.wait()
     return window_buf
@@ -471,6 +478,7 @@ class ShellMat:
         self._window_buf = None
         self._tr = None           # transposed exchange (set_transposed): (lo handle, hi handle, pieces, own, cnt)
         self._tr_bufs = None
+        self._splits = None       # window multiply in a local and a remote part (dnm_mat_window_split)
         self._msc = None          # (masks, mask_offsets, signs, coeffs, left subspace dict, right subspace dict): selfcheck
         self._check_pending = False
 
@@ -582,6 +590,8 @@ class ShellMat:
         from . import _comm
         if self._msc is None:
             raise RuntimeError('selfcheck needs the operator arrays (matrices built by build_mat have them)')
+        if knob('DNM_TEST_FAIL_SELFCHECK') == '1':       # tests: what a wrong first multiply looks like to the caller
+            return 1.0, 1.0
         masks, offs, signs, coeffs, lsub, rsub = self._msc
         lib = _lib.lib()
 
@@ -832,6 +842,13 @@ class ShellMat:
             return True
         return 'row-gather kernel' in d
 
+    def _window_splits(self):
+        if self._splits is None:
+            v = C.c_int()
+            _lib.check(_lib.lib().dnm_mat_window_split(self.handle, C.byref(v)))
+            self._splits = bool(v.value)
+        return self._splits
+
     def _is_windowed(self):
         """Partitions other than Full/Parity on 2^p ranks: rows split in index order (PetscSplitOwnership), the
         columns a rank reads come through a window gathered from its neighbours."""
@@ -879,8 +896,22 @@ class ShellMat:
         # the window is in index order: a swizzled block is straightened first (projection pairs); vectors in the
         # internal SpinConserve layout travel as they lie (the window is a range of the layout)
         xl = x.array if x.internal else x.local_natural()
-        self._window_buf = exchange_window(xl, self._owned, self._windows, self.rank, self._window_buf, self._needs)
         w0 = self._windows[self.rank][0]
+        if self._window_splits():
+            # two tiled passes in the internal SpinConserve layout: the part that reads only what the rank owns (bonds
+            # inside a block of equal top bits, the diagonal) runs while the window is on the links, the rest adds to
+            # it once the window is complete (the reference overlaps assembly and compute block by block,
+            # bpetsc_template_2.c:866-873)
+            L = _lib.lib()
+            self._window_buf, reqs = post_window_exchange(xl, self._owned, self._windows, self.rank, self._window_buf,
+                                                          self._needs)
+            _lib.check(L.dnm_mat_mult_window_local(self.handle, x.ptr, y.ptr, _stream()))
+            for r in reqs:
+                r.wait()
+            _lib.check(L.dnm_mat_mult_window_remote(self.handle, C.c_void_p(self._window_buf.data_ptr()), w0,
+                                                    self._window_buf.numel(), y.ptr, _stream()))
+            return
+        self._window_buf = exchange_window(xl, self._owned, self._windows, self.rank, self._window_buf, self._needs)
         _lib.check(_lib.lib().dnm_mat_mult_window(self.handle, C.c_void_p(self._window_buf.data_ptr()), w0,
                                                   self._window_buf.numel(), y.ptr, _stream()))
 

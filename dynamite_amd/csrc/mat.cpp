@@ -895,7 +895,7 @@ int dnm_mat_layouts(const dnm_mat *A, int *left, int *right) {
 
 // y = A x (- b z + c z2) in the SpinConserve internal layout; dot3 != null: the fused sums (device partials reduced here)
 static int sc3_mult(dnm_mat *A, const void *x, void *y, const void *z, double b, const void *z2, double c_re, double c_im,
-                    double *dot3_host, void *stream, int64_t win_start = -1) {
+                    double *dot3_host, void *stream, int64_t win_start = -1, int phase = 0) {
   Sc3Call call;
   call.row0 = A->sc3->row0;
   call.win_start = win_start >= 0 ? win_start : A->sc3->row0;     // one rank: x is the whole vector
@@ -905,7 +905,7 @@ static int sc3_mult(dnm_mat *A, const void *x, void *y, const void *z, double b,
   call.z2re = c_re;
   call.z2im = c_im;
   const double *dg = A->have_diag ? (const double *)A->diag.p : nullptr;
-  if (!dot3_host) return launch_sc3(*A->sc3, A->dmsc, call, dg, x, y, S(stream));
+  if (!dot3_host) return launch_sc3(*A->sc3, A->dmsc, call, dg, x, y, S(stream), phase);
   const size_t nwg = sc3_dot_partials(*A->sc3);
   double *part = nullptr;
   DNM_TRY(vec_scratch((nwg + 1) * 3 * sizeof(double), &part));
@@ -1180,6 +1180,31 @@ int dnm_mat_mult_window(dnm_mat *A, const void *x_window, int64_t win_start, int
   return launch_gather_matvec(A->dmsc, A->left.dev, A->right.dev, A->m_local,
                               A->have_diag ? (const double *)A->diag.p : nullptr, x_window, y_local, S(stream),
                               A->row0, win_start, 0, nullptr);
+}
+
+int dnm_mat_window_split(const dnm_mat *A, int *supported) {
+  DNM_CHECK(A && supported, "null argument");
+  *supported = (A->use_sc3 && A->sc3->tiled && A->nranks > 1) ? 1 : 0;
+  return 0;
+}
+
+int dnm_mat_mult_window_local(dnm_mat *A, const void *x_local, void *y_local, void *stream) {
+  DNM_CHECK(A && x_local && y_local && !A->host_only, "bad argument");
+  DNM_CHECK(A->use_sc3 && A->sc3->tiled, "this operator's window multiply does not split (dnm_mat_window_split)");
+  // the lo pass reads the rank's own rows and, for the Lo/W boundary bond, other rows of the same T block: all local
+  return sc3_mult(A, x_local, y_local, nullptr, 0.0, nullptr, 0.0, 0.0, nullptr, stream, A->sc3->row0, 1);
+}
+
+int dnm_mat_mult_window_remote(dnm_mat *A, const void *x_window, int64_t win_start, int64_t win_len, void *y_local,
+                               void *stream) {
+  DNM_CHECK(A && x_window && y_local && !A->host_only, "bad argument");
+  DNM_CHECK(A->use_sc3 && A->sc3->tiled, "this operator's window multiply does not split (dnm_mat_window_split)");
+  int64_t lo, hi;
+  DNM_TRY(dnm_mat_column_window(A, &lo, &hi, stream));
+  DNM_CHECK(win_start <= lo && win_start + win_len > hi,
+            "window [%lld, %lld) does not cover the positions [%lld, %lld] this rank reads", (long long)win_start,
+            (long long)(win_start + win_len), (long long)lo, (long long)hi);
+  return sc3_mult(A, x_window, y_local, nullptr, 0.0, nullptr, 0.0, 0.0, nullptr, stream, win_start, 2);
 }
 
 int dnm_mat_exchange_plan(const dnm_mat *A, int *nsend, dnm_xfer *sends, int *nrecv, dnm_xfer *recvs) {

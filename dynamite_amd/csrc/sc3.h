@@ -165,8 +165,11 @@ struct Sc3Mat {
 };
 bool sc3_instance(int a, int w);           // kernel instances exist for this field split
 size_t sc3_dot_partials(const Sc3Mat &M);
-// y = A x (- zscale zinit + z2 zinit2), fused sums if asked for; cached_diag: internal order or null
+// y = A x (- zscale zinit + z2 zinit2), fused sums if asked for; cached_diag: internal order or null.
+// phase 0: everything; tiled operators also split: phase 1 = the part whose columns a rank owns itself (the lo pass:
+// bonds inside Lo, the Lo/W boundary, the diagonal, the start vectors; writes y), phase 2 = the rest (the window
+// pass, adds to y) -- a partitioned multiply runs phase 1 while the window of x is assembled
 int launch_sc3(const Sc3Mat &M, const DevMsc &msc, const Sc3Call &call, const double *cached_diag, const void *xw,
-               void *y, hipStream_t st);
+               void *y, hipStream_t st, int phase = 0);
 
 }  // namespace dnm

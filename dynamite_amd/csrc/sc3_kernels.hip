@@ -77,7 +77,10 @@ __device__ __forceinline__ RowId decode_row(uint32_t e, const Sc3Tab &S) {
 //   over (kl, lr) (L2-resident), terms that see (T, W) only as one number per row, terms that see both as at most
 //   four (Lo sign mask, per-row coefficient) pairs.
 //   SYM: every bond coefficient is real and the same in both directions (Heisenberg, XXZ, XX chains).
-template <int A, int NT, int DIAGM, bool SYM>
+//   ACC: true = the second pass (y += ...); false = it runs first and writes y, starting from the solver's start
+//   vectors -- the order of a partitioned multiply, where this pass needs nothing from other ranks (a rank owns whole
+//   T blocks) and runs while the window of x is still on the links.
+template <int A, int NT, int DIAGM, bool SYM, bool ACC>
 __global__ void __launch_bounds__(NT, (2048 / NT) * NT / 256 > 8 ? 8 : (2048 / NT) * NT / 256)
 sc3_lo_pass(const Sc3Tab S, const Sc3Op O, const uint32_t *__restrict__ perm, const Sc3Call C,
             const c128 *__restrict__ xw, c128 *__restrict__ y) {
@@ -282,10 +285,23 @@ sc3_lo_pass(const Sc3Tab S, const Sc3Op O, const uint32_t *__restrict__ perm, co
     if (r < p) {                                  // the padding of a row is written too (zeros)
       double ar = accr[i], ai = acci[i];
       if (r < nrows) {
-        const c128 yo = load_nt(y + lbase + r);
-        ar += yo.x;
-        ai += yo.y;
-        if (C.dot_out) {                          // <x, y> and |y|^2 of the finished rows (the row of x is in LDS)
+        if (ACC) {
+          const c128 yo = load_nt(y + lbase + r);
+          ar += yo.x;
+          ai += yo.y;
+        } else if (C.zinit) {                     // y = A x - b z (+ c z2): the first pass carries the start vectors
+          const c128 zv = C.zinit[lbase + r];
+          ar = fma(-C.zscale, zv.x, ar);
+          ai = fma(-C.zscale, zv.y, ai);
+          if (C.zinit2) {
+            const c128 z2 = C.zinit2[lbase + r];
+            ar = fma(C.z2re, z2.x, ar);
+            ar = fma(-C.z2im, z2.y, ar);
+            ai = fma(C.z2re, z2.y, ai);
+            ai = fma(C.z2im, z2.x, ai);
+          }
+        }
+        if (ACC && C.dot_out) {                   // <x, y> and |y|^2 of the finished rows (the row of x is in LDS)
           const c128 xo = xs[r];
           dr = fma(xo.x, ar, dr);
           dr = fma(xo.y, ai, dr);
@@ -298,7 +314,7 @@ sc3_lo_pass(const Sc3Tab S, const Sc3Op O, const uint32_t *__restrict__ perm, co
       store_nt(y + lbase + r, ar, ai);
     }
   }
-  if (C.dot_out) {
+  if (ACC && C.dot_out) {
     dr = wave_sum(dr); di = wave_sum(di); dn = wave_sum(dn);
     if (lane == 0) {
       red[3 * (threadIdx.x >> 6)] = dr;
@@ -319,7 +335,7 @@ sc3_lo_pass(const Sc3Tab S, const Sc3Op O, const uint32_t *__restrict__ perm, co
 // ---------------------------------------------------------------------------------------------------------
 // window pass (the first pass: writes y): one workgroup per (T, cw, run of R = 16 << s columns): all window
 // patterns of the class x R columns in LDS; the accumulators start from -zscale * zinit + z2 * zinit2 if given.
-template <int WB, int NT, bool SYM>
+template <int WB, int NT, bool SYM, bool ACC>
 __global__ void __launch_bounds__(NT, (2048 / NT) * NT / 256 > 8 ? 8 : (2048 / NT) * NT / 256)
 sc3_win_pass(const Sc3Tab S, const Sc3Op O, const uint32_t *__restrict__ perm, const Sc3Call C,
              const c128 *__restrict__ xw, c128 *__restrict__ y) {
@@ -411,7 +427,7 @@ sc3_win_pass(const Sc3Tab S, const Sc3Op O, const uint32_t *__restrict__ perm, c
     acci[i] = 0.0;
     if (en < nent) {
       xs[en] = xv[i];
-      if (C.zinit && off[i] >= 0) {        // y = A x - b z (+ c z2): the start vectors open the accumulators
+      if (!ACC && C.zinit && off[i] >= 0) {        // y = A x - b z (+ c z2): the start vectors open the accumulators
         const c128 zv = C.zinit[lcb + off[i]];
         accr[i] = -C.zscale * zv.x;
         acci[i] = -C.zscale * zv.y;
@@ -477,7 +493,15 @@ sc3_win_pass(const Sc3Tab S, const Sc3Op O, const uint32_t *__restrict__ perm, c
   }
 #pragma unroll
   for (int i = 0; i < RPT; ++i)
-    if (off[i] >= 0) store_nt(y + lcb + off[i], accr[i], acci[i]);
+    if (off[i] >= 0) {
+      double ar = accr[i], ai = acci[i];
+      if (ACC) {
+        const c128 yo = load_nt(y + lcb + off[i]);
+        ar += yo.x;
+        ai += yo.y;
+      }
+      store_nt(y + lcb + off[i], ar, ai);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -993,9 +1017,11 @@ int Sc3Mat::init(const Sc3Layout *layout, const std::vector<int64_t> &masks, con
   return 0;
 }
 
+// phase 0: the whole multiply (window pass writes y, lo pass adds: one rank); phase 1: the part that needs nothing
+// from other ranks (lo pass, writes y); phase 2: the rest (window pass, adds)
 template <int A, int W, int NT>
 static int launch_two_pass(const Sc3Mat &M, const Sc3Call &call, const double *cached_diag, const void *xw, void *y,
-                           hipStream_t st) {
+                           hipStream_t st, int phase) {
   const Sc3Tab &S = M.ly->dev;
   constexpr size_t ldsA = (size_t)cbinom(A, A / 2) * 16, ldsB = (size_t)cbinom(W, W / 2) * 16 * 16;
   Sc3Op op = M.op;
@@ -1003,16 +1029,20 @@ static int launch_two_pass(const Sc3Mat &M, const Sc3Call &call, const double *c
   if (dm == 1) op.diag = cached_diag;
   DNM_CHECK(dm != 1 || op.diag, "this operator needs its diagonal precomputed (dnm_mat_precompute_diagonal)");
   using kern_t = void (*)(const Sc3Tab, const Sc3Op, const uint32_t *, const Sc3Call, const c128 *, c128 *);
-  const kern_t kB = M.sym ? sc3_win_pass<W, NT, true> : sc3_win_pass<W, NT, false>;
-  kern_t kA = nullptr;
+  const bool lo_first = phase != 0;
+  kern_t kB = nullptr, kA = nullptr;
+  if (lo_first) kB = M.sym ? sc3_win_pass<W, NT, true, true> : sc3_win_pass<W, NT, false, true>;
+  else kB = M.sym ? sc3_win_pass<W, NT, true, false> : sc3_win_pass<W, NT, false, false>;
+#define DNM_LO(DM_, SY_) (lo_first ? (kern_t)sc3_lo_pass<A, NT, DM_, SY_, false> : (kern_t)sc3_lo_pass<A, NT, DM_, SY_, true>)
   switch (dm * 2 + (M.sym ? 1 : 0)) {
-    case 0: kA = sc3_lo_pass<A, NT, 0, false>; break;
-    case 1: kA = sc3_lo_pass<A, NT, 0, true>; break;
-    case 2: kA = sc3_lo_pass<A, NT, 1, false>; break;
-    case 3: kA = sc3_lo_pass<A, NT, 1, true>; break;
-    case 4: kA = sc3_lo_pass<A, NT, 2, false>; break;
-    default: kA = sc3_lo_pass<A, NT, 2, true>; break;
+    case 0: kA = DNM_LO(0, false); break;
+    case 1: kA = DNM_LO(0, true); break;
+    case 2: kA = DNM_LO(1, false); break;
+    case 3: kA = DNM_LO(1, true); break;
+    case 4: kA = DNM_LO(2, false); break;
+    default: kA = DNM_LO(2, true); break;
   }
+#undef DNM_LO
   static std::map<const void *, bool> attr_done;
   for (auto kp : {std::make_pair((const void *)kA, ldsA), std::make_pair((const void *)kB, ldsB)})
     if (!attr_done[kp.first]) {
@@ -1023,10 +1053,12 @@ static int launch_two_pass(const Sc3Mat &M, const Sc3Call &call, const double *c
   first.dot_out = nullptr;
   second.zinit = nullptr;
   second.zinit2 = nullptr;
-  hipLaunchKernelGGL(kB, dim3((unsigned)M.permB.size()), dim3(NT), ldsB, st, S, op, (const uint32_t *)M.d_permB, first,
-                     (const c128 *)xw, (c128 *)y);
-  hipLaunchKernelGGL(kA, dim3((unsigned)M.permA.size()), dim3(NT), ldsA, st, S, op, (const uint32_t *)M.d_permA, second,
-                     (const c128 *)xw, (c128 *)y);
+  if (phase == 0 || phase == 2)
+    hipLaunchKernelGGL(kB, dim3((unsigned)M.permB.size()), dim3(NT), ldsB, st, S, op, (const uint32_t *)M.d_permB,
+                       phase == 0 ? first : second, (const c128 *)xw, (c128 *)y);
+  if (phase == 0 || phase == 1)
+    hipLaunchKernelGGL(kA, dim3((unsigned)M.permA.size()), dim3(NT), ldsA, st, S, op, (const uint32_t *)M.d_permA,
+                       phase == 0 ? second : first, (const c128 *)xw, (c128 *)y);
   DNM_HIP(hipGetLastError());
   return 0;
 }
@@ -1034,12 +1066,13 @@ static int launch_two_pass(const Sc3Mat &M, const Sc3Call &call, const double *c
 size_t sc3_dot_partials(const Sc3Mat &M) { return M.permA.size(); }
 
 int launch_sc3(const Sc3Mat &M, const DevMsc &msc, const Sc3Call &call, const double *cached_diag, const void *xw,
-               void *y, hipStream_t st) {
+               void *y, hipStream_t st, int phase) {
   DNM_CHECK(M.ly && M.ly->on_device, "layout tables are not on the device");
+  DNM_CHECK(phase == 0 || (M.tiled && !call.dot_out), "internal: only the tiled passes split into a local and a remote part");
   if (M.tiled) {
     if (call.dot_out) DNM_HIP(hipMemsetAsync(call.dot_out, 0, M.permA.size() * 3 * sizeof(double), st));
-    if (M.ly->host.a == 14) return launch_two_pass<14, 10, 1024>(M, call, cached_diag, xw, y, st);
-    return launch_two_pass<6, 4, 64>(M, call, cached_diag, xw, y, st);
+    if (M.ly->host.a == 14) return launch_two_pass<14, 10, 1024>(M, call, cached_diag, xw, y, st, phase);
+    return launch_two_pass<6, 4, 64>(M, call, cached_diag, xw, y, st, phase);
   }
   DNM_CHECK(!call.dot_out, "internal: the row kernel has no fused sums");
   hipLaunchKernelGGL(sc3_row_kernel, dim3((unsigned)M.rowsel.size()), dim3(SC3_ROW_NT), 0, st, M.ly->dev, msc,

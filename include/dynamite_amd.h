@@ -234,6 +234,14 @@ int dnm_mat_mult_remote(dnm_mat *A, int32_t recv_index, const void *x_recv,
  * that window IN INDEX ORDER from the owners' blocks (send/recv) and multiplies.  y_local is the rank's block of
  * the left vector in that subspace's own layout. */
 int dnm_mat_ownership(const dnm_mat *A, int64_t *row0, int64_t *m_local);
+/* Where dnm_mat_window_split says so (SpinConserve pairs in the internal layout, two tiled passes), the window multiply
+ * comes in two parts so that compute overlaps the exchange (bpetsc_template_2.c:866-873 overlaps assembly and compute
+ * block by block): _local needs the rank's own vector only (bonds inside a block of equal top bits, the diagonal) and
+ * WRITES y; _remote reads the assembled window and ADDS the bonds that reach other blocks.  y = _local, then _remote. */
+int dnm_mat_window_split(const dnm_mat *A, int *supported);
+int dnm_mat_mult_window_local(dnm_mat *A, const void *x_local, void *y_local, void *stream);
+int dnm_mat_mult_window_remote(dnm_mat *A, const void *x_window, int64_t win_start, int64_t win_len, void *y_local,
+                               void *stream);
 /* SpinConserve pairs in the internal layout (dnm_mat_layouts) partition differently: a rank owns whole blocks of equal
  * top bits T -- a contiguous range of the internal layout (dnm_vec_layout_partition; balanced to within one block)
  * that is also a contiguous range of the reference order -- and ownership, windows and chunks are expressed in

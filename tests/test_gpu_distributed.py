@@ -243,6 +243,25 @@ def test_bench_multi_rank_flow_one_gpu(world):
     assert d["config"]["exchange"] == ("transpose" if world >= 4 else "partner")
     assert d["config"]["xgmi_busiest_link_bytes"] > 0
     assert "cpu_baseline" not in d and d["roofline"]["bound"] == "hbm"
+    # the link rate measured in the run sits next to the assumed one; the transposed exchange validated itself
+    assert d["config"]["xgmi_link_GBs_measured"] > 0 and d["config"]["xgmi_exchange_only_ms"] > 0
+    assert d["config"]["exchange_selfcheck"].startswith("sampled rows" if world >= 4 else "not needed")
+
+
+def test_bench_falls_back_when_the_selfcheck_fails():
+    """A transposed-exchange operator whose first multiply fails its sampled-row check (forced here): every rank gets
+    the same verdict, the bench rebuilds the operator with partner blocks, times that, and says so in its line."""
+    import json
+    import subprocess
+    env = dict(os.environ, DNM_BENCH_BACKEND="gloo", DNM_TEST_FAIL_SELFCHECK="1", DNM_EXPERIMENTAL="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
+           "--gpus", "4", "--steps", "2", "--warmup", "1", "--L", "22"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["config"]["exchange"] == "partner" and d["config"]["exchange_selfcheck"].startswith("failed")
+    assert d["value"] > 0
 
 
 def _rccl_worker(rank, world, port, out_dir):
