@@ -293,7 +293,7 @@ sc3_lo_pass(const Sc3 S, const uint32_t *__restrict__ perm, const c128 *__restri
 
 // ---------------------------------------------------------------------------------------------------------
 // window pass: one workgroup per (T, cw, run of R = 16 << s columns): all window patterns of the class
-template <int WB, int NT, int NB, bool ACC, int DIAGM, bool SYM, bool EARLY, int SHB = 4>
+template <int WB, int NT, int NB, bool ACC, int DIAGM, bool SYM, bool EARLY, int SHB = 4, bool PIPE = false>
 __global__ void __launch_bounds__(NT, (2048 / NT) * NT / 256)
 sc3_win_pass(const Sc3 S, const uint32_t *__restrict__ perm, const c128 *__restrict__ x, c128 *__restrict__ y) {
   constexpr int MAXE = cbinom(WB, WB / 2) * (1 << SHB);
@@ -433,10 +433,23 @@ sc3_win_pass(const Sc3 S, const uint32_t *__restrict__ perm, const c128 *__restr
       }
     }
   }
-  if (EARLY && any) consume();
-  while (hb) { setup(); issue(); consume(); }
+  // PIPE: the gathered bonds ride on the LDS phase -- one gather is in flight while two LDS bonds are worked off,
+  // then it is consumed and the next one issued
+  bool pend = false;
+  if (PIPE) {
+    if (any && !EARLY) { setup(); issue(); }
+    pend = any;
+  } else {
+    if (EARLY && any) consume();
+    while (hb) { setup(); issue(); consume(); }
+  }
   __syncthreads();
   for (int lo = 0; lo < WB - 1; ++lo) {
+    if (PIPE && pend && lo > 0 && (lo & 1) == 0) {
+      consume();
+      pend = false;
+      if (hb) { setup(); issue(); pend = true; }
+    }
     const int b = S.a + lo;
     const double ure = S.bond[4 * b], uim = S.bond[4 * b + 1], dre = S.bond[4 * b + 2], dim_ = S.bond[4 * b + 3];
 #pragma unroll
@@ -460,6 +473,10 @@ sc3_win_pass(const Sc3 S, const uint32_t *__restrict__ perm, const c128 *__restr
         }
       }
     }
+  }
+  if (PIPE) {
+    if (pend) consume();
+    while (hb) { setup(); issue(); consume(); }
   }
 #pragma unroll
   for (int i = 0; i < RPT; ++i) {
@@ -826,6 +843,12 @@ int main(int argc, char **argv) {
   PICKV(NT_, NB_, 2, true, false) PICKV(NT_, NB_, 1, false, true) PICKV(NT_, NB_, 2, false, true) PICKV(NT_, NB_, 1, true, true) \
   PICKV(NT_, NB_, 2, true, true)
   PICKALL(512, 1) PICKALL(512, 2) PICKALL(1024, 1) PICKALL(1024, 2)
+  if (variant == 19) {     // gathers pipelined with the LDS phase (window pass), on-the-fly diagonal, symmetric bonds
+    kA_acc = sc3_lo_pass<14, 1024, 1, true, 2, true, false>;
+    kA_first = sc3_lo_pass<14, 1024, 1, false, 2, true, false>;
+    kB_acc = sc3_win_pass<10, 1024, 1, true, 0, true, true, 4, true>;
+    kB_first = sc3_win_pass<10, 1024, 1, false, 0, true, true, 4, true>;
+  }
   if (shb == 3) {          // 128-byte runs: 31.5 KB tiles, 512 threads x 4 entries, four workgroups per CU
     const bool sy = (variant & 2) != 0;
     kB_acc = sy ? sc3_win_pass<10, 512, 1, true, 0, true, false, 3> : sc3_win_pass<10, 512, 1, true, 0, false, false, 3>;
