@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Times the multiply in SpinConserve subspaces (generic row-gather kernel)."""
+"""Times the multiply in SpinConserve subspaces: sc_bench.py [--model NAME] L ...  (DNM_SC_LAYOUT=0: reference order)."""
 import os
 os.environ.setdefault("DNM_EXPERIMENTAL", "1")   # tools drive experiment knobs
 import sys
@@ -15,9 +15,16 @@ from dynamite_amd.subspaces import SpinConserve  # noqa: E402
 
 def main():
     config._initialize()
-    for L in [int(a) for a in sys.argv[1:]] or [24, 28, 32]:
+    model = "mbl"
+    args = list(sys.argv[1:])
+    if "--model" in args:
+        i = args.index("--model")
+        model = args[i + 1]
+        del args[i:i + 2]
+    for L in [int(a) for a in args] or [24, 28, 32]:
         k = L // 2
-        H = models.mbl(L)
+        H = models.BY_NAME[model](L)
+        H.establish_L()
         H.reduce_msc()
         masks, offs = msc_tools.get_mask_offsets(H.msc)
         sub = SpinConserve(L, k)
