@@ -68,7 +68,8 @@ class DevPass(C.Structure):
                 ("dbucket", C.c_uint32 * (MAXR + 1)), ("loop", C.c_uint32 * (LP_COUNT + 1)),
                 ("nquads", C.c_int32), ("n_eff", C.c_int32), ("quads", vp), ("dot_out", vp), ("zinit", vp), ("zscale", C.c_double), ("zinit2", vp), ("z2re", C.c_double), ("z2im", C.c_double),
                 ("tile_bits", C.c_int32), ("log_rows", C.c_int32),
-                ("swz_shift", C.c_int32), ("swz_xor_y", C.c_uint32), ("swz_xor_src", C.c_uint32), ("dtile", vp)]
+                ("swz_shift", C.c_int32), ("swz_xor_y", C.c_uint32), ("swz_xor_src", C.c_uint32), ("block_offset", C.c_uint32),
+                ("dtile", vp)]
 
 
 class Xfer(C.Structure):
@@ -76,6 +77,7 @@ class Xfer(C.Structure):
 
 
 MAT_DEFAULT, MAT_FORCE_GATHER, MAT_USE_GLDS, MAT_HOST_ONLY = 0, 1, 2, 4
+MAT_AMIN_SHIFT = 8        # flags bits 8..15: log2 of the contiguous run of a window tile
 WHICH = {"lowest": 0, "highest": 1, "exterior": 2}
 CONVERGED_TOL, CONVERGED_ITS, DIVERGED_ITS, DIVERGED_BREAKDOWN, DIVERGED_SYMMETRY_LOST = 1, 2, -1, -2, -3
 
@@ -111,6 +113,8 @@ SIGNATURES = {
     "dnm_vec_layout_set_random": (C.c_int, [C.POINTER(Subspace), C.POINTER(Partition), vp, C.c_uint64, vp]),
     "dnm_mat_layouts": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "dnm_mat_window_split": (C.c_int, [vp, C.POINTER(C.c_int)]),
+    "dnm_mat_mult_local_part": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp]),
+    "dnm_mat_local_part_bits": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "dnm_mat_mult_window_local": (C.c_int, [vp, vp, vp, vp]),
     "dnm_mat_mult_window_remote": (C.c_int, [vp, vp, C.c_int64, C.c_int64, vp, vp]),
     "dnm_mat_destroy": (C.c_int, [vp]),

@@ -478,6 +478,7 @@ class ShellMat:
         self._window_buf = None
         self._tr = None           # transposed exchange (set_transposed): (lo handle, hi handle, pieces, own, cnt)
         self._tr_bufs = None
+        self._tr_pipe = False     # layout-B pass and both all-to-alls run sub-piece by sub-piece (_mult_transposed_pipelined)
         self._splits = None       # window multiply in a local and a remote part (dnm_mat_window_split)
         self._msc = None          # (masks, mask_offsets, signs, coeffs, left subspace dict, right subspace dict): selfcheck
         self._check_pending = False
@@ -665,8 +666,17 @@ class ShellMat:
         n = (self.n_local - 1).bit_length()
         hs = []
         try:
-            for arrs in (lo, hi):
-                h = create_mat(*arrs, left_c, right_c, False, flags, self.rank, self.nranks)
+            for which, arrs in enumerate((lo, hi)):
+                fl = flags
+                if which == 1 and n - f <= 8:
+                    # layout B's masks live on the p exchanged bits and the top bit: a tile [0, a) + [f, n) holds them
+                    # all and leaves the bits right below f -- the top bits INSIDE a piece -- to the workgroup index,
+                    # so that ranges of workgroups are contiguous sub-pieces (dnm_mat_mult_local_part)
+                    tile_bits = int(knob('DNM_TILE_BITS', '12'))
+                    a = tile_bits - (n - f)
+                    if 2 <= a <= 9:
+                        fl |= a << _lib.MAT_AMIN_SHIFT
+                h = create_mat(*arrs, left_c, right_c, False, fl, self.rank, self.nranks)
                 hs.append(h)
                 snd, rcv = exchange_plan(h)
                 if snd or rcv:
@@ -677,6 +687,16 @@ class ShellMat:
             raise
         pieces, own, cnt = transpose_pieces(n, p, f, self.rank)
         self._tr = (hs[0], hs[1], pieces, own, cnt)
+        # sub-piece pipelining of the layout-B pass: its ranges of workgroups must be the top bits inside a piece and
+        # must not read outside themselves
+        top, gathers = C.c_int(), C.c_int()
+        _lib.check(_lib.lib().dnm_mat_local_part_bits(hs[1], C.byref(top), C.byref(gathers)))
+        sub = self.TR_SUB
+        logsub = sub.bit_length() - 1
+        swz = int(left_c.vec_swizzle)
+        self._tr_pipe = (knob('DNM_TRANSPOSE_PIPE', '1') != '0' and top.value == f - 1 and gathers.value == 0
+                         and cnt % sub == 0 and n - int(knob('DNM_TILE_BITS', '12')) >= logsub     # whole tiles per range
+                         and (swz == 0 or 2 * swz - 4 <= f - logsub))      # parts keep their order in the swizzled layout
 
     def launches_per_mult(self):
         """Kernel launches of one multiply on this rank (rank-local passes, partner passes / the pass in the
@@ -686,7 +706,7 @@ class ShellMat:
             _lib.check(_lib.lib().dnm_mat_plan_launches(h, C.byref(nl)))
             return nl.value
         if self._tr is not None:
-            return count(self._tr[0]) + count(self._tr[1]) + 1
+            return count(self._tr[0]) + count(self._tr[1]) * (self.TR_SUB if self._tr_pipe else 1) + 1
         return count(self.handle) + len(self.recvs)
 
     def exchange_summary(self):
@@ -729,6 +749,8 @@ class ShellMat:
         the masks that flip no top spin run here; the others are one rank-local pass in layout B, and its result
         comes back through the same all-to-all and is added.  ``self.trace`` (a list, tools/transpose_timeline.py):
         every phase appends (name, seconds since the call began) after the device has finished it."""
+        if self._tr_pipe:
+            return self._mult_transposed_pipelined(x, y)
         L = _lib.lib()
         lo, hi, pieces, own, cnt = self._tr
         xb, wb = self._transpose_buffers(x.array)
@@ -770,6 +792,46 @@ class ShellMat:
                 _lib.check(L.dnm_vec_axpby(vp(y.array[lo_:lo_ + part]), vp(xb[lo_:lo_ + part]), part, 1.0, 0.0, 1.0, 0.0,
                                            _stream()))
             mark('return batch %d of %d received and added' % (i + 1, len(batches)))
+
+    def _mult_transposed_pipelined(self, x, y):
+        """The transposed exchange sub-piece by sub-piece (the reference overlaps assembly of one block with compute of
+        the next, bpetsc_template_2.c:866-873).  Every piece of 2^f amplitudes is cut into TR_SUB contiguous parts; part
+        s of ALL pieces is what range s of the layout-B pass's workgroups reads and writes (its tile holds the
+        exchanged bits and the top bit, its workgroup index the bits below).  So: the forward all-to-all is posted part
+        by part; the layout-A passes run under it; as soon as part s has landed, range s of the layout-B pass runs and
+        its result goes straight back -- while part s + 1 is still arriving -- and is added to y on arrival.  Exposed
+        at the end: one part's return and addition."""
+        L = _lib.lib()
+        lo, hi, pieces, own, cnt = self._tr
+        xb, wb = self._transpose_buffers(x.array)
+        vp = lambda t: C.c_void_p(t.data_ptr())
+        mark = self._trace_marker()
+        sub = self.TR_SUB
+        part = cnt // sub
+        fwd = [post_transpose(x.array, xb, [(q, off + s * part, part) for q, off, _ in pieces]) for s in range(sub)]
+        mark('forward all-to-all posted in %d parts' % sub)
+        for off in own:
+            _lib.check(L.dnm_vec_copy(vp(x.array[off:off + cnt]), vp(xb[off:off + cnt]), cnt, _stream()))
+        _lib.check(L.dnm_mat_mult_local(lo, x.ptr, y.ptr, _stream()))           # overlaps the all-to-all
+        mark('layout-A passes (masks that flip no rank bit)')
+        back = []
+        for s in range(sub):
+            for r in fwd[s]:
+                r.wait()
+            _lib.check(L.dnm_mat_mult_local_part(hi, vp(xb), vp(wb), s, sub, _stream()))
+            # part s of xb has been consumed: it takes the returning part s
+            back.append(post_transpose(wb, xb, [(q, off + s * part, part) for q, off, _ in pieces]))
+            for off in own:
+                o = off + s * part
+                _lib.check(L.dnm_vec_axpby(vp(y.array[o:o + part]), vp(wb[o:o + part]), part, 1.0, 0.0, 1.0, 0.0, _stream()))
+            mark('part %d: landed, layout-B range run, return posted, own part added' % (s + 1))
+        for s in range(sub):
+            for r in back[s]:
+                r.wait()
+            for q, off, _ in pieces:
+                o = off + s * part
+                _lib.check(L.dnm_vec_axpby(vp(y.array[o:o + part]), vp(xb[o:o + part]), part, 1.0, 0.0, 1.0, 0.0, _stream()))
+            mark('returned part %d added' % (s + 1))
 
     trace = None   # set to a list to record the phases of _mult_transposed
 

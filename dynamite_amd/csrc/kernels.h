@@ -21,8 +21,9 @@ struct DevMsc {
 bool tile_config_supported(int B, int logR);
 
 // One pass of the tiled hypercube kernel over the local vector.
+// nparts > 1: only the 1/nparts of the workgroups that starts at P.block_offset
 int launch_tile_pass(const DevPass &P, int B, int logR, bool glds, int n_loc,
-                     const void *x, void *y, const void *xr, hipStream_t st);
+                     const void *x, void *y, const void *xr, hipStream_t st, unsigned nparts = 1);
 
 // y (+)= H x by one thread per row with index maps (MatMult semantics of
 // bcuda_template_2.cu:200-273 / bpetsc_template_2.c:371-412).

@@ -403,8 +403,8 @@ static hipStream_t S(void *stream) { return (hipStream_t)stream; }
 
 // d: the pass descriptor with this call's fields filled in; p: the pass it was copied from
 static int launch_pass(const dnm_mat *A, const PassOnDevice &p, const DevPass &d, const void *x, void *y,
-                       const void *xr, hipStream_t st) {
-  return launch_tile_pass(d, d.tile_bits, d.log_rows, (A->flags & DNM_MAT_USE_GLDS) != 0, p.n_eff, x, y, xr, st);
+                       const void *xr, hipStream_t st, unsigned nparts = 1) {
+  return launch_tile_pass(d, d.tile_bits, d.log_rows, (A->flags & DNM_MAT_USE_GLDS) != 0, p.n_eff, x, y, xr, st, nparts);
 }
 
 // partial sums a pass writes to dot_out: one per tile
@@ -820,6 +820,7 @@ int dnm_mat_create(int64_t nmasks, const int64_t *masks, const int64_t *mask_off
       A->op.n -= 1;
     }
     PlanConfig cfg = plan_config_from_env();
+    if (const int fa = (flags >> DNM_MAT_AMIN_SHIFT) & 0xff) cfg.amin = fa;      // caller-chosen run length of window tiles
     DNM_CHECK(A->left.host.swz == A->right.host.swz, "left and right vectors of a Full/Parity pair must share a layout");
     cfg.swz = A->left.host.swz;
     if (cfg.logR < 0) {
@@ -981,6 +982,43 @@ int dnm_mat_mult_local(dnm_mat *A, const void *x, void *y, void *stream) {
   if (A->sc_pair) return launch_sc(A, 0, A->N, x, y, stream);
   return launch_gather_matvec(A->dmsc, A->left.dev, A->right.dev, A->M,
                               A->have_diag ? (const double *)A->diag.p : nullptr, x, y, S(stream));
+}
+
+// The rank-local passes over ONE of nparts equal ranges of their workgroups (block ids [part, part + 1) * grid / nparts):
+// with an LDS-only plan whose tile holds the top index bits, range `part` reads and writes exactly the amplitudes whose
+// highest non-tile index bits equal `part` -- the transposed exchange runs its layout-B pass sub-piece by sub-piece.
+int dnm_mat_mult_local_part(dnm_mat *A, const void *x, void *y, int part, int nparts, void *stream) {
+  DNM_CHECK(A && x && y && x != y && !A->host_only, "bad argument");
+  DNM_CHECK(A->hypercube && A->plan.use_tiled, "only the tiled hypercube passes run over a range of their workgroups");
+  DNM_CHECK(nparts >= 1 && (nparts & (nparts - 1)) == 0 && part >= 0 && part < nparts, "bad range %d of %d", part, nparts);
+  for (auto &p : A->local_passes) {
+    const unsigned grid = 1u << (p->n_eff - p->desc.tile_bits);
+    DNM_CHECK((unsigned)nparts <= grid, "more ranges than workgroups");
+    DevPass d = p->desc;
+    d.block_offset = (uint32_t)part * (grid / (unsigned)nparts);
+    DNM_TRY(launch_pass(A, *p, d, x, y, nullptr, S(stream), (unsigned)nparts));
+  }
+  return 0;
+}
+
+// what the top non-tile index bits of the rank-local passes are: *top_free_bit = the highest index bit that is in no
+// pass's tile (the ranges of dnm_mat_mult_local_part split along it and the ones below it), -1 if passes disagree
+int dnm_mat_local_part_bits(const dnm_mat *A, int *top_free_bit, int *gathers) {
+  DNM_CHECK(A && top_free_bit && gathers, "null argument");
+  *top_free_bit = -1;
+  *gathers = 0;
+  if (!(A->hypercube && A->plan.use_tiled)) return 0;
+  int top = -2;
+  for (auto &p : A->local_passes) {
+    uint64_t tb = 0;
+    for (int j = 0; j < p->desc.nseg; ++j) tb |= ((((uint64_t)1 << p->desc.seg_len[j]) - 1) << p->desc.seg_pos[j]);
+    int hi = p->n_eff - 1;
+    while (hi >= 0 && ((tb >> hi) & 1)) --hi;
+    if (top == -2) top = hi; else if (top != hi) top = -1;
+    *gathers += (int)(p->desc.loop[LP_COUNT] - p->desc.loop[LP_GATHER_REAL]);     // gathered records
+  }
+  *top_free_bit = top < 0 ? -1 : top;
+  return 0;
 }
 
 // y = A x - b z, <x, y> = sum conj(x_i) y_i and |y|^2 (z may be null).  When the plan is tiled, the first pass

@@ -179,7 +179,7 @@ tile_pass_kernel(const DevPass P, const c128 *__restrict__ x, c128 *__restrict__
   c128 *tile = reinterpret_cast<c128 *>(smem);
 
   const uint32_t tid = threadIdx.x;
-  const uint32_t base = deposit<MAXBSEG>(blockIdx.x, P.nbseg, P.bseg_off, P.bseg_len, P.bseg_pos);
+  const uint32_t base = deposit<MAXBSEG>(blockIdx.x + P.block_offset, P.nbseg, P.bseg_off, P.bseg_len, P.bseg_pos);
   const uint32_t dep_t = deposit<MAXSEG>(tid, P.nseg, P.seg_off, P.seg_len, P.seg_pos);
   const uint64_t sbase = P.sign_base | (uint64_t)base;
 
@@ -428,7 +428,7 @@ tile_pass_kernel(const DevPass P, const c128 *__restrict__ x, c128 *__restrict__
 // ---------------------------------------------------------------------------
 template <int B, int LOGR>
 static int launch_cfg(const DevPass &P, bool glds, int n_loc, const void *x, void *y,
-                      const void *xr, hipStream_t st) {
+                      const void *xr, hipStream_t st, unsigned nparts) {
   constexpr int NT = 1 << (B - LOGR);
   // DNM_LDS_KB (experiments): request more LDS than the tile needs to cap the
   // number of resident workgroups per CU
@@ -437,7 +437,7 @@ static int launch_cfg(const DevPass &P, bool glds, int n_loc, const void *x, voi
     return e ? (size_t)atoi(e) * 1024 : (size_t)0;
   }();
   const size_t lds = std::max((size_t)16 << B, lds_req);
-  const unsigned grid = 1u << (n_loc - B);
+  const unsigned grid = (1u << (n_loc - B)) / nparts;       // nparts > 1: the range starting at P.block_offset
   // gather variant from the plan's cache policy: bit5 = early (default)
   const int gv = (P.cache_policy & 32) ? 1 : 0;
   using kern_t = void (*)(const DevPass, const c128 *, c128 *, const c128 *);
@@ -467,21 +467,21 @@ bool tile_config_supported(int B, int logR) {
 }
 
 int launch_tile_pass(const DevPass &P, int B, int logR, bool glds, int n_loc, const void *x,
-                     void *y, const void *xr, hipStream_t st) {
+                     void *y, const void *xr, hipStream_t st, unsigned nparts) {
   DNM_CHECK(n_loc >= B, "tile larger than the local vector");
   switch (B * 16 + logR) {
-    case 8 * 16 + 2: return launch_cfg<8, 2>(P, glds, n_loc, x, y, xr, st);
-    case 10 * 16 + 2: return launch_cfg<10, 2>(P, glds, n_loc, x, y, xr, st);
-    case 11 * 16 + 2: return launch_cfg<11, 2>(P, glds, n_loc, x, y, xr, st);
-    case 12 * 16 + 2: return launch_cfg<12, 2>(P, glds, n_loc, x, y, xr, st);
-    case 10 * 16 + 3: return launch_cfg<10, 3>(P, glds, n_loc, x, y, xr, st);
-    case 10 * 16 + 4: return launch_cfg<10, 4>(P, glds, n_loc, x, y, xr, st);
-    case 11 * 16 + 3: return launch_cfg<11, 3>(P, glds, n_loc, x, y, xr, st);
-    case 11 * 16 + 4: return launch_cfg<11, 4>(P, glds, n_loc, x, y, xr, st);
-    case 12 * 16 + 3: return launch_cfg<12, 3>(P, glds, n_loc, x, y, xr, st);
-    case 12 * 16 + 4: return launch_cfg<12, 4>(P, glds, n_loc, x, y, xr, st);
-    case 13 * 16 + 3: return launch_cfg<13, 3>(P, glds, n_loc, x, y, xr, st);
-    case 13 * 16 + 4: return launch_cfg<13, 4>(P, glds, n_loc, x, y, xr, st);
+    case 8 * 16 + 2: return launch_cfg<8, 2>(P, glds, n_loc, x, y, xr, st, nparts);
+    case 10 * 16 + 2: return launch_cfg<10, 2>(P, glds, n_loc, x, y, xr, st, nparts);
+    case 11 * 16 + 2: return launch_cfg<11, 2>(P, glds, n_loc, x, y, xr, st, nparts);
+    case 12 * 16 + 2: return launch_cfg<12, 2>(P, glds, n_loc, x, y, xr, st, nparts);
+    case 10 * 16 + 3: return launch_cfg<10, 3>(P, glds, n_loc, x, y, xr, st, nparts);
+    case 10 * 16 + 4: return launch_cfg<10, 4>(P, glds, n_loc, x, y, xr, st, nparts);
+    case 11 * 16 + 3: return launch_cfg<11, 3>(P, glds, n_loc, x, y, xr, st, nparts);
+    case 11 * 16 + 4: return launch_cfg<11, 4>(P, glds, n_loc, x, y, xr, st, nparts);
+    case 12 * 16 + 3: return launch_cfg<12, 3>(P, glds, n_loc, x, y, xr, st, nparts);
+    case 12 * 16 + 4: return launch_cfg<12, 4>(P, glds, n_loc, x, y, xr, st, nparts);
+    case 13 * 16 + 3: return launch_cfg<13, 3>(P, glds, n_loc, x, y, xr, st, nparts);
+    case 13 * 16 + 4: return launch_cfg<13, 4>(P, glds, n_loc, x, y, xr, st, nparts);
   }
   set_error("unsupported tile configuration B=%d logR=%d", B, logR);
   return 1;

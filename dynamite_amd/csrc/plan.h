@@ -118,6 +118,7 @@ struct DevPass {
   // sub-block and read a slice of the partner's block: the swizzle of the fixed offset bits is a constant XOR.
   int32_t swz_shift;
   uint32_t swz_xor_y, swz_xor_src;
+  uint32_t block_offset;   // first workgroup of a launch over a RANGE of the pass's workgroups (dnm_mat_mult_local_part)
   // diagonal terms whose sign mask lies entirely inside the tile do not depend on the block: their sum per tile
   // coordinate, 2^B doubles (32 KB at B = 12, L2-resident), computed once on the host -- one 8-byte load per
   // amplitude instead of ~25 vector instructions.  Terms that see the tile AND bits outside it stay in the

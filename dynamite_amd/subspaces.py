@@ -131,10 +131,11 @@ class Subspace:
         S = config.vec_swizzle
         from .backend import use_transposed_exchange
         if use_transposed_exchange(ws):
-            # the transposed exchange moves pieces of 2^f amplitudes, f = n_local_bits - 1 - p, between layouts:
-            # the swizzle field [S, 2S-4) has to end below them (backend.transpose_split)
+            # the transposed exchange moves pieces of 2^f amplitudes, f = n_local_bits - 1 - p, between layouts, each
+            # in ShellMat.TR_SUB = 4 contiguous parts: the swizzle field [S, 2S-4) has to end below the parts
+            # (backend.transpose_split, ShellMat._mult_transposed_pipelined)
             p = ws.bit_length() - 1
-            cap = ((dim.bit_length() - 1) - 2 * p - 1 + 4) // 2
+            cap = ((dim.bit_length() - 1) - 2 * p - 1 - 2 + 4) // 2
             if cap < S:
                 # shift 15 is the one value measured slower on MI355X (18.4-19.0 ms at 2^30 amplitudes against
                 # 17.4-18.0 for 13, 14 and 16; profiles/r02_exp29_transpose.txt, r02_exp30_transpose_probe.txt)

@@ -103,6 +103,8 @@ enum {
   DNM_MAT_FORCE_GATHER = 1,   /* use only the generic row-gather kernel */
   DNM_MAT_USE_GLDS     = 2,   /* stage LDS tiles with global_load_lds DMA instead of through registers
                                  (measured slower on MI355X for this access pattern; kept for A/B runs) */
+  DNM_MAT_AMIN_SHIFT   = 8,   /* flags bits 8..15: log2 of the contiguous run of a window tile (0: the planner's default);
+                                 the transposed exchange asks for tiles [0, a) + [f, n) so that sub-pieces are contiguous */
   DNM_MAT_HOST_ONLY    = 4    /* build the plan and its tables on the host only (no device needed;
                                  diagnostics and CPU tests) -- such a handle cannot multiply */
 };
@@ -239,6 +241,13 @@ int dnm_mat_ownership(const dnm_mat *A, int64_t *row0, int64_t *m_local);
  * block by block): _local needs the rank's own vector only (bonds inside a block of equal top bits, the diagonal) and
  * WRITES y; _remote reads the assembled window and ADDS the bonds that reach other blocks.  y = _local, then _remote. */
 int dnm_mat_window_split(const dnm_mat *A, int *supported);
+/* Tiled Full / Parity operators: the rank-local passes over one of `nparts` (a power of two) equal ranges of their
+ * workgroups.  dnm_mat_local_part_bits tells what a range is: *top_free_bit = the highest index bit outside every tile
+ * (range `part` covers the amplitudes whose log2(nparts) index bits ending there equal `part`), *gathers = records
+ * that read outside the tile (0: a range reads and writes its own amplitudes only).  The transposed exchange runs its
+ * layout-B pass sub-piece by sub-piece this way. */
+int dnm_mat_mult_local_part(dnm_mat *A, const void *x, void *y, int part, int nparts, void *stream);
+int dnm_mat_local_part_bits(const dnm_mat *A, int *top_free_bit, int *gathers);
 int dnm_mat_mult_window_local(dnm_mat *A, const void *x_local, void *y_local, void *stream);
 int dnm_mat_mult_window_remote(dnm_mat *A, const void *x_window, int64_t win_start, int64_t win_len, void *y_local,
                                void *stream);

@@ -102,14 +102,23 @@ def test_config4_plan_on_the_host(rank):
     assert split is not None
     lo, hi, f = split
     assert f == 31 - 1 - 3
+    import ctypes as C
     descr = []
-    for part in (lo, hi):
-        h = backend.create_mat(*part, lc, rc, False, _lib.MAT_HOST_ONLY, rank, world)
+    for which, part in enumerate((lo, hi)):
+        # layout B as ShellMat.set_transposed builds it: tiles [0, 8) + [f, n) so that ranges of workgroups are
+        # contiguous sub-pieces of the all-to-all's pieces
+        flags = _lib.MAT_HOST_ONLY | ((12 - (31 - f)) << _lib.MAT_AMIN_SHIFT if which == 1 else 0)
+        h = backend.create_mat(*part, lc, rc, False, flags, rank, world)
         assert backend.exchange_plan(h) == ([], [])
         descr.append(bench.C_describe(h))
+        if which == 1:
+            top, gathers = C.c_int(), C.c_int()
+            _lib.check(_lib.lib().dnm_mat_local_part_bits(h, C.byref(top), C.byref(gathers)))
+            assert (top.value, gathers.value) == (f - 1, 0)
         _lib.check(_lib.lib().dnm_mat_destroy(h))
     assert "n=34 n_loc=31" in descr[0] and "tiled=1" in descr[0] and descr[0].count("local pass") == 2
     assert "tiled=1" in descr[1] and descr[1].count("local pass") == 1        # layout B: one LDS-only window launch
+    assert "segs [0,8) [27,31)" in descr[1] and "gather_masks=0" in descr[1]
     pieces, own, cnt = backend.transpose_pieces(31, 3, f, rank)
     per_peer = {}
     for q, _, c in pieces:

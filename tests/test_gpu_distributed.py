@@ -156,6 +156,9 @@ def _worker(rank, world, port, case, out_dir):
         want_scheme = {"full": "transpose" if world >= 4 else "partner", "full_partner": "partner",
                        "full_transpose": "transpose", "parity": "transpose" if world >= 4 else "partner"}[case]
         assert H.get_mat().exchange_summary()["scheme"] == want_scheme
+        if want_scheme == "transpose" and case in ("full", "parity"):
+            # ... and runs sub-piece by sub-piece (forward parts, ranges of the layout-B pass, returns)
+            assert H.get_mat()._tr_pipe, "the transposed exchange should pipeline at this size"
     y = H.dot(x)
     yg = y.to_numpy(to_all=True)
     ref = orc.matvec(orc_msc(H), orc_sub(sub), orc_sub(sub), xg, nthreads=2)
