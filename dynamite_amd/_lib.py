@@ -69,7 +69,7 @@ class DevPass(C.Structure):
                 ("nquads", C.c_int32), ("n_eff", C.c_int32), ("quads", vp), ("dot_out", vp), ("zinit", vp), ("zscale", C.c_double), ("zinit2", vp), ("z2re", C.c_double), ("z2im", C.c_double),
                 ("tile_bits", C.c_int32), ("log_rows", C.c_int32),
                 ("swz_shift", C.c_int32), ("swz_xor_y", C.c_uint32), ("swz_xor_src", C.c_uint32), ("block_offset", C.c_uint32),
-                ("dtile", vp)]
+                ("pos_tmask", C.c_uint32), ("dtile", vp)]
 
 
 class Xfer(C.Structure):

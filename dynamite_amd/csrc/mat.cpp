@@ -207,7 +207,21 @@ static uint32_t compress_to_tile(uint64_t bits, const PassSpec &ps) {
 static int build_pass(const dnm_mat &A, const PassSpec &ps, PassOnDevice *out) {
   const OpForm &op = A.op;
   const Plan &pl = A.plan;
-  const int B = ps.B, logR = ps.logR ? ps.logR : pl.cfg.logR, lognt = B - logR, R = 1 << logR;
+  const int B = ps.B;
+  int logR = ps.logR ? ps.logR : pl.cfg.logR;
+  {
+    // the thread part of a position has to fit a 32-bit byte offset (DevPass::pos_tmask): a tile that reaches above
+    // bit 27 gives its top bits to the rows of a thread
+    auto top_thread_pos = [&](int lr) {
+      int c = 0, top = -1;
+      for (int j = 0; j < ps.nseg; ++j)
+        for (int i = 0; i < ps.seg_len[j]; ++i, ++c)
+          if (c < B - lr) top = std::max(top, ps.seg_pos[j] + i);
+      return top;
+    };
+    while (top_thread_pos(logR) >= 28 && tile_config_supported(B, logR + 1)) ++logR;
+  }
+  const int lognt = B - logR, R = 1 << logR;
   const int n_eff = ps.n_eff ? ps.n_eff : pl.n_loc;     // index bits this pass sweeps
   const uint64_t tb = ps.tile_bits();
   DevPass &d = out->desc;
@@ -279,6 +293,15 @@ static int build_pass(const dnm_mat &A, const PassSpec &ps, PassOnDevice *out) {
     };
     d.swz_xor_y = sw((uint64_t)ps.y_off);
     d.swz_xor_src = sw((uint64_t)ps.src_off);
+    // position bits the thread part of the tile coordinate reaches (the kernel keeps them in a 32-bit byte offset)
+    uint64_t tm = 0;
+    int c = 0;
+    for (int j = 0; j < ps.nseg; ++j)
+      for (int i = 0; i < ps.seg_len[j]; ++i, ++c)
+        if (c < lognt) tm |= ((uint64_t)1 << (ps.seg_pos[j] + i)) | sw((uint64_t)1 << (ps.seg_pos[j] + i));
+    DNM_CHECK((tm >> 28) == 0, "internal: thread bits of the tile above bit 27 (tile %llx, %d rows per thread)",
+              (unsigned long long)tb, R);
+    d.pos_tmask = (uint32_t)tm;
   }
 
   std::vector<DevQuad> quads;

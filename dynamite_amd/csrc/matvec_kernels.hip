@@ -39,6 +39,22 @@ __device__ __forceinline__ c128 load_streaming(const c128 *p) {
   return make_double2(v.x, v.y);
 }
 
+// Phase stamps of a workgroup (diagnostic builds only: DNM_HIPCC_EXTRA=-DDNM_PHASE_TIMING, tools/phase_times.py):
+// thread 0 writes the 100 MHz wall clock at eight points of tile_pass_kernel into a buffer set by
+// dnm_debug_phase_buffer; the waits that make a stamp mean "landed" slow the kernel down (L=30: 16.5 -> 25.8 ms)
+#ifdef DNM_PHASE_TIMING
+__device__ unsigned long long *g_phase_buf = nullptr;
+#define DNM_PH(i, waitvm)                                                                                  \
+  do {                                                                                                     \
+    if (waitvm) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                           \
+    if (g_phase_buf && threadIdx.x == 0)                                                                   \
+      g_phase_buf[((size_t)(P.accumulate ? gridDim.x : 0) + blockIdx.x) * 8 + (i)] = wall_clock64();        \
+    asm volatile("" ::: "memory");                                                                         \
+  } while (0)
+#else
+#define DNM_PH(i, waitvm)
+#endif
+
 // +-c by a parity bit: flips the IEEE sign bit (v_xor on the high dword)
 __device__ __forceinline__ double flip_sign(double c, uint32_t parity_bit) {
   int hi = __double2hiint(c) ^ (int)(parity_bit << 31);
@@ -62,6 +78,67 @@ __device__ __forceinline__ uint32_t deposit(uint32_t v, int nseg, const int32_t 
   return r;
 }
 
+// Where the R rows of a thread live.  position(row k) = upos ^ tpos ^ kpos[k]: the block part (wave-uniform), the
+// thread's tile coordinate, and the k bits (uniform per k).  Every bit the THREAD part can reach lies in tmask
+// (< 2^28, DevPass::pos_tmask), so the access to row k of a vector p, with a uniform XOR uxor on top, is
+//   (p + 16 * (u_k & ~tmask))  +  (t4 ^ 16 * (u_k & tmask)),     u_k = upos ^ uxor ^ kpos[k]:
+// a scalar base and a 32-bit byte offset -- one v_xor per 16-byte load or store, one address register per thread.
+template <int R>
+struct RowAddr {
+  uint32_t t4;        // 16 * tpos (per thread)
+  uint32_t upos;      // position of the block part
+  uint32_t tmask;
+  uint32_t kpos[R];
+  // (pointer arithmetic on the argument itself: a round trip through an integer would lose the global address space)
+  __device__ __forceinline__ const c128 *at(const c128 *p, int k, uint32_t uxor) const {
+    const uint32_t u = upos ^ uxor ^ kpos[k];
+    const char *b = reinterpret_cast<const char *>(p) + ((uint64_t)(u & ~tmask) << 4);
+    return reinterpret_cast<const c128 *>(b + (t4 ^ ((u & tmask) << 4)));
+  }
+  __device__ __forceinline__ c128 *at(c128 *p, int k, uint32_t uxor) const {
+    const uint32_t u = upos ^ uxor ^ kpos[k];
+    char *b = reinterpret_cast<char *>(p) + ((uint64_t)(u & ~tmask) << 4);
+    return reinterpret_cast<c128 *>(b + (t4 ^ ((u & tmask) << 4)));
+  }
+};
+
+// y += (coefficients of one record) * (partner amplitudes xv) for the R rows of this thread
+template <int R, int LOGNT, bool KVAR, bool CPLX>
+__device__ __forceinline__ void accum_record(const DevQuad &Q, double a0, double a1, double a2, double a3,
+                                             const c128 (&xv)[R], double (&ar)[R], double (&ai)[R]) {
+  if constexpr (!KVAR) {
+    const double cre = a0 + a1;
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      ar[k] = fma(cre, xv[k].x, ar[k]);
+      ai[k] = fma(cre, xv[k].y, ai[k]);
+    }
+    if constexpr (CPLX) {
+      const double cim = a2 + a3;
+#pragma unroll
+      for (int k = 0; k < R; ++k) {
+        ar[k] = fma(-cim, xv[k].y, ar[k]);
+        ai[k] = fma(cim, xv[k].x, ai[k]);
+      }
+    }
+  } else {
+    // per-row sign of each slot: one scalar parity, one v_xor on the high dword
+    const uint32_t s0 = Q.sign_tile[0] >> LOGNT, s1 = Q.sign_tile[1] >> LOGNT;
+    const uint32_t s2 = Q.sign_tile[2] >> LOGNT, s3 = Q.sign_tile[3] >> LOGNT;
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      const double cre = flip_sign(a0, (uint32_t)__popc(k & s0) & 1u) + flip_sign(a1, (uint32_t)__popc(k & s1) & 1u);
+      ar[k] = fma(cre, xv[k].x, ar[k]);
+      ai[k] = fma(cre, xv[k].y, ai[k]);
+      if constexpr (CPLX) {
+        const double cim = flip_sign(a2, (uint32_t)__popc(k & s2) & 1u) + flip_sign(a3, (uint32_t)__popc(k & s3) & 1u);
+        ar[k] = fma(-cim, xv[k].y, ar[k]);
+        ai[k] = fma(cim, xv[k].x, ai[k]);
+      }
+    }
+  }
+}
+
 // One loop of the off-diagonal part: records [b, e) all share the compile-time
 // traits, so the accumulators stay in place and the body has no branches.
 //   KVAR  : some sign mask reaches this thread's k bits -> the coefficient is
@@ -73,7 +150,7 @@ __device__ __forceinline__ uint32_t deposit(uint32_t v, int nseg, const int32_t 
 template <int R, int LOGNT, bool KVAR, bool CPLX, bool GATHER, bool K0>
 __device__ __forceinline__ void apply_records(const DevQuad *__restrict__ quads, uint32_t b, uint32_t e,
                                               double (&ar)[R], double (&ai)[R], const c128 *tile,
-                                              const uint32_t (&rows)[R], const c128 *__restrict__ x,
+                                              const RowAddr<R> &RA, const c128 *__restrict__ x,
                                               const c128 *__restrict__ xr, uint32_t tid, uint64_t sbase,
                                               uint32_t skw = 0, uint32_t xrx = 0) {
   constexpr uint32_t NT = 1u << LOGNT;
@@ -93,13 +170,13 @@ __device__ __forceinline__ void apply_records(const DevQuad *__restrict__ quads,
       const bool live = KVAR || (a0 + a1 != 0.0) || (CPLX && (a2 + a3 != 0.0));
       if (!__any(live)) continue;
       const c128 *__restrict__ src = Q.src ? xr : x;
-      // `rows` are positions (layout applied); the layout map is XOR-linear, so the partner of a mask sits at
-      // position(row) ^ position(mask): one scalar per record, one v_xor per load
+      // the layout map is XOR-linear, so the partner of a mask sits at position(row) ^ position(mask)
       const uint32_t mloc = Q.mask_loc;
       const uint32_t xm = (skw ? (mloc ^ (((mloc >> skw) & ((1u << (skw - 4)) - 1u)) << 4)) : mloc) ^ (Q.src ? xrx : 0u);
       if (live) {
+        // the partner sits at position(row) ^ position(mask)
 #pragma unroll
-        for (int k = 0; k < R; ++k) xv[k] = src[rows[k] ^ xm];
+        for (int k = 0; k < R; ++k) xv[k] = *RA.at(src, k, xm);
       } else {
 #pragma unroll
         for (int k = 0; k < R; ++k) xv[k] = make_double2(0.0, 0.0);
@@ -115,37 +192,7 @@ __device__ __forceinline__ void apply_records(const DevQuad *__restrict__ quads,
 #pragma unroll
       for (int k = 0; k < R; ++k) xv[k] = tile[p_lo + (((uint32_t)k ^ mk) << LOGNT)];
     }
-    if constexpr (!KVAR) {
-      const double cre = a0 + a1;
-#pragma unroll
-      for (int k = 0; k < R; ++k) {
-        ar[k] = fma(cre, xv[k].x, ar[k]);
-        ai[k] = fma(cre, xv[k].y, ai[k]);
-      }
-      if constexpr (CPLX) {
-        const double cim = a2 + a3;
-#pragma unroll
-        for (int k = 0; k < R; ++k) {
-          ar[k] = fma(-cim, xv[k].y, ar[k]);
-          ai[k] = fma(cim, xv[k].x, ai[k]);
-        }
-      }
-    } else {
-      // per-row sign of each slot: one scalar parity, one v_xor on the high dword
-      const uint32_t s0 = Q.sign_tile[0] >> LOGNT, s1 = Q.sign_tile[1] >> LOGNT;
-      const uint32_t s2 = Q.sign_tile[2] >> LOGNT, s3 = Q.sign_tile[3] >> LOGNT;
-#pragma unroll
-      for (int k = 0; k < R; ++k) {
-        const double cre = flip_sign(a0, (uint32_t)__popc(k & s0) & 1u) + flip_sign(a1, (uint32_t)__popc(k & s1) & 1u);
-        ar[k] = fma(cre, xv[k].x, ar[k]);
-        ai[k] = fma(cre, xv[k].y, ai[k]);
-        if constexpr (CPLX) {
-          const double cim = flip_sign(a2, (uint32_t)__popc(k & s2) & 1u) + flip_sign(a3, (uint32_t)__popc(k & s3) & 1u);
-          ar[k] = fma(-cim, xv[k].y, ar[k]);
-          ai[k] = fma(cim, xv[k].x, ai[k]);
-        }
-      }
-    }
+    accum_record<R, LOGNT, KVAR, CPLX>(Q, a0, a1, a2, a3, xv, ar, ai);
   }
 }
 
@@ -179,25 +226,24 @@ tile_pass_kernel(const DevPass P, const c128 *__restrict__ x, c128 *__restrict__
   c128 *tile = reinterpret_cast<c128 *>(smem);
 
   const uint32_t tid = threadIdx.x;
+  DNM_PH(0, 0);
   const uint32_t base = deposit<MAXBSEG>(blockIdx.x + P.block_offset, P.nbseg, P.bseg_off, P.bseg_len, P.bseg_pos);
   const uint32_t dep_t = deposit<MAXSEG>(tid, P.nseg, P.seg_off, P.seg_len, P.seg_pos);
   const uint64_t sbase = P.sign_base | (uint64_t)base;
 
-  // local row of the k-th amplitude this thread owns: tile coordinate tid + k*NT
-  uint32_t rows[R];
-#pragma unroll
-  for (int k = 0; k < R; ++k)
-    rows[k] = base | dep_t | deposit<MAXSEG>((uint32_t)k << LOGNT, P.nseg, P.seg_off, P.seg_len, P.seg_pos);
-
-  // XOR-swizzled vector layout: index bits [s, 2s-4) are folded onto bits [4, s); sub-block
-  // passes add the swizzle of the block's own offset (swz_xor_y for y, swz_xor_src for the partner's amplitudes)
+  // positions of the rows this thread owns (tile coordinate tid + k*NT): see RowAddr.  XOR-swizzled vector layout
+  // (DESIGN.md section 3): index bits [s, 2s-4) are folded onto bits [4, s); the map is linear, so it applies to the
+  // block part, the thread part and the k part separately.  Sub-block passes add the swizzle of the block's own
+  // offset (swz_xor_y for y, swz_xor_src for the partner's amplitudes)
   const uint32_t skw = (uint32_t)P.swz_shift;
-  uint32_t arows[R], yrows[R];
+  auto lay = [skw](uint32_t v) -> uint32_t { return skw ? (v ^ (((v >> skw) & ((1u << (skw - 4)) - 1u)) << 4)) : v; };
+  RowAddr<R> RA;
+  RA.t4 = lay(dep_t) << 4;
+  RA.upos = lay(base);
+  RA.tmask = P.pos_tmask;
 #pragma unroll
-  for (int k = 0; k < R; ++k) {
-    arows[k] = skw ? (rows[k] ^ (((rows[k] >> skw) & ((1u << (skw - 4)) - 1u)) << 4)) : rows[k];
-    yrows[k] = arows[k] ^ P.swz_xor_y;
-  }
+  for (int k = 0; k < R; ++k) RA.kpos[k] = lay(deposit<MAXSEG>((uint32_t)k << LOGNT, P.nseg, P.seg_off, P.seg_len, P.seg_pos));
+  const uint32_t yx = P.swz_xor_y;
 
   // ---- stage the tile: each wavefront moves 1 KB runs, lane = low 6 tile bits
   if (!P.need_tile) {
@@ -205,20 +251,21 @@ tile_pass_kernel(const DevPass P, const c128 *__restrict__ x, c128 *__restrict__
   } else if constexpr (GLDS) {
 #pragma unroll
     for (int k = 0; k < R; ++k)
-      __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *)(x + arows[k]),
+      __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *)RA.at(x, k, 0u),
                                        (LDS_AS void *)(tile + (k * NT + (tid & ~63u))), 16, 0, 0);
   } else {
     c128 v[R];
     if (P.cache_policy & 4) {
 #pragma unroll
-      for (int k = 0; k < R; ++k) v[k] = load_streaming(x + arows[k]);
+      for (int k = 0; k < R; ++k) v[k] = load_streaming(RA.at(x, k, 0u));
     } else {
 #pragma unroll
-      for (int k = 0; k < R; ++k) v[k] = x[arows[k]];
+      for (int k = 0; k < R; ++k) v[k] = *RA.at(x, k, 0u);
     }
 #pragma unroll
     for (int k = 0; k < R; ++k) tile[tid + k * NT] = v[k];
   }
+  DNM_PH(1, 1);
 
   double ar[R], ai[R];
   // cache_policy bit 7: an accumulating pass adds its y at the END (loaded right before the stores) instead of
@@ -228,14 +275,14 @@ tile_pass_kernel(const DevPass P, const c128 *__restrict__ x, c128 *__restrict__
     if (P.cache_policy & 2) {
 #pragma unroll
       for (int k = 0; k < R; ++k) {
-        c128 v = load_streaming(y + yrows[k]);
+        c128 v = load_streaming(RA.at((const c128 *)y, k, yx));
         ar[k] = v.x;
         ai[k] = v.y;
       }
     } else {
 #pragma unroll
       for (int k = 0; k < R; ++k) {
-        c128 v = y[yrows[k]];
+        c128 v = *RA.at((const c128 *)y, k, yx);
         ar[k] = v.x;
         ai[k] = v.y;
       }
@@ -245,7 +292,7 @@ tile_pass_kernel(const DevPass P, const c128 *__restrict__ x, c128 *__restrict__
     const double zs = -P.zscale;
 #pragma unroll
     for (int k = 0; k < R; ++k) {
-      const c128 v = load_streaming(z + yrows[k]);      // read once
+      const c128 v = load_streaming(RA.at(z, k, yx));      // read once
       ar[k] = zs * v.x;
       ai[k] = zs * v.y;
     }
@@ -254,7 +301,7 @@ tile_pass_kernel(const DevPass P, const c128 *__restrict__ x, c128 *__restrict__
       const double cr = P.z2re, ci = P.z2im;
 #pragma unroll
       for (int k = 0; k < R; ++k) {
-        const c128 v = load_streaming(z2 + yrows[k]);
+        const c128 v = load_streaming(RA.at(z2, k, yx));
         ar[k] = fma(cr, v.x, ar[k]);
         ar[k] = fma(-ci, v.y, ar[k]);
         ai[k] = fma(cr, v.y, ai[k]);
@@ -269,14 +316,17 @@ tile_pass_kernel(const DevPass P, const c128 *__restrict__ x, c128 *__restrict__
   const DevQuad *__restrict__ quads = P.quads;
 
 #define DNM_LOOP(LP, KV, CX, GA, KZ) \
-  apply_records<R, LOGNT, KV, CX, GA, KZ>(quads, P.loop[LP], P.loop[LP + 1], ar, ai, tile, arows, x, xr, tid, sbase, skw, P.swz_xor_src)
+  apply_records<R, LOGNT, KV, CX, GA, KZ>(quads, P.loop[LP], P.loop[LP + 1], ar, ai, tile, RA, x, xr, tid, sbase, skw, P.swz_xor_src)
   if constexpr (GV >= 1) {
+    // (two live records in flight at a time -- half the L2 round trips of this phase -- changed nothing:
+    // profiles/r03_exp9_gather_pairs.txt; the passes are not bound by the life of a workgroup)
     DNM_LOOP(LP_GATHER_REAL, false, false, true, false);
     DNM_LOOP(LP_GATHER_KVAR_REAL, true, false, true, false);
     DNM_LOOP(LP_GATHER_CPLX, false, true, true, false);
     DNM_LOOP(LP_GATHER_KVAR_CPLX, true, true, true, false);
   }
 #undef DNM_LOOP
+  DNM_PH(2, 1);
 
   // ---- diagonal, part 1 (before the barrier, under the tile loads): the terms
   // whose sign mask lies outside the tile are the same for the whole workgroup.
@@ -300,6 +350,7 @@ tile_pass_kernel(const DevPass P, const c128 *__restrict__ x, c128 *__restrict__
     for (int off = 32; off > 0; off >>= 1) dext += __shfl_xor(dext, off, 64);
   }
   __syncthreads();
+  DNM_PH(3, 0);
 
   // ---- diagonal, part 2: sum_t c_t chi_t(row) for the terms that see the tile.
   // Terms are bucketed by the part of their sign mask that falls on this
@@ -348,9 +399,10 @@ tile_pass_kernel(const DevPass P, const c128 *__restrict__ x, c128 *__restrict__
     }
   }
 
+  DNM_PH(4, 0);
   // ---- off-diagonal masks, one branch-free loop per record class
 #define DNM_LOOP(LP, KV, CX, GA, KZ) \
-  apply_records<R, LOGNT, KV, CX, GA, KZ>(quads, P.loop[LP], P.loop[LP + 1], ar, ai, tile, arows, x, xr, tid, sbase, skw, P.swz_xor_src)
+  apply_records<R, LOGNT, KV, CX, GA, KZ>(quads, P.loop[LP], P.loop[LP + 1], ar, ai, tile, RA, x, xr, tid, sbase, skw, P.swz_xor_src)
   DNM_LOOP(LP_TILE_REAL_K0, false, false, false, true);
   DNM_LOOP(LP_TILE_REAL, false, false, false, false);
   DNM_LOOP(LP_TILE_CPLX, false, true, false, false);
@@ -364,27 +416,30 @@ tile_pass_kernel(const DevPass P, const c128 *__restrict__ x, c128 *__restrict__
   }
 #undef DNM_LOOP
 
+  DNM_PH(5, 0);
   if (late_y) {
     c128 w[R];
 #pragma unroll
-    for (int k = 0; k < R; ++k) w[k] = load_streaming(y + yrows[k]);
+    for (int k = 0; k < R; ++k) w[k] = load_streaming(RA.at((const c128 *)y, k, yx));
 #pragma unroll
     for (int k = 0; k < R; ++k) {
       ar[k] += w[k].x;
       ai[k] += w[k].y;
     }
   }
+  DNM_PH(6, 1);
   if (P.cache_policy & 64) {
 #pragma unroll
-    for (int k = 0; k < R; ++k) store_streaming(y + yrows[k], ar[k], ai[k]);
+    for (int k = 0; k < R; ++k) store_streaming(RA.at(y, k, yx), ar[k], ai[k]);
   } else if (P.cache_policy & 1) {
 #pragma unroll
-    for (int k = 0; k < R; ++k) store_through(y + yrows[k], ar[k], ai[k]);
+    for (int k = 0; k < R; ++k) store_through(RA.at(y, k, yx), ar[k], ai[k]);
   } else {
 #pragma unroll
-    for (int k = 0; k < R; ++k) y[yrows[k]] = make_double2(ar[k], ai[k]);
+    for (int k = 0; k < R; ++k) *RA.at(y, k, yx) = make_double2(ar[k], ai[k]);
   }
 
+  DNM_PH(7, 1);
   // ---- fused <x, y> (Lanczos alpha) and |y|^2: the rows' own x values are still in the tile
   if (P.dot_out) {
     double dr = 0.0, di = 0.0, dn = 0.0;
@@ -424,6 +479,15 @@ tile_pass_kernel(const DevPass P, const c128 *__restrict__ x, c128 *__restrict__
     }
   }
 }
+
+#ifdef DNM_PHASE_TIMING
+}  // namespace dnm
+extern "C" int dnm_debug_phase_buffer(void *buf) {
+  unsigned long long *p = (unsigned long long *)buf;
+  return hipMemcpyToSymbol(HIP_SYMBOL(dnm::g_phase_buf), &p, sizeof(p)) == hipSuccess ? 0 : 1;
+}
+namespace dnm {
+#endif
 
 // ---------------------------------------------------------------------------
 template <int B, int LOGR>

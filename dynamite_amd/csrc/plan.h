@@ -119,6 +119,11 @@ struct DevPass {
   int32_t swz_shift;
   uint32_t swz_xor_y, swz_xor_src;
   uint32_t block_offset;   // first workgroup of a launch over a RANGE of the pass's workgroups (dnm_mat_mult_local_part)
+  // Addressing: the position of a row is pos(block part) ^ pos(thread's tile coordinate) ^ pos(k bits); pos_tmask holds
+  // every position bit the THREAD part can reach (the low B - LOGR tile bits and what the layout folds them onto), all
+  // below bit 28: the kernel adds everything outside the mask to the scalar base pointer and keeps a 32-bit byte offset
+  // per thread (build_pass raises LOGR of a pass whose tile reaches higher until its thread bits fit).
+  uint32_t pos_tmask;
   // diagonal terms whose sign mask lies entirely inside the tile do not depend on the block: their sum per tile
   // coordinate, 2^B doubles (32 KB at B = 12, L2-resident), computed once on the host -- one 8-byte load per
   // amplitude instead of ~25 vector instructions.  Terms that see the tile AND bits outside it stay in the
