@@ -117,6 +117,8 @@ SIGNATURES = {
     "dnm_mat_local_part_bits": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "dnm_mat_mult_window_local": (C.c_int, [vp, vp, vp, vp]),
     "dnm_mat_mult_window_remote": (C.c_int, [vp, vp, C.c_int64, C.c_int64, vp, vp]),
+    "dnm_mat_window_local_rows": (C.c_int, [vp, C.c_int64, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int), vp]),
+    "dnm_mat_mult_window_rows": (C.c_int, [vp, vp, C.c_int64, C.c_int64, vp, C.c_int64, C.c_int64, vp]),
     "dnm_mat_destroy": (C.c_int, [vp]),
     "dnm_mat_sizes": (C.c_int, [vp, i64p, i64p, i64p, i64p]),
     "dnm_mat_precompute_diagonal": (C.c_int, [vp, vp]),

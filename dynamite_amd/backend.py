@@ -480,6 +480,7 @@ class ShellMat:
         self._tr_bufs = None
         self._tr_pipe = False     # layout-B pass and both all-to-alls run sub-piece by sub-piece (_mult_transposed_pipelined)
         self._splits = None       # window multiply in a local and a remote part (dnm_mat_window_split)
+        self._row_ranges = None   # ... or by rows: (ranges that read only the rank's own block, the others)
         self._msc = None          # (masks, mask_offsets, signs, coeffs, left subspace dict, right subspace dict): selfcheck
         self._check_pending = False
 
@@ -973,9 +974,50 @@ class ShellMat:
             _lib.check(L.dnm_mat_mult_window_remote(self.handle, C.c_void_p(self._window_buf.data_ptr()), w0,
                                                     self._window_buf.numel(), y.ptr, _stream()))
             return
+        local, remote = self._window_row_ranges()
+        if local:
+            # reference order, Explicit, projections, odd rank counts: the rows that read only the rank's own block of x
+            # (whole stretches of equal top bits) are multiplied while the window is on the links, the others after
+            L = _lib.lib()
+            self._window_buf, reqs = post_window_exchange(xl, self._owned, self._windows, self.rank, self._window_buf,
+                                                          self._needs)
+            wp, wn = C.c_void_p(self._window_buf.data_ptr()), self._window_buf.numel()
+            for r0, r1 in local:
+                _lib.check(L.dnm_mat_mult_window_rows(self.handle, wp, w0, wn, y.ptr, r0, r1, _stream()))
+            for r in reqs:
+                r.wait()
+            for r0, r1 in remote:
+                _lib.check(L.dnm_mat_mult_window_rows(self.handle, wp, w0, wn, y.ptr, r0, r1, _stream()))
+            return
         self._window_buf = exchange_window(xl, self._owned, self._windows, self.rank, self._window_buf, self._needs)
         _lib.check(_lib.lib().dnm_mat_mult_window(self.handle, C.c_void_p(self._window_buf.data_ptr()), w0,
                                                   self._window_buf.numel(), y.ptr, _stream()))
+
+    WINDOW_ROW_RANGES = 8         # row ranges multiplied under the window exchange, at most
+    WINDOW_ROWS_MIN_SHARE = 0.05  # ... if they are at least this share of the rank's rows
+    WINDOW_ROWS_MIN_BLOCKS = 64   # ... and no range shorter than this many workgroups of 256 rows
+
+    def _window_row_ranges(self):
+        """(local, remote): ranges [r0, r1) of this rank's rows that read nothing but its own block of x, and the
+        rest (dnm_mat_window_local_rows; one sweep, cached).  ([], []) when the multiply does not split that way."""
+        if self._row_ranges is None:
+            self._row_ranges = ([], [])
+            my0, myn = self._owned[self.rank]
+            buf = (C.c_int64 * (2 * self.WINDOW_ROW_RANGES))()
+            n = C.c_int()
+            _lib.check(_lib.lib().dnm_mat_window_local_rows(self.handle, my0, my0 + myn, self.WINDOW_ROW_RANGES,
+                                                            self.WINDOW_ROWS_MIN_BLOCKS, buf, C.byref(n), _stream()))
+            local = [(int(buf[2 * i]), int(buf[2 * i + 1])) for i in range(n.value)]
+            if knob('DNM_WINDOW_ROWS', '1') != '0' and sum(b - a for a, b in local) >= self.WINDOW_ROWS_MIN_SHARE * self.m_local:
+                remote, at = [], 0
+                for a, b in local:
+                    if a > at:
+                        remote.append((at, a))
+                    at = b
+                if at < self.m_local:
+                    remote.append((at, self.m_local))
+                self._row_ranges = (local, remote)
+        return self._row_ranges
 
     def norm(self, norm_type='infinity'):
         if norm_type not in ('infinity', None):

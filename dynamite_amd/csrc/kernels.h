@@ -37,6 +37,7 @@ struct ColMark {
   int64_t first = 0;
 };
 int gather_num_blocks(int64_t M);
+int gather_rows_per_block();     // workgroup b covers rows [b, b + 1) * gather_rows_per_block()
 int launch_gather_matvec(const DevMsc &msc, const SubView &left, const SubView &right,
                          int64_t M, const double *diag, const void *x, void *y,
                          hipStream_t st, int64_t row0 = 0, int64_t win_start = 0, int xswz = -1,
@@ -62,6 +63,7 @@ struct ScLow {
   int32_t off[18];
 };
 int sc_num_blocks(int64_t M);
+int sc_rows_per_block();
 int launch_sc_matvec(const DevMsc &msc, const ScMask *scm, const ScLow &low, const SubView &sub, int64_t M, int64_t row0,
                      int64_t win_start, const double *diag, const void *xw, void *y, int64_t *colrange,
                      hipStream_t st, ColMark mark = ColMark());

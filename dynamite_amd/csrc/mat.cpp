@@ -1243,6 +1243,83 @@ int dnm_mat_mult_window(dnm_mat *A, const void *x_window, int64_t win_start, int
                               A->row0, win_start, 0, nullptr);
 }
 
+// Rows of a window partition whose columns all lie in [col_lo, col_hi) -- the rank's own block of x: they can be
+// multiplied while the rest of the window is on the links.  From the per-workgroup column ranges of the row kernels
+// (one sweep): runs of consecutive workgroups that read nothing else, the largest `max_ranges` of them, none
+// shorter than min_blocks workgroups (of 256 rows).  ranges: pairs [r0, r1) of local row numbers, ascending.
+int dnm_mat_window_local_rows(dnm_mat *A, int64_t col_lo, int64_t col_hi, int max_ranges, int min_blocks,
+                              int64_t *ranges, int *nranges, void *stream) {
+  DNM_CHECK(A && ranges && nranges && max_ranges >= 1, "bad argument");
+  *nranges = 0;
+  if (A->use_sc3 || A->host_only || (A->hypercube && A->plan.use_tiled) || A->m_local <= 0) return 0;
+  if (A->left.host.swz != 0) return 0;       // a swizzled result block is not a sequence of row ranges
+  const int64_t per = A->sc_pair ? sc_rows_per_block() : gather_rows_per_block();
+  const int nb = A->sc_pair ? sc_num_blocks(A->m_local) : gather_num_blocks(A->m_local);
+  DevBuf buf;
+  DNM_TRY(buf.alloc((size_t)nb * 2 * sizeof(int64_t)));
+  if (A->sc_pair)
+    DNM_TRY(launch_sc_matvec(A->dmsc, (const ScMask *)A->d_scmasks.p, A->sclow, A->right.dev, A->m_local, A->row0,
+                             0, nullptr, nullptr, nullptr, (int64_t *)buf.p, S(stream)));
+  else
+    DNM_TRY(launch_gather_matvec(A->dmsc, A->left.dev, A->right.dev, A->m_local, nullptr, nullptr, nullptr,
+                                 S(stream), A->row0, 0, 0, (int64_t *)buf.p));
+  std::vector<int64_t> h((size_t)nb * 2);
+  DNM_TRY(dnm_memcpy_d2h(h.data(), buf.p, h.size() * sizeof(int64_t), stream));
+  // (a SpinConserve pair reads its own rows' columns as well: the diagonal and the row's own amplitude)
+  struct Run { int64_t b0, b1; };
+  std::vector<Run> runs;
+  for (int b = 0; b < nb;) {
+    auto local = [&](int i) {
+      int64_t lo = h[2 * (size_t)i], hi = h[2 * (size_t)i + 1];
+      if (A->sc_pair) {
+        lo = std::min(lo, A->row0 + (int64_t)i * per);
+        hi = std::max(hi, std::min(A->row0 + A->m_local, A->row0 + (int64_t)(i + 1) * per) - 1);
+      }
+      return hi < lo || (lo >= col_lo && hi < col_hi);
+    };
+    if (!local(b)) { ++b; continue; }
+    int e = b;
+    while (e < nb && local(e)) ++e;
+    if (e - b >= std::max(1, min_blocks)) runs.push_back({b, e});
+    b = e;
+  }
+  std::sort(runs.begin(), runs.end(), [](const Run &a, const Run &b) { return a.b1 - a.b0 > b.b1 - b.b0; });
+  if ((int)runs.size() > max_ranges) runs.resize((size_t)max_ranges);
+  std::sort(runs.begin(), runs.end(), [](const Run &a, const Run &b) { return a.b0 < b.b0; });
+  for (const Run &r : runs) {
+    ranges[2 * *nranges] = r.b0 * per;
+    ranges[2 * *nranges + 1] = std::min(A->m_local, r.b1 * per);
+    ++*nranges;
+  }
+  return 0;
+}
+
+// dnm_mat_mult_window for the local rows [r0, r1) only (y_local is still the rank's whole result block)
+int dnm_mat_mult_window_rows(dnm_mat *A, const void *x_window, int64_t win_start, int64_t win_len, void *y_local,
+                             int64_t r0, int64_t r1, void *stream) {
+  DNM_CHECK(A && x_window && y_local && !A->host_only, "bad argument");
+  DNM_CHECK(!A->use_sc3 && !(A->hypercube && A->plan.use_tiled), "this operator does not multiply by row ranges");
+  DNM_CHECK(r0 >= 0 && r0 < r1 && r1 <= A->m_local, "row range [%lld, %lld) outside the %lld local rows", (long long)r0,
+            (long long)r1, (long long)A->m_local);
+  const double *dg = A->have_diag ? (const double *)A->diag.p + r0 : nullptr;
+  char *y = (char *)y_local + (size_t)r0 * 16;
+  if (A->sc_pair && A->scblock.lb) {
+    ScBlock blk = A->scblock;
+    blk.h_first = sub_i2s(A->row0 + r0, A->left.host) >> blk.lb;
+    blk.h_last = sub_i2s(A->row0 + r1 - 1, A->left.host) >> blk.lb;
+    blk.swizzle = 0;
+    blk.perm = nullptr;
+    blk.nperm = 0;
+    return launch_sc_block(A->dmsc, (const ScMask *)A->d_scmasks.p, blk, A->right.dev, r1 - r0, A->row0 + r0, win_start,
+                           win_len, dg, x_window, y, S(stream));
+  }
+  if (A->sc_pair)
+    return launch_sc_matvec(A->dmsc, (const ScMask *)A->d_scmasks.p, A->sclow, A->right.dev, r1 - r0, A->row0 + r0,
+                            win_start, dg, x_window, y, nullptr, S(stream));
+  return launch_gather_matvec(A->dmsc, A->left.dev, A->right.dev, r1 - r0, dg, x_window, y, S(stream), A->row0 + r0,
+                              win_start, 0, nullptr);
+}
+
 int dnm_mat_window_split(const dnm_mat *A, int *supported) {
   DNM_CHECK(A && supported, "null argument");
   *supported = (A->use_sc3 && A->sc3->tiled && A->nranks > 1) ? 1 : 0;

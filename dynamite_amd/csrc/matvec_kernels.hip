@@ -840,6 +840,7 @@ sc_matvec_kernel(const DevMsc msc, const ScMask *__restrict__ scm, const ScLow l
 #undef SC_TAB
 
 int sc_num_blocks(int64_t M) { return (int)((M + SC_NT - 1) / SC_NT); }
+int sc_rows_per_block() { return SC_NT; }
 
 int launch_sc_matvec(const DevMsc &msc, const ScMask *scm, const ScLow &low, const SubView &sub, int64_t M, int64_t row0,
                      int64_t win_start, const double *diag, const void *xw, void *y, int64_t *colrange,
@@ -1380,6 +1381,7 @@ static int gather_dispatch_r(const DevMsc &msc, const SubView &l, const SubView 
 }
 
 int gather_num_blocks(int64_t M) { return (int)((M + GATHER_NT - 1) / GATHER_NT); }
+int gather_rows_per_block() { return GATHER_NT; }
 
 int launch_gather_matvec(const DevMsc &msc, const SubView &left, const SubView &right, int64_t M,
                          const double *diag, const void *x, void *y, hipStream_t st, int64_t row0,

@@ -251,6 +251,16 @@ int dnm_mat_local_part_bits(const dnm_mat *A, int *top_free_bit, int *gathers);
 int dnm_mat_mult_window_local(dnm_mat *A, const void *x_local, void *y_local, void *stream);
 int dnm_mat_mult_window_remote(dnm_mat *A, const void *x_window, int64_t win_start, int64_t win_len, void *y_local,
                                void *stream);
+/* Every other window partition (SpinConserve in reference order, Explicit, projection pairs, odd rank counts) overlaps
+ * by ROWS: dnm_mat_window_local_rows lists up to max_ranges ranges [r0, r1) of the rank's local rows whose columns all
+ * lie in [col_lo, col_hi) -- the rank's own block of x, which sits in the window buffer before anything arrives; none
+ * shorter than min_blocks workgroups of 256 rows -- and
+ * dnm_mat_mult_window_rows multiplies one range of rows; the caller runs the listed ranges under the exchange and the
+ * rest after it (bpetsc_template_2.c:866-873). */
+int dnm_mat_window_local_rows(dnm_mat *A, int64_t col_lo, int64_t col_hi, int max_ranges, int min_blocks,
+                              int64_t *ranges, int *nranges, void *stream);
+int dnm_mat_mult_window_rows(dnm_mat *A, const void *x_window, int64_t win_start, int64_t win_len, void *y_local,
+                             int64_t r0, int64_t r1, void *stream);
 /* SpinConserve pairs in the internal layout (dnm_mat_layouts) partition differently: a rank owns whole blocks of equal
  * top bits T -- a contiguous range of the internal layout (dnm_vec_layout_partition; balanced to within one block)
  * that is also a contiguous range of the reference order -- and ownership, windows and chunks are expressed in

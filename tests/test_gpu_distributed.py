@@ -76,6 +76,11 @@ def _worker(rank, world, port, case, out_dir):
         assert summ["scheme"] == "window" and 0 < summ["bytes_in"] < summ["window_bytes"]
         # (three ranks: the middle rank's window has no holes; config 5's 8-rank share in test_gpu_fullsize.py has)
         assert summ["bytes_in"] <= summ["window_bytes"] - 16 * H.get_mat().m_local, summ
+        # the rows that read only the rank's own block ran under the exchange (dnm_mat_window_local_rows): the first
+        # and the last rank own long stretches of equal top bits
+        local, remote = H.get_mat()._row_ranges
+        if rank in (0, world - 1):
+            assert local and remote and sum(b - a for a, b in local) > 0.05 * H.get_mat().m_local, (local, remote)
         z = H.evolve(x, t=0.3, algo='chebyshev')
         assert abs(z.norm() - 1) < 1e-9 and abs(z.dot(H.dot(z)).imag) < 1e-9
         dist.barrier()
@@ -103,6 +108,9 @@ def _worker(rank, world, port, case, out_dir):
             left = right = Parity('odd', L=L)
         H.allow_projection = True
         H.add_subspace(left, right)
+        # small blocks: let the row-range split of the window multiply run whatever the length of the ranges
+        from dynamite_amd import backend as _be
+        _be.ShellMat.WINDOW_ROWS_MIN_BLOCKS, _be.ShellMat.WINDOW_ROWS_MIN_SHARE = 1, 0.0
         x = State(subspace=right, state='random', seed=3)
         y = H.dot(x, result=State(subspace=left))
         assert y.subspace == left and "tiled=1" not in H.get_mat(subspaces=(left, right)).describe()
