@@ -39,7 +39,7 @@ for a, b in zip(ids1, ids2):
     hit, miss = d2[b].get("TCC_HIT_sum", 0), d2[b].get("TCC_MISS_sum", 0)
     passes.append({"fetch_bytes": fetch, "write_bytes": write, "l2_hit_rate": hit / max(1.0, hit + miss)})
 tot = sum(p["fetch_bytes"] + p["write_bytes"] for p in passes)
-summ = {"L": L, "n_gpus": 1, "plan": str(line["config"]["plan_mode"]),
+summ = {"L": L, "n_gpus": 1, "plan": str(line["config"].get("plan_mode", 2)),
         "plan_signature": line["config"].get("plan_signature"), "launches_per_step": launches,
         "passes": passes, "hbm_bytes_per_step": tot, "hbm_bytes_per_launch": tot / launches,
         "bytes_per_amplitude": tot / dim,
