@@ -124,16 +124,20 @@ int vk_random(void *x, int64_t n, uint64_t seed, int64_t offset, hipStream_t st,
 int vk_swizzle_copy(void *dst, const void *src, int64_t n, int swz, hipStream_t st);
 // partial sums: out_dev[2*nv * nblocks]; reduce_blocks returns the block count
 int vk_mdot_blocks(int64_t n);
+int vk_sweep_blocks(int64_t n);                     // workgroups of the one-element-per-thread sweeps with partial sums
+size_t vk_sweep_scratch(int64_t n, int ncols);     // doubles their partials_dev needs: partials, results, second-level sums
 int vk_mdot(const void *V, int64_t ldv, int nv, const void *w, int64_t n, double *partials_dev,
             hipStream_t st);
 int vk_maxpy(void *w, const void *V, int64_t ldv, int nv, int64_t n, const double *c_dev,
              hipStream_t st);
 int vk_basis_update(void *V, int64_t ldv, int nin, int nout, int64_t n, const double *S_dev,
                     hipStream_t st);
-// p = scale * (p - (are + i aim) v - b u) (u may be null); partials_dev[vk_mdot_blocks(n)] then the sum of |p|^2
+// p = scale * (p - (are + i aim) v - b u) (u may be null); partials_dev[vk_sweep_blocks(n)] then the sum of |p|^2
+// (vk_sweep_scratch(n, 1) doubles in all)
 int vk_lanczos_update(void *p, const void *v, const void *u, int64_t n, double are, double aim, double b,
                       double scale, double *partials_dev, hipStream_t st);
-// y -= b z (z may be null) and the sums conj(x) y (re, im), |y|^2: partials_dev[3 * vk_mdot_blocks(n)] then [3]
+// y -= b z (z may be null) and the sums conj(x) y (re, im), |y|^2: partials_dev[3 * vk_sweep_blocks(n)] then [3]
+// (vk_sweep_scratch(n, 3) doubles in all)
 int vk_lanczos_dot(void *y, const void *z, const void *x, int64_t n, double b, double *partials_dev,
                    hipStream_t st);
 // out[c] = sum_b partials[b * ncols + c]

@@ -40,9 +40,9 @@ int vec_mdot_host(const void *V, int64_t ldv, int nv, const void *w, int64_t n, 
 
 int vec_lanczos_dot_host(void *y, const void *z, const void *x, int64_t n, double b, double *out3_host,
                          hipStream_t st) {
-  const int nb = vk_mdot_blocks(n);
+  const int nb = vk_sweep_blocks(n);
   double *part = nullptr;
-  DNM_TRY(vec_scratch(((size_t)nb + 1) * 3 * sizeof(double), &part));
+  DNM_TRY(vec_scratch(vk_sweep_scratch(n, 3) * sizeof(double), &part));
   DNM_TRY(vk_lanczos_dot(y, z, x, n, b, part, st));
   DNM_HIP(hipMemcpyAsync(out3_host, part + 3 * (size_t)nb, 3 * sizeof(double), hipMemcpyDeviceToHost, st));
   DNM_HIP(hipStreamSynchronize(st));
@@ -51,9 +51,9 @@ int vec_lanczos_dot_host(void *y, const void *z, const void *x, int64_t n, doubl
 
 int vec_lanczos_update_host(void *p, const void *v, const void *u, int64_t n, double are, double aim, double b,
                             double *norm2_host, hipStream_t st, double scale) {
-  const int nb = vk_mdot_blocks(n);
+  const int nb = vk_sweep_blocks(n);
   double *part = nullptr;
-  DNM_TRY(vec_scratch(((size_t)nb + 1) * sizeof(double), &part));
+  DNM_TRY(vec_scratch(vk_sweep_scratch(n, 1) * sizeof(double), &part));
   DNM_TRY(vk_lanczos_update(p, v, u, n, are, aim, b, scale, part, st));
   DNM_HIP(hipMemcpyAsync(norm2_host, part + nb, sizeof(double), hipMemcpyDeviceToHost, st));
   DNM_HIP(hipStreamSynchronize(st));

@@ -3,6 +3,8 @@
 // multi-axpy over a block of basis vectors, in-place basis rotation, and a
 // counter-based normal generator.  All are HBM-streaming; 16 B per lane,
 // grid-stride, deterministic two-stage reductions (no atomics).
+#include <algorithm>
+
 #include "kernels.h"
 #include "philox.h"
 
@@ -22,12 +24,19 @@ __device__ __forceinline__ void st_stream(c128 *p, c128 a) {
 }
 
 constexpr int VNT = 256;
-constexpr int VMAX_BLOCKS = 2048;   // 256 CUs x 8
+// Launch shapes, measured at 2^30 amplitudes (tools/vec_probe.hip, profiles/r03_vec_probe.txt).  A sweep that WRITES
+// streams fastest with one element per thread and no loop at all: x, y -> y at 6.48 TB/s against 4.9 with a
+// grid-stride loop over 2048 workgroups (5.3 over 65536); a read-only reduction reaches its 7.0-7.1 TB/s from 8192
+// workgroups on.  So: the streaming kernels get one workgroup per 256 elements (their loops run once), the multi-dot
+// 16384 workgroups, and the fused Lanczos sweeps one element per thread with a two-level sum of their partials.
+constexpr int64_t VMAX_BLOCKS = (int64_t)1 << 31;       // grid-stride loops only beyond 2^39 elements
+constexpr int64_t VRED_BLOCKS = 16384;                  // multi-dot: partials are 2 * nv doubles per workgroup
+constexpr int VRED2 = 1024;                             // second-level partial sums of the one-element-per-thread sweeps
 
-static inline unsigned vgrid(int64_t n, int per_thread = 1) {
+static inline unsigned vgrid(int64_t n, int per_thread = 1, int64_t cap = VMAX_BLOCKS - 1) {
   int64_t nb = (n + (int64_t)VNT * per_thread - 1) / ((int64_t)VNT * per_thread);
   if (nb < 1) nb = 1;
-  return (unsigned)(nb < VMAX_BLOCKS ? nb : VMAX_BLOCKS);
+  return (unsigned)(nb < cap ? nb : cap);
 }
 
 __global__ void __launch_bounds__(VNT) set_kernel(c128 *x, int64_t n, double re, double im) {
@@ -103,7 +112,14 @@ int vk_swizzle_copy(void *dst, const void *src, int64_t n, int swz, hipStream_t 
 }
 
 // ---- fused multi-dot: h[j] = sum_i conj(V_j[i]) w[i] -------------------------
-int vk_mdot_blocks(int64_t n) { return (int)vgrid(n, 4); }
+int vk_mdot_blocks(int64_t n) {
+  // 4096 elements per workgroup, at least 2048 workgroups (256 CUs x 8) and at most VRED_BLOCKS: the second stage reads
+  // every partial, which shows below 2^26 elements
+  const int64_t want = std::max<int64_t>(2048, n / 4096);
+  return (int)vgrid(n, 4, std::min<int64_t>(want, VRED_BLOCKS));
+}
+int vk_sweep_blocks(int64_t n) { return (int)vgrid(n); }
+size_t vk_sweep_scratch(int64_t n, int ncols) { return ((size_t)vgrid(n) + 1 + VRED2) * (size_t)ncols; }
 
 template <int NV>
 __global__ void __launch_bounds__(VNT)
@@ -161,10 +177,38 @@ reduce_partials_kernel(const double *__restrict__ partials, int nblocks, int nco
   }
 }
 
+// first level for many partials: workgroup (c, g) sums the g-th of G slices of column c into tmp[g * ncols + c]
+__global__ void __launch_bounds__(VNT)
+reduce_slices_kernel(const double *__restrict__ partials, int64_t nblocks, int ncols, int G, double *__restrict__ tmp) {
+  const int c = blockIdx.x % ncols, g = blockIdx.x / ncols;
+  const int64_t chunk = (nblocks + G - 1) / G, b0 = g * chunk, b1 = b0 + chunk < nblocks ? b0 + chunk : nblocks;
+  double s = 0.0;
+  for (int64_t b = b0 + threadIdx.x; b < b1; b += VNT) s += partials[b * ncols + c];
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+  __shared__ double red[VNT / 64];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int wv = 0; wv < VNT / 64; ++wv) t += red[wv];
+    tmp[(int64_t)g * ncols + c] = t;
+  }
+}
+
+// sums of the columns of partials[nblocks][ncols] -> out[ncols]; tmp: VRED2 * ncols doubles (used beyond 65536 rows)
+static void reduce_columns(const double *partials, int64_t nblocks, int ncols, double *out, double *tmp, hipStream_t st) {
+  if (nblocks <= 65536) {
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(ncols), dim3(VNT), 0, st, partials, (int)nblocks, ncols, out);
+    return;
+  }
+  hipLaunchKernelGGL(reduce_slices_kernel, dim3(ncols * VRED2), dim3(VNT), 0, st, partials, nblocks, ncols, VRED2, tmp);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(ncols), dim3(VNT), 0, st, (const double *)tmp, VRED2, ncols, out);
+}
+
 // partials_dev: [nblocks * 2*nv] scratch followed by [2*nv] results
 int vk_mdot(const void *V, int64_t ldv, int nv, const void *w, int64_t n, double *partials_dev,
             hipStream_t st) {
-  const unsigned nb = vgrid(n, 4);
+  const unsigned nb = (unsigned)vk_mdot_blocks(n);
   const c128 *Vp = (const c128 *)V;
   const c128 *wp = (const c128 *)w;
   int j0 = 0;
@@ -350,14 +394,14 @@ lanczos_update_kernel(c128 *p, const c128 *__restrict__ v, const c128 *__restric
   }
 }
 
-// partials_dev: [nblocks] scratch followed by [1] result; nblocks = vk_mdot_blocks(n)
+// partials_dev: vk_sweep_scratch(n, 1) doubles -- [nblocks] partials, [1] result, second-level sums;
+// nblocks = vk_sweep_blocks(n): one element per thread
 int vk_lanczos_update(void *p, const void *v, const void *u, int64_t n, double are, double aim, double b,
                       double scale, double *partials_dev, hipStream_t st) {
-  const unsigned nb = vgrid(n, 4);
+  const unsigned nb = (unsigned)vk_sweep_blocks(n);
   hipLaunchKernelGGL(lanczos_update_kernel, dim3(nb), dim3(VNT), 0, st, (c128 *)p, (const c128 *)v,
                      (const c128 *)u, n, are, aim, b, scale, partials_dev);
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(VNT), 0, st, partials_dev, (int)nb, 1,
-                     partials_dev + nb);
+  reduce_columns(partials_dev, nb, 1, partials_dev + nb, partials_dev + nb + 1, st);
   DNM_HIP(hipGetLastError());
   return 0;
 }
@@ -404,14 +448,14 @@ lanczos_dot_kernel(c128 *y, const c128 *__restrict__ z, const c128 *__restrict__
   }
 }
 
-// partials_dev: [3 * nblocks] scratch followed by [3] results; nblocks = vk_mdot_blocks(n)
+// partials_dev: vk_sweep_scratch(n, 3) doubles -- [3 * nblocks] partials, [3] results, second-level sums;
+// nblocks = vk_sweep_blocks(n)
 int vk_lanczos_dot(void *y, const void *z, const void *x, int64_t n, double b, double *partials_dev,
                    hipStream_t st) {
-  const unsigned nb = vgrid(n, 4);
+  const unsigned nb = (unsigned)vk_sweep_blocks(n);
   hipLaunchKernelGGL(lanczos_dot_kernel, dim3(nb), dim3(VNT), 0, st, (c128 *)y, (const c128 *)z, (const c128 *)x, n,
                      b, partials_dev);
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(3), dim3(VNT), 0, st, partials_dev, (int)nb, 3,
-                     partials_dev + 3 * (int64_t)nb);
+  reduce_columns(partials_dev, nb, 3, partials_dev + 3 * (int64_t)nb, partials_dev + 3 * (int64_t)nb + 3, st);
   DNM_HIP(hipGetLastError());
   return 0;
 }
