@@ -117,6 +117,7 @@ int launch_rdm(const void *x, const SubView &sub, const RdmGeom &geo, void *part
 
 // ---- vector kernels ---------------------------------------------------------
 int vk_set(void *x, int64_t n, double re, double im, hipStream_t st);
+int vk_copy(void *y, const void *x, int64_t n, hipStream_t st);      // y = x (complex128 elements; no overlap)
 int vk_scale(void *x, int64_t n, double re, double im, hipStream_t st);
 int vk_axpby(void *y, const void *x, int64_t n, double are, double aim, double bre, double bim,
              hipStream_t st);

@@ -647,7 +647,7 @@ static int cheb_core(Ops &ops, void *y, int64_t n_local, double t, double tol, d
   for (int step = 0; step < nsteps; ++step) {
     double gam[4];
     // U_0 = the state, U_1 = A U_0 / 2 (T_1 = A x / r = (2/r) U_1)
-    DNM_HIP(hipMemcpyAsync(slot(0), y, (size_t)n_local * 16, hipMemcpyDeviceToDevice, st));
+    DNM_TRY(vk_copy(slot(0), y, n_local, st));
     DNM_TRY(ops.mult(slot(0), slot(1)));
     DNM_TRY(vk_scale(slot(1), n_local, 0.5, 0.0, st));
     gam[0] = 1.0;
@@ -861,7 +861,7 @@ static int eigsolve_basis_free(Ops &ops, dnm_mat *A, int64_t n_local, int which,
     evals[0] = d.real();
     stats->err_est = std::sqrt(n2 > 0 ? n2 : 0.0) / std::max(std::fabs(evals[0]), 1e-300);
     measured = true;
-    if (evecs) DNM_HIP(hipMemcpyAsync(evecs, v, (size_t)n_local * 16, hipMemcpyDeviceToDevice, st));
+    if (evecs) DNM_TRY(vk_copy(evecs, v, n_local, st));
     // the contract is a residual below tol (computations.py:274-275 raises otherwise): the estimate of the first
     // run is not the vector's residual once rounding has crept into a long recurrence.  Polish: Lanczos again from
     // the Ritz vector itself (a handful of steps); a vector that still misses tol is reported as not converged.
@@ -920,7 +920,7 @@ int dnm_expm_chebyshev(dnm_mat *A, const void *x, void *y, int64_t n_local, doub
   Ops ops{A, hooks, st, n_local};
   stats->reason = 0; stats->its = 0; stats->matvecs = 0; stats->nconv = 0; stats->err_est = 0;
   if (tol <= 0) tol = 1e-8;
-  if (x != y) DNM_HIP(hipMemcpyAsync(y, x, (size_t)n_local * 16, hipMemcpyDeviceToDevice, st));
+  if (x != y) DNM_TRY(vk_copy(y, x, n_local, st));
   if (t == 0.0) { stats->reason = DNM_CONVERGED_TOL; return 0; }
   double r = 0;
   DNM_TRY(dnm_mat_norm_inf(A, &r, stream));
@@ -978,7 +978,7 @@ int dnm_expm_multiply(dnm_mat *A, const void *x, void *y, int64_t n_local, doubl
 
   const zc scale(scale_re, scale_im);
   const double t_out = std::abs(scale);
-  DNM_HIP(hipMemcpyAsync(y, x, (size_t)n_local * 16, hipMemcpyDeviceToDevice, st));
+  DNM_TRY(vk_copy(y, x, n_local, st));
   if (t_out == 0.0) { stats->reason = DNM_CONVERGED_TOL; return 0; }
   const zc dir = scale / t_out;
 
@@ -1085,7 +1085,7 @@ int dnm_expm_multiply(dnm_mat *A, const void *x, void *y, int64_t n_local, doubl
     std::vector<double> nv(m + 2, 1.0), bet(m + 2, 0.0);
     if (use_pro) {
       mon.reset(m, (double)Nglob, tol);
-      DNM_HIP(hipMemcpyAsync(vecptr(V, n_local, 0), y, (size_t)n_local * 16, hipMemcpyDeviceToDevice, st));
+      DNM_TRY(vk_copy(vecptr(V, n_local, 0), y, n_local, st));
       nv[0] = beta;
     } else {
       // v_0 = w / beta
@@ -1511,8 +1511,7 @@ int dnm_eigsolve(dnm_mat *A, int64_t n_local, int nev, int which, double tol, in
     const double *sd = nullptr;
     DNM_TRY(vec_upload_coefs(Ssel.data(), Ssel.size(), st, &sd));
     DNM_TRY(vk_basis_update(V, n_local, m, keep, n_local, sd, st));
-    DNM_HIP(hipMemcpyAsync(vecptr(V, n_local, keep), vecptr(V, n_local, m), (size_t)n_local * 16,
-                           hipMemcpyDeviceToDevice, st));
+    DNM_TRY(vk_copy(vecptr(V, n_local, keep), vecptr(V, n_local, m), n_local, st));
     if (use_pro) {
       // |q_m^H u_o| <= sum_k |S_ko| |omega_{m,k}|: the new q_l against the rotated basis
       row_l.assign(keep, 0.0);
@@ -1570,8 +1569,7 @@ int dnm_eigsolve(dnm_mat *A, int64_t n_local, int nev, int which, double tol, in
     for (int i = 0; i < nout; ++i) evals[i] = rq[ord[i]];
     if (evecs)
       for (int i = 0; i < nout; ++i)
-        DNM_HIP(hipMemcpyAsync((char *)evecs + (size_t)i * (size_t)n_local * 16, vecptr(V, n_local, ord[i]),
-                               (size_t)n_local * 16, hipMemcpyDeviceToDevice, st));
+        DNM_TRY(vk_copy((char *)evecs + (size_t)i * (size_t)n_local * 16, vecptr(V, n_local, ord[i]), n_local, st));
     if (knob("DNM_KRYLOV_DEBUG"))
       fprintf(stderr, "dnm_eigsolve (filtered): %d restarts, %d matvecs (+%d for the checks), degree %d, largest true "
               "relative residual %.2e\n", its, ops.matvecs, extra_matvecs, flt.d, worst_true);
@@ -1600,7 +1598,7 @@ int dnm_eigsolve(dnm_mat *A, int64_t n_local, int nev, int which, double tol, in
         DNM_CHECK(nn > 0, "zero Ritz vector");
         DNM_TRY(vk_scale(vecptr(V, n_local, o), n_local, 1.0 / nn, 0, st));
       }
-    if (evecs) DNM_HIP(hipMemcpyAsync(evecs, V, (size_t)nout * (size_t)n_local * 16, hipMemcpyDeviceToDevice, st));
+    if (evecs) DNM_TRY(vk_copy(evecs, V, (int64_t)nout * n_local, st));
     // what was promised, measured: the largest relative residual |H u - <u,Hu> u| / |theta| of the returned
     // pairs (one multiply each; the Lanczos vector in the last slot is no longer needed)
     double worst = 0.0;

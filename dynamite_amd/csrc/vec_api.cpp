@@ -74,7 +74,7 @@ int dnm_vec_set(void *x, int64_t n, double re, double im, void *stream) {
 
 int dnm_vec_copy(const void *x, void *y, int64_t n, void *stream) {
   DNM_CHECK(x && y && n >= 0, "bad vector");
-  DNM_HIP(hipMemcpyAsync(y, x, (size_t)n * 16, hipMemcpyDeviceToDevice, S(stream)));
+  DNM_TRY(vk_copy(y, x, n, S(stream)));
   return 0;
 }
 

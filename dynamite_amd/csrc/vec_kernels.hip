@@ -66,6 +66,17 @@ axpby_kernel(c128 *y, const c128 *__restrict__ x, int64_t n, double are, double 
   }
 }
 
+// y = x: one element per thread streams at 6.5 TB/s, hipMemcpyAsync device-to-device at 4.7 (profiles/r03_vec_abi.txt)
+__global__ void __launch_bounds__(VNT) copy_kernel(c128 *__restrict__ y, const c128 *__restrict__ x, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * VNT + threadIdx.x; i < n; i += (int64_t)gridDim.x * VNT) st_stream(y + i, ld_stream(x + i));
+}
+int vk_copy(void *y, const void *x, int64_t n, hipStream_t st) {
+  if (n <= 0 || x == y) return 0;
+  hipLaunchKernelGGL(copy_kernel, dim3(vgrid(n)), dim3(VNT), 0, st, (c128 *)y, (const c128 *)x, n);
+  DNM_HIP(hipGetLastError());
+  return 0;
+}
+
 int vk_set(void *x, int64_t n, double re, double im, hipStream_t st) {
   hipLaunchKernelGGL(set_kernel, dim3(vgrid(n)), dim3(VNT), 0, st, (c128 *)x, n, re, im);
   DNM_HIP(hipGetLastError());

@@ -36,6 +36,8 @@ def main():
         print("%-34s %8.3f ms  %7.1f GB/s (%d B/amp)" % (name, ms, bytes_per_amp * n / 1e6 / ms, bytes_per_amp), flush=True)
 
     timed("dnm_vec_set", lambda: _lib.check(lib.dnm_vec_set(xp, n, 1.0, 0.0, st)), 16)
+    timed("dnm_vec_copy (copy kernel)", lambda: _lib.check(lib.dnm_vec_copy(xp, yp, n, st)), 32)
+    timed("torch copy_ (device memcpy)", lambda: y.copy_(x), 32)
     timed("dnm_vec_scale", lambda: _lib.check(lib.dnm_vec_scale(xp, n, 0.5, 0.25, st)), 32)
     timed("dnm_vec_axpby", lambda: _lib.check(lib.dnm_vec_axpby(yp, xp, n, 0.5, 0.0, 0.25, 0.0, st)), 48)
     timed("dnm_vec_dot", lambda: _lib.check(lib.dnm_vec_dot(xp, yp, n, out, st)), 32)
