@@ -142,7 +142,8 @@ int vk_lanczos_update(void *p, const void *v, const void *u, int64_t n, double a
 int vk_lanczos_dot(void *y, const void *z, const void *x, int64_t n, double b, double *partials_dev,
                    hipStream_t st);
 // out[c] = sum_b partials[b * ncols + c]
-int vk_reduce_partials(const double *partials, int nblocks, int ncols, double *out, hipStream_t st);
+size_t vk_reduce_scratch(int ncols);      // doubles of the optional second-level scratch of vk_reduce_partials
+int vk_reduce_partials(const double *partials, int nblocks, int ncols, double *out, hipStream_t st, double *tmp = nullptr);
 int vk_norm2_partials(const void *x, int64_t n, double *partials_dev, hipStream_t st);
 
 }  // namespace dnm

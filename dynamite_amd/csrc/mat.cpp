@@ -932,10 +932,10 @@ static int sc3_mult(dnm_mat *A, const void *x, void *y, const void *z, double b,
   if (!dot3_host) return launch_sc3(*A->sc3, A->dmsc, call, dg, x, y, S(stream), phase);
   const size_t nwg = sc3_dot_partials(*A->sc3);
   double *part = nullptr;
-  DNM_TRY(vec_scratch((nwg + 1) * 3 * sizeof(double), &part));
+  DNM_TRY(vec_scratch(((nwg + 1) * 3 + vk_reduce_scratch(3)) * sizeof(double), &part));
   call.dot_out = part;
   DNM_TRY(launch_sc3(*A->sc3, A->dmsc, call, dg, x, y, S(stream)));
-  DNM_TRY(vk_reduce_partials(part, (int)nwg, 3, part + 3 * nwg, S(stream)));
+  DNM_TRY(vk_reduce_partials(part, (int)nwg, 3, part + 3 * nwg, S(stream), part + 3 * nwg + 3));
   DNM_HIP(hipMemcpyAsync(dot3_host, part + 3 * nwg, 3 * sizeof(double), hipMemcpyDeviceToHost, S(stream)));
   DNM_HIP(hipStreamSynchronize(S(stream)));
   return 0;
@@ -1077,7 +1077,7 @@ int dnm_mat_mult_lanczos(dnm_mat *A, const void *x, void *y, const void *z, doub
   const bool fused_dot = A->local_passes.back()->desc.need_tile != 0;
   const size_t nblk = pass_dot_partials(A, *A->local_passes.back());
   double *part = nullptr;
-  if (fused_dot) DNM_TRY(vec_scratch((nblk + 1) * 3 * sizeof(double), &part));
+  if (fused_dot) DNM_TRY(vec_scratch(((nblk + 1) * 3 + vk_reduce_scratch(3)) * sizeof(double), &part));
   for (size_t i = 0; i < A->local_passes.size(); ++i) {
     DevPass d = A->local_passes[i]->desc;
     if (i == 0 && z) {
@@ -1089,7 +1089,7 @@ int dnm_mat_mult_lanczos(dnm_mat *A, const void *x, void *y, const void *z, doub
     DNM_TRY(launch_pass(A, *A->local_passes[i], d, x, y, nullptr, S(stream)));
   }
   if (!fused_dot) return vec_lanczos_dot_host(y, nullptr, x, A->m_local, 0.0, dot, S(stream));
-  DNM_TRY(vk_reduce_partials(part, (int)nblk, 3, part + 3 * nblk, S(stream)));
+  DNM_TRY(vk_reduce_partials(part, (int)nblk, 3, part + 3 * nblk, S(stream), part + 3 * nblk + 3));
   DNM_HIP(hipMemcpyAsync(dot, part + 3 * nblk, 3 * sizeof(double), hipMemcpyDeviceToHost, S(stream)));
   DNM_HIP(hipStreamSynchronize(S(stream)));
   return 0;
