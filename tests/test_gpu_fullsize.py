@@ -360,3 +360,36 @@ def test_config4_transposed_exchange_layouts(rank, monkeypatch):
             scale = max(scale, abs(acc))
         assert scale > 0 and worst <= 1e-13 * max(1.0, scale) * max(1, len(masks)), (name, worst, scale)
         _lib.check(Lb.dnm_mat_destroy(h))
+
+
+def test_config5_solver_at_the_largest_single_gpu_size():
+    """BASELINE config 5's solver -- eigsolve(nev=1) by Lanczos without a stored basis, SpinConserve vectors in the
+    internal layout -- at the largest half-filling subspace one MI355X holds: SpinConserve(34,17), 2.33 G states
+    (34.8 GiB per vector, row numbers beyond 2^31, T = 10 top bits).  The reference's bars for an eigenpair
+    (tests/integration/test_eigsolve.py:17-88): the residual |H v - E v| measured from the RETURNED state, a unit
+    norm, and E = <v|H|v>; plus the value this repository measured for the open chain (E0 / L = -0.437744)."""
+    import torch
+    from dynamite_amd.config import config
+    _need(200 * 2**30)
+    L, tol = 34, 1e-7
+    saved = config.L
+    try:
+        config.L = L
+        sub = SpinConserve(L, L // 2)
+        assert sub.get_dimension() == 2333606220 and sub.vec_swizzle >= 256
+        H = models.heisenberg(L)
+        H.add_subspace(sub)
+        ev, vecs = H.eigsolve(nev=1, tol=tol, getvecs=True, subspace=sub)
+        v = vecs[0]
+        assert abs(v.norm() - 1.0) < 1e-10
+        w = H.dot(v)
+        assert abs(v.dot(w).real - ev[0]) < 1e-8 * abs(ev[0])
+        w.axpy(-ev[0], v)
+        assert w.norm() <= 2 * tol * abs(ev[0]), "residual %.2e" % w.norm()
+        assert abs(ev[0] / L + 0.437744) < 2e-6
+        del v, w, vecs
+        H.destroy_mat()
+    finally:
+        config.L = saved
+        _lib.check(_lib.lib().dnm_release_workspace())
+        torch.cuda.empty_cache()
