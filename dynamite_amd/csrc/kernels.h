@@ -137,10 +137,11 @@ int vk_basis_update(void *V, int64_t ldv, int nin, int nout, int64_t n, const do
 // (vk_sweep_scratch(n, 1) doubles in all)
 int vk_lanczos_update(void *p, const void *v, const void *u, int64_t n, double are, double aim, double b,
                       double scale, double *partials_dev, hipStream_t st);
-// y -= b z (z may be null) and the sums conj(x) y (re, im), |y|^2: partials_dev[3 * vk_sweep_blocks(n)] then [3]
+// y = yscale * y - b z (z may be null) and the sums conj(x) y (re, im), |y|^2: partials_dev[3 * vk_sweep_blocks(n)] then [3]
 // (vk_sweep_scratch(n, 3) doubles in all)
 int vk_lanczos_dot(void *y, const void *z, const void *x, int64_t n, double b, double *partials_dev,
-                   hipStream_t st);
+                   hipStream_t st,
+                   double yscale = 1.0);     // y = yscale * y - b z
 // out[c] = sum_b partials[b * ncols + c]
 size_t vk_reduce_scratch(int ncols);      // doubles of the optional second-level scratch of vk_reduce_partials
 int vk_reduce_partials(const double *partials, int nblocks, int ncols, double *out, hipStream_t st, double *tmp = nullptr);

@@ -216,7 +216,8 @@ struct Ops {
     return dnm_mat_mult_sub2(A, x, y, z ? z : x, b, x, c2, 0.0, (void *)st);
   }
   // y = p(A) x; y must differ from x and from the two work vectors
-  int apply_filter(const void *x, void *y) {
+  // scale_out != null: y is left unscaled and the factor handed back (the caller's next sweep applies it)
+  int apply_filter(const void *x, void *y, double *scale_out = nullptr) {
     const ChebFilter &F = *flt;
     // rotate through {ta, tb, y} so that the last term lands in y
     void *buf[3] = {F.ta, F.tb, y};
@@ -232,6 +233,10 @@ struct Ops {
     }
     // u_d = h^d T_d / 2^(d-1); normalise by the value at the reference point so that the wanted end is O(1..)
     const double logscale = -(F.d * std::log(F.h) - (F.d - 1) * std::log(2.0)) - F.log_tref();
+    if (scale_out) {
+      *scale_out = std::exp(logscale);
+      return 0;
+    }
     return vk_scale(y, n, std::exp(logscale), 0, st);
   }
 
@@ -248,7 +253,13 @@ struct Ops {
   // Lanczos step
   int mult_dot(const void *x, void *y, zc *d, const void *z = nullptr, double b = 0.0, double *nn = nullptr) {
     double buf[3];
-    if ((flt && flt->on) || (hooks && hooks->mult)) {
+    if (flt && flt->on) {
+      // the filter's normalisation rides on the sweep that subtracts b z and takes the sums
+      double ys = 1.0;
+      DNM_TRY(apply_filter(x, y, &ys));
+      DNM_TRY(vec_lanczos_dot_host(y, z, x, n, b, buf, st, ys));
+      DNM_TRY(sum(buf, 3));
+    } else if (hooks && hooks->mult) {
       DNM_TRY(mult(x, y));
       DNM_TRY(vec_lanczos_dot_host(y, z, x, n, b, buf, st));
       DNM_TRY(sum(buf, 3));

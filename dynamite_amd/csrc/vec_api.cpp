@@ -39,11 +39,11 @@ int vec_mdot_host(const void *V, int64_t ldv, int nv, const void *w, int64_t n, 
 }
 
 int vec_lanczos_dot_host(void *y, const void *z, const void *x, int64_t n, double b, double *out3_host,
-                         hipStream_t st) {
+                         hipStream_t st, double yscale) {
   const int nb = vk_sweep_blocks(n);
   double *part = nullptr;
   DNM_TRY(vec_scratch(vk_sweep_scratch(n, 3) * sizeof(double), &part));
-  DNM_TRY(vk_lanczos_dot(y, z, x, n, b, part, st));
+  DNM_TRY(vk_lanczos_dot(y, z, x, n, b, part, st, yscale));
   DNM_HIP(hipMemcpyAsync(out3_host, part + 3 * (size_t)nb, 3 * sizeof(double), hipMemcpyDeviceToHost, st));
   DNM_HIP(hipStreamSynchronize(st));
   return 0;

@@ -20,6 +20,6 @@ int vec_lanczos_update_host(void *p, const void *v, const void *u, int64_t n, do
                             double *norm2_host, hipStream_t st, double scale = 1.0);
 // y -= b z (z may be null); out3_host = { Re <x,y>, Im <x,y>, |y|^2 } (this rank's part)
 int vec_lanczos_dot_host(void *y, const void *z, const void *x, int64_t n, double b, double *out3_host,
-                         hipStream_t st);
+                         hipStream_t st, double yscale = 1.0);
 
 }  // namespace dnm

@@ -417,17 +417,22 @@ int vk_lanczos_update(void *p, const void *v, const void *u, int64_t n, double a
   return 0;
 }
 
-// y -= b z (z may be null: y untouched) with the partial sums of conj(x) y (re, im) and |y|^2 of the result
+// y = ys y - b z (z may be null; ys == 1 and no z: y untouched) with the partial sums of conj(x) y (re, im) and |y|^2
+// of the result
 __global__ void __launch_bounds__(VNT)
-lanczos_dot_kernel(c128 *y, const c128 *__restrict__ z, const c128 *__restrict__ x, int64_t n, double b,
+lanczos_dot_kernel(c128 *y, const c128 *__restrict__ z, const c128 *__restrict__ x, int64_t n, double b, double ys,
                    double *__restrict__ partials) {
   double dr = 0.0, di = 0.0, dn = 0.0;
   for (int64_t i = (int64_t)blockIdx.x * VNT + threadIdx.x; i < n; i += (int64_t)gridDim.x * VNT) {
     c128 acc = ld_stream(y + i);
-    if (z) {
-      const c128 zv = ld_stream(z + i);
-      acc.x = fma(-b, zv.x, acc.x);
-      acc.y = fma(-b, zv.y, acc.y);
+    if (z || ys != 1.0) {
+      acc.x *= ys;
+      acc.y *= ys;
+      if (z) {
+        const c128 zv = ld_stream(z + i);
+        acc.x = fma(-b, zv.x, acc.x);
+        acc.y = fma(-b, zv.y, acc.y);
+      }
       st_stream(y + i, acc);
     }
     const c128 xv = ld_stream(x + i);
@@ -462,10 +467,10 @@ lanczos_dot_kernel(c128 *y, const c128 *__restrict__ z, const c128 *__restrict__
 // partials_dev: vk_sweep_scratch(n, 3) doubles -- [3 * nblocks] partials, [3] results, second-level sums;
 // nblocks = vk_sweep_blocks(n)
 int vk_lanczos_dot(void *y, const void *z, const void *x, int64_t n, double b, double *partials_dev,
-                   hipStream_t st) {
+                   hipStream_t st, double yscale) {
   const unsigned nb = (unsigned)vk_sweep_blocks(n);
   hipLaunchKernelGGL(lanczos_dot_kernel, dim3(nb), dim3(VNT), 0, st, (c128 *)y, (const c128 *)z, (const c128 *)x, n,
-                     b, partials_dev);
+                     b, yscale, partials_dev);
   reduce_columns(partials_dev, nb, 3, partials_dev + 3 * (int64_t)nb, partials_dev + 3 * (int64_t)nb + 3, st);
   DNM_HIP(hipGetLastError());
   return 0;
