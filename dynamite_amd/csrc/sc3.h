@@ -48,6 +48,10 @@ struct Sc3Tab {
   int32_t rs[SC3_MAXW + 2];                        // window pass: log2(R / 16) by cw
   const uint16_t *lo_pat, *w_pat;  // patterns grouped by popcount, ascending inside a group
   const uint16_t *lo_rank, *w_rank;   // [1 << a], [1 << w]: rank of a pattern inside its group
+  // Partner table of the window pass's LDS bonds (one lookup per (row, bond) instead of a pair test, an ordinal
+  // popcount and a binomial): w_nb[2 * (w_off[cw] + wr)]: byte b of the 16 is the rank of the W pattern that bond b
+  // (inside W) couples pattern wr to, or nw[cw] -- the zero row behind the tile -- when the two spins are equal.
+  const uint64_t *w_nb;
   const int32_t *cbin;             // [17 * 17] C(n, j)
   const int64_t *nck;              // [(k+1) * (L+1)] C(LL, kk) at kk * (L+1) + LL: the reference's unranking table
 };
@@ -74,6 +78,8 @@ struct Sc3Layout {
   std::vector<uint16_t> lo_pat, w_pat, lo_rank, w_rank;
   std::vector<int32_t> cbin;
   std::vector<uint32_t> rows;      // every row (T << w | W) of the layout, in reference order
+  std::vector<uint64_t> w_nb;
+  void *d_w_nb = nullptr;
   void *d_ibase = nullptr, *d_nbase = nullptr, *d_icoff = nullptr, *d_ncoff = nullptr, *d_lo_pat = nullptr,
        *d_w_pat = nullptr, *d_lo_rank = nullptr, *d_w_rank = nullptr, *d_cbin = nullptr, *d_rows = nullptr, *d_nck = nullptr;
   Sc3Layout() = default;

@@ -253,6 +253,9 @@ sc3_lo_pass(const Sc3Tab S, const Sc3Op O, const uint32_t *__restrict__ perm, co
       }
     }
   }
+  // bonds inside Lo.  (A partner table per (entry, bond) -- what the window pass uses, Sc3Tab::w_nb -- was measured here
+  // too: 32 % fewer vector instructions and 0.3-0.9 ms MORE time, its 24 B per entry come from the L2 and every bond
+  // then reads LDS, profiles/r03_exp11_sc3_tables.txt: this pass is not bound by its instructions.)
   for (int lo = 0; lo < A - 1; ++lo) {
     if (!((O.present >> lo) & 1ull)) continue;
     const double ure = O.bond[4 * lo], uim = O.bond[4 * lo + 1], dre = O.bond[4 * lo + 2], dim_ = O.bond[4 * lo + 3];
@@ -342,8 +345,7 @@ sc3_win_pass(const Sc3Tab S, const Sc3Op O, const uint32_t *__restrict__ perm, c
   constexpr int MAXE = cbinom(WB, WB / 2) * 16;
   constexpr int RPT = (MAXE + NT - 1) / NT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  c128 *xs = reinterpret_cast<c128 *>(smem);
-  __shared__ int32_t cl[WB * (WB + 1)];
+  c128 *xs = reinterpret_cast<c128 *>(smem);       // the tile [wr][column], then one zero row (wr = nwp)
   const uint32_t e = perm[blockIdx.x];
   if (e == 0xffffffffu) return;
   const int lane = threadIdx.x & 63;
@@ -415,10 +417,7 @@ sc3_win_pass(const Sc3Tab S, const Sc3Op O, const uint32_t *__restrict__ perm, c
     }
   }
   uint64_t hb = __ballot(act);
-  for (int tt = threadIdx.x; tt < WB * (WB + 1); tt += NT) {
-    const int lo = tt / (WB + 1), o = tt % (WB + 1);
-    cl[tt] = S.cbin[lo * 17 + o];
-  }
+  for (int j = threadIdx.x; j < (1 << sh); j += NT) xs[nent + j] = make_double2(0.0, 0.0);       // the zero row
   double accr[RPT], acci[RPT];
 #pragma unroll
   for (int i = 0; i < RPT; ++i) {
@@ -465,23 +464,39 @@ sc3_win_pass(const Sc3Tab S, const Sc3Op O, const uint32_t *__restrict__ perm, c
     }
   }
   __syncthreads();
-  for (int lo = 0; lo < WB - 1; ++lo) {
-    const int b = S.a + lo;
-    if (!((O.present >> b) & 1ull)) continue;
-    const double ure = O.bond[4 * b], uim = O.bond[4 * b + 1], dre = O.bond[4 * b + 2], dim_ = O.bond[4 * b + 3];
+  // bonds inside W: the partner row of (row, bond) from the layout's table (Sc3Tab::w_nb) -- a row whose two spins are
+  // equal points at the zero row behind the tile, so the loop has no branches
+  {
+    uint64_t t0[RPT], t1[RPT];
+    uint32_t col[RPT];
+    const uint64_t *__restrict__ nb = S.w_nb + (size_t)2 * S.w_off[cw];
+    const uint64_t zr = (uint64_t)nwp * 0x0101010101010101ull;
 #pragma unroll
     for (int i = 0; i < RPT; ++i) {
       const int en = threadIdx.x + i * NT;
-      const uint32_t pair = (wpat[i] >> lo) & 3u;
-      if (off[i] >= 0 && (pair == 1u || pair == 2u)) {
-        const bool up = pair == 1u;
-        const int ord0 = __popc(wpat[i] & ((1u << lo) - 1u));
-        const int d = cl[lo * (WB + 1) + ord0] << sh;
-        const c128 xp = xs[up ? en + d : en - d];
+      const int wrr = (int)(wpat[i] >> 16);
+      col[i] = (uint32_t)en & ((1u << sh) - 1u);
+      t0[i] = zr;
+      t1[i] = zr;
+      if (en < nent) {
+        t0[i] = nb[2 * wrr];
+        if (WB - 1 > 8) t1[i] = nb[2 * wrr + 1];
+      }
+    }
+#pragma unroll
+    for (int lo = 0; lo < WB - 1; ++lo) {
+      const int b = S.a + lo;
+      if (!((O.present >> b) & 1ull)) continue;
+      const double ure = O.bond[4 * b], uim = O.bond[4 * b + 1], dre = O.bond[4 * b + 2], dim_ = O.bond[4 * b + 3];
+#pragma unroll
+      for (int i = 0; i < RPT; ++i) {
+        const uint32_t pr = (uint32_t)((lo < 8 ? t0[i] : t1[i]) >> (8 * (lo & 7))) & 0xffu;
+        const c128 xp = xs[(pr << sh) + col[i]];
         if (SYM) {
           accr[i] = fma(ure, xp.x, accr[i]);
           acci[i] = fma(ure, xp.y, acci[i]);
         } else {
+          const bool up = (wpat[i] >> lo) & 1u;
           const double cre = up ? ure : dre, cim = up ? uim : dim_;
           accr[i] = fma(cre, xp.x, accr[i]);
           acci[i] = fma(cre, xp.y, acci[i]);
@@ -630,7 +645,7 @@ bool sc3_valid(int L, int k, int a, int w) {
 }
 
 Sc3Layout::~Sc3Layout() {
-  for (void *p : {d_ibase, d_nbase, d_icoff, d_ncoff, d_lo_pat, d_w_pat, d_lo_rank, d_w_rank, d_cbin, d_rows, d_nck})
+  for (void *p : {d_ibase, d_nbase, d_icoff, d_ncoff, d_lo_pat, d_w_pat, d_lo_rank, d_w_rank, d_cbin, d_rows, d_nck, d_w_nb})
     if (p) (void)hipFree(p);
 }
 
@@ -676,6 +691,22 @@ int Sc3Layout::init(int L, int k, int a, int w, bool want_device) {
     S.rs[j] = s;
   }
   S.w_off[w + 1] = (int32_t)w_pat.size();
+  // partner table of the window pass's LDS bonds (Sc3Tab::w_nb)
+  // (only the field splits that have kernel instances need them; wider ones keep the tables empty)
+  const bool nbfit = w - 1 <= 16 && hbinom(w, w / 2) < 255;
+  w_nb.assign(nbfit ? (size_t)2 * w_pat.size() : 0, 0);
+  for (int j = 0; nbfit && j <= w; ++j)
+    for (int r = 0; r < S.nw[j]; ++r) {
+      const uint32_t v = w_pat[S.w_off[j] + r];
+      for (int b = 0; b < 16; ++b) {
+        uint64_t f = (uint64_t)S.nw[j];                        // the zero row
+        if (b < w - 1) {
+          const uint32_t pair = (v >> b) & 3u;
+          if (pair == 1u || pair == 2u) f = w_rank[v ^ (3u << b)];
+        }
+        w_nb[(size_t)2 * (S.w_off[j] + r) + (size_t)(b / 8)] |= f << (8 * (b % 8));
+      }
+    }
   icoff.assign((size_t)(a + w + 1) * (w + 1), 0);
   ncoff.assign((size_t)(a + w + 1) << w, 0);
   std::vector<int64_t> isize(a + w + 1, 0);
@@ -717,6 +748,7 @@ int Sc3Layout::init(int L, int k, int a, int w, bool want_device) {
   S.lo_pat = lo_pat.data(); S.w_pat = w_pat.data(); S.lo_rank = lo_rank.data(); S.w_rank = w_rank.data();
   S.cbin = cbin.data();
   S.nck = nck.data();
+  S.w_nb = w_nb.data();
   dev = S;
   if (want_device) {
     DNM_TRY(up(ibase, &d_ibase)); DNM_TRY(up(nbase, &d_nbase)); DNM_TRY(up(icoff, &d_icoff));
@@ -724,6 +756,8 @@ int Sc3Layout::init(int L, int k, int a, int w, bool want_device) {
     DNM_TRY(up(lo_rank, &d_lo_rank)); DNM_TRY(up(w_rank, &d_w_rank)); DNM_TRY(up(cbin, &d_cbin));
     DNM_TRY(up(rows, &d_rows));
     DNM_TRY(up(nck, &d_nck));
+    DNM_TRY(up(w_nb, &d_w_nb));
+    dev.w_nb = (const uint64_t *)d_w_nb;
     dev.ibase = (const int64_t *)d_ibase; dev.nbase = (const int64_t *)d_nbase;
     dev.icoff = (const int64_t *)d_icoff; dev.ncoff = (const int64_t *)d_ncoff;
     dev.lo_pat = (const uint16_t *)d_lo_pat; dev.w_pat = (const uint16_t *)d_w_pat;
@@ -1023,7 +1057,10 @@ template <int A, int W, int NT>
 static int launch_two_pass(const Sc3Mat &M, const Sc3Call &call, const double *cached_diag, const void *xw, void *y,
                            hipStream_t st, int phase) {
   const Sc3Tab &S = M.ly->dev;
-  constexpr size_t ldsA = (size_t)cbinom(A, A / 2) * 16, ldsB = (size_t)cbinom(W, W / 2) * 16 * 16;
+  // LDS: the lo pass's row; the window pass's tile plus its zero row (largest over the classes)
+  constexpr size_t ldsA = (size_t)cbinom(A, A / 2) * 16;
+  size_t ldsB = 0;
+  for (int cw = 0; cw <= W; ++cw) ldsB = std::max(ldsB, ((size_t)M.ly->host.nw[cw] + 1) << (4 + M.ly->host.rs[cw] + 4));
   Sc3Op op = M.op;
   const int dm = M.diag_mode;       // 2: on the fly whether or not a cached copy exists (8 B/row less to read)
   if (dm == 1) op.diag = cached_diag;

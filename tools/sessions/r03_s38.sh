@@ -1,0 +1,14 @@
+#!/bin/bash
+# round 3, GPU session 38: window pass with its partner table, lo pass as before -- parity, timing, config-5 rank, distributed sc3
+set -u
+cd "${GRAFT_REPO_ROOT:-.}"; export TMPDIR=/tmp
+OUT=gpurun_out/r03_s38; mkdir -p $OUT
+export DNM_EXPERIMENTAL=1
+timeout 900 python -m pytest tests/test_gpu_sc3.py -q -x 2>&1 | tail -3 | tee $OUT/pytest_sc3.txt
+timeout 600 python tools/sc_bench.py 32 2>&1 | grep -v amdgpu.ids | tee $OUT/sc_bench_32.txt
+bash tools/prof_cmd.sh $OUT/sc32_kernel_stats.txt python3 tools/sc_bench.py 32 > /dev/null
+timeout 900 python tools/sc3_config5.py --rank 3 2>&1 | grep -v amdgpu.ids | tail -4 | tee $OUT/config5_rank3.txt
+timeout 900 python tools/sc3_config5.py --rank 2 2>&1 | grep -v amdgpu.ids | tail -2 | tee -a $OUT/config5_rank3.txt
+bash tools/pmc_kernels.sh sc3_ 'FETCH_SIZE' -- python3 tools/sc_bench.py 32 | tee $OUT/sc32_fetch.txt
+bash tools/pmc_kernels.sh sc3_ 'WRITE_SIZE' -- python3 tools/sc_bench.py 32 | tee $OUT/sc32_write.txt
+timeout 1500 python -m pytest tests/test_gpu_distributed.py tests/test_gpu_fullsize.py -q -x -k "sc3 or config5 or internal" 2>&1 | tail -3 | tee $OUT/pytest_more.txt
