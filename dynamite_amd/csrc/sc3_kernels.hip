@@ -238,18 +238,38 @@ sc3_lo_pass(const Sc3Tab S, const Sc3Op O, const uint32_t *__restrict__ perm, co
       }
     }
   }
-  __syncthreads();
-  if (DIAGM == 2) {
-    const double dg0 = dsh[0];
+  // the accumulating pass asks for its y now: it arrives while the bonds are served from LDS (the x values of the
+  // entries are read back from the tile below, so their registers are free for it)
+  c128 yv[RPT];
+  if (ACC) {
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+      const int r = threadIdx.x + i * NT;
+      yv[i] = make_double2(0.0, 0.0);
+      if (r < nrows) yv[i] = load_nt(y + lbase + r);
+    }
+  }
+  double dlv[RPT];
+  if (DIAGM == 2) {          // the Lo-only part of the diagonal (L2-resident table), asked for before the barrier as well
     const double *__restrict__ dl = O.dlo + S.lo_off[kl];
 #pragma unroll
     for (int i = 0; i < RPT; ++i) {
       const int r = threadIdx.x + i * NT;
+      dlv[i] = r < nrows ? dl[r] : 0.0;
+    }
+  }
+  __syncthreads();
+  if (DIAGM == 2) {
+    const double dg0 = dsh[0];
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+      const int r = threadIdx.x + i * NT;
       if (r < nrows) {
-        double dg = dl[r] + dg0;
+        double dg = dlv[i] + dg0;
         for (int j = 0; j < O.ngroups; ++j) dg += flip(dsh[j + 1], (uint32_t)__popc(lowb[i] & O.glo[j]) & 1u);
-        accr[i] = fma(dg, xv[i].x, accr[i]);
-        acci[i] = fma(dg, xv[i].y, acci[i]);
+        const c128 xo = xs[r];
+        accr[i] = fma(dg, xo.x, accr[i]);
+        acci[i] = fma(dg, xo.y, acci[i]);
       }
     }
   }
@@ -289,9 +309,8 @@ sc3_lo_pass(const Sc3Tab S, const Sc3Op O, const uint32_t *__restrict__ perm, co
       double ar = accr[i], ai = acci[i];
       if (r < nrows) {
         if (ACC) {
-          const c128 yo = load_nt(y + lbase + r);
-          ar += yo.x;
-          ai += yo.y;
+          ar += yv[i].x;
+          ai += yv[i].y;
         } else if (C.zinit) {                     // y = A x - b z (+ c z2): the first pass carries the start vectors
           const c128 zv = C.zinit[lbase + r];
           ar = fma(-C.zscale, zv.x, ar);
@@ -418,6 +437,10 @@ sc3_win_pass(const Sc3Tab S, const Sc3Op O, const uint32_t *__restrict__ perm, c
   }
   uint64_t hb = __ballot(act);
   for (int j = threadIdx.x; j < (1 << sh); j += NT) xs[nent + j] = make_double2(0.0, 0.0);       // the zero row
+  // the class's partner table (Sc3Tab::w_nb, 16 bytes per row) behind it: read back from LDS after the barrier
+  ulonglong2 *wtab = reinterpret_cast<ulonglong2 *>(xs + nent + (1 << sh));
+  for (int j = threadIdx.x; j < nwp; j += NT)
+    wtab[j] = reinterpret_cast<const ulonglong2 *>(S.w_nb + (size_t)2 * S.w_off[cw])[j];
   double accr[RPT], acci[RPT];
 #pragma unroll
   for (int i = 0; i < RPT; ++i) {
@@ -469,7 +492,6 @@ sc3_win_pass(const Sc3Tab S, const Sc3Op O, const uint32_t *__restrict__ perm, c
   {
     uint64_t t0[RPT], t1[RPT];
     uint32_t col[RPT];
-    const uint64_t *__restrict__ nb = S.w_nb + (size_t)2 * S.w_off[cw];
     const uint64_t zr = (uint64_t)nwp * 0x0101010101010101ull;
 #pragma unroll
     for (int i = 0; i < RPT; ++i) {
@@ -479,8 +501,9 @@ sc3_win_pass(const Sc3Tab S, const Sc3Op O, const uint32_t *__restrict__ perm, c
       t0[i] = zr;
       t1[i] = zr;
       if (en < nent) {
-        t0[i] = nb[2 * wrr];
-        if (WB - 1 > 8) t1[i] = nb[2 * wrr + 1];
+        const ulonglong2 tw = wtab[wrr];
+        t0[i] = tw.x;
+        if (WB - 1 > 8) t1[i] = tw.y;
       }
     }
 #pragma unroll
@@ -1011,7 +1034,7 @@ int Sc3Mat::init(const Sc3Layout *layout, const std::vector<int64_t> &masks, con
   }
   op.ndt = diag_mode == 2 ? (int32_t)dt_sign.size() : 0;
   // dispatch order: workgroups that gather from each other run on one XCD at one time (their requests meet in that
-  // XCD's L2).  lo pass: groups (kt, cw, wr) over the T's of a popcount class; window pass: (kt, cw, run) likewise.
+  // XCD's L2).  Window pass: groups (kt, cw, run) over the T's of a popcount class -- siblings under the T bonds.
   std::vector<std::vector<uint32_t>> Tby(t + 1), gA, gB;
   for (uint32_t T = T0; T < T1 && T < (1u << t); ++T) if (ly->ibase[T] >= 0) Tby[__builtin_popcount(T)].push_back(T);
   for (int kt = 0; kt <= t; ++kt) {
@@ -1020,10 +1043,19 @@ int Sc3Mat::init(const Sc3Layout *layout, const std::vector<int64_t> &masks, con
     for (int cw = 0; cw <= w; ++cw) {
       const int kl = kr - cw;
       if (kl < 0 || kl > a) continue;
+      // lo pass: it gathers the Lo/W boundary bond only, which couples the rows (T, W) and (T, W ^ 1): each pair goes to
+      // one XCD back to back, so that what one row gathers is what the other stages (their requests meet in the L2);
+      // pairs of one (cw, wr) over the T's of the class follow each other -- equal lengths side by side
       for (int wr = 0; wr < S.nw[cw]; ++wr) {
-        std::vector<uint32_t> g;
-        for (uint32_t T : Tby[kt]) g.push_back((T << w) | ly->w_pat[S.w_off[cw] + wr]);
-        gA.push_back(g);
+        const uint32_t W = ly->w_pat[S.w_off[cw] + wr];
+        const int klp = (W & 1u) ? kl + 1 : kl - 1;                 // Lo ones of the partner row (T, W ^ 1)
+        const bool partner = klp >= 0 && klp <= a;
+        if ((W & 1u) && partner) continue;                          // listed with its even partner
+        for (uint32_t T : Tby[kt]) {
+          std::vector<uint32_t> g{(T << w) | W};
+          if (partner) g.push_back((T << w) | (W ^ 1u));
+          gA.push_back(g);
+        }
       }
       const int Rr = 16 << S.rs[cw], nrun = (S.pitch[kl] + Rr - 1) / Rr;
       DNM_CHECK(nrun < 4096, "internal: too many runs");
@@ -1060,7 +1092,8 @@ static int launch_two_pass(const Sc3Mat &M, const Sc3Call &call, const double *c
   // LDS: the lo pass's row; the window pass's tile plus its zero row (largest over the classes)
   constexpr size_t ldsA = (size_t)cbinom(A, A / 2) * 16;
   size_t ldsB = 0;
-  for (int cw = 0; cw <= W; ++cw) ldsB = std::max(ldsB, ((size_t)M.ly->host.nw[cw] + 1) << (4 + M.ly->host.rs[cw] + 4));
+  for (int cw = 0; cw <= W; ++cw)      // ... and the class's partner table
+    ldsB = std::max(ldsB, (((size_t)M.ly->host.nw[cw] + 1) << (4 + M.ly->host.rs[cw] + 4)) + (size_t)M.ly->host.nw[cw] * 16);
   Sc3Op op = M.op;
   const int dm = M.diag_mode;       // 2: on the fly whether or not a cached copy exists (8 B/row less to read)
   if (dm == 1) op.diag = cached_diag;
