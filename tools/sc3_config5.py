@@ -84,6 +84,25 @@ def main():
     print("rank %d of %d, SpinConserve(%d,%d): %.2f ms per multiply for %d rows = %.2f Grows/s" % (rank, P, L, k, ms, rows,
                                                                                                  rows / ms / 1e6))
     assert torch.isfinite(torch.view_as_real(y)).all()
+    # the order of a partitioned multiply: the lo pass first (it needs the rank's own rows only and runs under the
+    # exchange), then the window pass adds what reaches other blocks
+    own0 = C.c_int64()
+    _lib.check(_lib.lib().dnm_mat_ownership(mat.handle, C.byref(own0), None))
+    xl = xw[own0.value - lo: own0.value - lo + mat.m_local]
+    L_ = _lib.lib()
+    for timed in (False, True):
+        if timed:
+            torch.cuda.synchronize()
+            e0.record()
+        for _ in range(n if timed else 2):
+            _lib.check(L_.dnm_mat_mult_window_local(mat.handle, C.c_void_p(xl.data_ptr()), C.c_void_p(y.data_ptr()), backend._stream()))
+            if timed:
+                pass
+            _lib.check(L_.dnm_mat_mult_window_remote(mat.handle, C.c_void_p(xw.data_ptr()), lo, wlen, C.c_void_p(y.data_ptr()),
+                                                     backend._stream()))
+    e1.record()
+    torch.cuda.synchronize()
+    print("   split as a partitioned multiply runs it (lo pass writes y, window pass adds): %.2f ms" % (e0.elapsed_time(e1) / n))
 
 
 if __name__ == "__main__":
