@@ -357,8 +357,22 @@ sc3_lo_pass(const Sc3Tab S, const Sc3Op O, const uint32_t *__restrict__ perm, co
 // ---------------------------------------------------------------------------------------------------------
 // window pass (the first pass: writes y): one workgroup per (T, cw, run of R = 16 << s columns): all window
 // patterns of the class x R columns in LDS; the accumulators start from -zscale * zinit + z2 * zinit2 if given.
+// waves per SIMD the window pass can have: what its LDS tile lets be resident (two workgroups per CU for the 64 KB
+// tiles), at most 8 -- the register budget follows from it (128 registers at 512 threads, 64 at 1024)
+constexpr int sc3_win_waves(int nt, int tile_kb) {
+  int wgs = 160 / (tile_kb > 0 ? tile_kb : 1);
+  if (wgs > 2048 / nt) wgs = 2048 / nt;
+  if (wgs < 1) wgs = 1;
+  const int w = wgs * nt / 256;
+  return w > 8 ? 8 : (w < 1 ? 1 : w);
+}
+
+// (512 threads x 8 entries against 1024 x 4: 5.40 against 5.75 ms at SpinConserve(32,16), level on a rank of config 5,
+// profiles/r03_exp12_sc3_win512.txt.  Two gathered bonds in flight at a time -- half the round trips of a workgroup's
+// life, 12 of them on a rank of config 5 -- do not fit: the compiler needs 12-13 registers per entry where 8 are live,
+// and the spills cost more than the round trips: 22 ms.)
 template <int WB, int NT, bool SYM, bool ACC>
-__global__ void __launch_bounds__(NT, (2048 / NT) * NT / 256 > 8 ? 8 : (2048 / NT) * NT / 256)
+__global__ void __launch_bounds__(NT, sc3_win_waves(NT, (cbinom(WB, WB / 2) * 16 * 16 + 1023) / 1024 + 1))
 sc3_win_pass(const Sc3Tab S, const Sc3Op O, const uint32_t *__restrict__ perm, const Sc3Call C,
              const c128 *__restrict__ xw, c128 *__restrict__ y) {
   constexpr int MAXE = cbinom(WB, WB / 2) * 16;
@@ -1085,7 +1099,7 @@ int Sc3Mat::init(const Sc3Layout *layout, const std::vector<int64_t> &masks, con
 
 // phase 0: the whole multiply (window pass writes y, lo pass adds: one rank); phase 1: the part that needs nothing
 // from other ranks (lo pass, writes y); phase 2: the rest (window pass, adds)
-template <int A, int W, int NT>
+template <int A, int W, int NT, int NTW>
 static int launch_two_pass(const Sc3Mat &M, const Sc3Call &call, const double *cached_diag, const void *xw, void *y,
                            hipStream_t st, int phase) {
   const Sc3Tab &S = M.ly->dev;
@@ -1101,8 +1115,8 @@ static int launch_two_pass(const Sc3Mat &M, const Sc3Call &call, const double *c
   using kern_t = void (*)(const Sc3Tab, const Sc3Op, const uint32_t *, const Sc3Call, const c128 *, c128 *);
   const bool lo_first = phase != 0;
   kern_t kB = nullptr, kA = nullptr;
-  if (lo_first) kB = M.sym ? sc3_win_pass<W, NT, true, true> : sc3_win_pass<W, NT, false, true>;
-  else kB = M.sym ? sc3_win_pass<W, NT, true, false> : sc3_win_pass<W, NT, false, false>;
+  if (lo_first) kB = M.sym ? sc3_win_pass<W, NTW, true, true> : sc3_win_pass<W, NTW, false, true>;
+  else kB = M.sym ? sc3_win_pass<W, NTW, true, false> : sc3_win_pass<W, NTW, false, false>;
 #define DNM_LO(DM_, SY_) (lo_first ? (kern_t)sc3_lo_pass<A, NT, DM_, SY_, false> : (kern_t)sc3_lo_pass<A, NT, DM_, SY_, true>)
   switch (dm * 2 + (M.sym ? 1 : 0)) {
     case 0: kA = DNM_LO(0, false); break;
@@ -1124,7 +1138,7 @@ static int launch_two_pass(const Sc3Mat &M, const Sc3Call &call, const double *c
   second.zinit = nullptr;
   second.zinit2 = nullptr;
   if (phase == 0 || phase == 2)
-    hipLaunchKernelGGL(kB, dim3((unsigned)M.permB.size()), dim3(NT), ldsB, st, S, op, (const uint32_t *)M.d_permB,
+    hipLaunchKernelGGL(kB, dim3((unsigned)M.permB.size()), dim3(NTW), ldsB, st, S, op, (const uint32_t *)M.d_permB,
                        phase == 0 ? first : second, (const c128 *)xw, (c128 *)y);
   if (phase == 0 || phase == 1)
     hipLaunchKernelGGL(kA, dim3((unsigned)M.permA.size()), dim3(NT), ldsA, st, S, op, (const uint32_t *)M.d_permA,
@@ -1141,8 +1155,12 @@ int launch_sc3(const Sc3Mat &M, const DevMsc &msc, const Sc3Call &call, const do
   DNM_CHECK(phase == 0 || (M.tiled && !call.dot_out), "internal: only the tiled passes split into a local and a remote part");
   if (M.tiled) {
     if (call.dot_out) DNM_HIP(hipMemsetAsync(call.dot_out, 0, M.permA.size() * 3 * sizeof(double), st));
-    if (M.ly->host.a == 14) return launch_two_pass<14, 10, 1024>(M, call, cached_diag, xw, y, st, phase);
-    return launch_two_pass<6, 4, 64>(M, call, cached_diag, xw, y, st, phase);
+    if (M.ly->host.a == 14) {
+      static const bool w1024 = [] { const char *e = knob("DNM_SC3_WIN_THREADS"); return e && atoi(e) == 1024; }();   // experiments
+      if (w1024) return launch_two_pass<14, 10, 1024, 1024>(M, call, cached_diag, xw, y, st, phase);
+      return launch_two_pass<14, 10, 1024, 512>(M, call, cached_diag, xw, y, st, phase);
+    }
+    return launch_two_pass<6, 4, 64, 64>(M, call, cached_diag, xw, y, st, phase);
   }
   DNM_CHECK(!call.dot_out, "internal: the row kernel has no fused sums");
   hipLaunchKernelGGL(sc3_row_kernel, dim3((unsigned)M.rowsel.size()), dim3(SC3_ROW_NT), 0, st, M.ly->dev, msc,
