@@ -70,6 +70,16 @@ __device__ __forceinline__ RowId decode_row(uint32_t e, const Sc3Tab &S) {
   return r;
 }
 
+// waves per SIMD a tiled pass can have: what its LDS tile lets be resident (two workgroups per CU for the 64 KB
+// tiles), at most 8 -- the register budget follows from it (128 registers at 512 threads, 64 at 1024)
+constexpr int sc3_win_waves(int nt, int tile_kb) {
+  int wgs = 160 / (tile_kb > 0 ? tile_kb : 1);
+  if (wgs > 2048 / nt) wgs = 2048 / nt;
+  if (wgs < 1) wgs = 1;
+  const int w = wgs * nt / 256;
+  return w > 8 ? 8 : (w < 1 ? 1 : w);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // lo pass (the second, accumulating pass): y += (bonds inside Lo, the Lo/W boundary, whatever else bondsA names
 // and the diagonal) x.  One workgroup per row (T, W).
@@ -81,7 +91,7 @@ __device__ __forceinline__ RowId decode_row(uint32_t e, const Sc3Tab &S) {
 //   vectors -- the order of a partitioned multiply, where this pass needs nothing from other ranks (a rank owns whole
 //   T blocks) and runs while the window of x is still on the links.
 template <int A, int NT, int DIAGM, bool SYM, bool ACC>
-__global__ void __launch_bounds__(NT, (2048 / NT) * NT / 256 > 8 ? 8 : (2048 / NT) * NT / 256)
+__global__ void __launch_bounds__(NT, sc3_win_waves(NT, (cbinom(A, A / 2) * 16 + 1023) / 1024 + 1))
 sc3_lo_pass(const Sc3Tab S, const Sc3Op O, const uint32_t *__restrict__ perm, const Sc3Call C,
             const c128 *__restrict__ xw, c128 *__restrict__ y) {
   constexpr int MAXROWS = cbinom(A, A / 2);
@@ -357,16 +367,6 @@ sc3_lo_pass(const Sc3Tab S, const Sc3Op O, const uint32_t *__restrict__ perm, co
 // ---------------------------------------------------------------------------------------------------------
 // window pass (the first pass: writes y): one workgroup per (T, cw, run of R = 16 << s columns): all window
 // patterns of the class x R columns in LDS; the accumulators start from -zscale * zinit + z2 * zinit2 if given.
-// waves per SIMD the window pass can have: what its LDS tile lets be resident (two workgroups per CU for the 64 KB
-// tiles), at most 8 -- the register budget follows from it (128 registers at 512 threads, 64 at 1024)
-constexpr int sc3_win_waves(int nt, int tile_kb) {
-  int wgs = 160 / (tile_kb > 0 ? tile_kb : 1);
-  if (wgs > 2048 / nt) wgs = 2048 / nt;
-  if (wgs < 1) wgs = 1;
-  const int w = wgs * nt / 256;
-  return w > 8 ? 8 : (w < 1 ? 1 : w);
-}
-
 // (512 threads x 8 entries against 1024 x 4: 5.40 against 5.75 ms at SpinConserve(32,16), level on a rank of config 5,
 // profiles/r03_exp12_sc3_win512.txt.  Two gathered bonds in flight at a time -- half the round trips of a workgroup's
 // life, 12 of them on a rank of config 5 -- do not fit: the compiler needs 12-13 registers per entry where 8 are live,
@@ -1099,7 +1099,7 @@ int Sc3Mat::init(const Sc3Layout *layout, const std::vector<int64_t> &masks, con
 
 // phase 0: the whole multiply (window pass writes y, lo pass adds: one rank); phase 1: the part that needs nothing
 // from other ranks (lo pass, writes y); phase 2: the rest (window pass, adds)
-template <int A, int W, int NT, int NTW>
+template <int A, int W, int NT, int NTW>      // NT: threads of the lo pass (512 x 7 entries: 7.4 ms against 6.4), NTW: of the window pass
 static int launch_two_pass(const Sc3Mat &M, const Sc3Call &call, const double *cached_diag, const void *xw, void *y,
                            hipStream_t st, int phase) {
   const Sc3Tab &S = M.ly->dev;
