@@ -1274,14 +1274,15 @@ norm_kernel(const DevMsc msc, const SubView left_g, const SubView right_g, int64
     for (int m = 0; m < msc.nmasks; ++m) {
       const int64_t mask = msc.masks[m];
       const int64_t bra = ket ^ mask;
-      if (Sub<RT>::s2i(bra, right) < 0) continue;
+      if (!Sub<RT>::contains(bra, right)) continue;       // (membership only: the column index is not needed)
       double cre = 0.0, cim = 0.0;
+      bool imag = false;                                   // wave-uniform: does any term of this mask carry an i?
       for (int64_t t = msc.mask_offsets[m]; t < msc.mask_offsets[m + 1]; ++t) {
         const int64_t sg = msc.signs[t];
         const double c = flip_sign(msc.real_coeffs[t], (uint32_t)__popcll((uint64_t)(bra & sg)) & 1u);
-        if (__popcll((uint64_t)(mask & sg)) & 1) cim += c; else cre += c;
+        if (__popcll((uint64_t)(mask & sg)) & 1) { cim += c; imag = true; } else cre += c;
       }
-      const double comp = hypot(cre, cim) - err;
+      const double comp = (imag ? hypot(cre, cim) : fabs(cre)) - err;
       const double tot = sum + comp;
       err = (tot - sum) - comp;
       sum = tot;

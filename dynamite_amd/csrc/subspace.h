@@ -66,6 +66,7 @@ struct Sub<DNM_FULL> {
   static DNM_HD int64_t dim(const SubView &s) { return (int64_t)1 << s.L; }
   static DNM_HD int64_t i2s(int64_t idx, const SubView &) { return idx; }
   static DNM_HD int64_t s2i(int64_t st, const SubView &) { return st; }
+  static DNM_HD bool contains(int64_t, const SubView &) { return true; }     // membership without the index
 };
 
 template <>
@@ -77,6 +78,7 @@ struct Sub<DNM_PARITY> {
   static DNM_HD int64_t s2i(int64_t st, const SubView &s) {
     return hd_par((uint64_t)st) == s.space ? (st >> 1) : (int64_t)-1;
   }
+  static DNM_HD bool contains(int64_t st, const SubView &s) { return hd_par((uint64_t)st) == s.space; }
 };
 
 template <>
@@ -114,6 +116,7 @@ struct Sub<DNM_SPIN_CONSERVE> {
     if (hd_popc((uint64_t)st) != s.k) return -1;
     return rank(st, s);
   }
+  static DNM_HD bool contains(int64_t st, const SubView &s) { return hd_popc((uint64_t)st) == s.k; }
 };
 
 template <>
@@ -136,6 +139,7 @@ struct Sub<DNM_EXPLICIT> {
     }
     return -1;
   }
+  static DNM_HD bool contains(int64_t st, const SubView &s) { return s2i(st, s) >= 0; }
 };
 
 // run-time dispatch (host side of the C ABI)
