@@ -1317,7 +1317,7 @@ conserves_kernel(const DevMsc msc, const double *__restrict__ coeffs_im, const S
   const int64_t bra = Sub<RT>::i2s(col, right);
   for (int m = 0; m < msc.nmasks; ++m) {
     const int64_t ket = bra ^ msc.masks[m];
-    if (Sub<LT>::s2i(ket, left) >= 0) continue;
+    if (Sub<LT>::contains(ket, left)) continue;
     // complex sum of the terms of this matrix element (the reference sums msc->coeffs)
     double vr = 0.0, vi = 0.0;
     for (int64_t t = msc.mask_offsets[m]; t < msc.mask_offsets[m + 1]; ++t) {
