@@ -496,3 +496,40 @@ def test_window_needed_ranges_and_schedule():
     full = window_exchange_ops(owned, windows, 2)
     assert sum(hi - lo for _, lo, hi in full[0]) == windows[2][1] + 1 - windows[2][0] - \
         (min(windows[2][1] + 1, owned[2][0] + owned[2][1]) - max(windows[2][0], owned[2][0]))
+
+
+@pytest.mark.parametrize("L,P,S,flags_amin", [(30, 1, 16, 0), (31, 1, 16, 0), (32, 1, 16, 0), (34, 8, 14, 0), (34, 8, 14, 8),
+                                              (33, 4, 14, 7), (26, 1, 16, 0), (20, 1, 0, 0), (24, 3, 0, 0)])
+def test_pass_addressing_fits_32_bit_offsets(L, P, S, flags_amin):
+    """tile_pass_kernel addresses a row as (scalar base) + (32-bit byte offset of the thread): every position bit the
+    thread's part of the tile coordinate can reach -- the low B - LOGR tile bits and what the layout folds them onto --
+    lies in DevPass::pos_tmask, below bit 28, for every pass of the plans the benchmark configurations take (a tile
+    that reaches higher, like the layout-B operator of the transposed exchange at 2^31 amplitudes per rank, gets
+    more rows per thread: csrc/mat.cpp build_pass)."""
+    from dynamite_amd import models, msc_tools, _lib
+    from dynamite_amd.subspaces import Full
+    from plan_emulator import HostMat, vec_pos
+    H = models.heisenberg(L)
+    H.establish_L()
+    H.reduce_msc()
+    masks, offs = msc_tools.get_mask_offsets(H.msc)
+    sub = Full(L=L)
+    c = sub._c()
+    pow2 = P & (P - 1) == 0
+    c.vec_swizzle = S if pow2 else 0
+    for rank in sorted({0, P - 1, P // 2}):
+        flags = _lib.MAT_HOST_ONLY | (flags_amin << _lib.MAT_AMIN_SHIFT)
+        hm = HostMat(masks, offs, H.msc['signs'], H.msc['coeffs'], c, c, rank=rank, nranks=P, flags=flags)
+        if not hm.tiled:
+            continue
+        for desc, _ in hm.local + hm.remote:
+            lognt = desc.tile_bits - desc.log_rows
+            want, cnt = 0, 0
+            for j in range(desc.nseg):
+                for i in range(desc.seg_len[j]):
+                    if cnt < lognt:
+                        bit = 1 << (desc.seg_pos[j] + i)
+                        want |= int(vec_pos(bit, desc.swz_shift)) | bit
+                    cnt += 1
+            assert desc.pos_tmask == want, (L, P, rank, hm.describe())
+            assert desc.pos_tmask >> 28 == 0
