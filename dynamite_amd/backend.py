@@ -72,6 +72,20 @@ def window_exchange_ops(owned, windows, me, needs=None):
     return recvs, sends
 
 
+def complement_ranges(ranges, n):
+    """The parts of [0, n) that the ascending, disjoint ``ranges`` [(a, b), ...] leave out."""
+    out, at = [], 0
+    for a, b in ranges:
+        if not (at <= a < b <= n):
+            raise ValueError('ranges must be ascending, disjoint and inside [0, %d): %r' % (n, ranges))
+        if a > at:
+            out.append((at, a))
+        at = b
+    if at < n:
+        out.append((at, n))
+    return out
+
+
 def needed_ranges(chunk_map, shift, window):
     """[lo, hi) column ranges covering the marked chunks of ``dnm_mat_column_chunks`` (clipped to the window)."""
     wlo, whi = window[0], window[1] + 1
@@ -1014,14 +1028,7 @@ class ShellMat:
                                                             self.WINDOW_ROWS_MIN_BLOCKS, buf, C.byref(n), _stream()))
             local = [(int(buf[2 * i]), int(buf[2 * i + 1])) for i in range(n.value)]
             if knob('DNM_WINDOW_ROWS', '1') != '0' and sum(b - a for a, b in local) >= self.WINDOW_ROWS_MIN_SHARE * self.m_local:
-                remote, at = [], 0
-                for a, b in local:
-                    if a > at:
-                        remote.append((at, a))
-                    at = b
-                if at < self.m_local:
-                    remote.append((at, self.m_local))
-                self._row_ranges = (local, remote)
+                self._row_ranges = (local, complement_ranges(local, self.m_local))
         return self._row_ranges
 
     def norm(self, norm_type='infinity'):

@@ -533,3 +533,25 @@ def test_pass_addressing_fits_32_bit_offsets(L, P, S, flags_amin):
                     cnt += 1
             assert desc.pos_tmask == want, (L, P, rank, hm.describe())
             assert desc.pos_tmask >> 28 == 0
+
+
+def test_complement_ranges():
+    """The rows a window partition multiplies after its exchange are what the listed local ranges leave out."""
+    from dynamite_amd.backend import complement_ranges
+    assert complement_ranges([], 10) == [(0, 10)]
+    assert complement_ranges([(0, 10)], 10) == []
+    assert complement_ranges([(2, 4), (4, 6), (8, 9)], 10) == [(0, 2), (6, 8), (9, 10)]
+    rs = np.random.RandomState(3)
+    for _ in range(50):
+        n = int(rs.randint(1, 1000))
+        cuts = np.unique(rs.randint(0, n + 1, size=int(rs.randint(0, 12))))
+        ranges = [(int(a), int(b)) for a, b in zip(cuts[0::2], cuts[1::2])]
+        rest = complement_ranges(ranges, n)
+        cover = np.zeros(n, dtype=int)
+        for a, b in ranges + rest:
+            cover[a:b] += 1
+        assert np.all(cover == 1)
+    with pytest.raises(ValueError):
+        complement_ranges([(4, 2)], 10)
+    with pytest.raises(ValueError):
+        complement_ranges([(0, 5), (3, 8)], 10)
