@@ -128,6 +128,110 @@ def cpu_baseline(sample_L=26, reps=3):
     return out
 
 
+def secondary(wd, budget_s=15.0):
+    """The Krylov half of the path (wall time and multiply count of evolve / eigsolve; the
+    reference harness times them as phases of their own, benchmarking/benchmark.py:205-226, 311-313), on rank 0 of a
+    one-GPU run, after the timed multiplies:
+      * `evolve(t=1)` on the L=26 XXZ chain (BASELINE.json configs[1]);
+      * the basis-free Lanczos of `eigsolve(nev=1)` at the headline size (L=30 random-field Heisenberg): ms per step
+        and the step's own roofline -- one step is a multiply (32 B/amp) plus the three-term update sweep (48 B/amp:
+        it reads v_j and w and writes v_{j+1}), `(32 + 48) * dim / t_step / peak`;
+      * `eigsolve(nev=1)` on SpinConserve(32,16) (BASELINE.json configs[4]'s subspace family at one-GPU size).
+    Each carries a sanity check (norm preserved / measured residual within tol).  A phase is skipped (and says so) once
+    the budget is spent."""
+    import numpy as np
+    import torch
+    from dynamite_amd import models
+    from dynamite_amd.config import config
+    from dynamite_amd.states import State
+    from dynamite_amd.subspaces import Full, SpinConserve
+    from dynamite_amd.computations import evolve, eigsolve
+    t_begin = time.perf_counter()
+    out = {}
+
+    def timed(fn):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r = fn()
+        torch.cuda.synchronize()
+        return r, time.perf_counter() - t0
+
+    def left():
+        return budget_s - (time.perf_counter() - t_begin)
+
+    # -- evolve, L=26 XXZ
+    wd.phase("secondary: evolve L=26")
+    L = 26
+    sub = Full(L=L)
+    H = models.xxz(L)
+    H.add_subspace(sub)
+    psi = State(L=L, subspace=sub)
+    psi.set_random(seed=0)
+    res = State(L=L, subspace=sub)
+    runs = []
+    for _ in range(2):          # the first call grows the solver workspace
+        _, dt = timed(lambda: H.evolve(psi, t=1.0, result=res))
+        runs.append((dt, dict(evolve.last_stats)))
+    nrm = res.norm()
+    assert abs(nrm - 1.0) < 1e-8, "evolve did not preserve the norm: %r" % nrm
+    dt, st = runs[-1]
+    out["evolve_L26_xxz_t1"] = {"wall_s": dt, "first_call_wall_s": runs[0][0], "matvecs": st["matvecs"],
+                                "outer_steps": st["its"], "ms_per_matvec_equivalent": dt / max(1, st["matvecs"]) * 1e3,
+                                "algo": "default: Krylov (expokit-style sub-steps) handing the rest of a real-time "
+                                        "interval to the Chebyshev expansion",
+                                "norm_error": abs(nrm - 1.0), "dim": 1 << L}
+    H.destroy_mat()
+    del psi, res, H
+
+    # -- one Lanczos step at the headline size
+    if left() > 7.0:
+        wd.phase("secondary: Lanczos L=30")
+        L = 30
+        sub = Full(L=L)
+        H = models.mbl(L)
+        H.add_subspace(sub)
+        tol = 1e-6
+        (ev, dt0) = timed(lambda: H.eigsolve(nev=1, tol=tol))
+        st0 = dict(eigsolve.last_stats)
+        dt, st = dt0, st0
+        if left() > dt0 + 3.0:      # again with the workspace in place (the first call allocates it)
+            (ev, dt) = timed(lambda: H.eigsolve(nev=1, tol=tol))
+            st = dict(eigsolve.last_stats)
+        assert st["max_rel_residual"] <= tol * 1.01, "Lanczos residual %r above tol" % st["max_rel_residual"]
+        dim = 1 << L
+        step_ms = dt / st["matvecs"] * 1e3
+        bw = (ALG_BYTES_PER_AMP + 48.0) * dim / (step_ms * 1e-3) / 1e9
+        out["lanczos_L30"] = {"wall_s": dt, "first_call_wall_s": dt0, "matvecs": st["matvecs"], "E0": float(ev[0]),
+                              "ms_per_step": step_ms, "measured_rel_residual": st["max_rel_residual"], "tol": tol,
+                              "roofline": {"bound": "hbm", "alg_bytes_per_amp_per_step": ALG_BYTES_PER_AMP + 48.0,
+                                           "achieved": bw, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                           "frac": bw / HBM_PEAK_GBS}}
+        H.destroy_mat()
+        del H
+    else:
+        out["lanczos_L30"] = "skipped: budget"
+
+    # -- eigsolve on SpinConserve(32,16)
+    if left() > 5.0:
+        wd.phase("secondary: eigsolve SpinConserve(32,16)")
+        L, k = 32, 16
+        sub = SpinConserve(L, k)
+        H = models.heisenberg(L)
+        H.add_subspace(sub)
+        tol = 1e-8
+        (ev, dt) = timed(lambda: H.eigsolve(nev=1, tol=tol, subspace=sub))
+        st = dict(eigsolve.last_stats)
+        assert st["max_rel_residual"] <= tol * 1.01, "residual %r above tol" % st["max_rel_residual"]
+        out["eigsolve_sc32_16"] = {"wall_s": dt, "matvecs": st["matvecs"], "E0": float(ev[0]), "dim": sub.get_dimension(),
+                                   "measured_rel_residual": st["max_rel_residual"], "tol": tol,
+                                   "ms_per_step": dt / st["matvecs"] * 1e3}
+        H.destroy_mat()
+    else:
+        out["eigsolve_sc32_16"] = "skipped: budget"
+    out["total_s"] = time.perf_counter() - t_begin
+    return out
+
+
 XGMI_LINK_GBS = 64.0      # assumed sustained one-direction rate of one xGMI link (spec 153 GB/s bidirectional per
                           # link pair; RCCL send/recv reaches 60-77 GB/s per direction): used for the PREDICTION only
 
@@ -380,6 +484,7 @@ def main():
     ap.add_argument("--L", type=int, default=0)
     ap.add_argument("--model", default="mbl")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the evolve / eigsolve phases of the one-GPU line")
     ap.add_argument("--watchdog", type=int, default=900, help="seconds a phase may take before the rank gives up (0: off)")
     ap.add_argument("--timeout", type=int, default=3600, help="time limit of a self-launched multi-rank run (0: none)")
     args = ap.parse_args()
@@ -557,11 +662,19 @@ def main():
                          "alg_bytes_per_launch": alg_bytes_launch,
                          "read_only_frac": 0.5 * achieved / HBM_PEAK_GBS},
         }
+        if n_gpus == 1 and not args.no_secondary and L == 30:
+            # the headline's vectors and operator go first: the solvers size their work space to the free memory
+            mat.destroy()
+            mat = None
+            del x, y
+            torch.cuda.empty_cache()
+            out["secondary"] = secondary(wd)
         if n_gpus == 1 and not args.no_cpu_baseline:
             wd.phase("cpu baseline")
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
-    mat.destroy()
+    if mat is not None:
+        mat.destroy()
     if world > 1:
         dist.destroy_process_group()
 

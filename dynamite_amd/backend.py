@@ -47,6 +47,34 @@ def layout_partition(sub_c, nranks, rank):
     return tuple(x.value for x in v)
 
 
+def redistribute(local, src_parts, dst_parts, me):
+    """Move a vector between two contiguous partitions of the same index order: ``local`` is this rank's block under
+    ``src_parts`` (a list of (start, n) per rank), the result its block under ``dst_parts``.  Collective; overlaps
+    of a rank's old and new block are copied in place, the rest travels as one batch of sends and receives (between a
+    pair of ranks at most one message each way, so in-order matching is trivially right)."""
+    import torch
+    from . import _comm
+    s0, sn = src_parts[me]
+    d0, dn = dst_parts[me]
+    if local.numel() != sn:
+        raise ValueError('redistribute: the local block has %d elements, its partition says %d' % (local.numel(), sn))
+    out = torch.empty(dn, dtype=local.dtype, device=local.device)
+    sends, recvs = [], []
+    for q in range(len(src_parts)):
+        lo, hi = max(s0, dst_parts[q][0]), min(s0 + sn, dst_parts[q][0] + dst_parts[q][1])      # mine -> q's new block
+        if lo < hi:
+            if q == me:
+                out[lo - d0:hi - d0] = local[lo - s0:hi - s0]
+            else:
+                sends.append((local[lo - s0:hi - s0], q))
+        lo, hi = max(d0, src_parts[q][0]), min(d0 + dn, src_parts[q][0] + src_parts[q][1])      # q's old block -> mine
+        if lo < hi and q != me:
+            recvs.append((out[lo - d0:hi - d0], q))
+    for r in _comm.batch_p2p(sends, recvs):
+        r.wait()
+    return out
+
+
 def window_exchange_ops(owned, windows, me, needs=None):
     """Who sends what to whom so that every rank holds the columns of its window.
     owned[q] = (start, n) of rank q's block; windows[q] = inclusive (cmin, cmax) rank q reads; needs[q] (optional)
@@ -268,6 +296,9 @@ class Vec:
             self.istart, self.local_size, self.start, self.rows = layout_partition(sub_c, config.world_size, config.rank)
         if array is None:
             array = device_zeros(self.local_size)
+        elif array.numel() != self.local_size:
+            raise ValueError('Vec: the array holds %d elements, this rank\'s part of a vector of %d in layout %d has %d'
+                             % (array.numel(), self.size, self.swz, self.local_size))
         self.array = array
 
     @property
@@ -345,6 +376,13 @@ class Vec:
         return self.size
 
     def getLocalSize(self):
+        """Elements of the vector this rank owns (hi - lo of getOwnershipRange, the petsc4py contract); the length of
+        ``array`` -- what the vector kernels sweep, padding of the SpinConserve internal layout included -- is
+        ``alloc_size``."""
+        return self.rows
+
+    @property
+    def alloc_size(self):
         return self.local_size
 
     def getOwnershipRange(self):
@@ -519,17 +557,32 @@ class ShellMat:
         """A vector in the SpinConserve internal layout meets a matrix that works in reference order (a projection
         onto / from another subspace, XParity ...): multiply on reference-order copies."""
         xn, yn = x, y
+        P = self.nranks
+
+        def parts(v):
+            """(block of the internal layout's partition, block of the reference-order partition) per rank: on
+            several ranks the two differ (whole top-bit blocks against PetscSplitOwnership) and the copy is
+            redistributed between them."""
+            return ([layout_partition(v.sub_c, P, q)[2:4] for q in range(P)],
+                    [split_ownership(v.size, P, q) for q in range(P)])
         if x.swz != self.swz_right:
             if not (x.internal and self.swz_right == 0):
                 return False
-            xn = Vec(x.size, array=x.local_natural(), swz=0)
+            arr = x.local_natural()
+            if P > 1:
+                arr = redistribute(arr, *parts(x), self.rank)
+            xn = Vec(x.size, array=arr, swz=0)
         if y.swz != self.swz_left:
             if not (y.internal and self.swz_left == 0):
                 return False
             yn = Vec(y.size, swz=0)
         self.mult(xn, yn)
         if yn is not y:
-            y.set_local_natural(yn.array)
+            arr = yn.array
+            if P > 1:
+                lay, ref = parts(y)
+                arr = redistribute(arr, ref, lay, self.rank)
+            y.set_local_natural(arr)
         return True
 
     def describe(self):
@@ -599,8 +652,9 @@ class ShellMat:
                 raise ValueError('%s vector layout (swizzle %d) does not match the matrix (%d): the state was '
                                  'created under a different vector layout or rank count than the operator'
                                  % (name, v.swz, want))
-            if v.local_size != n:
-                raise ValueError('%s vector holds %d local elements, the matrix expects %d' % (name, v.local_size, n))
+            if v.local_size != n or v.array.numel() != n:
+                raise ValueError('%s vector holds %d local elements (array of %d), the matrix expects %d'
+                                 % (name, v.local_size, v.array.numel(), n))
 
     def selfcheck(self, x, y, nsample=24):
         """Collective: recompute ``nsample`` rows per rank of y = A x on the host from the operator's definition
@@ -1112,7 +1166,8 @@ def build_mat(masks, mask_offsets, signs, coeffs, left_subspace, right_subspace,
 def use_transposed_exchange(nranks, mode=None):
     """Exchange scheme of a partitioned Full-space or Parity multiply: with four or more ranks the all-to-all of the
     transposed scheme puts less on the busiest link than the partner blocks (two ranks: the partner block is
-    half of what two transposes move).  DNM_EXCHANGE=partner / transpose overrides."""
+    half of what two transposes move).  DNM_EXCHANGE=partner / transpose overrides (an experiment knob: counted only
+    under DNM_EXPERIMENTAL=1, like every DNM_* variable; `build_mat(..., exchange=...)` is the production way)."""
     mode = mode or knob('DNM_EXCHANGE', 'auto')
     if mode == 'partner' or nranks < 2:
         return False

@@ -9,10 +9,18 @@ rank this process drives.  One process per GPU; ranks come from
 import os
 
 
+_warned = set()
+
+
 def knob(name, default=None):
     """Experiment knobs (DNM_* environment variables) count only under DNM_EXPERIMENTAL=1, as in the native
-    library (csrc/dnm_common.h: knob); tests and the A/B tools set the gate, production runs ignore them."""
+    library (csrc/dnm_common.h: knob); tests and the A/B tools set the gate, production runs ignore them -- and say
+    so once per knob, so that an A/B run without the gate does not silently measure the default twice."""
     if os.environ.get('DNM_EXPERIMENTAL') != '1':
+        if os.environ.get(name) and name not in _warned:
+            _warned.add(name)
+            import warnings
+            warnings.warn('%s is set but ignored: experiment knobs need DNM_EXPERIMENTAL=1' % name, stacklevel=2)
         return default
     v = os.environ.get(name)
     return v if v else default

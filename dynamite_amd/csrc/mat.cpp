@@ -1406,7 +1406,7 @@ int dnm_mat_plan_describe(const dnm_mat *A, char *buf, size_t buflen) {
       snprintf(tmp, sizeof tmp, "SpinConserve two-pass kernels, internal layout [T %d | W %d | Lo %d]: window pass (%zu "
                "workgroups, %d bonds in LDS, %d gathered) then lo pass (%zu workgroups, %d bonds in LDS, %d gathered), "
                "diagonal %s, coefficients %s\n", T.t, T.w, T.a, A->sc3->permB.size(), T.w - 1,
-               __builtin_popcountll(A->sc3->op.bondsB), A->sc3->permA.size(), T.a - 1,
+               __builtin_popcountll(A->sc3->op.bondsB), A->sc3->permA.size() / 8, T.a - 1,
                __builtin_popcountll(A->sc3->op.bondsA),
                A->sc3->diag_mode == 2 ? "on the fly" : (A->sc3->diag_mode == 1 ? "cached" : "none"),
                A->sc3->sym ? "real symmetric" : "complex");

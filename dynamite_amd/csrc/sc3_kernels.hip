@@ -44,6 +44,25 @@ __device__ __forceinline__ double flip(double c, uint32_t parity_bit) {
   return __hiloint2double(hi, __double2loint(c));
 }
 
+// wave priority by phase (round 4, as in tile_pass_kernel): raised while a workgroup is in a memory phase, lowered for
+// its LDS bond loops, so that of the two workgroups of a CU the one asking for memory wins the issue slots
+// the layout's and the operator's tables are read-only: through the constant address space their wave-uniform reads
+// stay scalar loads whatever else the kernel contains (see CQuad in matvec_kernels.hip)
+#define SC3_CP(T, p) ((const __attribute__((address_space(4))) T *)(p))
+#ifndef DNM_SC3_PRIO
+#define DNM_SC3_PRIO 0
+#endif
+#if DNM_SC3_PRIO == 1
+#define SC3_PRIO_MEM() asm volatile("s_setprio 3")
+#define SC3_PRIO_LDS() asm volatile("s_setprio 0")
+#else
+#define SC3_PRIO_MEM()
+#define SC3_PRIO_LDS()
+#endif
+
+constexpr int ilog2c(int v) { return v <= 1 ? 0 : 1 + ilog2c(v >> 1); }
+constexpr uint32_t SC3_NOROW = 1u << 29;       // lo pass: a sub-group slot without a row
+
 constexpr int cbinom(int n, int k) {
   long long r = 1;
   for (int i = 1; i <= k; ++i) r = r * (n - k + i) / i;
@@ -65,10 +84,13 @@ __device__ __forceinline__ RowId decode_row(uint32_t e, const Sc3Tab &S) {
   r.kl = r.kr - r.cw;
   r.nrows = S.nl[r.kl];
   r.pitch = S.pitch[r.kl];
-  r.tb = S.ibase[r.T];
-  r.base = r.tb + S.icoff[r.kr * (S.w + 1) + r.cw] + (int64_t)S.w_rank[r.W] * r.pitch;
+  r.tb = SC3_CP(int64_t, S.ibase)[r.T];
+  r.base = r.tb + SC3_CP(int64_t, S.icoff)[r.kr * (S.w + 1) + r.cw] + (int64_t)SC3_CP(uint16_t, S.w_rank)[r.W] * r.pitch;
   return r;
 }
+
+// entries of the lo pass's LDS tile: what the workgroup's threads hold (RPT entries each), at least the longest row
+constexpr int sc3_lo_cap(int a, int nt) { return ((cbinom(a, a / 2) + nt - 1) / nt) * nt; }
 
 // waves per SIMD a tiled pass can have: what its LDS tile lets be resident (two workgroups per CU for the 64 KB
 // tiles), at most 8 -- the register budget follows from it (128 registers at 512 threads, 64 at 1024)
@@ -82,7 +104,11 @@ constexpr int sc3_win_waves(int nt, int tile_kb) {
 
 // ---------------------------------------------------------------------------------------------------------
 // lo pass (the second, accumulating pass): y += (bonds inside Lo, the Lo/W boundary, whatever else bondsA names
-// and the diagonal) x.  One workgroup per row (T, W).
+// and the diagonal) x.  A workgroup takes 2^m rows (T, W), m = 0..3 (round 4): a row has C(a, kl) states -- 3432 at
+// kl = 7, 2002 at kl = 5, 364 at kl = 3 -- and one row per 1024-thread workgroup left 44 % of the lanes idle at
+// SpinConserve(32,16).  The workgroup splits into 2^m sub-groups of NT >> m threads (whole wavefronts), each with its
+// own row and its own slice of the LDS tile; everything that is uniform per row is uniform per wavefront, as before.
+// perm holds 8 entries per workgroup: entry j = row of sub-group j | m << 30, bit 29 set = no row (SC3_NOROW).
 //   DIAGM 0: no diagonal; 1: cached (internal order, 8 B/row); 2: on the fly -- terms that see Lo only from a table
 //   over (kl, lr) (L2-resident), terms that see (T, W) only as one number per row, terms that see both as at most
 //   four (Lo sign mask, per-row coefficient) pairs.
@@ -91,33 +117,41 @@ constexpr int sc3_win_waves(int nt, int tile_kb) {
 //   vectors -- the order of a partitioned multiply, where this pass needs nothing from other ranks (a rank owns whole
 //   T blocks) and runs while the window of x is still on the links.
 template <int A, int NT, int DIAGM, bool SYM, bool ACC>
-__global__ void __launch_bounds__(NT, sc3_win_waves(NT, (cbinom(A, A / 2) * 16 + 1023) / 1024 + 1))
+__global__ void __launch_bounds__(NT, sc3_win_waves(NT, (sc3_lo_cap(A, NT) * 16 + 1023) / 1024 + 1))
 sc3_lo_pass(const Sc3Tab S, const Sc3Op O, const uint32_t *__restrict__ perm, const Sc3Call C,
             const c128 *__restrict__ xw, c128 *__restrict__ y) {
   constexpr int MAXROWS = cbinom(A, A / 2);
   constexpr int RPT = (MAXROWS + NT - 1) / NT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  c128 *xs = reinterpret_cast<c128 *>(smem);
   __shared__ int32_t cl[A * (A + 1)];
   __shared__ double red[3 * (NT / 64)];
-  __shared__ double dsh[5];
-  const uint32_t e = perm[blockIdx.x];
-  if (e == 0xffffffffu) return;
+  __shared__ double dsh[5 * 8];
+  const uint32_t e0 = SC3_CP(uint32_t, perm)[8 * (size_t)blockIdx.x];
+  if (e0 == 0xffffffffu) return;                        // padding of the dispatch order: a workgroup without rows
   const int lane = threadIdx.x & 63;
   const int w = S.w;
-  const RowId R = decode_row(e, S);
+  // sub-group of this wavefront: NTS threads, RPT entries each, its own slice of the tile
+  const int logm = (int)(e0 >> 30);
+  const int NTS = NT >> logm;
+  const int sub = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) >> (ilog2c(NT) - 6 - logm);
+  const int tsub = (int)threadIdx.x & (NTS - 1);
+  const uint32_t e = SC3_CP(uint32_t, perm)[8 * (size_t)blockIdx.x + sub];
+  const bool has_row = !(e & SC3_NOROW);
+  c128 *xs = reinterpret_cast<c128 *>(smem) + (size_t)sub * ((NT * RPT) >> logm);
+  const RowId R = decode_row(has_row ? (e & (SC3_NOROW - 1u)) : (e0 & (SC3_NOROW - 1u)), S);
   const uint32_t T = R.T, W = R.W;
-  const int cw = R.cw, kr = R.kr, kl = R.kl, nrows = R.nrows, p = R.pitch;
+  const int cw = R.cw, kr = R.kr, kl = R.kl, nrows = has_row ? R.nrows : 0, p = has_row ? R.pitch : 0;
   const int64_t tb = R.tb, base = R.base;
   const c128 *__restrict__ x = xw - C.win_start;
   const int64_t lbase = base - C.row0;                 // position of the row in this rank's vectors
 
+  SC3_PRIO_MEM();
   uint32_t lowb[RPT];
   c128 xv[RPT];
-  const uint16_t *__restrict__ pat = S.lo_pat + S.lo_off[kl];
+  const auto pat = SC3_CP(uint16_t, S.lo_pat) + S.lo_off[kl];
 #pragma unroll
   for (int i = 0; i < RPT; ++i) {
-    const int r = threadIdx.x + i * NT;
+    const int r = tsub + i * NTS;
     lowb[i] = 0;
     xv[i] = make_double2(0.0, 0.0);
     if (r < nrows) {
@@ -135,66 +169,66 @@ sc3_lo_pass(const Sc3Tab S, const Sc3Op O, const uint32_t *__restrict__ perm, co
     if (b < S.L - 1 && ((O.bondsA >> b) & 1ull)) {
       bool up = false;
       if (lane == 0) {
-        const int cut = S.cbin[(A - 1) * 17 + kl];                   // rows below: top bit of Lo clear
+        const int cut = SC3_CP(int32_t, S.cbin)[(A - 1) * 17 + kl];                   // rows below: top bit of Lo clear
         if (W & 1u) {                                                // the one comes down into Lo
           if (cut > 0) {
             act = 1; r0 = 0; r1 = cut; up = false;
-            delta = tb + S.icoff[kr * (w + 1) + cw - 1] + (int64_t)S.w_rank[W & ~1u] * S.pitch[kl + 1] +
-                    S.cbin[(A - 1) * 17 + kl + 1] - base;
+            delta = tb + SC3_CP(int64_t, S.icoff)[kr * (w + 1) + cw - 1] + (int64_t)SC3_CP(uint16_t, S.w_rank)[W & ~1u] * S.pitch[kl + 1] +
+                    SC3_CP(int32_t, S.cbin)[(A - 1) * 17 + kl + 1] - base;
           }
         } else if (cut < nrows) {                                    // the one goes up into W
           act = 1; r0 = cut; r1 = nrows; up = true;
-          delta = tb + S.icoff[kr * (w + 1) + cw + 1] + (int64_t)S.w_rank[W | 1u] * S.pitch[kl - 1] - cut - base;
+          delta = tb + SC3_CP(int64_t, S.icoff)[kr * (w + 1) + cw + 1] + (int64_t)SC3_CP(uint16_t, S.w_rank)[W | 1u] * S.pitch[kl - 1] - cut - base;
         }
       } else if (lane < w) {
         const int bw = lane - 1;
         const uint32_t pair = (W >> bw) & 3u;
         if (pair == 1u || pair == 2u) {
           act = 1; up = pair == 1u;
-          delta = ((int64_t)S.w_rank[W ^ (3u << bw)] - (int64_t)S.w_rank[W]) * p;
+          delta = ((int64_t)SC3_CP(uint16_t, S.w_rank)[W ^ (3u << bw)] - (int64_t)SC3_CP(uint16_t, S.w_rank)[W]) * p;
         }
       } else if (lane == w) {
         const uint32_t pair = ((W >> (w - 1)) & 1u) | ((T & 1u) << 1);
         if (pair == 1u) {
           act = 1; up = true;
-          delta = S.ibase[T | 1u] + S.icoff[(kr - 1) * (w + 1) + cw - 1] +
-                  (int64_t)S.w_rank[W & ~(1u << (w - 1))] * p - base;
+          delta = SC3_CP(int64_t, S.ibase)[T | 1u] + SC3_CP(int64_t, S.icoff)[(kr - 1) * (w + 1) + cw - 1] +
+                  (int64_t)SC3_CP(uint16_t, S.w_rank)[W & ~(1u << (w - 1))] * p - base;
         } else if (pair == 2u) {
           act = 1; up = false;
-          delta = S.ibase[T & ~1u] + S.icoff[(kr + 1) * (w + 1) + cw + 1] +
-                  (int64_t)S.w_rank[W | (1u << (w - 1))] * p - base;
+          delta = SC3_CP(int64_t, S.ibase)[T & ~1u] + SC3_CP(int64_t, S.icoff)[(kr + 1) * (w + 1) + cw + 1] +
+                  (int64_t)SC3_CP(uint16_t, S.w_rank)[W | (1u << (w - 1))] * p - base;
         }
       } else {
         const int bt = lane - w - 1;
         const uint32_t pair = (T >> bt) & 3u;
         if (pair == 1u || pair == 2u) {
           act = 1; up = pair == 1u;
-          delta = S.ibase[T ^ (3u << bt)] - tb;
+          delta = SC3_CP(int64_t, S.ibase)[T ^ (3u << bt)] - tb;
         }
       }
       if (act) {
-        c0 = O.bond[4 * b + (up ? 0 : 2)];
-        c1 = O.bond[4 * b + (up ? 1 : 3)];
+        c0 = SC3_CP(double, O.bond)[4 * b + (up ? 0 : 2)];
+        c1 = SC3_CP(double, O.bond)[4 * b + (up ? 1 : 3)];
       }
     }
   }
-  uint64_t hb = __ballot(act);
+  uint64_t hb = has_row ? __ballot(act) : 0ull;
 
   for (int tt = threadIdx.x; tt < A * (A + 1); tt += NT) {
     const int lo = tt / (A + 1), o = tt % (A + 1);
-    cl[tt] = S.cbin[lo * 17 + o];
+    cl[tt] = SC3_CP(int32_t, S.cbin)[lo * 17 + o];
   }
   // on-the-fly diagonal: what the row (T, W) contributes -- group 0 to every state of the row, groups 1..4 with the
   // sign of a Lo pattern.  The first wavefront evaluates the terms, one per lane, and leaves the sums in LDS; they
   // are applied after the barrier the tile needs anyway.
-  if (DIAGM == 2 && threadIdx.x < 64) {
+  if (DIAGM == 2 && tsub < 64) {
     const uint64_t hi = ((uint64_t)T << w) | W;
     double v0 = 0.0, vm[4] = {0.0, 0.0, 0.0, 0.0};
     for (int t0 = 0; t0 < O.ndt; t0 += 64) {
       const int t = t0 + lane;
       if (t < O.ndt) {
-        const uint64_t sg = O.dt_sign[t];                       // bits 61..63: the group
-        const double c = flip(O.dt_coef[t], (uint32_t)__popcll(hi & sg & 0x1fffffffffffffffull) & 1u);
+        const uint64_t sg = SC3_CP(uint64_t, O.dt_sign)[t];                       // bits 61..63: the group
+        const double c = flip(SC3_CP(double, O.dt_coef)[t], (uint32_t)__popcll(hi & sg & 0x1fffffffffffffffull) & 1u);
         const int g = (int)(sg >> 61);
         if (g == 0) v0 += c;
 #pragma unroll
@@ -202,18 +236,18 @@ sc3_lo_pass(const Sc3Tab S, const Sc3Op O, const uint32_t *__restrict__ perm, co
       }
     }
     v0 = wave_sum(v0);
-    if (lane == 0) dsh[0] = v0;
+    if (lane == 0) dsh[5 * sub] = v0;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       if (j < O.ngroups) {
         const double s = wave_sum(vm[j]);
-        if (lane == 0) dsh[j + 1] = s;
+        if (lane == 0) dsh[5 * sub + j + 1] = s;
       }
   }
   double accr[RPT], acci[RPT];
 #pragma unroll
   for (int i = 0; i < RPT; ++i) {
-    const int r = threadIdx.x + i * NT;
+    const int r = tsub + i * NTS;
     accr[i] = 0.0;
     acci[i] = 0.0;
     if (r < nrows) {
@@ -234,7 +268,7 @@ sc3_lo_pass(const Sc3Tab S, const Sc3Op O, const uint32_t *__restrict__ perm, co
     c128 v[RPT];
 #pragma unroll
     for (int i = 0; i < RPT; ++i) {
-      const int r = threadIdx.x + i * NT;
+      const int r = tsub + i * NTS;
       v[i] = make_double2(0.0, 0.0);
       if (r >= q0 && r < q1) v[i] = pp[r];
     }
@@ -254,29 +288,30 @@ sc3_lo_pass(const Sc3Tab S, const Sc3Op O, const uint32_t *__restrict__ perm, co
   if (ACC) {
 #pragma unroll
     for (int i = 0; i < RPT; ++i) {
-      const int r = threadIdx.x + i * NT;
+      const int r = tsub + i * NTS;
       yv[i] = make_double2(0.0, 0.0);
       if (r < nrows) yv[i] = load_nt(y + lbase + r);
     }
   }
   double dlv[RPT];
   if (DIAGM == 2) {          // the Lo-only part of the diagonal (L2-resident table), asked for before the barrier as well
-    const double *__restrict__ dl = O.dlo + S.lo_off[kl];
+    const auto dl = SC3_CP(double, O.dlo) + S.lo_off[kl];
 #pragma unroll
     for (int i = 0; i < RPT; ++i) {
-      const int r = threadIdx.x + i * NT;
+      const int r = tsub + i * NTS;
       dlv[i] = r < nrows ? dl[r] : 0.0;
     }
   }
   __syncthreads();
+  SC3_PRIO_LDS();
   if (DIAGM == 2) {
-    const double dg0 = dsh[0];
+    const double dg0 = dsh[5 * sub];
 #pragma unroll
     for (int i = 0; i < RPT; ++i) {
-      const int r = threadIdx.x + i * NT;
+      const int r = tsub + i * NTS;
       if (r < nrows) {
         double dg = dlv[i] + dg0;
-        for (int j = 0; j < O.ngroups; ++j) dg += flip(dsh[j + 1], (uint32_t)__popc(lowb[i] & O.glo[j]) & 1u);
+        for (int j = 0; j < O.ngroups; ++j) dg += flip(dsh[5 * sub + j + 1], (uint32_t)__popc(lowb[i] & O.glo[j]) & 1u);
         const c128 xo = xs[r];
         accr[i] = fma(dg, xo.x, accr[i]);
         acci[i] = fma(dg, xo.y, acci[i]);
@@ -288,10 +323,10 @@ sc3_lo_pass(const Sc3Tab S, const Sc3Op O, const uint32_t *__restrict__ perm, co
   // then reads LDS, profiles/r03_exp11_sc3_tables.txt: this pass is not bound by its instructions.)
   for (int lo = 0; lo < A - 1; ++lo) {
     if (!((O.present >> lo) & 1ull)) continue;
-    const double ure = O.bond[4 * lo], uim = O.bond[4 * lo + 1], dre = O.bond[4 * lo + 2], dim_ = O.bond[4 * lo + 3];
+    const double ure = SC3_CP(double, O.bond)[4 * lo], uim = SC3_CP(double, O.bond)[4 * lo + 1], dre = SC3_CP(double, O.bond)[4 * lo + 2], dim_ = SC3_CP(double, O.bond)[4 * lo + 3];
 #pragma unroll
     for (int i = 0; i < RPT; ++i) {
-      const int r = threadIdx.x + i * NT;
+      const int r = tsub + i * NTS;
       const uint32_t pair = (lowb[i] >> lo) & 3u;
       if (r < nrows && (pair == 1u || pair == 2u)) {
         const bool up = pair == 1u;
@@ -312,9 +347,10 @@ sc3_lo_pass(const Sc3Tab S, const Sc3Op O, const uint32_t *__restrict__ perm, co
     }
   }
   double dr = 0.0, di = 0.0, dn = 0.0;
+  SC3_PRIO_MEM();
 #pragma unroll
   for (int i = 0; i < RPT; ++i) {
-    const int r = threadIdx.x + i * NT;
+    const int r = tsub + i * NTS;
     if (r < p) {                                  // the padding of a row is written too (zeros)
       double ar = accr[i], ai = acci[i];
       if (r < nrows) {
@@ -379,7 +415,7 @@ sc3_win_pass(const Sc3Tab S, const Sc3Op O, const uint32_t *__restrict__ perm, c
   constexpr int RPT = (MAXE + NT - 1) / NT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   c128 *xs = reinterpret_cast<c128 *>(smem);       // the tile [wr][column], then one zero row (wr = nwp)
-  const uint32_t e = perm[blockIdx.x];
+  const uint32_t e = SC3_CP(uint32_t, perm)[blockIdx.x];
   if (e == 0xffffffffu) return;
   const int lane = threadIdx.x & 63;
   const uint32_t T = e >> 16;
@@ -389,17 +425,18 @@ sc3_win_pass(const Sc3Tab S, const Sc3Op O, const uint32_t *__restrict__ perm, c
   const int sh = 4 + S.rs[cw];
   const int lr0 = run << sh;
   const int ncols = min(1 << sh, p - lr0);
-  const int64_t tb = S.ibase[T];
-  const int64_t own = tb + S.icoff[kr * (WB + 1) + cw];
+  const int64_t tb = SC3_CP(int64_t, S.ibase)[T];
+  const int64_t own = tb + SC3_CP(int64_t, S.icoff)[kr * (WB + 1) + cw];
   const int64_t cbase = own + lr0;
   const int64_t lcb = cbase - C.row0;
   const int nent = nwp << sh;
   const c128 *__restrict__ x = xw - C.win_start;
 
+  SC3_PRIO_MEM();
   uint32_t wpat[RPT];
   int32_t off[RPT];          // offset of the entry from cbase, -1: not an entry
   c128 xv[RPT];
-  const uint16_t *__restrict__ pat = S.w_pat + S.w_off[cw];
+  const auto pat = SC3_CP(uint16_t, S.w_pat) + S.w_off[cw];
 #pragma unroll
   for (int i = 0; i < RPT; ++i) {
     const int en = threadIdx.x + i * NT;
@@ -424,28 +461,28 @@ sc3_win_pass(const Sc3Tab S, const Sc3Op O, const uint32_t *__restrict__ perm, c
     if (b < S.L - 1 && ((O.bondsB >> b) & 1ull)) {
       bool up = false;
       if (lane == 0) {
-        const int cut = S.cbin[(WB - 1) * 17 + cw];                // rows below: top bit of W clear
+        const int cut = SC3_CP(int32_t, S.cbin)[(WB - 1) * 17 + cw];                // rows below: top bit of W clear
         if (T & 1u) {                                              // the one comes down into W
           if (cut > 0) {
             act = 1; r0 = 0; r1 = cut; up = false;
-            delta = S.ibase[T & ~1u] + S.icoff[(kr + 1) * (WB + 1) + cw + 1] +
-                    (int64_t)S.cbin[(WB - 1) * 17 + cw + 1] * p - own;
+            delta = SC3_CP(int64_t, S.ibase)[T & ~1u] + SC3_CP(int64_t, S.icoff)[(kr + 1) * (WB + 1) + cw + 1] +
+                    (int64_t)SC3_CP(int32_t, S.cbin)[(WB - 1) * 17 + cw + 1] * p - own;
           }
         } else if (cut < nwp) {                                    // the one goes up into T
           act = 1; r0 = cut; r1 = nwp; up = true;
-          delta = S.ibase[T | 1u] + S.icoff[(kr - 1) * (WB + 1) + cw - 1] - (int64_t)cut * p - own;
+          delta = SC3_CP(int64_t, S.ibase)[T | 1u] + SC3_CP(int64_t, S.icoff)[(kr - 1) * (WB + 1) + cw - 1] - (int64_t)cut * p - own;
         }
       } else {
         const int bt = lane - 1;
         const uint32_t pair = (T >> bt) & 3u;
         if (pair == 1u || pair == 2u) {
           act = 1; up = pair == 1u;
-          delta = S.ibase[T ^ (3u << bt)] - tb;
+          delta = SC3_CP(int64_t, S.ibase)[T ^ (3u << bt)] - tb;
         }
       }
       if (act) {
-        c0 = O.bond[4 * b + (up ? 0 : 2)];
-        c1 = O.bond[4 * b + (up ? 1 : 3)];
+        c0 = SC3_CP(double, O.bond)[4 * b + (up ? 0 : 2)];
+        c1 = SC3_CP(double, O.bond)[4 * b + (up ? 1 : 3)];
       }
     }
   }
@@ -501,6 +538,7 @@ sc3_win_pass(const Sc3Tab S, const Sc3Op O, const uint32_t *__restrict__ perm, c
     }
   }
   __syncthreads();
+  SC3_PRIO_LDS();
   // bonds inside W: the partner row of (row, bond) from the layout's table (Sc3Tab::w_nb) -- a row whose two spins are
   // equal points at the zero row behind the tile, so the loop has no branches
   {
@@ -524,7 +562,7 @@ sc3_win_pass(const Sc3Tab S, const Sc3Op O, const uint32_t *__restrict__ perm, c
     for (int lo = 0; lo < WB - 1; ++lo) {
       const int b = S.a + lo;
       if (!((O.present >> b) & 1ull)) continue;
-      const double ure = O.bond[4 * b], uim = O.bond[4 * b + 1], dre = O.bond[4 * b + 2], dim_ = O.bond[4 * b + 3];
+      const double ure = SC3_CP(double, O.bond)[4 * b], uim = SC3_CP(double, O.bond)[4 * b + 1], dre = SC3_CP(double, O.bond)[4 * b + 2], dim_ = SC3_CP(double, O.bond)[4 * b + 3];
 #pragma unroll
       for (int i = 0; i < RPT; ++i) {
         const uint32_t pr = (uint32_t)((lo < 8 ? t0[i] : t1[i]) >> (8 * (lo & 7))) & 0xffu;
@@ -543,6 +581,7 @@ sc3_win_pass(const Sc3Tab S, const Sc3Op O, const uint32_t *__restrict__ perm, c
       }
     }
   }
+  SC3_PRIO_MEM();
 #pragma unroll
   for (int i = 0; i < RPT; ++i)
     if (off[i] >= 0) {
@@ -899,6 +938,51 @@ static std::vector<uint32_t> deal(const std::vector<std::vector<uint32_t>> &grou
   return out;
 }
 
+// lo pass: rows -> workgroups.  `order` is the dispatch order of the rows (8 interleaved XCD streams, 0xffffffff =
+// padding); inside a stream rows are packed, in that order, 2^m to a workgroup where 2^m rows of their length fit the
+// NT * RPT entries a workgroup's threads hold (sub-groups of whole wavefronts, m <= 3).  Rows that follow each other in
+// a stream are the same (cw, wr) over the T's of a popcount class, so a workgroup's rows have equal lengths and its
+// place in the stream stays next to the boundary-bond partners of its rows.  Returns 8 entries per workgroup, the
+// workgroups of the streams interleaved again.
+static std::vector<uint32_t> pack_lo_rows(const std::vector<uint32_t> &order, const Sc3Layout &ly, int nt) {
+  const Sc3Tab &S = ly.host;
+  const int cap = sc3_lo_cap(S.a, nt);
+  int maxm = 0;
+  while (maxm < 3 && (nt >> (maxm + 1)) >= 64) ++maxm;
+  auto logm_of = [&](uint32_t e) {
+    const uint32_t T = e >> S.w, W = e & ((1u << S.w) - 1u);
+    const int kl = S.k - __builtin_popcount(T) - __builtin_popcount(W);
+    int m = 0;
+    while (m < maxm && S.nl[kl] <= (cap >> (m + 1))) ++m;
+    return m;
+  };
+  std::vector<std::vector<uint32_t>> wgs(8);        // per stream: 8 entries per workgroup
+  for (int s = 0; s < 8; ++s) {
+    std::vector<uint32_t> open[4];                  // rows waiting for their workgroup to fill, by m
+    auto flush = [&](int m) {
+      if (open[m].empty()) return;
+      for (int j = 0; j < 8; ++j)
+        wgs[s].push_back(j < (int)open[m].size() ? (open[m][j] | ((uint32_t)m << 30)) : (SC3_NOROW | ((uint32_t)m << 30)));
+      open[m].clear();
+    };
+    for (size_t i = s; i < order.size(); i += 8) {
+      const uint32_t e = order[i];
+      if (e == 0xffffffffu) continue;
+      const int m = logm_of(e);
+      open[m].push_back(e);
+      if ((int)open[m].size() == (1 << m)) flush(m);
+    }
+    for (int m = 0; m < 4; ++m) flush(m);
+  }
+  size_t n = 0;
+  for (auto &v : wgs) n = std::max(n, v.size() / 8);
+  std::vector<uint32_t> out(8 * 8 * n, 0xffffffffu);
+  for (int s = 0; s < 8; ++s)
+    for (size_t i = 0; i < wgs[s].size() / 8; ++i)
+      for (int j = 0; j < 8; ++j) out[8 * (8 * i + s) + j] = wgs[s][8 * i + j];
+  return out;
+}
+
 bool sc3_instance(int a, int w) { return (a == 14 && w == 10) || (a == 6 && w == 4); }
 
 Sc3Mat::~Sc3Mat() {
@@ -1080,7 +1164,7 @@ int Sc3Mat::init(const Sc3Layout *layout, const std::vector<int64_t> &masks, con
       }
     }
   }
-  permA = deal(gA);
+  permA = pack_lo_rows(deal(gA), *ly, a == 14 ? 1024 : 256);       // thread counts of launch_sc3's instances
   permB = deal(gB);
   if (permA.empty()) permA.assign(8, 0xffffffffu);
   if (permB.empty()) permB.assign(8, 0xffffffffu);
@@ -1104,7 +1188,7 @@ static int launch_two_pass(const Sc3Mat &M, const Sc3Call &call, const double *c
                            hipStream_t st, int phase) {
   const Sc3Tab &S = M.ly->dev;
   // LDS: the lo pass's row; the window pass's tile plus its zero row (largest over the classes)
-  constexpr size_t ldsA = (size_t)cbinom(A, A / 2) * 16;
+  constexpr size_t ldsA = (size_t)sc3_lo_cap(A, NT) * 16;
   size_t ldsB = 0;
   for (int cw = 0; cw <= W; ++cw)      // ... and the class's partner table
     ldsB = std::max(ldsB, (((size_t)M.ly->host.nw[cw] + 1) << (4 + M.ly->host.rs[cw] + 4)) + (size_t)M.ly->host.nw[cw] * 16);
@@ -1141,28 +1225,31 @@ static int launch_two_pass(const Sc3Mat &M, const Sc3Call &call, const double *c
     hipLaunchKernelGGL(kB, dim3((unsigned)M.permB.size()), dim3(NTW), ldsB, st, S, op, (const uint32_t *)M.d_permB,
                        phase == 0 ? first : second, (const c128 *)xw, (c128 *)y);
   if (phase == 0 || phase == 1)
-    hipLaunchKernelGGL(kA, dim3((unsigned)M.permA.size()), dim3(NT), ldsA, st, S, op, (const uint32_t *)M.d_permA,
+    hipLaunchKernelGGL(kA, dim3((unsigned)(M.permA.size() / 8)), dim3(NT), ldsA, st, S, op, (const uint32_t *)M.d_permA,
                        phase == 0 ? second : first, (const c128 *)xw, (c128 *)y);
   DNM_HIP(hipGetLastError());
   return 0;
 }
 
-size_t sc3_dot_partials(const Sc3Mat &M) { return M.permA.size(); }
+size_t sc3_dot_partials(const Sc3Mat &M) { return M.permA.size() / 8; }
 
 int launch_sc3(const Sc3Mat &M, const DevMsc &msc, const Sc3Call &call, const double *cached_diag, const void *xw,
                void *y, hipStream_t st, int phase) {
   DNM_CHECK(M.ly && M.ly->on_device, "layout tables are not on the device");
   DNM_CHECK(phase == 0 || (M.tiled && !call.dot_out), "internal: only the tiled passes split into a local and a remote part");
   if (M.tiled) {
-    if (call.dot_out) DNM_HIP(hipMemsetAsync(call.dot_out, 0, M.permA.size() * 3 * sizeof(double), st));
+    if (call.dot_out) DNM_HIP(hipMemsetAsync(call.dot_out, 0, sc3_dot_partials(M) * 3 * sizeof(double), st));
     if (M.ly->host.a == 14) {
       static const bool w1024 = [] { const char *e = knob("DNM_SC3_WIN_THREADS"); return e && atoi(e) == 1024; }();   // experiments
       if (w1024) return launch_two_pass<14, 10, 1024, 1024>(M, call, cached_diag, xw, y, st, phase);
       return launch_two_pass<14, 10, 1024, 512>(M, call, cached_diag, xw, y, st, phase);
     }
-    return launch_two_pass<6, 4, 64, 64>(M, call, cached_diag, xw, y, st, phase);
+    // (256 threads for rows of at most 20 states: the small instance runs four rows per workgroup, so that the tests
+    // at L = 11...24 cover the sub-group form of the lo pass)
+    return launch_two_pass<6, 4, 256, 64>(M, call, cached_diag, xw, y, st, phase);
   }
   DNM_CHECK(!call.dot_out, "internal: the row kernel has no fused sums");
+  if (M.rowsel.empty()) return 0;      // a rank that owns no rows
   hipLaunchKernelGGL(sc3_row_kernel, dim3((unsigned)M.rowsel.size()), dim3(SC3_ROW_NT), 0, st, M.ly->dev, msc,
                      (const uint32_t *)M.d_rowsel, call, cached_diag, (const c128 *)xw, (c128 *)y);
   DNM_HIP(hipGetLastError());

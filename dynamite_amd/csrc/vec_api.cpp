@@ -182,11 +182,12 @@ int dnm_vec_layout_copy_f64(const dnm_subspace *s, const dnm_partition *part, do
 }
 
 int dnm_vec_layout_zero_padding(const dnm_subspace *s, const dnm_partition *part, void *x, void *stream) {
-  DNM_CHECK(x, "null vector");
   const Sc3Layout *ly = layout_of(s, true);
   if (!ly) return 1;
   uint32_t T0, T1;
   DNM_TRY(part_range(*ly, part, &T0, &T1));
+  if (T0 >= T1) return 0;          // a rank that owns no block (an empty tensor has a null data pointer)
+  DNM_CHECK(x, "null vector");
   return sc3_zero_padding(*ly, x, S(stream), T0, T1);
 }
 
@@ -223,11 +224,12 @@ int dnm_vec_layout_positions_host(const dnm_subspace *s, const dnm_partition *pa
 }
 
 int dnm_vec_layout_set_random(const dnm_subspace *s, const dnm_partition *part, void *x, uint64_t seed, void *stream) {
-  DNM_CHECK(x, "null vector");
   const Sc3Layout *ly = layout_of(s, true);
   if (!ly) return 1;
   uint32_t T0, T1;
   DNM_TRY(part_range(*ly, part, &T0, &T1));
+  if (T0 >= T1) return 0;          // a rank that owns no block
+  DNM_CHECK(x, "null vector");
   return sc3_random(*ly, x, seed, S(stream), T0, T1);
 }
 

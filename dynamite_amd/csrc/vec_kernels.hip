@@ -29,7 +29,9 @@ constexpr int VNT = 256;
 // grid-stride loop over 2048 workgroups (5.3 over 65536); a read-only reduction reaches its 7.0-7.1 TB/s from 8192
 // workgroups on.  So: the streaming kernels get one workgroup per 256 elements (their loops run once), the multi-dot
 // 16384 workgroups, and the fused Lanczos sweeps one element per thread with a two-level sum of their partials.
-constexpr int64_t VMAX_BLOCKS = (int64_t)1 << 31;       // grid-stride loops only beyond 2^39 elements
+// (HIP rejects launches of 2^32 or more threads per grid dimension: the cap keeps gridDim.x * VNT below that, the
+// grid-stride loops take over from 2^32 - VNT elements -- a 64 GiB local vector -- on)
+constexpr int64_t VMAX_BLOCKS = (((int64_t)1 << 32) - 1) / VNT + 1;
 constexpr int64_t VRED_BLOCKS = 16384;                  // multi-dot: partials are 2 * nv doubles per workgroup
 constexpr int VRED2 = 1024;                             // second-level partial sums of the one-element-per-thread sweeps
 

@@ -283,7 +283,9 @@ class SpinConserve(Subspace):
     def vec_swizzle(self):
         """Layout of this subspace's state vectors (dnm_subspace.vec_swizzle): a | w << 8 for the three-field
         internal layout of csrc/sc3.h (large subspaces; partitions give whole blocks of equal top bits to a rank),
-        0 for the reference's index order."""
+        0 for the reference's index order.  On several ranks the internal layout is taken only where its partition
+        is usable (``layout_usable``): otherwise the vectors stay in reference order, split like PETSc splits them, and
+        the window kernels run."""
         from .config import config
         lay = config.sc_layout
         if not lay or self.L is None:
@@ -291,7 +293,38 @@ class SpinConserve(Subspace):
         a, w = lay
         if self.L - a - w < 1 or math.comb(self.L, self.k) < config.sc_layout_min_dim:
             return 0
+        if not self.layout_usable(a, w, config.world_size):
+            return 0
         return a | (w << 8)
+
+    # a rank of a partitioned internal layout owns whole blocks of equal top bits T (2^(L - a - w) of them, of very
+    # different sizes): with few blocks per rank some ranks get nothing or twice the mean
+    LAYOUT_MAX_IMBALANCE = 1.10
+
+    def layout_usable(self, a, w, nranks):
+        """Can ``nranks`` ranks share this subspace in the (a, w) internal layout?  One rank: always.  Several: every
+        rank must own rows and the largest share may exceed the mean by at most LAYOUT_MAX_IMBALANCE (L=26, k=13 on 4
+        ranks would leave a rank empty and give another twice the mean; L=36, k=18 on 8 ranks is balanced to
+        0.24 %).  Decided from the host tables of dnm_vec_layout_partition; the same on every rank."""
+        if nranks <= 1:
+            return True
+        key = (self.L, self.k, a, w, nranks)
+        hit = _LAYOUT_USABLE.get(key)
+        if hit is None:
+            from . import backend
+            d = _lib.Subspace()
+            d.type, d.L, d.k = SPIN_CONSERVE, self.L, self.k
+            d.ld_nchoosek = self.L + 1
+            d.nchoosek = _lib.p64(self._nchoosek)
+            d.vec_swizzle = a | (w << 8)
+            rows = [backend.layout_partition(d, nranks, q)[3] for q in range(nranks)]
+            mean = sum(rows) / float(nranks)
+            hit = min(rows) > 0 and max(rows) <= self.LAYOUT_MAX_IMBALANCE * mean
+            _LAYOUT_USABLE[key] = hit
+        return hit
+
+
+_LAYOUT_USABLE = {}
 
 
 class Explicit(Subspace):

@@ -147,3 +147,54 @@ def test_window_exchange_gloo(tmp_path):
     import torch.multiprocessing as mp
     mp.spawn(_window_worker, args=(3, _free_port(), str(tmp_path)), nprocs=3, join=True)
     assert float(open(tmp_path / "ok.txt").read()) == 1.0
+
+
+def _redistribute_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dynamite_amd import backend
+    from dynamite_amd.subspaces import SpinConserve
+    ok = True
+    # the two partitions a SpinConserve vector in the internal layout and its reference-order copy have on several
+    # ranks: whole top-bit blocks (dnm_vec_layout_partition) against PetscSplitOwnership -- L=14, k=6, (a, w) = (6, 4)
+    sub = SpinConserve(14, 6)
+    d = sub._c()
+    d.vec_swizzle = 6 | (4 << 8)
+    n = sub.get_dimension()
+    lay = [backend.layout_partition(d, world, q)[2:4] for q in range(world)]
+    ref = [backend.split_ownership(n, world, q) for q in range(world)]
+    assert sum(c for _, c in lay) == n and lay != ref
+    xg = torch.arange(n, dtype=torch.float64).to(torch.complex128) * (1 - 3j)
+    s, c = lay[rank]
+    there = backend.redistribute(xg[s:s + c].clone(), lay, ref, rank)
+    s2, c2 = ref[rank]
+    ok = ok and torch.equal(there, xg[s2:s2 + c2])
+    back = backend.redistribute(there, ref, lay, rank)
+    ok = ok and torch.equal(back, xg[s:s + c])
+    # a partition with an empty rank and one with everything on one rank
+    odd = [(0, 0), (0, n - 5), (n - 5, 5)][:world] if world == 3 else [(0, n)] + [(n, 0)] * (world - 1)
+    s3, c3 = odd[rank]
+    got = backend.redistribute(xg[s2:s2 + c2].clone(), ref, odd, rank)
+    ok = ok and torch.equal(got, xg[s3:s3 + c3])
+    try:
+        backend.redistribute(xg[:3], lay, ref, rank)
+        ok = False
+    except ValueError:
+        pass
+    flag = torch.tensor([1.0 if ok else 0.0])
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        open(os.path.join(out_dir, "ok_redist.txt"), "w").write(str(flag.item()))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_redistribute_between_partitions_gloo(tmp_path, world):
+    """backend.redistribute: a vector moves between the internal layout's partition and the reference-order one
+    (what ShellMat._mult_converted does on several ranks), and through partitions with empty ranks."""
+    import torch.multiprocessing as mp
+    mp.spawn(_redistribute_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert float(open(tmp_path / "ok_redist.txt").read()) == 1.0

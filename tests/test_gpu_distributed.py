@@ -335,3 +335,27 @@ def test_rccl_transport_when_several_gpus(tmp_path):
     world = 2 if n < 4 else 4
     mp.spawn(_rccl_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     assert os.path.exists(os.path.join(str(tmp_path), "ok_rccl_%d" % world))
+
+
+def test_rccl_transport_world_one():
+    """First execution of the unstaged (device-to-device, RCCL) branch of dynamite_amd/_comm.py on a one-GPU box: a
+    process group of world size 1 over the "nccl" backend whose only peer is the rank itself -- isend + irecv of
+    complex128 device slices in one batch, the message lists of real partner / transposed plans, all_gather, reduce,
+    and the solver hooks' all-reduces (tests/rccl_self_child.py, started as a fresh process).  If RCCL refuses a send
+    to the sending rank, the collectives and the hooks must still have run and the test is skipped with RCCL's
+    message.  Replaces bcuda_template_2.cu:161-171."""
+    import json
+    import subprocess
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rccl_self_child.py")], env=env, cwd=ROOT,
+                         capture_output=True, text=True, timeout=400)
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert out.returncode in (0, 77) and lines, "rc %d\n%s\n%s" % (out.returncode, out.stdout[-1500:], out.stderr[-3000:])
+    rep = json.loads(lines[-1])
+    assert rep["backend"] == "nccl" and rep["stage"].endswith("D") and rep["hook_allreduces"] > 0, rep
+    if out.returncode == 77:
+        assert rep["stage"] in ("AD", "BD"), rep
+        pytest.skip("RCCL refused a send to the sending rank: " + str(rep["refused"]))
+    assert rep["stage"] == "CD" and rep["refused"] is None, rep

@@ -425,6 +425,110 @@ def test_full_size_default_plan(monkeypatch, L):
     mat.destroy(); mat2.destroy()
 
 
+PLAN_KNOBS = ("DNM_TILE_BITS", "DNM_LOG_ROWS", "DNM_PLAN_MODE", "DNM_AMIN", "DNM_GBITS", "DNM_WINDOW_FIRST",
+              "DNM_DIAG_PASS", "DNM_GBITS_WINDOW", "DNM_CACHE_POLICY", "DNM_SC_BLOCK", "DNM_SC_LAYOUT", "DNM_SWZ")
+
+DEFAULT_PLAN_CASES = [(name, L) for L in (13, 16, 18, 20, 22, 24, 25) for name in ("mbl", "xxz", "heisenberg")] + \
+                     [("long_range", 13), ("long_range", 16), ("long_range", 18), ("long_range", 20), ("syk", 12)]
+
+
+@pytest.mark.default_layout
+@pytest.mark.parametrize("name,L", DEFAULT_PLAN_CASES)
+def test_default_plan_vs_oracle(monkeypatch, name, L):
+    """The plan the production planner picks -- no DNM_* knob, production vector layout -- element-wise against the
+    oracle at the sizes between the knob-driven tests (<= 2^20) and the full-size property tests (2^26, 2^30): the
+    planner changes shape with the size (one pass up to 2^18; a second, window pass from 2^19; the window pass first
+    from 2^25 on; group bits) and every one of those decisions is pinned here.  The reference tests every size the
+    same way (tests/integration/test_multiply.py:85-106)."""
+    for k in PLAN_KNOBS:
+        monkeypatch.delenv(k, raising=False)
+    H = models.BY_NAME[name](L)
+    arrs = marshal(H)
+    sub = Full(L=L)
+    assert sub.vec_swizzle == 16
+    n = 1 << L
+    x = rand_state(n, seed=100 + L)
+    ref = orc.matvec(orc_msc(H), orc_sub(sub), orc_sub(sub), x, nthreads=min(16, orc.max_threads()))
+    mat = shell(H, sub)
+    d = mat.describe()
+    lines = d.splitlines()
+    if name == "syk":           # 2^12 amplitudes, 1820 four-Majorana strings: one tile, every mask inside it
+        assert "tiled=1" in d and len(lines) == 2, d
+    else:
+        assert "tiled=1" in d and "mode=2" in d and "B=12 logR=2" in d, d
+    # where DESIGN.md section 4.1 says the plan changes shape
+    if name not in ("syk", "long_range"):
+        if L <= 18:
+            assert len(lines) == 2 and "segs [0,12)" in lines[1], d
+        elif L < 25:
+            assert len(lines) == 3 and "segs [0,12)" in lines[1] and "segs [0,4) [%d,%d)" % (L - 8, L) in lines[2], d
+            assert "acc=0" in lines[1] and "acc=1" in lines[2], d
+        else:
+            assert len(lines) == 3 and "segs [0,4) [17,25)" in lines[1] and "segs [0,12)" in lines[2], d
+            assert "acc=0" in lines[1] and "acc=1" in lines[2] and "diag=1" in lines[2], d
+    xv, yv = mat.createVecs()
+    assert xv.swz == 16
+    xv.set_local_from_numpy(x)
+    yv.set(777.0)
+    mat.mult(xv, yv)
+    y = yv.local_numpy()
+    assert np.max(np.abs(y - ref)) <= tol_for(arrs, x), d
+    # the fused <x, y> of the same plan (what the Krylov loops call)
+    import ctypes as C
+    dd = (C.c_double * 2)()
+    _lib.check(_lib.lib().dnm_mat_mult_dot(mat.handle, xv.ptr, yv.ptr, dd, None))
+    want = np.vdot(x, ref)
+    assert abs(complex(dd[0], dd[1]) - want) <= 1e-11 * max(1.0, abs(want)) * L
+    assert np.max(np.abs(yv.local_numpy() - ref)) <= tol_for(arrs, x)
+    mat.destroy()
+
+
+@pytest.mark.default_layout
+@pytest.mark.parametrize("L", [17, 21, 25])
+def test_default_plan_parity_vs_oracle(monkeypatch, L):
+    """Parity subspaces (an (L-1)-bit hypercube on the same tiled kernel) under the production planner."""
+    for k in PLAN_KNOBS:
+        monkeypatch.delenv(k, raising=False)
+    H = models.ising(L)
+    arrs = marshal(H)
+    for space in (0, 1):
+        sub = Parity(space, L=L)
+        n = sub.get_dimension()
+        x = rand_state(n, seed=200 + L + space)
+        ref = orc.matvec(orc_msc(H), orc_sub(sub), orc_sub(sub), x, nthreads=min(16, orc.max_threads()))
+        mat = shell(H, sub)
+        assert "tiled=1" in mat.describe() and "n=%d" % (L - 1) in mat.describe()
+        y = mult_numpy(mat, x)
+        assert np.max(np.abs(y - ref)) <= tol_for(arrs, x), mat.describe()
+        mat.destroy()
+
+
+@pytest.mark.default_layout
+@pytest.mark.parametrize("L,k,internal", [(24, 12, False), (25, 12, True), (26, 13, True), (25, 9, False)])
+def test_default_spinconserve_vs_oracle(monkeypatch, L, k, internal):
+    """SpinConserve under the production configuration on both sides of the 2^22-state threshold of the internal
+    three-field layout (config.sc_layout_min_dim): reference order and the row / block kernels below it, the (14, 10)
+    layout and the two-pass kernels above -- element-wise against the oracle in reference order."""
+    for kk in PLAN_KNOBS:
+        monkeypatch.delenv(kk, raising=False)
+    sub = SpinConserve(L, k)
+    n = sub.get_dimension()
+    assert (n >= 1 << 22) == internal
+    assert (sub.vec_swizzle >= 256) == internal
+    H = models.mbl(L)
+    arrs = marshal(H)
+    x = rand_state(n, seed=300 + L)
+    ref = orc.matvec(orc_msc(H), orc_sub(sub), orc_sub(sub), x, nthreads=min(16, orc.max_threads()))
+    mat = shell(H, sub)
+    xv, yv = mat.createVecs()
+    assert xv.internal == internal
+    xv.set_local_from_numpy(x)
+    yv.set(777.0)
+    mat.mult(xv, yv)
+    assert np.max(np.abs(yv.local_numpy() - ref)) <= tol_for(arrs, x), (L, k)
+    mat.destroy()
+
+
 def test_spinconserve_large_properties():
     """SpinConserve L=28, k=14 (40 M amplitudes): the incremental-rank kernel against the generic
     row-gather kernel element-wise, with and without the cached diagonal, and Hermiticity."""
@@ -465,7 +569,7 @@ def _random_hermitian(L, nterms, rs):
     return H
 
 
-@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("DNM_FUZZ_N", "8"))))
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("DNM_FUZZ_N", "64"))))
 def test_fuzz_random_operators(monkeypatch, seed):
     """Random Pauli-string Hamiltonians (long strings, imaginary matrix elements, many terms per mask,
     masks straddling tile / group / window boundaries) on random subspaces, tile shapes and plan modes,

@@ -307,7 +307,7 @@ def _random_chain(L, rs):
     return H
 
 
-@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("DNM_SC3_FUZZ_N", "12"))))
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("DNM_SC3_FUZZ_N", "64"))))
 def test_fuzz_internal_layout(small_layout, seed):
     """Random chains (two tiled passes) and random Pauli-string sums (row kernel) on random SpinConserve sectors in the
     internal layout, against the oracle."""

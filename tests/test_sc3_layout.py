@@ -115,3 +115,28 @@ def test_config5_plan_on_the_host():
         assert lo.value <= row0.value and hi.value >= row0.value + ml.value - 1
         assert hi.value - lo.value + 1 <= nint.value
         _lib.check(_lib.lib().dnm_mat_destroy(h))
+
+
+def test_layout_choice_depends_on_rank_count():
+    """The internal layout hands whole top-bit blocks to a rank, 2^(L - 24) of them under (14, 10): it is taken on
+    several ranks only where no rank stays empty and the largest share is within 10 % of the mean
+    (SpinConserve.layout_usable); elsewhere vectors stay in reference order, split as PETSc splits them."""
+    from dynamite_amd.subspaces import SpinConserve
+    from dynamite_amd import backend, _lib
+    import dynamite_amd.subspaces as S
+    usable = {(26, 13, 4): False, (26, 13, 8): False, (27, 13, 8): False, (28, 14, 8): False, (28, 14, 2): True,
+              (32, 16, 8): True, (34, 17, 8): True, (36, 18, 8): True, (36, 18, 4): True, (30, 15, 4): True,
+              (26, 13, 1): True}
+    for (L, k, P), want in usable.items():
+        sub = SpinConserve(L, k)
+        assert sub.layout_usable(14, 10, P) == want, (L, k, P)
+        if P > 1:
+            d = _lib.Subspace()
+            d.type, d.L, d.k, d.ld_nchoosek = S.SPIN_CONSERVE, L, k, L + 1
+            d.nchoosek = _lib.p64(sub._nchoosek)
+            d.vec_swizzle = 14 | (10 << 8)
+            rows = [backend.layout_partition(d, P, q)[3] for q in range(P)]
+            assert sum(rows) == sub.get_dimension()
+            assert want == (min(rows) > 0 and max(rows) <= 1.10 * sum(rows) / P)
+    # one rank: the production choice is the internal layout from 2^22 states on
+    assert SpinConserve(26, 13).vec_swizzle == (14 | (10 << 8)) and SpinConserve(24, 12).vec_swizzle == 0

@@ -2,7 +2,7 @@
 # usage: tools/pmc_cmd.sh KERNEL_SUBSTR 'CTR ...' -- cmd...   prints the last dispatch of the matching kernel
 set -u
 K=$1; CTRS=$2; shift 3
-cd "${GRAFT_REPO_ROOT:-.}"; export TMPDIR=/tmp
+cd "${GRAFT_REPO_ROOT:-.}"; export TMPDIR=/tmp; export DNM_EXPERIMENTAL=1
 rm -rf /tmp/pmc_cmd; rocprofv3 --pmc $CTRS -d /tmp/pmc_cmd -o p -- "$@" > /tmp/pmc_cmd.txt 2>&1
 python3 - "$K" <<'PY'
 import sqlite3, sys, glob

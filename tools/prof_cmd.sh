@@ -2,7 +2,7 @@
 # usage: tools/prof_cmd.sh OUTFILE cmd...   kernel-trace stats of an arbitrary command (top kernels by total time)
 set -u
 OUTF=$1; shift
-cd "${GRAFT_REPO_ROOT:-.}"; export TMPDIR=/tmp
+cd "${GRAFT_REPO_ROOT:-.}"; export TMPDIR=/tmp; export DNM_EXPERIMENTAL=1
 rm -rf /tmp/rp_cmd
 rocprofv3 --kernel-trace --stats -f csv -d /tmp/rp_cmd -o t -- "$@" > /tmp/rp_cmd.log 2>&1
 grep -v "rocprofv3\|amdgpu.ids" /tmp/rp_cmd.log | tail -3 > $OUTF

@@ -2,7 +2,7 @@
 # usage: tools/prof_multi.sh L 'cfgjson' ['ENV=V ...'] ... : for each config prints per-pass ms, FETCH (x2 corrected) and WRITE bytes per amplitude
 set -u
 L=$1; shift
-cd "${GRAFT_REPO_ROOT:-.}"; export TMPDIR=/tmp
+cd "${GRAFT_REPO_ROOT:-.}"; export TMPDIR=/tmp; export DNM_EXPERIMENTAL=1
 i=0
 for CFG in "$@"; do
   i=$((i+1))

@@ -2,7 +2,7 @@
 # usage: tools/prof_pmc.sh L 'cfgjson' 'CTR CTR ...' ['CTR ...' ...] : one rocprofv3 --pmc pass per counter group; prints last tile_pass dispatches
 set -u
 L=$1; CFG=$2; shift 2
-cd "${GRAFT_REPO_ROOT:-.}"; export TMPDIR=/tmp
+cd "${GRAFT_REPO_ROOT:-.}"; export TMPDIR=/tmp; export DNM_EXPERIMENTAL=1
 ENVS=$(python3 -c "import json,sys; c=json.loads(sys.argv[1]); print(' '.join('%s=%s'%(k,v) for k,v in c.get('env',{}).items()))" "$CFG")
 export SWEEP="[$CFG]"
 echo "== $CFG"

@@ -7,7 +7,7 @@
 set -u
 cd "${GRAFT_REPO_ROOT:-.}"; export TMPDIR=/tmp
 OUT=gpurun_out/profiles; rm -rf $OUT; mkdir -p $OUT
-CMD="python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline"
+CMD="python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-secondary"
 rocprofv3 --kernel-trace --stats -f csv -d /tmp/rp_trace -o t -- $CMD > $OUT/bench_line.json 2> $OUT/bench_stderr.txt
 find /tmp/rp_trace -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
 TR=$(find /tmp/rp_trace -name "*kernel_trace.csv" | head -1)
