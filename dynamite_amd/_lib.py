@@ -77,6 +77,7 @@ class Xfer(C.Structure):
 
 
 MAT_DEFAULT, MAT_FORCE_GATHER, MAT_USE_GLDS, MAT_HOST_ONLY = 0, 1, 2, 4
+MAT_REAL_PACKED = 16      # real arithmetic for a real-symmetric operator: vectors of dim / 2 elements, two amplitudes each
 MAT_AMIN_SHIFT = 8        # flags bits 8..15: log2 of the contiguous run of a window tile
 WHICH = {"lowest": 0, "highest": 1, "exterior": 2}
 CONVERGED_TOL, CONVERGED_ITS, DIVERGED_ITS, DIVERGED_BREAKDOWN, DIVERGED_SYMMETRY_LOST = 1, 2, -1, -2, -3
@@ -103,6 +104,7 @@ SIGNATURES = {
     "dnm_reduced_density_matrix": (C.c_int, [vp, C.POINTER(Subspace), C.c_int, i64p, vp, vp]),
     "dnm_vec_set_random_swz": (C.c_int, [vp, C.c_int64, C.c_uint64, C.c_int64, C.c_int, vp]),
     "dnm_vec_swizzle_copy": (C.c_int, [vp, vp, C.c_int64, C.c_int, vp]),
+    "dnm_vec_unpack_real": (C.c_int, [vp, vp, C.c_int64, C.c_int, C.c_int, vp]),
     "dnm_vec_layout_size": (C.c_int, [C.POINTER(Subspace), C.POINTER(C.c_int64)]),
     "dnm_vec_layout_partition": (C.c_int, [C.POINTER(Subspace), C.c_int, C.c_int, i64p, i64p, i64p, i64p]),
     "dnm_vec_layout_copy": (C.c_int, [C.POINTER(Subspace), C.POINTER(Partition), vp, vp, C.c_int, vp]),

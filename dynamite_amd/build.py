@@ -40,6 +40,10 @@ def build(force=False, verbose=False):
         return LIB
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
+    # objects of sources that have left the library (they would ship to the GPU box with the snapshot)
+    for f in os.listdir(objdir):
+        if f.endswith(".o") and f[:-2] not in SOURCES:
+            os.remove(os.path.join(objdir, f))
     flags = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
     flags += os.environ.get("DNM_HIPCC_EXTRA", "").split()        # experiments (scheduler options ...)
     procs = []

@@ -208,6 +208,23 @@ def eigsolve(H, getvecs=False, nev=1, which='lowest', target=None, tol=None, sub
         raise ValueError(f'invalid value "{which}" for which')
 
     mat = H.get_mat(subspaces=(subspace, subspace))
+    # A real-symmetric operator (Heisenberg, XXZ, Ising, random-field chains: every matrix element real in the
+    # product basis) needs no complex arithmetic for its eigenpairs: on one rank, from 2^23 amplitudes on, the solver
+    # runs on real vectors stored two amplitudes to a complex128 element (DNM_MAT_REAL_PACKED) -- half the bytes per
+    # multiply and per Krylov vector, twice the basis in the same memory -- and the eigenvectors are handed back as
+    # the complex states the reference returns.  config.eigs_real_arithmetic (DNM_EIGS_REAL=0 / 1 in tests) forces the choice.
+    cmat = mat
+    er = knob('DNM_EIGS_REAL')
+    want_real = config.eigs_real_arithmetic
+    if er:
+        want_real = er[:1] == '1'
+    if want_real is None:
+        want_real = mat.n_local >= (1 << 23)
+    if config.world_size == 1 and want_real:
+        pm = H.get_real_packed_mat(subspace)
+        if pm is not None:
+            mat = pm
+    packed = mat is not cmat
     keep = []
     hooks = _hooks(mat, keep)
     import torch
@@ -258,7 +275,7 @@ def eigsolve(H, getvecs=False, nev=1, which='lowest', target=None, tol=None, sub
         C.byref(hooks) if hooks is not None else None, nev_max, _lib.pf64(evals),
         C.c_void_p(evec_buf.data_ptr()) if evec_buf is not None else None, C.byref(stats), _stream()))
     eigsolve.last_stats = {'reason': stats.reason, 'its': stats.its, 'matvecs': stats.matvecs,
-                           'nconv': stats.nconv, 'max_rel_residual': stats.err_est}
+                           'nconv': stats.nconv, 'max_rel_residual': stats.err_est, 'real_arithmetic': packed}
     nconv = stats.nconv
     if stats.reason == _lib.DIVERGED_ITS:
         raise MaxIterationsError('eigensolver reached maximum number of iterations without '
@@ -278,9 +295,15 @@ def eigsolve(H, getvecs=False, nev=1, which='lowest', target=None, tol=None, sub
     evecs = []
     for i in range(nconv):
         v = State(L=H.L, subspace=subspace)
-        # (views of one buffer: no second copy of the vectors)
-        v._vec = Vec(mat.N, array=evec_buf[i * mat.n_local:(i + 1) * mat.n_local], swz=mat.swz_right,
-                     sub_c=mat._keep[1])
+        piece = evec_buf[i * mat.n_local:(i + 1) * mat.n_local]
+        if packed:
+            # the real eigenvector as the complex state of the full dimension (imaginary parts zero)
+            v._vec = Vec(cmat.N, swz=cmat.swz_right, sub_c=cmat._keep[1])
+            _lib.check(_lib.lib().dnm_vec_unpack_real(v._vec.ptr, C.c_void_p(piece.data_ptr()), mat.n_local,
+                                                      mat.swz_right, cmat.swz_right, _stream()))
+        else:
+            # (views of one buffer: no second copy of the vectors)
+            v._vec = Vec(mat.N, array=piece, swz=mat.swz_right, sub_c=mat._keep[1])
         v.set_initialized()
         evecs.append(v)
     return vals, evecs

@@ -123,6 +123,7 @@ int vk_axpby(void *y, const void *x, int64_t n, double are, double aim, double b
              hipStream_t st);
 int vk_random(void *x, int64_t n, uint64_t seed, int64_t offset, hipStream_t st, int swz = 0);
 int vk_swizzle_copy(void *dst, const void *src, int64_t n, int swz, hipStream_t st);
+int vk_unpack_real(void *dst, const void *src, int64_t n_packed, int swz_src, int swz_dst, hipStream_t st);
 // partial sums: out_dev[2*nv * nblocks]; reduce_blocks returns the block count
 int vk_mdot_blocks(int64_t n);
 int vk_sweep_blocks(int64_t n);                     // workgroups of the one-element-per-thread sweeps with partial sums

@@ -202,6 +202,10 @@ struct Ops {
   int64_t n;
   int matvecs = 0;
   ChebFilter *flt = nullptr;
+  // real-packed operator (DNM_MAT_REAL_PACKED): the vectors are real, two amplitudes to a complex128 element; the
+  // real part of the complex inner product of two such vectors IS their real inner product, its imaginary part
+  // means nothing and is dropped wherever an inner product comes back
+  bool real = false;
 
   // y = A x - b z + c2 x, the filter's step (z may be null when b == 0); 2 A x is avoided by halving the
   // recurrence: u_j = s_j / 2^(j-1)  =>  u_{j+1} = (A - c) u_j - (h/2)^2 u_{j-1}, u_1 = (A - c) u_0, u_2 = (A - c) u_1 - (h^2/2) u_0
@@ -267,7 +271,7 @@ struct Ops {
       ++matvecs;
       DNM_TRY(dnm_mat_mult_lanczos(A, x, y, z, b, buf, (void *)st));
     }
-    *d = zc(buf[0], buf[1]);
+    *d = zc(buf[0], real ? 0.0 : buf[1]);
     if (nn) *nn = buf[2];
     return 0;
   }
@@ -301,7 +305,7 @@ struct Ops {
     DNM_TRY(vec_mdot_host(V, n, nv, w, n, buf.data(), st));
     DNM_TRY(sum(buf.data(), 2 * nv));
     h.resize(nv);
-    for (int j = 0; j < nv; ++j) h[j] = zc(buf[2 * j], buf[2 * j + 1]);
+    for (int j = 0; j < nv; ++j) h[j] = zc(buf[2 * j], real ? 0.0 : buf[2 * j + 1]);
     return 0;
   }
   int norm(const void *w, double *out) {
@@ -927,6 +931,7 @@ extern "C" {
 int dnm_expm_chebyshev(dnm_mat *A, const void *x, void *y, int64_t n_local, double t, double tol,
                        const dnm_hooks *hooks, dnm_solver_stats *stats, void *stream) {
   DNM_CHECK(A && x && y && stats, "null argument");
+  DNM_CHECK(!A->real_packed, "exp(-iHt) needs complex vectors: not for a real-packed operator");
   hipStream_t st = (hipStream_t)stream;
   Ops ops{A, hooks, st, n_local};
   stats->reason = 0; stats->its = 0; stats->matvecs = 0; stats->nconv = 0; stats->err_est = 0;
@@ -953,6 +958,7 @@ int dnm_expm_multiply(dnm_mat *A, const void *x, void *y, int64_t n_local, doubl
                       double scale_im, double tol, int ncv, int max_its, size_t work_limit_bytes,
                       const dnm_hooks *hooks, dnm_solver_stats *stats, void *stream) {
   DNM_CHECK(A && x && y && stats, "null argument");
+  DNM_CHECK(!A->real_packed, "exp(-iHt) needs complex vectors: not for a real-packed operator");
   hipStream_t st = (hipStream_t)stream;
   Ops ops{A, hooks, st, n_local};
   stats->reason = 0; stats->its = 0; stats->matvecs = 0; stats->nconv = 0; stats->err_est = 0;
@@ -1232,6 +1238,8 @@ int dnm_eigsolve(dnm_mat *A, int64_t n_local, int nev, int which, double tol, in
   DNM_CHECK(A && evals && stats && nev >= 1 && nev_max >= nev, "bad argument");
   hipStream_t st = (hipStream_t)stream;
   Ops ops{A, hooks, st, n_local};
+  ops.real = A->real_packed;
+  DNM_CHECK(!A->real_packed || !(hooks && hooks->mult), "real-packed operators run on one rank");
   stats->reason = 0; stats->its = 0; stats->matvecs = 0; stats->nconv = 0; stats->err_est = 0;
   const int64_t Nglob = A->N;
   if (tol <= 0) tol = 1e-8;

@@ -204,6 +204,52 @@ static uint32_t compress_to_tile(uint64_t bits, const PassSpec &ps) {
   return out;
 }
 
+// Real-packed form of a real operator (DNM_MAT_REAL_PACKED): index r = 2 j + b, element j of a vector holds the
+// amplitudes b = 0 (real part) and b = 1 (imaginary part).  A term (mask m, sign s, coefficient c) contributes
+// c (-1)^popcount(r & s) x[r ^ m] to y[r]; with m' = m >> 1, s' = s >> 1, f = m & 1:
+//   y[j].lane(b) += c (-1)^popcount(j & s') (-1)^(b (s & 1)) x[j ^ m'].lane(b ^ f)
+// -- one coefficient per lane.  The form keeps the record layout: a term's is_imag names its lane, the records of a
+// mask carry both lanes (slots 0, 1: lane 0; slots 2, 3: lane 1) and RowMask::pack_flip = f.  Diagonal terms whose
+// sign reaches bit 0 differ between the lanes: they become a mask-0 off-diagonal entry (partner = the element itself).
+static int pack_opform(OpForm *op) {
+  DNM_CHECK(op->n >= 2, "real-packed form needs at least two index bits");
+  std::vector<RowMask> out;
+  for (const RowMask &rm : op->masks) {
+    for (const RowTerm &t : rm.terms) DNM_CHECK(!t.is_imag, "operator has an imaginary matrix element: no real-packed form");
+    DNM_CHECK(!rm.zero_mask_offdiag, "operator has an imaginary matrix element: no real-packed form");
+    RowMask lanes;
+    lanes.mask = rm.mask >> 1;
+    lanes.pack_flip = (rm.mask & 1) != 0;
+    if (rm.mask == 0) {
+      RowMask diag;                       // what both lanes share stays the diagonal
+      diag.mask = 0;
+      lanes.zero_mask_offdiag = true;
+      for (const RowTerm &t : rm.terms) {
+        if (!(t.sign & 1)) { diag.terms.push_back({t.sign >> 1, t.coeff, 0}); continue; }
+        lanes.terms.push_back({t.sign >> 1, t.coeff, 0});
+        lanes.terms.push_back({t.sign >> 1, -t.coeff, 1});
+      }
+      if (!diag.terms.empty()) out.push_back(std::move(diag));
+      if (!lanes.terms.empty()) out.push_back(std::move(lanes));
+      continue;
+    }
+    lanes.zero_mask_offdiag = lanes.mask == 0;       // the mask flipped bit 0 only: the element's own other lane
+    for (const RowTerm &t : rm.terms) {
+      lanes.terms.push_back({t.sign >> 1, t.coeff, 0});
+      lanes.terms.push_back({t.sign >> 1, (t.sign & 1) ? -t.coeff : t.coeff, 1});
+    }
+    out.push_back(std::move(lanes));
+  }
+  std::stable_sort(out.begin(), out.end(), [](const RowMask &a, const RowMask &b) {
+    if (a.mask != b.mask) return a.mask < b.mask;
+    return (int)a.zero_mask_offdiag < (int)b.zero_mask_offdiag;        // the diagonal first
+  });
+  op->masks.swap(out);
+  op->n -= 1;
+  op->packed = true;
+  return 0;
+}
+
 static int build_pass(const dnm_mat &A, const PassSpec &ps, PassOnDevice *out) {
   const OpForm &op = A.op;
   const Plan &pl = A.plan;
@@ -283,7 +329,7 @@ static int build_pass(const dnm_mat &A, const PassSpec &ps, PassOnDevice *out) {
   DNM_CHECK(tile_config_supported(B, logR), "unsupported tile configuration B=%d logR=%d", B, logR);
   d.accumulate = ps.accumulate ? 1 : 0;
   d.has_diag = 0;
-  d.cache_policy = pl.cfg.cache_policy;
+  d.cache_policy = pl.cfg.cache_policy | (op.packed ? 256 : 0);      // bit 8: real-packed records (kernel instance)
   {
     const int S = pl.cfg.swz;
     DNM_CHECK(S == 0 || (S >= 5 && S <= 24), "swizzle shift %d out of range", S);
@@ -377,6 +423,7 @@ static int build_pass(const dnm_mat &A, const PassSpec &ps, PassOnDevice *out) {
       q.mask_tile = compress_to_tile(mloc & tb, ps);
       q.mask_loc = (uint32_t)mloc;
       q.src = (uint32_t)src;
+      q.nslots = m.pack_flip ? 1u : 0u;       // real-packed operators: a lane reads the partner's other lane
       bool kvar = false, cplx = false;
       for (int s = 0; s < 2 && ir < re.size(); ++s, ++ir) {
         set_slot(q, s, *re[ir]);
@@ -833,6 +880,12 @@ int dnm_mat_create(int64_t nmasks, const int64_t *masks, const int64_t *mask_off
 
   if (A->hypercube) {
     DNM_TRY(build_opform(*A, &A->op));
+    if (flags & DNM_MAT_REAL_PACKED) {
+      DNM_CHECK(A->nranks == 1 && !A->xparity && A->M == A->N, "real-packed operators: one rank, square, no XParity");
+      DNM_TRY(pack_opform(&A->op));
+      A->real_packed = true;
+      A->M /= 2; A->N /= 2; A->m_local /= 2; A->n_local /= 2;         // complex128 elements, two amplitudes each
+    }
     if (A->xparity) {
       // rows and columns have the top index bit clear: the hypercube loses one dimension
       const uint64_t topbit = (uint64_t)1 << (A->op.n - 1);
@@ -874,6 +927,7 @@ int dnm_mat_create(int64_t nmasks, const int64_t *masks, const int64_t *mask_off
     }
     DNM_TRY(make_plan(A->op, A->rank, A->nranks, cfg, &A->plan));
     if (flags & DNM_MAT_FORCE_GATHER) A->plan.use_tiled = false;
+    DNM_CHECK(!A->real_packed || A->plan.use_tiled, "real-packed operators run on the tiled kernel only (vector too small)");
     if (A->nranks > 1 && !A->plan.use_tiled) {
       // blocks smaller than one tile (or DNM_MAT_FORCE_GATHER): the window partition of the row kernel
       A->plan.remote.clear();

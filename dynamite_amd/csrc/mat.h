@@ -69,6 +69,9 @@ struct dnm_mat {
   bool host_only = false;         // DNM_MAT_HOST_ONLY: plan and tables only, no device
 
   bool hypercube = false;        // Full/Full or Parity/Parity: index space is a hypercube
+  // DNM_MAT_REAL_PACKED: vectors are real, two amplitudes per complex128 element (M, N, m_local, n_local count
+  // elements; rows_local / row0 still describe the operator's rows for the norm kernel)
+  bool real_packed = false;
   dnm::OpForm op;
   dnm::Plan plan;
   std::vector<std::unique_ptr<dnm::PassOnDevice>> local_passes, remote_passes;

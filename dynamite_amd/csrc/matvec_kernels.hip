@@ -170,10 +170,27 @@ struct RowAddr {
 };
 
 // y += (coefficients of one record) * (partner amplitudes xv) for the R rows of this thread
-template <int R, int LOGNT, bool KVAR, bool CPLX>
+// PACK: real-packed operators (plan.h, RowMask::pack_flip): an element holds two REAL amplitudes, slots 0,1 are the
+// coefficient of its first lane (.x), slots 2,3 of its second (.y), and Q.nslots says whether a lane reads the
+// partner element's other lane
+template <int R, int LOGNT, bool KVAR, bool CPLX, bool PACK>
 __device__ __forceinline__ void accum_record(CQuad &Q, double a0, double a1, double a2, double a3,
                                              const c128 (&xv)[R], double (&ar)[R], double (&ai)[R]) {
-  if constexpr (!KVAR) {
+  if constexpr (PACK && CPLX) {
+    const bool fl = Q.nslots != 0u;
+    const uint32_t s0 = Q.sign_tile[0] >> LOGNT, s1 = Q.sign_tile[1] >> LOGNT;
+    const uint32_t s2 = Q.sign_tile[2] >> LOGNT, s3 = Q.sign_tile[3] >> LOGNT;
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      double c0 = a0 + a1, c1 = a2 + a3;
+      if constexpr (KVAR) {
+        c0 = flip_sign(a0, (uint32_t)__popc(k & s0) & 1u) + flip_sign(a1, (uint32_t)__popc(k & s1) & 1u);
+        c1 = flip_sign(a2, (uint32_t)__popc(k & s2) & 1u) + flip_sign(a3, (uint32_t)__popc(k & s3) & 1u);
+      }
+      ar[k] = fma(c0, fl ? xv[k].y : xv[k].x, ar[k]);
+      ai[k] = fma(c1, fl ? xv[k].x : xv[k].y, ai[k]);
+    }
+  } else if constexpr (!KVAR) {
     const double cre = a0 + a1;
 #pragma unroll
     for (int k = 0; k < R; ++k) {
@@ -214,7 +231,7 @@ __device__ __forceinline__ void accum_record(CQuad &Q, double a0, double a1, dou
 //   GATHER: partner amplitudes come from global memory instead of the LDS tile
 //   K0    : (LDS, !KVAR) the mask does not touch the k bits: the R partner rows
 //           sit at fixed LDS offsets from one address
-template <int R, int LOGNT, bool KVAR, bool CPLX, bool GATHER, bool K0, int SPLITSEL = 0>
+template <int R, int LOGNT, bool KVAR, bool CPLX, bool GATHER, bool K0, int SPLITSEL = 0, bool PACK = false>
 __device__ __forceinline__ void apply_records(CQuad *__restrict__ quads, uint32_t b, uint32_t e,
                                               double (&ar)[R], double (&ai)[R], const c128 *tile,
                                               const RowAddr<R> &RA, const c128 *__restrict__ x,
@@ -263,7 +280,7 @@ __device__ __forceinline__ void apply_records(CQuad *__restrict__ quads, uint32_
 #pragma unroll
       for (int k = 0; k < R; ++k) xv[k] = tile[p_lo + (((uint32_t)k ^ mk) << LOGNT)];
     }
-    accum_record<R, LOGNT, KVAR, CPLX>(Q, a0, a1, a2, a3, xv, ar, ai);
+    accum_record<R, LOGNT, KVAR, CPLX, PACK>(Q, a0, a1, a2, a3, xv, ar, ai);
   }
 }
 
@@ -286,7 +303,7 @@ constexpr int tile_waves_per_simd(int B, int LOGR) {
 // GV (gather variant): 0 = gathers after the LDS masks; 1 = right behind the tile loads, before the barrier
 // (default: sibling workgroups then ask for the same lines within the same microsecond and the L2 merges the
 // requests).  (Two records in flight was tried: spills at 8 rows per thread, no gain at 16.)
-template <int B, int LOGR, bool GLDS, int GV>
+template <int B, int LOGR, bool GLDS, int GV, bool PACK = false>
 __global__ void __launch_bounds__(1 << (B - LOGR), tile_waves_per_simd(B, LOGR))
 tile_pass_kernel(const DevPass P, const c128 *__restrict__ x, c128 *__restrict__ y,
                  const c128 *__restrict__ xr) {
@@ -390,7 +407,7 @@ tile_pass_kernel(const DevPass P, const c128 *__restrict__ x, c128 *__restrict__
   CQuad *__restrict__ quads = (CQuad *)P.quads;
 
 #define DNM_LOOP(LP, KV, CX, GA, KZ) \
-  apply_records<R, LOGNT, KV, CX, GA, KZ>(quads, P.loop[LP], P.loop[LP + 1], ar, ai, tile, RA, x, xr, tid, sbase, skw, xp_rot(P.swz_xor_src))
+  apply_records<R, LOGNT, KV, CX, GA, KZ, 0, PACK>(quads, P.loop[LP], P.loop[LP + 1], ar, ai, tile, RA, x, xr, tid, sbase, skw, xp_rot(P.swz_xor_src))
   if constexpr (GV >= 1) {
     // (two live records in flight at a time -- half the L2 round trips of this phase -- changed nothing:
     // profiles/r03_exp9_gather_pairs.txt; the passes are not bound by the life of a workgroup)
@@ -519,7 +536,7 @@ tile_pass_kernel(const DevPass P, const c128 *__restrict__ x, c128 *__restrict__
   DNM_PH(4, 0);
   // ---- off-diagonal masks, one branch-free loop per record class
 #define DNM_LOOP(LP, KV, CX, GA, KZ) \
-  apply_records<R, LOGNT, KV, CX, GA, KZ>(quads, P.loop[LP], P.loop[LP + 1], ar, ai, tile, RA, x, xr, tid, sbase, skw, xp_rot(P.swz_xor_src))
+  apply_records<R, LOGNT, KV, CX, GA, KZ, 0, PACK>(quads, P.loop[LP], P.loop[LP + 1], ar, ai, tile, RA, x, xr, tid, sbase, skw, xp_rot(P.swz_xor_src))
 #if DNM_XP_SPLIT >= 1
   apply_records<R, LOGNT, false, false, false, true, 2>(quads, P.loop[LP_TILE_REAL_K0], P.loop[LP_TILE_REAL_K0 + 1], ar, ai,
                                                         tile, RA, x, xr, tid, sbase, skw, 0u);
@@ -636,11 +653,13 @@ static int launch_cfg(const DevPass &P, bool glds, int n_loc, const void *x, voi
   const int gv = (P.cache_policy & 32) ? 1 : 0;
   using kern_t = void (*)(const DevPass, const c128 *, c128 *, const c128 *);
   kern_t k = nullptr;
-  if (glds) k = tile_pass_kernel<B, LOGR, true, 1>;
+  const bool pack = (P.cache_policy & 256) != 0;          // real-packed records: their own instance (early gathers only)
+  if (pack) k = tile_pass_kernel<B, LOGR, false, 1, true>;
+  else if (glds) k = tile_pass_kernel<B, LOGR, true, 1>;
   else if (gv == 0) k = tile_pass_kernel<B, LOGR, false, 0>;
   else k = tile_pass_kernel<B, LOGR, false, 1>;
-  static size_t attr_done[4] = {0, 0, 0, 0};
-  const int slot = glds ? 3 : gv;
+  static size_t attr_done[5] = {0, 0, 0, 0, 0};
+  const int slot = pack ? 4 : (glds ? 3 : gv);
   if (attr_done[slot] < lds) {
     DNM_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_done[slot] = lds;

@@ -46,10 +46,16 @@ struct RowMask {
   // Walsh-Hadamard path).  Mixed Parity pairs can map an imaginary term onto
   // index mask 0; those live in a second mask-0 entry treated like any other mask.
   bool zero_mask_offdiag = false;
+  // Real-packed operators (DNM_MAT_REAL_PACKED, mat.cpp pack_opform): the index space has lost its bit 0, which now
+  // distinguishes the real and the imaginary part of an element.  is_imag of a term then names the LANE its
+  // coefficient belongs to (0: rows with bit 0 clear = real parts, 1: imaginary parts) and pack_flip says whether the
+  // mask flipped bit 0, i.e. whether a lane reads the partner element's OTHER lane.
+  bool pack_flip = false;
 };
 
 // Operator in row-evaluated index-space form.
 struct OpForm {
+  bool packed = false;           // real-packed form (see RowMask::pack_flip)
   int n = 0;                     // index-space bits
   std::vector<RowMask> masks;    // sorted by mask; masks[0].mask == 0 is the diagonal
 };

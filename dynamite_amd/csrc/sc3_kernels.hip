@@ -46,11 +46,13 @@ __device__ __forceinline__ double flip(double c, uint32_t parity_bit) {
 
 // wave priority by phase (round 4, as in tile_pass_kernel): raised while a workgroup is in a memory phase, lowered for
 // its LDS bond loops, so that of the two workgroups of a CU the one asking for memory wins the issue slots
+// (SpinConserve(32,16): window pass 5.38 -> 5.25 ms, lo pass level; a rank of config 5 25.7 -> 24.8 ms;
+// profiles/r04_sc3_spans.txt; -DDNM_SC3_PRIO=0 builds without)
 // the layout's and the operator's tables are read-only: through the constant address space their wave-uniform reads
 // stay scalar loads whatever else the kernel contains (see CQuad in matvec_kernels.hip)
 #define SC3_CP(T, p) ((const __attribute__((address_space(4))) T *)(p))
 #ifndef DNM_SC3_PRIO
-#define DNM_SC3_PRIO 0
+#define DNM_SC3_PRIO 1
 #endif
 #if DNM_SC3_PRIO == 1
 #define SC3_PRIO_MEM() asm volatile("s_setprio 3")

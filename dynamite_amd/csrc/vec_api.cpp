@@ -110,6 +110,13 @@ int dnm_vec_set_random_swz(void *x, int64_t n, uint64_t seed, int64_t offset, in
   return vk_random(x, n, seed, offset, S(stream), swizzle);
 }
 
+int dnm_vec_unpack_real(void *dst, const void *src, int64_t n_packed, int swizzle_packed, int swizzle_out, void *stream) {
+  DNM_CHECK(dst && src && dst != src && n_packed >= 0, "bad vector");
+  for (int sw : {swizzle_packed, swizzle_out})
+    DNM_CHECK(sw == 0 || (sw >= 5 && sw <= 24), "swizzle shift %d out of range", sw);
+  return vk_unpack_real(dst, src, n_packed, swizzle_packed, swizzle_out, S(stream));
+}
+
 int dnm_vec_swizzle_copy(void *dst, const void *src, int64_t n, int swizzle, void *stream) {
   DNM_CHECK((dst && src) || n == 0, "null vector");
   DNM_CHECK(dst != src, "dnm_vec_swizzle_copy works out of place");

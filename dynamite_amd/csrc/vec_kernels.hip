@@ -118,6 +118,22 @@ __global__ void __launch_bounds__(VNT) swizzle_copy_kernel(c128 *dst, const c128
   for (int64_t i = (int64_t)blockIdx.x * VNT + threadIdx.x; i < n; i += (int64_t)gridDim.x * VNT)
     st_stream(dst + i, ld_stream(src + vec_pos(i, swz)));
 }
+// real-packed vectors (DNM_MAT_REAL_PACKED): element j of src holds the real amplitudes of indices 2j (.x) and 2j + 1
+// (.y); dst is the complex128 vector of 2 n elements they stand for (imaginary parts zero), each in its own layout
+__global__ void __launch_bounds__(VNT) unpack_real_kernel(c128 *dst, const c128 *__restrict__ src, int64_t n2, int swz_src,
+                                                          int swz_dst) {
+  for (int64_t p = (int64_t)blockIdx.x * VNT + threadIdx.x; p < n2; p += (int64_t)gridDim.x * VNT) {
+    const int64_t i = vec_pos(p, swz_dst);               // the index stored at position p (the map is an involution)
+    const c128 v = src[vec_pos(i >> 1, swz_src)];
+    st_stream(dst + p, make_double2((i & 1) ? v.y : v.x, 0.0));
+  }
+}
+int vk_unpack_real(void *dst, const void *src, int64_t n_packed, int swz_src, int swz_dst, hipStream_t st) {
+  hipLaunchKernelGGL(unpack_real_kernel, dim3(vgrid(2 * n_packed)), dim3(VNT), 0, st, (c128 *)dst, (const c128 *)src,
+                     2 * n_packed, swz_src, swz_dst);
+  DNM_HIP(hipGetLastError());
+  return 0;
+}
 int vk_swizzle_copy(void *dst, const void *src, int64_t n, int swz, hipStream_t st) {
   hipLaunchKernelGGL(swizzle_copy_kernel, dim3(vgrid(n)), dim3(VNT), 0, st, (c128 *)dst, (const c128 *)src, n, swz);
   DNM_HIP(hipGetLastError());

@@ -11,7 +11,7 @@ import warnings
 
 import numpy as np
 
-from . import msc_tools, backend
+from . import msc_tools, backend, _lib
 from .computations import evolve, eigsolve
 from .config import config
 from .msc_tools import msc_dtype
@@ -316,8 +316,35 @@ class Operator:
             backend.precompute_diagonal(mat)
         self._mats[(hash(subspaces[0]), hash(subspaces[1]))] = mat
 
+    def get_real_packed_mat(self, subspace):
+        """The operator in real arithmetic on ``subspace`` (Full or Parity, one rank), or None when it has an
+        imaginary matrix element in the product basis (or the subspace / size has no such form): a second native
+        handle built with ``DNM_MAT_REAL_PACKED`` that multiplies real vectors stored two amplitudes to a complex128
+        element -- half the bytes per multiply and per Krylov vector.  Not in the reference (its PETSc build is complex
+        throughout); used inside ``eigsolve`` only, which hands back complex states as the reference does."""
+        from .subspaces import Full, Parity
+        key = ('real_packed', hash(subspace))
+        if key in self._mats:
+            return self._mats[key]
+        mat = None
+        if isinstance(subspace, (Full, Parity)) and config.world_size == 1 and self.shell:
+            self.establish_L()
+            self.reduce_msc()
+            masks, mask_offsets = msc_tools.get_mask_offsets(self.msc)
+            try:
+                mat = backend.build_mat(
+                    masks=np.ascontiguousarray(masks), mask_offsets=np.ascontiguousarray(mask_offsets),
+                    signs=np.ascontiguousarray(self.msc['signs']), coeffs=np.ascontiguousarray(self.msc['coeffs']),
+                    left_subspace=subspace._to_c(), right_subspace=subspace._to_c(), flags=_lib.MAT_REAL_PACKED)
+            except _lib.BackendError:
+                mat = None            # an imaginary matrix element, or a vector too small for the tiled kernel
+        self._mats[key] = mat
+        return mat
+
     def destroy_mat(self, subspaces=None):
         keys = [(hash(subspaces[0]), hash(subspaces[1]))] if subspaces is not None else list(self._mats)
+        if subspaces is not None:
+            keys.append(('real_packed', hash(subspaces[0])))
         for k in keys:
             mat = self._mats.pop(k, None)
             if mat is not None:

@@ -105,8 +105,19 @@ enum {
                                  (measured slower on MI355X for this access pattern; kept for A/B runs) */
   DNM_MAT_AMIN_SHIFT   = 8,   /* flags bits 8..15: log2 of the contiguous run of a window tile (0: the planner's default);
                                  the transposed exchange asks for tiles [0, a) + [f, n) so that sub-pieces are contiguous */
-  DNM_MAT_HOST_ONLY    = 4    /* build the plan and its tables on the host only (no device needed;
+  DNM_MAT_HOST_ONLY    = 4,   /* build the plan and its tables on the host only (no device needed;
                                  diagnostics and CPU tests) -- such a handle cannot multiply */
+  DNM_MAT_REAL_PACKED  = 16   /* Real arithmetic for a real-symmetric operator (every matrix element real in the
+                                 product basis: Heisenberg, XXZ, Ising, random-field chains ...) on a Full / Parity pair,
+                                 one rank: the handle multiplies REAL vectors of the same dimension, stored two
+                                 amplitudes to a complex128 element -- element j holds the amplitudes of indices 2j
+                                 (real part) and 2j + 1 (imaginary part), so a vector is dim / 2 elements, 8 bytes per
+                                 amplitude, and dnm_mat_sizes reports the halved sizes.  Solver-internal (eigsolve of a
+                                 real-symmetric operator needs no complex arithmetic; the reference's PETSc build is
+                                 complex throughout): dnm_eigsolve on such a handle keeps every inner product real, and
+                                 dnm_vec_unpack_real turns a packed vector into the complex128 vector the caller sees.
+                                 dnm_mat_create fails (and the caller keeps the complex handle) when the operator has
+                                 an imaginary matrix element. */
 };
 
 /* Row-block partition of the state vector over `nranks` devices, as PetscSplitOwnership splits it
@@ -298,6 +309,11 @@ int dnm_vec_set_random(void *x, int64_t n, uint64_t seed, int64_t offset, void *
 int dnm_vec_set_random_swz(void *x, int64_t n, uint64_t seed, int64_t offset, int swizzle, void *stream);
 /* dst[i] = src[i ^ sw(i)]: swizzled <-> index order (the map is an involution); dst != src */
 int dnm_vec_swizzle_copy(void *dst, const void *src, int64_t n, int swizzle, void *stream);
+/* The complex128 vector a real-packed one stands for (DNM_MAT_REAL_PACKED; no counterpart in the reference, whose PETSc
+ * build is complex throughout -- what its EPS hands to computations.py:273-284 is what dst holds): src has n_packed
+ * elements, element j = the real amplitudes of indices 2j and 2j + 1, in the layout swizzle_packed; dst gets
+ * 2 * n_packed elements with zero imaginary parts in the layout swizzle_out; dst != src */
+int dnm_vec_unpack_real(void *dst, const void *src, int64_t n_packed, int swizzle_packed, int swizzle_out, void *stream);
 /* Vectors of a SpinConserve subspace in the internal layout (dnm_subspace.vec_swizzle = a | w << 8).  No counterpart
  * in the reference: what a petsc4py Vec of that subspace holds, element by element, is reached through these.
  * size: elements of a vector (rows + padding); copy: to_internal != 0: dst (internal) <- src (reference order, C(L,k)

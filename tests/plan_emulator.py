@@ -195,7 +195,13 @@ def run_pass(hm, p, x, y, xr=None):
                 assert desc.need_tile
                 partner = base | deposit(tt ^ np.uint64(Q.mask_tile))
                 xv = x[partner.astype(np.int64)]
-            acc += (cre + 1j * cim) * xv
+            if desc.cache_policy & 256:
+                # real-packed records (accum_record<PACK>): slots 0,1 = coefficient of the element's first lane,
+                # slots 2,3 of its second; nslots != 0: a lane reads the partner element's other lane
+                assert cplx and Q.nslots in (0, 1)
+                acc += cre * (xv.imag if Q.nslots else xv.real) + 1j * (cim * (xv.real if Q.nslots else xv.imag))
+            else:
+                acc += (cre + 1j * cim) * xv
     y[:] = acc
 
 

@@ -1152,3 +1152,99 @@ def test_evolve_probe_of_the_norm_bound(monkeypatch, capfd):
         assert "spectral extent seen by x" in err and ("-> " + want) in err, err
         ref = spla.expm_multiply(-1j * t * H.to_numpy(sparse=True), x.to_numpy())
         assert np.max(np.abs(y.to_numpy() - ref)) < 1e-8
+
+
+@pytest.mark.parametrize("name,L,sub", [("mbl", 16, "full"), ("ising", 15, "parity"), ("xxz", 14, "full"), ("xsum", 13, "full")])
+def test_real_packed_multiply_vs_oracle(monkeypatch, name, L, sub):
+    """DNM_MAT_REAL_PACKED on the GPU: the tiled kernel's real-arithmetic instance (two real amplitudes per element)
+    against the oracle for a real x, the fused <x, y> / |y|^2 of the Lanczos step, and dnm_vec_unpack_real."""
+    import ctypes as C
+    from gpu_util import marshal, orc_msc, orc_sub, shell
+    from oracle import oracle as orc
+    from dynamite_amd import _lib
+    for k, v in (("DNM_TILE_BITS", "8"), ("DNM_LOG_ROWS", "2"), ("DNM_PLAN_MODE", "2"), ("DNM_GBITS", "3"), ("DNM_AMIN", "3")):
+        monkeypatch.setenv(k, v)
+    H = models.BY_NAME[name](L)
+    s = Full(L=L) if sub == "full" else Parity('even', L=L)
+    dim = s.get_dimension()
+    mat = shell(H, s, flags=_lib.MAT_REAL_PACKED)
+    assert mat.N == dim // 2 and "tiled=1" in mat.describe()
+    xv, yv = mat.createVecs()
+    rs = np.random.RandomState(L)
+    xr = rs.standard_normal(dim)
+    xv.set_local_from_numpy(xr[0::2] + 1j * xr[1::2])
+    yv.set(7.0)
+    mat.mult(xv, yv)
+    ref = orc.matvec(orc_msc(H), orc_sub(s), orc_sub(s), xr.astype(np.complex128)).real
+    yp = yv.local_numpy()
+    got = np.empty(dim)
+    got[0::2], got[1::2] = yp.real, yp.imag
+    tol = 64 * 2.2e-16 * np.abs(H.msc['coeffs']).sum() * np.abs(xr).max()
+    assert np.abs(got - ref).max() <= tol
+    # the Lanczos step's fused sums: <x, y> is the REAL inner product, |y|^2 the real norm
+    d = (C.c_double * 3)()
+    _lib.check(_lib.lib().dnm_mat_mult_lanczos(mat.handle, xv.ptr, yv.ptr, None, 0.0, d, None))
+    assert abs(d[0] - xr @ ref) <= 1e-11 * max(1.0, abs(xr @ ref)) and abs(d[2] - ref @ ref) <= 1e-11 * (ref @ ref)
+    # unpacked: the complex vector of the full dimension, in the subspace's own layout
+    from dynamite_amd import backend
+    out = backend.Vec(dim, swz=s.vec_swizzle)
+    _lib.check(_lib.lib().dnm_vec_unpack_real(out.ptr, yv.ptr, mat.n_local, mat.swz_right, s.vec_swizzle, None))
+    assert np.abs(out.local_numpy() - ref).max() <= tol
+    mat.destroy()
+
+
+@pytest.mark.parametrize("mode", ["restarted", "basis_free", "filtered"])
+@pytest.mark.parametrize("name,L,sub", [("mbl", 14, "full"), ("xxz", 13, "parity"), ("heisenberg", 13, "full")])
+def test_eigsolve_real_arithmetic(monkeypatch, name, L, sub, mode):
+    """eigsolve of a real-symmetric operator in real arithmetic (the default from 2^23 amplitudes on one rank, forced
+    here): the same eigenvalues as dense diagonalisation, and the returned COMPLEX states pass the reference's
+    residual / Rayleigh-quotient / orthogonality bars (tests/integration/test_eigsolve.py:17-88, 127-137) -- through
+    the restarted scheme, the basis-free Lanczos and the Chebyshev-filtered scheme."""
+    from dynamite_amd.computations import eigsolve
+    monkeypatch.setenv("DNM_EIGS_REAL", "1")
+    nev = 1 if mode == "basis_free" else 3
+    if mode == "basis_free":
+        monkeypatch.setenv("DNM_EIGS_BASISFREE", "1")
+    if mode == "filtered":
+        monkeypatch.setenv("DNM_EIGS_FILTER", "1")
+    H = models.BY_NAME[name](L)
+    s = Full(L=L) if sub == "full" else Parity('even', L=L)
+    H.add_subspace(s)
+    w = np.linalg.eigvalsh(H.to_numpy(subspaces=(s, s), sparse=False))
+    ev, vecs = H.eigsolve(nev=nev, tol=1e-11, subspace=s, getvecs=True)
+    assert eigsolve.last_stats['real_arithmetic'] is True
+    assert len(ev) >= nev and abs(ev[0] - w[0]) < 1e-9 * max(1.0, abs(w[0]))
+    for e in ev[:nev]:
+        assert np.min(np.abs(w - e)) < 1e-9 * max(1.0, abs(e))
+    for i, (e, v) in enumerate(zip(ev[:nev], vecs[:nev])):
+        assert v.vec.size == s.get_dimension()
+        Hv = H.dot(v)
+        assert abs(v.norm() - 1) < 1e-10
+        assert abs(Hv.dot(v).real - e) < 1e-10 * max(1.0, abs(e))
+        r = Hv.copy()
+        r.axpy(-e, v)
+        assert r.norm() < 1e-9 * max(1.0, abs(e))
+        assert np.abs(v.to_numpy().imag).max() == 0.0
+        for j in range(i):
+            assert abs(v.dot(vecs[j])) < 1e-10
+    # values only, and the complex path on the same operator agrees
+    ev_r = H.eigsolve(nev=nev, tol=1e-11, subspace=s)
+    monkeypatch.setenv("DNM_EIGS_REAL", "0")
+    ev_c = H.eigsolve(nev=nev, tol=1e-11, subspace=s)
+    assert eigsolve.last_stats['real_arithmetic'] is False
+    assert np.abs(np.asarray(ev_r[:nev]) - np.asarray(ev_c[:nev])).max() < 1e-9
+
+
+def test_eigsolve_real_arithmetic_falls_back():
+    """An operator with an imaginary matrix element (single sigma_y terms) keeps the complex path whatever is asked."""
+    import os
+    from dynamite_amd.computations import eigsolve
+    os.environ["DNM_EIGS_REAL"] = "1"
+    try:
+        H = models.long_range(13)
+        ev = H.eigsolve(nev=2, tol=1e-10)
+        assert eigsolve.last_stats['real_arithmetic'] is False
+        w = np.linalg.eigvalsh(H.to_numpy(sparse=False))
+        assert abs(ev[0] - w[0]) < 1e-8
+    finally:
+        del os.environ["DNM_EIGS_REAL"]

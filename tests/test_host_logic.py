@@ -555,3 +555,56 @@ def test_complement_ranges():
         complement_ranges([(4, 2)], 10)
     with pytest.raises(ValueError):
         complement_ranges([(0, 5), (3, 8)], 10)
+
+
+@pytest.mark.parametrize("name,L,sub", [("mbl", 14, "full"), ("xxz", 13, "full"), ("heisenberg", 14, "full"),
+                                        ("localized", 13, "full"), ("ising", 14, "full"), ("ising", 15, "parity0"),
+                                        ("ising", 15, "parity1"), ("xsum", 13, "full")])
+def test_real_packed_operator_form(monkeypatch, name, L, sub):
+    """DNM_MAT_REAL_PACKED (csrc/mat.cpp pack_opform): the records of a real-symmetric operator in real arithmetic --
+    vectors of dim / 2 elements holding two real amplitudes each -- run through the kernel emulation reproduce the
+    oracle's y = H x for a real x; an operator with an imaginary matrix element has no such form."""
+    from dynamite_amd import models, msc_tools, _lib
+    from dynamite_amd.subspaces import Full, Parity
+    from oracle import oracle as orc
+    from plan_emulator import HostMat, multiply, vec_pos
+    for k, v in (("DNM_TILE_BITS", "8"), ("DNM_LOG_ROWS", "2"), ("DNM_PLAN_MODE", "2"), ("DNM_GBITS", "3"), ("DNM_AMIN", "3")):
+        monkeypatch.setenv(k, v)
+    H = models.BY_NAME[name](L)
+    H.establish_L()
+    H.reduce_msc()
+    masks, offs = msc_tools.get_mask_offsets(H.msc)
+    s = Full(L=L) if sub == "full" else Parity(int(sub[-1]), L=L)
+    c = s._c()
+    c.vec_swizzle = 6
+    hm = HostMat(masks, offs, H.msc['signs'], H.msc['coeffs'], c, c, flags=_lib.MAT_REAL_PACKED)
+    dim = s.get_dimension()
+    assert hm.tiled and (1 << hm.n_loc) == dim // 2
+    assert all(d.cache_policy & 256 for d, _ in hm.local)
+    rs = np.random.RandomState(L)
+    xr = rs.standard_normal(dim)
+    pos = vec_pos(np.arange(dim // 2), 6)
+    xp = np.empty(dim // 2, dtype=np.complex128)
+    xp[pos] = xr[0::2] + 1j * xr[1::2]                # element j = amplitudes 2j and 2j + 1, in the vector layout
+    yp = multiply(hm, xp)[pos]
+    y = np.empty(dim)
+    y[0::2], y[1::2] = yp.real, yp.imag
+    osub = orc.full(L) if sub == "full" else orc.parity(L, int(sub[-1]))
+    ref = orc.matvec(orc.Msc(masks, offs, H.msc['signs'], H.msc['coeffs']), osub, osub, xr.astype(np.complex128))
+    assert np.abs(ref.imag).max() == 0.0
+    assert np.abs(y - ref.real).max() <= 1e-13 * max(1.0, np.abs(ref).max()), hm.describe()
+
+
+def test_real_packed_refuses_imaginary_elements():
+    from dynamite_amd import msc_tools, _lib, backend
+    from dynamite_amd.operators import sigmax, sigmay, sigmaz, index_sum
+    from dynamite_amd.subspaces import Full
+    L = 13
+    H = index_sum(sigmax(0) * sigmay(1) - sigmay(0) * sigmax(1), size=L) + index_sum(sigmaz(0), size=L)
+    H.L = L
+    H.reduce_msc()
+    masks, offs = msc_tools.get_mask_offsets(H.msc)
+    c = Full(L=L)._c()
+    with pytest.raises(_lib.BackendError, match="imaginary"):
+        backend.create_mat(masks, offs, H.msc['signs'], H.msc['coeffs'], c, c, False,
+                           _lib.MAT_HOST_ONLY | _lib.MAT_REAL_PACKED, 0, 1)

@@ -16,7 +16,7 @@ for d, k, n, v, dur, g in rows:
 keep = {k: sorted(v)[-nlast:] for k, v in ids.items()}
 for d, k, n, v, dur, g in rows:
     if d in keep[k]:
-        short = k.split("(")[0][-60:]
+        short = k.replace("(anonymous namespace)::", "").split("(")[0][-60:]
         tag = ("  [dispatch -%d]" % (len(keep[k]) - 1 - keep[k].index(d))) if nlast > 1 else ""
         print("   %-60s %-14s %18.0f   (%.3f ms, grid %d)%s" % (short, n, v, dur / 1e6, g, tag))
 PY
