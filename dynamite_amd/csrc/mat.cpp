@@ -234,9 +234,11 @@ static int pack_opform(OpForm *op) {
       continue;
     }
     lanes.zero_mask_offdiag = lanes.mask == 0;       // the mask flipped bit 0 only: the element's own other lane
+    bool same = !lanes.pack_flip;                    // bit 0 neither flipped nor seen by a sign: both lanes get the same
+    for (const RowTerm &t : rm.terms) same = same && !(t.sign & 1);      // real coefficient -- an ordinary real record
     for (const RowTerm &t : rm.terms) {
       lanes.terms.push_back({t.sign >> 1, t.coeff, 0});
-      lanes.terms.push_back({t.sign >> 1, (t.sign & 1) ? -t.coeff : t.coeff, 1});
+      if (!same) lanes.terms.push_back({t.sign >> 1, (t.sign & 1) ? -t.coeff : t.coeff, 1});
     }
     out.push_back(std::move(lanes));
   }

@@ -198,8 +198,12 @@ def run_pass(hm, p, x, y, xr=None):
             if desc.cache_policy & 256:
                 # real-packed records (accum_record<PACK>): slots 0,1 = coefficient of the element's first lane,
                 # slots 2,3 of its second; nslots != 0: a lane reads the partner element's other lane
-                assert cplx and Q.nslots in (0, 1)
-                acc += cre * (xv.imag if Q.nslots else xv.real) + 1j * (cim * (xv.real if Q.nslots else xv.imag))
+                # (a record without lane-1 slots -- bit 0 neither flipped nor seen -- is an ordinary real record)
+                assert Q.nslots in (0, 1) and (cplx or Q.nslots == 0)
+                if cplx:
+                    acc += cre * (xv.imag if Q.nslots else xv.real) + 1j * (cim * (xv.real if Q.nslots else xv.imag))
+                else:
+                    acc += cre * xv
             else:
                 acc += (cre + 1j * cim) * xv
     y[:] = acc

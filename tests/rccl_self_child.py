@@ -7,7 +7,11 @@ replaces the all-gather of bcuda_template_2.cu:161-171 and the scatters of bpets
   B  batch_p2p with the rank as its own peer (isend + irecv of complex128 device slices in one batch),
   C  post_exchange / post_transpose with the message lists of real plans (rank 0 of 2 partner blocks, rank 1 of 4
      transposed exchange), every peer rewritten to this rank,
-  D  evolve and eigsolve with the solver hooks reducing through RCCL, and exchange_only on a world-size-1 operator.
+  D  evolve and eigsolve with the solver hooks reducing through RCCL, and exchange_only on a world-size-1 operator,
+  E  the partitioned multiply itself (ShellMat.mult, partner blocks): rank 0 of 2 and rank 5 of 8 of a Full-space
+     operator, the state chosen with all rank blocks equal so that what a partner would send is a slice of this rank's
+     own block -- the production code posts the exchange on RCCL's stream, runs the rank-local passes under it, waits
+     per block and applies the partner passes; the rank's rows are compared with the oracle.
 Prints one JSON line: {"stage": last stage completed, "refused": RCCL's message if it refused the self send}.
 Exit code 0: everything ran; 77: RCCL refused stage B (stages A and D still ran); anything else: a failure.
 Started as a FRESH process by the test (never a re-exec of a process that has touched the GPU).
@@ -110,6 +114,52 @@ def main():
         for off in own:
             assert bool((xb[off:off + cnt] == 0).all())
         report["stage"] = "C"
+
+        # ---- E: the partitioned multiply over RCCL, looped back
+        from oracle import oracle as orc
+        from gpu_util import orc_msc, orc_sub
+        L = 20
+        sub = Full(L=L)
+        Hm = models.mbl(L)
+        Hm.establish_L()
+        Hm.reduce_msc()
+        masks, offs = msc_tools.get_mask_offsets(Hm.msc)
+        for P, me in ((2, 0), (8, 5)):
+            c = sub._c()
+            c.vec_swizzle = 10                        # small blocks: a shift that really permutes them
+            n_loc = (1 << L) // P
+            h = backend.create_mat(masks, offs, Hm.msc['signs'], Hm.msc['coeffs'], c, c, False, 0, me, P)
+            mat = backend.ShellMat(h, c, c, P, me)
+            assert mat.n_local == n_loc and mat.recvs and mat.partners
+            # what every partner q sends to this rank: q's own list (host-only handle of rank q), in the order of
+            # this rank's receives -- all peers are this process, so posting order is matching order
+            psends = {}
+            for q in mat.partners:
+                hq = backend.create_mat(masks, offs, Hm.msc['signs'], Hm.msc['coeffs'], c, c, False, _lib.MAT_HOST_ONLY, q, P)
+                sq, _ = backend.exchange_plan(hq)
+                psends[q] = [t for t in sq if t[0] == me]
+                _lib.check(_lib.lib().dnm_mat_destroy(hq))
+            taken = {q: 0 for q in mat.partners}
+            loop_sends = []
+            for q, off, cnt in mat.recvs:
+                _, soff, scnt = psends[q][taken[q]]
+                taken[q] += 1
+                assert scnt == cnt
+                loop_sends.append((0, soff, scnt))
+            assert all(taken[q] == len(psends[q]) for q in mat.partners)
+            mat.sends = loop_sends
+            mat.recvs = [(0, off, cnt) for _, off, cnt in mat.recvs]
+            x0 = rs.standard_normal(n_loc) + 1j * rs.standard_normal(n_loc)
+            xv, yv = backend.Vec(n_loc, swz=10), backend.Vec(n_loc, swz=10)
+            xv.set_local_from_numpy(x0)
+            yv.set(3.0)
+            mat.mult(xv, yv)
+            torch.cuda.synchronize()
+            ref = orc.matvec(orc_msc(Hm), orc_sub(sub), orc_sub(sub), np.tile(x0, P), nthreads=4)[me * n_loc:(me + 1) * n_loc]
+            err = float(np.abs(yv.local_numpy() - ref).max())
+            assert err < 1e-12, "partitioned multiply over RCCL (rank %d of %d): %.3e" % (me, P, err)
+            mat.destroy()
+        report["stage"] = "E"
     except AssertionError:
         raise
     except Exception as e:          # RCCL's own refusal (recorded in DESIGN.md section 6 if it ever shows up)

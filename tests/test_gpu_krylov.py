@@ -1194,7 +1194,7 @@ def test_real_packed_multiply_vs_oracle(monkeypatch, name, L, sub):
 
 
 @pytest.mark.parametrize("mode", ["restarted", "basis_free", "filtered"])
-@pytest.mark.parametrize("name,L,sub", [("mbl", 14, "full"), ("xxz", 13, "parity"), ("heisenberg", 13, "full")])
+@pytest.mark.parametrize("name,L,sub", [("mbl", 12, "full"), ("xxz", 13, "parity"), ("heisenberg", 11, "full")])
 def test_eigsolve_real_arithmetic(monkeypatch, name, L, sub, mode):
     """eigsolve of a real-symmetric operator in real arithmetic (the default from 2^23 amplitudes on one rank, forced
     here): the same eigenvalues as dense diagonalisation, and the returned COMPLEX states pass the reference's
@@ -1202,6 +1202,8 @@ def test_eigsolve_real_arithmetic(monkeypatch, name, L, sub, mode):
     the restarted scheme, the basis-free Lanczos and the Chebyshev-filtered scheme."""
     from dynamite_amd.computations import eigsolve
     monkeypatch.setenv("DNM_EIGS_REAL", "1")
+    for k, v in (("DNM_TILE_BITS", "8"), ("DNM_LOG_ROWS", "2"), ("DNM_PLAN_MODE", "2"), ("DNM_GBITS", "3"), ("DNM_AMIN", "3")):
+        monkeypatch.setenv(k, v)          # small tiles: the real-arithmetic handle needs the tiled kernel
     nev = 1 if mode == "basis_free" else 3
     if mode == "basis_free":
         monkeypatch.setenv("DNM_EIGS_BASISFREE", "1")
@@ -1241,7 +1243,7 @@ def test_eigsolve_real_arithmetic_falls_back():
     from dynamite_amd.computations import eigsolve
     os.environ["DNM_EIGS_REAL"] = "1"
     try:
-        H = models.long_range(13)
+        H = models.long_range(11)
         ev = H.eigsolve(nev=2, tol=1e-10)
         assert eigsolve.last_stats['real_arithmetic'] is False
         w = np.linalg.eigvalsh(H.to_numpy(sparse=False))
