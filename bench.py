@@ -198,11 +198,14 @@ def secondary(wd, budget_s=15.0):
             own for this operator: real arithmetic, two amplitudes per complex128 element (half the bytes)"""
             config.eigs_real_arithmetic = real
             try:
-                # (one call: the solver's four work vectors come from the workspace the evolve above has grown; a
-                # second call measured the same to 0.1 %)
-                (ev, dt0) = timed(lambda: H.eigsolve(nev=1, tol=tol))
+                # the first solve of the process may pay for its 64 GiB of work vectors (device memory that was
+                # used and freed -- the headline's x and y -- is scrubbed when it is handed out again, about 1 s):
+                # the complex128 solve runs twice and the faster call counts, the real one finds the workspace in place
+                (ev, dt) = timed(lambda: H.eigsolve(nev=1, tol=tol))
                 st = dict(eigsolve.last_stats)
-                dt = dt0
+                if not real and left() > dt + 6.0:
+                    (ev, dt2) = timed(lambda: H.eigsolve(nev=1, tol=tol))
+                    dt = min(dt, dt2)
             finally:
                 config.eigs_real_arithmetic = None
             assert st["max_rel_residual"] <= tol * 1.01, "Lanczos residual %r above tol" % st["max_rel_residual"]
