@@ -136,7 +136,8 @@ def secondary(wd, budget_s=15.0):
       * the basis-free Lanczos of `eigsolve(nev=1)` at the headline size (L=30 random-field Heisenberg): ms per step
         and the step's own roofline -- one step is a multiply (32 B/amp) plus the three-term update sweep (48 B/amp:
         it reads v_j and w and writes v_{j+1}), `(32 + 48) * dim / t_step / peak`;
-      * `eigsolve(nev=1)` on SpinConserve(32,16) (BASELINE.json configs[4]'s subspace family at one-GPU size).
+      * `eigsolve(nev=1)` on SpinConserve(32,16) (BASELINE.json configs[4]'s subspace family at one-GPU size), in
+        complex128 and in the real arithmetic eigsolve takes on its own for a real-symmetric operator.
     Each carries a sanity check (norm preserved / measured residual within tol).  A phase is skipped (and says so) once
     the budget is spent."""
     import numpy as np
@@ -234,12 +235,22 @@ def secondary(wd, budget_s=15.0):
         H = models.heisenberg(L)
         H.add_subspace(sub)
         tol = 1e-8
-        (ev, dt) = timed(lambda: H.eigsolve(nev=1, tol=tol, subspace=sub))
-        st = dict(eigsolve.last_stats)
-        assert st["max_rel_residual"] <= tol * 1.01, "residual %r above tol" % st["max_rel_residual"]
-        out["eigsolve_sc32_16"] = {"wall_s": dt, "matvecs": st["matvecs"], "E0": float(ev[0]), "dim": sub.get_dimension(),
-                                   "measured_rel_residual": st["max_rel_residual"], "tol": tol,
-                                   "ms_per_step": dt / st["matvecs"] * 1e3}
+
+        def sc_solve(real):
+            config.eigs_real_arithmetic = real
+            try:
+                (ev, dt) = timed(lambda: H.eigsolve(nev=1, tol=tol, subspace=sub))
+            finally:
+                config.eigs_real_arithmetic = None
+            st = dict(eigsolve.last_stats)
+            assert st["max_rel_residual"] <= tol * 1.01, "residual %r above tol" % st["max_rel_residual"]
+            assert bool(st["real_arithmetic"]) == real
+            return {"wall_s": dt, "matvecs": st["matvecs"], "E0": float(ev[0]), "dim": sub.get_dimension(),
+                    "measured_rel_residual": st["max_rel_residual"], "tol": tol, "ms_per_step": dt / st["matvecs"] * 1e3,
+                    "arithmetic": "real (f64, 8 B per amplitude)" if real else "complex128 (16 B per amplitude)"}
+        out["eigsolve_sc32_16"] = sc_solve(False)
+        if left() > 2.0:
+            out["eigsolve_sc32_16_real_arithmetic"] = sc_solve(True)      # what eigsolve takes on its own here
         H.destroy_mat()
     else:
         out["eigsolve_sc32_16"] = "skipped: budget"

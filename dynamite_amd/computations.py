@@ -299,8 +299,12 @@ def eigsolve(H, getvecs=False, nev=1, which='lowest', target=None, tol=None, sub
         if packed:
             # the real eigenvector as the complex state of the full dimension (imaginary parts zero)
             v._vec = Vec(cmat.N, swz=cmat.swz_right, sub_c=cmat._keep[1])
-            _lib.check(_lib.lib().dnm_vec_unpack_real(v._vec.ptr, C.c_void_p(piece.data_ptr()), mat.n_local,
-                                                      mat.swz_right, cmat.swz_right, _stream()))
+            if v._vec.internal:           # SpinConserve: one double per position of the layout
+                _lib.check(_lib.lib().dnm_vec_layout_unpack_real(C.byref(cmat._keep[1]), v._vec.ptr,
+                                                                 C.c_void_p(piece.data_ptr()), _stream()))
+            else:                         # Full / Parity: two amplitudes per element
+                _lib.check(_lib.lib().dnm_vec_unpack_real(v._vec.ptr, C.c_void_p(piece.data_ptr()), mat.n_local,
+                                                          mat.swz_right, cmat.swz_right, _stream()))
         else:
             # (views of one buffer: no second copy of the vectors)
             v._vec = Vec(mat.N, array=piece, swz=mat.swz_right, sub_c=mat._keep[1])

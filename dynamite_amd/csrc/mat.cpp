@@ -869,8 +869,9 @@ int dnm_mat_create(int64_t nmasks, const int64_t *masks, const int64_t *mask_off
     A->sc3.reset(new Sc3Mat());
     // partitioned: whole T blocks per rank (a contiguous range of both the internal layout and the reference order)
     const std::vector<uint32_t> Tb = sc3_partition(*ly, A->nranks);
+    const bool want_real = (flags & DNM_MAT_REAL_PACKED) != 0;
     DNM_TRY(A->sc3->init(ly, A->masks, A->mask_offsets, A->signs, A->real_coeffs, scm, !A->host_only, Tb[A->rank],
-                         Tb[A->rank + 1]));
+                         Tb[A->rank + 1], want_real));
     if (const char *e = knob("DNM_SC3_TILED")) if (e[0] == '0') A->sc3->tiled = false;     // tests: the row kernel
     if (const char *e = knob("DNM_SC3_DIAG")) if (e[0] == 'c' && A->sc3->diag_mode == 2) A->sc3->diag_mode = 1;
     int64_t is, il, ns, nl;
@@ -878,6 +879,17 @@ int dnm_mat_create(int64_t nmasks, const int64_t *masks, const int64_t *mask_off
     A->m_local = A->n_local = il;          // what the vector kernels sweep: rows + padding
     A->rows_local = nl;
     A->row0 = ns;                          // first row in reference order (norm / diagonal kernels)
+    if (want_real) {
+      // real vectors in the same positions of the layout, one double each: a vector is il / 2 complex128 elements for
+      // everything that sweeps it (the Krylov kernels); the two tiled passes only (chain operators, real symmetric)
+      DNM_CHECK(A->nranks == 1, "real-packed operators run on one rank");
+      DNM_CHECK(A->sc3->tiled && A->sc3->sym && A->sc3->diag_mode != 1,
+                "operator has an imaginary matrix element or is not a chain: no real-packed form in this layout");
+      A->real_packed = true;
+      A->m_local = A->n_local = il / 2;
+    }
+  } else if (flags & DNM_MAT_REAL_PACKED) {
+    DNM_CHECK(A->hypercube, "real-packed operators: Full / Parity pairs, or a SpinConserve pair in the internal layout");
   }
 
   if (A->hypercube) {

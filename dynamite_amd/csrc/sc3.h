@@ -72,6 +72,12 @@ __host__ __device__ __forceinline__ int64_t sc3_pos(uint64_t state, const Sc3Tab
 // Host side: owns the tables (and, optionally, their device mirrors)
 struct Sc3Layout {
   Sc3Tab host{}, dev{};
+  // The same tables with every position halved (ibase, icoff, pitch, nint): a REAL vector of this layout read as
+  // complex128 elements of two adjacent entries.  The window pass never looks inside a row, so on real vectors it is
+  // the complex kernel run on these tables (rows of pitch / 2 elements).
+  Sc3Tab host_h{}, dev_h{};
+  std::vector<int64_t> ibase_h, icoff_h;
+  void *d_ibase_h = nullptr, *d_icoff_h = nullptr;
   int64_t dim = 0;                 // C(L, k)
   bool on_device = false;
   std::vector<int64_t> ibase, nbase, icoff, ncoff, nck;
@@ -111,6 +117,9 @@ int sc3_positions(const Sc3Layout &Ly, int64_t n, const int64_t *idx, int64_t *p
                   uint32_t T1 = 0xffffffffu);
 // counter-based normal deviates keyed by the global reference index (the numbers reference order would get), padding zero
 int sc3_random(const Sc3Layout &Ly, void *x, uint64_t seed, hipStream_t st, uint32_t T0 = 0, uint32_t T1 = 0xffffffffu);
+// real vectors of the layout (one double per position): normal deviates / the complex128 vector a real one stands for
+int sc3_random_real(const Sc3Layout &Ly, double *x, uint64_t seed, hipStream_t st);
+int sc3_unpack_real(const Sc3Layout &Ly, void *dst, const double *src, hipStream_t st);
 
 // ---- the operator in this layout ---------------------------------------------------------------------------------
 // Per-operator device data of the tiled passes.  A chain bond b couples spins b, b+1 with the two matrix elements of
@@ -153,6 +162,7 @@ struct Sc3Mat {
   std::vector<char> needT;         // T blocks its rows read (own blocks included)
   bool tiled = false;              // two tiled passes (every off-diagonal mask is a chain bond); else the row kernel
   bool sym = false;                // every bond real and direction-independent
+  bool real = false;               // real vectors (DNM_MAT_REAL_PACKED): sc3_lo_pass_r, window pass on the halved tables
   int diag_mode = 0;               // 0: no diagonal terms; 2: on the fly; 1: needs the cached diagonal
   Sc3Op op{};
   std::vector<uint32_t> permA, permB;
@@ -164,7 +174,7 @@ struct Sc3Mat {
   ~Sc3Mat();
   int init(const Sc3Layout *layout, const std::vector<int64_t> &masks, const std::vector<int64_t> &mask_offsets,
            const std::vector<int64_t> &signs, const std::vector<double> &rcoef, const std::vector<ScMask> &scm,
-           bool want_device, uint32_t T0, uint32_t T1);
+           bool want_device, uint32_t T0, uint32_t T1, bool real_vectors = false);
   // the internal positions [lo, hi] this rank's rows read; marks the chunks of 2^shift positions among them
   void window(int64_t *lo, int64_t *hi) const;
   void chunks(int shift, int64_t first_chunk, int64_t nchunks, uint8_t *map) const;

@@ -403,6 +403,276 @@ sc3_lo_pass(const Sc3Tab S, const Sc3Op O, const uint32_t *__restrict__ perm, co
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// lo pass on REAL vectors (DNM_MAT_REAL_PACKED on a SpinConserve pair, round 4): x and y are arrays of doubles in the
+// same positions of the layout.  A thread owns PAIRS of adjacent row entries (2q, 2q + 1) -- rows start at multiples of
+// 8 entries, so a pair is one aligned 16-byte access -- and twice as many entries as the complex pass (the same 64 KB
+// tile holds 8192 doubles: two rows of 3432 states per workgroup, four of 2002 ...); the tile in LDS is an array of
+// doubles, so the bonds inside Lo (partner r +- d, d of either parity) read 8 bytes.  Real operators have equal `up`
+// and `dn` elements (Hermitian and real), so there is only the SYM form.  Everything per row -- sub-groups, the bond
+// table in the lanes, the on-the-fly diagonal -- is as in sc3_lo_pass.
+constexpr int sc3_lo_cap_r(int a, int nt) { return 2 * sc3_lo_cap(a, nt); }
+
+template <int A, int NT, int DIAGM, bool ACC>
+__global__ void __launch_bounds__(NT, sc3_win_waves(NT, (sc3_lo_cap_r(A, NT) * 8 + 1023) / 1024 + 1))
+sc3_lo_pass_r(const Sc3Tab S, const Sc3Op O, const uint32_t *__restrict__ perm, const Sc3Call C,
+              const double *__restrict__ xw, double *__restrict__ y) {
+  constexpr int MAXROWS = cbinom(A, A / 2);
+  constexpr int PPT = (MAXROWS + NT - 1) / NT;          // pairs per thread
+  constexpr int EPT = 2 * PPT;                          // entries per thread
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ int32_t cl[A * (A + 1)];
+  __shared__ double red[3 * (NT / 64)];
+  __shared__ double dsh[5 * 8];
+  const uint32_t e0 = SC3_CP(uint32_t, perm)[8 * (size_t)blockIdx.x];
+  if (e0 == 0xffffffffu) return;
+  const int lane = threadIdx.x & 63;
+  const int w = S.w;
+  const int logm = (int)(e0 >> 30);
+  const int NTS = NT >> logm;
+  const int sub = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) >> (ilog2c(NT) - 6 - logm);
+  const int tsub = (int)threadIdx.x & (NTS - 1);
+  const uint32_t e = SC3_CP(uint32_t, perm)[8 * (size_t)blockIdx.x + sub];
+  const bool has_row = !(e & SC3_NOROW);
+  double *xs = reinterpret_cast<double *>(smem) + (size_t)sub * ((NT * EPT) >> logm);
+  const RowId R = decode_row(has_row ? (e & (SC3_NOROW - 1u)) : (e0 & (SC3_NOROW - 1u)), S);
+  const uint32_t T = R.T, W = R.W;
+  const int cw = R.cw, kr = R.kr, kl = R.kl, nrows = has_row ? R.nrows : 0, p = has_row ? R.pitch : 0;
+  const int64_t tb = R.tb, base = R.base;
+  const double *__restrict__ x = xw - C.win_start;
+  const int64_t lbase = base - C.row0;
+  // entry i of this thread: pair i >> 1, lane i & 1
+#define SC3R_ENT(i) (2 * (tsub + ((i) >> 1) * NTS) + ((i) & 1))
+
+  SC3_PRIO_MEM();
+  uint32_t lowp[PPT];                                   // the Lo patterns of a pair's entries, 16 bits each
+#define SC3R_PAT(i) ((lowp[(i) >> 1] >> (((i) & 1) * 16)) & 0xffffu)
+  double xv[EPT];
+  const auto pat = SC3_CP(uint16_t, S.lo_pat) + S.lo_off[kl];
+#pragma unroll
+  for (int i = 0; i < EPT; i += 2) {
+    const int r = SC3R_ENT(i);
+    lowp[i >> 1] = 0;
+    xv[i] = xv[i + 1] = 0.0;
+    if (r < p) {                                        // (the padding of a row holds zeros)
+      const d2v v = *reinterpret_cast<const d2v *>(x + base + r);
+      xv[i] = v.x;
+      xv[i + 1] = v.y;
+      if (r < nrows) lowp[i >> 1] = pat[r];
+      if (r + 1 < nrows) lowp[i >> 1] |= (uint32_t)pat[r + 1] << 16;
+    }
+  }
+  int act = 0, r0 = 0, r1 = nrows;
+  int64_t delta = 0;
+  double c0 = 0.0;
+  {
+    const int b = A - 1 + lane;
+    if (b < S.L - 1 && ((O.bondsA >> b) & 1ull)) {
+      bool up = false;
+      if (lane == 0) {
+        const int cut = SC3_CP(int32_t, S.cbin)[(A - 1) * 17 + kl];
+        if (W & 1u) {
+          if (cut > 0) {
+            act = 1; r0 = 0; r1 = cut; up = false;
+            delta = tb + SC3_CP(int64_t, S.icoff)[kr * (w + 1) + cw - 1] + (int64_t)SC3_CP(uint16_t, S.w_rank)[W & ~1u] * S.pitch[kl + 1] +
+                    SC3_CP(int32_t, S.cbin)[(A - 1) * 17 + kl + 1] - base;
+          }
+        } else if (cut < nrows) {
+          act = 1; r0 = cut; r1 = nrows; up = true;
+          delta = tb + SC3_CP(int64_t, S.icoff)[kr * (w + 1) + cw + 1] + (int64_t)SC3_CP(uint16_t, S.w_rank)[W | 1u] * S.pitch[kl - 1] - cut - base;
+        }
+      } else if (lane < w) {
+        const int bw = lane - 1;
+        const uint32_t pair = (W >> bw) & 3u;
+        if (pair == 1u || pair == 2u) {
+          act = 1; up = pair == 1u;
+          delta = ((int64_t)SC3_CP(uint16_t, S.w_rank)[W ^ (3u << bw)] - (int64_t)SC3_CP(uint16_t, S.w_rank)[W]) * p;
+        }
+      } else if (lane == w) {
+        const uint32_t pair = ((W >> (w - 1)) & 1u) | ((T & 1u) << 1);
+        if (pair == 1u) {
+          act = 1; up = true;
+          delta = SC3_CP(int64_t, S.ibase)[T | 1u] + SC3_CP(int64_t, S.icoff)[(kr - 1) * (w + 1) + cw - 1] +
+                  (int64_t)SC3_CP(uint16_t, S.w_rank)[W & ~(1u << (w - 1))] * p - base;
+        } else if (pair == 2u) {
+          act = 1; up = false;
+          delta = SC3_CP(int64_t, S.ibase)[T & ~1u] + SC3_CP(int64_t, S.icoff)[(kr + 1) * (w + 1) + cw + 1] +
+                  (int64_t)SC3_CP(uint16_t, S.w_rank)[W | (1u << (w - 1))] * p - base;
+        }
+      } else {
+        const int bt = lane - w - 1;
+        const uint32_t pair = (T >> bt) & 3u;
+        if (pair == 1u || pair == 2u) {
+          act = 1; up = pair == 1u;
+          delta = SC3_CP(int64_t, S.ibase)[T ^ (3u << bt)] - tb;
+        }
+      }
+      if (act) c0 = SC3_CP(double, O.bond)[4 * b + (up ? 0 : 2)];
+    }
+  }
+  uint64_t hb = has_row ? __ballot(act) : 0ull;
+
+  for (int tt = threadIdx.x; tt < A * (A + 1); tt += NT) {
+    const int lo = tt / (A + 1), o = tt % (A + 1);
+    cl[tt] = SC3_CP(int32_t, S.cbin)[lo * 17 + o];
+  }
+  if (DIAGM == 2 && tsub < 64) {
+    const uint64_t hi = ((uint64_t)T << w) | W;
+    double v0 = 0.0, vm[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int t0 = 0; t0 < O.ndt; t0 += 64) {
+      const int t = t0 + lane;
+      if (t < O.ndt) {
+        const uint64_t sg = SC3_CP(uint64_t, O.dt_sign)[t];
+        const double c = flip(SC3_CP(double, O.dt_coef)[t], (uint32_t)__popcll(hi & sg & 0x1fffffffffffffffull) & 1u);
+        const int g = (int)(sg >> 61);
+        if (g == 0) v0 += c;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (g == j + 1) vm[j] += c;
+      }
+    }
+    v0 = wave_sum(v0);
+    if (lane == 0) dsh[5 * sub] = v0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (j < O.ngroups) {
+        const double s = wave_sum(vm[j]);
+        if (lane == 0) dsh[5 * sub + j + 1] = s;
+      }
+  }
+  double acc[EPT];
+#pragma unroll
+  for (int i = 0; i < EPT; i += 2) {
+    const int r = SC3R_ENT(i);
+    acc[i] = acc[i + 1] = 0.0;
+    if (r < p) {
+      *reinterpret_cast<d2v *>(xs + r) = d2v{xv[i], xv[i + 1]};
+      if (DIAGM == 1) {
+        const d2v dg = __builtin_nontemporal_load(reinterpret_cast<const d2v *>(O.diag + lbase + r));
+        acc[i] = dg.x * xv[i];
+        acc[i + 1] = dg.y * xv[i + 1];
+      }
+    }
+  }
+  while (hb) {
+    const int m = __ffsll((long long)hb) - 1;
+    hb &= hb - 1;
+    const int64_t dl_ = rl_i64(delta, m);
+    const double *__restrict__ pp = x + (base + dl_);
+    const double cr = rl_f64(c0, m);
+    const int q0 = rl_i32(r0, m), q1 = rl_i32(r1, m);
+    double v[EPT];
+    if (!(dl_ & 1)) {                 // whole elements line up (every bond but, mostly, the Lo/W boundary)
+#pragma unroll
+      for (int i = 0; i < EPT; i += 2) {
+        const int r = SC3R_ENT(i);
+        v[i] = v[i + 1] = 0.0;
+        if (r >= q0 && r + 1 < q1) {                // the whole pair lies in [q0, q1): one 16-byte load
+          const d2v t = *reinterpret_cast<const d2v *>(pp + r);
+          v[i] = t.x;
+          v[i + 1] = t.y;
+        } else {                                    // a pair that straddles an end of the range
+          if (r >= q0 && r < q1) v[i] = pp[r];
+          if (r + 1 >= q0 && r + 1 < q1) v[i + 1] = pp[r + 1];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < EPT; ++i) {
+        const int r = SC3R_ENT(i);
+        v[i] = 0.0;
+        if (r >= q0 && r < q1) v[i] = pp[r];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) acc[i] = fma(cr, v[i], acc[i]);
+  }
+  d2v yv[PPT];
+  if (ACC) {
+#pragma unroll
+    for (int i = 0; i < EPT; i += 2) {
+      const int r = SC3R_ENT(i);
+      yv[i >> 1] = d2v{0.0, 0.0};
+      if (r < p) yv[i >> 1] = __builtin_nontemporal_load(reinterpret_cast<const d2v *>(y + lbase + r));
+    }
+  }
+  __syncthreads();
+  SC3_PRIO_LDS();
+  if (DIAGM == 2) {
+    // (the Lo-only part of the diagonal comes from its L2-resident table here, not before the barrier as in the
+    // complex pass: eight entries per thread leave no registers to carry it across)
+    const auto dl = SC3_CP(double, O.dlo) + S.lo_off[kl];
+    const double dg0 = dsh[5 * sub];
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+      const int r = SC3R_ENT(i);
+      if (r < nrows) {
+        double dg = dl[r] + dg0;
+        for (int j = 0; j < O.ngroups; ++j) dg += flip(dsh[5 * sub + j + 1], (uint32_t)__popc(SC3R_PAT(i) & O.glo[j]) & 1u);
+        acc[i] = fma(dg, xs[r], acc[i]);
+      }
+    }
+  }
+  for (int lo = 0; lo < A - 1; ++lo) {
+    if (!((O.present >> lo) & 1ull)) continue;
+    const double ure = SC3_CP(double, O.bond)[4 * lo];
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+      const int r = SC3R_ENT(i);
+      const uint32_t pt = SC3R_PAT(i);
+      const uint32_t pair = (pt >> lo) & 3u;
+      if (r < nrows && (pair == 1u || pair == 2u)) {
+        const int ord0 = __popc(pt & ((1u << lo) - 1u));
+        const int d = cl[lo * (A + 1) + ord0];
+        acc[i] = fma(ure, xs[pair == 1u ? r + d : r - d], acc[i]);
+      }
+    }
+  }
+  double dr = 0.0, dn = 0.0;
+  SC3_PRIO_MEM();
+#pragma unroll
+  for (int i = 0; i < EPT; i += 2) {
+    const int r = SC3R_ENT(i);
+    if (r < p) {                                  // the padding of a row is written too (zeros)
+      double a2[2] = {acc[i], acc[i + 1]};
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        if (r + b < nrows) {
+          if (ACC) a2[b] += b ? yv[i >> 1].y : yv[i >> 1].x;
+          else if (C.zinit) {
+            a2[b] = fma(-C.zscale, reinterpret_cast<const double *>(C.zinit)[lbase + r + b], a2[b]);
+            if (C.zinit2) a2[b] = fma(C.z2re, reinterpret_cast<const double *>(C.zinit2)[lbase + r + b], a2[b]);
+          }
+          if (ACC && C.dot_out) {
+            dr = fma(xs[r + b], a2[b], dr);
+            dn = fma(a2[b], a2[b], dn);
+          }
+        } else {
+          a2[b] = 0.0;
+        }
+      }
+      __builtin_nontemporal_store(d2v{a2[0], a2[1]}, reinterpret_cast<d2v *>(y + lbase + r));
+    }
+  }
+#undef SC3R_ENT
+#undef SC3R_PAT
+  if (ACC && C.dot_out) {
+    dr = wave_sum(dr); dn = wave_sum(dn);
+    if (lane == 0) {
+      red[3 * (threadIdx.x >> 6)] = dr;
+      red[3 * (threadIdx.x >> 6) + 1] = 0.0;
+      red[3 * (threadIdx.x >> 6) + 2] = dn;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double sr = 0.0, sn = 0.0;
+      for (int wv = 0; wv < NT / 64; ++wv) { sr += red[3 * wv]; sn += red[3 * wv + 2]; }
+      C.dot_out[3 * (size_t)blockIdx.x] = sr;
+      C.dot_out[3 * (size_t)blockIdx.x + 1] = 0.0;
+      C.dot_out[3 * (size_t)blockIdx.x + 2] = sn;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // window pass (the first pass: writes y): one workgroup per (T, cw, run of R = 16 << s columns): all window
 // patterns of the class x R columns in LDS; the accumulators start from -zscale * zinit + z2 * zinit2 if given.
 // (512 threads x 8 entries against 1024 x 4: 5.40 against 5.75 ms at SpinConserve(32,16), level on a rank of config 5,
@@ -686,6 +956,17 @@ sc3_random_kernel(const Sc3Tab S, const uint32_t *__restrict__ rows, c128 *__res
   for (int r = threadIdx.x; r < R.pitch; r += 256)
     x[R.base - ioff + r] = r < R.nrows ? philox_normal((uint64_t)(nat + r), seed) : make_double2(0.0, 0.0);
 }
+__global__ void __launch_bounds__(256)
+sc3_random_real_kernel(const Sc3Tab S, const uint32_t *__restrict__ rows, double *__restrict__ x, uint64_t seed) {
+  const RowId R = decode_row(rows[blockIdx.x], S);
+  const int64_t nat = S.nbase[R.T] + S.ncoff[(int64_t)R.kr * ((int64_t)1 << S.w) + R.W];
+  for (int r = threadIdx.x; r < R.pitch; r += 256)
+    x[R.base + r] = r < R.nrows ? philox_normal((uint64_t)(nat + r), seed).x : 0.0;
+}
+__global__ void __launch_bounds__(256) sc3_unpack_real_kernel(c128 *__restrict__ dst, const double *__restrict__ src, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    dst[i] = make_double2(src[i], 0.0);
+}
 // reference index -> internal position: unrank (bsubspace_impl.h:210-228), then the tables
 __global__ void __launch_bounds__(256)
 sc3_positions_kernel(const Sc3Tab S, int64_t n, const int64_t *__restrict__ idx, int64_t *__restrict__ pos, int64_t ioff,
@@ -723,7 +1004,7 @@ bool sc3_valid(int L, int k, int a, int w) {
 }
 
 Sc3Layout::~Sc3Layout() {
-  for (void *p : {d_ibase, d_nbase, d_icoff, d_ncoff, d_lo_pat, d_w_pat, d_lo_rank, d_w_rank, d_cbin, d_rows, d_nck, d_w_nb})
+  for (void *p : {d_ibase, d_nbase, d_icoff, d_ncoff, d_lo_pat, d_w_pat, d_lo_rank, d_w_rank, d_cbin, d_rows, d_nck, d_w_nb, d_ibase_h, d_icoff_h})
     if (p) (void)hipFree(p);
 }
 
@@ -828,6 +1109,16 @@ int Sc3Layout::init(int L, int k, int a, int w, bool want_device) {
   S.nck = nck.data();
   S.w_nb = w_nb.data();
   dev = S;
+  // halved positions (real vectors read as pairs of entries): everything is a multiple of 8 entries
+  ibase_h.assign(ibase.size(), -1);
+  for (size_t i = 0; i < ibase.size(); ++i) if (ibase[i] >= 0) ibase_h[i] = ibase[i] / 2;
+  icoff_h.assign(icoff.size(), 0);
+  for (size_t i = 0; i < icoff.size(); ++i) icoff_h[i] = icoff[i] / 2;
+  host_h = S;
+  host_h.ibase = ibase_h.data();
+  host_h.icoff = icoff_h.data();
+  host_h.nint = S.nint / 2;
+  for (int j = 0; j <= a; ++j) host_h.pitch[j] = S.pitch[j] / 2;
   if (want_device) {
     DNM_TRY(up(ibase, &d_ibase)); DNM_TRY(up(nbase, &d_nbase)); DNM_TRY(up(icoff, &d_icoff));
     DNM_TRY(up(ncoff, &d_ncoff)); DNM_TRY(up(lo_pat, &d_lo_pat)); DNM_TRY(up(w_pat, &d_w_pat));
@@ -842,6 +1133,12 @@ int Sc3Layout::init(int L, int k, int a, int w, bool want_device) {
     dev.lo_rank = (const uint16_t *)d_lo_rank; dev.w_rank = (const uint16_t *)d_w_rank;
     dev.cbin = (const int32_t *)d_cbin;
     dev.nck = (const int64_t *)d_nck;
+    DNM_TRY(up(ibase_h, &d_ibase_h)); DNM_TRY(up(icoff_h, &d_icoff_h));
+    dev_h = dev;
+    dev_h.ibase = (const int64_t *)d_ibase_h;
+    dev_h.icoff = (const int64_t *)d_icoff_h;
+    dev_h.nint = host_h.nint;
+    for (int j = 0; j <= a; ++j) dev_h.pitch[j] = host_h.pitch[j];
     on_device = true;
   }
   return 0;
@@ -913,6 +1210,20 @@ int sc3_random(const Sc3Layout &Ly, void *x, uint64_t seed, hipStream_t st, uint
   DNM_HIP(hipGetLastError());
   return 0;
 }
+int sc3_random_real(const Sc3Layout &Ly, double *x, uint64_t seed, hipStream_t st) {
+  DNM_CHECK(Ly.on_device, "layout tables are not on the device");
+  hipLaunchKernelGGL(sc3_random_real_kernel, dim3((unsigned)Ly.rows.size()), dim3(256), 0, st, Ly.dev,
+                     (const uint32_t *)Ly.d_rows, x, seed);
+  DNM_HIP(hipGetLastError());
+  return 0;
+}
+int sc3_unpack_real(const Sc3Layout &Ly, void *dst, const double *src, hipStream_t st) {
+  const int64_t n = Ly.host.nint;
+  const unsigned nb = (unsigned)std::min<int64_t>((n + 255) / 256, (int64_t)1 << 22);
+  hipLaunchKernelGGL(sc3_unpack_real_kernel, dim3(nb), dim3(256), 0, st, (c128 *)dst, src, n);
+  DNM_HIP(hipGetLastError());
+  return 0;
+}
 int sc3_positions(const Sc3Layout &Ly, int64_t n, const int64_t *idx, int64_t *pos, hipStream_t st, uint32_t T0, uint32_t T1) {
   DNM_CHECK(Ly.on_device, "layout tables are not on the device");
   if (n <= 0) return 0;
@@ -946,9 +1257,9 @@ static std::vector<uint32_t> deal(const std::vector<std::vector<uint32_t>> &grou
 // a stream are the same (cw, wr) over the T's of a popcount class, so a workgroup's rows have equal lengths and its
 // place in the stream stays next to the boundary-bond partners of its rows.  Returns 8 entries per workgroup, the
 // workgroups of the streams interleaved again.
-static std::vector<uint32_t> pack_lo_rows(const std::vector<uint32_t> &order, const Sc3Layout &ly, int nt) {
+static std::vector<uint32_t> pack_lo_rows(const std::vector<uint32_t> &order, const Sc3Layout &ly, int nt, bool real) {
   const Sc3Tab &S = ly.host;
-  const int cap = sc3_lo_cap(S.a, nt);
+  const int cap = real ? sc3_lo_cap_r(S.a, nt) : sc3_lo_cap(S.a, nt);      // entries a workgroup's threads hold
   int maxm = 0;
   while (maxm < 3 && (nt >> (maxm + 1)) >= 64) ++maxm;
   auto logm_of = [&](uint32_t e) {
@@ -1044,8 +1355,9 @@ void Sc3Mat::chunks(int shift, int64_t first_chunk, int64_t nchunks, uint8_t *ma
 
 int Sc3Mat::init(const Sc3Layout *layout, const std::vector<int64_t> &masks, const std::vector<int64_t> &mask_offsets,
                  const std::vector<int64_t> &signs, const std::vector<double> &rcoef, const std::vector<ScMask> &scm,
-                 bool want_device, uint32_t T0_, uint32_t T1_) {
+                 bool want_device, uint32_t T0_, uint32_t T1_, bool real_vectors) {
   ly = layout;
+  real = real_vectors;
   T0 = T0_;
   T1 = T1_;
   const Sc3Tab &S = ly->host;
@@ -1157,7 +1469,8 @@ int Sc3Mat::init(const Sc3Layout *layout, const std::vector<int64_t> &masks, con
           gA.push_back(g);
         }
       }
-      const int Rr = 16 << S.rs[cw], nrun = (S.pitch[kl] + Rr - 1) / Rr;
+      // (real vectors: the window pass runs on pairs of entries, rows of pitch / 2 elements)
+      const int Rr = 16 << S.rs[cw], nrun = ((real ? S.pitch[kl] / 2 : S.pitch[kl]) + Rr - 1) / Rr;
       DNM_CHECK(nrun < 4096, "internal: too many runs");
       for (int run = 0; run < nrun; ++run) {
         std::vector<uint32_t> g;
@@ -1166,7 +1479,7 @@ int Sc3Mat::init(const Sc3Layout *layout, const std::vector<int64_t> &masks, con
       }
     }
   }
-  permA = pack_lo_rows(deal(gA), *ly, a == 14 ? 1024 : 256);       // thread counts of launch_sc3's instances
+  permA = pack_lo_rows(deal(gA), *ly, a == 14 ? 1024 : 256, real);       // thread counts of launch_sc3's instances
   permB = deal(gB);
   if (permA.empty()) permA.assign(8, 0xffffffffu);
   if (permB.empty()) permB.assign(8, 0xffffffffu);
@@ -1223,6 +1536,31 @@ static int launch_two_pass(const Sc3Mat &M, const Sc3Call &call, const double *c
   first.dot_out = nullptr;
   second.zinit = nullptr;
   second.zinit2 = nullptr;
+  if (M.real) {
+    // real vectors: the window pass is the complex kernel on the halved tables (pairs of entries as elements: every
+    // offset it forms is even), the lo pass its own kernel on doubles
+    DNM_CHECK(M.sym && dm != 1, "internal: real vectors need a real operator with the diagonal on the fly");
+    using kern_r = void (*)(const Sc3Tab, const Sc3Op, const uint32_t *, const Sc3Call, const double *, double *);
+    kern_r kR = nullptr;
+    if (dm == 0) kR = lo_first ? (kern_r)sc3_lo_pass_r<A, NT, 0, false> : (kern_r)sc3_lo_pass_r<A, NT, 0, true>;
+    else kR = lo_first ? (kern_r)sc3_lo_pass_r<A, NT, 2, false> : (kern_r)sc3_lo_pass_r<A, NT, 2, true>;
+    constexpr size_t ldsR = (size_t)sc3_lo_cap_r(A, NT) * 8;
+    if (!attr_done[(const void *)kR]) {
+      DNM_HIP(hipFuncSetAttribute((const void *)kR, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsR));
+      attr_done[(const void *)kR] = true;
+    }
+    Sc3Call firstw = phase == 0 ? first : second;
+    firstw.row0 /= 2;
+    firstw.win_start /= 2;
+    if (phase == 0 || phase == 2)
+      hipLaunchKernelGGL(kB, dim3((unsigned)M.permB.size()), dim3(NTW), ldsB, st, M.ly->dev_h, op, (const uint32_t *)M.d_permB,
+                         firstw, (const c128 *)xw, (c128 *)y);
+    if (phase == 0 || phase == 1)
+      hipLaunchKernelGGL(kR, dim3((unsigned)(M.permA.size() / 8)), dim3(NT), ldsR, st, S, op, (const uint32_t *)M.d_permA,
+                         phase == 0 ? second : first, (const double *)xw, (double *)y);
+    DNM_HIP(hipGetLastError());
+    return 0;
+  }
   if (phase == 0 || phase == 2)
     hipLaunchKernelGGL(kB, dim3((unsigned)M.permB.size()), dim3(NTW), ldsB, st, S, op, (const uint32_t *)M.d_permB,
                        phase == 0 ? first : second, (const c128 *)xw, (c128 *)y);

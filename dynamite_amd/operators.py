@@ -317,17 +317,19 @@ class Operator:
         self._mats[(hash(subspaces[0]), hash(subspaces[1]))] = mat
 
     def get_real_packed_mat(self, subspace):
-        """The operator in real arithmetic on ``subspace`` (Full or Parity, one rank), or None when it has an
-        imaginary matrix element in the product basis (or the subspace / size has no such form): a second native
-        handle built with ``DNM_MAT_REAL_PACKED`` that multiplies real vectors stored two amplitudes to a complex128
-        element -- half the bytes per multiply and per Krylov vector.  Not in the reference (its PETSc build is complex
+        """The operator in real arithmetic on ``subspace`` (Full or Parity, or SpinConserve in the internal layout;
+        one rank), or None when it has an imaginary matrix element in the product basis (or the subspace / size has no
+        such form): a second native handle built with ``DNM_MAT_REAL_PACKED`` that multiplies real vectors -- two
+        amplitudes to a complex128 element (Full / Parity) or one double per position of the layout (SpinConserve) --
+        half the bytes per multiply and per Krylov vector.  Not in the reference (its PETSc build is complex
         throughout); used inside ``eigsolve`` only, which hands back complex states as the reference does."""
-        from .subspaces import Full, Parity
+        from .subspaces import Full, Parity, SpinConserve
         key = ('real_packed', hash(subspace))
         if key in self._mats:
             return self._mats[key]
         mat = None
-        if isinstance(subspace, (Full, Parity)) and config.world_size == 1 and self.shell:
+        ok = isinstance(subspace, (Full, Parity)) or (isinstance(subspace, SpinConserve) and subspace.vec_swizzle >= 256)
+        if ok and config.world_size == 1 and self.shell:
             self.establish_L()
             self.reduce_msc()
             masks, mask_offsets = msc_tools.get_mask_offsets(self.msc)

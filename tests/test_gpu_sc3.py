@@ -330,3 +330,107 @@ def test_fuzz_internal_layout(small_layout, seed):
     scale = max(1.0, np.abs(H.msc['coeffs']).sum()) * np.abs(x).max()
     assert np.abs(got - want).max() <= 64 * 2.2e-16 * scale, (L, k, mat.describe())
     mat.destroy()
+
+
+def _real_mult(mat, sub, xr):
+    """y = A x for a real x through a DNM_MAT_REAL_PACKED handle of a SpinConserve pair: the vectors are one double per
+    position of the internal layout (nint / 2 complex128 elements); returns y in reference order."""
+    import torch
+    v = vec_for(sub)
+    v.set_local_from_numpy(xr.astype(np.complex128))
+    xd = v.array.real.contiguous()                      # double[nint], padding zero
+    assert xd.numel() == v.local_size and mat.n_local * 2 == v.local_size
+    yd = torch.full_like(xd, 7.0)
+    _lib.check(_lib.lib().dnm_mat_mult(mat.handle, C.c_void_p(xd.data_ptr()), C.c_void_p(yd.data_ptr()), None))
+    torch.cuda.synchronize()
+    out = vec_for(sub)
+    _lib.check(_lib.lib().dnm_vec_layout_unpack_real(C.byref(sub._c()), out.ptr, C.c_void_p(yd.data_ptr()), None))
+    pad = np.ones(v.local_size, dtype=bool)
+    pad[v.positions(torch.arange(sub.get_dimension(), device=v.array.device)).cpu().numpy()] = False
+    assert np.all(yd.cpu().numpy()[pad] == 0.0), "padding of the result is not zero"
+    return out.local_numpy(), xd, yd
+
+
+@pytest.mark.parametrize("name", ["heisenberg", "mbl", "xxz", "nnn"])
+@pytest.mark.parametrize("L,k", [(11, 5), (13, 6), (14, 3), (14, 7), (12, 11), (24, 12)])
+def test_real_packed_spinconserve_multiply(small_layout, name, L, k):
+    """The two tiled passes on REAL vectors (sc3_lo_pass_r; the window pass on the halved tables) against the oracle,
+    with the fused sums of the Lanczos step."""
+    if L == 24 and name != "mbl":
+        pytest.skip("one operator at the larger size")
+    H = MODELS[name](L)
+    sub = SpinConserve(L, k)
+    n = sub.get_dimension()
+    mat = shell(H, sub, flags=_lib.MAT_REAL_PACKED)
+    assert "two-pass" in mat.describe()
+    xr = np.random.RandomState(L * 31 + k).standard_normal(n)
+    want = orc.matvec(orc_msc(H), orc_sub(sub), orc_sub(sub), xr.astype(np.complex128), nthreads=4)
+    assert np.abs(want.imag).max() == 0.0
+    got, xd, yd = _real_mult(mat, sub, xr)
+    scale = max(1.0, np.abs(H.msc['coeffs']).sum()) * np.abs(xr).max()
+    assert np.abs(got.imag).max() == 0.0
+    assert np.abs(got.real - want.real).max() <= 64 * 2.2e-16 * scale, mat.describe()
+    d = (C.c_double * 3)()
+    _lib.check(_lib.lib().dnm_mat_mult_lanczos(mat.handle, C.c_void_p(xd.data_ptr()), C.c_void_p(yd.data_ptr()), None,
+                                               0.0, d, None))
+    assert abs(d[0] - xr @ want.real) <= 1e-11 * max(1.0, abs(xr @ want.real))
+    assert abs(d[2] - want.real @ want.real) <= 1e-11 * (want.real @ want.real)
+    mat.destroy()
+
+
+def test_real_packed_spinconserve_refusals(small_layout):
+    """No real form for an operator with imaginary bond elements, nor for one that is not a chain (row kernel)."""
+    sub = SpinConserve(13, 6)
+    for H in (_dm_chain(13), models.long_range(13)):
+        with pytest.raises(_lib.BackendError):
+            shell(H, sub, flags=_lib.MAT_REAL_PACKED)
+
+
+@pytest.mark.default_layout
+@pytest.mark.parametrize("L,k", [(25, 12), (26, 13)])
+def test_real_packed_spinconserve_production_instance(L, k):
+    """The (14, 10) instance (1024 threads, eight entries per thread, 2^m rows per workgroup) against the oracle."""
+    sub = SpinConserve(L, k)
+    assert sub.vec_swizzle == (14 | (10 << 8))
+    H = models.mbl(L)
+    mat = shell(H, sub, flags=_lib.MAT_REAL_PACKED)
+    n = sub.get_dimension()
+    xr = np.random.RandomState(L).standard_normal(n)
+    want = orc.matvec(orc_msc(H), orc_sub(sub), orc_sub(sub), xr.astype(np.complex128), nthreads=min(16, orc.max_threads()))
+    got, _, _ = _real_mult(mat, sub, xr)
+    scale = max(1.0, np.abs(H.msc['coeffs']).sum()) * np.abs(xr).max()
+    assert np.abs(got.real - want.real).max() <= 64 * 2.2e-16 * scale
+    mat.destroy()
+
+
+@pytest.mark.parametrize("mode", ["restarted", "basis_free", "filtered"])
+def test_eigsolve_real_arithmetic_spinconserve(monkeypatch, small_layout, mode):
+    """eigsolve in real arithmetic on a SpinConserve subspace in the internal layout: eigenvalues against dense
+    diagonalisation, the returned complex states against the reference's residual / orthogonality bars."""
+    from dynamite_amd.computations import eigsolve
+    monkeypatch.setenv("DNM_EIGS_REAL", "1")
+    if mode == "basis_free":
+        monkeypatch.setenv("DNM_EIGS_BASISFREE", "1")
+    if mode == "filtered":
+        monkeypatch.setenv("DNM_EIGS_FILTER", "1")
+    nev = 1 if mode == "basis_free" else 3
+    L, k = 14, 7
+    H = models.mbl(L)
+    sub = SpinConserve(L, k)
+    H.add_subspace(sub)
+    w = np.linalg.eigvalsh(H.to_numpy(subspaces=(sub, sub), sparse=False))
+    ev, vecs = H.eigsolve(nev=nev, tol=1e-11, subspace=sub, getvecs=True)
+    assert eigsolve.last_stats['real_arithmetic'] is True
+    for e in ev[:nev]:
+        assert np.min(np.abs(w - e)) < 1e-9 * max(1.0, abs(e))
+    assert abs(ev[0] - w[0]) < 1e-9 * max(1.0, abs(w[0]))
+    for i, (e, v) in enumerate(zip(ev[:nev], vecs[:nev])):
+        assert v.vec.internal and v.vec.rows == sub.get_dimension()
+        Hv = H.dot(v)
+        assert abs(v.norm() - 1) < 1e-10
+        r = Hv.copy()
+        r.axpy(-e, v)
+        assert r.norm() < 1e-9 * max(1.0, abs(e))
+        assert np.abs(v.to_numpy().imag).max() == 0.0
+        for j in range(i):
+            assert abs(v.dot(vecs[j])) < 1e-10
