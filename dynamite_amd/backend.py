@@ -509,8 +509,24 @@ class Vec:
         self.array = None
 
 
+class RawVec:
+    """A device array taken as a vector in a matrix's own layout without the bookkeeping of ``Vec`` -- what the solver
+    hooks wrap raw work-vector pointers of a real-arithmetic SpinConserve operator in (its vectors are one double per
+    position of the layout, i.e. half as many complex128 elements as ``Vec`` would size them)."""
+    internal = True
+
+    def __init__(self, array, swz):
+        self.array, self.swz = array, int(swz)
+        self.local_size = self.rows = array.numel()
+
+    @property
+    def ptr(self):
+        return C.c_void_p(self.array.data_ptr())
+
+
 class ShellMat:
     """Matrix-free operator handle (PETSc MatShell + shell_context in the reference)."""
+    real_packed = False       # DNM_MAT_REAL_PACKED handle (set by build_mat)
 
     def __init__(self, handle, left_c, right_c, nranks, rank):
         self._h = handle
@@ -1023,6 +1039,8 @@ class ShellMat:
         self._needs = [nd for _, nd in allw] if needs is not None else None
         if self.swz_right >= 256:      # internal SpinConserve layout: ownership and windows are positions of the layout
             self._owned = [layout_partition(self._keep[1], self.nranks, q)[:2] for q in range(self.nranks)]
+            if self.real_packed:       # real vectors: the handle counts pairs of positions (complex128 elements)
+                self._owned = [(a // 2, b // 2) for a, b in self._owned]
         else:
             self._owned = [split_ownership(self.N, self.nranks, q) for q in range(self.nranks)]
 
@@ -1149,6 +1167,7 @@ def build_mat(masks, mask_offsets, signs, coeffs, left_subspace, right_subspace,
     h = create_mat(masks, mask_offsets, signs, coeffs, lc, rc, xparity, flags,
                    rank=config.rank, nranks=config.world_size)
     mat = ShellMat(h, lc, rc, config.world_size, config.rank)
+    mat.real_packed = bool(flags & _lib.MAT_REAL_PACKED)
     if not xparity:
         mat._msc = (np.array(masks, dtype=np.int64), np.array(mask_offsets, dtype=np.int64),
                     np.array(signs, dtype=np.int64), np.array(coeffs, dtype=np.complex128), left_subspace, right_subspace)

@@ -29,14 +29,17 @@ def _hooks(mat, keep):
     if d is None:
         return None
     import torch
-    from .backend import Vec
+    from .backend import Vec, RawVec
 
     def mult(ctx, xp, yp):
         try:
             n = mat.n_local
             # wrap raw device pointers as Vec views without copying
-            x = Vec(mat.N, array=_tensor_from_ptr(xp, n), swz=mat.swz_right, sub_c=mat._keep[1])
-            y = Vec(mat.M, array=_tensor_from_ptr(yp, n), swz=mat.swz_left, sub_c=mat._keep[0])
+            if mat.real_packed:
+                x, y = RawVec(_tensor_from_ptr(xp, n), mat.swz_right), RawVec(_tensor_from_ptr(yp, n), mat.swz_left)
+            else:
+                x = Vec(mat.N, array=_tensor_from_ptr(xp, n), swz=mat.swz_right, sub_c=mat._keep[1])
+                y = Vec(mat.M, array=_tensor_from_ptr(yp, n), swz=mat.swz_left, sub_c=mat._keep[0])
             mat.mult(x, y)
             return 0
         except Exception as e:   # pragma: no cover
@@ -220,7 +223,7 @@ def eigsolve(H, getvecs=False, nev=1, which='lowest', target=None, tol=None, sub
         want_real = er[:1] == '1'
     if want_real is None:
         want_real = mat.n_local >= (1 << 23)
-    if config.world_size == 1 and want_real:
+    if want_real:                   # (several ranks: SpinConserve in the internal layout only)
         pm = H.get_real_packed_mat(subspace)
         if pm is not None:
             mat = pm
@@ -300,8 +303,8 @@ def eigsolve(H, getvecs=False, nev=1, which='lowest', target=None, tol=None, sub
             # the real eigenvector as the complex state of the full dimension (imaginary parts zero)
             v._vec = Vec(cmat.N, swz=cmat.swz_right, sub_c=cmat._keep[1])
             if v._vec.internal:           # SpinConserve: one double per position of the layout
-                _lib.check(_lib.lib().dnm_vec_layout_unpack_real(C.byref(cmat._keep[1]), v._vec.ptr,
-                                                                 C.c_void_p(piece.data_ptr()), _stream()))
+                _lib.check(_lib.lib().dnm_vec_layout_unpack_real(C.byref(cmat._keep[1]), C.byref(v._vec._part),
+                                                                 v._vec.ptr, C.c_void_p(piece.data_ptr()), _stream()))
             else:                         # Full / Parity: two amplitudes per element
                 _lib.check(_lib.lib().dnm_vec_unpack_real(v._vec.ptr, C.c_void_p(piece.data_ptr()), mat.n_local,
                                                           mat.swz_right, cmat.swz_right, _stream()))

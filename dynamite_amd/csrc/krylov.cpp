@@ -168,7 +168,7 @@ static void jacobi_eig(int n, std::vector<double> &A, std::vector<double> &w, st
 // y = A x - b z + c2 z2 (dnm_mat_mult_sub2); the scale that brings s_d back to O(1) is known on the host.
 // seeded start vector in the layout of A's vectors (padding of an internal SpinConserve layout stays zero)
 static int random_start(dnm_mat *A, void *x, int64_t n_local, uint64_t seed, int64_t offset, hipStream_t st) {
-  if (A->use_sc3 && A->real_packed) return sc3_random_real(*A->sc3->ly, (double *)x, seed, st);
+  if (A->use_sc3 && A->real_packed) return sc3_random_real(*A->sc3->ly, (double *)x, seed, st, A->sc3->T0, A->sc3->T1);
   if (A->use_sc3) return sc3_random(*A->sc3->ly, x, seed, st, A->sc3->T0, A->sc3->T1);
   return vk_random(x, n_local, seed, offset, st, A->right.host.swz);
 }
@@ -1240,7 +1240,7 @@ int dnm_eigsolve(dnm_mat *A, int64_t n_local, int nev, int which, double tol, in
   hipStream_t st = (hipStream_t)stream;
   Ops ops{A, hooks, st, n_local};
   ops.real = A->real_packed;
-  DNM_CHECK(!A->real_packed || !(hooks && hooks->mult), "real-packed operators run on one rank");
+  DNM_CHECK(!A->real_packed || A->use_sc3 || !(hooks && hooks->mult), "real-packed Full / Parity operators run on one rank");
   stats->reason = 0; stats->its = 0; stats->matvecs = 0; stats->nconv = 0; stats->err_est = 0;
   const int64_t Nglob = A->N;
   if (tol <= 0) tol = 1e-8;

@@ -882,7 +882,9 @@ int dnm_mat_create(int64_t nmasks, const int64_t *masks, const int64_t *mask_off
     if (want_real) {
       // real vectors in the same positions of the layout, one double each: a vector is il / 2 complex128 elements for
       // everything that sweeps it (the Krylov kernels); the two tiled passes only (chain operators, real symmetric)
-      DNM_CHECK(A->nranks == 1, "real-packed operators run on one rank");
+      // Partitions: every position the C ABI speaks of for such a handle -- ownership, column windows, chunk maps,
+      // window starts -- counts complex128 ELEMENTS (pairs of entries; blocks of equal top bits start at multiples of 8
+      // entries), so the caller's exchange code is the one it runs for complex vectors, on half the bytes
       DNM_CHECK(A->sc3->tiled && A->sc3->sym && A->sc3->diag_mode != 1,
                 "operator has an imaginary matrix element or is not a chain: no real-packed form in this layout");
       A->real_packed = true;
@@ -1228,7 +1230,7 @@ int dnm_mat_mult(dnm_mat *A, const void *x, void *y, void *stream) {
 int dnm_mat_ownership(const dnm_mat *A, int64_t *row0, int64_t *m_local) {
   DNM_CHECK(A, "null matrix");
   // (internal SpinConserve layout: the rank's range of the layout -- the index space its windows are expressed in)
-  if (row0) *row0 = A->use_sc3 ? A->sc3->row0 : A->row0;
+  if (row0) *row0 = A->use_sc3 ? (A->real_packed ? A->sc3->row0 / 2 : A->sc3->row0) : A->row0;
   if (m_local) *m_local = A->m_local;
   return 0;
 }
@@ -1237,6 +1239,10 @@ int dnm_mat_column_window(dnm_mat *A, int64_t *cmin, int64_t *cmax, void *stream
   DNM_CHECK(A && cmin && cmax, "bad argument");
   if (A->use_sc3) {          // positions of the internal layout, from the T blocks the rank's rows reach (host tables)
     A->sc3->window(cmin, cmax);
+    if (A->real_packed) {     // whole blocks: [cmin, cmax + 1) is a range of pairs
+      *cmin /= 2;
+      *cmax = (*cmax + 1) / 2 - 1;
+    }
     return 0;
   }
   DNM_CHECK(!A->host_only, "bad argument");
@@ -1273,7 +1279,7 @@ int dnm_mat_column_chunks(dnm_mat *A, int chunk_shift, uint8_t *map, int64_t nch
   DNM_CHECK(nchunks == (hi >> chunk_shift) - first + 1, "the window [%lld, %lld] has %lld chunks of 2^%d columns",
             (long long)lo, (long long)hi, (long long)((hi >> chunk_shift) - first + 1), chunk_shift);
   if (A->use_sc3) {
-    A->sc3->chunks(chunk_shift, first, nchunks, map);
+    A->sc3->chunks(chunk_shift + (A->real_packed ? 1 : 0), first, nchunks, map);      // (chunks of 2^shift elements)
     return 0;
   }
   const int nb = A->sc_pair ? sc_num_blocks(A->m_local) : gather_num_blocks(A->m_local);
@@ -1303,7 +1309,9 @@ int dnm_mat_mult_window(dnm_mat *A, const void *x_window, int64_t win_start, int
   DNM_CHECK(win_start <= lo && win_start + win_len > hi,
             "window [%lld, %lld) does not cover the columns [%lld, %lld] this rank reads", (long long)win_start,
             (long long)(win_start + win_len), (long long)lo, (long long)hi);
-  if (A->use_sc3) return sc3_mult(A, x_window, y_local, nullptr, 0.0, nullptr, 0.0, 0.0, nullptr, stream, win_start);
+  if (A->use_sc3)
+    return sc3_mult(A, x_window, y_local, nullptr, 0.0, nullptr, 0.0, 0.0, nullptr, stream,
+                    A->real_packed ? 2 * win_start : win_start);
   if (A->sc_pair) return launch_sc(A, win_start, win_len, x_window, y_local, stream);
   // any other subspace pair: one thread per row, columns read from the window (index order)
   return launch_gather_matvec(A->dmsc, A->left.dev, A->right.dev, A->m_local,
@@ -1410,7 +1418,8 @@ int dnm_mat_mult_window_remote(dnm_mat *A, const void *x_window, int64_t win_sta
   DNM_CHECK(win_start <= lo && win_start + win_len > hi,
             "window [%lld, %lld) does not cover the positions [%lld, %lld] this rank reads", (long long)win_start,
             (long long)(win_start + win_len), (long long)lo, (long long)hi);
-  return sc3_mult(A, x_window, y_local, nullptr, 0.0, nullptr, 0.0, 0.0, nullptr, stream, win_start, 2);
+  return sc3_mult(A, x_window, y_local, nullptr, 0.0, nullptr, 0.0, 0.0, nullptr, stream,
+                  A->real_packed ? 2 * win_start : win_start, 2);
 }
 
 int dnm_mat_exchange_plan(const dnm_mat *A, int *nsend, dnm_xfer *sends, int *nrecv, dnm_xfer *recvs) {

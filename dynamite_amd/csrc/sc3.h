@@ -118,8 +118,8 @@ int sc3_positions(const Sc3Layout &Ly, int64_t n, const int64_t *idx, int64_t *p
 // counter-based normal deviates keyed by the global reference index (the numbers reference order would get), padding zero
 int sc3_random(const Sc3Layout &Ly, void *x, uint64_t seed, hipStream_t st, uint32_t T0 = 0, uint32_t T1 = 0xffffffffu);
 // real vectors of the layout (one double per position): normal deviates / the complex128 vector a real one stands for
-int sc3_random_real(const Sc3Layout &Ly, double *x, uint64_t seed, hipStream_t st);
-int sc3_unpack_real(const Sc3Layout &Ly, void *dst, const double *src, hipStream_t st);
+int sc3_random_real(const Sc3Layout &Ly, double *x, uint64_t seed, hipStream_t st, uint32_t T0 = 0, uint32_t T1 = 0xffffffffu);
+int sc3_unpack_real(const Sc3Layout &Ly, void *dst, const double *src, hipStream_t st, uint32_t T0 = 0, uint32_t T1 = 0xffffffffu);
 
 // ---- the operator in this layout ---------------------------------------------------------------------------------
 // Per-operator device data of the tiled passes.  A chain bond b couples spins b, b+1 with the two matrix elements of

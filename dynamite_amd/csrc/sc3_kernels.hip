@@ -957,11 +957,11 @@ sc3_random_kernel(const Sc3Tab S, const uint32_t *__restrict__ rows, c128 *__res
     x[R.base - ioff + r] = r < R.nrows ? philox_normal((uint64_t)(nat + r), seed) : make_double2(0.0, 0.0);
 }
 __global__ void __launch_bounds__(256)
-sc3_random_real_kernel(const Sc3Tab S, const uint32_t *__restrict__ rows, double *__restrict__ x, uint64_t seed) {
+sc3_random_real_kernel(const Sc3Tab S, const uint32_t *__restrict__ rows, double *__restrict__ x, uint64_t seed, int64_t ioff) {
   const RowId R = decode_row(rows[blockIdx.x], S);
   const int64_t nat = S.nbase[R.T] + S.ncoff[(int64_t)R.kr * ((int64_t)1 << S.w) + R.W];
   for (int r = threadIdx.x; r < R.pitch; r += 256)
-    x[R.base + r] = r < R.nrows ? philox_normal((uint64_t)(nat + r), seed).x : 0.0;
+    x[R.base - ioff + r] = r < R.nrows ? philox_normal((uint64_t)(nat + r), seed).x : 0.0;
 }
 __global__ void __launch_bounds__(256) sc3_unpack_real_kernel(c128 *__restrict__ dst, const double *__restrict__ src, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
@@ -1210,15 +1210,19 @@ int sc3_random(const Sc3Layout &Ly, void *x, uint64_t seed, hipStream_t st, uint
   DNM_HIP(hipGetLastError());
   return 0;
 }
-int sc3_random_real(const Sc3Layout &Ly, double *x, uint64_t seed, hipStream_t st) {
+int sc3_random_real(const Sc3Layout &Ly, double *x, uint64_t seed, hipStream_t st, uint32_t T0, uint32_t T1) {
   DNM_CHECK(Ly.on_device, "layout tables are not on the device");
-  hipLaunchKernelGGL(sc3_random_real_kernel, dim3((unsigned)Ly.rows.size()), dim3(256), 0, st, Ly.dev,
-                     (const uint32_t *)Ly.d_rows, x, seed);
+  const RowRange r = row_range(Ly, T0, T1);
+  if (!r.count) return 0;
+  hipLaunchKernelGGL(sc3_random_real_kernel, dim3((unsigned)r.count), dim3(256), 0, st, Ly.dev,
+                     (const uint32_t *)Ly.d_rows + r.first, x, seed, r.ioff);
   DNM_HIP(hipGetLastError());
   return 0;
 }
-int sc3_unpack_real(const Sc3Layout &Ly, void *dst, const double *src, hipStream_t st) {
-  const int64_t n = Ly.host.nint;
+int sc3_unpack_real(const Sc3Layout &Ly, void *dst, const double *src, hipStream_t st, uint32_t T0, uint32_t T1) {
+  int64_t is, n, ns, nl;
+  sc3_range(Ly, T0, T1, &is, &n, &ns, &nl);
+  if (n <= 0) return 0;
   const unsigned nb = (unsigned)std::min<int64_t>((n + 255) / 256, (int64_t)1 << 22);
   hipLaunchKernelGGL(sc3_unpack_real_kernel, dim3(nb), dim3(256), 0, st, (c128 *)dst, src, n);
   DNM_HIP(hipGetLastError());

@@ -230,11 +230,14 @@ int dnm_vec_layout_positions_host(const dnm_subspace *s, const dnm_partition *pa
   return 0;
 }
 
-int dnm_vec_layout_unpack_real(const dnm_subspace *s, void *dst, const void *src, void *stream) {
-  DNM_CHECK(dst && src && dst != src, "dnm_vec_layout_unpack_real works out of place on non-null arrays");
+int dnm_vec_layout_unpack_real(const dnm_subspace *s, const dnm_partition *part, void *dst, const void *src, void *stream) {
   const Sc3Layout *ly = layout_of(s, true);
   if (!ly) return 1;
-  return sc3_unpack_real(*ly, dst, (const double *)src, S(stream));
+  uint32_t T0, T1;
+  DNM_TRY(part_range(*ly, part, &T0, &T1));
+  if (T0 >= T1) return 0;
+  DNM_CHECK(dst && src && dst != src, "dnm_vec_layout_unpack_real works out of place on non-null arrays");
+  return sc3_unpack_real(*ly, dst, (const double *)src, S(stream), T0, T1);
 }
 
 int dnm_vec_layout_set_random(const dnm_subspace *s, const dnm_partition *part, void *x, uint64_t seed, void *stream) {

@@ -328,8 +328,9 @@ class Operator:
         if key in self._mats:
             return self._mats[key]
         mat = None
-        ok = isinstance(subspace, (Full, Parity)) or (isinstance(subspace, SpinConserve) and subspace.vec_swizzle >= 256)
-        if ok and config.world_size == 1 and self.shell:
+        sc = isinstance(subspace, SpinConserve) and subspace.vec_swizzle >= 256
+        ok = sc or (isinstance(subspace, (Full, Parity)) and config.world_size == 1)
+        if ok and self.shell:
             self.establish_L()
             self.reduce_msc()
             masks, mask_offsets = msc_tools.get_mask_offsets(self.msc)

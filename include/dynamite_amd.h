@@ -317,10 +317,10 @@ int dnm_vec_swizzle_copy(void *dst, const void *src, int64_t n, int swizzle, voi
  * elements, element j = the real amplitudes of indices 2j and 2j + 1, in the layout swizzle_packed; dst gets
  * 2 * n_packed elements with zero imaginary parts in the layout swizzle_out; dst != src */
 int dnm_vec_unpack_real(void *dst, const void *src, int64_t n_packed, int swizzle_packed, int swizzle_out, void *stream);
-/* The same for a SpinConserve subspace in the internal layout (one rank): src holds one double per position of the
- * layout (dnm_vec_layout_size(s) doubles -- what a DNM_MAT_REAL_PACKED operator of that subspace multiplies), dst
- * gets the complex128 vector of the layout with zero imaginary parts; dst != src */
-int dnm_vec_layout_unpack_real(const dnm_subspace *s, void *dst, const void *src, void *stream);
+/* The same for a SpinConserve subspace in the internal layout: src holds one double per position of the rank's part of
+ * the layout (what a DNM_MAT_REAL_PACKED operator of that subspace multiplies; part may be NULL on one rank), dst gets
+ * the complex128 vector of the layout with zero imaginary parts; dst != src */
+int dnm_vec_layout_unpack_real(const dnm_subspace *s, const dnm_partition *part, void *dst, const void *src, void *stream);
 /* Vectors of a SpinConserve subspace in the internal layout (dnm_subspace.vec_swizzle = a | w << 8).  No counterpart
  * in the reference: what a petsc4py Vec of that subspace holds, element by element, is reached through these.
  * size: elements of a vector (rows + padding); copy: to_internal != 0: dst (internal) <- src (reference order, C(L,k)

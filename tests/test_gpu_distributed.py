@@ -197,6 +197,24 @@ def _worker(rank, world, port, case, out_dir):
     v1g = v1[0].to_numpy(to_all=True)
     assert np.linalg.norm(Hs @ v1g - e1[0] * v1g) < 1e-7
 
+    if case == "sc3":
+        # the same solves in real arithmetic (DNM_MAT_REAL_PACKED on the partitioned internal layout: one double per
+        # position, windows and exchange in pairs of positions -- half the bytes on the links)
+        from dynamite_amd.computations import eigsolve as _eig
+        os.environ["DNM_EIGS_REAL"] = "1"
+        er, vr = H.eigsolve(nev=2, getvecs=True, tol=1e-10, subspace=sub)
+        assert _eig.last_stats['real_arithmetic'] is True
+        assert np.max(np.abs(np.array(er[:2]) - lowest)) < 1e-8, "partitioned eigsolve, real arithmetic"
+        vg = vr[0].to_numpy(to_all=True)
+        assert np.abs(vg.imag).max() == 0.0 and np.linalg.norm(Hs @ vg - er[0] * vg) < 1e-7
+        os.environ["DNM_EIGS_BASISFREE"] = "1"
+        e2, v2 = H.eigsolve(nev=1, getvecs=True, tol=1e-10, subspace=sub)
+        os.environ.pop("DNM_EIGS_BASISFREE")
+        os.environ.pop("DNM_EIGS_REAL")
+        assert _eig.last_stats['real_arithmetic'] is True and abs(e2[0] - lowest[0]) < 1e-8
+        v2g = v2[0].to_numpy(to_all=True)
+        assert np.linalg.norm(Hs @ v2g - e2[0] * v2g) < 1e-7
+
     # reduced density matrix / entropy of the partitioned state
     for keep in ([0, 1, 2], [L - 3, L - 2], [1, 5, L - 1]):
         rho = reduced_density_matrix(z, keep)

@@ -344,7 +344,7 @@ def _real_mult(mat, sub, xr):
     _lib.check(_lib.lib().dnm_mat_mult(mat.handle, C.c_void_p(xd.data_ptr()), C.c_void_p(yd.data_ptr()), None))
     torch.cuda.synchronize()
     out = vec_for(sub)
-    _lib.check(_lib.lib().dnm_vec_layout_unpack_real(C.byref(sub._c()), out.ptr, C.c_void_p(yd.data_ptr()), None))
+    _lib.check(_lib.lib().dnm_vec_layout_unpack_real(C.byref(sub._c()), None, out.ptr, C.c_void_p(yd.data_ptr()), None))
     pad = np.ones(v.local_size, dtype=bool)
     pad[v.positions(torch.arange(sub.get_dimension(), device=v.array.device)).cpu().numpy()] = False
     assert np.all(yd.cpu().numpy()[pad] == 0.0), "padding of the result is not zero"
