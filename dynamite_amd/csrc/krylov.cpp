@@ -1240,7 +1240,6 @@ int dnm_eigsolve(dnm_mat *A, int64_t n_local, int nev, int which, double tol, in
   hipStream_t st = (hipStream_t)stream;
   Ops ops{A, hooks, st, n_local};
   ops.real = A->real_packed;
-  DNM_CHECK(!A->real_packed || A->use_sc3 || !(hooks && hooks->mult), "real-packed Full / Parity operators run on one rank");
   stats->reason = 0; stats->its = 0; stats->matvecs = 0; stats->nconv = 0; stats->err_est = 0;
   const int64_t Nglob = A->N;
   if (tol <= 0) tol = 1e-8;

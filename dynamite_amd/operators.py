@@ -329,7 +329,8 @@ class Operator:
             return self._mats[key]
         mat = None
         sc = isinstance(subspace, SpinConserve) and subspace.vec_swizzle >= 256
-        ok = sc or (isinstance(subspace, (Full, Parity)) and config.world_size == 1)
+        ws = config.world_size
+        ok = sc or (isinstance(subspace, (Full, Parity)) and ws & (ws - 1) == 0)
         if ok and self.shell:
             self.establish_L()
             self.reduce_msc()
@@ -338,7 +339,8 @@ class Operator:
                 mat = backend.build_mat(
                     masks=np.ascontiguousarray(masks), mask_offsets=np.ascontiguousarray(mask_offsets),
                     signs=np.ascontiguousarray(self.msc['signs']), coeffs=np.ascontiguousarray(self.msc['coeffs']),
-                    left_subspace=subspace._to_c(), right_subspace=subspace._to_c(), flags=_lib.MAT_REAL_PACKED)
+                    left_subspace=subspace._to_c(), right_subspace=subspace._to_c(), flags=_lib.MAT_REAL_PACKED,
+                    exchange='partner')      # (the transposed exchange is not built for packed operators)
             except _lib.BackendError:
                 mat = None            # an imaginary matrix element, or a vector too small for the tiled kernel
         self._mats[key] = mat

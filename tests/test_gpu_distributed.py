@@ -197,6 +197,18 @@ def _worker(rank, world, port, case, out_dir):
     v1g = v1[0].to_numpy(to_all=True)
     assert np.linalg.norm(Hs @ v1g - e1[0] * v1g) < 1e-7
 
+    if case in ("full", "full_partner", "parity"):
+        # real arithmetic on a partitioned Full / Parity operator: the packed operator (bit 0 of the index = the lane)
+        # exchanges partner blocks of half the bytes (the transposed exchange is not built for it: partner blocks on
+        # four ranks too)
+        from dynamite_amd.computations import eigsolve as _eig
+        os.environ["DNM_EIGS_REAL"] = "1"
+        er, vr = H.eigsolve(nev=2, getvecs=True, tol=1e-10, subspace=sub)
+        os.environ.pop("DNM_EIGS_REAL")
+        assert _eig.last_stats['real_arithmetic'] is True
+        assert np.max(np.abs(np.array(er[:2]) - lowest)) < 1e-8, "partitioned eigsolve, real arithmetic"
+        vg = vr[0].to_numpy(to_all=True)
+        assert np.abs(vg.imag).max() == 0.0 and np.linalg.norm(Hs @ vg - er[0] * vg) < 1e-7
     if case == "sc3":
         # the same solves in real arithmetic (DNM_MAT_REAL_PACKED on the partitioned internal layout: one double per
         # position, windows and exchange in pairs of positions -- half the bytes on the links)

@@ -608,3 +608,33 @@ def test_real_packed_refuses_imaginary_elements():
     with pytest.raises(_lib.BackendError, match="imaginary"):
         backend.create_mat(masks, offs, H.msc['signs'], H.msc['coeffs'], c, c, False,
                            _lib.MAT_HOST_ONLY | _lib.MAT_REAL_PACKED, 0, 1)
+
+
+@pytest.mark.parametrize("P", [2, 4, 8])
+def test_real_packed_partitioned_plan(monkeypatch, P):
+    """A real-packed operator on 2^p ranks: the rank bits are the top index bits and the packed bit is bit 0, so the
+    partner exchange is that of an operator on one bit less -- rank-local and partner passes (emulated ranks, exchange
+    = numpy slicing of the packed vector) reproduce the oracle for a real x."""
+    from dynamite_amd import _lib
+    L = 15
+    _cfg(monkeypatch, 8, 2)
+    H = models.mbl(L)
+    omsc, arrs = _orc_msc(H)
+    sub = Full(L=L)
+    xr = np.random.RandomState(9).standard_normal(1 << L)
+    xp = xr[0::2] + 1j * xr[1::2]
+    nloc = (1 << (L - 1)) // P
+    yp = np.zeros(1 << (L - 1), dtype=complex)
+    for r in range(P):
+        hm = HostMat(*arrs, sub._c(), sub._c(), rank=r, nranks=P, flags=_lib.MAT_REAL_PACKED)
+        assert hm.tiled and (1 << hm.n_loc) == nloc and hm.recvs
+        yl = np.zeros(nloc, dtype=complex)
+        for p in hm.local:
+            run_pass(hm, p, xp[r * nloc:(r + 1) * nloc], yl)
+        for i, (partner, off, cnt) in enumerate(hm.recvs):
+            run_remote(hm, i, xp[partner * nloc + off:partner * nloc + off + cnt], yl)
+        yp[r * nloc:(r + 1) * nloc] = yl
+    y = np.empty(1 << L)
+    y[0::2], y[1::2] = yp.real, yp.imag
+    ref = orc.matvec(omsc, orc.full(L), orc.full(L), xr.astype(complex)).real
+    assert np.max(np.abs(y - ref)) <= 64 * len(arrs[0]) * EPS * np.abs(xr).max()
