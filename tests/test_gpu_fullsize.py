@@ -255,6 +255,71 @@ def test_config5_rank3_of_eight_internal_layout():
     mat.destroy()
 
 
+def test_config5_rank3_of_eight_real_arithmetic():
+    """The same share in real arithmetic (DNM_MAT_REAL_PACKED: one double per position of the layout; ownership, window and
+    window start of the C ABI count pairs of positions): the window pass on the halved tables and the real lo pass at
+    full size, sampled rows recomputed on the host from the definition with the real x values."""
+    import ctypes as C
+    import torch
+    L, k, P, R = 36, 18, 8, 3
+    sub = SpinConserve(L, k)
+    d = sub._c()
+    H = models.heisenberg(L)
+    arrs = marshal(H)
+    masks, offs, signs, coeffs = arrs
+    istart, ilen, nstart, nlen = backend.layout_partition(d, P, R)
+    h = backend.create_mat(*arrs, d, d, flags=_lib.MAT_REAL_PACKED, rank=R, nranks=P)
+    mat = backend.ShellMat(h, d, d, P, R)
+    mat.real_packed = True
+    assert "two-pass" in mat.describe()
+    assert (mat.row0, mat.m_local) == (istart // 2, ilen // 2)
+    lo, hi = mat.column_window()                     # pairs of positions
+    assert 2 * lo <= istart and istart + ilen <= 2 * (hi + 1)
+    _need(16 * (hi - lo + 1 + ilen // 2) + (4 << 30))
+    Lb = _lib.lib()
+    xw = backend.Vec(hi - lo + 1)
+    xw.set_random(3)
+    y = backend.Vec(ilen // 2)
+    _lib.check(Lb.dnm_mat_mult_window(mat.handle, xw.ptr, lo, hi - lo + 1, y.ptr, None))
+    torch.cuda.synchronize()
+    xd = torch.view_as_real(xw.array).reshape(-1)    # one double per position, from position 2 * lo on
+    yd = torch.view_as_real(y.array).reshape(-1)
+
+    def positions(idx, part):
+        idx = np.ascontiguousarray(idx, dtype=np.int64)
+        out = np.empty_like(idx)
+        _lib.check(Lb.dnm_vec_layout_positions_host(C.byref(d), C.byref(part) if part is not None else None, idx.size,
+                                                    _lib.p64(idx), _lib.p64(out)))
+        return out
+    rs = np.random.RandomState(2)
+    rows = np.unique(np.concatenate([[0, nlen - 1], rs.randint(0, 1 << 30, 64) % nlen,
+                                     [(nlen >> s) for s in range(1, 30)]])).astype(np.int64)
+    kets = sub.idx_to_state(rows + nstart)
+    lpos = positions(rows, _lib.Partition(R, P))
+    ys = yd[torch.from_numpy(lpos).to(yd.device)].cpu().numpy()
+    worst, scale = 0.0, 0.0
+    for yv, ket in zip(ys, kets):
+        acc = 0.0
+        bras = int(ket) ^ masks
+        cols = sub.state_to_idx(bras)
+        live = cols >= 0
+        gpos = np.full(cols.shape, -1, dtype=np.int64)
+        gpos[live] = positions(cols[live], None)
+        for m in range(len(masks)):
+            if cols[m] < 0:
+                continue
+            c = 0j
+            for t in range(offs[m], offs[m + 1]):
+                c += (1 - 2 * (bin(int(bras[m]) & int(signs[t])).count("1") & 1)) * coeffs[t]
+            if c != 0:
+                assert c.imag == 0 and 2 * lo <= gpos[m] < 2 * (hi + 1)
+                acc += c.real * float(xd[int(gpos[m]) - 2 * lo].item())
+        worst = max(worst, abs(acc - yv))
+        scale = max(scale, abs(acc))
+    assert worst <= 1e-13 * max(1.0, scale) * len(masks), (worst, scale)
+    mat.destroy()
+
+
 def test_config4_hermiticity_between_ranks():
     """<u_r, H_rs v_s> = conj(<v_s, H_sr u_r>) with both ranks' shares of L=34 / P=8 resident: the remote passes of
     rank 5 fed from slices of rank s's block, those of rank s fed from rank 5's -- for the partner across the

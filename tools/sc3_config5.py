@@ -55,9 +55,12 @@ def main():
     import torch
     from dynamite_amd.config import config
     config._initialize()
-    h = backend.create_mat(masks, offs, H.msc['signs'], H.msc['coeffs'], d, d, False, 0, rank, P)
+    real = "--real" in sys.argv       # real arithmetic: one double per position, every position of the ABI in pairs
+    h = backend.create_mat(masks, offs, H.msc['signs'], H.msc['coeffs'], d, d, False, _lib.MAT_REAL_PACKED if real else 0,
+                           rank, P)
     mat = backend.ShellMat(h, d, d, P, rank)
-    print(mat.describe().strip())
+    mat.real_packed = real
+    print(mat.describe().strip() + (" [REAL arithmetic: sizes below count pairs of positions]" if real else ""))
     lo, hi = mat.column_window()
     wlen = hi - lo + 1
     print("rank %d: window of %.1f GiB, rows %.1f GiB" % (rank, 16 * wlen / 2 ** 30, 16 * mat.m_local / 2 ** 30), flush=True)
@@ -81,8 +84,8 @@ def main():
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / n
     rows = backend.layout_partition(d, P, rank)[3]
-    print("rank %d of %d, SpinConserve(%d,%d): %.2f ms per multiply for %d rows = %.2f Grows/s" % (rank, P, L, k, ms, rows,
-                                                                                                 rows / ms / 1e6))
+    print("rank %d of %d, SpinConserve(%d,%d)%s: %.2f ms per multiply for %d rows = %.2f Grows/s"
+          % (rank, P, L, k, " REAL" if real else "", ms, rows, rows / ms / 1e6))
     assert torch.isfinite(torch.view_as_real(y)).all()
     # the order of a partitioned multiply: the lo pass first (it needs the rank's own rows only and runs under the
     # exchange), then the window pass adds what reaches other blocks
