@@ -442,6 +442,20 @@ sc3_lo_pass_r(const Sc3Tab S, const Sc3Op O, const uint32_t *__restrict__ perm, 
   const int64_t lbase = base - C.row0;
   // entry i of this thread: pair i >> 1, lane i & 1
 #define SC3R_ENT(i) (2 * (tsub + ((i) >> 1) * NTS) + ((i) & 1))
+  // where entry r of the row sits in the LDS slice.  The lanes of a wavefront read entries two apart (their own lane
+  // of consecutive pairs, shifted by the bond's offset): two lanes per bank.  -DDNM_SC3R_DEINT=1 stores even entries
+  // in the first half of the slice and odd ones in the second, which removes the conflicts -- and measured SLOWER
+  // (5.11 against 4.45 ms at SpinConserve(32,16): the index arithmetic and 12-16 B/lane of spills cost more than the
+  // conflicts; gpurun_out/r04_s16) -- so the interleaved form is the default
+#ifndef DNM_SC3R_DEINT
+#define DNM_SC3R_DEINT 0
+#endif
+#if DNM_SC3R_DEINT
+  const int half = (NT * EPT >> logm) >> 1;
+#define SC3R_LDS(r) (((r) >> 1) + (((r) & 1) ? half : 0))
+#else
+#define SC3R_LDS(r) (r)
+#endif
 
   SC3_PRIO_MEM();
   uint32_t lowp[PPT];                                   // the Lo patterns of a pair's entries, 16 bits each
@@ -544,7 +558,12 @@ sc3_lo_pass_r(const Sc3Tab S, const Sc3Op O, const uint32_t *__restrict__ perm, 
     const int r = SC3R_ENT(i);
     acc[i] = acc[i + 1] = 0.0;
     if (r < p) {
+#if DNM_SC3R_DEINT
+      xs[r >> 1] = xv[i];
+      xs[half + (r >> 1)] = xv[i + 1];
+#else
       *reinterpret_cast<d2v *>(xs + r) = d2v{xv[i], xv[i + 1]};
+#endif
       if (DIAGM == 1) {
         const d2v dg = __builtin_nontemporal_load(reinterpret_cast<const d2v *>(O.diag + lbase + r));
         acc[i] = dg.x * xv[i];
@@ -607,7 +626,7 @@ sc3_lo_pass_r(const Sc3Tab S, const Sc3Op O, const uint32_t *__restrict__ perm, 
       if (r < nrows) {
         double dg = dl[r] + dg0;
         for (int j = 0; j < O.ngroups; ++j) dg += flip(dsh[5 * sub + j + 1], (uint32_t)__popc(SC3R_PAT(i) & O.glo[j]) & 1u);
-        acc[i] = fma(dg, xs[r], acc[i]);
+        acc[i] = fma(dg, xs[SC3R_LDS(r)], acc[i]);
       }
     }
   }
@@ -622,7 +641,8 @@ sc3_lo_pass_r(const Sc3Tab S, const Sc3Op O, const uint32_t *__restrict__ perm, 
       if (r < nrows && (pair == 1u || pair == 2u)) {
         const int ord0 = __popc(pt & ((1u << lo) - 1u));
         const int d = cl[lo * (A + 1) + ord0];
-        acc[i] = fma(ure, xs[pair == 1u ? r + d : r - d], acc[i]);
+        const int rp = pair == 1u ? r + d : r - d;
+        acc[i] = fma(ure, xs[SC3R_LDS(rp)], acc[i]);
       }
     }
   }
@@ -642,7 +662,7 @@ sc3_lo_pass_r(const Sc3Tab S, const Sc3Op O, const uint32_t *__restrict__ perm, 
             if (C.zinit2) a2[b] = fma(C.z2re, reinterpret_cast<const double *>(C.zinit2)[lbase + r + b], a2[b]);
           }
           if (ACC && C.dot_out) {
-            dr = fma(xs[r + b], a2[b], dr);
+            dr = fma(xs[SC3R_LDS(r + b)], a2[b], dr);
             dn = fma(a2[b], a2[b], dn);
           }
         } else {
@@ -654,6 +674,7 @@ sc3_lo_pass_r(const Sc3Tab S, const Sc3Op O, const uint32_t *__restrict__ perm, 
   }
 #undef SC3R_ENT
 #undef SC3R_PAT
+#undef SC3R_LDS
   if (ACC && C.dot_out) {
     dr = wave_sum(dr); dn = wave_sum(dn);
     if (lane == 0) {
