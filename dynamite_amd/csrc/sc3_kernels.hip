@@ -410,15 +410,25 @@ sc3_lo_pass(const Sc3Tab S, const Sc3Op O, const uint32_t *__restrict__ perm, co
 // doubles, so the bonds inside Lo (partner r +- d, d of either parity) read 8 bytes.  Real operators have equal `up`
 // and `dn` elements (Hermitian and real), so there is only the SYM form.  Everything per row -- sub-groups, the bond
 // table in the lanes, the on-the-fly diagonal -- is as in sc3_lo_pass.
-constexpr int sc3_lo_cap_r(int a, int nt) { return 2 * sc3_lo_cap(a, nt); }
+// shape of the real lo pass: NTR threads with PPT pairs each (DNM_SC3R_SHAPE 0: as many threads as the complex pass and
+// twice its entries per thread -- 1024 x 8 entries, a 64 KB tile, two workgroups per CU; 1: half the threads, 512 x 8, a
+// 32 KB tile, four workgroups per CU; 2: 1024 x 4, 32 KB, two per CU)
+#ifndef DNM_SC3R_SHAPE
+#define DNM_SC3R_SHAPE 0
+#endif
+constexpr int sc3r_threads(int nt) { return (DNM_SC3R_SHAPE == 1 && nt >= 512) ? nt / 2 : nt; }
+constexpr int sc3r_pairs(int a, int nt) {
+  return (DNM_SC3R_SHAPE == 2 && nt >= 512) ? (cbinom(a, a / 2) / 2 + nt - 1) / nt : (cbinom(a, a / 2) + nt - 1) / nt;
+}
+constexpr int sc3_lo_cap_r(int a, int nt) { return 2 * sc3r_pairs(a, nt) * sc3r_threads(nt); }
 
-template <int A, int NT, int DIAGM, bool ACC>
-__global__ void __launch_bounds__(NT, sc3_win_waves(NT, (sc3_lo_cap_r(A, NT) * 8 + 1023) / 1024 + 1))
+template <int A, int NT, int PPT, int DIAGM, bool ACC>
+__global__ void __launch_bounds__(NT, sc3_win_waves(NT, (NT * 2 * PPT * 8 + 1023) / 1024 + 1))
 sc3_lo_pass_r(const Sc3Tab S, const Sc3Op O, const uint32_t *__restrict__ perm, const Sc3Call C,
               const double *__restrict__ xw, double *__restrict__ y) {
   constexpr int MAXROWS = cbinom(A, A / 2);
-  constexpr int PPT = (MAXROWS + NT - 1) / NT;          // pairs per thread
-  constexpr int EPT = 2 * PPT;                          // entries per thread
+  constexpr int EPT = 2 * PPT;                          // entries per thread (PPT pairs)
+  static_assert(NT * EPT >= MAXROWS, "the longest row does not fit the workgroup");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ int32_t cl[A * (A + 1)];
   __shared__ double red[3 * (NT / 64)];
@@ -1285,6 +1295,7 @@ static std::vector<uint32_t> deal(const std::vector<std::vector<uint32_t>> &grou
 static std::vector<uint32_t> pack_lo_rows(const std::vector<uint32_t> &order, const Sc3Layout &ly, int nt, bool real) {
   const Sc3Tab &S = ly.host;
   const int cap = real ? sc3_lo_cap_r(S.a, nt) : sc3_lo_cap(S.a, nt);      // entries a workgroup's threads hold
+  if (real) nt = sc3r_threads(nt);
   int maxm = 0;
   while (maxm < 3 && (nt >> (maxm + 1)) >= 64) ++maxm;
   auto logm_of = [&](uint32_t e) {
@@ -1567,8 +1578,9 @@ static int launch_two_pass(const Sc3Mat &M, const Sc3Call &call, const double *c
     DNM_CHECK(M.sym && dm != 1, "internal: real vectors need a real operator with the diagonal on the fly");
     using kern_r = void (*)(const Sc3Tab, const Sc3Op, const uint32_t *, const Sc3Call, const double *, double *);
     kern_r kR = nullptr;
-    if (dm == 0) kR = lo_first ? (kern_r)sc3_lo_pass_r<A, NT, 0, false> : (kern_r)sc3_lo_pass_r<A, NT, 0, true>;
-    else kR = lo_first ? (kern_r)sc3_lo_pass_r<A, NT, 2, false> : (kern_r)sc3_lo_pass_r<A, NT, 2, true>;
+    constexpr int NTR = sc3r_threads(NT), PPR = sc3r_pairs(A, NT);
+    if (dm == 0) kR = lo_first ? (kern_r)sc3_lo_pass_r<A, NTR, PPR, 0, false> : (kern_r)sc3_lo_pass_r<A, NTR, PPR, 0, true>;
+    else kR = lo_first ? (kern_r)sc3_lo_pass_r<A, NTR, PPR, 2, false> : (kern_r)sc3_lo_pass_r<A, NTR, PPR, 2, true>;
     constexpr size_t ldsR = (size_t)sc3_lo_cap_r(A, NT) * 8;
     if (!attr_done[(const void *)kR]) {
       DNM_HIP(hipFuncSetAttribute((const void *)kR, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsR));
@@ -1581,7 +1593,7 @@ static int launch_two_pass(const Sc3Mat &M, const Sc3Call &call, const double *c
       hipLaunchKernelGGL(kB, dim3((unsigned)M.permB.size()), dim3(NTW), ldsB, st, M.ly->dev_h, op, (const uint32_t *)M.d_permB,
                          firstw, (const c128 *)xw, (c128 *)y);
     if (phase == 0 || phase == 1)
-      hipLaunchKernelGGL(kR, dim3((unsigned)(M.permA.size() / 8)), dim3(NT), ldsR, st, S, op, (const uint32_t *)M.d_permA,
+      hipLaunchKernelGGL(kR, dim3((unsigned)(M.permA.size() / 8)), dim3(NTR), ldsR, st, S, op, (const uint32_t *)M.d_permA,
                          phase == 0 ? second : first, (const double *)xw, (double *)y);
     DNM_HIP(hipGetLastError());
     return 0;
