@@ -1015,6 +1015,7 @@ static int sc3_mult(dnm_mat *A, const void *x, void *y, const void *z, double b,
 
 int dnm_mat_precompute_diagonal(dnm_mat *A, void *stream) {
   DNM_CHECK(A && !A->host_only, "null or host-only matrix");
+  DNM_CHECK(!A->real_packed, "real-packed operators evaluate their diagonal on the fly: nothing to precompute");
   // only when the first mask is the identity (bpetsc_template_1.c:177-180) and
   // left == right (operators.py:627-629; the caller guarantees it)
   if (A->masks.empty() || A->masks[0] != 0) return 0;
