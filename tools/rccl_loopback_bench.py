@@ -1,0 +1,99 @@
+#!/usr/bin/env python
+"""The partitioned Full-space multiply (partner blocks) of ONE rank at full size on ONE GPU, with its exchange looped
+back over RCCL: a process group of world size 1 on the nccl backend, every send and receive addressed to the rank
+itself (tests/rccl_self_child.py stage E has the small, oracle-checked form).  What it measures: the production code
+path of ShellMat.mult -- batch_isend_irecv on RCCL's stream, the rank-local passes under it, per-block waits, the partner
+passes -- with full-size messages (GiB each) and a link that is as fast as device memory, i.e. the compute side of a
+partitioned step and what RCCL's own copy kernels cost the passes they overlap with.  NOT an xGMI measurement.
+    python tools/rccl_loopback_bench.py [L P rank] ...      (default: 31 2 0   33 8 5)"""
+import os
+os.environ.setdefault("DNM_EXPERIMENTAL", "1")
+import datetime
+import socket
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0),
+                            timeout=datetime.timedelta(seconds=300))
+    from dynamite_amd import backend, models, msc_tools, _lib
+    from dynamite_amd.config import config
+    from dynamite_amd.subspaces import Full
+    config._initialize()
+    args = [int(a) for a in sys.argv[1:]] or [31, 2, 0, 33, 8, 5]
+    for L, P, me in zip(args[0::3], args[1::3], args[2::3]):
+        sub = Full(L=L)
+        H = models.mbl(L)
+        H.establish_L()
+        H.reduce_msc()
+        masks, offs = msc_tools.get_mask_offsets(H.msc)
+        c = sub._c()
+        c.vec_swizzle = 16
+        n_loc = (1 << L) // P
+        h = backend.create_mat(masks, offs, H.msc['signs'], H.msc['coeffs'], c, c, False, 0, me, P)
+        mat = backend.ShellMat(h, c, c, P, me)
+        psends = {}
+        for q in mat.partners:
+            hq = backend.create_mat(masks, offs, H.msc['signs'], H.msc['coeffs'], c, c, False, _lib.MAT_HOST_ONLY, q, P)
+            sq, _ = backend.exchange_plan(hq)
+            psends[q] = [t for t in sq if t[0] == me]
+            _lib.check(_lib.lib().dnm_mat_destroy(hq))
+        taken = {q: 0 for q in mat.partners}
+        loop = []
+        for q, off, cnt in mat.recvs:
+            _, soff, scnt = psends[q][taken[q]]
+            taken[q] += 1
+            loop.append((0, soff, scnt))
+        recv_bytes = 16 * sum(cnt for _, _, cnt in mat.recvs)
+        mat.sends = loop
+        mat.recvs = [(0, off, cnt) for _, off, cnt in mat.recvs]
+        x, y = backend.Vec(n_loc, swz=16), backend.Vec(n_loc, swz=16)
+        x.set_random(1)
+        print("L=%d rank %d of %d: block 2^%d amplitudes, receives %.1f GiB in %d blocks per multiply"
+              % (L, me, P, n_loc.bit_length() - 1, recv_bytes / 2 ** 30, len(mat.recvs)), flush=True)
+        print(mat.describe().strip(), flush=True)
+
+        def timed(fn, n=5):
+            for _ in range(2):
+                fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / n * 1e3
+        t_full = timed(lambda: mat.mult(x, y))
+        t_exch = timed(lambda: mat.exchange_only(x))
+        L_ = _lib.lib()
+        t_local = timed(lambda: _lib.check(L_.dnm_mat_mult_local(mat.handle, x.ptr, y.ptr, backend._stream())))
+
+        def remote_only():
+            for i in range(len(mat.recvs)):
+                _lib.check(L_.dnm_mat_mult_remote(mat.handle, i, backend.C.c_void_p(mat._recv[i].data_ptr()), y.ptr,
+                                                  backend._stream()))
+        t_remote = timed(remote_only)
+        print("   multiply with the exchange looped back over RCCL: %.2f ms; exchange alone %.2f ms (%.0f GB/s through RCCL's "
+              "copies); rank-local passes alone %.2f ms; partner passes alone %.2f ms; local + partner %.2f ms"
+              % (t_full, t_exch, recv_bytes / t_exch / 1e6, t_local, t_remote, t_local + t_remote), flush=True)
+        assert torch.isfinite(torch.view_as_real(y.array)).all()
+        mat.destroy()
+        del x, y
+        torch.cuda.empty_cache()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
