@@ -92,6 +92,35 @@ def main():
         mat.destroy()
         del x, y
         torch.cuda.empty_cache()
+        if P >= 4:
+            # the transposed exchange (the default from four ranks on): its two all-to-alls looped back -- every piece
+            # lands where the same piece of a peer would (the bytes are this rank's own, so the RESULT means nothing;
+            # the schedule, the message sizes and the overlap of RCCL's stream with the passes are the production ones)
+            p_ = P.bit_length() - 1
+            S = 16
+            cap = (L - 2 * p_ - 1 - 2 + 4) // 2
+            if cap < S:
+                S = 14 if cap == 15 else cap
+            c2 = Full(L=L)._c()
+            c2.vec_swizzle = S
+            h2 = backend.create_mat(masks, offs, H.msc['signs'], H.msc['coeffs'], c2, c2, False, 0, me, P)
+            mat2 = backend.ShellMat(h2, c2, c2, P, me)
+            split = backend.transpose_split(masks, offs, H.msc['signs'], H.msc['coeffs'], L, P, S, 0)
+            assert split is not None
+            mat2.set_transposed(split, c2, c2, 0)
+            lo_h, hi_h, pieces, own, cnt = mat2._tr
+            mat2._tr = (lo_h, hi_h, [(0, off, c_) for _, off, c_ in pieces], own, cnt)
+            x, y = backend.Vec(n_loc, swz=S), backend.Vec(n_loc, swz=S)
+            x.set_random(1)
+            t_tr = timed(lambda: mat2.mult(x, y))
+            t_ex = timed(lambda: mat2.exchange_only(x))
+            moved = 2 * 16 * cnt * len(pieces)
+            print("   transposed exchange looped back (swizzle %d, %s): %.2f ms per multiply; its two all-to-alls alone %.2f ms "
+                  "(%.1f GiB, %.0f GB/s through RCCL's copies)"
+                  % (S, "pipelined" if mat2._tr_pipe else "whole pieces", t_tr, t_ex, moved / 2 ** 30, moved / t_ex / 1e6), flush=True)
+            mat2.destroy()
+            del x, y
+            torch.cuda.empty_cache()
     dist.destroy_process_group()
 
 
