@@ -1250,3 +1250,24 @@ def test_eigsolve_real_arithmetic_falls_back():
         assert abs(ev[0] - w[0]) < 1e-8
     finally:
         del os.environ["DNM_EIGS_REAL"]
+
+
+@pytest.mark.parametrize("which", ["highest", "exterior"])
+def test_eigsolve_real_arithmetic_other_ends(monkeypatch, which):
+    """The other ends of the spectrum in real arithmetic (restarted scheme and, for one pair, the basis-free Lanczos)."""
+    from dynamite_amd.computations import eigsolve
+    monkeypatch.setenv("DNM_EIGS_REAL", "1")
+    for k, v in (("DNM_TILE_BITS", "8"), ("DNM_LOG_ROWS", "2"), ("DNM_PLAN_MODE", "2"), ("DNM_GBITS", "3"), ("DNM_AMIN", "3")):
+        monkeypatch.setenv(k, v)
+    L = 12
+    H = models.mbl(L)
+    w = np.linalg.eigvalsh(H.to_numpy(sparse=False))
+    want = w[-1] if which == "highest" else (w[0] if abs(w[0]) > abs(w[-1]) else w[-1])
+    ev = H.eigsolve(nev=2, which=which, tol=1e-10)
+    assert eigsolve.last_stats['real_arithmetic'] is True and abs(ev[0] - want) < 1e-8 * max(1.0, abs(want))
+    monkeypatch.setenv("DNM_EIGS_BASISFREE", "1")
+    ev1, v1 = H.eigsolve(nev=1, which=which, tol=1e-10, getvecs=True)
+    assert eigsolve.last_stats['real_arithmetic'] is True and abs(ev1[0] - want) < 1e-8 * max(1.0, abs(want))
+    r = H.dot(v1[0])
+    r.axpy(-ev1[0], v1[0])
+    assert r.norm() < 1e-8 * max(1.0, abs(want))
