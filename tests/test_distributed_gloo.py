@@ -198,3 +198,47 @@ def test_redistribute_between_partitions_gloo(tmp_path, world):
     import torch.multiprocessing as mp
     mp.spawn(_redistribute_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     assert float(open(tmp_path / "ok_redist.txt").read()) == 1.0
+
+
+def _layout_choice_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import ctypes as C
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dynamite_amd import backend, models, msc_tools, _lib
+    from dynamite_amd.config import config
+    from dynamite_amd.subspaces import SpinConserve
+    ok = config.world_size == world
+    # L=26, k=13 under the production configuration on four ranks: 4 blocks of equal top bits cannot be shared out
+    #  -> reference order, PETSc's even split, the window kernels
+    sub = SpinConserve(26, 13)
+    ok = ok and sub.vec_swizzle == 0
+    H = models.heisenberg(26)
+    H.reduce_msc()
+    masks, offs = msc_tools.get_mask_offsets(H.msc)
+    h = backend.create_mat(masks, offs, H.msc['signs'], H.msc['coeffs'], sub._c(), sub._c(), False, _lib.MAT_HOST_ONLY,
+                           rank, world)
+    M, N, m, n = (C.c_int64() for _ in range(4))
+    _lib.check(_lib.lib().dnm_mat_sizes(h, C.byref(M), C.byref(N), C.byref(m), C.byref(n)))
+    ok = ok and (rank * (M.value // world) + min(rank, M.value % world), m.value) == backend.split_ownership(M.value, world, rank)
+    ll, lr = C.c_int(), C.c_int()
+    _lib.check(_lib.lib().dnm_mat_layouts(h, C.byref(ll), C.byref(lr)))
+    ok = ok and (ll.value, lr.value) == (0, 0)
+    _lib.check(_lib.lib().dnm_mat_destroy(h))
+    # ... while a subspace whose blocks balance keeps the internal layout on the same four ranks
+    ok = ok and SpinConserve(32, 16).vec_swizzle == (14 | (10 << 8))
+    flag = torch.tensor([1.0 if ok else 0.0])
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        open(os.path.join(out_dir, "ok_layout.txt"), "w").write(str(flag.item()))
+    dist.destroy_process_group()
+
+
+def test_spinconserve_layout_choice_on_four_ranks(tmp_path):
+    """SpinConserve.vec_swizzle under a real process group: L=26, k=13 on 4 ranks stays in reference order (every rank
+    owns a quarter of the rows), L=32, k=16 takes the internal layout."""
+    import torch.multiprocessing as mp
+    mp.spawn(_layout_choice_worker, args=(4, _free_port(), str(tmp_path)), nprocs=4, join=True)
+    assert float(open(tmp_path / "ok_layout.txt").read()) == 1.0
