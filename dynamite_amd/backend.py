@@ -195,7 +195,7 @@ def post_exchange(x_local, sends, recvs, recv_bufs):
                            [(buf, p) for (p, _, _), buf in zip(recvs, recv_bufs)])
 
 
-def transpose_split(masks, mask_offsets, signs, coeffs, L, nranks, swizzle=0, shift=0):
+def transpose_split(masks, mask_offsets, signs, coeffs, L, nranks, swizzle=0, shift=0, packed=False):
     """Split a Full-space (``shift`` = 0) or Parity (``shift`` = 1: basis index = configuration >> 1, so index bit
     j is spin j + 1 and ``L`` counts the index bits) operator on P = 2^p ranks for the transposed exchange, or None
     if it does not apply.
@@ -209,14 +209,17 @@ def transpose_split(masks, mask_offsets, signs, coeffs, L, nranks, swizzle=0, sh
     all-to-all of the state, one local pass, one all-to-all of the result: every xGMI link carries
     2 * 2^n / P amplitudes per multiply instead of up to 2^n on one link.
 
+    ``packed``: the two operators will be built in real-packed form (DNM_MAT_REAL_PACKED: index bit 0 becomes the lane
+    of an element, every other bit moves down by one): F must leave bit 0 alone and a piece is 2^(f-1) elements.
+
     Returns (lo, hi, f): ``lo`` = (masks, offsets, signs, coeffs) of the terms that flip no top spin (layout A),
     ``hi`` = the others with bits permuted (layout B)."""
     p = nranks.bit_length() - 1
     n = L - p
     f = n - 1 - p
-    if nranks != 1 << p or p < 1 or f < 0:
+    if nranks != 1 << p or p < 1 or f < (1 if packed else 0):
         return None
-    if swizzle and f < 2 * swizzle - 4:
+    if swizzle and f - (1 if packed else 0) < 2 * swizzle - 4:
         return None                    # pieces of 2^f amplitudes must keep their internal order in both layouts
     masks = np.asarray(masks, dtype=np.int64)
     offs = np.asarray(mask_offsets, dtype=np.int64)
@@ -752,6 +755,8 @@ class ShellMat:
         rank-local passes only -- the masks that flip no top spin in the state's own layout, the others in the
         redistributed layout -- and the piece list of the all-to-all between the layouts."""
         lo, hi, f = split
+        if self.real_packed:
+            f -= 1              # positions of the packed operator: index bit 0 is the lane, the fields sit one bit lower
         p = self.nranks.bit_length() - 1
         n = (self.n_local - 1).bit_length()
         hs = []
@@ -1175,10 +1180,12 @@ def build_mat(masks, mask_offsets, signs, coeffs, left_subspace, right_subspace,
     if use_transposed_exchange(config.world_size, exchange) and same and not xparity and 'tiled=1' in mat.describe():
         shift = int(lc.type)                   # Full: index = configuration; Parity: index = configuration >> 1
         split = transpose_split(masks, mask_offsets, signs, coeffs, int(lc.L) - shift, config.world_size,
-                                int(lc.vec_swizzle), shift)
+                                int(lc.vec_swizzle), shift, packed=mat.real_packed)
         if split is not None:
             mat.set_transposed(split, lc, rc, flags)
-            mat._check_pending = knob('DNM_EXCHANGE_SELFCHECK', '1') != '0'
+            # (the sampled-row check reads x and y as complex amplitudes: not for the packed form, whose first use
+            # -- eigsolve -- measures its residuals in H anyway)
+            mat._check_pending = knob('DNM_EXCHANGE_SELFCHECK', '1') != '0' and not mat.real_packed
     return mat
 
 

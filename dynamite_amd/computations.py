@@ -222,10 +222,7 @@ def eigsolve(H, getvecs=False, nev=1, which='lowest', target=None, tol=None, sub
     if er:
         want_real = er[:1] == '1'
     if want_real is None:
-        # (Full / Parity on four or more ranks: the packed operator exchanges partner blocks -- the transposed exchange
-        # is not built for it -- and half the bytes on ONE link lose against the all-to-all's even load: complex128 there)
-        from .subspaces import Full, Parity
-        want_real = mat.n_local >= (1 << 23) and not (config.world_size >= 4 and isinstance(subspace, (Full, Parity)))
+        want_real = mat.n_local >= (1 << 23)
     if want_real:                   # (several ranks: SpinConserve in the internal layout only)
         pm = H.get_real_packed_mat(subspace)
         if pm is not None:

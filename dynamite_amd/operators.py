@@ -335,12 +335,25 @@ class Operator:
             self.establish_L()
             self.reduce_msc()
             masks, mask_offsets = msc_tools.get_mask_offsets(self.msc)
+            sc_desc = subspace._to_c()
+            if not sc and ws >= 4:
+                # Full / Parity on four or more ranks: the packed vectors are one index bit shorter, and the transposed
+                # exchange wants their swizzle field to end below its sub-pieces -- their own shift (they live inside
+                # eigsolve only; dnm_vec_unpack_real converts between the two layouts)
+                d = type(sc_desc['data']).from_buffer_copy(sc_desc['data'])
+                S = int(d.vec_swizzle)
+                bits = (self.L if isinstance(subspace, Full) else self.L - 1) - 1
+                p = ws.bit_length() - 1
+                cap = (bits - 2 * p - 1 - 2 + 4) // 2
+                if S and cap < S:
+                    S = 14 if cap == 15 else cap
+                d.vec_swizzle = S if S >= 5 else 0
+                sc_desc = {'type': sc_desc['type'], 'data': d}
             try:
                 mat = backend.build_mat(
                     masks=np.ascontiguousarray(masks), mask_offsets=np.ascontiguousarray(mask_offsets),
                     signs=np.ascontiguousarray(self.msc['signs']), coeffs=np.ascontiguousarray(self.msc['coeffs']),
-                    left_subspace=subspace._to_c(), right_subspace=subspace._to_c(), flags=_lib.MAT_REAL_PACKED,
-                    exchange='partner')      # (the transposed exchange is not built for packed operators)
+                    left_subspace=sc_desc, right_subspace=sc_desc, flags=_lib.MAT_REAL_PACKED)
             except _lib.BackendError:
                 mat = None            # an imaginary matrix element, or a vector too small for the tiled kernel
         self._mats[key] = mat

@@ -197,15 +197,17 @@ def _worker(rank, world, port, case, out_dir):
     v1g = v1[0].to_numpy(to_all=True)
     assert np.linalg.norm(Hs @ v1g - e1[0] * v1g) < 1e-7
 
-    if case in ("full", "full_partner", "parity"):
+    if case in ("full", "full_partner", "full_transpose", "parity"):
         # real arithmetic on a partitioned Full / Parity operator: the packed operator (bit 0 of the index = the lane)
-        # exchanges partner blocks of half the bytes (the transposed exchange is not built for it: partner blocks on
-        # four ranks too)
+        # exchanges like an operator on one bit less -- partner blocks on two ranks, the transposed exchange from four on
+        # (or as DNM_EXCHANGE says), half the bytes either way
         from dynamite_amd.computations import eigsolve as _eig
         os.environ["DNM_EIGS_REAL"] = "1"
         er, vr = H.eigsolve(nev=2, getvecs=True, tol=1e-10, subspace=sub)
         os.environ.pop("DNM_EIGS_REAL")
         assert _eig.last_stats['real_arithmetic'] is True
+        pm = H.get_real_packed_mat(sub)
+        assert pm.real_packed and pm.exchange_summary()["scheme"] == H.get_mat().exchange_summary()["scheme"]
         assert np.max(np.abs(np.array(er[:2]) - lowest)) < 1e-8, "partitioned eigsolve, real arithmetic"
         vg = vr[0].to_numpy(to_all=True)
         assert np.abs(vg.imag).max() == 0.0 and np.linalg.norm(Hs @ vg - er[0] * vg) < 1e-7

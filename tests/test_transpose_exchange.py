@@ -207,3 +207,82 @@ def test_transposed_multiply_gloo(tmp_path, world, name):
     arrs = _arrays(name, L)
     ref = orc.matvec_fast_ranks(orc.Msc(*arrs), orc.full(L), res["x"], world)
     assert np.max(np.abs(res["y"] - ref)) < 30 * 64 * 2.2e-16 * np.abs(res["x"]).max()
+
+
+def _worker_packed(rank, world, port, L, name, out_dir):
+    """The transposed exchange of a REAL-PACKED operator (DNM_MAT_REAL_PACKED: index bit 0 is the lane of an element,
+    the exchanged field and the pieces sit one bit lower): ShellMat._mult_transposed on packed vectors, the two layout
+    operators built packed, passes run by the emulation."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), DNM_TILE_BITS="8", DNM_LOG_ROWS="2",
+                      DNM_PLAN_MODE="2", DNM_GBITS="3", DNM_EXCHANGE="transpose", DNM_SWZ="6")
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dynamite_amd import _lib
+    from dynamite_amd.subspaces import Full
+    from dynamite_amd.backend import transpose_split, transpose_pieces, post_transpose
+    from plan_emulator import HostMat, run_pass, vec_pos
+
+    arrs = _arrays(name, L)
+    sub = Full(L=L)
+    S = sub.vec_swizzle
+    lo, hi, f = transpose_split(*arrs, L, world, S, packed=True)
+    sc = sub._c()
+    mats = [HostMat(*part, sc, sc, rank=rank, nranks=world, flags=_lib.MAT_REAL_PACKED) for part in (lo, hi)]
+    assert all(not m.recvs and not m.sends and m.tiled for m in mats)
+    p = world.bit_length() - 1
+    n = L - p - 1                    # local index bits of the packed operator
+    fp = f - 1
+    nloc = 1 << n
+    assert all((1 << m.n_loc) == nloc for m in mats) and (S == 0 or fp >= 2 * S - 4)
+    pieces, own, cnt = transpose_pieces(n, p, fp, rank)
+    rs = np.random.RandomState(12)
+    xg = rs.standard_normal(1 << L)
+    xpk = xg[0::2] + 1j * xg[1::2]
+    pos = vec_pos(np.arange(nloc), S)
+    xl = np.empty(nloc, dtype=complex)
+    xl[pos] = xpk[rank * nloc:(rank + 1) * nloc]
+    x = torch.from_numpy(xl)
+    xb, wb = torch.empty_like(x), torch.zeros_like(x)
+    reqs = post_transpose(x, xb, pieces)
+    for off in own:
+        xb[off:off + cnt] = x[off:off + cnt]
+    y = np.zeros(nloc, dtype=complex)
+    for ps in mats[0].local:
+        run_pass(mats[0], ps, x.numpy(), y)
+    for r in reqs:
+        r.wait()
+    w = np.zeros(nloc, dtype=complex)
+    for ps in mats[1].local:
+        run_pass(mats[1], ps, xb.numpy(), w)
+    wb.copy_(torch.from_numpy(w))
+    reqs = post_transpose(wb, xb, pieces)
+    for off in own:
+        y[off:off + cnt] += w[off:off + cnt]
+    for r in reqs:
+        r.wait()
+    edges = [0] + [e for off in own for e in (off, off + cnt)] + [nloc]
+    for a, b in zip(edges[0::2], edges[1::2]):
+        y[a:b] += xb.numpy()[a:b]
+    parts = [torch.empty(nloc, dtype=torch.complex128) for _ in range(world)]
+    dist.all_gather(parts, torch.from_numpy(y[pos]))
+    if rank == 0:
+        yp = torch.cat(parts).numpy()
+        yr = np.empty(1 << L)
+        yr[0::2], yr[1::2] = yp.real, yp.imag
+        np.savez(os.path.join(out_dir, "result_packed.npz"), y=yr, x=xg)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,name", [(4, "mbl"), (2, "heisenberg")])
+def test_transposed_multiply_packed_gloo(tmp_path, world, name):
+    import torch.multiprocessing as mp
+    from oracle import oracle as orc
+    L = 14
+    mp.spawn(_worker_packed, args=(world, _free_port(), L, name, str(tmp_path)), nprocs=world, join=True)
+    res = np.load(tmp_path / "result_packed.npz")
+    arrs = _arrays(name, L)
+    ref = orc.matvec(orc.Msc(*arrs), orc.full(L), orc.full(L), res["x"].astype(complex)).real
+    assert np.max(np.abs(res["y"] - ref)) < 30 * 64 * 2.2e-16 * np.abs(res["x"]).max()
