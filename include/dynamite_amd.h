@@ -109,7 +109,7 @@ enum {
                                  diagnostics and CPU tests) -- such a handle cannot multiply */
   DNM_MAT_REAL_PACKED  = 16   /* Real arithmetic for a real-symmetric operator (every matrix element real in the
                                  product basis: Heisenberg, XXZ, Ising, random-field chains ...) on a Full / Parity pair
-                                 (one rank, or 2^p ranks with the partner exchange): the handle multiplies REAL vectors of the same dimension, stored two
+                                 (one rank or 2^p ranks: the exchange is that of an operator on one index bit less): the handle multiplies REAL vectors of the same dimension, stored two
                                  amplitudes to a complex128 element -- element j holds the amplitudes of indices 2j
                                  (real part) and 2j + 1 (imaginary part), so a vector is dim / 2 elements, 8 bytes per
                                  amplitude, and dnm_mat_sizes reports the halved sizes.  Solver-internal (eigsolve of a
