@@ -638,6 +638,83 @@ def test_fuzz_random_operators(monkeypatch, seed):
             assert np.max(np.abs(yp - ref)) <= tol_for(arrs, x), (L, Pw, "sc windows")
 
 
+def _random_real_symmetric(L, nterms, rs):
+    """Sum of random Pauli strings with an EVEN number of sigma_y each and real coefficients: a real symmetric matrix
+    (many terms per mask, signs that reach bit 0, masks that flip bit 0 alone, diagonal strings)."""
+    from dynamite_amd.operators import sigmax, sigmay, sigmaz, op_sum, op_product
+    terms = []
+    for _ in range(nterms):
+        w = rs.randint(1, min(L, 5) + 1)
+        sites = [int(i) for i in rs.choice(L, size=w, replace=False)]
+        if rs.randint(4) == 0:
+            sites[0] = 0                                     # bit 0 is the packed bit: make it busy
+            sites = list(dict.fromkeys(sites))
+        kinds = [int(rs.randint(3)) for _ in sites]
+        if sum(k == 1 for k in kinds) % 2:
+            j = kinds.index(1)
+            kinds[j] = 0 if rs.randint(2) else 2
+        terms.append(float(rs.uniform(-1, 1)) * op_product([(sigmax, sigmay, sigmaz)[k](i) for k, i in zip(kinds, sites)]))
+    H = op_sum(terms)
+    H.L = L
+    return H
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("DNM_FUZZ_REAL_N", "32"))))
+def test_fuzz_real_packed_operators(monkeypatch, seed):
+    """DNM_MAT_REAL_PACKED (the real-arithmetic form eigsolve uses, two real amplitudes per element) on random real
+    symmetric Pauli sums, random tile shapes and plan modes, Full and Parity, whole and partitioned over 2 / 4 ranks
+    (partner blocks), against the oracle's complex multiply of the same real vector."""
+    rs = np.random.RandomState(4000 + seed)
+    B, logR = [(8, 2), (10, 2), (10, 3), (11, 3), (12, 3), (12, 4)][rs.randint(6)]
+    L = int(rs.randint(B + 2, 19))            # the packed form runs on the tiled kernel only: >= B packed index bits
+    mode = int(rs.randint(3))
+    cfg(monkeypatch, B=B, logR=logR, mode=mode, amin=int(rs.randint(3, 6)), gbits=int(rs.randint(0, 7)))
+    monkeypatch.setenv("DNM_CACHE_POLICY", str([0, 32, 226][rs.randint(3)]))
+    H = _random_real_symmetric(L, int(rs.randint(3, 40)), rs)
+    arrs = marshal(H)
+    sub = Full(L=L) if rs.randint(2) else Parity(int(rs.randint(2)), L=L)
+    dim = sub.get_dimension()
+    xr = rs.standard_normal(dim)
+    ref = orc.matvec(orc_msc(H), orc_sub(sub), orc_sub(sub), xr.astype(np.complex128))
+    assert np.abs(ref.imag).max() == 0.0
+    ref = ref.real
+    tol = tol_for(arrs, xr)
+
+    def unpack(yp):
+        got = np.empty(2 * yp.shape[0])
+        got[0::2], got[1::2] = yp.real, yp.imag
+        return got
+
+    xp = xr[0::2] + 1j * xr[1::2]
+    mat = shell(H, sub, flags=_lib.MAT_REAL_PACKED)
+    assert mat.real_packed and mat.N == dim // 2
+    y = unpack(mult_numpy(mat, xp))
+    assert np.abs(y - ref).max() <= tol, (L, B, logR, mode, mat.describe())
+    mat.destroy()
+    P = int(2 ** rs.randint(1, 3))
+    n = (L if isinstance(sub, Full) else L - 1) - 1              # index bits of the packed operator
+    if n - int(np.log2(P)) - 1 >= B:
+        Lb = _lib.lib()
+        nloc = dim // 2 // P
+        yp = np.empty(dim // 2, dtype=complex)
+        c = sub._c()
+        xls = None
+        for r in range(P):
+            h = backend.create_mat(*arrs, c, c, flags=_lib.MAT_REAL_PACKED, rank=r, nranks=P)
+            m = backend.ShellMat(h, c, c, P, r)
+            assert m.n_local == nloc
+            if xls is None:
+                xls = [vec_from(xp[q * nloc:(q + 1) * nloc], m.swz_right) for q in range(P)]
+            yl = backend.Vec(nloc, swz=m.swz_left)
+            _lib.check(Lb.dnm_mat_mult_local(m.handle, xls[r].ptr, yl.ptr, None))
+            for i, (p_, off, cnt) in enumerate(m.recvs):
+                xq = partner_slice(xls[p_], off, cnt)
+                _lib.check(Lb.dnm_mat_mult_remote(m.handle, i, xq.ptr, yl.ptr, None))
+            yp[r * nloc:(r + 1) * nloc] = yl.local_numpy()
+            m.destroy()
+        assert np.abs(unpack(yp) - ref).max() <= tol, (L, B, P, "partitioned")
+
+
 def test_error_behaviour():
     H = models.mbl(12)
     sub = Full(L=12)
