@@ -354,8 +354,13 @@ class Operator:
                     masks=np.ascontiguousarray(masks), mask_offsets=np.ascontiguousarray(mask_offsets),
                     signs=np.ascontiguousarray(self.msc['signs']), coeffs=np.ascontiguousarray(self.msc['coeffs']),
                     left_subspace=sc_desc, right_subspace=sc_desc, flags=_lib.MAT_REAL_PACKED)
-            except _lib.BackendError:
-                mat = None            # an imaginary matrix element, or a vector too small for the tiled kernel
+            except _lib.BackendError as e:
+                # the native layer's refusals all name the form: an imaginary matrix element, no chain operator in the
+                # SpinConserve layout, a vector too small for the tiled kernel.  Anything else (memory, a bad table) is
+                # an error of the build, not a reason to fall back to complex arithmetic silently
+                if 'real-packed' not in str(e):
+                    raise
+                mat = None
         self._mats[key] = mat
         return mat
 

@@ -555,6 +555,47 @@ def test_spinconserve_large_properties():
     mat.destroy(); matg.destroy()
 
 
+@pytest.mark.default_layout
+@pytest.mark.parametrize("name,L,kind", [("mbl", 20, "full"), ("heisenberg", 24, "full"), ("xxz", 25, "full"),
+                                         ("heisenberg", 25, "parity"), ("mbl", 26, "parity")])
+def test_default_plan_real_packed_vs_oracle(monkeypatch, name, L, kind):
+    """The real-arithmetic operator eigsolve builds by default from 2^23 amplitudes on (Operator.get_real_packed_mat:
+    no DNM_* knob, production layout of the packed vectors, the planner's own choice of passes for a vector of half
+    the elements) element-wise against the oracle, with the Lanczos step's fused sums and the unpacking of a result
+    into the complex state of the subspace's own layout."""
+    import ctypes as C
+    from dynamite_amd import backend
+    for k in PLAN_KNOBS:
+        monkeypatch.delenv(k, raising=False)
+    H = models.BY_NAME[name](L)
+    sub = Full(L=L) if kind == "full" else Parity('even', L=L)
+    H.add_subspace(sub)
+    arrs = marshal(H)
+    dim = sub.get_dimension()
+    mat = H.get_real_packed_mat(sub)
+    assert mat is not None and mat.real_packed and mat.N == dim // 2
+    d = mat.describe()
+    assert "tiled=1" in d and "B=12 logR=2" in d, d
+    rs = np.random.RandomState(L)
+    xr = rs.standard_normal(dim)
+    ref = orc.matvec(orc_msc(H), orc_sub(sub), orc_sub(sub), xr.astype(np.complex128), nthreads=min(16, orc.max_threads())).real
+    xv, yv = mat.createVecs()
+    xv.set_local_from_numpy(xr[0::2] + 1j * xr[1::2])
+    yv.set(777.0)
+    mat.mult(xv, yv)
+    yp = yv.local_numpy()
+    tol = tol_for(arrs, xr)
+    assert max(np.abs(yp.real - ref[0::2]).max(), np.abs(yp.imag - ref[1::2]).max()) <= tol, d
+    dd = (C.c_double * 3)()
+    _lib.check(_lib.lib().dnm_mat_mult_lanczos(mat.handle, xv.ptr, yv.ptr, None, 0.0, dd, None))
+    assert abs(dd[0] - xr @ ref) <= 1e-11 * L * max(1.0, abs(xr @ ref)) and abs(dd[2] - ref @ ref) <= 1e-11 * L * (ref @ ref)
+    out = backend.Vec(dim, swz=sub.vec_swizzle)
+    _lib.check(_lib.lib().dnm_vec_unpack_real(out.ptr, yv.ptr, mat.n_local, mat.swz_right, sub.vec_swizzle, None))
+    got = out.local_numpy()
+    assert np.abs(got.real - ref).max() <= tol and np.abs(got.imag).max() == 0.0
+    H.destroy_mat()
+
+
 def _random_hermitian(L, nterms, rs):
     """Sum of random Pauli strings with real coefficients (Hermitian by construction)."""
     from dynamite_amd.operators import sigmax, sigmay, sigmaz, op_sum, op_product
