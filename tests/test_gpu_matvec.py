@@ -425,6 +425,66 @@ def test_full_size_default_plan(monkeypatch, L):
     mat.destroy(); mat2.destroy()
 
 
+@pytest.mark.default_layout
+@pytest.mark.parametrize("L", [27, 30, 31])
+def test_full_size_real_packed(monkeypatch, L):
+    """The real-arithmetic operator at the sizes eigsolve uses it by default (L=30: 8 GiB vectors; L=31: two real
+    amplitudes in each of 2^30 elements -- a size the complex form does not reach with a Krylov basis on one GPU):
+    sampled rows against the MSC definition (row 2j + b is lane b of element j), symmetry of the real inner product,
+    and the Lanczos step's fused sums."""
+    import ctypes as C
+    import torch
+    free, _ = torch.cuda.mem_get_info()
+    if free < 4.5 * 8 * (1 << L):
+        pytest.skip("not enough HBM")
+    for k in PLAN_KNOBS:
+        monkeypatch.delenv(k, raising=False)
+    H = models.mbl(L)
+    sub = Full(L=L)
+    H.add_subspace(sub)
+    mat = H.get_real_packed_mat(sub)
+    assert mat is not None and mat.real_packed and mat.N == 1 << (L - 1)
+    a, b = mat.createVecs()
+    Ha, Hb = mat.createVecs()
+    a.set_random(11); b.set_random(12)
+    a.normalize(); b.normalize()
+    mat.mult(a, Ha)
+    mat.mult(b, Hb)
+    masks, offs, signs, coeffs = marshal(H)
+    assert np.abs(np.asarray(coeffs).imag).max() == 0.0
+    rs = np.random.RandomState(L)
+    edge = []
+    for bit in range(1, L):
+        edge += [(1 << bit) - 1, 1 << bit, ((1 << L) - 1) ^ (1 << bit), (int(rs.randint(0, 1 << (L - bit))) << bit) | int(rs.randint(0, 1 << bit))]
+    rows = np.unique(np.concatenate([[0, 1, (1 << L) - 1], edge, rs.randint(0, 1 << L, 64)])).astype(np.int64)
+
+    def lanes(v, idx):             # amplitudes idx of the packed vector v
+        el = v.array[v.positions(torch.from_numpy(idx >> 1).to(v.array.device))].cpu().numpy()
+        return np.where(idx & 1, el.imag, el.real)
+
+    got = lanes(Ha, rows)
+    worst = 0.0
+    for i, r in enumerate(rows):
+        cols = r ^ masks
+        xs = lanes(a, cols)
+        acc = 0.0
+        for m in range(len(masks)):
+            c = 0.0
+            for t in range(offs[m], offs[m + 1]):
+                c += (1 - 2 * (bin(int(cols[m] & signs[t])).count("1") & 1)) * coeffs[t].real
+            acc += c * xs[m]
+        worst = max(worst, abs(acc - got[i]))
+    assert worst < 1e-13, worst
+    # real symmetric: <a, H b> = <H a, b> (Vec.dot is the complex one: the real inner product is its real part when the
+    # lanes are read as (re, im) of both factors -- sum_j re re + im im)
+    assert abs(Hb.dot(a).real - b.dot(Ha).real) < 1e-10
+    d = (C.c_double * 3)()
+    _lib.check(_lib.lib().dnm_mat_mult_lanczos(mat.handle, a.ptr, Hb.ptr, None, 0.0, d, None))
+    want = Ha.dot(a).real
+    assert abs(d[0] - want) < 1e-10 and abs(d[2] - Ha.dot(Ha).real) < 1e-9
+    H.destroy_mat()
+
+
 PLAN_KNOBS = ("DNM_TILE_BITS", "DNM_LOG_ROWS", "DNM_PLAN_MODE", "DNM_AMIN", "DNM_GBITS", "DNM_WINDOW_FIRST",
               "DNM_DIAG_PASS", "DNM_GBITS_WINDOW", "DNM_CACHE_POLICY", "DNM_SC_BLOCK", "DNM_SC_LAYOUT", "DNM_SWZ")
 
