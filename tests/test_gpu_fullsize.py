@@ -458,3 +458,35 @@ def test_config5_solver_at_the_largest_single_gpu_size():
         config.L = saved
         _lib.check(_lib.lib().dnm_release_workspace())
         torch.cuda.empty_cache()
+
+
+def test_full_space_solver_beyond_the_complex_limit():
+    """eigsolve(nev=1) on the Full space at L = 31 (2^31 states) on ONE GPU: the solver runs in real arithmetic (the
+    default for a real-symmetric operator of this size: 16 GiB per work vector where complex128 takes 32), and the
+    eigenpair is judged on the RETURNED complex state with the COMPLEX operator -- a kernel instance the solve never
+    used: unit norm, E = <v|H|v>, residual |H v - E v| (tests/integration/test_eigsolve.py:17-88)."""
+    import torch
+    from dynamite_amd.computations import eigsolve
+    from dynamite_amd.config import config
+    _need(190 * 2**30)
+    L, tol = 31, 1e-7
+    saved = config.L
+    try:
+        config.L = L
+        sub = Full(L=L)
+        H = models.mbl(L)
+        H.add_subspace(sub)
+        ev, vecs = H.eigsolve(nev=1, tol=tol, getvecs=True, subspace=sub)
+        assert eigsolve.last_stats['real_arithmetic'] is True
+        v = vecs[0]
+        assert abs(v.norm() - 1.0) < 1e-10
+        w = H.dot(v)
+        assert abs(v.dot(w).real - ev[0]) < 1e-8 * abs(ev[0]) and abs(v.dot(w).imag) < 1e-10
+        w.axpy(-ev[0], v)
+        assert w.norm() <= 2 * tol * abs(ev[0]), "residual %.2e" % w.norm()
+        del v, w, vecs
+        H.destroy_mat()
+    finally:
+        config.L = saved
+        _lib.check(_lib.lib().dnm_release_workspace())
+        torch.cuda.empty_cache()
