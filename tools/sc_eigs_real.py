@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""eigsolve(nev=1) on SpinConserve(L, L/2) in complex128 and in real arithmetic: sc_eigs_real.py [L] [tol]"""
+"""eigsolve(nev=1) on SpinConserve(L, L/2) in complex128 and in real arithmetic: sc_eigs_real.py [L] [tol] [real]
+(a third argument `real` runs the real-arithmetic solve only, twice -- sizes whose complex vectors do not fit)"""
 import os
 os.environ.setdefault("DNM_EXPERIMENTAL", "1")
 import sys
@@ -18,7 +19,7 @@ config._initialize()
 sub = SpinConserve(L, L // 2)
 H = models.heisenberg(L)
 H.add_subspace(sub)
-for real in (False, True, False, True):
+for real in ((True, True) if len(sys.argv) > 3 and sys.argv[3] == 'real' else (False, True, False, True)):
     config.eigs_real_arithmetic = real
     torch.cuda.synchronize(); t0 = time.perf_counter()
     ev = H.eigsolve(nev=1, tol=tol, subspace=sub)
