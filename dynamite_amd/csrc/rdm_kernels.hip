@@ -161,6 +161,128 @@ rdm_tile_kernel(const c128 *__restrict__ x, const SubView sub, const RdmGeom geo
   }
 }
 
+// ---- 64 x 64 tiles on the matrix cores (k >= 6) ------------------------------------------------------------
+// The same tile, slices and scratch as rdm_tile_kernel<ST, 6>, with the rank-T update done by
+// v_mfma_f64_16x16x4_f64: a wavefront owns a 32 x 32 block of the tile (2 x 2 MFMA blocks, real and imaginary
+// accumulators: 64 VGPRs) and per four traced configurations reads two A and two B fragments from LDS -- each lane one
+// complex amplitude (ds_read_b128: row / column = lane & 15, traced slot = lane >> 4) -- where the VALU form reads
+// eight amplitudes per 16 complex products: an eighth of the LDS traffic per flop, and the FMAs leave the vector unit.
+//   rho = A B^H:  Re += Ar Br^T + Ai Bi^T,   Im += Ai Br^T + (-Ar) Bi^T      (four real MFMAs per complex block)
+// C/D layout of the f64 MFMA (not the f32 one): col = lane & 15, row = (lane >> 4) + 4 * reg.
+// The next chunk's amplitudes are gathered into registers while the matrix cores work on the staged one.
+typedef double mfma_acc __attribute__((ext_vector_type(4)));
+
+template <int ST>
+__global__ void __launch_bounds__(RDM_NT)
+rdm_mfma_kernel(const c128 *__restrict__ x, const SubView sub, const RdmGeom geo, int64_t chunks_per_split,
+                int ntiles, c128 *__restrict__ partial) {
+  constexpr int TM = 64;
+  constexpr int TK = RDM_STAGE / TM;      // traced configurations per chunk (16: four MFMA steps)
+  constexpr int EPT = RDM_STAGE / RDM_NT; // amplitudes per thread and operand in a chunk
+  __shared__ c128 As[RDM_STAGE];
+  __shared__ c128 Bs[RDM_STAGE];
+  __shared__ uint64_t pa[TM], pb[TM];
+
+  const int tid = threadIdx.x;
+  const int tile = blockIdx.x;
+  int ti = (int)((sqrt(8.0 * (double)tile + 1.0) - 1.0) * 0.5);
+  while ((int64_t)(ti + 1) * (ti + 2) / 2 <= tile) ++ti;
+  while ((int64_t)ti * (ti + 1) / 2 > tile) --ti;
+  const int tj = tile - (int)((int64_t)ti * (ti + 1) / 2);
+  const bool diag_tile = ti == tj;
+  const int64_t K = (int64_t)1 << geo.k, T = (int64_t)1 << (geo.L - geo.k);
+  const int64_t a0 = (int64_t)ti * TM, b0 = (int64_t)tj * TM;
+  if (tid < TM) {
+    pa[tid] = rdm_deposit((uint64_t)(a0 + tid), geo.klen, geo.kpos, geo.nseg_keep);
+    pb[tid] = rdm_deposit((uint64_t)(b0 + tid), geo.klen, geo.kpos, geo.nseg_keep);
+  }
+  __syncthreads();
+
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wy = wave >> 1, wx = wave & 1;
+  mfma_acc re[2][2], im[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) re[i][j] = im[i][j] = mfma_acc{0.0, 0.0, 0.0, 0.0};
+
+  const int64_t nchunks = (T + TK - 1) / TK;
+  const int64_t c_begin = (int64_t)blockIdx.y * chunks_per_split;
+  int64_t c_end = c_begin + chunks_per_split;
+  if (c_end > nchunks) c_end = nchunks;
+  const c128 *Bp = diag_tile ? As : Bs;
+
+  // a thread's amplitudes of a chunk share the row (RDM_NT is a multiple of TM): its part of the state and the
+  // bounds tests are loop-invariant; the traced parts of a chunk's TK configurations are deposited once per
+  // workgroup (one lane each) instead of once per amplitude
+  __shared__ uint64_t pts[2][TK];
+  const int rr = tid % TM, t0 = tid / TM;
+  const uint64_t par = pa[rr], pbr = pb[rr];
+  const bool arow = a0 + rr < K, brow = !diag_tile && b0 + rr < K;
+  auto deposit_chunk = [&](int64_t c) {
+    if (tid < TK) {
+      const int64_t tr = c * TK + tid;
+      pts[c & 1][tid] = tr < T ? rdm_deposit((uint64_t)tr, geo.tlen, geo.tpos, geo.nseg_tr) : ~(uint64_t)0;
+    }
+  };
+  c128 va[EPT], vb[EPT];
+  auto gather = [&](int64_t c) {
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+      const uint64_t pt = pts[c & 1][t0 + i * (RDM_NT / TM)];
+      va[i] = vb[i] = make_double2(0.0, 0.0);
+      if (pt != ~(uint64_t)0) {
+        if (arow) va[i] = rdm_fetch<ST>(x, par | pt, sub);
+        if (brow) vb[i] = rdm_fetch<ST>(x, pbr | pt, sub);
+      }
+    }
+  };
+  deposit_chunk(c_begin);
+  deposit_chunk(c_begin + 1);
+  __syncthreads();
+  if (c_begin < c_end) gather(c_begin);
+  __syncthreads();                              // every wave has read its slots before deposit_chunk(c_begin + 2)
+  for (int64_t c = c_begin; c < c_end; ++c) {
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+      As[tid + i * RDM_NT] = va[i];
+      if (!diag_tile) Bs[tid + i * RDM_NT] = vb[i];
+    }
+    deposit_chunk(c + 2);                       // (its slot was last read by gather(c), before this barrier)
+    __syncthreads();
+    if (c + 1 < c_end) gather(c + 1);           // in flight under the MFMAs below
+#pragma unroll
+    for (int kk = 0; kk < TK; kk += 4) {
+      const int slot = (kk + (lane >> 4)) * TM + (lane & 15);
+      c128 a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[i] = As[slot + wy * 32 + i * 16];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) b[j] = Bp[slot + wx * 32 + j * 16];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          re[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].x, b[j].x, re[i][j], 0, 0, 0);
+          re[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].y, b[j].y, re[i][j], 0, 0, 0);
+          im[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].y, b[j].x, im[i][j], 0, 0, 0);
+          im[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[i].x, b[j].y, im[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+  }
+  c128 *out = partial + ((int64_t)blockIdx.y * ntiles + tile) * (TM * TM);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = wy * 32 + i * 16 + (lane >> 4) + 4 * r, col = wx * 32 + j * 16 + (lane & 15);
+        out[row * TM + col] = make_double2(re[i][j][r], im[i][j][r]);
+      }
+}
+
 // rho = sum over slices of the partial tiles; the upper triangle is the conjugate transpose
 template <int LOGTM>
 __global__ void __launch_bounds__(RDM_NT)
@@ -210,8 +332,14 @@ template <int ST, int LOGTM>
 static int rdm_launch(const c128 *x, const SubView &sub, const RdmGeom &geo, int ntiles, int nsplit,
                       int64_t chunks_per_split, c128 *partial, c128 *rho, hipStream_t st) {
   constexpr int TM = 1 << LOGTM;
-  hipLaunchKernelGGL((rdm_tile_kernel<ST, LOGTM>), dim3((unsigned)ntiles, (unsigned)nsplit), dim3(RDM_NT), 0, st, x,
-                     sub, geo, chunks_per_split, ntiles, partial);
+  // 64 x 64 tiles run on the matrix cores (DNM_RDM_MFMA=0: the vector-unit form, for comparison)
+  static const bool use_mfma = [] { const char *e = knob("DNM_RDM_MFMA"); return !(e && e[0] == '0'); }();
+  if (LOGTM == 6 && use_mfma)
+    hipLaunchKernelGGL((rdm_mfma_kernel<ST>), dim3((unsigned)ntiles, (unsigned)nsplit), dim3(RDM_NT), 0, st, x, sub,
+                       geo, chunks_per_split, ntiles, partial);
+  else
+    hipLaunchKernelGGL((rdm_tile_kernel<ST, LOGTM>), dim3((unsigned)ntiles, (unsigned)nsplit), dim3(RDM_NT), 0, st, x,
+                       sub, geo, chunks_per_split, ntiles, partial);
   // sum the slices by a fan-in-32 tree (ping-pong inside the scratch), then mirror
   const int64_t nelem = (int64_t)ntiles * TM * TM;
   c128 *cur = partial, *nxt = partial + (int64_t)nsplit * nelem;

@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Times reduced_density_matrix (GPU) for several cuts; prints effective FMA rate and bytes/s."""
+"""Times reduced_density_matrix (GPU) for several cuts; prints effective FMA rate and bytes/s.
+rdm_bench.py [L] [k]: with k, only the cut keep = range(k) on the Full space (for kernel-level profiles)."""
 import os, sys, time
 os.environ.setdefault("DNM_EXPERIMENTAL", "1")   # tools drive experiment knobs
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,13 +15,14 @@ from dynamite_amd.subspaces import Full, SpinConserve  # noqa: E402
 def main():
     L = int(sys.argv[1]) if len(sys.argv) > 1 else 26
     config._initialize()
-    for sub in (Full(L=L), SpinConserve(L, L // 2)):
+    only = int(sys.argv[2]) if len(sys.argv) > 2 else None
+    for sub in ((Full(L=L),) if only else (Full(L=L), SpinConserve(L, L // 2))):
         st = State(L=L, subspace=sub, state='random', seed=0, ) if sub.get_dimension() <= (1 << 26) else None
         if st is None:
             st = State(L=L, subspace=sub)
             st.set_random(seed=0, device_rng=True)
         for keep in ([0], [L // 2], list(range(4)), list(range(L - 6, L)), list(range(0, 16, 2)), list(range(10)),
-                     list(range(L // 2))):
+                     list(range(L // 2))) if not only else (list(range(only)),):
             if len(keep) > 13:
                 continue
             for _ in range(2):
