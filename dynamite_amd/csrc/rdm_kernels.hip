@@ -172,15 +172,24 @@ rdm_tile_kernel(const c128 *__restrict__ x, const SubView sub, const RdmGeom geo
 // The next chunk's amplitudes are gathered into registers while the matrix cores work on the staged one.
 typedef double mfma_acc __attribute__((ext_vector_type(4)));
 
+// waves per SIMD the kernel is compiled for / chunk size: 4 waves (128 registers, 8 B/lane of scratch) run 2.4 % faster
+// than 3; chunks of 32 traced configurations (64 KB of LDS, two workgroups per CU) 2.7 % slower (GPU session 39)
+#ifndef DNM_RDM_WAVES
+#define DNM_RDM_WAVES 4
+#endif
+#ifndef DNM_RDM_MSTAGE
+#define DNM_RDM_MSTAGE 1024
+#endif
 template <int ST>
-__global__ void __launch_bounds__(RDM_NT)
+__global__ void __launch_bounds__(RDM_NT, DNM_RDM_WAVES)
 rdm_mfma_kernel(const c128 *__restrict__ x, const SubView sub, const RdmGeom geo, int64_t chunks_per_split,
                 int ntiles, c128 *__restrict__ partial) {
   constexpr int TM = 64;
-  constexpr int TK = RDM_STAGE / TM;      // traced configurations per chunk (16: four MFMA steps)
-  constexpr int EPT = RDM_STAGE / RDM_NT; // amplitudes per thread and operand in a chunk
-  __shared__ c128 As[RDM_STAGE];
-  __shared__ c128 Bs[RDM_STAGE];
+  constexpr int MST = DNM_RDM_MSTAGE;     // amplitudes per operand in a staged chunk
+  constexpr int TK = MST / TM;            // traced configurations per chunk (16: four MFMA steps)
+  constexpr int EPT = MST / RDM_NT;       // amplitudes per thread and operand in a chunk
+  __shared__ c128 As[MST];
+  __shared__ c128 Bs[MST];
   __shared__ uint64_t pa[TM], pb[TM];
 
   const int tid = threadIdx.x;
@@ -206,10 +215,13 @@ rdm_mfma_kernel(const c128 *__restrict__ x, const SubView sub, const RdmGeom geo
 #pragma unroll
     for (int j = 0; j < 2; ++j) re[i][j] = im[i][j] = mfma_acc{0.0, 0.0, 0.0, 0.0};
 
-  const int64_t nchunks = (T + TK - 1) / TK;
-  const int64_t c_begin = (int64_t)blockIdx.y * chunks_per_split;
-  int64_t c_end = c_begin + chunks_per_split;
-  if (c_end > nchunks) c_end = nchunks;
+  // the slice of traced configurations of this workgroup (rdm_plan counts it in chunks of RDM_STAGE / TM), walked in
+  // chunks of TK from its first configuration
+  constexpr int64_t PLAN_TK = RDM_STAGE / TM;
+  const int64_t tr_begin = (int64_t)blockIdx.y * chunks_per_split * PLAN_TK;
+  int64_t tr_end = tr_begin + chunks_per_split * PLAN_TK;
+  if (tr_end > T) tr_end = T;
+  const int64_t c_begin = 0, c_end = tr_end > tr_begin ? (tr_end - tr_begin + TK - 1) / TK : 0;
   const c128 *Bp = diag_tile ? As : Bs;
 
   // a thread's amplitudes of a chunk share the row (RDM_NT is a multiple of TM): its part of the state and the
@@ -221,8 +233,8 @@ rdm_mfma_kernel(const c128 *__restrict__ x, const SubView sub, const RdmGeom geo
   const bool arow = a0 + rr < K, brow = !diag_tile && b0 + rr < K;
   auto deposit_chunk = [&](int64_t c) {
     if (tid < TK) {
-      const int64_t tr = c * TK + tid;
-      pts[c & 1][tid] = tr < T ? rdm_deposit((uint64_t)tr, geo.tlen, geo.tpos, geo.nseg_tr) : ~(uint64_t)0;
+      const int64_t tr = tr_begin + c * TK + tid;
+      pts[c & 1][tid] = tr < tr_end ? rdm_deposit((uint64_t)tr, geo.tlen, geo.tpos, geo.nseg_tr) : ~(uint64_t)0;
     }
   };
   c128 va[EPT], vb[EPT];
