@@ -1247,12 +1247,23 @@ def rdm_partial(x_block, sub_c, keep):
     return rho
 
 
-def reduced_density_matrix(vec, subspace, keep):
+def reduced_density_matrix(vec, subspace, keep, on_device=False):
     """Mirror of ``bpetsc.reduced_density_matrix`` (bpetsc.pyx:245-276): host array of
     shape (2^len(keep),)*2 on rank 0, ``[[-1]]`` elsewhere.  Partitioned states: when the kept
     spins lie inside every rank's block (Full / Parity), each rank sums over its own traced
     configurations and the partial matrices are added on rank 0; otherwise the state is gathered on
-    rank 0 as the reference does (bpetsc_template_1.c:126-141)."""
+    rank 0 as the reference does (bpetsc_template_1.c:126-141).
+    ``on_device``: the matrix stays in HBM -- a (2^k, 2^k) complex128 device tensor on rank 0, None elsewhere (the
+    entropies diagonalise it there: a 8192 x 8192 matrix is 1 GiB to copy and minutes of host LAPACK)."""
+    rho = _reduced_density_matrix(vec, subspace, keep)
+    K = 1 << len(keep)
+    if rho is None:
+        return None if on_device else np.array([[-1]], dtype=np.complex128)
+    return rho.reshape(K, K) if on_device else rho.cpu().numpy().reshape(K, K)
+
+
+def _reduced_density_matrix(vec, subspace, keep):
+    """The reduced density matrix as a flat device tensor on rank 0, None on the other ranks."""
     import torch
     config._initialize()
     keep = np.ascontiguousarray(keep, dtype=np.int64)
@@ -1265,9 +1276,7 @@ def reduced_density_matrix(vec, subspace, keep):
             from . import _comm
             rho = rdm_partial(x, blk, keep)
             _comm.reduce_sum(rho, dst=0)
-            if config.rank != 0:
-                return np.array([[-1]], dtype=np.complex128)
-            return rho.cpu().numpy().reshape(K, K)
+            return rho if config.rank == 0 else None
         from . import _comm
         if vec.internal:
             sizes = [layout_partition(vec.sub_c, config.world_size, q)[3] for q in range(config.world_size)]
@@ -1275,18 +1284,18 @@ def reduced_density_matrix(vec, subspace, keep):
             sizes = [split_ownership(vec.size, config.world_size, q)[1] for q in range(config.world_size)]
         parts = _comm.gather_varied(vec.local_natural(), sizes, dst=0)
         if config.rank != 0:
-            return np.array([[-1]], dtype=np.complex128)
+            return None
         x = torch.cat(parts)                 # the whole state in index order
         sub_c = _lib.Subspace.from_buffer_copy(subspace['data'])
         sub_c.vec_swizzle = 0
-        return rdm_partial(x, sub_c, keep).cpu().numpy().reshape(K, K)
+        return rdm_partial(x, sub_c, keep)
     sub_c = subspace['data']
     if vec.internal:
         # the kernel gathers by reference index: hand it the state in that order
         x = vec.local_natural()
         sub_c = _lib.Subspace.from_buffer_copy(sub_c)
         sub_c.vec_swizzle = 0
-    return rdm_partial(x, sub_c, keep).cpu().numpy().reshape(K, K)
+    return rdm_partial(x, sub_c, keep)
 
 
 def precompute_diagonal(mat):

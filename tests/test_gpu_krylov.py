@@ -538,6 +538,27 @@ def test_rdm_large_properties():
     assert abs(sA - sB) < 1e-9 and 0 < sA <= 9 * np.log(2)
 
 
+def test_entropies_device_spectrum():
+    """entanglement_entropy / renyi_entropy diagonalise reduced density matrices of 256 x 256 and more on the device
+    (torch.linalg.eigvalsh on the tensor the RDM kernel wrote -- no copy of the matrix to the host): the same numbers as
+    the reference's route, numpy on the host array (computations.py:351-454), for every alpha branch."""
+    from dynamite_amd import computations as cp
+    assert cp._DEVICE_EIG_FROM == 256
+    st = State(L=20, state='random', seed=21)
+    for keep in (list(range(8)), [1, 2, 3, 5, 8, 11, 12, 15, 17], list(range(10, 20))):
+        dm = cp.reduced_density_matrix(st, keep)
+        assert dm.shape == (1 << len(keep),) * 2
+        want = cp.dm_entanglement_entropy(dm)
+        assert abs(cp.entanglement_entropy(st, keep) - want) < 1e-11
+        for alpha in (0, 1, 2, 2.5, 'inf'):
+            assert abs(cp.renyi_entropy(st, keep, alpha) - cp.dm_renyi_entropy(dm, alpha)) < 1e-10, alpha
+        assert abs(cp.renyi_entropy(st, keep, 3, method='matrix_power') - cp.dm_renyi_entropy(dm, 3, 'eigsolve')) < 1e-10
+    with pytest.raises(ValueError):
+        cp.entanglement_entropy(st, list(range(9, 0, -1)))        # the reference's argument checks hold on this route too
+    with pytest.raises(ValueError):
+        cp.renyi_entropy(st, list(range(12, 21)), 2)
+
+
 # ------------------------------------------------------------------ files
 
 def test_state_and_operator_files(tmp_path):
