@@ -60,67 +60,23 @@ __device__ unsigned long long *g_phase_buf = nullptr;
 #define DNM_PH(i, waitvm)
 #endif
 
-// ---- round-4 experiments on the overlap of the two resident workgroups of a CU (profiles/r04_exp1_overlap.txt,
-// DESIGN.md section 4.2).  Compile-time (tools/build_variant.py builds each into its own library, DNM_LIB picks it).
-//   DNM_XP_PRIO   1 (default since round 4: -0.7 % at L=30, same box, three alternating runs): s_setprio 3 while the
-//                    workgroup is in a memory phase (tile loads, early gathers, late y, stores), 0 in its LDS record
-//                    loops; 0: no priority changes; 2: the reverse (+0.4 %); 3: raised only around the ISSUE of
-//                    memory instructions (-0.1 %)
-//   DNM_XP_SPLIT  1: LDS records whose partner lies in the wave's own 1 KB runs (mask_tile < 64) run before the
-//                    barrier (+1.0 %); 2: also the diagonal (own x from the tile; +1.9 %)
-//   DNM_XP_PF     d: before its LDS phase a workgroup touches the tile of workgroup blockIdx + d (one dword per 64 B)
-//                    so that the successor on this XCD finds x in the L2 / Infinity Cache (+13...+19 %: the touched
-//                    lines are fetched again, FETCH_SIZE +59 % in the accumulating pass); DNM_XP_PFY: also its y
+// ---- wave priority by phase (round 4; profiles/r04_exp1_overlap.txt): s_setprio 3 while the
+// workgroup is in a memory phase (tile loads, early gathers, late y, stores), 0 in its LDS record loops, so that of the
+// two workgroups resident on a CU the one that can put requests on the memory pipeline wins the issue slots: -0.7 % at
+// L=30 (same box, three alternating runs).  The variants measured against it and rejected -- the reverse, priority
+// around the issue of memory instructions only, a split barrier, a touch of the successor's tile, a rotated vector
+// layout -- are kept as a patch against this file: tools/experiments/r04_overlap_variants.patch.
+// (inline asm, not the builtin: see the CQuad note below on what either does to the table loads)
 #ifndef DNM_XP_PRIO
 #define DNM_XP_PRIO 1
-#endif
-#ifndef DNM_XP_SPLIT
-#define DNM_XP_SPLIT 0
-#endif
-#ifndef DNM_XP_PF
-#define DNM_XP_PF 0
-#endif
-#ifndef DNM_XP_PFY
-#define DNM_XP_PFY 0
-#endif
-#ifndef DNM_XP_PF_SHIFT_A
-#define DNM_XP_PF_SHIFT_A 21
-#define DNM_XP_PF_SHIFT_W 7
-#endif
-#ifndef DNM_XP_ROT_N
-#define DNM_XP_ROT_N 0
-#define DNM_XP_ROT_LO 0
-#define DNM_XP_ROT_SRC 0
 #endif
 #if DNM_XP_PRIO == 1
 #define DNM_PRIO_MEM() asm volatile("s_setprio 3")
 #define DNM_PRIO_LDS() asm volatile("s_setprio 0")
-#define DNM_PRIO_ISSUE(hi)
-#elif DNM_XP_PRIO == 2
-#define DNM_PRIO_MEM() asm volatile("s_setprio 0")
-#define DNM_PRIO_LDS() asm volatile("s_setprio 3")
-#define DNM_PRIO_ISSUE(hi)
-#elif DNM_XP_PRIO == 3
-#define DNM_PRIO_MEM()
-#define DNM_PRIO_LDS()
-#define DNM_PRIO_ISSUE(hi) do { if (hi) asm volatile("s_setprio 3"); else asm volatile("s_setprio 0"); } while (0)
 #else
 #define DNM_PRIO_MEM()
 #define DNM_PRIO_LDS()
-#define DNM_PRIO_ISSUE(hi)
 #endif
-// (timing experiment) bit rotation of a position: bits [SRC, SRC+N) -> [LO, LO+N), bits [LO, SRC) move up by N
-__device__ __forceinline__ uint32_t xp_rot(uint32_t v) {
-#if DNM_XP_ROT_N > 0
-  constexpr uint32_t lo = DNM_XP_ROT_LO, src = DNM_XP_ROT_SRC, n = DNM_XP_ROT_N;
-  const uint32_t keep = v & ~(((1u << (src + n)) - 1u) ^ ((1u << lo) - 1u));
-  const uint32_t mid = (v >> lo) & ((1u << (src - lo)) - 1u);
-  const uint32_t top = (v >> src) & ((1u << n) - 1u);
-  return keep | (mid << (lo + n)) | (top << lo);
-#else
-  return v;
-#endif
-}
 
 // +-c by a parity bit: flips the IEEE sign bit (v_xor on the high dword)
 __device__ __forceinline__ double flip_sign(double c, uint32_t parity_bit) {
@@ -231,7 +187,7 @@ __device__ __forceinline__ void accum_record(CQuad &Q, double a0, double a1, dou
 //   GATHER: partner amplitudes come from global memory instead of the LDS tile
 //   K0    : (LDS, !KVAR) the mask does not touch the k bits: the R partner rows
 //           sit at fixed LDS offsets from one address
-template <int R, int LOGNT, bool KVAR, bool CPLX, bool GATHER, bool K0, int SPLITSEL = 0, bool PACK = false>
+template <int R, int LOGNT, bool KVAR, bool CPLX, bool GATHER, bool K0, bool PACK = false>
 __device__ __forceinline__ void apply_records(CQuad *__restrict__ quads, uint32_t b, uint32_t e,
                                               double (&ar)[R], double (&ai)[R], const c128 *tile,
                                               const RowAddr<R> &RA, const c128 *__restrict__ x,
@@ -240,8 +196,6 @@ __device__ __forceinline__ void apply_records(CQuad *__restrict__ quads, uint32_
   constexpr uint32_t NT = 1u << LOGNT;
   for (uint32_t qi = b; qi < e; ++qi) {
     CQuad &Q = quads[qi];
-    if constexpr (SPLITSEL == 1) { if (Q.mask_tile >= 64u) continue; }
-    if constexpr (SPLITSEL == 2) { if (Q.mask_tile < 64u) continue; }
     const double a0 = slot_amp(Q, 0, tid, sbase);
     const double a1 = slot_amp(Q, 1, tid, sbase);
     double a2 = 0.0, a3 = 0.0;
@@ -258,13 +212,11 @@ __device__ __forceinline__ void apply_records(CQuad *__restrict__ quads, uint32_
       const c128 *__restrict__ src = Q.src ? xr : x;
       // the layout map is XOR-linear, so the partner of a mask sits at position(row) ^ position(mask)
       const uint32_t mloc = Q.mask_loc;
-      const uint32_t xm = xp_rot(skw ? (mloc ^ (((mloc >> skw) & ((1u << (skw - 4)) - 1u)) << 4)) : mloc) ^ (Q.src ? xrx : 0u);
+      const uint32_t xm = (skw ? (mloc ^ (((mloc >> skw) & ((1u << (skw - 4)) - 1u)) << 4)) : mloc) ^ (Q.src ? xrx : 0u);
       if (live) {
         // the partner sits at position(row) ^ position(mask)
-        DNM_PRIO_ISSUE(1);
 #pragma unroll
         for (int k = 0; k < R; ++k) xv[k] = *RA.at(src, k, xm);
-        DNM_PRIO_ISSUE(0);
       } else {
 #pragma unroll
         for (int k = 0; k < R; ++k) xv[k] = make_double2(0.0, 0.0);
@@ -324,18 +276,17 @@ tile_pass_kernel(const DevPass P, const c128 *__restrict__ x, c128 *__restrict__
   // block part, the thread part and the k part separately.  Sub-block passes add the swizzle of the block's own
   // offset (swz_xor_y for y, swz_xor_src for the partner's amplitudes)
   const uint32_t skw = (uint32_t)P.swz_shift;
-  auto lay = [skw](uint32_t v) -> uint32_t { return xp_rot(skw ? (v ^ (((v >> skw) & ((1u << (skw - 4)) - 1u)) << 4)) : v); };
+  auto lay = [skw](uint32_t v) -> uint32_t { return skw ? (v ^ (((v >> skw) & ((1u << (skw - 4)) - 1u)) << 4)) : v; };
   RowAddr<R> RA;
   RA.t4 = lay(dep_t) << 4;
   RA.upos = lay(base);
-  RA.tmask = xp_rot(P.pos_tmask);
+  RA.tmask = P.pos_tmask;
 #pragma unroll
   for (int k = 0; k < R; ++k) RA.kpos[k] = lay(deposit<MAXSEG>((uint32_t)k << LOGNT, P.nseg, P.seg_off, P.seg_len, P.seg_pos));
-  const uint32_t yx = xp_rot(P.swz_xor_y);
+  const uint32_t yx = P.swz_xor_y;
 
   // ---- stage the tile: each wavefront moves 1 KB runs, lane = low 6 tile bits
   DNM_PRIO_MEM();
-  DNM_PRIO_ISSUE(1);
   if (!P.need_tile) {
     // pure gather pass (remote partner vector): nothing to stage
   } else if constexpr (GLDS) {
@@ -352,7 +303,6 @@ tile_pass_kernel(const DevPass P, const c128 *__restrict__ x, c128 *__restrict__
 #pragma unroll
       for (int k = 0; k < R; ++k) v[k] = *RA.at(x, k, 0u);
     }
-    DNM_PRIO_ISSUE(0);
 #pragma unroll
     for (int k = 0; k < R; ++k) tile[tid + k * NT] = v[k];
   }
@@ -407,7 +357,7 @@ tile_pass_kernel(const DevPass P, const c128 *__restrict__ x, c128 *__restrict__
   CQuad *__restrict__ quads = (CQuad *)P.quads;
 
 #define DNM_LOOP(LP, KV, CX, GA, KZ) \
-  apply_records<R, LOGNT, KV, CX, GA, KZ, 0, PACK>(quads, P.loop[LP], P.loop[LP + 1], ar, ai, tile, RA, x, xr, tid, sbase, skw, xp_rot(P.swz_xor_src))
+  apply_records<R, LOGNT, KV, CX, GA, KZ, PACK>(quads, P.loop[LP], P.loop[LP + 1], ar, ai, tile, RA, x, xr, tid, sbase, skw, P.swz_xor_src)
   if constexpr (GV >= 1) {
     // (two live records in flight at a time -- half the L2 round trips of this phase -- changed nothing:
     // profiles/r03_exp9_gather_pairs.txt; the passes are not bound by the life of a workgroup)
@@ -488,61 +438,16 @@ tile_pass_kernel(const DevPass P, const c128 *__restrict__ x, c128 *__restrict__
     }
   }
   };
-#if DNM_XP_SPLIT >= 1
-  // records whose partner amplitudes this wavefront staged itself need no barrier (LDS operations of one wave
-  // complete in order)
-  if (P.need_tile)
-    apply_records<R, LOGNT, false, false, false, true, 1>(quads, P.loop[LP_TILE_REAL_K0], P.loop[LP_TILE_REAL_K0 + 1], ar, ai,
-                                                          tile, RA, x, xr, tid, sbase, skw, 0u);
-#endif
-#if DNM_XP_SPLIT >= 2
-  diag_part2();
-#endif
-#if DNM_XP_PF > 0
-  // touch the x tile of the workgroup that will follow on this XCD (dispatch is in block order and block b runs on
-  // XCD b % 8): one dword per 64 bytes, moved by the LDS DMA into a dump area (no register holds it).  Inline asm:
-  // the compiler must not know about the transfer, or it waits for it before the first LDS read.  The successor is
-  // DNM_XP_PF = 2^(selector + group bits) workgroups ahead, i.e. one step in the block field above them: its base is
-  // base + 2^shift (shifts of the L=30 headline plan: DNM_XP_PF_SHIFT_A for the accumulating pass, _W for the window
-  // pass; a timing experiment for that plan only)
-  if (P.need_tile && blockIdx.x + (uint32_t)DNM_XP_PF < gridDim.x && (tid & 3u) == 0u) {
-    __shared__ uint32_t pf_dump[NT];
-    const uint32_t sh = P.accumulate ? DNM_XP_PF_SHIFT_A : DNM_XP_PF_SHIFT_W;
-    const uint32_t ux = RA.upos ^ lay(base + ((uint32_t)(DNM_XP_PF / 512) << sh));
-    const uint32_t dump_u = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(LDS_AS uint32_t *)(pf_dump + (tid & ~63u)));
-#pragma unroll
-    for (int k = 0; k < R; ++k) {
-      const uint32_t u = RA.upos ^ ux ^ RA.kpos[k];
-      const char *sb = reinterpret_cast<const char *>(x) + ((uint64_t)(u & ~RA.tmask) << 4);
-      const uint32_t vo = RA.t4 ^ ((u & RA.tmask) << 4);
-      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(vo), "s"(sb), "s"(dump_u));
-#if DNM_XP_PFY
-      if (P.accumulate) {
-        const char *yb = reinterpret_cast<const char *>(y) + ((uint64_t)((u ^ yx) & ~RA.tmask) << 4);
-        const uint32_t yo = RA.t4 ^ (((u ^ yx) & RA.tmask) << 4);
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(yo), "s"(yb), "s"(dump_u));
-      }
-#endif
-    }
-  }
-#endif
   __syncthreads();
   DNM_PRIO_LDS();
   DNM_PH(3, 0);
-#if DNM_XP_SPLIT < 2
   diag_part2();
-#endif
 
   DNM_PH(4, 0);
   // ---- off-diagonal masks, one branch-free loop per record class
 #define DNM_LOOP(LP, KV, CX, GA, KZ) \
-  apply_records<R, LOGNT, KV, CX, GA, KZ, 0, PACK>(quads, P.loop[LP], P.loop[LP + 1], ar, ai, tile, RA, x, xr, tid, sbase, skw, xp_rot(P.swz_xor_src))
-#if DNM_XP_SPLIT >= 1
-  apply_records<R, LOGNT, false, false, false, true, 2>(quads, P.loop[LP_TILE_REAL_K0], P.loop[LP_TILE_REAL_K0 + 1], ar, ai,
-                                                        tile, RA, x, xr, tid, sbase, skw, 0u);
-#else
+  apply_records<R, LOGNT, KV, CX, GA, KZ, PACK>(quads, P.loop[LP], P.loop[LP + 1], ar, ai, tile, RA, x, xr, tid, sbase, skw, P.swz_xor_src)
   DNM_LOOP(LP_TILE_REAL_K0, false, false, false, true);
-#endif
   DNM_LOOP(LP_TILE_REAL, false, false, false, false);
   DNM_LOOP(LP_TILE_CPLX, false, true, false, false);
   DNM_LOOP(LP_TILE_KVAR_REAL, true, false, false, false);
@@ -557,16 +462,10 @@ tile_pass_kernel(const DevPass P, const c128 *__restrict__ x, c128 *__restrict__
 
   DNM_PH(5, 0);
   DNM_PRIO_MEM();
-#if DNM_XP_PF > 0
-  // the touched words have to land before the workgroup's LDS is given up
-  asm volatile("s_waitcnt vmcnt(0)");
-#endif
   if (late_y) {
     c128 w[R];
-    DNM_PRIO_ISSUE(1);
 #pragma unroll
     for (int k = 0; k < R; ++k) w[k] = load_streaming(RA.at((const c128 *)y, k, yx));
-    DNM_PRIO_ISSUE(0);
 #pragma unroll
     for (int k = 0; k < R; ++k) {
       ar[k] += w[k].x;
@@ -574,7 +473,6 @@ tile_pass_kernel(const DevPass P, const c128 *__restrict__ x, c128 *__restrict__
     }
   }
   DNM_PH(6, 1);
-  DNM_PRIO_ISSUE(1);
   if (P.cache_policy & 64) {
 #pragma unroll
     for (int k = 0; k < R; ++k) store_streaming(RA.at(y, k, yx), ar[k], ai[k]);
