@@ -161,6 +161,89 @@ rdm_tile_kernel(const c128 *__restrict__ x, const SubView sub, const RdmGeom geo
   }
 }
 
+// ---- one to three kept spins: a streaming kernel -----------------------------------------------------------------
+// K = 2^k <= 8 rows: the whole matrix fits a thread's registers.  A thread walks traced configurations (consecutive
+// threads take consecutive configurations: their loads are neighbours wherever the lowest traced bits are), loads the
+// K amplitudes psi(a, tr) and adds psi(a) conj(psi(b)) for a >= b to K (K + 1) / 2 complex accumulators; wavefronts
+// reduce by shuffles, the workgroup through LDS, and every workgroup writes one slice of the ONE tile (TM = max(4, K))
+// that rdm_reduce_kernel / rdm_finalize_kernel then sum -- the scratch format, the slice tree and the mirroring are
+// those of the tiled form.  The tiled kernel moves such a state in 8 KB chunks between barriers (1.3-2.5 TB/s of x at
+// L = 26); this one is bound by the read.
+constexpr int RDM_SMALL_MAXK = 2;      // (three spins: 1.33x on the Full space, 0.76x on SpinConserve -- left to the tiles)
+constexpr int rdm_small_cfg(int k) { return k <= 2 ? 4 : 1; }      // configurations a thread has in flight (registers)
+
+template <int ST, int LOGK>
+__global__ void __launch_bounds__(RDM_NT)
+rdm_small_kernel(const c128 *__restrict__ x, const SubView sub, const RdmGeom geo, c128 *__restrict__ partial) {
+  constexpr int K = 1 << LOGK;
+  constexpr int TM = K < 4 ? 4 : K;
+  constexpr int NP = K * (K + 1) / 2;
+  constexpr int RDM_SMALL_CFG = rdm_small_cfg(LOGK);
+  __shared__ double red[RDM_NT / 64][2 * NP];
+  uint64_t pa[K];
+#pragma unroll
+  for (int a = 0; a < K; ++a) pa[a] = rdm_deposit((uint64_t)a, geo.klen, geo.kpos, geo.nseg_keep);
+  const int64_t T = (int64_t)1 << (geo.L - geo.k);
+  double ar[NP], ai[NP];
+#pragma unroll
+  for (int p = 0; p < NP; ++p) ar[p] = ai[p] = 0.0;
+  const int64_t stride = (int64_t)gridDim.x * RDM_NT;
+  for (int64_t tr0 = (int64_t)blockIdx.x * RDM_NT + threadIdx.x; tr0 < T; tr0 += stride * RDM_SMALL_CFG) {
+    c128 psi[RDM_SMALL_CFG][K];
+#pragma unroll
+    for (int c = 0; c < RDM_SMALL_CFG; ++c) {
+      const int64_t tr = tr0 + c * stride;
+      const uint64_t pt = rdm_deposit((uint64_t)(tr < T ? tr : 0), geo.tlen, geo.tpos, geo.nseg_tr);
+#pragma unroll
+      for (int a = 0; a < K; ++a) psi[c][a] = tr < T ? rdm_fetch<ST>(x, pa[a] | pt, sub) : make_double2(0.0, 0.0);
+    }
+#pragma unroll
+    for (int c = 0; c < RDM_SMALL_CFG; ++c) {
+      int p = 0;
+#pragma unroll
+      for (int a = 0; a < K; ++a)
+#pragma unroll
+        for (int b = 0; b <= a; ++b, ++p) {      // psi(a) conj(psi(b))
+          ar[p] = fma(psi[c][a].x, psi[c][b].x, ar[p]);
+          ar[p] = fma(psi[c][a].y, psi[c][b].y, ar[p]);
+          ai[p] = fma(psi[c][a].y, psi[c][b].x, ai[p]);
+          ai[p] = fma(-psi[c][a].x, psi[c][b].y, ai[p]);
+        }
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      ar[p] += __shfl_xor(ar[p], off, 64);
+      ai[p] += __shfl_xor(ai[p], off, 64);
+    }
+    if (lane == 0) {
+      red[wave][2 * p] = ar[p];
+      red[wave][2 * p + 1] = ai[p];
+    }
+  }
+  __syncthreads();
+  // one slice of the tile, both triangles (a diagonal tile is not mirrored by rdm_finalize_kernel): element (a, b)
+  // with b > a is the conjugate of (b, a); rows and columns beyond K stay zero
+  c128 *out = partial + (int64_t)blockIdx.x * (TM * TM);
+  for (int e = threadIdx.x; e < TM * TM; e += RDM_NT) {
+    const int a = e / TM, b = e % TM;
+    c128 v = make_double2(0.0, 0.0);
+    if (a < K && b < K) {
+      const int hi = a > b ? a : b, lo = a > b ? b : a;
+      const int p = hi * (hi + 1) / 2 + lo;
+      for (int w = 0; w < RDM_NT / 64; ++w) {
+        v.x += red[w][2 * p];
+        v.y += red[w][2 * p + 1];
+      }
+      if (b > a) v.y = -v.y;
+    }
+    out[e] = v;
+  }
+}
+
 // ---- 64 x 64 tiles on the matrix cores (k >= 6) ------------------------------------------------------------
 // The same tile, slices and scratch as rdm_tile_kernel<ST, 6>, with the rank-T update done by
 // v_mfma_f64_16x16x4_f64: a wavefront owns a 32 x 32 block of the tile (2 x 2 MFMA blocks, real and imaginary
@@ -346,7 +429,15 @@ static int rdm_launch(const c128 *x, const SubView &sub, const RdmGeom &geo, int
   constexpr int TM = 1 << LOGTM;
   // 64 x 64 tiles run on the matrix cores (DNM_RDM_MFMA=0: the vector-unit form, for comparison)
   static const bool use_mfma = [] { const char *e = knob("DNM_RDM_MFMA"); return !(e && e[0] == '0'); }();
-  if (LOGTM == 6 && use_mfma)
+  static const bool use_small = [] { const char *e = knob("DNM_RDM_SMALL"); return !(e && e[0] == '0'); }();
+  if (geo.k >= 1 && geo.k <= RDM_SMALL_MAXK && LOGTM <= 3 && use_small) {
+    // (nsplit is the number of workgroups of the streaming kernel: rdm_plan)
+    switch (geo.k) {
+      case 1: hipLaunchKernelGGL((rdm_small_kernel<ST, 1>), dim3((unsigned)nsplit), dim3(RDM_NT), 0, st, x, sub, geo, partial); break;
+      case 2: hipLaunchKernelGGL((rdm_small_kernel<ST, 2>), dim3((unsigned)nsplit), dim3(RDM_NT), 0, st, x, sub, geo, partial); break;
+      default: hipLaunchKernelGGL((rdm_small_kernel<ST, 3>), dim3((unsigned)nsplit), dim3(RDM_NT), 0, st, x, sub, geo, partial); break;
+    }
+  } else if (LOGTM == 6 && use_mfma)
     hipLaunchKernelGGL((rdm_mfma_kernel<ST>), dim3((unsigned)ntiles, (unsigned)nsplit), dim3(RDM_NT), 0, st, x, sub,
                        geo, chunks_per_split, ntiles, partial);
   else
@@ -387,6 +478,23 @@ void rdm_plan(const RdmGeom &geo, int *logtm, int *ntiles, int *nsplit, int64_t 
               size_t *partial_bytes) {
   int ltm = geo.k < 2 ? 2 : (geo.k > 6 ? 6 : geo.k);
   const int64_t K = (int64_t)1 << geo.k, T = (int64_t)1 << (geo.L - geo.k);
+  {
+    static const bool use_small = [] { const char *e = knob("DNM_RDM_SMALL"); return !(e && e[0] == '0'); }();
+    if (geo.k >= 1 && geo.k <= RDM_SMALL_MAXK && use_small) {
+      // streaming kernel: one tile, one slice per workgroup; a thread takes RDM_SMALL_CFG configurations per trip
+      const int64_t per_wg = (int64_t)RDM_NT * rdm_small_cfg(geo.k);
+      int64_t ns = (T + per_wg - 1) / per_wg;
+      if (ns > 4096) ns = 4096;
+      if (ns < 1) ns = 1;
+      const int64_t TMs = (int64_t)1 << ltm;
+      *logtm = ltm;
+      *ntiles = 1;
+      *nsplit = (int)ns;
+      *chunks_per_split = 0;
+      *partial_bytes = ((size_t)ns + (size_t)ns / 31 + 2) * (size_t)(TMs * TMs) * sizeof(c128);
+      return;
+    }
+  }
   const int64_t TM = (int64_t)1 << ltm, TK = RDM_STAGE / TM;
   const int64_t side = (K + TM - 1) / TM;
   const int64_t nt = side * (side + 1) / 2;

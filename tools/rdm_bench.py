@@ -21,7 +21,7 @@ def main():
         if st is None:
             st = State(L=L, subspace=sub)
             st.set_random(seed=0, device_rng=True)
-        for keep in ([0], [L // 2], list(range(4)), list(range(L - 6, L)), list(range(0, 16, 2)), list(range(10)),
+        for keep in ([0], [L // 2], [3, 20], [1, 2, 3], [0, 9, L - 1], list(range(4)), list(range(L - 6, L)), list(range(0, 16, 2)), list(range(10)),
                      list(range(L // 2))) if not only else (list(range(only)),):
             if len(keep) > 13:
                 continue
