@@ -35,13 +35,13 @@ def main():
     s.close()
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1",
                       HSA_ENABLE_IPC_MODE_LEGACY="0")
-    faulthandler.dump_traceback_later(int(os.environ.get("DNM_TEST_HANG_S", "150")), exit=True)
+    faulthandler.dump_traceback_later(int(os.environ.get("DNM_TEST_HANG_S", "500")), exit=True)
     import numpy as np
     import torch
     import torch.distributed as dist
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev, timeout=datetime.timedelta(seconds=60))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev, timeout=datetime.timedelta(seconds=600))
     from dynamite_amd import _comm, backend, computations, config, models, msc_tools, _lib
     from dynamite_amd.states import State
     from dynamite_amd.subspaces import Full

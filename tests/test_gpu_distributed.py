@@ -41,10 +41,12 @@ def _worker(rank, world, port, case, out_dir):
     elif case == "full_transpose":
         os.environ["DNM_EXCHANGE"] = "transpose"        # two ranks would take the partner blocks
     import faulthandler
-    faulthandler.dump_traceback_later(int(os.environ.get("DNM_TEST_HANG_S", "90")), exit=True)   # a stuck rank reports where
+    faulthandler.dump_traceback_later(int(os.environ.get("DNM_TEST_HANG_S", "600")), exit=True)   # a stuck rank reports where
     import datetime
     import torch.distributed as dist
-    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    # (generous: on a fresh box the ranks page the image in at different speeds -- the first import of torch and of the
+    # HIP libraries takes a minute or two -- and a rank that arrives late must not time its peers out)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=900))
     import scipy.sparse.linalg as spla
     from dynamite_amd import config, models
     from dynamite_amd.states import State
@@ -275,7 +277,7 @@ def test_bench_multi_rank_flow_one_gpu(world):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
            "--gpus", str(world), "--steps", "2", "--warmup", "1", "--L", "22"]
-    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=240)
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout
@@ -300,7 +302,7 @@ def test_bench_falls_back_when_the_selfcheck_fails():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
            "--gpus", "4", "--steps", "2", "--warmup", "1", "--L", "22"]
-    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=240)
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
     assert d["config"]["exchange"] == "partner" and d["config"]["exchange_selfcheck"].startswith("failed")
@@ -314,13 +316,13 @@ def _rccl_worker(rank, world, port, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_RANK=str(rank), RANK=str(rank),
                       WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0")
     import faulthandler
-    faulthandler.dump_traceback_later(int(os.environ.get("DNM_TEST_HANG_S", "120")), exit=True)
+    faulthandler.dump_traceback_later(int(os.environ.get("DNM_TEST_HANG_S", "600")), exit=True)
     import datetime
     import torch
     import torch.distributed as dist
     torch.cuda.set_device(rank)
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank),
-                            timeout=datetime.timedelta(seconds=90))
+                            timeout=datetime.timedelta(seconds=900))
     from dynamite_amd import config, models, _comm
     from dynamite_amd.states import State
     from dynamite_amd.subspaces import Full
@@ -383,7 +385,7 @@ def test_rccl_transport_world_one():
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rccl_self_child.py")], env=env, cwd=ROOT,
-                         capture_output=True, text=True, timeout=400)
+                         capture_output=True, text=True, timeout=900)
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert out.returncode in (0, 77) and lines, "rc %d\n%s\n%s" % (out.returncode, out.stdout[-1500:], out.stderr[-3000:])
     rep = json.loads(lines[-1])
