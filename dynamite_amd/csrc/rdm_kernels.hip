@@ -392,6 +392,10 @@ rdm_finalize_kernel(const c128 *__restrict__ partial, int ntiles, int nsplit, in
     const int r = e / TM, cidx = e % TM;
     const int64_t a = (int64_t)ti * TM + r, b = (int64_t)tj * TM + cidx;
     if (a >= K || b >= K) continue;
+    // a diagonal tile holds both triangles, accumulated in different orders (MFMA: the imaginary part of (a, b) and
+    // of (b, a) add the same products in different sequence): the lower one is taken and mirrored like every other
+    // tile, so that rho is Hermitian to the last bit, as the reference's element-by-element sum is
+    if (ti == tj && cidx > r) continue;
     double sr = 0.0, si = 0.0;
     for (int s = 0; s < nsplit; ++s) {
       const c128 v = partial[((int64_t)s * ntiles + tile) * (TM * TM) + e];
@@ -400,7 +404,7 @@ rdm_finalize_kernel(const c128 *__restrict__ partial, int ntiles, int nsplit, in
     }
     if (a == b) si = 0.0;     // |psi|^2 sums: the reference's a * conj(a) has no imaginary part either
     rho[a * K + b] = make_double2(sr, si);
-    if (ti != tj) rho[b * K + a] = make_double2(sr, -si);
+    if (a != b) rho[b * K + a] = make_double2(sr, -si);
   }
 }
 

@@ -517,6 +517,32 @@ def test_rdm_vs_oracle_and_reshape(kind):
         assert abs(np.trace(dm) - 1) < 1e-13 and np.allclose(dm, dm.conj().T, atol=1e-17, rtol=0)
 
 
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("DNM_FUZZ_RDM_N", "24"))))
+def test_fuzz_rdm(seed):
+    """Random sizes, subspaces and SCATTERED keep sets of 1..10 spins (the streaming kernel for one / two spins, the
+    vector-unit tiles, the MFMA tiles from six spins on with several tiles and slices) against the oracle's restatement
+    of rdm_<SUBSPACE> (bpetsc_template_1.c:87-165)."""
+    from oracle import oracle as orc
+    from gpu_util import orc_sub
+    from dynamite_amd.computations import reduced_density_matrix
+    rs = np.random.RandomState(9000 + seed)
+    L = int(rs.randint(6, 17))
+    kind = ["full", "even", "odd", "sc", "explicit"][rs.randint(5)]
+    sub = {"full": lambda: Full(L=L), "even": lambda: Parity('even', L=L), "odd": lambda: Parity('odd', L=L),
+           "sc": lambda: SpinConserve(L, int(rs.randint(1, L))),
+           "explicit": lambda: Explicit(np.sort(rs.choice(1 << L, min(1 << L, int(rs.randint(2, 3000))), replace=False)), L=L)}[kind]()
+    st = State(L=L, subspace=sub, state='random', seed=seed)
+    v = st.to_numpy()
+    osub = orc_sub(sub)
+    for _ in range(4):
+        k = int(rs.randint(1, min(L, 10) + 1))
+        keep = sorted(int(i) for i in rs.choice(L, size=k, replace=False))
+        dm = reduced_density_matrix(st, keep)
+        want = orc.rdm(osub, v, np.array(keep, dtype=np.int64))
+        assert dm.shape == want.shape and np.max(np.abs(dm - want)) < 1e-14, (L, kind, keep)
+        assert np.allclose(dm, dm.conj().T, atol=1e-17, rtol=0)
+
+
 def test_rdm_large_properties():
     """L = 24 (2^24 amplitudes): trace, Hermiticity, S(A) = S(complement) for a pure state,
     and agreement with the host on a sampled 2-spin block."""
