@@ -378,6 +378,55 @@ def test_real_packed_spinconserve_multiply(small_layout, name, L, k):
     mat.destroy()
 
 
+def _random_real_chain(L, rs):
+    """Nearest-neighbour chain with a random REAL hopping per bond (some bonds missing), random ZZ couplings at distance
+    1..3 and random fields: real symmetric, a chain -- what the real two-pass form accepts."""
+    from dynamite_amd.operators import sigmax, sigmay, sigmaz, op_sum
+    terms = []
+    for i in range(L - 1):
+        if rs.rand() < 0.2:
+            continue
+        terms.append(rs.uniform(-1, 1) * (sigmax(i) * sigmax(i + 1) + sigmay(i) * sigmay(i + 1)))
+    for i in range(L):
+        terms.append(rs.uniform(-1, 1) * sigmaz(i))
+        for dist in (1, 2, 3):
+            if i + dist < L and rs.rand() < 0.5:
+                terms.append(rs.uniform(-1, 1) * sigmaz(i) * sigmaz(i + dist))
+    H = op_sum(terms)
+    H.L = L
+    return H
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("DNM_SC3_FUZZ_REAL_N", "32"))))
+def test_fuzz_internal_layout_real(small_layout, seed):
+    """The real-arithmetic form of the two tiled passes on random real chains and random SpinConserve sectors, with its
+    fused sums, against the oracle."""
+    rs = np.random.RandomState(7000 + seed)
+    L = int(rs.randint(11, 16))
+    k = int(rs.randint(1, L))
+    H = _random_real_chain(L, rs)
+    sub = SpinConserve(L, k)
+    n = sub.get_dimension()
+    try:
+        mat = shell(H, sub, flags=_lib.MAT_REAL_PACKED)
+    except _lib.BackendError as e:          # (more mixed diagonal patterns than the on-the-fly diagonal takes: no real form)
+        assert "real-packed" in str(e)
+        return
+    xr = rs.standard_normal(n)
+    want = orc.matvec(orc_msc(H), orc_sub(sub), orc_sub(sub), xr.astype(np.complex128))
+    assert np.abs(want.imag).max() == 0.0
+    got, xd, yd = _real_mult(mat, sub, xr)
+    scale = max(1.0, np.abs(H.msc['coeffs']).sum()) * np.abs(xr).max()
+    assert np.abs(got.imag).max() == 0.0
+    assert np.abs(got.real - want.real).max() <= 64 * 2.2e-16 * scale, (L, k, mat.describe())
+    d = (C.c_double * 3)()
+    _lib.check(_lib.lib().dnm_mat_mult_lanczos(mat.handle, C.c_void_p(xd.data_ptr()), C.c_void_p(yd.data_ptr()), None,
+                                               0.0, d, None))
+    assert abs(d[0] - xr @ want.real) <= 1e-11 * max(1.0, abs(xr @ want.real))
+    assert abs(d[2] - want.real @ want.real) <= 1e-11 * max(1e-300, want.real @ want.real)
+    mat.destroy()
+
+
 def test_real_packed_spinconserve_refusals(small_layout):
     """No real form for an operator with imaginary bond elements, nor for one that is not a chain (row kernel)."""
     sub = SpinConserve(13, 6)
