@@ -729,6 +729,50 @@ def test_fuzz_krylov_random_operators(seed):
         assert abs(hi[0] - w[-1]) < 1e-9
 
 
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("DNM_FUZZ_EIGS_REAL_N", "12"))))
+def test_fuzz_eigsolve_real_arithmetic(monkeypatch, seed):
+    """eigsolve in real arithmetic (forced) on random real symmetric Pauli sums, Full and Parity, through the restarted,
+    the basis-free and the filtered driver, at both ends: eigenvalues against dense diagonalisation, the returned complex
+    states against the reference's residual bar (tests/integration/test_eigsolve.py:17-88)."""
+    from test_gpu_matvec import _random_real_symmetric
+    from dynamite_amd.computations import eigsolve
+    rs = np.random.RandomState(8000 + seed)
+    L = int(rs.randint(10, 13))              # (the dense reference on the host sets the size)
+    for k, v in (("DNM_TILE_BITS", "8"), ("DNM_LOG_ROWS", "2"), ("DNM_PLAN_MODE", str(int(rs.randint(3)))), ("DNM_GBITS", "3"),
+                 ("DNM_AMIN", "3"), ("DNM_EIGS_REAL", "1")):
+        monkeypatch.setenv(k, v)
+    mode = ["restarted", "basis_free", "filtered"][rs.randint(3)]
+    if mode == "basis_free":
+        monkeypatch.setenv("DNM_EIGS_BASISFREE", "1")
+    elif mode == "filtered":
+        monkeypatch.setenv("DNM_EIGS_FILTER", "1")
+    H = _random_real_symmetric(L, int(rs.randint(6, 30)), rs)
+    sub = Full(L=L) if rs.randint(2) else Parity(int(rs.randint(2)), L=L)
+    H.add_subspace(sub)
+    H.allow_projection = True
+    A = H.to_numpy(subspaces=(sub, sub)).toarray()
+    A = (A + A.conj().T) / 2
+    if np.abs(A.imag).max() > 0:
+        return                                   # (the projection onto a parity sector of a real operator stays real; guard)
+    w = np.linalg.eigvalsh(A)
+    if np.ptp(w) < 1e-6:
+        return
+    which = ["lowest", "highest"][rs.randint(2)]
+    nev = 1 if mode == "basis_free" else int(rs.randint(1, 4))
+    ev, vecs = H.eigsolve(nev=nev, which=which, tol=1e-10, subspace=sub, getvecs=True)
+    if eigsolve.last_stats['real_arithmetic'] is not True:
+        # a parity projection that drops terms can leave an operator the packed form refuses; then complex ran
+        assert isinstance(sub, Parity)
+    want = w[0] if which == "lowest" else w[-1]
+    assert abs(ev[0] - want) < 1e-8 * max(1.0, abs(want)), (L, mode, which)
+    for e, vs in zip(ev, vecs):
+        v = vs.to_numpy()
+        assert np.min(np.abs(w - e)) < 1e-8 * max(1.0, abs(e))                    # every returned value is an eigenvalue
+        assert np.linalg.norm(A @ v - e * v) < 1e-7 * max(1.0, abs(e)), (L, mode, which)
+        assert abs(np.linalg.norm(v) - 1) < 1e-10
+    H.destroy_mat()
+
+
 def test_tools_memory():
     from dynamite_amd import tools
     tools.track_memory()
