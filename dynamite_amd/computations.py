@@ -365,19 +365,21 @@ def _rdm_spectrum(state, keep):
     rho = _reduced_density_matrix(state, keep, on_device=True)
     if rho is None:
         return None
-    from .subspaces import SpinConserve
-    if type(state.subspace) is SpinConserve:
+    from .subspaces import Parity, SpinConserve
+    if type(state.subspace) in (SpinConserve, Parity):
         # a state of fixed magnetisation: rho couples only kept configurations with equal numbers of up spins -- the
         # spectrum is that of its blocks (C(k, n) rows each: at 13 of 26 spins 14 blocks of <= 1716 rows instead of
-        # one matrix of 8192)
+        # one matrix of 8192); a state of fixed parity: equal parities of that number, two blocks of half the size
         K = rho.shape[0]
         a = torch.arange(K, device=rho.device)
-        ones = torch.zeros(K, dtype=torch.int64, device=rho.device)
+        label = torch.zeros(K, dtype=torch.int64, device=rho.device)
         for b in range(len(keep)):
-            ones += (a >> b) & 1
+            label += (a >> b) & 1
+        if type(state.subspace) is Parity:
+            label &= 1
         out = []
-        for n in range(len(keep) + 1):
-            idx = torch.nonzero(ones == n).flatten()
+        for n in range(int(label.max()) + 1):
+            idx = torch.nonzero(label == n).flatten()
             out.append(torch.linalg.eigvalsh(rho.index_select(0, idx).index_select(1, idx)))
         return np.sort(torch.cat(out).cpu().numpy())
     return torch.linalg.eigvalsh(rho).cpu().numpy()
