@@ -142,7 +142,7 @@ def secondary(wd, budget_s=15.0):
     the budget is spent."""
     import numpy as np
     import torch
-    from dynamite_amd import models
+    from dynamite_amd import models, _lib
     from dynamite_amd.config import config
     from dynamite_amd.states import State
     from dynamite_amd.subspaces import Full, SpinConserve
@@ -174,17 +174,18 @@ def secondary(wd, budget_s=15.0):
         _, dt = timed(lambda: H.evolve(psi, t=1.0, result=res))
         runs.append((dt, dict(evolve.last_stats)))
     nrm = res.norm()
-    assert abs(nrm - 1.0) < 1e-8, "evolve did not preserve the norm: %r" % nrm
     dt, st = runs[-1]
     out["evolve_L26_xxz_t1"] = {"wall_s": dt, "first_call_wall_s": runs[0][0], "matvecs": st["matvecs"],
                                 "outer_steps": st["its"], "ms_per_matvec_equivalent": dt / max(1, st["matvecs"]) * 1e3,
                                 "algo": "default: Krylov (expokit-style sub-steps) handing the rest of a real-time "
                                         "interval to the Chebyshev expansion",
                                 "norm_error": abs(nrm - 1.0), "dim": 1 << L}
+    if not abs(nrm - 1.0) < 1e-8:
+        out["evolve_L26_xxz_t1"]["failed_checks"] = ["evolve did not preserve the norm: %r" % nrm]
     H.destroy_mat()
     del psi, res, H
 
-    # -- one Lanczos step at the headline size
+    # -- one Lanczos step at the headline size, and evolve(t=1) there
     if left() > 7.0:
         wd.phase("secondary: Lanczos L=30")
         L = 30
@@ -193,35 +194,59 @@ def secondary(wd, budget_s=15.0):
         H.add_subspace(sub)
         tol = 1e-6
         dim = 1 << L
+        # Every solve below is timed WARM: the basis-free Lanczos works in four vectors (64 GiB at L=30) that the
+        # library keeps between solves; a first solve pays for acquiring them (fresh device memory is scrubbed when it
+        # is handed out: 1-2 s).  They are acquired and touched here, untimed as a solve but timed on their own, so
+        # that `wall_s` is what every solve after the first takes and `cold_wall_s` what the first one does.
+        _, acquire_s = timed(lambda: _lib.check(_lib.lib().dnm_workspace_reserve(4 * dim * 16, None)))
 
         def lanczos(real):
             """complex128 vectors as the reference's EPS has them (real=False), then the path eigsolve takes on its
             own for this operator: real arithmetic, two amplitudes per complex128 element (half the bytes)"""
             config.eigs_real_arithmetic = real
             try:
-                # the first solve of the process may pay for its 64 GiB of work vectors (device memory that was
-                # used and freed -- the headline's x and y -- is scrubbed when it is handed out again, about 1 s):
-                # the complex128 solve runs twice and the faster call counts, the real one finds the workspace in place
                 (ev, dt) = timed(lambda: H.eigsolve(nev=1, tol=tol))
                 st = dict(eigsolve.last_stats)
-                if not real and left() > dt + 6.0:
-                    (ev, dt2) = timed(lambda: H.eigsolve(nev=1, tol=tol))
-                    dt = min(dt, dt2)
             finally:
                 config.eigs_real_arithmetic = None
-            assert st["max_rel_residual"] <= tol * 1.01, "Lanczos residual %r above tol" % st["max_rel_residual"]
-            assert bool(st["real_arithmetic"]) == real
+            problems = []
+            if not st["max_rel_residual"] <= tol * 1.01:
+                problems.append("Lanczos residual %r above tol" % st["max_rel_residual"])
+            if bool(st["real_arithmetic"]) != real:
+                problems.append("arithmetic is not the one asked for")
             step_ms = dt / st["matvecs"] * 1e3
             per_amp = (ALG_BYTES_PER_AMP + 48.0) * (0.5 if real else 1.0)
             bw = per_amp * dim / (step_ms * 1e-3) / 1e9
-            return {"wall_s": dt, "matvecs": st["matvecs"], "E0": float(ev[0]),
-                    "ms_per_step": step_ms, "measured_rel_residual": st["max_rel_residual"], "tol": tol,
-                    "arithmetic": "real (f64, 8 B per amplitude)" if real else "complex128 (16 B per amplitude)",
-                    "roofline": {"bound": "hbm", "alg_bytes_per_amp_per_step": per_amp, "achieved": bw,
-                                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bw / HBM_PEAK_GBS}}
+            r = {"wall_s": dt, "call": "warm (workspace in place before the timed call)",
+                 "workspace_acquire_s": acquire_s, "cold_wall_s": dt + acquire_s,
+                 "matvecs": st["matvecs"], "E0": float(ev[0]),
+                 "ms_per_step": step_ms, "measured_rel_residual": st["max_rel_residual"], "tol": tol,
+                 "arithmetic": "real (f64, 8 B per amplitude)" if real else "complex128 (16 B per amplitude)",
+                 "roofline": {"bound": "hbm", "alg_bytes_per_amp_per_step": per_amp, "achieved": bw,
+                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bw / HBM_PEAK_GBS}}
+            if problems:
+                r["failed_checks"] = problems
+            return r
         out["lanczos_L30"] = lanczos(False)
-        if left() > 4.0:
+        if left() > 3.0:
             out["lanczos_L30_real_arithmetic"] = lanczos(True)
+        if left() > 3.5:
+            wd.phase("secondary: evolve L=30")
+            psi = State(L=L, subspace=sub)
+            psi.set_random(seed=0)
+            res = State(L=L, subspace=sub)
+            _, dt = timed(lambda: H.evolve(psi, t=1.0, result=res))
+            st = dict(evolve.last_stats)
+            nrm = res.norm()
+            out["evolve_L30_mbl_t1"] = {"wall_s": dt, "call": "warm (workspace in place)", "matvecs": st["matvecs"],
+                                        "outer_steps": st["its"],
+                                        "ms_per_matvec_equivalent": dt / max(1, st["matvecs"]) * 1e3,
+                                        "norm_error": abs(nrm - 1.0), "dim": dim}
+            if not abs(nrm - 1.0) < 1e-8:
+                out["evolve_L30_mbl_t1"]["failed_checks"] = ["evolve did not preserve the norm: %r" % nrm]
+            del psi, res
+        else:
+            out["evolve_L30_mbl_t1"] = "skipped: budget"
         H.destroy_mat()
         del H
     else:
@@ -243,11 +268,18 @@ def secondary(wd, budget_s=15.0):
             finally:
                 config.eigs_real_arithmetic = None
             st = dict(eigsolve.last_stats)
-            assert st["max_rel_residual"] <= tol * 1.01, "residual %r above tol" % st["max_rel_residual"]
-            assert bool(st["real_arithmetic"]) == real
-            return {"wall_s": dt, "matvecs": st["matvecs"], "E0": float(ev[0]), "dim": sub.get_dimension(),
-                    "measured_rel_residual": st["max_rel_residual"], "tol": tol, "ms_per_step": dt / st["matvecs"] * 1e3,
-                    "arithmetic": "real (f64, 8 B per amplitude)" if real else "complex128 (16 B per amplitude)"}
+            r = {"wall_s": dt, "call": "warm (its workspace is smaller than the one already in place)",
+                 "matvecs": st["matvecs"], "E0": float(ev[0]), "dim": sub.get_dimension(),
+                 "measured_rel_residual": st["max_rel_residual"], "tol": tol, "ms_per_step": dt / st["matvecs"] * 1e3,
+                 "arithmetic": "real (f64, 8 B per amplitude)" if real else "complex128 (16 B per amplitude)"}
+            problems = []
+            if not st["max_rel_residual"] <= tol * 1.01:
+                problems.append("residual %r above tol" % st["max_rel_residual"])
+            if bool(st["real_arithmetic"]) != real:
+                problems.append("arithmetic is not the one asked for")
+            if problems:
+                r["failed_checks"] = problems
+            return r
         out["eigsolve_sc32_16"] = sc_solve(False)
         if left() > 2.0:
             out["eigsolve_sc32_16_real_arithmetic"] = sc_solve(True)      # what eigsolve takes on its own here
@@ -694,10 +726,18 @@ def main():
             mat = None
             del x, y
             torch.cuda.empty_cache()
-            out["secondary"] = secondary(wd)
+            # (a failure in the Krylov phases -- memory for the 64 GiB of work vectors, a failed check -- is recorded,
+            # it must not cost the headline that has already been measured)
+            try:
+                out["secondary"] = secondary(wd)
+            except Exception as e:       # noqa: BLE001
+                out["secondary"] = {"error": repr(e)}
         if n_gpus == 1 and not args.no_cpu_baseline:
             wd.phase("cpu baseline")
-            out["cpu_baseline"] = cpu_baseline()
+            try:
+                out["cpu_baseline"] = cpu_baseline()
+            except Exception as e:       # noqa: BLE001
+                out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out))
     if mat is not None:
         mat.destroy()

@@ -157,6 +157,7 @@ SIGNATURES = {
     "dnm_vec_basis_update": (C.c_int, [vp, C.c_int64, C.c_int, C.c_int, C.c_int64, f64p, vp]),
     "dnm_workspace_bytes": (C.c_int, [C.POINTER(C.c_size_t)]),
     "dnm_release_workspace": (C.c_int, []),
+    "dnm_workspace_reserve": (C.c_int, [C.c_size_t, C.c_void_p]),
     "dnm_expm_chebyshev": (C.c_int, [vp, vp, vp, C.c_int64, C.c_double, C.c_double, C.POINTER(Hooks),
                                      C.POINTER(SolverStats), vp]),
     "dnm_mat_mult_sub": (C.c_int, [vp, vp, vp, vp, C.c_double, vp]),

@@ -222,10 +222,13 @@ def eigsolve(H, getvecs=False, nev=1, which='lowest', target=None, tol=None, sub
     if er:
         want_real = er[:1] == '1'
     if want_real is None:
-        want_real = mat.n_local >= (1 << 23)
-    if want_real:                   # (several ranks: SpinConserve in the internal layout only)
+        # (the smallest block decides: blocks of the partitioned SpinConserve layout differ by up to 10 %, and ranks
+        # on either side of the threshold would build handles whose exchanges do not match -- ADVICE r4)
+        want_real = _min_over_ranks(mat.n_local) >= (1 << 23)
+    if want_real:                   # (Full / Parity on 2^p ranks; SpinConserve in the internal layout on any count)
         pm = H.get_real_packed_mat(subspace)
-        if pm is not None:
+        # every rank or none: a rank whose build was refused keeps its peers on complex128 as well
+        if _min_over_ranks(0 if pm is None else 1) == 1:
             mat = pm
     packed = mat is not cmat
     keep = []

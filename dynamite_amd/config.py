@@ -45,10 +45,11 @@ class _Config:
         lay = knob('DNM_SC_LAYOUT', '14,10')
         self.sc_layout = None if lay in ('0', '') else tuple(int(v) for v in lay.split(','))
         self.sc_layout_min_dim = 1 << 22
-        # eigsolve of a real-symmetric operator (every matrix element real in the product basis) on Full / Parity
-        # subspaces, one rank: real arithmetic on vectors stored two amplitudes to a complex128 element
-        # (DNM_MAT_REAL_PACKED, half the bytes per multiply and per Krylov vector; eigenvectors are handed back as
-        # complex states).  None: from 2^23 amplitudes on; True / False: always / never.
+        # eigsolve of a real-symmetric operator (every matrix element real in the product basis): real arithmetic on
+        # vectors stored two amplitudes to a complex128 element (Full / Parity, on a power-of-two number of ranks) or one
+        # double per position of the internal layout (SpinConserve, any rank count) -- DNM_MAT_REAL_PACKED, half the
+        # bytes per multiply and per Krylov vector; eigenvectors are handed back as complex states.
+        # None: from 2^23 amplitudes per rank on (the smallest rank decides); True / False: always / never.
         self.eigs_real_arithmetic = None
 
     # -- L / subspace / shell: same validation as the reference --------------

@@ -561,6 +561,15 @@ int dnm_workspace_bytes(size_t *bytes) {
   return 0;
 }
 
+int dnm_workspace_reserve(size_t bytes, void *stream) {
+  if (g_basis.bytes >= bytes) return 0;
+  void *p = nullptr;
+  DNM_TRY(basis_workspace(bytes, &p));
+  DNM_HIP(hipMemsetAsync(p, 0, bytes, (hipStream_t)stream));
+  DNM_HIP(hipStreamSynchronize((hipStream_t)stream));
+  return 0;
+}
+
 int dnm_release_workspace(void) {
   g_basis.release();
   rdm_release_scratch();

@@ -317,9 +317,10 @@ class Operator:
         self._mats[(hash(subspaces[0]), hash(subspaces[1]))] = mat
 
     def get_real_packed_mat(self, subspace):
-        """The operator in real arithmetic on ``subspace`` (Full or Parity, or SpinConserve in the internal layout;
-        one rank), or None when it has an imaginary matrix element in the product basis (or the subspace / size has no
-        such form): a second native handle built with ``DNM_MAT_REAL_PACKED`` that multiplies real vectors -- two
+        """The operator in real arithmetic on ``subspace`` -- Full or Parity on a power-of-two number of ranks (two
+        ranks: partner exchange; four and more: the transposed exchange with a swizzle of its own), or SpinConserve in
+        the internal layout on any rank count -- or None when it has an imaginary matrix element in the product basis
+        (or the subspace / size has no such form): a second native handle built with ``DNM_MAT_REAL_PACKED`` that multiplies real vectors -- two
         amplitudes to a complex128 element (Full / Parity) or one double per position of the layout (SpinConserve) --
         half the bytes per multiply and per Krylov vector.  Not in the reference (its PETSc build is complex
         throughout); used inside ``eigsolve`` only, which hands back complex states as the reference does."""

@@ -428,6 +428,10 @@ int dnm_expm_chebyshev(dnm_mat *A, const void *x, void *y, int64_t n_local, doub
 int dnm_release_workspace(void);
 /* bytes of Krylov basis currently cached (reusable by the next solve) */
 int dnm_workspace_bytes(size_t *bytes);
+/* Acquire (and touch: every page is written once) at least `bytes` of that workspace now, so that the next solve finds
+ * it in place -- what a caller that times solves does once, untimed (bench.py: a first solve at L=30 otherwise pays
+ * 1-2 s for 64 GiB of fresh device memory).  No-op when the cached workspace is already that large. */
+int dnm_workspace_reserve(size_t bytes, void *stream);
 
 enum { DNM_WHICH_LOWEST = 0, DNM_WHICH_HIGHEST = 1, DNM_WHICH_EXTERIOR = 2 };
 
