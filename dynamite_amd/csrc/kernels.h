@@ -3,6 +3,8 @@
 // given stream.
 #pragma once
 
+#include <vector>
+
 #include "plan.h"
 #include "subspace.h"
 
@@ -47,11 +49,17 @@ int launch_gather_matvec(const DevMsc &msc, const SubView &left, const SubView &
 // bond of two adjacent spins (3 << lo) whose sign masks all lie inside the bond,
 // so the matrix element takes one of two values: `up` when the down spin moves
 // from site lo to lo+1 (ket has bit lo set), `dn` for the opposite hop.
+// pair != 0: the same for any two spins lo < hi (`up`: the ket has bit lo set, the down spin moves to hi); dead != 0:
+// the mask flips an odd number of spins and never keeps a state in the subspace.
 struct ScMask {
   int32_t fast;
   int32_t lo;
   double up_re, up_im, dn_re, dn_im;
+  int32_t pair, hi, dead, pad;
 };
+// the table for an operator (host arrays as dnm_mat keeps them)
+std::vector<ScMask> sc_masks(const std::vector<int64_t> &masks, const std::vector<int64_t> &mask_offsets,
+                             const std::vector<int64_t> &signs, const std::vector<double> &rcoef);
 
 // SpinConserve(L,k) on both sides: columns by incremental colex rank (row + delta)
 // rows [row0, row0+M); xw holds columns [win_start, ...); y / diag are local.  colrange != null:

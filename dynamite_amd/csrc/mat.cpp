@@ -488,6 +488,40 @@ static size_t pass_dot_partials(const dnm_mat *, const PassOnDevice &p) {
 
 using namespace dnm;
 
+namespace dnm {
+std::vector<ScMask> sc_masks(const std::vector<int64_t> &masks, const std::vector<int64_t> &mask_offsets,
+                             const std::vector<int64_t> &signs, const std::vector<double> &rcoef) {
+  std::vector<ScMask> scm(masks.size());
+  for (size_t mi = 0; mi < masks.size(); ++mi) {
+    ScMask &e = scm[mi];
+    memset(&e, 0, sizeof(e));
+    const uint64_t mask = (uint64_t)masks[mi];
+    e.dead = __builtin_popcountll(mask) & 1;
+    if (__builtin_popcountll(mask) != 2) continue;
+    const int lo = __builtin_ctzll(mask), hi = 63 - __builtin_clzll(mask);
+    bool local = true;
+    for (int64_t t = mask_offsets[mi]; t < mask_offsets[mi + 1]; ++t)
+      if ((uint64_t)signs[t] & ~mask) local = false;
+    if (!local) continue;
+    e.pair = 1;
+    e.fast = hi == lo + 1;
+    e.lo = lo;
+    e.hi = hi;
+    for (int64_t t = mask_offsets[mi]; t < mask_offsets[mi + 1]; ++t) {
+      const uint64_t sg = (uint64_t)signs[t];
+      const double rc = rcoef[t];
+      const bool imag = parity64(mask & sg);
+      // column state (bra) carries the moved spin: bit hi for an up hop, bit lo for a down hop
+      const double up = ((sg >> hi) & 1) ? -rc : rc;
+      const double dn = ((sg >> lo) & 1) ? -rc : rc;
+      (imag ? e.up_im : e.up_re) += up;
+      (imag ? e.dn_im : e.dn_re) += dn;
+    }
+  }
+  return scm;
+}
+}  // namespace dnm
+
 extern "C" {
 
 const char *dnm_last_error(void) { return g_err.c_str(); }
@@ -806,33 +840,7 @@ int dnm_mat_create(int64_t nmasks, const int64_t *masks, const int64_t *mask_off
                A->left.host.L == A->right.host.L;
 
   std::vector<ScMask> scm;
-  if (lt == DNM_SPIN_CONSERVE && rt == DNM_SPIN_CONSERVE) {
-    scm.resize((size_t)nmasks);
-    for (int64_t mi = 0; mi < nmasks; ++mi) {
-      ScMask &e = scm[mi];
-      memset(&e, 0, sizeof(e));
-      const uint64_t mask = (uint64_t)A->masks[mi];
-      if (__builtin_popcountll(mask) != 2) continue;
-      const int lo = __builtin_ctzll(mask);
-      if (mask != (3ull << lo)) continue;
-      bool local = true;
-      for (int64_t t = A->mask_offsets[mi]; t < A->mask_offsets[mi + 1]; ++t)
-        if ((uint64_t)A->signs[t] & ~mask) local = false;
-      if (!local) continue;
-      e.fast = 1;
-      e.lo = lo;
-      for (int64_t t = A->mask_offsets[mi]; t < A->mask_offsets[mi + 1]; ++t) {
-        const uint64_t sg = (uint64_t)A->signs[t];
-        const double rc = A->real_coeffs[t];
-        const bool imag = parity64(mask & sg);
-        // column state (bra) carries the moved spin: bit lo+1 for an up hop, bit lo for a down hop
-        const double up = ((sg >> (lo + 1)) & 1) ? -rc : rc;
-        const double dn = ((sg >> lo) & 1) ? -rc : rc;
-        (imag ? e.up_im : e.up_re) += up;
-        (imag ? e.dn_im : e.dn_re) += dn;
-      }
-    }
-  }
+  if (lt == DNM_SPIN_CONSERVE && rt == DNM_SPIN_CONSERVE) scm = sc_masks(A->masks, A->mask_offsets, A->signs, A->real_coeffs);
   // tables for the generic kernels (always: norm and diagonal use them)
   if (!A->host_only) {
   DNM_TRY(A->d_masks.upload(A->masks.data(), A->masks.size() * 8));
@@ -885,7 +893,7 @@ int dnm_mat_create(int64_t nmasks, const int64_t *masks, const int64_t *mask_off
       // Partitions: every position the C ABI speaks of for such a handle -- ownership, column windows, chunk maps,
       // window starts -- counts complex128 ELEMENTS (pairs of entries; blocks of equal top bits start at multiples of 8
       // entries), so the caller's exchange code is the one it runs for complex vectors, on half the bytes
-      DNM_CHECK(A->sc3->tiled && A->sc3->sym && A->sc3->diag_mode != 1,
+      DNM_CHECK(A->sc3->tiled && !A->sc3->graph && A->sc3->sym && A->sc3->diag_mode != 1,
                 "operator has an imaginary matrix element or is not a chain: no real-packed form in this layout");
       A->real_packed = true;
       A->m_local = A->n_local = il / 2;
@@ -1401,7 +1409,7 @@ int dnm_mat_mult_window_rows(dnm_mat *A, const void *x_window, int64_t win_start
 
 int dnm_mat_window_split(const dnm_mat *A, int *supported) {
   DNM_CHECK(A && supported, "null argument");
-  *supported = (A->use_sc3 && A->sc3->tiled && A->nranks > 1) ? 1 : 0;
+  *supported = (A->use_sc3 && A->sc3->tiled && !A->sc3->graph && A->nranks > 1) ? 1 : 0;    // (a bond graph's lo pass reads other blocks)
   return 0;
 }
 
@@ -1482,7 +1490,14 @@ int dnm_mat_plan_describe(const dnm_mat *A, char *buf, size_t buflen) {
   else if (A->use_sc3) {
     const Sc3Tab &T = A->sc3->ly->host;
     char tmp[512];
-    if (A->sc3->tiled)
+    if (A->sc3->tiled && A->sc3->graph)
+      snprintf(tmp, sizeof tmp, "SpinConserve two-pass kernels on a bond graph, internal layout [T %d | W %d | Lo %d]: "
+               "window pass (%zu workgroups, %d hops in LDS, %d gathered) then lo pass (%zu workgroups, %d hops in LDS, "
+               "%d gathered), diagonal %s, coefficients %s\n", T.t, T.w, T.a, A->sc3->permB.size(), A->sc3->op.nldsB,
+               A->sc3->op.ngatB, A->sc3->permA.size() / 8, A->sc3->op.nldsA, A->sc3->op.ngatA,
+               A->sc3->diag_mode == 2 ? "on the fly" : (A->sc3->diag_mode == 1 ? "cached" : "none"),
+               A->sc3->sym ? "real symmetric" : "complex");
+    else if (A->sc3->tiled)
       snprintf(tmp, sizeof tmp, "SpinConserve two-pass kernels, internal layout [T %d | W %d | Lo %d]: window pass (%zu "
                "workgroups, %d bonds in LDS, %d gathered) then lo pass (%zu workgroups, %d bonds in LDS, %d gathered), "
                "diagonal %s, coefficients %s\n", T.t, T.w, T.a, A->sc3->permB.size(), T.w - 1,

@@ -53,6 +53,10 @@ struct Sc3Tab {
   // (inside W) couples pattern wr to, or nw[cw] -- the zero row behind the tile -- when the two spins are equal.
   const uint64_t *w_nb;
   const int32_t *cbin;             // [17 * 17] C(n, j)
+  // lo_rank in two halves (operators on any bond graph, sc3g_kernels.hip: 2.3 KB that a workgroup keeps in LDS where
+  // lo_rank itself is 32 KB): with h = a / 2, lo = p & (2^h - 1), hi = p >> h:
+  //   lo_rank[p] = lo_rlo[lo] + lo_rhi[hi * (h + 1) + popcount(lo)]
+  const uint16_t *lo_rlo, *lo_rhi;
   const int64_t *nck;              // [(k+1) * (L+1)] C(LL, kk) at kk * (L+1) + LL: the reference's unranking table
 };
 
@@ -86,6 +90,8 @@ struct Sc3Layout {
   std::vector<uint32_t> rows;      // every row (T << w | W) of the layout, in reference order
   std::vector<uint64_t> w_nb;
   void *d_w_nb = nullptr;
+  std::vector<uint16_t> lo_rlo, lo_rhi;
+  void *d_lo_rlo = nullptr, *d_lo_rhi = nullptr;
   void *d_ibase = nullptr, *d_nbase = nullptr, *d_icoff = nullptr, *d_ncoff = nullptr, *d_lo_pat = nullptr,
        *d_w_pat = nullptr, *d_lo_rank = nullptr, *d_w_rank = nullptr, *d_cbin = nullptr, *d_rows = nullptr, *d_nck = nullptr;
   Sc3Layout() = default;
@@ -122,6 +128,18 @@ int sc3_random_real(const Sc3Layout &Ly, double *x, uint64_t seed, hipStream_t s
 int sc3_unpack_real(const Sc3Layout &Ly, void *dst, const double *src, hipStream_t st, uint32_t T0 = 0, uint32_t T1 = 0xffffffffu);
 
 // ---- the operator in this layout ---------------------------------------------------------------------------------
+// One off-diagonal term of a pair-hop operator on any bond graph (sc3g_kernels.hip), in the layout's bit labelling: the
+// XOR mask split by field and the two matrix elements.  The term acts on a ket iff popcount(ket & mask) == half (the
+// result keeps k ones); `up` applies when the direction bit -- the lower spin of the pair -- is set in the ket (the
+// down spin moves up), `dn` otherwise: ScMask's convention with (lo, lo + 1) replaced by any pair.
+struct Sc3Hop {
+  uint32_t mT, mW, mLo;
+  int32_t half;
+  int32_t dfield, dbit;            // field of the direction bit (0 Lo, 1 W, 2 T; 3: `up` always) and its place inside it
+  int32_t pad0, pad1;
+  double up_re, up_im, dn_re, dn_im;
+};
+
 // Per-operator device data of the tiled passes.  A chain bond b couples spins b, b+1 with the two matrix elements of
 // ScMask (kernels.h): `up` when the ket has bit b set and bit b+1 clear, `dn` for the opposite hop.
 struct Sc3Op {
@@ -135,6 +153,13 @@ struct Sc3Op {
   const int32_t *dt_group = nullptr;
   int32_t ndt = 0, ngroups = 0;
   uint32_t glo[4] = {0, 0, 0, 0};
+  // operators on any bond graph: the off-diagonal terms by the pass and the way they are applied -- from the LDS tile
+  // (both spins inside Lo / inside W) or gathered (lo pass: one spin in Lo, the other in W or T; window pass: none in Lo)
+  const Sc3Hop *ldsA = nullptr, *gatA = nullptr, *ldsB = nullptr, *gatB = nullptr;
+  int32_t nldsA = 0, ngatA = 0, nldsB = 0, ngatB = 0;
+  // window pass, its LDS hops: wnb[(w_off[cw] + wr) * nldsB + h] = rank of the row hop h couples row wr of class cw to,
+  // nw[cw] (the zero row behind the tile) where it does not act
+  const uint8_t *wnb = nullptr;
 };
 // Per-call data: partition offsets (x holds the internal positions [win_start, ...), y / diag / z are this rank's
 // vectors starting at internal position row0), start vectors and fused sums as in launch_sc_block
@@ -160,14 +185,17 @@ struct Sc3Mat {
   std::vector<uint32_t> rowsel;    // its rows (T << w | W), for the row kernel
   void *d_rowsel = nullptr;
   std::vector<char> needT;         // T blocks its rows read (own blocks included)
-  bool tiled = false;              // two tiled passes (every off-diagonal mask is a chain bond); else the row kernel
+  bool tiled = false;              // two tiled passes (every off-diagonal mask is a pair hop); else the row kernel
+  bool graph = false;              // ... of sc3g_kernels.hip (any bond graph); false: the chain kernels
   bool sym = false;                // every bond real and direction-independent
   bool real = false;               // real vectors (DNM_MAT_REAL_PACKED): sc3_lo_pass_r, window pass on the halved tables
   int diag_mode = 0;               // 0: no diagonal terms; 2: on the fly; 1: needs the cached diagonal
   Sc3Op op{};
   std::vector<uint32_t> permA, permB;
   void *d_permA = nullptr, *d_permB = nullptr, *d_bond = nullptr, *d_dlo = nullptr, *d_dt_sign = nullptr,
-       *d_dt_coef = nullptr, *d_dt_group = nullptr;
+       *d_dt_coef = nullptr, *d_dt_group = nullptr, *d_hops = nullptr, *d_wnb = nullptr;
+  std::vector<Sc3Hop> hops;        // ldsA, gatA, ldsB, gatB back to back
+  std::vector<uint8_t> wnb;
   Sc3Mat() = default;
   Sc3Mat(const Sc3Mat &) = delete;
   Sc3Mat &operator=(const Sc3Mat &) = delete;
@@ -180,6 +208,10 @@ struct Sc3Mat {
   void chunks(int shift, int64_t first_chunk, int64_t nchunks, uint8_t *map) const;
 };
 bool sc3_instance(int a, int w);           // kernel instances exist for this field split
+// the two passes for operators on any bond graph (sc3g_kernels.hip); same contract as launch_sc3's tiled branch
+constexpr int SC3G_MAX_GATHER = 64, SC3G_MAX_WLDS = 40;
+int launch_sc3g(const Sc3Mat &M, const Sc3Call &call, const double *cached_diag, const void *xw, void *y, hipStream_t st,
+                int phase);
 size_t sc3_dot_partials(const Sc3Mat &M);
 // y = A x (- zscale zinit + z2 zinit2), fused sums if asked for; cached_diag: internal order or null.
 // phase 0: everything; tiled operators also split: phase 1 = the part whose columns a rank owns itself (the lo pass:

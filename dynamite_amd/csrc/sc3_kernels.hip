@@ -12,97 +12,11 @@
 #include "dnm_common.h"
 #include "kernels.h"
 #include "philox.h"
+#include "sc3_dev.h"
 
 namespace dnm {
 
-typedef double2 c128;
-typedef double d2v __attribute__((ext_vector_type(2)));
-
 namespace {
-
-__device__ __forceinline__ int64_t rl_i64(int64_t v, int l) {
-  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(v & 0xffffffff), l);
-  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(v >> 32), l);
-  return (int64_t)(((uint64_t)hi << 32) | lo);
-}
-__device__ __forceinline__ double rl_f64(double v, int l) { return __longlong_as_double(rl_i64(__double_as_longlong(v), l)); }
-__device__ __forceinline__ int rl_i32(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
-__device__ __forceinline__ void store_nt(c128 *p, double re, double im) {
-  d2v v = {re, im};
-  __builtin_nontemporal_store(v, reinterpret_cast<d2v *>(p));
-}
-__device__ __forceinline__ c128 load_nt(const c128 *p) {
-  d2v v = __builtin_nontemporal_load(reinterpret_cast<const d2v *>(p));
-  return make_double2(v.x, v.y);
-}
-__device__ __forceinline__ double wave_sum(double v) {
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
-}
-__device__ __forceinline__ double flip(double c, uint32_t parity_bit) {
-  int hi = __double2hiint(c) ^ (int)(parity_bit << 31);
-  return __hiloint2double(hi, __double2loint(c));
-}
-
-// wave priority by phase (round 4, as in tile_pass_kernel): raised while a workgroup is in a memory phase, lowered for
-// its LDS bond loops, so that of the two workgroups of a CU the one asking for memory wins the issue slots
-// (SpinConserve(32,16): window pass 5.38 -> 5.25 ms, lo pass level; a rank of config 5 25.7 -> 24.8 ms;
-// profiles/r04_sc3_spans.txt; -DDNM_SC3_PRIO=0 builds without)
-// the layout's and the operator's tables are read-only: through the constant address space their wave-uniform reads
-// stay scalar loads whatever else the kernel contains (see CQuad in matvec_kernels.hip)
-#define SC3_CP(T, p) ((const __attribute__((address_space(4))) T *)(p))
-#ifndef DNM_SC3_PRIO
-#define DNM_SC3_PRIO 1
-#endif
-#if DNM_SC3_PRIO == 1
-#define SC3_PRIO_MEM() asm volatile("s_setprio 3")
-#define SC3_PRIO_LDS() asm volatile("s_setprio 0")
-#else
-#define SC3_PRIO_MEM()
-#define SC3_PRIO_LDS()
-#endif
-
-constexpr int ilog2c(int v) { return v <= 1 ? 0 : 1 + ilog2c(v >> 1); }
-constexpr uint32_t SC3_NOROW = 1u << 29;       // lo pass: a sub-group slot without a row
-
-constexpr int cbinom(int n, int k) {
-  long long r = 1;
-  for (int i = 1; i <= k; ++i) r = r * (n - k + i) / i;
-  return (int)r;
-}
-
-// row (T, W) of a workgroup: everything the kernels derive from the perm entry
-struct RowId {
-  uint32_t T, W;
-  int cw, kr, kl, nrows, pitch;
-  int64_t tb, base;        // internal offset of the T block / of the row
-};
-__device__ __forceinline__ RowId decode_row(uint32_t e, const Sc3Tab &S) {
-  RowId r;
-  r.T = e >> S.w;
-  r.W = e & ((1u << S.w) - 1u);
-  r.cw = __popc(r.W);
-  r.kr = S.k - __popc(r.T);
-  r.kl = r.kr - r.cw;
-  r.nrows = S.nl[r.kl];
-  r.pitch = S.pitch[r.kl];
-  r.tb = SC3_CP(int64_t, S.ibase)[r.T];
-  r.base = r.tb + SC3_CP(int64_t, S.icoff)[r.kr * (S.w + 1) + r.cw] + (int64_t)SC3_CP(uint16_t, S.w_rank)[r.W] * r.pitch;
-  return r;
-}
-
-// entries of the lo pass's LDS tile: what the workgroup's threads hold (RPT entries each), at least the longest row
-constexpr int sc3_lo_cap(int a, int nt) { return ((cbinom(a, a / 2) + nt - 1) / nt) * nt; }
-
-// waves per SIMD a tiled pass can have: what its LDS tile lets be resident (two workgroups per CU for the 64 KB
-// tiles), at most 8 -- the register budget follows from it (128 registers at 512 threads, 64 at 1024)
-constexpr int sc3_win_waves(int nt, int tile_kb) {
-  int wgs = 160 / (tile_kb > 0 ? tile_kb : 1);
-  if (wgs > 2048 / nt) wgs = 2048 / nt;
-  if (wgs < 1) wgs = 1;
-  const int w = wgs * nt / 256;
-  return w > 8 ? 8 : (w < 1 ? 1 : w);
-}
 
 // ---------------------------------------------------------------------------------------------------------
 // lo pass (the second, accumulating pass): y += (bonds inside Lo, the Lo/W boundary, whatever else bondsA names
@@ -410,18 +324,6 @@ sc3_lo_pass(const Sc3Tab S, const Sc3Op O, const uint32_t *__restrict__ perm, co
 // doubles, so the bonds inside Lo (partner r +- d, d of either parity) read 8 bytes.  Real operators have equal `up`
 // and `dn` elements (Hermitian and real), so there is only the SYM form.  Everything per row -- sub-groups, the bond
 // table in the lanes, the on-the-fly diagonal -- is as in sc3_lo_pass.
-// shape of the real lo pass: NTR threads with PPT pairs each (DNM_SC3R_SHAPE 0: as many threads as the complex pass and
-// twice its entries per thread -- 1024 x 8 entries, a 64 KB tile, two workgroups per CU; 1: half the threads, 512 x 8, a
-// 32 KB tile, four workgroups per CU; 2: 1024 x 4, 32 KB, two per CU)
-#ifndef DNM_SC3R_SHAPE
-#define DNM_SC3R_SHAPE 0
-#endif
-constexpr int sc3r_threads(int nt) { return (DNM_SC3R_SHAPE == 1 && nt >= 512) ? nt / 2 : nt; }
-constexpr int sc3r_pairs(int a, int nt) {
-  return (DNM_SC3R_SHAPE == 2 && nt >= 512) ? (cbinom(a, a / 2) / 2 + nt - 1) / nt : (cbinom(a, a / 2) + nt - 1) / nt;
-}
-constexpr int sc3_lo_cap_r(int a, int nt) { return 2 * sc3r_pairs(a, nt) * sc3r_threads(nt); }
-
 template <int A, int NT, int PPT, int DIAGM, bool ACC>
 __global__ void __launch_bounds__(NT, sc3_win_waves(NT, (NT * 2 * PPT * 8 + 1023) / 1024 + 1))
 sc3_lo_pass_r(const Sc3Tab S, const Sc3Op O, const uint32_t *__restrict__ perm, const Sc3Call C,
@@ -1035,7 +937,7 @@ bool sc3_valid(int L, int k, int a, int w) {
 }
 
 Sc3Layout::~Sc3Layout() {
-  for (void *p : {d_ibase, d_nbase, d_icoff, d_ncoff, d_lo_pat, d_w_pat, d_lo_rank, d_w_rank, d_cbin, d_rows, d_nck, d_w_nb, d_ibase_h, d_icoff_h})
+  for (void *p : {d_ibase, d_nbase, d_icoff, d_ncoff, d_lo_pat, d_w_pat, d_lo_rank, d_w_rank, d_cbin, d_rows, d_nck, d_w_nb, d_ibase_h, d_icoff_h, d_lo_rlo, d_lo_rhi})
     if (p) (void)hipFree(p);
 }
 
@@ -1097,6 +999,30 @@ int Sc3Layout::init(int L, int k, int a, int w, bool want_device) {
         w_nb[(size_t)2 * (S.w_off[j] + r) + (size_t)(b / 8)] |= f << (8 * (b % 8));
       }
     }
+  // lo_rank in two halves (Sc3Tab::lo_rlo / lo_rhi): colex rank = sum over the ones, m-th one at position q: C(q, m)
+  {
+    const int h = a / 2, hb = a - h;
+    lo_rlo.assign((size_t)1 << h, 0);
+    lo_rhi.assign(((size_t)1 << hb) * (h + 1), 0);
+    for (uint32_t v = 0; v < (1u << h); ++v) {
+      int64_t r = 0;
+      int m = 0;
+      for (int q = 0; q < h; ++q) if ((v >> q) & 1u) r += hbinom(q, ++m);
+      lo_rlo[v] = (uint16_t)r;
+    }
+    for (uint32_t v = 0; v < (1u << hb); ++v)
+      for (int cl = 0; cl <= h; ++cl) {
+        int64_t r = 0;
+        int m = cl;
+        for (int q = 0; q < hb; ++q) if ((v >> q) & 1u) r += hbinom(h + q, ++m);
+        lo_rhi[(size_t)v * (h + 1) + cl] = (uint16_t)r;
+      }
+    for (uint32_t v = 0; v < (1u << a); ++v) {
+      const uint32_t lo = v & ((1u << h) - 1u);
+      DNM_CHECK(lo_rank[v] == lo_rlo[lo] + lo_rhi[(size_t)(v >> h) * (h + 1) + __builtin_popcount(lo)],
+                "internal: split rank table of pattern %u", v);
+    }
+  }
   icoff.assign((size_t)(a + w + 1) * (w + 1), 0);
   ncoff.assign((size_t)(a + w + 1) << w, 0);
   std::vector<int64_t> isize(a + w + 1, 0);
@@ -1139,6 +1065,8 @@ int Sc3Layout::init(int L, int k, int a, int w, bool want_device) {
   S.cbin = cbin.data();
   S.nck = nck.data();
   S.w_nb = w_nb.data();
+  S.lo_rlo = lo_rlo.data();
+  S.lo_rhi = lo_rhi.data();
   dev = S;
   // halved positions (real vectors read as pairs of entries): everything is a multiple of 8 entries
   ibase_h.assign(ibase.size(), -1);
@@ -1158,6 +1086,8 @@ int Sc3Layout::init(int L, int k, int a, int w, bool want_device) {
     DNM_TRY(up(nck, &d_nck));
     DNM_TRY(up(w_nb, &d_w_nb));
     dev.w_nb = (const uint64_t *)d_w_nb;
+    DNM_TRY(up(lo_rlo, &d_lo_rlo)); DNM_TRY(up(lo_rhi, &d_lo_rhi));
+    dev.lo_rlo = (const uint16_t *)d_lo_rlo; dev.lo_rhi = (const uint16_t *)d_lo_rhi;
     dev.ibase = (const int64_t *)d_ibase; dev.nbase = (const int64_t *)d_nbase;
     dev.icoff = (const int64_t *)d_icoff; dev.ncoff = (const int64_t *)d_ncoff;
     dev.lo_pat = (const uint16_t *)d_lo_pat; dev.w_pat = (const uint16_t *)d_w_pat;
@@ -1335,7 +1265,7 @@ static std::vector<uint32_t> pack_lo_rows(const std::vector<uint32_t> &order, co
 bool sc3_instance(int a, int w) { return (a == 14 && w == 10) || (a == 6 && w == 4); }
 
 Sc3Mat::~Sc3Mat() {
-  for (void *p : {d_permA, d_permB, d_bond, d_dlo, d_dt_sign, d_dt_coef, d_dt_group, d_rowsel})
+  for (void *p : {d_permA, d_permB, d_bond, d_dlo, d_dt_sign, d_dt_coef, d_dt_group, d_rowsel, d_hops, d_wnb})
     if (p) (void)hipFree(p);
 }
 
@@ -1422,27 +1352,83 @@ int Sc3Mat::init(const Sc3Layout *layout, const std::vector<int64_t> &masks, con
       needT[U] = 1;
     }
   }
-  // two tiled passes need every off-diagonal mask to be a chain bond with local signs (ScMask::fast)
-  tiled = sc3_instance(a, w);
-  for (int64_t m = 0; m < nmasks; ++m)
-    if (masks[m] != 0 && !scm[m].fast) tiled = false;
+  // Two tiled passes need every off-diagonal mask to be a pair hop with signs inside the pair (ScMask::pair); masks
+  // that never keep a state in the subspace (an odd number of flips: the fields of the harness's long-range model)
+  // are skipped.  Chains of adjacent spins take the kernels of this file, any other bond graph those of
+  // sc3g_kernels.hip (DNM_SC3_GRAPH=1: chains as well, for A/B runs).
+  bool chain = sc3_instance(a, w), pairs = sc3_instance(a, w);
+  for (int64_t m = 0; m < nmasks; ++m) {
+    if (masks[m] == 0 || scm[m].dead) continue;
+    if (!scm[m].fast) chain = false;
+    if (!scm[m].pair) pairs = false;
+  }
+  if (const char *e = knob("DNM_SC3_GRAPH")) if (e[0] == '1') chain = false;
+  tiled = chain || pairs;
+  graph = tiled && !chain;
   if (!tiled) return 0;
   std::vector<double> bond(4 * (size_t)std::max(1, L - 1), 0.0);
   op.present = 0;
   sym = true;
   for (int64_t m = 0; m < nmasks; ++m) {
-    if (masks[m] == 0) continue;
+    if (masks[m] == 0 || scm[m].dead) continue;
+    if (scm[m].up_im != 0.0 || scm[m].dn_im != 0.0 || scm[m].up_re != scm[m].dn_re) sym = false;
+    if (graph) continue;
     const int b = scm[m].lo;
     bond[4 * b] = scm[m].up_re; bond[4 * b + 1] = scm[m].up_im;
     bond[4 * b + 2] = scm[m].dn_re; bond[4 * b + 3] = scm[m].dn_im;
     op.present |= 1ull << b;
-    if (scm[m].up_im != 0.0 || scm[m].dn_im != 0.0 || scm[m].up_re != scm[m].dn_re) sym = false;
   }
   // which pass gathers which bond outside its LDS tile: the Lo/W boundary in the lo pass, the W/T boundary and the
   // bonds inside T in the window pass (measured, profiles/r03_exp3_sc3_v2.txt)
   op.bondsA = op.present & (1ull << (a - 1));
   op.bondsB = 0;
   for (int b = a + w - 1; b < L - 1; ++b) op.bondsB |= op.present & (1ull << b);
+  // any bond graph: the hops by pass and by the way they are applied
+  hops.clear();
+  wnb.clear();
+  size_t nh[4] = {0, 0, 0, 0};
+  if (graph) {
+    std::vector<Sc3Hop> part[4];       // lds A, gathered A, lds B, gathered B
+    auto field = [&](int b) { return b < a ? 0 : (b < a + w ? 1 : 2); };
+    auto fstart = [&](int f) { return f == 0 ? 0 : (f == 1 ? a : a + w); };
+    for (int64_t m = 0; m < nmasks; ++m) {
+      if (masks[m] == 0 || scm[m].dead) continue;
+      const uint64_t mk = (uint64_t)masks[m];
+      Sc3Hop h{};
+      h.mLo = (uint32_t)(mk & (((uint64_t)1 << a) - 1));
+      h.mW = (uint32_t)((mk >> a) & (((uint64_t)1 << w) - 1));
+      h.mT = (uint32_t)(mk >> (a + w));
+      h.half = __builtin_popcountll(mk) / 2;
+      const int fi = field(scm[m].lo), fj = field(scm[m].hi);
+      h.dfield = fi;
+      h.dbit = scm[m].lo - fstart(fi);
+      h.up_re = scm[m].up_re; h.up_im = scm[m].up_im; h.dn_re = scm[m].dn_re; h.dn_im = scm[m].dn_im;
+      part[fi == 0 ? (fj == 0 ? 0 : 1) : (fi == 1 && fj == 1 ? 2 : 3)].push_back(h);
+    }
+    if ((int)part[1].size() > SC3G_MAX_GATHER || (int)part[3].size() > SC3G_MAX_GATHER ||
+        (int)part[2].size() > SC3G_MAX_WLDS) {      // more hops than a pass has lanes / table columns for: the row kernel
+      tiled = graph = false;
+      return 0;
+    }
+    for (int q = 0; q < 4; ++q) {
+      nh[q] = part[q].size();
+      hops.insert(hops.end(), part[q].begin(), part[q].end());
+    }
+    if (hops.empty()) hops.push_back(Sc3Hop{});
+    // partner rows of the window pass's LDS hops
+    const size_t nb = nh[2];
+    wnb.assign(std::max<size_t>(1, ly->w_pat.size() * nb), 0);
+    for (int cw = 0; cw <= w; ++cw)
+      for (int wr = 0; wr < S.nw[cw]; ++wr) {
+        const uint32_t v = ly->w_pat[S.w_off[cw] + wr];
+        for (size_t q = 0; q < nb; ++q) {
+          const uint32_t mw = part[2][q].mW;
+          wnb[(size_t)(S.w_off[cw] + wr) * nb + q] =
+              (uint8_t)(__builtin_popcount(v & mw) == part[2][q].half ? ly->w_rank[v ^ mw] : S.nw[cw]);
+        }
+      }
+  }
+  op.nldsA = (int32_t)nh[0]; op.ngatA = (int32_t)nh[1]; op.nldsB = (int32_t)nh[2]; op.ngatB = (int32_t)nh[3];
   // diagonal on the fly: split the mask-0 terms by what their sign masks see
   diag_mode = 0;
   std::vector<double> dlo;
@@ -1522,6 +1508,12 @@ int Sc3Mat::init(const Sc3Layout *layout, const std::vector<int64_t> &masks, con
   if (want_device) {
     DNM_TRY(up(permA, &d_permA)); DNM_TRY(up(permB, &d_permB)); DNM_TRY(up(bond, &d_bond));
     op.bond = (const double *)d_bond;
+    if (graph) {
+      DNM_TRY(up(hops, &d_hops)); DNM_TRY(up(wnb, &d_wnb));
+      const Sc3Hop *hp = (const Sc3Hop *)d_hops;
+      op.ldsA = hp; op.gatA = hp + nh[0]; op.ldsB = hp + nh[0] + nh[1]; op.gatB = hp + nh[0] + nh[1] + nh[2];
+      op.wnb = (const uint8_t *)d_wnb;
+    }
     if (diag_mode == 2) {
       DNM_TRY(up(dlo, &d_dlo)); DNM_TRY(up(dt_sign, &d_dt_sign)); DNM_TRY(up(dt_coef, &d_dt_coef));
       DNM_TRY(up(dt_group, &d_dt_group));
@@ -1616,6 +1608,7 @@ int launch_sc3(const Sc3Mat &M, const DevMsc &msc, const Sc3Call &call, const do
   DNM_CHECK(phase == 0 || (M.tiled && !call.dot_out), "internal: only the tiled passes split into a local and a remote part");
   if (M.tiled) {
     if (call.dot_out) DNM_HIP(hipMemsetAsync(call.dot_out, 0, sc3_dot_partials(M) * 3 * sizeof(double), st));
+    if (M.graph) return launch_sc3g(M, call, cached_diag, xw, y, st, phase);
     if (M.ly->host.a == 14) {
       static const bool w1024 = [] { const char *e = knob("DNM_SC3_WIN_THREADS"); return e && atoi(e) == 1024; }();   // experiments
       if (w1024) return launch_two_pass<14, 10, 1024, 1024>(M, call, cached_diag, xw, y, st, phase);

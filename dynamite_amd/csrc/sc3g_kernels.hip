@@ -1,0 +1,568 @@
+// SpinConserve(L,k) x SpinConserve(L,k) multiply in the three-field internal layout (sc3.h) for operators whose
+// off-diagonal terms are pair hops on ANY bond graph (the kagome Heisenberg model of the reference's flagship example,
+// examples/scripts/kagome/run_kagome.py:20-77; long-range exchange; ladders ...): the two tiled passes of
+// sc3_kernels.hip with the chain's "bond b couples spins b, b + 1" replaced by a hop table (Sc3Hop).
+// Semantics: MatMult_CPU_General (src/dynamite/_backend/bpetsc_template_2.c:371-412) with the index maps of
+// bsubspace_impl.h:187-245.
+//
+// With state = [T | W | Lo] a hop between spins i < j is applied
+//   both in Lo      lo pass, from its LDS tile: the partner column is the rank of (pattern ^ mask), looked up in the two
+//                   halves of lo_rank that the workgroup keeps in LDS (Sc3Tab::lo_rlo / lo_rhi);
+//   both in W       window pass, from its LDS tile: the partner row comes from the operator's table (Sc3Op::wnb);
+//   i in Lo, j above   lo pass, gathered: ONE other row (T', W'), the column again by rank -- ascending with the
+//                   entry, so a wavefront's loads stay inside a few lines of that row;
+//   both above Lo   window pass, gathered: one other block / class at a uniform offset (both in T) or with the rows
+//                   remapped (i in W, j in T), the columns as they are.
+// Which ket a hop acts on is one popcount: popcount(ket & mask) == |mask| / 2 keeps the number of down spins.
+#include "sc3.h"
+
+#include <algorithm>
+#include <map>
+
+#include "dnm_common.h"
+#include "kernels.h"
+#include "sc3_dev.h"
+
+namespace dnm {
+
+namespace {
+
+// what a lane holds of the gathered hop it evaluated for its workgroup's row
+struct HopEval {
+  int act;
+  int64_t delta;
+  double c0, c1;
+  int need;
+  uint32_t xm;
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// lo pass: y (+)= (hops inside Lo, hops between Lo and the fields above, the diagonal) x.  Workgroup shape, sub-groups
+// of 2^m rows, diagonal modes, ACC and the fused sums exactly as sc3_lo_pass (sc3_kernels.hip).
+template <int A, int NT, int DIAGM, bool SYM, bool ACC>
+__global__ void __launch_bounds__(NT, sc3_win_waves(NT, (sc3_lo_cap(A, NT) * 16 + 1023) / 1024 + 4))
+sc3g_lo_pass(const Sc3Tab S, const Sc3Op O, const uint32_t *__restrict__ perm, const Sc3Call C,
+             const c128 *__restrict__ xw, c128 *__restrict__ y) {
+  constexpr int MAXROWS = cbinom(A, A / 2);
+  constexpr int RPT = (MAXROWS + NT - 1) / NT;
+  constexpr int H = A / 2, HB = A - H;
+  constexpr uint32_t HM = (1u << H) - 1u;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ uint16_t rka[1 << H];
+  __shared__ uint16_t rkb[(1 << HB) * (H + 1)];
+  __shared__ double red[3 * (NT / 64)];
+  __shared__ double dsh[5 * 8];
+  const uint32_t e0 = SC3_CP(uint32_t, perm)[8 * (size_t)blockIdx.x];
+  if (e0 == 0xffffffffu) return;
+  // the two halves of lo_rank: asked for first, in LDS before the first gathered hop needs them
+  uint16_t tka[((1 << H) + NT - 1) / NT], tkb[((1 << HB) * (H + 1) + NT - 1) / NT];
+#pragma unroll
+  for (int i = 0; i < ((1 << H) + NT - 1) / NT; ++i) {
+    const int tt = threadIdx.x + i * NT;
+    tka[i] = tt < (1 << H) ? S.lo_rlo[tt] : (uint16_t)0;
+  }
+#pragma unroll
+  for (int i = 0; i < ((1 << HB) * (H + 1) + NT - 1) / NT; ++i) {
+    const int tt = threadIdx.x + i * NT;
+    tkb[i] = tt < (1 << HB) * (H + 1) ? S.lo_rhi[tt] : (uint16_t)0;
+  }
+  const int lane = threadIdx.x & 63;
+  const int w = S.w;
+  const int logm = (int)(e0 >> 30);
+  const int NTS = NT >> logm;
+  const int sub = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) >> (ilog2c(NT) - 6 - logm);
+  const int tsub = (int)threadIdx.x & (NTS - 1);
+  const uint32_t e = SC3_CP(uint32_t, perm)[8 * (size_t)blockIdx.x + sub];
+  const bool has_row = !(e & SC3_NOROW);
+  c128 *xs = reinterpret_cast<c128 *>(smem) + (size_t)sub * ((NT * RPT) >> logm);
+  const RowId R = decode_row(has_row ? (e & (SC3_NOROW - 1u)) : (e0 & (SC3_NOROW - 1u)), S);
+  const uint32_t T = R.T, W = R.W;
+  const int kl = R.kl, nrows = has_row ? R.nrows : 0, p = has_row ? R.pitch : 0;
+  const int64_t base = R.base;
+  const c128 *__restrict__ x = xw - C.win_start;
+  const int64_t lbase = base - C.row0;
+
+  SC3_PRIO_MEM();
+  uint32_t lowb[RPT];
+  c128 xv[RPT];
+  const auto pat = SC3_CP(uint16_t, S.lo_pat) + S.lo_off[kl];
+#pragma unroll
+  for (int i = 0; i < RPT; ++i) {
+    const int r = tsub + i * NTS;
+    lowb[i] = 0;
+    xv[i] = make_double2(0.0, 0.0);
+    if (r < nrows) {
+      lowb[i] = pat[r];
+      xv[i] = x[base + r];
+    }
+  }
+  // gathered hops, one per lane: spin i in Lo, spin j in W or T.  The hop couples this row to ONE other row (T', W');
+  // it acts on the entries whose Lo bit has the value the row's bit j leaves open.
+  HopEval g{0, 0, 0.0, 0.0, 0, 0u};
+  if (lane < O.ngatA) {
+    const Sc3Hop h = O.gatA[lane];
+    const uint32_t T2 = T ^ h.mT, W2 = W ^ h.mW;
+    const int nd = h.half - __popc(T & h.mT) - __popc(W & h.mW);
+    const int nlo = __popc(h.mLo);
+    const int kr2 = S.k - __popc(T2), cw2 = __popc(W2), kl2 = kr2 - cw2;
+    if (nd >= 0 && nd <= nlo && kl2 >= 0 && kl2 <= A && cw2 <= w) {
+      const int64_t tb2 = S.ibase[T2];
+      if (tb2 >= 0) {
+        g.act = 1;
+        g.delta = tb2 + S.icoff[kr2 * (w + 1) + cw2] + (int64_t)S.w_rank[W2] * S.pitch[kl2] - base;
+        g.need = nd;
+        g.xm = h.mLo;
+        const bool up = h.dfield == 3 || nd == 1;       // the direction bit is the Lo spin of the pair
+        g.c0 = up ? h.up_re : h.dn_re;
+        g.c1 = up ? h.up_im : h.dn_im;
+      }
+    }
+  }
+  uint64_t hb = has_row ? __ballot(g.act) : 0ull;
+
+#pragma unroll
+  for (int i = 0; i < ((1 << H) + NT - 1) / NT; ++i) {
+    const int tt = threadIdx.x + i * NT;
+    if (tt < (1 << H)) rka[tt] = tka[i];
+  }
+#pragma unroll
+  for (int i = 0; i < ((1 << HB) * (H + 1) + NT - 1) / NT; ++i) {
+    const int tt = threadIdx.x + i * NT;
+    if (tt < (1 << HB) * (H + 1)) rkb[tt] = tkb[i];
+  }
+  // on-the-fly diagonal: per-row sums by the first wavefront of each sub-group (as sc3_lo_pass)
+  if (DIAGM == 2 && tsub < 64) {
+    const uint64_t hi = ((uint64_t)T << w) | W;
+    double v0 = 0.0, vm[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int t0 = 0; t0 < O.ndt; t0 += 64) {
+      const int t = t0 + lane;
+      if (t < O.ndt) {
+        const uint64_t sg = SC3_CP(uint64_t, O.dt_sign)[t];
+        const double c = flip(SC3_CP(double, O.dt_coef)[t], (uint32_t)__popcll(hi & sg & 0x1fffffffffffffffull) & 1u);
+        const int gq = (int)(sg >> 61);
+        if (gq == 0) v0 += c;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (gq == j + 1) vm[j] += c;
+      }
+    }
+    v0 = wave_sum(v0);
+    if (lane == 0) dsh[5 * sub] = v0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (j < O.ngroups) {
+        const double s = wave_sum(vm[j]);
+        if (lane == 0) dsh[5 * sub + j + 1] = s;
+      }
+  }
+  double accr[RPT], acci[RPT];
+#pragma unroll
+  for (int i = 0; i < RPT; ++i) {
+    const int r = tsub + i * NTS;
+    accr[i] = 0.0;
+    acci[i] = 0.0;
+    if (r < nrows) {
+      xs[r] = xv[i];
+      if (DIAGM == 1) {
+        const double dg = __builtin_nontemporal_load(O.diag + lbase + r);
+        accr[i] = dg * xv[i].x;
+        acci[i] = dg * xv[i].y;
+      }
+    }
+  }
+  __syncthreads();                 // the rank tables (and the tile) are in LDS; loads in flight are not waited for
+  while (hb) {
+    const int m = __ffsll((long long)hb) - 1;
+    hb &= hb - 1;
+    const c128 *__restrict__ pp = x + (base + rl_i64(g.delta, m));
+    const double cr = rl_f64(g.c0, m), ci = rl_f64(g.c1, m);
+    const int nd = rl_i32(g.need, m);
+    const uint32_t xm = (uint32_t)rl_i32((int)g.xm, m);
+    c128 v[RPT];
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+      const int r = tsub + i * NTS;
+      v[i] = make_double2(0.0, 0.0);
+      if (r < nrows && __popc(lowb[i] & xm) == nd) {
+        const uint32_t p2 = lowb[i] ^ xm;
+        const int col = (int)rka[p2 & HM] + (int)rkb[(p2 >> H) * (H + 1) + __popc(p2 & HM)];
+        v[i] = pp[col];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+      accr[i] = fma(cr, v[i].x, accr[i]);
+      acci[i] = fma(cr, v[i].y, acci[i]);
+      if (!SYM) {
+        accr[i] = fma(-ci, v[i].y, accr[i]);
+        acci[i] = fma(ci, v[i].x, acci[i]);
+      }
+    }
+  }
+  c128 yv[RPT];
+  if (ACC) {
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+      const int r = tsub + i * NTS;
+      yv[i] = make_double2(0.0, 0.0);
+      if (r < nrows) yv[i] = load_nt(y + lbase + r);
+    }
+  }
+  double dlv[RPT];
+  if (DIAGM == 2) {
+    const auto dl = SC3_CP(double, O.dlo) + S.lo_off[kl];
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+      const int r = tsub + i * NTS;
+      dlv[i] = r < nrows ? dl[r] : 0.0;
+    }
+  }
+  SC3_PRIO_LDS();
+  if (DIAGM == 2) {
+    const double dg0 = dsh[5 * sub];
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+      const int r = tsub + i * NTS;
+      if (r < nrows) {
+        double dg = dlv[i] + dg0;
+        for (int j = 0; j < O.ngroups; ++j) dg += flip(dsh[5 * sub + j + 1], (uint32_t)__popc(lowb[i] & O.glo[j]) & 1u);
+        const c128 xo = xs[r];
+        accr[i] = fma(dg, xo.x, accr[i]);
+        acci[i] = fma(dg, xo.y, acci[i]);
+      }
+    }
+  }
+  // hops inside Lo: the partner column is the rank of the flipped pattern
+  for (int hq = 0; hq < O.nldsA; ++hq) {
+    const auto hp = SC3_CP(Sc3Hop, O.ldsA) + hq;
+    const uint32_t m = hp->mLo;
+    const int half = hp->half, dbit = hp->dbit;
+    const double ure = hp->up_re, uim = hp->up_im, dre = hp->dn_re, dim_ = hp->dn_im;
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+      const int r = tsub + i * NTS;
+      if (r < nrows && __popc(lowb[i] & m) == half) {
+        const uint32_t p2 = lowb[i] ^ m;
+        const int col = (int)rka[p2 & HM] + (int)rkb[(p2 >> H) * (H + 1) + __popc(p2 & HM)];
+        const c128 xp = xs[col];
+        if (SYM) {
+          accr[i] = fma(ure, xp.x, accr[i]);
+          acci[i] = fma(ure, xp.y, acci[i]);
+        } else {
+          const bool up = (lowb[i] >> dbit) & 1u;
+          const double cre = up ? ure : dre, cim = up ? uim : dim_;
+          accr[i] = fma(cre, xp.x, accr[i]);
+          acci[i] = fma(cre, xp.y, acci[i]);
+          accr[i] = fma(-cim, xp.y, accr[i]);
+          acci[i] = fma(cim, xp.x, acci[i]);
+        }
+      }
+    }
+  }
+  double dr = 0.0, di = 0.0, dn = 0.0;
+  SC3_PRIO_MEM();
+#pragma unroll
+  for (int i = 0; i < RPT; ++i) {
+    const int r = tsub + i * NTS;
+    if (r < p) {                                  // the padding of a row is written too (zeros)
+      double ar = accr[i], ai = acci[i];
+      if (r < nrows) {
+        if (ACC) {
+          ar += yv[i].x;
+          ai += yv[i].y;
+        } else if (C.zinit) {
+          const c128 zv = C.zinit[lbase + r];
+          ar = fma(-C.zscale, zv.x, ar);
+          ai = fma(-C.zscale, zv.y, ai);
+          if (C.zinit2) {
+            const c128 z2 = C.zinit2[lbase + r];
+            ar = fma(C.z2re, z2.x, ar);
+            ar = fma(-C.z2im, z2.y, ar);
+            ai = fma(C.z2re, z2.y, ai);
+            ai = fma(C.z2im, z2.x, ai);
+          }
+        }
+        if (ACC && C.dot_out) {
+          const c128 xo = xs[r];
+          dr = fma(xo.x, ar, dr);
+          dr = fma(xo.y, ai, dr);
+          di = fma(xo.x, ai, di);
+          di = fma(-xo.y, ar, di);
+          dn = fma(ar, ar, dn);
+          dn = fma(ai, ai, dn);
+        }
+      }
+      store_nt(y + lbase + r, ar, ai);
+    }
+  }
+  if (ACC && C.dot_out) {
+    dr = wave_sum(dr); di = wave_sum(di); dn = wave_sum(dn);
+    if (lane == 0) {
+      red[3 * (threadIdx.x >> 6)] = dr;
+      red[3 * (threadIdx.x >> 6) + 1] = di;
+      red[3 * (threadIdx.x >> 6) + 2] = dn;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double sr = 0.0, si = 0.0, sn = 0.0;
+      for (int wv = 0; wv < NT / 64; ++wv) { sr += red[3 * wv]; si += red[3 * wv + 1]; sn += red[3 * wv + 2]; }
+      C.dot_out[3 * (size_t)blockIdx.x] = sr;
+      C.dot_out[3 * (size_t)blockIdx.x + 1] = si;
+      C.dot_out[3 * (size_t)blockIdx.x + 2] = sn;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// window pass: y (+)= (hops inside W from the LDS tile, hops between W and T and inside T gathered) x.  Workgroup =
+// (T, cw, run of R = 16 << s columns), the tile all window patterns of the class x R columns, as sc3_win_pass.
+template <int WB, int NT, bool SYM, bool ACC>
+__global__ void __launch_bounds__(NT, sc3_win_waves(NT, (cbinom(WB, WB / 2) * 16 * 16 + 1023) / 1024 + 12))
+sc3g_win_pass(const Sc3Tab S, const Sc3Op O, const uint32_t *__restrict__ perm, const Sc3Call C,
+              const c128 *__restrict__ xw, c128 *__restrict__ y) {
+  constexpr int MAXE = cbinom(WB, WB / 2) * 16;
+  constexpr int RPT = (MAXE + NT - 1) / NT;
+  constexpr uint32_t WM = (1u << WB) - 1u;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ uint8_t wrk[1 << WB];               // rank of a window pattern inside its class
+  c128 *xs = reinterpret_cast<c128 *>(smem);     // the tile [wr][column], then one zero row (wr = nwp)
+  const uint32_t e = SC3_CP(uint32_t, perm)[blockIdx.x];
+  if (e == 0xffffffffu) return;
+  constexpr int NWR = ((1 << WB) + NT - 1) / NT;
+  uint16_t twr[NWR];               // asked for first, stored with the tile
+#pragma unroll
+  for (int i = 0; i < NWR; ++i) {
+    const int j = threadIdx.x + i * NT;
+    twr[i] = j < (1 << WB) ? S.w_rank[j] : (uint16_t)0;
+  }
+  const int lane = threadIdx.x & 63;
+  const uint32_t T = e >> 16;
+  const int cw = (e >> 12) & 15, run = e & 0xfff;
+  const int kr = S.k - __popc(T), kl = kr - cw;
+  const int nwp = S.nw[cw], p = S.pitch[kl];
+  const int sh = 4 + S.rs[cw];
+  const int lr0 = run << sh;
+  const int ncols = min(1 << sh, p - lr0);
+  const int64_t tb = SC3_CP(int64_t, S.ibase)[T];
+  const int64_t own = tb + SC3_CP(int64_t, S.icoff)[kr * (WB + 1) + cw];
+  const int64_t cbase = own + lr0;
+  const int64_t lcb = cbase - C.row0;
+  const int nent = nwp << sh;
+  const c128 *__restrict__ x = xw - C.win_start;
+
+  SC3_PRIO_MEM();
+  uint32_t wpat[RPT];
+  int32_t off[RPT];          // offset of the entry from cbase, -1: not an entry
+  c128 xv[RPT];
+  const auto pat = SC3_CP(uint16_t, S.w_pat) + S.w_off[cw];
+#pragma unroll
+  for (int i = 0; i < RPT; ++i) {
+    const int en = threadIdx.x + i * NT;
+    wpat[i] = 0;
+    off[i] = -1;
+    xv[i] = make_double2(0.0, 0.0);
+    if (en < nent) {
+      const int wrr = en >> sh, j = en & ((1 << sh) - 1);
+      wpat[i] = pat[wrr] | ((uint32_t)wrr << 16);
+      if (j < ncols) {
+        off[i] = wrr * p + j;
+        xv[i] = x[cbase + off[i]];
+      }
+    }
+  }
+  // gathered hops, one per lane: both spins in T (a uniform offset), or spin i in W and spin j in T (the rows of the
+  // partner class by rank, the columns as they are)
+  HopEval g{0, 0, 0.0, 0.0, 0, 0u};
+  if (lane < O.ngatB) {
+    const Sc3Hop h = O.gatB[lane];
+    const uint32_t T2 = T ^ h.mT;
+    const int nd = h.half - __popc(T & h.mT);
+    const int nwm = __popc(h.mW);
+    const int kr2 = S.k - __popc(T2), cw2 = cw + nwm - 2 * nd, kl2 = kr2 - cw2;
+    if (nd >= 0 && nd <= nwm && cw2 >= 0 && cw2 <= WB && kl2 == kl) {
+      const int64_t tb2 = S.ibase[T2];
+      if (tb2 >= 0) {
+        g.act = 1;
+        g.delta = tb2 + S.icoff[kr2 * (WB + 1) + cw2] - own;
+        g.need = nd;
+        g.xm = h.mW;
+        const bool up = h.dfield == 3 || (h.dfield == 1 ? nd == 1 : ((T >> h.dbit) & 1u) != 0);
+        g.c0 = up ? h.up_re : h.dn_re;
+        g.c1 = up ? h.up_im : h.dn_im;
+      }
+    }
+  }
+  uint64_t hb = __ballot(g.act);
+  for (int j = threadIdx.x; j < (1 << sh); j += NT) xs[nent + j] = make_double2(0.0, 0.0);       // the zero row
+  // the partner rows of the hops inside W, behind it (Sc3Op::wnb: nldsB bytes per row of the class)
+  uint8_t *wtab = reinterpret_cast<uint8_t *>(xs + nent + (1 << sh));
+  const int nhl = O.nldsB;
+  for (int j = threadIdx.x; j < nwp * nhl; j += NT) wtab[j] = O.wnb[(size_t)S.w_off[cw] * nhl + j];
+#pragma unroll
+  for (int i = 0; i < NWR; ++i) {
+    const int j = threadIdx.x + i * NT;
+    if (j < (1 << WB)) wrk[j] = (uint8_t)twr[i];
+  }
+  double accr[RPT], acci[RPT];
+#pragma unroll
+  for (int i = 0; i < RPT; ++i) {
+    const int en = threadIdx.x + i * NT;
+    accr[i] = 0.0;
+    acci[i] = 0.0;
+    if (en < nent) {
+      xs[en] = xv[i];
+      if (!ACC && C.zinit && off[i] >= 0) {
+        const c128 zv = C.zinit[lcb + off[i]];
+        accr[i] = -C.zscale * zv.x;
+        acci[i] = -C.zscale * zv.y;
+        if (C.zinit2) {
+          const c128 z2 = C.zinit2[lcb + off[i]];
+          accr[i] = fma(C.z2re, z2.x, accr[i]);
+          accr[i] = fma(-C.z2im, z2.y, accr[i]);
+          acci[i] = fma(C.z2re, z2.y, acci[i]);
+          acci[i] = fma(C.z2im, z2.x, acci[i]);
+        }
+      }
+    }
+  }
+  __syncthreads();                 // tile, zero row and tables are in LDS (loads in flight are not waited for)
+  while (hb) {
+    const int m = __ffsll((long long)hb) - 1;
+    hb &= hb - 1;
+    const c128 *__restrict__ pp = x + (cbase + rl_i64(g.delta, m));
+    const double cr = rl_f64(g.c0, m), ci = rl_f64(g.c1, m);
+    const int nd = rl_i32(g.need, m);
+    const uint32_t xm = (uint32_t)rl_i32((int)g.xm, m);
+    c128 v[RPT];
+    if (xm == 0u) {                // both spins in T: every entry, the same offset
+#pragma unroll
+      for (int i = 0; i < RPT; ++i) {
+        v[i] = make_double2(0.0, 0.0);
+        if (off[i] >= 0) v[i] = pp[off[i]];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < RPT; ++i) {
+        v[i] = make_double2(0.0, 0.0);
+        const uint32_t wp = wpat[i] & WM;
+        if (off[i] >= 0 && __popc(wp & xm) == nd) {
+          const int wr2 = (int)wrk[wp ^ xm], wrr = (int)(wpat[i] >> 16);
+          v[i] = pp[off[i] + (wr2 - wrr) * p];
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+      accr[i] = fma(cr, v[i].x, accr[i]);
+      acci[i] = fma(cr, v[i].y, acci[i]);
+      if (!SYM) {
+        accr[i] = fma(-ci, v[i].y, accr[i]);
+        acci[i] = fma(ci, v[i].x, acci[i]);
+      }
+    }
+  }
+  SC3_PRIO_LDS();
+  // hops inside W: partner row from the operator's table; a row the hop does not act on points at the zero row
+  {
+    uint32_t col[RPT], trow[RPT];
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+      const int en = threadIdx.x + i * NT;
+      col[i] = (uint32_t)en & ((1u << sh) - 1u);
+      trow[i] = en < nent ? (wpat[i] >> 16) * (uint32_t)nhl : 0u;
+    }
+    for (int hq = 0; hq < nhl; ++hq) {
+      const auto hp = SC3_CP(Sc3Hop, O.ldsB) + hq;
+      const int dbit = hp->dbit;
+      const double ure = hp->up_re, uim = hp->up_im, dre = hp->dn_re, dim_ = hp->dn_im;
+#pragma unroll
+      for (int i = 0; i < RPT; ++i) {
+        const int en = threadIdx.x + i * NT;
+        const uint32_t pr = en < nent ? (uint32_t)wtab[trow[i] + hq] : (uint32_t)nwp;
+        const c128 xp = xs[(pr << sh) + col[i]];
+        if (SYM) {
+          accr[i] = fma(ure, xp.x, accr[i]);
+          acci[i] = fma(ure, xp.y, acci[i]);
+        } else {
+          const bool up = (wpat[i] >> dbit) & 1u;
+          const double cre = up ? ure : dre, cim = up ? uim : dim_;
+          accr[i] = fma(cre, xp.x, accr[i]);
+          acci[i] = fma(cre, xp.y, acci[i]);
+          accr[i] = fma(-cim, xp.y, accr[i]);
+          acci[i] = fma(cim, xp.x, acci[i]);
+        }
+      }
+    }
+  }
+  SC3_PRIO_MEM();
+#pragma unroll
+  for (int i = 0; i < RPT; ++i)
+    if (off[i] >= 0) {
+      double ar = accr[i], ai = acci[i];
+      if (ACC) {
+        const c128 yo = load_nt(y + lcb + off[i]);
+        ar += yo.x;
+        ai += yo.y;
+      }
+      store_nt(y + lcb + off[i], ar, ai);
+    }
+}
+
+}  // namespace
+
+// phase 0: window pass writes y, lo pass adds (one rank); phase 1: lo pass alone (writes y); phase 2: window pass (adds)
+template <int A, int W, int NT, int NTW>
+static int launch_graph_passes(const Sc3Mat &M, const Sc3Call &call, const double *cached_diag, const void *xw, void *y,
+                               hipStream_t st, int phase) {
+  const Sc3Tab &S = M.ly->dev;
+  constexpr size_t ldsA = (size_t)sc3_lo_cap(A, NT) * 16;
+  size_t ldsB = 0;
+  for (int cw = 0; cw <= W; ++cw)
+    ldsB = std::max(ldsB, (((size_t)M.ly->host.nw[cw] + 1) << (4 + M.ly->host.rs[cw] + 4)) +
+                              (((size_t)M.ly->host.nw[cw] * (size_t)M.op.nldsB + 15) & ~(size_t)15));
+  Sc3Op op = M.op;
+  const int dm = M.diag_mode;
+  if (dm == 1) op.diag = cached_diag;
+  DNM_CHECK(dm != 1 || op.diag, "this operator needs its diagonal precomputed (dnm_mat_precompute_diagonal)");
+  DNM_CHECK(!M.real, "internal: no real-arithmetic form of the bond-graph passes");
+  using kern_t = void (*)(const Sc3Tab, const Sc3Op, const uint32_t *, const Sc3Call, const c128 *, c128 *);
+  const bool lo_first = phase != 0;
+  kern_t kB = nullptr, kA = nullptr;
+  if (lo_first) kB = M.sym ? sc3g_win_pass<W, NTW, true, true> : sc3g_win_pass<W, NTW, false, true>;
+  else kB = M.sym ? sc3g_win_pass<W, NTW, true, false> : sc3g_win_pass<W, NTW, false, false>;
+#define DNM_LO(DM_, SY_) (lo_first ? (kern_t)sc3g_lo_pass<A, NT, DM_, SY_, false> : (kern_t)sc3g_lo_pass<A, NT, DM_, SY_, true>)
+  switch (dm * 2 + (M.sym ? 1 : 0)) {
+    case 0: kA = DNM_LO(0, false); break;
+    case 1: kA = DNM_LO(0, true); break;
+    case 2: kA = DNM_LO(1, false); break;
+    case 3: kA = DNM_LO(1, true); break;
+    case 4: kA = DNM_LO(2, false); break;
+    default: kA = DNM_LO(2, true); break;
+  }
+#undef DNM_LO
+  static std::map<const void *, size_t> attr_done;
+  for (auto kp : {std::make_pair((const void *)kA, ldsA), std::make_pair((const void *)kB, ldsB)})
+    if (attr_done[kp.first] < kp.second) {
+      DNM_HIP(hipFuncSetAttribute(kp.first, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kp.second));
+      attr_done[kp.first] = kp.second;
+    }
+  Sc3Call first = call, second = call;
+  first.dot_out = nullptr;
+  second.zinit = nullptr;
+  second.zinit2 = nullptr;
+  if (phase == 0 || phase == 2)
+    hipLaunchKernelGGL(kB, dim3((unsigned)M.permB.size()), dim3(NTW), ldsB, st, S, op, (const uint32_t *)M.d_permB,
+                       phase == 0 ? first : second, (const c128 *)xw, (c128 *)y);
+  if (phase == 0 || phase == 1)
+    hipLaunchKernelGGL(kA, dim3((unsigned)(M.permA.size() / 8)), dim3(NT), ldsA, st, S, op, (const uint32_t *)M.d_permA,
+                       phase == 0 ? second : first, (const c128 *)xw, (c128 *)y);
+  DNM_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_sc3g(const Sc3Mat &M, const Sc3Call &call, const double *cached_diag, const void *xw, void *y, hipStream_t st,
+                int phase) {
+  if (M.ly->host.a == 14) return launch_graph_passes<14, 10, 1024, 512>(M, call, cached_diag, xw, y, st, phase);
+  return launch_graph_passes<6, 4, 256, 64>(M, call, cached_diag, xw, y, st, phase);
+}
+
+}  // namespace dnm

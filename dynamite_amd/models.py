@@ -91,5 +91,64 @@ def xsum(L):
     return H
 
 
-BY_NAME = {'mbl': mbl, 'heisenberg': heisenberg, 'xxz': xxz, 'ising': ising,
+def bond_heisenberg(edges, L=None, J=1.0):
+    """sum over the bonds (i, j) of J * 0.25 (XX + YY + ZZ): the Heisenberg model on any bond graph
+    (examples/scripts/kagome/run_kagome.py:12-28 in the reference tree)."""
+    H = op_sum(op_sum(J * 0.25 * s(i) * s(j) for s in (sigmax, sigmay, sigmaz)) for i, j in edges)
+    if L is not None:
+        H.L = L
+    return H
+
+
+def kagome(cluster):
+    """Nearest-neighbour Heisenberg model on a kagome torus of the reference's cluster library
+    (run_kagome.py:20-28; clusters and vertex numbering: ``lattices.kagome``)."""
+    from . import lattices
+    n, edges = lattices.kagome(cluster)
+    return bond_heisenberg(edges, L=n)
+
+
+def bench_long_range(L):
+    """benchmarking/benchmark.py:139-146 ('long_range': ZZ between all pairs, nearest-neighbour XX, small fields)."""
+    H = op_sum(index_sum(0.25 * sigmaz(0) * sigmaz(i), size=L) for i in range(1, L))
+    H += 0.5 * index_sum(0.25 * sigmax(0) * sigmax(1), size=L)
+    H += op_sum(0.05 * index_sum(s(), size=L) for s in (sigmax, sigmay, sigmaz))
+    H.L = L
+    return H
+
+
+def bench_ising(L):
+    """benchmarking/benchmark.py:162-163."""
+    H = index_sum(0.25 * sigmaz(0) * sigmaz(1), size=L) + 0.1 * index_sum(sigmax(), size=L)
+    H.L = L
+    return H
+
+
+def bench_xx(L):
+    """benchmarking/benchmark.py:165-166."""
+    H = index_sum(0.25 * sigmax(0) * sigmax(1), size=L)
+    H.L = L
+    return H
+
+
+def bench_syk(L):
+    """benchmarking/benchmark.py:148-160 (stdlib random.seed(0), uniform(-1, 1) per product, overall scale)."""
+    from random import seed, uniform
+    seed(0)
+    maj = [majorana(i) for i in range(L * 2)]
+
+    def gen():
+        for idxs in combinations(range(L * 2), 4):
+            p = op_product(maj[i] for i in idxs)
+            p.scale(uniform(-1, 1))
+            yield p
+    H = op_sum(gen())
+    H.scale(np.sqrt(6 / (L * 2) ** 3))
+    H.L = L
+    return H
+
+
+BY_NAME = {'bench_long_range': bench_long_range, 'bench_ising': bench_ising, 'bench_xx': bench_xx,
+           'bench_syk': bench_syk,
+           'mbl': mbl, 'heisenberg': heisenberg, 'xxz': xxz, 'ising': ising,
            'long_range': long_range, 'localized': localized, 'syk': syk, 'xsum': xsum}

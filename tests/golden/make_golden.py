@@ -330,5 +330,46 @@ def main():
     save("xparity.npz", xp)
 
 
+def kagome():
+    """Fixtures of the reference's flagship large-scale example (examples/scripts/kagome): `kagome_edges.json` = the
+    edge lists `lattice_library.basis_to_graph` produces for every cluster of `kagome_clusters` (data: the bond
+    graphs run_kagome.py builds its Hamiltonian on); `kagome.npz` = the Heisenberg operator of run_kagome.py:12-28 on
+    the 12- and 15-site tori, built with the reference's operator algebra, in SpinConserve(N, N // 2) (and its XParity
+    sectors for N = 12): arrays, y = H x and the lowest eigenvalues from the reference's matrix builder."""
+    sys.path.insert(0, os.path.join(REF, "examples", "scripts", "kagome"))
+    import lattice_library as ll
+    from dynamite import subspaces as rsub
+    edges = {}
+    for name, basis in ll.kagome_clusters.items():
+        verts, e = ll.basis_to_graph(basis)
+        edges[name] = {"n": len(verts), "edges": sorted([int(a), int(b)] for a, b in e)}
+    with open(os.path.join(HERE, "kagome_edges.json"), "w") as f:
+        json.dump(edges, f, separators=(",", ":"))
+    print("wrote kagome_edges.json", {k: (v["n"], len(v["edges"])) for k, v in edges.items()})
+
+    def h_kagome(name):
+        e = edges[name]
+        set_L(e["n"])
+        return op_sum(op_sum(0.25 * s(i) * s(j) for s in (sigmax, sigmay, sigmaz))
+                      for i, j in e["edges"])
+    out = {}
+    for name in ("12", "15"):
+        N = edges[name]["n"]
+        sc = orc.spin_conserve(N, N // 2)
+        d = case_sub("kagome_%s_sc" % name, h_kagome(name), N, sc, sc, out)
+        msc, _, _ = marshal(h_kagome(name))
+        A = msc_tools.msc_to_numpy(msc, (sc.dim, sc.dim), idx_to_state=lambda r: int(sc.i2s(r)[0]),
+                                   state_to_idx=lambda st: sc.s2i(st))
+        d["evals_lowest"] = np.linalg.eigvalsh(A.toarray())[:6]
+    for sector in (+1, -1):
+        case_xparity("kagome_12_sc_xparity_" + ("plus" if sector == 1 else "minus"), h_kagome("12"), 12,
+                     rsub.SpinConserve(12, 6), orc.spin_conserve(12, 6), sector, out)
+    save("kagome.npz", out)
+
+
 if __name__ == "__main__":
-    main()
+    if "--kagome" in sys.argv:
+        kagome()
+    else:
+        main()
+        kagome()

@@ -91,7 +91,8 @@ def test_layout_round_trip(small_layout):
 @pytest.mark.parametrize("L,k", [(11, 5), (12, 6), (13, 4), (14, 7)])
 def test_multiply_vs_oracle(small_layout, monkeypatch, name, L, k):
     """Every kernel path of the internal layout against the oracle: two tiled passes (chains; on-the-fly and cached
-    diagonal; real symmetric and complex bonds) and the row kernel (long-range couplings)."""
+    diagonal; real symmetric and complex bonds; the long-range model, whose single-spin X / Y fields never act inside
+    the subspace and whose all-to-all ZZ part needs the cached diagonal) and the row kernel."""
     H = MODELS[name](L)
     sub = SpinConserve(L, k)
     n = sub.get_dimension()
@@ -104,12 +105,12 @@ def test_multiply_vs_oracle(small_layout, monkeypatch, name, L, k):
         mat = shell(H, sub)
         d = mat.describe()
         assert "internal layout" in d
-        if name == "long_range" or env.get("DNM_SC3_TILED") == "0":
+        if env.get("DNM_SC3_TILED") == "0":
             assert "row kernel" in d
         else:
             assert "two-pass" in d
-            assert ("real symmetric" in d) == (name in ("heisenberg", "mbl", "xxz", "nnn"))
-            assert ("diagonal cached" in d) == ("DNM_SC3_DIAG" in env)
+            assert ("real symmetric" in d) == (name in ("heisenberg", "mbl", "xxz", "nnn", "long_range"))
+            assert ("diagonal cached" in d) == ("DNM_SC3_DIAG" in env or name == "long_range")
         if mat.uses_cached_diagonal():
             mat.precompute_diagonal()
         got = mult_numpy(mat, x)

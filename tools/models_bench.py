@@ -1,0 +1,91 @@
+#!/usr/bin/env python
+"""One table over the Hamiltonians the reference's harness and flagship example run (benchmarking/benchmark.py:129-170,
+examples/scripts/kagome/run_kagome.py): for each (model, subspace, size) the plan line, ms per multiply, Gamp/s and the
+32 B/amp rate; `--eigs` adds the wall time of eigsolve(nev=2) for the kagome cases.
+
+    python tools/models_bench.py CASE ...       CASE = model:subspace:L[:k]   e.g. kagome30:sc, bench_long_range:full:28,
+                                                 bench_long_range:sc:28, kagome30:scx (SpinConserve + XParity)
+"""
+import os
+os.environ.setdefault("DNM_EXPERIMENTAL", "1")
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+from dynamite_amd import models  # noqa: E402
+from dynamite_amd.config import config  # noqa: E402
+from dynamite_amd.states import State  # noqa: E402
+from dynamite_amd.subspaces import Full, SpinConserve, XParity  # noqa: E402
+from dynamite_amd.computations import eigsolve  # noqa: E402
+
+
+def build(case):
+    parts = case.split(":")
+    model, space = parts[0], parts[1]
+    if model.startswith("kagome"):
+        H = models.kagome(model[len("kagome"):])
+        L = H.L
+    else:
+        L = int(parts[2])
+        H = models.BY_NAME[model](L)
+    k = int(parts[3]) if len(parts) > 3 else L // 2
+    if space == "full":
+        sub = Full(L=L)
+    elif space == "sc":
+        sub = SpinConserve(L, k)
+    elif space == "scx":
+        sub = XParity(SpinConserve(L, k), sector='+' if L % 4 == 0 else '-')
+    else:
+        raise SystemExit("subspace: full / sc / scx")
+    H.allow_projection = True
+    H.add_subspace(sub)
+    return H, sub, L
+
+
+def main():
+    config._initialize()
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    eigs = "--eigs" in sys.argv
+    for case in args:
+        t0 = time.perf_counter()
+        H, sub, L = build(case)
+        mat = H.get_mat(subspaces=(sub, sub))
+        t_build = time.perf_counter() - t0
+        dim = sub.get_dimension()
+        x = State(L=L, subspace=sub)
+        x.set_random(seed=0)
+        y = State(L=L, subspace=sub)
+        for _ in range(2):
+            H.dot(x, result=y)
+        torch.cuda.synchronize()
+        n = 5
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            H.dot(x, result=y)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / n
+        print("CASE %s  L=%d dim=%d nmasks=%d nterms=%d build %.2f s" % (case, L, dim, len(set(H.msc['masks'].tolist())),
+                                                                       H.msc.size, t_build), flush=True)
+        print("   plan: " + mat.describe().strip().replace("\n", " | "), flush=True)
+        print("   multiply %.3f ms  %.2f Gamp/s  %.1f GB/s (32 B/amp)  frac %.3f" %
+              (ms, dim / ms / 1e6, 32.0 * dim / ms / 1e6, 32.0 * dim / ms / 1e6 / 8000.0), flush=True)
+        if eigs:
+            del x, y
+            t0 = time.perf_counter()
+            ev = H.eigsolve(nev=2, subspace=sub)
+            torch.cuda.synchronize()
+            st = dict(eigsolve.last_stats)
+            print("   eigsolve(nev=2): %.2f s  %d multiplies  E0=%.10f E1=%.10f  real_arithmetic=%s residual %.2e" %
+                  (time.perf_counter() - t0, st["matvecs"], ev[0], ev[1], st.get("real_arithmetic"),
+                   st["max_rel_residual"]), flush=True)
+        H.destroy_mat()
+        del H
+        torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()
