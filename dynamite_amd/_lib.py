@@ -22,7 +22,8 @@ class Subspace(C.Structure):
     """dnm_subspace"""
     _fields_ = [("type", C.c_int32), ("L", C.c_int64), ("space", C.c_int64), ("k", C.c_int64),
                 ("ld_nchoosek", C.c_int64), ("nchoosek", i64p), ("dim", C.c_int64),
-                ("state_map", i64p), ("rmap_indices", i64p), ("rmap_states", i64p), ("vec_swizzle", C.c_int32)]
+                ("state_map", i64p), ("rmap_indices", i64p), ("rmap_states", i64p), ("vec_swizzle", C.c_int32),
+                ("site_perm", C.POINTER(C.c_int8))]
 
 
 class Partition(C.Structure):
@@ -157,6 +158,8 @@ SIGNATURES = {
     "dnm_vec_basis_update": (C.c_int, [vp, C.c_int64, C.c_int, C.c_int, C.c_int64, f64p, vp]),
     "dnm_workspace_bytes": (C.c_int, [C.POINTER(C.c_size_t)]),
     "dnm_release_workspace": (C.c_int, []),
+    "dnm_sc_choose_site_perm": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int64, i64p, C.c_int, C.POINTER(C.c_int8),
+                                          C.POINTER(C.c_int32)]),
     "dnm_workspace_reserve": (C.c_int, [C.c_size_t, C.c_void_p]),
     "dnm_expm_chebyshev": (C.c_int, [vp, vp, vp, C.c_int64, C.c_double, C.c_double, C.POINTER(Hooks),
                                      C.POINTER(SolverStats), vp]),

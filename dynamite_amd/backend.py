@@ -272,6 +272,34 @@ class ExchangeCheckError(RuntimeError):
     definition (``ShellMat.selfcheck``)."""
 
 
+def site_perm_of(sub_c):
+    """The site relabelling of a SpinConserve descriptor (dnm_subspace.site_perm) as a tuple, None for the identity."""
+    if sub_c is None or not sub_c.site_perm:
+        return None
+    perm = tuple(int(sub_c.site_perm[i]) for i in range(int(sub_c.L)))
+    return None if perm == tuple(range(int(sub_c.L))) else perm
+
+
+def with_site_perm(sub_c, perm):
+    """A copy of a SpinConserve descriptor whose vectors live in the relabelled layout ``perm`` (spin i -> bit
+    perm[i]); the copy keeps the permutation array and the original descriptor (whose tables it points into) alive."""
+    d = _lib.Subspace.from_buffer_copy(sub_c)
+    arr = np.ascontiguousarray(perm, dtype=np.int8)
+    d.site_perm = arr.ctypes.data_as(C.POINTER(C.c_int8))
+    d._keepalive = (arr, sub_c)
+    return d
+
+
+def choose_site_perm(masks, L, a, w, fix_top=False):
+    """(site_perm as an int8 array, hop counts [Lo, W, T, Lo-W, Lo-T, W-T]) -- dnm_sc_choose_site_perm."""
+    masks = np.ascontiguousarray(masks, dtype=np.int64)
+    perm = np.zeros(int(L), dtype=np.int8)
+    counts = (C.c_int32 * 6)()
+    _lib.check(_lib.lib().dnm_sc_choose_site_perm(int(L), int(a), int(w), masks.size, _lib.p64(masks), int(bool(fix_top)),
+                                                  perm.ctypes.data_as(C.POINTER(C.c_int8)), counts))
+    return perm, [int(c) for c in counts]
+
+
 class Vec:
     """Distributed complex128 vector: this rank's block lives in ``self.array``
     (a 1-D torch tensor on the rank's GPU).  ``swz``: layout of the block (dnm_subspace.vec_swizzle): 0 = element
@@ -287,6 +315,7 @@ class Vec:
         self.size = int(size)
         self.swz = int(swz)
         self.sub_c = sub_c
+        self.perm = site_perm_of(sub_c) if int(swz) >= 256 else None
         self.start, self.local_size = split_ownership(self.size, config.world_size, config.rank)
         self.rows = self.local_size              # elements of the vector this rank holds
         self.istart = self.start                 # where this rank's part starts in the layout's own index space
@@ -401,11 +430,31 @@ class Vec:
         if v != 0:
             self._zero_padding()
 
+    @property
+    def layout(self):
+        """What two vectors must share to be combined element by element: the layout code and, in the SpinConserve
+        internal layout, the site relabelling."""
+        return (self.swz, self.perm)
+
+    def _in_my_layout(self, other):
+        """``other`` (a vector of the same subspace) as a vector laid out like this one: itself, or a copy made
+        through the reference order (a state built for one operator's relabelled layout meeting another's)."""
+        if other.layout == self.layout:
+            return other
+        if other.size != self.size or not (self.internal or other.internal):
+            raise ValueError('vectors of different layouts (%r, %r)' % (self.layout, other.layout))
+        tmp = Vec(self.size, swz=self.swz, sub_c=self.sub_c)
+        tmp.set_local_natural(other.local_natural())
+        return tmp
+
     def copy(self, result=None):
         if result is None:
             result = Vec(self.size, swz=self.swz, sub_c=self.sub_c)
-        if result.swz != self.swz:
-            raise ValueError('vectors of different layouts')
+        if result.layout != self.layout:
+            if not (self.internal and result.internal and result.size == self.size):
+                raise ValueError('vectors of different layouts')
+            result.set_local_natural(self.local_natural())
+            return result
         _lib.check(_lib.lib().dnm_vec_copy(self.ptr, result.ptr, self.local_size, _stream()))
         return result
 
@@ -416,6 +465,7 @@ class Vec:
     def axpby(self, alpha, beta, x):
         """self = alpha*x + beta*self (VecAXPBY)."""
         a, b = complex(alpha), complex(beta)
+        x = self._in_my_layout(x)
         _lib.check(_lib.lib().dnm_vec_axpby(self.ptr, x.ptr, self.local_size, a.real, a.imag,
                                             b.real, b.imag, _stream()))
 
@@ -431,6 +481,7 @@ class Vec:
     def dot(self, other):
         """VecDot(self, other) = sum_i self_i * conj(other_i)."""
         out = (C.c_double * 2)()
+        other = self._in_my_layout(other)
         _lib.check(_lib.lib().dnm_vec_dot(self.ptr, other.ptr, self.local_size, out, _stream()))
         re, im = self._reduce([out[0], out[1]])
         return complex(re, im)
@@ -517,6 +568,7 @@ class RawVec:
     hooks wrap raw work-vector pointers of a real-arithmetic SpinConserve operator in (its vectors are one double per
     position of the layout, i.e. half as many complex128 elements as ``Vec`` would size them)."""
     internal = True
+    perm = None
 
     def __init__(self, array, swz):
         self.array, self.swz = array, int(swz)
@@ -543,6 +595,9 @@ class ShellMat:
         ll, lr = C.c_int(), C.c_int()
         _lib.check(_lib.lib().dnm_mat_layouts(handle, C.byref(ll), C.byref(lr)))
         self.swz_left, self.swz_right = ll.value, lr.value
+        # ... and the site relabelling of a SpinConserve pair in the internal layout (dnm_subspace.site_perm)
+        self.perm_left = site_perm_of(left_c) if ll.value >= 256 else None
+        self.perm_right = site_perm_of(right_c) if lr.value >= 256 else None
         self.sends, self.recvs = exchange_plan(handle)
         self.partners = sorted({r[0] for r in self.recvs})
         self._recv = {}
@@ -573,8 +628,10 @@ class ShellMat:
         return (Vec(self.N, swz=self.swz_right, sub_c=self._keep[1]), Vec(self.M, swz=self.swz_left, sub_c=self._keep[0]))
 
     def _mult_converted(self, x, y):
-        """A vector in the SpinConserve internal layout meets a matrix that works in reference order (a projection
-        onto / from another subspace, XParity ...): multiply on reference-order copies."""
+        """A vector whose layout is not the matrix's: a state in the SpinConserve internal layout meets a matrix that
+        works in reference order (a projection onto / from another subspace, XParity ...), or a matrix that works in
+        a relabelled layout of its own (an operator on a bond graph, ``choose_site_perm``).  Multiply on copies made
+        through the reference order."""
         xn, yn = x, y
         P = self.nranks
 
@@ -584,20 +641,34 @@ class ShellMat:
             redistributed between them."""
             return ([layout_partition(v.sub_c, P, q)[2:4] for q in range(P)],
                     [split_ownership(v.size, P, q) for q in range(P)])
-        if x.swz != self.swz_right:
-            if not (x.internal and self.swz_right == 0):
+
+        def mine(v, want_swz, want_perm):
+            return v.swz == want_swz and v.perm == want_perm
+        if not mine(x, self.swz_right, self.perm_right):
+            if not x.internal:
                 return False
             arr = x.local_natural()
-            if P > 1:
-                arr = redistribute(arr, *parts(x), self.rank)
-            xn = Vec(x.size, array=arr, swz=0)
-        if y.swz != self.swz_left:
-            if not (y.internal and self.swz_left == 0):
+            if self.swz_right == 0:
+                if P > 1:
+                    arr = redistribute(arr, *parts(x), self.rank)
+                xn = Vec(x.size, array=arr, swz=0)
+            elif P == 1:
+                xn = Vec(x.size, swz=self.swz_right, sub_c=self._keep[1])
+                xn.set_local_natural(arr)
+            else:
                 return False
-            yn = Vec(y.size, swz=0)
+        if not mine(y, self.swz_left, self.perm_left):
+            if not y.internal:
+                return False
+            if self.swz_left == 0:
+                yn = Vec(y.size, swz=0)
+            elif P == 1:
+                yn = Vec(y.size, swz=self.swz_left, sub_c=self._keep[0])
+            else:
+                return False
         self.mult(xn, yn)
         if yn is not y:
-            arr = yn.array
+            arr = yn.array if yn.swz == 0 else yn.local_natural()
             if P > 1:
                 lay, ref = parts(y)
                 arr = redistribute(arr, ref, lay, self.rank)
@@ -616,7 +687,8 @@ class ShellMat:
         L = _lib.lib()
         if x.array.data_ptr() == y.array.data_ptr():
             raise ValueError('x and y must be different vectors')
-        if (x.swz != self.swz_right or y.swz != self.swz_left) and self._mult_converted(x, y):
+        if ((x.swz, x.perm) != (self.swz_right, self.perm_right) or (y.swz, y.perm) != (self.swz_left, self.perm_left)) \
+                and self._mult_converted(x, y):
             return
         self.check_layout(x, y)
         if self._tr is not None:
@@ -661,16 +733,40 @@ class ShellMat:
             for i in range(nr):
                 _lib.check(L.dnm_mat_mult_remote(self.handle, i, C.c_void_p(bufs[i].data_ptr()), y.ptr, _stream()))
 
+    def vec_in(self, v):
+        """``v`` as an input vector in this matrix's layout: itself, or a copy made through the reference order (a
+        state of the subspace's own layout handed to an operator that works in a relabelled one)."""
+        if (v.swz, v.perm) == (self.swz_right, self.perm_right):
+            return v
+        if not (v.internal and self.swz_right >= 256 and self.nranks == 1):
+            return v                      # check_layout names the mismatch
+        out = Vec(v.size, swz=self.swz_right, sub_c=self._keep[1])
+        out.set_local_natural(v.local_natural())
+        return out
+
+    def vec_out(self, v):
+        """A result vector in this matrix's layout standing in for ``v`` (itself when the layouts agree); the caller
+        copies it back with ``Vec.copy``, which converts."""
+        if (v.swz, v.perm) == (self.swz_left, self.perm_left):
+            return v
+        if not (v.internal and self.swz_left >= 256 and self.nranks == 1):
+            return v
+        return Vec(v.size, swz=self.swz_left, sub_c=self._keep[0])
+
     def check_layout(self, x, y):
         """Raise unless the vectors are laid out as this matrix expects them (x: right subspace, y: left).  Every
         caller that hands raw vector pointers to the native library -- ``mult`` and the Krylov solvers -- goes
         through here: the layout of a vector is fixed when it is created, the matrix's when it is built, and
         process state in between (``config.vec_swizzle``, the number of ranks) may have changed."""
-        for v, want, n, name in ((x, self.swz_right, self.n_local, 'input'), (y, self.swz_left, self.m_local, 'result')):
+        for v, want, wperm, n, name in ((x, self.swz_right, self.perm_right, self.n_local, 'input'),
+                                        (y, self.swz_left, self.perm_left, self.m_local, 'result')):
             if v.swz != want:
                 raise ValueError('%s vector layout (swizzle %d) does not match the matrix (%d): the state was '
                                  'created under a different vector layout or rank count than the operator'
                                  % (name, v.swz, want))
+            if getattr(v, 'perm', None) != wperm:
+                raise ValueError('%s vector and matrix differ in the site relabelling of their SpinConserve layout'
+                                 % name)
             if v.local_size != n or v.array.numel() != n:
                 raise ValueError('%s vector holds %d local elements (array of %d), the matrix expects %d'
                                  % (name, v.local_size, v.array.numel(), n))
@@ -1158,17 +1254,40 @@ def create_mat(masks, mask_offsets, signs, coeffs, left_c, right_c, xparity=Fals
     return h
 
 
+def _relabelled(masks, lc, rc, xparity, site_perm):
+    """The descriptors a SpinConserve pair in the internal layout is built on: with a site relabelling
+    (dnm_subspace.site_perm) when the operator's bond graph gains from one -- ``site_perm``: None = choose
+    (dnm_sc_choose_site_perm; the identity for chains), False = never, an array = that one.  One rank, same subspace on
+    both sides, no XParity on top; everything else keeps the descriptors as they are."""
+    if site_perm is False or xparity or config.world_size != 1 or not config.sc_site_perm:
+        return lc, rc
+    if not (lc.type == 3 and rc.type == 3 and lc.L == rc.L and lc.k == rc.k and lc.vec_swizzle >= 256
+            and lc.vec_swizzle == rc.vec_swizzle and not lc.site_perm and not rc.site_perm):
+        return lc, rc
+    L = int(lc.L)
+    if site_perm is None:
+        a, w = lc.vec_swizzle & 0xff, (lc.vec_swizzle >> 8) & 0xff
+        site_perm, _ = choose_site_perm(np.unique(np.asarray(masks, dtype=np.int64)), L, a, w)
+    site_perm = np.ascontiguousarray(site_perm, dtype=np.int8)
+    if np.array_equal(site_perm, np.arange(L)):
+        return lc, rc
+    d = with_site_perm(lc, site_perm)
+    return d, d
+
+
 def build_mat(masks, mask_offsets, signs, coeffs, left_subspace, right_subspace, xparity=False,
-              shell=True, gpu=True, flags=0, exchange=None):
+              shell=True, gpu=True, flags=0, exchange=None, site_perm=None):
     """Mirror of ``bpetsc.build_mat`` (bpetsc.pyx:78-138).  ``left_subspace`` /
     ``right_subspace`` are the dicts ``Subspace._to_c()`` returns.  ``exchange`` (not in the reference):
-    'partner' / 'transpose' picks the scheme of a partitioned Full / Parity multiply, None decides by rank count."""
+    'partner' / 'transpose' picks the scheme of a partitioned Full / Parity multiply, None decides by rank count.
+    ``site_perm`` (not in the reference): see ``_relabelled``."""
     if not shell:
         raise ValueError('this engine builds matrix-free (shell) operators only')
     if not gpu:
         raise RuntimeError('dynamite_amd has no CPU path')
     config._initialize()
     lc, rc = left_subspace['data'], right_subspace['data']
+    lc, rc = _relabelled(masks, lc, rc, xparity, site_perm)
     h = create_mat(masks, mask_offsets, signs, coeffs, lc, rc, xparity, flags,
                    rank=config.rank, nranks=config.world_size)
     mat = ShellMat(h, lc, rc, config.world_size, config.rank)

@@ -45,6 +45,9 @@ class _Config:
         lay = knob('DNM_SC_LAYOUT', '14,10')
         self.sc_layout = None if lay in ('0', '') else tuple(int(v) for v in lay.split(','))
         self.sc_layout_min_dim = 1 << 22
+        # operators on a bond graph in such a subspace (one rank): relabel the spins so that as many pair hops as the
+        # graph allows fall inside the layout's fields (backend._relabelled, csrc/sc3_perm.cpp); chains keep the identity
+        self.sc_site_perm = knob('DNM_SC_SITE_PERM', '1') != '0'
         # eigsolve of a real-symmetric operator (every matrix element real in the product basis): real arithmetic on
         # vectors stored two amplitudes to a complex128 element (Full / Parity, on a power-of-two number of ranks) or one
         # double per position of the internal layout (SpinConserve, any rank count) -- DNM_MAT_REAL_PACKED, half the

@@ -168,8 +168,9 @@ static void jacobi_eig(int n, std::vector<double> &A, std::vector<double> &w, st
 // y = A x - b z + c2 z2 (dnm_mat_mult_sub2); the scale that brings s_d back to O(1) is known on the host.
 // seeded start vector in the layout of A's vectors (padding of an internal SpinConserve layout stays zero)
 static int random_start(dnm_mat *A, void *x, int64_t n_local, uint64_t seed, int64_t offset, hipStream_t st) {
-  if (A->use_sc3 && A->real_packed) return sc3_random_real(*A->sc3->ly, (double *)x, seed, st, A->sc3->T0, A->sc3->T1);
-  if (A->use_sc3) return sc3_random(*A->sc3->ly, x, seed, st, A->sc3->T0, A->sc3->T1);
+  if (A->use_sc3 && A->real_packed)
+    return sc3_random_real(*A->sc3->ly, (double *)x, seed, st, A->sc3->T0, A->sc3->T1, &A->sc3->perm);
+  if (A->use_sc3) return sc3_random(*A->sc3->ly, x, seed, st, A->sc3->T0, A->sc3->T1, &A->sc3->perm);
   return vk_random(x, n_local, seed, offset, st, A->right.host.swz);
 }
 

@@ -878,7 +878,52 @@ int dnm_mat_create(int64_t nmasks, const int64_t *masks, const int64_t *mask_off
     // partitioned: whole T blocks per rank (a contiguous range of both the internal layout and the reference order)
     const std::vector<uint32_t> Tb = sc3_partition(*ly, A->nranks);
     const bool want_real = (flags & DNM_MAT_REAL_PACKED) != 0;
-    DNM_TRY(A->sc3->init(ly, A->masks, A->mask_offsets, A->signs, A->real_coeffs, scm, !A->host_only, Tb[A->rank],
+    // site relabelling of the vectors (dnm_subspace.site_perm): the kernels of the layout see the operator in it
+    Sc3Perm P, Pr;
+    DNM_CHECK(sc3_perm_make(left->site_perm, h.L, &P) && sc3_perm_make(right->site_perm, h.L, &Pr),
+              "site_perm is not a permutation of the %d spins", h.L);
+    DNM_CHECK(memcmp(P.to_int, Pr.to_int, sizeof P.to_int) == 0, "left and right vectors must share their site relabelling");
+    DNM_CHECK(!P.on || A->nranks == 1, "a relabelled SpinConserve layout is not partitioned over ranks");
+    A->sc3->perm = P;
+    std::vector<int64_t> pmasks = A->masks, poffs = A->mask_offsets, psigns = A->signs;
+    std::vector<double> pcoef = A->real_coeffs;
+    if (P.on) {
+      // masks and signs bit by bit into the layout's labelling; the mask groups sorted again (terms keep their order
+      // inside a group; a coefficient is unchanged: it multiplies the same product of Pauli matrices)
+      std::vector<int64_t> order((size_t)nmasks);
+      std::vector<uint64_t> nm((size_t)nmasks);
+      for (int64_t i = 0; i < nmasks; ++i) {
+        order[(size_t)i] = i;
+        nm[(size_t)i] = sc3_permute((uint64_t)A->masks[(size_t)i], P.to_int, h.L);
+      }
+      std::sort(order.begin(), order.end(), [&](int64_t x, int64_t y) { return nm[(size_t)x] < nm[(size_t)y]; });
+      pmasks.clear(); psigns.clear(); pcoef.clear();
+      poffs.assign(1, 0);
+      for (int64_t q = 0; q < nmasks; ++q) {
+        const int64_t i = order[(size_t)q];
+        pmasks.push_back((int64_t)nm[(size_t)i]);
+        for (int64_t t = A->mask_offsets[(size_t)i]; t < A->mask_offsets[(size_t)i + 1]; ++t) {
+          psigns.push_back((int64_t)sc3_permute((uint64_t)A->signs[(size_t)t], P.to_int, h.L));
+          pcoef.push_back(A->real_coeffs[(size_t)t]);
+        }
+        poffs.push_back((int64_t)psigns.size());
+      }
+      scm = sc_masks(pmasks, poffs, psigns, pcoef);
+      if (!A->host_only) {           // the row kernel's tables in the layout's labelling
+        DNM_TRY(A->d_pmasks.upload(pmasks.data(), pmasks.size() * 8));
+        DNM_TRY(A->d_poffsets.upload(poffs.data(), poffs.size() * 8));
+        DNM_TRY(A->d_psigns.upload(psigns.data(), psigns.size() * 8));
+        DNM_TRY(A->d_prcoeffs.upload(pcoef.data(), pcoef.size() * 8));
+      }
+    }
+    A->dmsc_sc3 = A->dmsc;
+    if (P.on && !A->host_only) {
+      A->dmsc_sc3.masks = (const int64_t *)A->d_pmasks.p;
+      A->dmsc_sc3.mask_offsets = (const int64_t *)A->d_poffsets.p;
+      A->dmsc_sc3.signs = (const int64_t *)A->d_psigns.p;
+      A->dmsc_sc3.real_coeffs = (const double *)A->d_prcoeffs.p;
+    }
+    DNM_TRY(A->sc3->init(ly, pmasks, poffs, psigns, pcoef, scm, !A->host_only, Tb[A->rank],
                          Tb[A->rank + 1], want_real));
     if (const char *e = knob("DNM_SC3_TILED")) if (e[0] == '0') A->sc3->tiled = false;     // tests: the row kernel
     if (const char *e = knob("DNM_SC3_DIAG")) if (e[0] == 'c' && A->sc3->diag_mode == 2) A->sc3->diag_mode = 1;
@@ -1009,12 +1054,12 @@ static int sc3_mult(dnm_mat *A, const void *x, void *y, const void *z, double b,
   call.z2re = c_re;
   call.z2im = c_im;
   const double *dg = A->have_diag ? (const double *)A->diag.p : nullptr;
-  if (!dot3_host) return launch_sc3(*A->sc3, A->dmsc, call, dg, x, y, S(stream), phase);
+  if (!dot3_host) return launch_sc3(*A->sc3, A->dmsc_sc3, call, dg, x, y, S(stream), phase);
   const size_t nwg = sc3_dot_partials(*A->sc3);
   double *part = nullptr;
   DNM_TRY(vec_scratch(((nwg + 1) * 3 + vk_reduce_scratch(3)) * sizeof(double), &part));
   call.dot_out = part;
-  DNM_TRY(launch_sc3(*A->sc3, A->dmsc, call, dg, x, y, S(stream)));
+  DNM_TRY(launch_sc3(*A->sc3, A->dmsc_sc3, call, dg, x, y, S(stream)));
   DNM_TRY(vk_reduce_partials(part, (int)nwg, 3, part + 3 * nwg, S(stream), part + 3 * nwg + 3));
   DNM_HIP(hipMemcpyAsync(dot3_host, part + 3 * nwg, 3 * sizeof(double), hipMemcpyDeviceToHost, S(stream)));
   DNM_HIP(hipStreamSynchronize(S(stream)));
@@ -1037,7 +1082,7 @@ int dnm_mat_precompute_diagonal(dnm_mat *A, void *stream) {
     DNM_TRY(launch_diag(A->dmsc, A->right.dev, A->rows_local, A->row0, (double *)nat.p, S(stream)));
     DNM_TRY(A->diag.alloc((size_t)A->m_local * sizeof(double)));
     DNM_TRY(sc3_layout_copy_f64(*A->sc3->ly, (double *)A->diag.p, (const double *)nat.p, true, S(stream), A->sc3->T0,
-                                A->sc3->T1));
+                                A->sc3->T1, &A->sc3->perm));
     DNM_HIP(hipStreamSynchronize(S(stream)));      // `nat` is released on return
     A->have_diag = true;
     return 0;
@@ -1054,7 +1099,7 @@ int dnm_mat_get_diagonal(dnm_mat *A, double *diag_host, void *stream) {
     DevBuf nat;
     DNM_TRY(nat.alloc((size_t)A->rows_local * sizeof(double)));
     DNM_TRY(sc3_layout_copy_f64(*A->sc3->ly, (double *)nat.p, (const double *)A->diag.p, false, S(stream), A->sc3->T0,
-                                A->sc3->T1));
+                                A->sc3->T1, &A->sc3->perm));
     return dnm_memcpy_d2h(diag_host, nat.p, (size_t)A->rows_local * sizeof(double), stream);
   }
   return dnm_memcpy_d2h(diag_host, A->diag.p, (size_t)A->m_local * sizeof(double), stream);

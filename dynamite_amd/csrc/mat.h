@@ -79,6 +79,8 @@ struct dnm_mat {
   // generic-kernel tables
   dnm::DevBuf d_masks, d_offsets, d_signs, d_rcoeffs;
   dnm::DevMsc dmsc{};
+  dnm::DevBuf d_pmasks, d_poffsets, d_psigns, d_prcoeffs;     // the same in the labelling of a relabelled sc3 layout
+  dnm::DevMsc dmsc_sc3{};         // what the sc3 row kernel reads (dmsc unless the layout is relabelled)
   dnm::DevBuf d_sclow;            // SpinConserve kernel: 16-bit unranking table
   dnm::ScLow sclow{};
   dnm::DevBuf d_scblock;          // block kernel: lb-bit patterns grouped by popcount

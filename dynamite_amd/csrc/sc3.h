@@ -73,6 +73,30 @@ __host__ __device__ __forceinline__ int64_t sc3_pos(uint64_t state, const Sc3Tab
   return S.ibase[T] + S.icoff[kr * (S.w + 1) + cw] + (int64_t)S.w_rank[W] * S.pitch[kr - cw] + S.lo_rank[Lo];
 }
 
+// Site relabelling on top of the layout (dnm_subspace::site_perm): spin i of the reference's labelling is bit
+// to_int[i] of the states the layout orders.  SpinConserve is invariant under it; the layout's tables are too.  The
+// operator is rewritten into the layout's labelling when it is built (dnm_mat_create), vectors pass through it
+// wherever they meet the reference order (dnm_vec_layout_copy / _positions / _set_random).  One rank only.
+struct Sc3Perm {
+  uint8_t to_int[64];              // reference spin -> layout bit
+  uint8_t to_ref[64];              // layout bit -> reference spin
+  int32_t L = 0;
+  int32_t on = 0;                  // 0: identity
+};
+// from the descriptor's array (null: identity); false if it is not a permutation of 0 .. L-1
+bool sc3_perm_make(const int8_t *site_perm, int L, Sc3Perm *out);
+__host__ __device__ __forceinline__ uint64_t sc3_permute(uint64_t v, const uint8_t *map, int L) {
+  uint64_t r = 0;
+  for (int b = 0; b < L; ++b) r |= ((v >> b) & 1ull) << map[b];
+  return r;
+}
+// Choose the relabelling for an operator: the assignment of its spins to the fields [T | W | Lo] that leaves the
+// fewest (cheapest) hops between fields -- hops inside Lo or W come from LDS, the others are gathered (weights in
+// sc3_perm.cpp).  masks: the operator's distinct masks; fix_top: spin L-1 keeps bit L-1 (XParity).  The identity is
+// kept when nothing found is cheaper.  counts[6]: hops of the result inside Lo, inside W, inside T, Lo-W, Lo-T, W-T.
+void sc3_choose_perm(int L, int a, int w, int64_t nmasks, const int64_t *masks, bool fix_top, int8_t *site_perm,
+                     int32_t *counts);
+
 // Host side: owns the tables (and, optionally, their device mirrors)
 struct Sc3Layout {
   Sc3Tab host{}, dev{};
@@ -113,18 +137,23 @@ const Sc3Layout *sc3_get(int L, int k, int a, int w, bool want_device);
 // dst (internal) <- src (reference order) when to_internal, else dst (reference order) <- src (internal);
 // padding of an internal destination is zeroed
 int sc3_layout_copy(const Sc3Layout &Ly, void *dst, const void *src, bool to_internal, hipStream_t st, uint32_t T0 = 0,
-                    uint32_t T1 = 0xffffffffu);
+                    uint32_t T1 = 0xffffffffu,
+    const Sc3Perm *perm = nullptr);
 // same for a real array (the cached diagonal)
 int sc3_layout_copy_f64(const Sc3Layout &Ly, double *dst, const double *src, bool to_internal, hipStream_t st,
-                        uint32_t T0 = 0, uint32_t T1 = 0xffffffffu);
+                        uint32_t T0 = 0, uint32_t T1 = 0xffffffffu,
+    const Sc3Perm *perm = nullptr);
 int sc3_zero_padding(const Sc3Layout &Ly, void *x, hipStream_t st, uint32_t T0 = 0, uint32_t T1 = 0xffffffffu);
 // pos[i] = local internal position of the local reference index idx[i] (device arrays)
 int sc3_positions(const Sc3Layout &Ly, int64_t n, const int64_t *idx, int64_t *pos, hipStream_t st, uint32_t T0 = 0,
-                  uint32_t T1 = 0xffffffffu);
+                  uint32_t T1 = 0xffffffffu,
+    const Sc3Perm *perm = nullptr);
 // counter-based normal deviates keyed by the global reference index (the numbers reference order would get), padding zero
-int sc3_random(const Sc3Layout &Ly, void *x, uint64_t seed, hipStream_t st, uint32_t T0 = 0, uint32_t T1 = 0xffffffffu);
+int sc3_random(const Sc3Layout &Ly, void *x, uint64_t seed, hipStream_t st, uint32_t T0 = 0, uint32_t T1 = 0xffffffffu,
+    const Sc3Perm *perm = nullptr);
 // real vectors of the layout (one double per position): normal deviates / the complex128 vector a real one stands for
-int sc3_random_real(const Sc3Layout &Ly, double *x, uint64_t seed, hipStream_t st, uint32_t T0 = 0, uint32_t T1 = 0xffffffffu);
+int sc3_random_real(const Sc3Layout &Ly, double *x, uint64_t seed, hipStream_t st, uint32_t T0 = 0, uint32_t T1 = 0xffffffffu,
+    const Sc3Perm *perm = nullptr);
 int sc3_unpack_real(const Sc3Layout &Ly, void *dst, const double *src, hipStream_t st, uint32_t T0 = 0, uint32_t T1 = 0xffffffffu);
 
 // ---- the operator in this layout ---------------------------------------------------------------------------------
@@ -188,6 +217,7 @@ struct Sc3Mat {
   bool tiled = false;              // two tiled passes (every off-diagonal mask is a pair hop); else the row kernel
   bool graph = false;              // ... of sc3g_kernels.hip (any bond graph); false: the chain kernels
   bool sym = false;                // every bond real and direction-independent
+  Sc3Perm perm;                    // site relabelling of the vectors (the operator arrays handed to init are in it already)
   bool real = false;               // real vectors (DNM_MAT_REAL_PACKED): sc3_lo_pass_r, window pass on the halved tables
   int diag_mode = 0;               // 0: no diagonal terms; 2: on the fly; 1: needs the cached diagonal
   Sc3Op op{};

@@ -919,6 +919,69 @@ sc3_positions_kernel(const Sc3Tab S, int64_t n, const int64_t *__restrict__ idx,
   pos[i] = sc3_pos(st, S) - ioff;
 }
 
+// ---- the same utilities under a site relabelling (Sc3Perm; one rank, whole vectors) -----------------------
+// reference index of a state given in the layout's labelling: back to the reference's spins, then the colex rank
+// (bsubspace_impl.h:191-208)
+__device__ __forceinline__ int64_t ref_index_of(uint64_t s_ref, const Sc3Tab &S) {
+  int64_t idx = 0;
+  int j = 0;
+  const int ld = S.L + 1;
+  while (s_ref) {
+    const int n = __ffsll((long long)s_ref) - 1;
+    ++j;
+    if (j <= n) idx += S.nck[(int64_t)j * ld + n];
+    s_ref &= s_ref - 1;
+  }
+  return idx;
+}
+template <typename V>
+__global__ void __launch_bounds__(256)
+sc3_copy_perm_kernel(const Sc3Tab S, const Sc3Perm P, const uint32_t *__restrict__ rows, V *__restrict__ dst,
+                     const V *__restrict__ src, int to_internal) {
+  const RowId R = decode_row(rows[blockIdx.x], S);
+  const uint64_t hi = sc3_permute((((uint64_t)R.T << S.w) | R.W) << S.a, P.to_ref, S.L);
+  const uint16_t *__restrict__ pat = S.lo_pat + S.lo_off[R.kl];
+  V zero{};
+  for (int r = threadIdx.x; r < R.pitch; r += 256) {
+    if (r < R.nrows) {
+      const int64_t nat = ref_index_of(hi | sc3_permute(pat[r], P.to_ref, S.a), S);
+      if (to_internal) dst[R.base + r] = src[nat];
+      else dst[nat] = src[R.base + r];
+    } else if (to_internal) {
+      dst[R.base + r] = zero;
+    }
+  }
+}
+template <bool REAL>
+__global__ void __launch_bounds__(256)
+sc3_random_perm_kernel(const Sc3Tab S, const Sc3Perm P, const uint32_t *__restrict__ rows, void *__restrict__ xv, uint64_t seed) {
+  const RowId R = decode_row(rows[blockIdx.x], S);
+  const uint64_t hi = sc3_permute((((uint64_t)R.T << S.w) | R.W) << S.a, P.to_ref, S.L);
+  const uint16_t *__restrict__ pat = S.lo_pat + S.lo_off[R.kl];
+  for (int r = threadIdx.x; r < R.pitch; r += 256) {
+    c128 v = make_double2(0.0, 0.0);
+    if (r < R.nrows) v = philox_normal((uint64_t)ref_index_of(hi | sc3_permute(pat[r], P.to_ref, S.a), S), seed);
+    if (REAL) reinterpret_cast<double *>(xv)[R.base + r] = v.x;
+    else reinterpret_cast<c128 *>(xv)[R.base + r] = v;
+  }
+}
+__global__ void __launch_bounds__(256)
+sc3_positions_perm_kernel(const Sc3Tab S, const Sc3Perm P, int64_t n, const int64_t *__restrict__ idx, int64_t *__restrict__ pos) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int64_t *__restrict__ nck = S.nck;
+  const int ld = S.L + 1;
+  int64_t id = idx[i];
+  uint64_t st = 0;
+  int k = S.k;
+  for (int b = S.L; b > 0; --b) {
+    const int64_t here = (k > b - 1) ? 0 : nck[(int64_t)k * ld + (b - 1)];
+    st <<= 1;
+    if (id >= here) { id -= here; --k; st |= 1; }
+  }
+  pos[i] = sc3_pos(sc3_permute(st, P.to_int, S.L), S);
+}
+
 }  // namespace
 
 // ===========================================================================================================
@@ -1134,20 +1197,58 @@ static RowRange row_range(const Sc3Layout &Ly, uint32_t T0, uint32_t T1) {
   return r;
 }
 
-int sc3_layout_copy(const Sc3Layout &Ly, void *dst, const void *src, bool to_internal, hipStream_t st, uint32_t T0, uint32_t T1) {
+bool sc3_perm_make(const int8_t *site_perm, int L, Sc3Perm *out) {
+  *out = Sc3Perm{};
+  out->L = L;
+  for (int i = 0; i < 64; ++i) out->to_int[i] = out->to_ref[i] = (uint8_t)i;
+  if (!site_perm) return true;
+  uint64_t seen = 0;
+  for (int i = 0; i < L; ++i) {
+    const int b = site_perm[i];
+    if (b < 0 || b >= L || ((seen >> b) & 1ull)) return false;
+    seen |= 1ull << b;
+    out->to_int[i] = (uint8_t)b;
+    out->to_ref[b] = (uint8_t)i;
+    if (b != i) out->on = 1;
+  }
+  return true;
+}
+
+// a relabelled layout covers whole vectors on one rank
+static int perm_whole(const Sc3Layout &Ly, const Sc3Perm *perm, const RowRange &r) {
+  DNM_CHECK(!perm || !perm->on || r.count == Ly.rows.size(), "a relabelled SpinConserve layout is not partitioned over ranks");
+  return 0;
+}
+
+int sc3_layout_copy(const Sc3Layout &Ly, void *dst, const void *src, bool to_internal, hipStream_t st, uint32_t T0, uint32_t T1,
+                    const Sc3Perm *perm) {
   DNM_CHECK(Ly.on_device, "layout tables are not on the device");
   const RowRange r = row_range(Ly, T0, T1);
   if (!r.count) return 0;
+  DNM_TRY(perm_whole(Ly, perm, r));
+  if (perm && perm->on) {
+    hipLaunchKernelGGL(sc3_copy_perm_kernel<c128>, dim3((unsigned)r.count), dim3(256), 0, st, Ly.dev, *perm,
+                       (const uint32_t *)Ly.d_rows, (c128 *)dst, (const c128 *)src, to_internal ? 1 : 0);
+    DNM_HIP(hipGetLastError());
+    return 0;
+  }
   hipLaunchKernelGGL(sc3_copy_kernel<c128>, dim3((unsigned)r.count), dim3(256), 0, st, Ly.dev,
                      (const uint32_t *)Ly.d_rows + r.first, (c128 *)dst, (const c128 *)src, to_internal ? 1 : 0, r.ioff, r.noff);
   DNM_HIP(hipGetLastError());
   return 0;
 }
 int sc3_layout_copy_f64(const Sc3Layout &Ly, double *dst, const double *src, bool to_internal, hipStream_t st, uint32_t T0,
-                        uint32_t T1) {
+                        uint32_t T1, const Sc3Perm *perm) {
   DNM_CHECK(Ly.on_device, "layout tables are not on the device");
   const RowRange r = row_range(Ly, T0, T1);
   if (!r.count) return 0;
+  DNM_TRY(perm_whole(Ly, perm, r));
+  if (perm && perm->on) {
+    hipLaunchKernelGGL(sc3_copy_perm_kernel<double>, dim3((unsigned)r.count), dim3(256), 0, st, Ly.dev, *perm,
+                       (const uint32_t *)Ly.d_rows, dst, src, to_internal ? 1 : 0);
+    DNM_HIP(hipGetLastError());
+    return 0;
+  }
   hipLaunchKernelGGL(sc3_copy_kernel<double>, dim3((unsigned)r.count), dim3(256), 0, st, Ly.dev,
                      (const uint32_t *)Ly.d_rows + r.first, dst, src, to_internal ? 1 : 0, r.ioff, r.noff);
   DNM_HIP(hipGetLastError());
@@ -1162,19 +1263,34 @@ int sc3_zero_padding(const Sc3Layout &Ly, void *x, hipStream_t st, uint32_t T0, 
   DNM_HIP(hipGetLastError());
   return 0;
 }
-int sc3_random(const Sc3Layout &Ly, void *x, uint64_t seed, hipStream_t st, uint32_t T0, uint32_t T1) {
+int sc3_random(const Sc3Layout &Ly, void *x, uint64_t seed, hipStream_t st, uint32_t T0, uint32_t T1, const Sc3Perm *perm) {
   DNM_CHECK(Ly.on_device, "layout tables are not on the device");
   const RowRange r = row_range(Ly, T0, T1);
   if (!r.count) return 0;
+  DNM_TRY(perm_whole(Ly, perm, r));
+  if (perm && perm->on) {
+    hipLaunchKernelGGL(sc3_random_perm_kernel<false>, dim3((unsigned)r.count), dim3(256), 0, st, Ly.dev, *perm,
+                       (const uint32_t *)Ly.d_rows, x, seed);
+    DNM_HIP(hipGetLastError());
+    return 0;
+  }
   hipLaunchKernelGGL(sc3_random_kernel, dim3((unsigned)r.count), dim3(256), 0, st, Ly.dev,
                      (const uint32_t *)Ly.d_rows + r.first, (c128 *)x, seed, r.ioff);
   DNM_HIP(hipGetLastError());
   return 0;
 }
-int sc3_random_real(const Sc3Layout &Ly, double *x, uint64_t seed, hipStream_t st, uint32_t T0, uint32_t T1) {
+int sc3_random_real(const Sc3Layout &Ly, double *x, uint64_t seed, hipStream_t st, uint32_t T0, uint32_t T1,
+                    const Sc3Perm *perm) {
   DNM_CHECK(Ly.on_device, "layout tables are not on the device");
   const RowRange r = row_range(Ly, T0, T1);
   if (!r.count) return 0;
+  DNM_TRY(perm_whole(Ly, perm, r));
+  if (perm && perm->on) {
+    hipLaunchKernelGGL(sc3_random_perm_kernel<true>, dim3((unsigned)r.count), dim3(256), 0, st, Ly.dev, *perm,
+                       (const uint32_t *)Ly.d_rows, (void *)x, seed);
+    DNM_HIP(hipGetLastError());
+    return 0;
+  }
   hipLaunchKernelGGL(sc3_random_real_kernel, dim3((unsigned)r.count), dim3(256), 0, st, Ly.dev,
                      (const uint32_t *)Ly.d_rows + r.first, x, seed, r.ioff);
   DNM_HIP(hipGetLastError());
@@ -1189,10 +1305,17 @@ int sc3_unpack_real(const Sc3Layout &Ly, void *dst, const double *src, hipStream
   DNM_HIP(hipGetLastError());
   return 0;
 }
-int sc3_positions(const Sc3Layout &Ly, int64_t n, const int64_t *idx, int64_t *pos, hipStream_t st, uint32_t T0, uint32_t T1) {
+int sc3_positions(const Sc3Layout &Ly, int64_t n, const int64_t *idx, int64_t *pos, hipStream_t st, uint32_t T0, uint32_t T1,
+                  const Sc3Perm *perm) {
   DNM_CHECK(Ly.on_device, "layout tables are not on the device");
   if (n <= 0) return 0;
   const RowRange r = row_range(Ly, T0, T1);
+  DNM_TRY(perm_whole(Ly, perm, r));
+  if (perm && perm->on) {
+    hipLaunchKernelGGL(sc3_positions_perm_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, Ly.dev, *perm, n, idx, pos);
+    DNM_HIP(hipGetLastError());
+    return 0;
+  }
   hipLaunchKernelGGL(sc3_positions_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, Ly.dev, n, idx, pos, r.ioff,
                      r.noff);
   DNM_HIP(hipGetLastError());

@@ -138,6 +138,12 @@ static const Sc3Layout *layout_of(const dnm_subspace *s, bool device) {
   return sc3_get((int)s->L, (int)s->k, a, w, device);
 }
 
+// the descriptor's site relabelling
+static int perm_of(const dnm_subspace *s, Sc3Perm *P) {
+  DNM_CHECK(sc3_perm_make(s->site_perm, (int)s->L, P), "site_perm is not a permutation of the %d spins", (int)s->L);
+  return 0;
+}
+
 // the T blocks of a partition's rank (null: one rank)
 static int part_range(const Sc3Layout &ly, const dnm_partition *part, uint32_t *T0, uint32_t *T1) {
   *T0 = 0;
@@ -175,7 +181,9 @@ int dnm_vec_layout_copy(const dnm_subspace *s, const dnm_partition *part, void *
   if (!ly) return 1;
   uint32_t T0, T1;
   DNM_TRY(part_range(*ly, part, &T0, &T1));
-  return sc3_layout_copy(*ly, dst, src, to_internal != 0, S(stream), T0, T1);
+  Sc3Perm P;
+  DNM_TRY(perm_of(s, &P));
+  return sc3_layout_copy(*ly, dst, src, to_internal != 0, S(stream), T0, T1, &P);
 }
 
 int dnm_vec_layout_copy_f64(const dnm_subspace *s, const dnm_partition *part, double *dst, const double *src,
@@ -185,7 +193,9 @@ int dnm_vec_layout_copy_f64(const dnm_subspace *s, const dnm_partition *part, do
   if (!ly) return 1;
   uint32_t T0, T1;
   DNM_TRY(part_range(*ly, part, &T0, &T1));
-  return sc3_layout_copy_f64(*ly, dst, src, to_internal != 0, S(stream), T0, T1);
+  Sc3Perm P;
+  DNM_TRY(perm_of(s, &P));
+  return sc3_layout_copy_f64(*ly, dst, src, to_internal != 0, S(stream), T0, T1, &P);
 }
 
 int dnm_vec_layout_zero_padding(const dnm_subspace *s, const dnm_partition *part, void *x, void *stream) {
@@ -205,7 +215,9 @@ int dnm_vec_layout_positions(const dnm_subspace *s, const dnm_partition *part, i
   if (!ly) return 1;
   uint32_t T0, T1;
   DNM_TRY(part_range(*ly, part, &T0, &T1));
-  return sc3_positions(*ly, n, idx, pos, S(stream), T0, T1);
+  Sc3Perm P;
+  DNM_TRY(perm_of(s, &P));
+  return sc3_positions(*ly, n, idx, pos, S(stream), T0, T1, &P);
 }
 
 int dnm_vec_layout_positions_host(const dnm_subspace *s, const dnm_partition *part, int64_t n, const int64_t *idx,
@@ -223,9 +235,14 @@ int dnm_vec_layout_positions_host(const dnm_subspace *s, const dnm_partition *pa
   v.k = ly->host.k;
   v.ld = ly->host.L + 1;
   v.nchoosek = ly->host.nck;
+  Sc3Perm P;
+  DNM_TRY(perm_of(s, &P));
+  DNM_CHECK(!P.on || (is == 0 && il == ly->host.nint), "a relabelled SpinConserve layout is not partitioned over ranks");
   for (int64_t i = 0; i < n; ++i) {
     DNM_CHECK(idx[i] >= 0 && idx[i] < nl, "index %lld out of range", (long long)idx[i]);
-    pos[i] = sc3_pos((uint64_t)Sub<DNM_SPIN_CONSERVE>::i2s(idx[i] + ns, v), ly->host) - is;
+    uint64_t st = (uint64_t)Sub<DNM_SPIN_CONSERVE>::i2s(idx[i] + ns, v);
+    if (P.on) st = sc3_permute(st, P.to_int, P.L);
+    pos[i] = sc3_pos(st, ly->host) - is;
   }
   return 0;
 }
@@ -247,7 +264,17 @@ int dnm_vec_layout_set_random(const dnm_subspace *s, const dnm_partition *part, 
   DNM_TRY(part_range(*ly, part, &T0, &T1));
   if (T0 >= T1) return 0;          // a rank that owns no block
   DNM_CHECK(x, "null vector");
-  return sc3_random(*ly, x, seed, S(stream), T0, T1);
+  Sc3Perm P;
+  DNM_TRY(perm_of(s, &P));
+  return sc3_random(*ly, x, seed, S(stream), T0, T1, &P);
+}
+
+int dnm_sc_choose_site_perm(int L, int a, int w, int64_t nmasks, const int64_t *masks, int fix_top, int8_t *site_perm,
+                            int32_t *counts) {
+  DNM_CHECK(site_perm && (nmasks == 0 || masks), "null argument");
+  DNM_CHECK(L >= 1 && L <= 63 && a >= 1 && w >= 1 && L - a - w >= 1, "no such layout: L=%d a=%d w=%d", L, a, w);
+  sc3_choose_perm(L, a, w, nmasks, masks, fix_top != 0, site_perm, counts);
+  return 0;
 }
 
 int dnm_vec_set_random(void *x, int64_t n, uint64_t seed, int64_t offset, void *stream) {

@@ -83,6 +83,14 @@ typedef struct dnm_subspace {
    * SpinConserve multiply works in this layout; dnm_vec_layout_copy / _positions convert.  Partitions hand whole
    * T blocks to a rank (dnm_vec_layout_partition). */
   int32_t vec_swizzle;
+  /* SpinConserve in the internal layout, one rank: NULL, or L entries -- spin i of the reference's labelling is bit
+   * site_perm[i] of the states the layout orders (a relabelling of the spins: the subspace is invariant under it).
+   * dnm_mat_create rewrites the operator into that labelling, so that the pair hops of an operator on a bond graph
+   * (the kagome Heisenberg model of examples/scripts/kagome/run_kagome.py) fall inside the layout's fields wherever
+   * the graph allows; vectors pass through it wherever they meet the reference order (dnm_vec_layout_copy,
+   * _positions, _set_random).  Everything index-wise at this boundary -- rows of dnm_mat_get_diagonal, indices of
+   * dnm_vec_layout_positions, files -- stays in the reference's order.  dnm_sc_choose_site_perm picks one. */
+  const int8_t *site_perm;
 } dnm_subspace;
 
 /* get_dimension_* (bsubspace.pyx:144-162) -> Dim_* */
@@ -91,6 +99,15 @@ int dnm_subspace_dim(const dnm_subspace *s, int64_t *dim);
 int dnm_idx_to_state(const dnm_subspace *s, int64_t n, const int64_t *idxs, int64_t *states);
 /* state_to_idx_* (bsubspace.pyx:186-206) -> S2I_*_array; -1 when not in the subspace */
 int dnm_state_to_idx(const dnm_subspace *s, int64_t n, const int64_t *states, int64_t *idxs);
+
+/* Site relabelling (dnm_subspace.site_perm) for an operator with the distinct masks `masks` on SpinConserve(L, .)
+ * vectors in the (a, w) internal layout: the assignment of spins to the layout's three fields that leaves the fewest
+ * pair hops between fields (host search, deterministic; the identity is kept on ties, so chains stay as they are).
+ * fix_top != 0: spin L-1 keeps bit L-1 (what an XParity subspace on top needs).  counts (6 ints, may be NULL): hops
+ * of the result inside Lo, inside W, inside T, between Lo-W, Lo-T, W-T.  No counterpart in the reference, whose
+ * kernels gather every column (bpetsc_template_2.c:371-412). */
+int dnm_sc_choose_site_perm(int L, int a, int w, int64_t nmasks, const int64_t *masks, int fix_top, int8_t *site_perm,
+                            int32_t *counts);
 
 /* ------------------------------------------------------------------ */
 /* shell matrix -- bpetsc.pyx:78-147, bpetsc_impl.h:42-63             */

@@ -32,12 +32,12 @@ def orc_sub(sub):
     raise TypeError(sub)
 
 
-def shell(H, left, right=None, flags=0):
+def shell(H, left, right=None, flags=0, site_perm=None):
     """ShellMat for (left, right) with explicit flags (bypasses Operator's cache)."""
     right = left if right is None else right
     config._initialize()
     m = marshal(H)
-    return backend.build_mat(*m, left._to_c(), right._to_c(), flags=flags)
+    return backend.build_mat(*m, left._to_c(), right._to_c(), flags=flags, site_perm=site_perm)
 
 
 def vec_from(arr, swz=0, sub_c=None):

@@ -180,3 +180,122 @@ def test_production_instances_vs_oracle(case):
     got = mult_numpy(mat, x)
     assert np.abs(got - want).max() <= tol_for(H, L, x)
     mat.destroy()
+
+
+# ---- site relabelling (dnm_subspace.site_perm) ------------------------------------------------------------
+
+def test_relabelled_layout_round_trip(small_layout):
+    """A vector in a relabelled layout: reference order -> layout -> reference order is the identity, single
+    positions agree with the bulk copy and with the definition (permute the state's bits, then the layout's tables),
+    the seeded random state holds the numbers the reference order would."""
+    import torch
+    from dynamite_amd import backend
+    for L, k, seed in ((11, 5, 0), (13, 6, 1), (14, 3, 2)):
+        sub = SpinConserve(L, k)
+        n = sub.get_dimension()
+        perm = np.random.RandomState(seed).permutation(L).astype(np.int8)
+        d = backend.with_site_perm(sub._c(), perm)
+        v = backend.Vec(n, swz=sub.vec_swizzle, sub_c=d)
+        plain = backend.Vec(n, swz=sub.vec_swizzle, sub_c=sub._c())
+        assert v.perm == tuple(int(b) for b in perm) and plain.perm is None
+        x = rand_state(n, seed=L)
+        v.set_local_from_numpy(x)
+        assert np.array_equal(v.local_numpy(), x)
+        pos = v.positions(torch.arange(n, device=v.array.device)).cpu().numpy()
+        assert len(set(pos.tolist())) == n
+        assert np.array_equal(v.array.cpu().numpy()[pos], x)
+        # the definition: index -> state -> bits moved (spin i -> bit perm[i]) -> position in the plain layout
+        states = orc_sub(sub).i2s(np.arange(n))
+        moved = np.zeros_like(states)
+        for i in range(L):
+            moved |= ((states >> i) & 1) << int(perm[i])
+        idx_moved = orc_sub(sub).s2i(moved)
+        ppos = plain.positions(torch.from_numpy(idx_moved).to(v.array.device)).cpu().numpy()
+        assert np.array_equal(pos, ppos)
+        for i in (0, n // 3, n - 1):
+            assert v.positions(int(i)) == pos[i]
+        v.set_random(7)
+        plain.set_random(7)
+        assert np.array_equal(v.local_numpy(), plain.local_numpy())
+        # vectors of different layouts combine through the reference order
+        assert abs(v.dot(plain) - plain.dot(plain)) < 1e-12 * n
+        w = plain.copy()
+        w.axpby(2.0, 1.0, v)
+        assert np.abs(w.local_numpy() - 3.0 * plain.local_numpy()).max() < 1e-13
+        w2 = backend.Vec(n, swz=sub.vec_swizzle, sub_c=d)
+        plain.copy(w2)
+        assert np.array_equal(w2.local_numpy(), plain.local_numpy())
+
+
+@pytest.mark.parametrize("mode", ["auto", "random", "off"])
+def test_relabelled_multiply_vs_oracle(small_layout, mode):
+    """The same operator in the layout the chooser picks, in a random relabelling and without one: all equal the
+    oracle; the chosen relabelling has no more gathered hops than the identity."""
+    from dynamite_amd import backend
+    L, k = 14, 7
+    H = pair_graph(L, seed=77, nbonds=24, complex_hops=True)
+    sub = SpinConserve(L, k)
+    x = rand_state(sub.get_dimension(), seed=8)
+    want = orc.matvec(orc_msc(H), orc_sub(sub), orc_sub(sub), x)
+    sp = {"auto": None, "off": False, "random": np.random.RandomState(5).permutation(L).astype(np.int8)}[mode]
+    mat = shell(H, sub, site_perm=sp)
+    assert (mat.perm_left is None) == (mode == "off")
+    if mat.uses_cached_diagonal():
+        mat.precompute_diagonal()
+    assert np.abs(mult_numpy(mat, x) - want).max() <= tol_for(H, L, x), mat.describe()
+    # a state in the subspace's own layout goes through the conversion of ShellMat.mult
+    from gpu_util import vec_for
+    xv, yv = vec_for(sub), vec_for(sub)
+    xv.set_local_from_numpy(x)
+    mat.mult(xv, yv)
+    assert np.abs(yv.local_numpy() - want).max() <= tol_for(H, L, x)
+    # the diagonal is handed out in reference order whatever the layout
+    from dynamite_amd import _lib
+    if mat.uses_cached_diagonal():
+        got = np.empty(sub.get_dimension())
+        _lib.check(_lib.lib().dnm_mat_get_diagonal(mat.handle, _lib.pf64(got), backend._stream()))
+        assert np.abs(got - orc.precompute_diagonal(orc_msc(H), orc_sub(sub))).max() < 1e-12
+    if mode == "auto":
+        def gathered(m):
+            d = m.describe()
+            import re
+            return sum(int(v) for v in re.findall(r"(\d+) gathered", d))
+        ident = shell(H, sub, site_perm=False)
+        assert gathered(mat) <= gathered(ident)
+        ident.destroy()
+    mat.destroy()
+
+
+def test_kagome_solvers_in_the_relabelled_layout(small_layout):
+    """eigsolve and evolve on the 12-site kagome torus (the flow of run_kagome.py:51-77 without XParity): eigenvalues
+    against the reference-built matrix (tests/golden/kagome.npz), eigenvectors and evolved states -- handed back as
+    states of the subspace -- against the oracle's multiply."""
+    from dynamite_amd.states import State
+    g = np.load(os.path.join(GOLDEN, "kagome.npz"))
+    H = models.kagome("12")
+    sub = SpinConserve(12, 6)
+    H.add_subspace(sub)
+    mat = H.get_mat(subspaces=(sub, sub))
+    assert mat.perm_left is not None and "bond graph" in mat.describe()
+    vals, vecs = H.eigsolve(nev=2, getvecs=True, subspace=sub, tol=1e-12)
+    assert np.abs(vals[:2] - g["kagome_12_sc/evals_lowest"][:2]).max() < 1e-10
+    for lam, v in zip(vals[:1], vecs[:1]):
+        xv = v.to_numpy()
+        Hx = orc.matvec(orc_msc(H), orc_sub(sub), orc_sub(sub), xv)
+        assert np.linalg.norm(Hx - lam * xv) < 1e-9
+        assert abs(v.norm() - 1.0) < 1e-12
+    psi = State(L=12, subspace=sub, state='random', seed=3)
+    x0 = psi.to_numpy()
+    out = H.evolve(psi, t=0.7)
+    import scipy.sparse.linalg as spla
+    import scipy.sparse as sp
+    n = sub.get_dimension()
+    cols = np.eye(n, dtype=np.complex128)
+    A = np.stack([orc.matvec(orc_msc(H), orc_sub(sub), orc_sub(sub), cols[:, j].copy()) for j in range(n)], axis=1)
+    want = spla.expm_multiply(-0.7j * sp.csc_matrix(A), x0)
+    got = out.to_numpy()
+    assert abs(1 - np.vdot(want, got) / np.vdot(got, got)) < 1e-9
+    y = H.dot(psi)                       # a state of the subspace's own layout through Operator.dot
+    assert np.abs(y.to_numpy() - A @ x0).max() < 1e-12
+    assert abs(psi.dot(out) - np.vdot(out.to_numpy(), x0)) < 1e-12
+    H.destroy_mat()
