@@ -320,12 +320,24 @@ class Vec:
         self.rows = self.local_size              # elements of the vector this rank holds
         self.istart = self.start                 # where this rank's part starts in the layout's own index space
         self._part = None
+        self.half = False
         if self.internal:
             if sub_c is None:
                 raise ValueError('a vector in the SpinConserve internal layout needs its subspace descriptor')
-            # whole blocks of equal top bits per rank: a contiguous range of the layout and of the reference order
-            self._part = _lib.Partition(config.rank, config.world_size)
-            self.istart, self.local_size, self.start, self.rows = layout_partition(sub_c, config.world_size, config.rank)
+            full = C.c_int64()
+            _lib.check(_lib.lib().dnm_subspace_dim(C.byref(sub_c), C.byref(full)))
+            if 2 * self.size == full.value and config.world_size == 1:
+                # an XParity vector on top of the subspace: the representatives are the states whose spin L-1 is up --
+                # the blocks of the layout whose top bit is clear, its first half (what rank 0 of 2 would own)
+                self.half = True
+                self._part = _lib.Partition(0, 2)
+                self.istart, self.local_size, self.start, self.rows = layout_partition(sub_c, 2, 0)
+                if self.rows != self.size:
+                    raise ValueError('the layout does not split into halves for this subspace')
+            else:
+                # whole blocks of equal top bits per rank: a contiguous range of the layout and of the reference order
+                self._part = _lib.Partition(config.rank, config.world_size)
+                self.istart, self.local_size, self.start, self.rows = layout_partition(sub_c, config.world_size, config.rank)
         if array is None:
             array = device_zeros(self.local_size)
         elif array.numel() != self.local_size:
@@ -1258,8 +1270,10 @@ def _relabelled(masks, lc, rc, xparity, site_perm):
     """The descriptors a SpinConserve pair in the internal layout is built on: with a site relabelling
     (dnm_subspace.site_perm) when the operator's bond graph gains from one -- ``site_perm``: None = choose
     (dnm_sc_choose_site_perm; the identity for chains), False = never, an array = that one.  One rank, same subspace on
-    both sides, no XParity on top; everything else keeps the descriptors as they are."""
-    if site_perm is False or xparity or config.world_size != 1 or not config.sc_site_perm:
+    both sides (XParity on top of it: spin L-1 stays); everything else keeps the descriptors as they are."""
+    if site_perm is False or config.world_size != 1 or not config.sc_site_perm:
+        return lc, rc
+    if xparity and 2 * int(lc.k) != int(lc.L):
         return lc, rc
     if not (lc.type == 3 and rc.type == 3 and lc.L == rc.L and lc.k == rc.k and lc.vec_swizzle >= 256
             and lc.vec_swizzle == rc.vec_swizzle and not lc.site_perm and not rc.site_perm):
@@ -1267,7 +1281,8 @@ def _relabelled(masks, lc, rc, xparity, site_perm):
     L = int(lc.L)
     if site_perm is None:
         a, w = lc.vec_swizzle & 0xff, (lc.vec_swizzle >> 8) & 0xff
-        site_perm, _ = choose_site_perm(np.unique(np.asarray(masks, dtype=np.int64)), L, a, w)
+        # (XParity on top: spin L-1 -- the one that tells a representative from its mirror image -- keeps its place)
+        site_perm, _ = choose_site_perm(np.unique(np.asarray(masks, dtype=np.int64)), L, a, w, fix_top=bool(xparity))
     site_perm = np.ascontiguousarray(site_perm, dtype=np.int8)
     if np.array_equal(site_perm, np.arange(L)):
         return lc, rc

@@ -48,6 +48,9 @@ class _Config:
         # operators on a bond graph in such a subspace (one rank): relabel the spins so that as many pair hops as the
         # graph allows fall inside the layout's fields (backend._relabelled, csrc/sc3_perm.cpp); chains keep the identity
         self.sc_site_perm = knob('DNM_SC_SITE_PERM', '1') != '0'
+        # XParity on top of a SpinConserve subspace in the internal layout: its vectors are the layout's first half
+        # (one rank); DNM_SC_XPARITY_LAYOUT=0 keeps them in reference order (the row kernels)
+        self.sc_xparity_layout = knob('DNM_SC_XPARITY_LAYOUT', '1') != '0'
         # eigsolve of a real-symmetric operator (every matrix element real in the product basis): real arithmetic on
         # vectors stored two amplitudes to a complex128 element (Full / Parity, on a power-of-two number of ranks) or one
         # double per position of the internal layout (SpinConserve, any rank count) -- DNM_MAT_REAL_PACKED, half the

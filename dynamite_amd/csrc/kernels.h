@@ -49,8 +49,10 @@ int launch_gather_matvec(const DevMsc &msc, const SubView &left, const SubView &
 // bond of two adjacent spins (3 << lo) whose sign masks all lie inside the bond,
 // so the matrix element takes one of two values: `up` when the down spin moves
 // from site lo to lo+1 (ket has bit lo set), `dn` for the opposite hop.
-// pair != 0: the same for any two spins lo < hi (`up`: the ket has bit lo set, the down spin moves to hi); dead != 0:
-// the mask flips an odd number of spins and never keeps a state in the subspace.
+// pair == 1: the same for any two spins lo < hi (`up`: the ket has bit lo set, the down spin moves to hi); pair == 2
+// (XParity on top, subspaces.py:632-674): the hop between spin lo and spin L-1 composed with the global flip -- the
+// mask is every spin but those two, it acts on a representative (spin L-1 up) iff spin lo is down, with the element
+// `up`; dead != 0: the mask flips an odd number of spins and never keeps a state in the subspace.
 struct ScMask {
   int32_t fast;
   int32_t lo;
@@ -59,7 +61,8 @@ struct ScMask {
 };
 // the table for an operator (host arrays as dnm_mat keeps them)
 std::vector<ScMask> sc_masks(const std::vector<int64_t> &masks, const std::vector<int64_t> &mask_offsets,
-                             const std::vector<int64_t> &signs, const std::vector<double> &rcoef);
+                             const std::vector<int64_t> &signs, const std::vector<double> &rcoef, int L = 0,
+                             bool xparity = false);
 
 // SpinConserve(L,k) on both sides: columns by incremental colex rank (row + delta)
 // rows [row0, row0+M); xw holds columns [win_start, ...); y / diag are local.  colrange != null:

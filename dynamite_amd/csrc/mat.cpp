@@ -490,13 +490,33 @@ using namespace dnm;
 
 namespace dnm {
 std::vector<ScMask> sc_masks(const std::vector<int64_t> &masks, const std::vector<int64_t> &mask_offsets,
-                             const std::vector<int64_t> &signs, const std::vector<double> &rcoef) {
+                             const std::vector<int64_t> &signs, const std::vector<double> &rcoef, int L, bool xparity) {
   std::vector<ScMask> scm(masks.size());
   for (size_t mi = 0; mi < masks.size(); ++mi) {
     ScMask &e = scm[mi];
     memset(&e, 0, sizeof(e));
     const uint64_t mask = (uint64_t)masks[mi];
     e.dead = __builtin_popcountll(mask) & 1;
+    if (xparity && L >= 3 && __builtin_popcountll(mask) == L - 2 && !((mask >> (L - 1)) & 1ull)) {
+      // a hop between spin i and spin L-1 times the global flip (XParity.reduce_msc): every spin but those two
+      const uint64_t miss = ~mask & ((((uint64_t)1 << (L - 1)) - 1));
+      const int i = __builtin_ctzll(miss);
+      const uint64_t pairbits = ((uint64_t)1 << i) | ((uint64_t)1 << (L - 1));
+      bool local = true;
+      for (int64_t t = mask_offsets[mi]; t < mask_offsets[mi + 1]; ++t)
+        if ((uint64_t)signs[t] & ~pairbits) local = false;
+      if (!local) continue;
+      e.pair = 2;
+      e.lo = i;
+      e.hi = L - 1;
+      for (int64_t t = mask_offsets[mi]; t < mask_offsets[mi + 1]; ++t) {
+        // the column state keeps spin i down and spin L-1 up; the sign masks do not meet the mask: a real element
+        const double c = (((uint64_t)signs[t] >> i) & 1) ? -rcoef[t] : rcoef[t];
+        e.up_re += c;
+        e.dn_re += c;
+      }
+      continue;
+    }
     if (__builtin_popcountll(mask) != 2) continue;
     const int lo = __builtin_ctzll(mask), hi = 63 - __builtin_clzll(mask);
     bool local = true;
@@ -836,11 +856,16 @@ int dnm_mat_create(int64_t nmasks, const int64_t *masks, const int64_t *mask_off
   // SpinConserve pair whose vectors are in the internal layout: the two-pass / row kernels of sc3_kernels.hip.  Any
   // other use of such a subspace (another partner, XParity, several ranks) works in reference order: the caller
   // converts (dnm_mat_layouts tells).
-  A->use_sc3 = A->sc_pair && A->left.host.sc3 != 0 && A->left.host.sc3 == A->right.host.sc3 && !A->xparity &&
-               A->left.host.L == A->right.host.L;
+  // (XParity on top: one rank, half filling -- the vectors are the blocks whose top bit is clear, the first half of the
+  // layout as of the reference order)
+  A->use_sc3 = A->sc_pair && A->left.host.sc3 != 0 && A->left.host.sc3 == A->right.host.sc3 &&
+               A->left.host.L == A->right.host.L &&
+               (!A->xparity || (A->nranks == 1 && 2 * A->left.host.k == A->left.host.L &&
+                                sc3_instance(sc3_code_a(A->left.host.sc3), sc3_code_w(A->left.host.sc3))));
 
   std::vector<ScMask> scm;
-  if (lt == DNM_SPIN_CONSERVE && rt == DNM_SPIN_CONSERVE) scm = sc_masks(A->masks, A->mask_offsets, A->signs, A->real_coeffs);
+  if (lt == DNM_SPIN_CONSERVE && rt == DNM_SPIN_CONSERVE)
+    scm = sc_masks(A->masks, A->mask_offsets, A->signs, A->real_coeffs, A->left.host.L, A->xparity);
   // tables for the generic kernels (always: norm and diagonal use them)
   if (!A->host_only) {
   DNM_TRY(A->d_masks.upload(A->masks.data(), A->masks.size() * 8));
@@ -876,7 +901,8 @@ int dnm_mat_create(int64_t nmasks, const int64_t *masks, const int64_t *mask_off
     DNM_CHECK(ly, "could not build the SpinConserve vector layout");
     A->sc3.reset(new Sc3Mat());
     // partitioned: whole T blocks per rank (a contiguous range of both the internal layout and the reference order)
-    const std::vector<uint32_t> Tb = sc3_partition(*ly, A->nranks);
+    std::vector<uint32_t> Tb = sc3_partition(*ly, A->nranks);
+    if (A->xparity) Tb = {0u, 1u << (ly->host.t - 1)};
     const bool want_real = (flags & DNM_MAT_REAL_PACKED) != 0;
     // site relabelling of the vectors (dnm_subspace.site_perm): the kernels of the layout see the operator in it
     Sc3Perm P, Pr;
@@ -884,6 +910,7 @@ int dnm_mat_create(int64_t nmasks, const int64_t *masks, const int64_t *mask_off
               "site_perm is not a permutation of the %d spins", h.L);
     DNM_CHECK(memcmp(P.to_int, Pr.to_int, sizeof P.to_int) == 0, "left and right vectors must share their site relabelling");
     DNM_CHECK(!P.on || A->nranks == 1, "a relabelled SpinConserve layout is not partitioned over ranks");
+    DNM_CHECK(!A->xparity || P.to_int[h.L - 1] == h.L - 1, "XParity: the site relabelling must keep spin L-1 in place");
     A->sc3->perm = P;
     std::vector<int64_t> pmasks = A->masks, poffs = A->mask_offsets, psigns = A->signs;
     std::vector<double> pcoef = A->real_coeffs;
@@ -908,7 +935,7 @@ int dnm_mat_create(int64_t nmasks, const int64_t *masks, const int64_t *mask_off
         }
         poffs.push_back((int64_t)psigns.size());
       }
-      scm = sc_masks(pmasks, poffs, psigns, pcoef);
+      scm = sc_masks(pmasks, poffs, psigns, pcoef, h.L, A->xparity);
       if (!A->host_only) {           // the row kernel's tables in the layout's labelling
         DNM_TRY(A->d_pmasks.upload(pmasks.data(), pmasks.size() * 8));
         DNM_TRY(A->d_poffsets.upload(poffs.data(), poffs.size() * 8));

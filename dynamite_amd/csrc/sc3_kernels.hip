@@ -1216,7 +1216,10 @@ bool sc3_perm_make(const int8_t *site_perm, int L, Sc3Perm *out) {
 
 // a relabelled layout covers whole vectors on one rank
 static int perm_whole(const Sc3Layout &Ly, const Sc3Perm *perm, const RowRange &r) {
-  DNM_CHECK(!perm || !perm->on || r.count == Ly.rows.size(), "a relabelled SpinConserve layout is not partitioned over ranks");
+  // (whole vectors, or the blocks below a bound -- the half whose top bit is clear, an XParity vector: both start at
+  // position 0 of the layout and at index 0 of the reference order)
+  DNM_CHECK(!perm || !perm->on || (r.first == 0 && r.ioff == 0 && r.noff == 0),
+            "a relabelled SpinConserve layout is not partitioned over ranks");
   return 0;
 }
 
@@ -1523,7 +1526,7 @@ int Sc3Mat::init(const Sc3Layout *layout, const std::vector<int64_t> &masks, con
       h.mT = (uint32_t)(mk >> (a + w));
       h.half = __builtin_popcountll(mk) / 2;
       const int fi = field(scm[m].lo), fj = field(scm[m].hi);
-      h.dfield = fi;
+      h.dfield = scm[m].pair == 2 ? 3 : fi;      // (the flip-composed hops of XParity act one way only)
       h.dbit = scm[m].lo - fstart(fi);
       h.up_re = scm[m].up_re; h.up_im = scm[m].up_im; h.dn_re = scm[m].dn_re; h.dn_im = scm[m].dn_im;
       part[fi == 0 ? (fj == 0 ? 0 : 1) : (fi == 1 && fj == 1 ? 2 : 3)].push_back(h);

@@ -41,7 +41,10 @@ void sc3_choose_perm(int L, int a, int w, int64_t nmasks, const int64_t *masks, 
   std::vector<std::vector<int>> adj(L);
   std::vector<std::pair<int, int>> bonds;
   for (int64_t m = 0; m < nmasks; ++m) {
-    const uint64_t mk = (uint64_t)masks[m];
+    uint64_t mk = (uint64_t)masks[m];
+    // (under XParity a hop that touches spin L-1 comes composed with the global flip: every spin but the pair)
+    if (fix_top && L >= 3 && __builtin_popcountll(mk) == L - 2 && !((mk >> (L - 1)) & 1ull))
+      mk = ~mk & (((uint64_t)1 << L) - 1);
     if (__builtin_popcountll(mk) != 2) continue;
     const int i = __builtin_ctzll(mk), j = 63 - __builtin_clzll(mk);
     if (j >= L) continue;

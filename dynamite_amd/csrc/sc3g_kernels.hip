@@ -34,6 +34,7 @@ struct HopEval {
   double c0, c1;
   int need;
   uint32_t xm;
+  int rev;
 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -98,7 +99,7 @@ sc3g_lo_pass(const Sc3Tab S, const Sc3Op O, const uint32_t *__restrict__ perm, c
   }
   // gathered hops, one per lane: spin i in Lo, spin j in W or T.  The hop couples this row to ONE other row (T', W');
   // it acts on the entries whose Lo bit has the value the row's bit j leaves open.
-  HopEval g{0, 0, 0.0, 0.0, 0, 0u};
+  HopEval g{0, 0, 0.0, 0.0, 0, 0u, 0};
   if (lane < O.ngatA) {
     const Sc3Hop h = O.gatA[lane];
     const uint32_t T2 = T ^ h.mT, W2 = W ^ h.mW;
@@ -371,20 +372,24 @@ sc3g_win_pass(const Sc3Tab S, const Sc3Op O, const uint32_t *__restrict__ perm, 
   }
   // gathered hops, one per lane: both spins in T (a uniform offset), or spin i in W and spin j in T (the rows of the
   // partner class by rank, the columns as they are)
-  HopEval g{0, 0, 0.0, 0.0, 0, 0u};
+  // (XParity's flip-composed hops complement all of Lo: the partner column is the row's column counted from the
+  // other end -- the complement reverses the order of the patterns)
+  HopEval g{0, 0, 0.0, 0.0, 0, 0u, 0};
   if (lane < O.ngatB) {
     const Sc3Hop h = O.gatB[lane];
     const uint32_t T2 = T ^ h.mT;
-    const int nd = h.half - __popc(T & h.mT);
+    const bool flip_lo = h.mLo != 0u;
+    const int nd = h.half - __popc(T & h.mT) - (flip_lo ? kl : 0);
     const int nwm = __popc(h.mW);
     const int kr2 = S.k - __popc(T2), cw2 = cw + nwm - 2 * nd, kl2 = kr2 - cw2;
-    if (nd >= 0 && nd <= nwm && cw2 >= 0 && cw2 <= WB && kl2 == kl) {
+    if (nd >= 0 && nd <= nwm && cw2 >= 0 && cw2 <= WB && kl2 == (flip_lo ? S.a - kl : kl)) {
       const int64_t tb2 = S.ibase[T2];
       if (tb2 >= 0) {
         g.act = 1;
         g.delta = tb2 + S.icoff[kr2 * (WB + 1) + cw2] - own;
         g.need = nd;
         g.xm = h.mW;
+        g.rev = flip_lo ? 1 : 0;
         const bool up = h.dfield == 3 || (h.dfield == 1 ? nd == 1 : ((T >> h.dbit) & 1u) != 0);
         g.c0 = up ? h.up_re : h.dn_re;
         g.c1 = up ? h.up_im : h.dn_im;
@@ -432,8 +437,18 @@ sc3g_win_pass(const Sc3Tab S, const Sc3Op O, const uint32_t *__restrict__ perm, 
     const double cr = rl_f64(g.c0, m), ci = rl_f64(g.c1, m);
     const int nd = rl_i32(g.need, m);
     const uint32_t xm = (uint32_t)rl_i32((int)g.xm, m);
+    const int rev = rl_i32(g.rev, m);
     c128 v[RPT];
-    if (xm == 0u) {                // both spins in T: every entry, the same offset
+    if (rev) {                     // rows by rank, columns from the other end of the row
+      const int last = S.nl[kl] - 1 - lr0;            // column of the partner of this run's first column, from cbase - lr0
+#pragma unroll
+      for (int i = 0; i < RPT; ++i) {
+        v[i] = make_double2(0.0, 0.0);
+        const uint32_t wp = wpat[i] & WM;
+        const int wrr = (int)(wpat[i] >> 16), j = off[i] - wrr * p;
+        if (off[i] >= 0 && j <= last && __popc(wp & xm) == nd) v[i] = pp[(int)wrk[wp ^ xm] * p + last - j - lr0];
+      }
+    } else if (xm == 0u) {         // both spins in T: every entry, the same offset
 #pragma unroll
       for (int i = 0; i < RPT; ++i) {
         v[i] = make_double2(0.0, 0.0);

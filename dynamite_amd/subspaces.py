@@ -567,13 +567,34 @@ class XParity(Subspace):
         return self.parent.state_to_idx(state)
 
     def _c(self):
-        return self.parent._c()
+        """The parent's descriptor -- with this subspace's own vector layout where the two differ (a SpinConserve
+        parent in the internal layout whose XParity vectors stay in reference order: several ranks, a knob)."""
+        d = self.parent._c()
+        if int(d.vec_swizzle) == self.vec_swizzle:
+            return d
+        from . import _lib
+        if self._cdesc is None or self._cdesc.vec_swizzle != self.vec_swizzle or self._cdesc._parent_desc is not d:
+            c = _lib.Subspace.from_buffer_copy(d)
+            c.vec_swizzle = self.vec_swizzle
+            c._parent_desc = d            # (the copy points into the parent's tables)
+            self._cdesc = c
+        return self._cdesc
 
     def _to_c(self):
-        return self.parent._to_c()
+        return {'type': self.parent._enum, 'data': self._c()}
 
     @property
     def vec_swizzle(self):
         # an XParity vector is the first half of the parent's in reference order: Full / Parity parents keep their
-        # swizzle (it acts on the local index), a SpinConserve parent's internal layout does not apply
-        return 0 if isinstance(self.parent, SpinConserve) else self.parent.vec_swizzle
+        # swizzle (it acts on the local index); of a SpinConserve parent's internal layout it is the first half as well
+        # (the blocks whose top bit is clear) -- on one rank, where the bond-graph passes of csrc/sc3g_kernels.hip apply
+        # the flip-composed hops; several ranks keep reference order
+        if isinstance(self.parent, SpinConserve):
+            from .config import config
+            code = self.parent.vec_swizzle
+            if config.world_size != 1 or not config.sc_xparity_layout or code < 256:
+                return 0
+            from . import _lib
+            a, w = code & 0xff, (code >> 8) & 0xff
+            return code if (a, w) in ((14, 10), (6, 4)) else 0
+        return self.parent.vec_swizzle

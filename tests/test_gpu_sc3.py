@@ -241,9 +241,15 @@ def test_projection_pairs_convert(small_layout):
     want2 = orc.matvec(orc_msc(H), orc_sub(sub), orc_sub(full), got)
     assert np.abs(y2.local_numpy() - want2).max() < 1e-11
     mat.destroy(); mat2.destroy()
-    # XParity on top of the subspace keeps reference order
+    # XParity on top of the subspace: the first half of the layout (tests/test_gpu_sc3_graph.py), or reference order
     xp = XParity(SpinConserve(L, k), '+')
-    assert xp.vec_swizzle == 0 and not State(L=L, subspace=xp, state='random', seed=1).vec.internal
+    v = State(L=L, subspace=xp, state='random', seed=1).vec
+    assert xp.vec_swizzle == sub.vec_swizzle and v.internal and v.half and v.rows == sub.get_dimension() // 2
+    config.sc_xparity_layout = False
+    try:
+        assert xp.vec_swizzle == 0 and not State(L=L, subspace=xp, state='random', seed=1).vec.internal
+    finally:
+        config.sc_xparity_layout = True
 
 
 @pytest.mark.parametrize("L,k,name", [(25, 12, "mbl"), (26, 13, "dm"), (26, 11, "heisenberg")])

@@ -299,3 +299,74 @@ def test_kagome_solvers_in_the_relabelled_layout(small_layout):
     assert np.abs(y.to_numpy() - A @ x0).max() < 1e-12
     assert abs(psi.dot(out) - np.vdot(out.to_numpy(), x0)) < 1e-12
     H.destroy_mat()
+
+
+# ---- XParity on top (the default of run_kagome.py:51-66) ---------------------------------------------------
+
+def _xparity_case(H, L, sector, seed=0):
+    """(multiply in the layout's first half, the same through reference-order vectors and the row kernels)"""
+    from dynamite_amd.states import State
+    from dynamite_amd.subspaces import XParity
+    outs = []
+    for layout in (True, False):
+        config.sc_xparity_layout = layout
+        try:
+            sub = XParity(SpinConserve(L, L // 2), sector)
+            Hc = H.copy()
+            Hc.add_subspace(sub)
+            x = State(L=L, subspace=sub, state='random', seed=seed)
+            assert x.vec.internal == layout
+            y = Hc.dot(x)
+            outs.append((x.to_numpy(), y.to_numpy(), Hc.get_mat(subspaces=(sub, sub)).describe()))
+            Hc.destroy_mat()
+        finally:
+            config.sc_xparity_layout = True
+    return outs
+
+
+@pytest.mark.parametrize("sector", ['+', '-'])
+@pytest.mark.parametrize("kind", ["kagome12", "graph14", "chain14"])
+def test_xparity_in_the_layout(small_layout, kind, sector):
+    """XParity(SpinConserve(L, L/2)): the hops that touch spin L-1 come composed with the global flip (every spin but
+    the pair flipped, subspaces.py:632-674).  In the layout's first half they are gathered hops with the Lo pattern's
+    rank taken after the complement (lo pass) or the columns counted from the other end (window pass).  Against the
+    reference-order kernels, and for the 12-site kagome torus against the reference's own reduced matrix."""
+    if kind == "kagome12":
+        H, L = models.kagome("12"), 12
+    elif kind == "graph14":
+        H, L = pair_graph(14, seed=21, nbonds=30, complex_hops=False, fields=False), 14
+    else:
+        H, L = models.heisenberg(14), 14
+    (x1, y1, d1), (x2, y2, d2) = _xparity_case(H, L, sector)
+    assert "bond graph" in d1 and "internal layout" in d1, d1
+    assert "internal layout" not in d2
+    assert np.array_equal(x1, x2)                 # the seeded state is the same in both layouts
+    assert np.abs(y1 - y2).max() <= 1e-12 * max(1.0, np.abs(y2).max()), d1
+    if kind == "kagome12":
+        from dynamite_amd.states import State
+        from dynamite_amd.subspaces import XParity
+        g = np.load(os.path.join(GOLDEN, "kagome.npz"))
+        pre = "kagome_12_sc_xparity_%s/" % ("plus" if sector == '+' else "minus")
+        sub = XParity(SpinConserve(12, 6), sector)
+        H.add_subspace(sub)
+        x = State(L=12, subspace=sub)
+        x.vec.set_local_from_numpy(g[pre + "x"])
+        x.set_initialized()
+        y = H.dot(x)
+        assert np.abs(y.to_numpy() - g[pre + "y"]).max() <= 1e-12
+        vals = H.eigsolve(nev=2, subspace=sub, tol=1e-12)
+        # (the '-' sector's lowest level is doubly degenerate on this torus: a Krylov space from one start vector holds
+        # one copy of it, as SLEPc's would -- the second value returned is the next level)
+        want = g[pre + "evals_lowest"]
+        assert abs(vals[0] - want[0]) < 1e-10 and np.abs(want - vals[1]).min() < 1e-10
+        H.destroy_mat()
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_fuzz_xparity_pair_graphs(small_layout, seed):
+    rs = np.random.RandomState(300 + seed)
+    L = int(rs.choice([12, 14]))
+    H = pair_graph(L, seed=50 + seed, nbonds=int(rs.randint(4, 40)), complex_hops=False, fields=False)
+    (x1, y1, d1), (x2, y2, d2) = _xparity_case(H, L, '+' if seed & 1 else '-', seed=seed)
+    assert "bond graph" in d1, d1
+    assert np.abs(y1 - y2).max() <= 1e-12 * max(1.0, np.abs(y2).max()), d1
