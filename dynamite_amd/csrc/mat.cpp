@@ -965,8 +965,10 @@ int dnm_mat_create(int64_t nmasks, const int64_t *masks, const int64_t *mask_off
       // Partitions: every position the C ABI speaks of for such a handle -- ownership, column windows, chunk maps,
       // window starts -- counts complex128 ELEMENTS (pairs of entries; blocks of equal top bits start at multiples of 8
       // entries), so the caller's exchange code is the one it runs for complex vectors, on half the bytes
-      DNM_CHECK(A->sc3->tiled && !A->sc3->graph && A->sc3->sym && A->sc3->diag_mode != 1,
-                "operator has an imaginary matrix element or is not a chain: no real-packed form in this layout");
+      // (XParity's flip-composed hops read their columns backwards: the window pass on pairs of entries cannot)
+      DNM_CHECK(A->sc3->tiled && A->sc3->sym && !A->xparity,
+                "operator has an imaginary matrix element, is not a sum of pair hops, or lives under XParity: no "
+                "real-packed form in this layout");
       A->real_packed = true;
       A->m_local = A->n_local = il / 2;
     }
@@ -1095,7 +1097,8 @@ static int sc3_mult(dnm_mat *A, const void *x, void *y, const void *z, double b,
 
 int dnm_mat_precompute_diagonal(dnm_mat *A, void *stream) {
   DNM_CHECK(A && !A->host_only, "null or host-only matrix");
-  DNM_CHECK(!A->real_packed, "real-packed operators evaluate their diagonal on the fly: nothing to precompute");
+  DNM_CHECK(!A->real_packed || (A->use_sc3 && A->sc3->diag_mode == 1),
+            "this real-packed operator evaluates its diagonal on the fly: nothing to precompute");
   // only when the first mask is the identity (bpetsc_template_1.c:177-180) and
   // left == right (operators.py:627-629; the caller guarantees it)
   if (A->masks.empty() || A->masks[0] != 0) return 0;
@@ -1107,7 +1110,8 @@ int dnm_mat_precompute_diagonal(dnm_mat *A, void *stream) {
     DevBuf nat;
     DNM_TRY(nat.alloc((size_t)A->rows_local * sizeof(double)));
     DNM_TRY(launch_diag(A->dmsc, A->right.dev, A->rows_local, A->row0, (double *)nat.p, S(stream)));
-    DNM_TRY(A->diag.alloc((size_t)A->m_local * sizeof(double)));
+    // (one double per position of the layout; a real-packed handle counts its vectors in pairs of positions)
+    DNM_TRY(A->diag.alloc((size_t)A->m_local * (A->real_packed ? 2 : 1) * sizeof(double)));
     DNM_TRY(sc3_layout_copy_f64(*A->sc3->ly, (double *)A->diag.p, (const double *)nat.p, true, S(stream), A->sc3->T0,
                                 A->sc3->T1, &A->sc3->perm));
     DNM_HIP(hipStreamSynchronize(S(stream)));      // `nat` is released on return

@@ -1693,11 +1693,12 @@ static int launch_two_pass(const Sc3Mat &M, const Sc3Call &call, const double *c
   if (M.real) {
     // real vectors: the window pass is the complex kernel on the halved tables (pairs of entries as elements: every
     // offset it forms is even), the lo pass its own kernel on doubles
-    DNM_CHECK(M.sym && dm != 1, "internal: real vectors need a real operator with the diagonal on the fly");
+    DNM_CHECK(M.sym, "internal: real vectors need a real operator");
     using kern_r = void (*)(const Sc3Tab, const Sc3Op, const uint32_t *, const Sc3Call, const double *, double *);
     kern_r kR = nullptr;
     constexpr int NTR = sc3r_threads(NT), PPR = sc3r_pairs(A, NT);
     if (dm == 0) kR = lo_first ? (kern_r)sc3_lo_pass_r<A, NTR, PPR, 0, false> : (kern_r)sc3_lo_pass_r<A, NTR, PPR, 0, true>;
+    else if (dm == 1) kR = lo_first ? (kern_r)sc3_lo_pass_r<A, NTR, PPR, 1, false> : (kern_r)sc3_lo_pass_r<A, NTR, PPR, 1, true>;
     else kR = lo_first ? (kern_r)sc3_lo_pass_r<A, NTR, PPR, 2, false> : (kern_r)sc3_lo_pass_r<A, NTR, PPR, 2, true>;
     constexpr size_t ldsR = (size_t)sc3_lo_cap_r(A, NT) * 8;
     if (!attr_done[(const void *)kR]) {

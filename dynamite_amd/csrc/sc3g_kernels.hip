@@ -314,6 +314,244 @@ sc3g_lo_pass(const Sc3Tab S, const Sc3Op O, const uint32_t *__restrict__ perm, c
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// lo pass on REAL vectors (DNM_MAT_REAL_PACKED): x and y are arrays of doubles in the same positions of the layout; a
+// thread owns PAIRS of adjacent row entries, the tile in LDS is an array of doubles -- the shape of sc3_lo_pass_r
+// (sc3_kernels.hip) with the hop tables of this file.  Real operators have equal `up` and `dn` elements.
+template <int A, int NT, int PPT, int DIAGM, bool ACC>
+__global__ void __launch_bounds__(NT, sc3_win_waves(NT, (NT * 2 * PPT * 8 + 1023) / 1024 + 4))
+sc3g_lo_pass_r(const Sc3Tab S, const Sc3Op O, const uint32_t *__restrict__ perm, const Sc3Call C,
+               const double *__restrict__ xw, double *__restrict__ y) {
+  constexpr int MAXROWS = cbinom(A, A / 2);
+  constexpr int EPT = 2 * PPT;
+  constexpr int H = A / 2, HB = A - H;
+  constexpr uint32_t HM = (1u << H) - 1u;
+  static_assert(NT * EPT >= MAXROWS, "the longest row does not fit the workgroup");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ uint16_t rka[1 << H];
+  __shared__ uint16_t rkb[(1 << HB) * (H + 1)];
+  __shared__ double red[3 * (NT / 64)];
+  __shared__ double dsh[5 * 8];
+  const uint32_t e0 = SC3_CP(uint32_t, perm)[8 * (size_t)blockIdx.x];
+  if (e0 == 0xffffffffu) return;
+  uint16_t tka[((1 << H) + NT - 1) / NT], tkb[((1 << HB) * (H + 1) + NT - 1) / NT];
+#pragma unroll
+  for (int i = 0; i < ((1 << H) + NT - 1) / NT; ++i) {
+    const int tt = threadIdx.x + i * NT;
+    tka[i] = tt < (1 << H) ? S.lo_rlo[tt] : (uint16_t)0;
+  }
+#pragma unroll
+  for (int i = 0; i < ((1 << HB) * (H + 1) + NT - 1) / NT; ++i) {
+    const int tt = threadIdx.x + i * NT;
+    tkb[i] = tt < (1 << HB) * (H + 1) ? S.lo_rhi[tt] : (uint16_t)0;
+  }
+  const int lane = threadIdx.x & 63;
+  const int w = S.w;
+  const int logm = (int)(e0 >> 30);
+  const int NTS = NT >> logm;
+  const int sub = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) >> (ilog2c(NT) - 6 - logm);
+  const int tsub = (int)threadIdx.x & (NTS - 1);
+  const uint32_t e = SC3_CP(uint32_t, perm)[8 * (size_t)blockIdx.x + sub];
+  const bool has_row = !(e & SC3_NOROW);
+  double *xs = reinterpret_cast<double *>(smem) + (size_t)sub * ((NT * EPT) >> logm);
+  const RowId R = decode_row(has_row ? (e & (SC3_NOROW - 1u)) : (e0 & (SC3_NOROW - 1u)), S);
+  const uint32_t T = R.T, W = R.W;
+  const int kl = R.kl, nrows = has_row ? R.nrows : 0, p = has_row ? R.pitch : 0;
+  const int64_t base = R.base;
+  const double *__restrict__ x = xw - C.win_start;
+  const int64_t lbase = base - C.row0;
+#define SC3R_ENT(i) (2 * (tsub + ((i) >> 1) * NTS) + ((i) & 1))
+
+  SC3_PRIO_MEM();
+  uint32_t lowp[PPT];                                   // the Lo patterns of a pair's entries, 16 bits each
+#define SC3R_PAT(i) ((lowp[(i) >> 1] >> (((i) & 1) * 16)) & 0xffffu)
+  double xv[EPT];
+  const auto pat = SC3_CP(uint16_t, S.lo_pat) + S.lo_off[kl];
+#pragma unroll
+  for (int i = 0; i < EPT; i += 2) {
+    const int r = SC3R_ENT(i);
+    lowp[i >> 1] = 0;
+    xv[i] = xv[i + 1] = 0.0;
+    if (r < p) {
+      const d2v v = *reinterpret_cast<const d2v *>(x + base + r);
+      xv[i] = v.x;
+      xv[i + 1] = v.y;
+      if (r < nrows) lowp[i >> 1] = pat[r];
+      if (r + 1 < nrows) lowp[i >> 1] |= (uint32_t)pat[r + 1] << 16;
+    }
+  }
+  HopEval g{0, 0, 0.0, 0.0, 0, 0u, 0};
+  if (lane < O.ngatA) {
+    const Sc3Hop h = O.gatA[lane];
+    const uint32_t T2 = T ^ h.mT, W2 = W ^ h.mW;
+    const int nd = h.half - __popc(T & h.mT) - __popc(W & h.mW);
+    const int nlo = __popc(h.mLo);
+    const int kr2 = S.k - __popc(T2), cw2 = __popc(W2), kl2 = kr2 - cw2;
+    if (nd >= 0 && nd <= nlo && kl2 >= 0 && kl2 <= A && cw2 <= w) {
+      const int64_t tb2 = S.ibase[T2];
+      if (tb2 >= 0) {
+        g.act = 1;
+        g.delta = tb2 + S.icoff[kr2 * (w + 1) + cw2] + (int64_t)S.w_rank[W2] * S.pitch[kl2] - base;
+        g.need = nd;
+        g.xm = h.mLo;
+        g.c0 = h.up_re;
+      }
+    }
+  }
+  uint64_t hb = has_row ? __ballot(g.act) : 0ull;
+#pragma unroll
+  for (int i = 0; i < ((1 << H) + NT - 1) / NT; ++i) {
+    const int tt = threadIdx.x + i * NT;
+    if (tt < (1 << H)) rka[tt] = tka[i];
+  }
+#pragma unroll
+  for (int i = 0; i < ((1 << HB) * (H + 1) + NT - 1) / NT; ++i) {
+    const int tt = threadIdx.x + i * NT;
+    if (tt < (1 << HB) * (H + 1)) rkb[tt] = tkb[i];
+  }
+  if (DIAGM == 2 && tsub < 64) {
+    const uint64_t hi = ((uint64_t)T << w) | W;
+    double v0 = 0.0, vm[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int t0 = 0; t0 < O.ndt; t0 += 64) {
+      const int t = t0 + lane;
+      if (t < O.ndt) {
+        const uint64_t sg = SC3_CP(uint64_t, O.dt_sign)[t];
+        const double c = flip(SC3_CP(double, O.dt_coef)[t], (uint32_t)__popcll(hi & sg & 0x1fffffffffffffffull) & 1u);
+        const int gq = (int)(sg >> 61);
+        if (gq == 0) v0 += c;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (gq == j + 1) vm[j] += c;
+      }
+    }
+    v0 = wave_sum(v0);
+    if (lane == 0) dsh[5 * sub] = v0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (j < O.ngroups) {
+        const double s = wave_sum(vm[j]);
+        if (lane == 0) dsh[5 * sub + j + 1] = s;
+      }
+  }
+  double acc[EPT];
+#pragma unroll
+  for (int i = 0; i < EPT; i += 2) {
+    const int r = SC3R_ENT(i);
+    acc[i] = acc[i + 1] = 0.0;
+    if (r < p) {
+      *reinterpret_cast<d2v *>(xs + r) = d2v{xv[i], xv[i + 1]};
+      if (DIAGM == 1) {
+        const d2v dg = __builtin_nontemporal_load(reinterpret_cast<const d2v *>(O.diag + lbase + r));
+        acc[i] = dg.x * xv[i];
+        acc[i + 1] = dg.y * xv[i + 1];
+      }
+    }
+  }
+  __syncthreads();
+  while (hb) {
+    const int m = __ffsll((long long)hb) - 1;
+    hb &= hb - 1;
+    const double *__restrict__ pp = x + (base + rl_i64(g.delta, m));
+    const double cr = rl_f64(g.c0, m);
+    const int nd = rl_i32(g.need, m);
+    const uint32_t xm = (uint32_t)rl_i32((int)g.xm, m);
+    double v[EPT];
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+      const int r = SC3R_ENT(i);
+      const uint32_t pt = SC3R_PAT(i);
+      v[i] = 0.0;
+      if (r < nrows && __popc(pt & xm) == nd) {
+        const uint32_t p2 = pt ^ xm;
+        v[i] = pp[(int)rka[p2 & HM] + (int)rkb[(p2 >> H) * (H + 1) + __popc(p2 & HM)]];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) acc[i] = fma(cr, v[i], acc[i]);
+  }
+  d2v yv[PPT];
+  if (ACC) {
+#pragma unroll
+    for (int i = 0; i < EPT; i += 2) {
+      const int r = SC3R_ENT(i);
+      yv[i >> 1] = d2v{0.0, 0.0};
+      if (r < p) yv[i >> 1] = __builtin_nontemporal_load(reinterpret_cast<const d2v *>(y + lbase + r));
+    }
+  }
+  SC3_PRIO_LDS();
+  if (DIAGM == 2) {
+    const auto dl = SC3_CP(double, O.dlo) + S.lo_off[kl];
+    const double dg0 = dsh[5 * sub];
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+      const int r = SC3R_ENT(i);
+      if (r < nrows) {
+        double dg = dl[r] + dg0;
+        for (int j = 0; j < O.ngroups; ++j) dg += flip(dsh[5 * sub + j + 1], (uint32_t)__popc(SC3R_PAT(i) & O.glo[j]) & 1u);
+        acc[i] = fma(dg, xs[r], acc[i]);
+      }
+    }
+  }
+  for (int hq = 0; hq < O.nldsA; ++hq) {
+    const auto hp = SC3_CP(Sc3Hop, O.ldsA) + hq;
+    const uint32_t m = hp->mLo;
+    const int half = hp->half;
+    const double ure = hp->up_re;
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+      const int r = SC3R_ENT(i);
+      const uint32_t pt = SC3R_PAT(i);
+      if (r < nrows && __popc(pt & m) == half) {
+        const uint32_t p2 = pt ^ m;
+        acc[i] = fma(ure, xs[(int)rka[p2 & HM] + (int)rkb[(p2 >> H) * (H + 1) + __popc(p2 & HM)]], acc[i]);
+      }
+    }
+  }
+  double dr = 0.0, dn = 0.0;
+  SC3_PRIO_MEM();
+#pragma unroll
+  for (int i = 0; i < EPT; i += 2) {
+    const int r = SC3R_ENT(i);
+    if (r < p) {
+      double a2[2] = {acc[i], acc[i + 1]};
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        if (r + b < nrows) {
+          if (ACC) a2[b] += b ? yv[i >> 1].y : yv[i >> 1].x;
+          else if (C.zinit) {
+            a2[b] = fma(-C.zscale, reinterpret_cast<const double *>(C.zinit)[lbase + r + b], a2[b]);
+            if (C.zinit2) a2[b] = fma(C.z2re, reinterpret_cast<const double *>(C.zinit2)[lbase + r + b], a2[b]);
+          }
+          if (ACC && C.dot_out) {
+            dr = fma(xs[r + b], a2[b], dr);
+            dn = fma(a2[b], a2[b], dn);
+          }
+        } else {
+          a2[b] = 0.0;
+        }
+      }
+      __builtin_nontemporal_store(d2v{a2[0], a2[1]}, reinterpret_cast<d2v *>(y + lbase + r));
+    }
+  }
+#undef SC3R_ENT
+#undef SC3R_PAT
+  if (ACC && C.dot_out) {
+    dr = wave_sum(dr); dn = wave_sum(dn);
+    if (lane == 0) {
+      red[3 * (threadIdx.x >> 6)] = dr;
+      red[3 * (threadIdx.x >> 6) + 1] = 0.0;
+      red[3 * (threadIdx.x >> 6) + 2] = dn;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double sr = 0.0, sn = 0.0;
+      for (int wv = 0; wv < NT / 64; ++wv) { sr += red[3 * wv]; sn += red[3 * wv + 2]; }
+      C.dot_out[3 * (size_t)blockIdx.x] = sr;
+      C.dot_out[3 * (size_t)blockIdx.x + 1] = 0.0;
+      C.dot_out[3 * (size_t)blockIdx.x + 2] = sn;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // window pass: y (+)= (hops inside W from the LDS tile, hops between W and T and inside T gathered) x.  Workgroup =
 // (T, cw, run of R = 16 << s columns), the tile all window patterns of the class x R columns, as sc3_win_pass.
 template <int WB, int NT, bool SYM, bool ACC>
@@ -538,7 +776,6 @@ static int launch_graph_passes(const Sc3Mat &M, const Sc3Call &call, const doubl
   const int dm = M.diag_mode;
   if (dm == 1) op.diag = cached_diag;
   DNM_CHECK(dm != 1 || op.diag, "this operator needs its diagonal precomputed (dnm_mat_precompute_diagonal)");
-  DNM_CHECK(!M.real, "internal: no real-arithmetic form of the bond-graph passes");
   using kern_t = void (*)(const Sc3Tab, const Sc3Op, const uint32_t *, const Sc3Call, const c128 *, c128 *);
   const bool lo_first = phase != 0;
   kern_t kB = nullptr, kA = nullptr;
@@ -564,6 +801,34 @@ static int launch_graph_passes(const Sc3Mat &M, const Sc3Call &call, const doubl
   first.dot_out = nullptr;
   second.zinit = nullptr;
   second.zinit2 = nullptr;
+  if (M.real) {
+    // real vectors: the window pass is the complex kernel on the halved tables (pairs of entries as elements: it never
+    // looks inside a row -- which is why the flip-composed hops of XParity, whose columns run backwards, have no real
+    // form), the lo pass its own kernel on doubles
+    DNM_CHECK(M.sym, "internal: real vectors need a real operator");
+    using kern_r = void (*)(const Sc3Tab, const Sc3Op, const uint32_t *, const Sc3Call, const double *, double *);
+    kern_r kR = nullptr;
+    constexpr int NTR = sc3r_threads(NT), PPR = sc3r_pairs(A, NT);
+#define DNM_LOR(DM_) (lo_first ? (kern_r)sc3g_lo_pass_r<A, NTR, PPR, DM_, false> : (kern_r)sc3g_lo_pass_r<A, NTR, PPR, DM_, true>)
+    kR = dm == 0 ? DNM_LOR(0) : (dm == 1 ? DNM_LOR(1) : DNM_LOR(2));
+#undef DNM_LOR
+    constexpr size_t ldsR = (size_t)sc3_lo_cap_r(A, NT) * 8;
+    if (attr_done[(const void *)kR] < ldsR) {
+      DNM_HIP(hipFuncSetAttribute((const void *)kR, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsR));
+      attr_done[(const void *)kR] = ldsR;
+    }
+    Sc3Call firstw = phase == 0 ? first : second;
+    firstw.row0 /= 2;
+    firstw.win_start /= 2;
+    if (phase == 0 || phase == 2)
+      hipLaunchKernelGGL(kB, dim3((unsigned)M.permB.size()), dim3(NTW), ldsB, st, M.ly->dev_h, op, (const uint32_t *)M.d_permB,
+                         firstw, (const c128 *)xw, (c128 *)y);
+    if (phase == 0 || phase == 1)
+      hipLaunchKernelGGL(kR, dim3((unsigned)(M.permA.size() / 8)), dim3(NTR), ldsR, st, S, op, (const uint32_t *)M.d_permA,
+                         phase == 0 ? second : first, (const double *)xw, (double *)y);
+    DNM_HIP(hipGetLastError());
+    return 0;
+  }
   if (phase == 0 || phase == 2)
     hipLaunchKernelGGL(kB, dim3((unsigned)M.permB.size()), dim3(NTW), ldsB, st, S, op, (const uint32_t *)M.d_permB,
                        phase == 0 ? first : second, (const c128 *)xw, (c128 *)y);

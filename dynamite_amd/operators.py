@@ -362,6 +362,8 @@ class Operator:
                 if 'real-packed' not in str(e):
                     raise
                 mat = None
+            if mat is not None and masks.size and masks[0] == 0 and mat.uses_cached_diagonal():
+                backend.precompute_diagonal(mat)        # (more mixed diagonal patterns than the passes evaluate on the fly)
         self._mats[key] = mat
         return mat
 

@@ -436,11 +436,21 @@ def test_fuzz_internal_layout_real(small_layout, seed):
 
 
 def test_real_packed_spinconserve_refusals(small_layout):
-    """No real form for an operator with imaginary bond elements, nor for one that is not a chain (row kernel)."""
+    """No real form for an operator with imaginary bond elements.  (The long-range model -- a chain with an all-to-all
+    diagonal -- has one since round 5: its real lo pass reads the cached diagonal.)"""
     sub = SpinConserve(13, 6)
-    for H in (_dm_chain(13), models.long_range(13)):
-        with pytest.raises(_lib.BackendError):
-            shell(H, sub, flags=_lib.MAT_REAL_PACKED)
+    with pytest.raises(_lib.BackendError):
+        shell(_dm_chain(13), sub, flags=_lib.MAT_REAL_PACKED)
+    H = models.long_range(13)
+    mat = shell(H, sub, flags=_lib.MAT_REAL_PACKED, site_perm=False)
+    assert "diagonal cached" in mat.describe()
+    mat.precompute_diagonal()
+    xr = np.random.RandomState(4).standard_normal(sub.get_dimension())
+    want = orc.matvec(orc_msc(H), orc_sub(sub), orc_sub(sub), xr.astype(np.complex128))
+    got, _, _ = _real_mult(mat, sub, xr)
+    assert np.abs(got.imag).max() == 0.0
+    assert np.abs(got.real - want.real).max() <= 64 * 2.2e-16 * np.abs(H.msc['coeffs']).sum() * np.abs(xr).max()
+    mat.destroy()
 
 
 @pytest.mark.default_layout

@@ -370,3 +370,79 @@ def test_fuzz_xparity_pair_graphs(small_layout, seed):
     (x1, y1, d1), (x2, y2, d2) = _xparity_case(H, L, '+' if seed & 1 else '-', seed=seed)
     assert "bond graph" in d1, d1
     assert np.abs(y1 - y2).max() <= 1e-12 * max(1.0, np.abs(y2).max()), d1
+
+
+def test_xparity_production_instance():
+    """The flagship case at size: the 30-site kagome torus in XParity(SpinConserve(30, 15)) -- 77.6 M representatives
+    in the (14, 10) layout's first half -- against the reference-order kernels on the same seeded state."""
+    H = models.kagome("30")
+    (x1, y1, d1), (x2, y2, d2) = _xparity_case(H, 30, '-')
+    assert "bond graph" in d1 and "[T 6 | W 10 | Lo 14]" in d1, d1
+    assert np.array_equal(x1, x2)
+    assert np.abs(y1 - y2).max() <= 1e-12 * max(1.0, np.abs(y2).max())
+
+
+# ---- real arithmetic ---------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("case", ["kagome15", "graph13", "graph14_fields"])
+def test_real_packed_graph_multiply(small_layout, case):
+    """DNM_MAT_REAL_PACKED on a bond graph: the lo pass on doubles (sc3g_lo_pass_r), the window pass on pairs of
+    entries, cached and on-the-fly diagonals, the fused sums of the Lanczos step -- against the oracle."""
+    import ctypes as C
+    import torch
+    from dynamite_amd import _lib
+    from gpu_util import vec_for
+    if case == "kagome15":
+        H, L, k = models.kagome("15"), 15, 7
+    elif case == "graph13":
+        H, L, k = pair_graph(13, seed=5, nbonds=20, fields=False), 13, 6
+    else:
+        H, L, k = pair_graph(14, seed=6, nbonds=28, fields=True), 14, 5
+    sub = SpinConserve(L, k)
+    n = sub.get_dimension()
+    mat = shell(H, sub, flags=_lib.MAT_REAL_PACKED, site_perm=False)      # raw vectors of the subspace's own layout below
+    assert "bond graph" in mat.describe()
+    if mat.uses_cached_diagonal():
+        mat.precompute_diagonal()
+    xr = np.random.RandomState(L).standard_normal(n)
+    want = orc.matvec(orc_msc(H), orc_sub(sub), orc_sub(sub), xr.astype(np.complex128))
+    assert np.abs(want.imag).max() == 0.0
+    v = vec_for(sub)
+    v.set_local_from_numpy(xr.astype(np.complex128))
+    xd = v.array.real.contiguous()
+    yd = torch.full_like(xd, 7.0)
+    _lib.check(_lib.lib().dnm_mat_mult(mat.handle, C.c_void_p(xd.data_ptr()), C.c_void_p(yd.data_ptr()), None))
+    out = vec_for(sub)
+    _lib.check(_lib.lib().dnm_vec_layout_unpack_real(C.byref(sub._c()), None, out.ptr, C.c_void_p(yd.data_ptr()), None))
+    got = out.local_numpy()
+    assert np.abs(got.imag).max() == 0.0
+    assert np.abs(got.real - want.real).max() <= tol_for(H, L, xr), mat.describe()
+    d = (C.c_double * 3)()
+    _lib.check(_lib.lib().dnm_mat_mult_lanczos(mat.handle, C.c_void_p(xd.data_ptr()), C.c_void_p(yd.data_ptr()), None,
+                                               0.0, d, None))
+    assert abs(d[0] - xr @ want.real) <= 1e-11 * max(1.0, abs(xr @ want.real))
+    assert abs(d[2] - want.real @ want.real) <= 1e-11 * max(1e-300, want.real @ want.real)
+    mat.destroy()
+
+
+@pytest.mark.parametrize("mode", ["basis_free", "restarted"])
+def test_kagome_eigsolve_real_arithmetic(small_layout, monkeypatch, mode):
+    """eigsolve of the 12-site kagome torus in real arithmetic, in the relabelled layout: eigenvalues against the
+    reference-built matrix, the eigenvector -- handed back as a complex state of the subspace -- against the oracle."""
+    g = np.load(os.path.join(GOLDEN, "kagome.npz"))
+    H = models.kagome("12")
+    sub = SpinConserve(12, 6)
+    H.add_subspace(sub)
+    config.eigs_real_arithmetic = True
+    monkeypatch.setenv("DNM_EIGS_BASISFREE", "1" if mode == "basis_free" else "0")
+    try:
+        from dynamite_amd.computations import eigsolve
+        vals, vecs = H.eigsolve(nev=1, getvecs=True, subspace=sub, tol=1e-11)
+        assert eigsolve.last_stats["real_arithmetic"]
+    finally:
+        config.eigs_real_arithmetic = None
+    assert abs(vals[0] - g["kagome_12_sc/evals_lowest"][0]) < 1e-9
+    xv = vecs[0].to_numpy()
+    Hx = orc.matvec(orc_msc(H), orc_sub(sub), orc_sub(sub), xv)
+    assert np.linalg.norm(Hx - vals[0] * xv) < 1e-8 and abs(np.linalg.norm(xv) - 1.0) < 1e-12
+    H.destroy_mat()
