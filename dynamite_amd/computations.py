@@ -92,6 +92,16 @@ def _tensor_from_ptr(ptr, n):
     return torch.as_tensor(w, device=config.device).view(torch.complex128)
 
 
+def _adopt(mat, state, result):
+    """The vectors of ``state`` and ``result`` in the layout ``mat`` works in: where it differs from theirs (a
+    relabelled SpinConserve layout, backend._relabelled) the state is converted once and keeps the new layout, the
+    result gets a fresh vector in it.  Returns (input Vec, result Vec)."""
+    state._vec = mat.vec_in(state.vec)
+    if result is not state:
+        result._vec = mat.vec_out(result.vec)
+    return state.vec, result.vec
+
+
 def evolve(H, state, t, result=None, tol=None, ncv=None, algo=None, max_its=None):
     r"""result = exp(-i H t) state   (computations.py:10-126)."""
     state.assert_initialized()
@@ -118,9 +128,8 @@ def evolve(H, state, t, result=None, tol=None, ncv=None, algo=None, max_its=None
     hooks = _hooks(mat, keep)
     stats = _lib.SolverStats()
     import torch
-    # (an operator on a bond graph works in a relabelled layout of its own: the state goes in and the result comes
-    # back through the reference order, once per call)
-    xin, yout = mat.vec_in(state.vec), mat.vec_out(result.vec)
+    # (an operator on a bond graph works in a relabelled layout of its own: the states adopt it, as in Operator.dot)
+    xin, yout = _adopt(mat, state, result)
     mat.check_layout(xin, yout)
     mat.prepare_exchange(state.vec.array)
     free, _ = torch.cuda.mem_get_info()
@@ -160,8 +169,6 @@ def evolve(H, state, t, result=None, tol=None, ncv=None, algo=None, max_its=None
         raise ConvergenceError('solver failed to converge with MFN_DIVERGED_BREAKDOWN.')
     elif stats.reason <= 0:
         raise ConvergenceError('solver failed to converge.')
-    if yout is not result.vec:
-        yout.copy(result.vec)
     result.set_initialized()
     return result
 
@@ -179,7 +186,7 @@ def _evolve_chebyshev(H, state, t, result, tol):
     keep = []
     hooks = _hooks(mat, keep)
     stats = _lib.SolverStats()
-    xin, yout = mat.vec_in(state.vec), mat.vec_out(result.vec)
+    xin, yout = _adopt(mat, state, result)
     mat.check_layout(xin, yout)
     mat.prepare_exchange(state.vec.array)
     _lib.check(_lib.lib().dnm_expm_chebyshev(
@@ -190,8 +197,6 @@ def _evolve_chebyshev(H, state, t, result, tol):
                          'err_est': stats.err_est}
     if stats.reason <= 0:
         raise ConvergenceError('solver failed to converge.')
-    if yout is not result.vec:
-        yout.copy(result.vec)
     result.set_initialized()
     return result
 

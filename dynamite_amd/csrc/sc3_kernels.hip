@@ -1627,6 +1627,37 @@ int Sc3Mat::init(const Sc3Layout *layout, const std::vector<int64_t> &masks, con
       }
     }
   }
+  // Bond graphs: the lo pass gathers, for every hop between Lo and W, from the row (T, W ^ bit) -- rows that differ
+  // in the window bits such hops touch go to one XCD back to back (what one of them gathers is what another stages:
+  // the requests meet in that XCD's L2), and the groups of one window pattern over all T's follow each other, so that
+  // the partner blocks of the hops between Lo and T are at least in the Infinity Cache.  DNM_SC3G_ORDER=0: the chain's
+  // order (pairs under window bit 0).
+  if (graph && !(knob("DNM_SC3G_ORDER") && knob("DNM_SC3G_ORDER")[0] == '0')) {
+    uint32_t jw = 0;
+    for (size_t q = nh[0]; q < nh[0] + nh[1]; ++q)
+      if (hops[q].mT == 0 && __builtin_popcount(hops[q].mW) == 1) jw |= hops[q].mW;
+    while (__builtin_popcount(jw) > 6) jw &= jw - 1;              // at most 64 rows to a group (what an XCD holds)
+    gA.clear();
+    std::vector<uint32_t> subs;
+    for (uint32_t sset = jw;; sset = (sset - 1) & jw) {           // the subsets of jw, descending
+      subs.push_back(sset);
+      if (!sset) break;
+    }
+    std::reverse(subs.begin(), subs.end());
+    for (uint32_t W0 = 0; W0 < (1u << w); ++W0) {
+      if (W0 & jw) continue;
+      for (uint32_t T = T0; T < T1 && T < (1u << t); ++T) {
+        if (ly->ibase[T] < 0) continue;
+        const int kr = k - __builtin_popcount(T);
+        std::vector<uint32_t> g;
+        for (uint32_t sset : subs) {
+          const int kl = kr - __builtin_popcount(W0 | sset);
+          if (kl >= 0 && kl <= a) g.push_back((T << w) | W0 | sset);
+        }
+        if (!g.empty()) gA.push_back(g);
+      }
+    }
+  }
   permA = pack_lo_rows(deal(gA), *ly, a == 14 ? 1024 : 256, real);       // thread counts of launch_sc3's instances
   permB = deal(gB);
   if (permA.empty()) permA.assign(8, 0xffffffffu);

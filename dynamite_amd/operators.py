@@ -431,7 +431,15 @@ class Operator:
             left_subspace = result.subspace
         if not any(l.identical(left_subspace) for l, _ in right_match):
             raise ValueError('Subspaces of matrix and result vector do not match.')
-        self.get_mat(subspaces=(left_subspace, right_subspace)).mult(x.vec, result.vec)
+        mat = self.get_mat(subspaces=(left_subspace, right_subspace))
+        # An operator on a bond graph works in a relabelled layout of its own (backend._relabelled): the states ADOPT
+        # it -- x is converted once (it keeps its content; every State operation converts where layouts meet) and
+        # the result is created in it, so that repeated products with this operator move nothing through the
+        # reference order.
+        x._vec = mat.vec_in(x.vec)
+        if result is not x:
+            result._vec = mat.vec_out(result.vec)
+        mat.mult(x.vec, result.vec)
         result.set_initialized()
         return result
 

@@ -295,9 +295,16 @@ def test_kagome_solvers_in_the_relabelled_layout(small_layout):
     want = spla.expm_multiply(-0.7j * sp.csc_matrix(A), x0)
     got = out.to_numpy()
     assert abs(1 - np.vdot(want, got) / np.vdot(got, got)) < 1e-9
-    y = H.dot(psi)                       # a state of the subspace's own layout through Operator.dot
+    # evolve made psi adopt the operator's layout: its content is unchanged, later products move nothing
+    assert psi.vec.perm == mat.perm_right and out.vec.perm == mat.perm_left
+    assert np.array_equal(psi.to_numpy(), x0)
+    y = H.dot(psi)
     assert np.abs(y.to_numpy() - A @ x0).max() < 1e-12
     assert abs(psi.dot(out) - np.vdot(out.to_numpy(), x0)) < 1e-12
+    fresh = State(L=12, subspace=sub, state='random', seed=3)       # the subspace's own layout
+    assert fresh.vec.perm is None and abs(fresh.dot(psi) - 1.0) < 1e-12
+    y2 = H.dot(fresh)
+    assert fresh.vec.perm == mat.perm_right and np.abs(y2.to_numpy() - A @ x0).max() < 1e-12
     H.destroy_mat()
 
 
