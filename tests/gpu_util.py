@@ -71,3 +71,20 @@ def mult_numpy(mat, x):
 def rand_state(n, seed=0):
     rs = np.random.RandomState(seed)
     return rs.standard_normal(n) + 1j * rs.standard_normal(n)
+
+
+_SPECTRA = {}
+
+
+def dense_spectrum(H, sub=None):
+    """Ascending eigenvalues of H on ``sub`` (default: the operator's own subspace) by dense diagonalisation on the
+    host, computed once per (operator, subspace) and session: several tests solve the same 4096 x 4096 problem, and
+    LAPACK on the host is what they spend their time on."""
+    import hashlib
+    H.establish_L()
+    H.reduce_msc()
+    key = (hashlib.sha1(H.msc.tobytes()).hexdigest(), repr(sub))
+    if key not in _SPECTRA:
+        A = H.to_numpy(sparse=False) if sub is None else H.to_numpy(subspaces=(sub, sub), sparse=False)
+        _SPECTRA[key] = np.linalg.eigvalsh(A)
+    return _SPECTRA[key].copy()

@@ -185,13 +185,24 @@ def _worker(rank, world, port, case, out_dir):
     zg = z.to_numpy(to_all=True)
     want = spla.expm_multiply(-0.6j * Hs, xg)
     assert np.max(np.abs(zg - want)) < 1e-8, "partitioned evolve"
-    zc = H.evolve(x, t=0.6, algo='chebyshev').to_numpy(to_all=True)
-    assert np.max(np.abs(zc - want)) < 1e-8, "partitioned Chebyshev evolve"
+    # (eight ranks on one GPU: the multiply, the norm, one evolve and one eigsolve -- the schedules that differ with
+    # the rank count; the other solver variants run at two and four ranks)
+    light = world >= 8
+    if not light:
+        zc = H.evolve(x, t=0.6, algo='chebyshev').to_numpy(to_all=True)
+        assert np.max(np.abs(zc - want)) < 1e-8, "partitioned Chebyshev evolve"
     evals, evecs = H.eigsolve(nev=2, getvecs=True, tol=1e-10, subspace=sub)
     lowest = np.sort(spla.eigsh(Hs, k=2, which='SA', tol=1e-12, return_eigenvectors=False))
     assert np.max(np.abs(np.array(evals[:2]) - lowest)) < 1e-8, "partitioned eigsolve"
     v0 = evecs[0].to_numpy(to_all=True)
     assert np.linalg.norm(Hs @ v0 - evals[0] * v0) < 1e-7
+    if light:
+        dist.barrier()
+        faulthandler.cancel_dump_traceback_later()
+        if rank == 0:
+            open(os.path.join(out_dir, "ok_%s_%d" % (case, world)), "w").write("ok")
+        dist.destroy_process_group()
+        return
     os.environ["DNM_EIGS_BASISFREE"] = "1"        # one extremal pair without a stored basis, through the hooks
     e1, v1 = H.eigsolve(nev=1, getvecs=True, tol=1e-10, subspace=sub)
     os.environ.pop("DNM_EIGS_BASISFREE")
