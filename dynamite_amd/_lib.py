@@ -158,6 +158,14 @@ SIGNATURES = {
     "dnm_vec_basis_update": (C.c_int, [vp, C.c_int64, C.c_int, C.c_int, C.c_int64, f64p, vp]),
     "dnm_workspace_bytes": (C.c_int, [C.POINTER(C.c_size_t)]),
     "dnm_release_workspace": (C.c_int, []),
+    "dnm_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "dnm_comm_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "dnm_comm_destroy": (C.c_int, [C.c_void_p]),
+    "dnm_comm_forget": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "dnm_comm_loopback": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "dnm_comm_allreduce": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_int]),
+    "dnm_mat_mult_partitioned": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dnm_comm_hooks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Hooks)]),
     "dnm_sc_choose_site_perm": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int64, i64p, C.c_int, C.POINTER(C.c_int8),
                                           C.POINTER(C.c_int32)]),
     "dnm_workspace_reserve": (C.c_int, [C.c_size_t, C.c_void_p]),

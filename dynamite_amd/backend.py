@@ -32,6 +32,30 @@ def _dist():
     return dist if (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) else None
 
 
+_NATIVE_COMM = None
+
+
+def native_comm():
+    """The library's own RCCL communicator over the ranks of the torch.distributed process group (dnm_comm_create,
+    csrc/comm.cpp), made on first use: rank 0 draws the 128-byte id, the process group's store hands it round.
+    Collective.  One rank: a communicator of one (dnm_comm_loopback can make it stand for a rank of many: tests)."""
+    global _NATIVE_COMM
+    if _NATIVE_COMM is None:
+        config._initialize()
+        ident = (C.c_char * 128)()
+        d = _dist()
+        if d is None or config.rank == 0:
+            _lib.check(_lib.lib().dnm_comm_unique_id(ident))
+        if d is not None:
+            box = [bytes(ident.raw)]
+            d.broadcast_object_list(box, src=0)
+            ident = (C.c_char * 128).from_buffer_copy(box[0])
+        h = C.c_void_p()
+        _lib.check(_lib.lib().dnm_comm_create(ident, config.rank, config.world_size, C.byref(h)))
+        _NATIVE_COMM = h
+    return _NATIVE_COMM
+
+
 def split_ownership(size, world, rank):
     """PetscSplitOwnership: size // world entries each, the first size % world ranks one more.
     Returns (start, local_size)."""
@@ -626,6 +650,10 @@ class ShellMat:
         self._row_ranges = None   # ... or by rows: (ranges that read only the rank's own block, the others)
         self._msc = None          # (masks, mask_offsets, signs, coeffs, left subspace dict, right subspace dict): selfcheck
         self._check_pending = False
+        # the partitioned multiply as one native call (dnm_mat_mult_partitioned: exchange on the library's own RCCL
+        # communicator and stream) instead of the schedules below over torch.distributed -- config.native_comm, RCCL
+        # transport only; the transposed exchange keeps its host schedule
+        self._native = None
 
     @property
     def handle(self):
@@ -715,6 +743,11 @@ class ShellMat:
                     raise ExchangeCheckError('transposed exchange: sampled rows of the first multiply are off by %.3e '
                                              '(scale %.3e); build the operator with exchange="partner"' % (err, scale))
             return
+        if self._native is None and self.nranks > 1 and config.native_comm and self._native_applies(x):
+            self._native = native_comm()
+        if self._native is not None and self.nranks > 1:
+            _lib.check(L.dnm_mat_mult_partitioned(self.handle, self._native, x.ptr, y.ptr, _stream()))
+            return
         if self.nranks > 1 and not self.partners and self._is_windowed():
             return self._mult_window(x, y)
         if not self.recvs and not self.sends:
@@ -764,6 +797,14 @@ class ShellMat:
         if not (v.internal and self.swz_left >= 256 and self.nranks == 1):
             return v
         return Vec(v.size, swz=self.swz_left, sub_c=self._keep[0])
+
+    def _native_applies(self, x):
+        """The native schedule moves device memory over RCCL: not for the gloo-staged transport of the CPU / one-GPU
+        tests, nor for window partitions whose right vectors are swizzled (their window is assembled in index order)."""
+        d = _dist()
+        if d is None or d.get_backend() != 'nccl' or not x.array.is_cuda:
+            return False
+        return bool(self.partners) or x.internal or not x.swz
 
     def check_layout(self, x, y):
         """Raise unless the vectors are laid out as this matrix expects them (x: right subspace, y: left).  Every
@@ -1235,6 +1276,9 @@ class ShellMat:
 
     def destroy(self):
         if self._h is not None:
+            if self._native is not None:
+                _lib.check(_lib.lib().dnm_comm_forget(self._native, self._h))
+                self._native = None
             _lib.check(_lib.lib().dnm_mat_destroy(self._h))
             self._h = None
             self._recv = {}

@@ -9,7 +9,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdynamite_amd.so")
-SOURCES = ["matvec_kernels.hip", "sc3_kernels.hip", "sc3g_kernels.hip", "vec_kernels.hip", "rdm_kernels.hip", "plan.cpp", "sc3_perm.cpp", "mat.cpp", "vec_api.cpp", "krylov.cpp"]
+SOURCES = ["matvec_kernels.hip", "sc3_kernels.hip", "sc3g_kernels.hip", "vec_kernels.hip", "rdm_kernels.hip", "plan.cpp", "sc3_perm.cpp", "mat.cpp", "vec_api.cpp", "krylov.cpp", "comm.cpp"]
 ARCH = "gfx950"
 # tile_pass_kernel sits at the 128-VGPR edge of 4 waves per SIMD; these two scheduler options of the AMDGPU backend
 # measured -2.1 % on the L=30 multiply, same box (profiles/r02_exp22_sched.txt; max-ilp / iterative-minreg: +12...17 %);
@@ -65,7 +65,7 @@ def build(force=False, verbose=False):
             sys.stderr.write(out.decode())
     if failed:
         raise RuntimeError("hipcc failed")
-    cmd = [_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+    cmd = [_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
     subprocess.check_call(cmd)
     return LIB
 

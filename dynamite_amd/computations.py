@@ -29,7 +29,15 @@ def _hooks(mat, keep):
     if d is None:
         return None
     import torch
-    from .backend import Vec, RawVec
+    from .backend import Vec, RawVec, native_comm
+    if config.native_comm and d.get_backend() == 'nccl' and mat._tr is None and (mat.partners or mat.swz_right >= 256
+                                                                                or mat.swz_right == 0):
+        # the library's own communicator: multiply and reductions of every solver step stay native (dnm_comm_hooks)
+        mat._native = native_comm()
+        h = _lib.Hooks()
+        _lib.check(_lib.lib().dnm_comm_hooks(mat._native, mat.handle, _stream(), C.byref(h)))
+        keep.append(h)
+        return h
 
     def mult(ctx, xp, yp):
         try:

@@ -51,6 +51,9 @@ class _Config:
         # XParity on top of a SpinConserve subspace in the internal layout: its vectors are the layout's first half
         # (one rank); DNM_SC_XPARITY_LAYOUT=0 keeps them in reference order (the row kernels)
         self.sc_xparity_layout = knob('DNM_SC_XPARITY_LAYOUT', '1') != '0'
+        # partitioned multiplies through the library's own RCCL communicator and exchange stream
+        # (dnm_mat_mult_partitioned) instead of the host schedules over torch.distributed; RCCL transport only
+        self.native_comm = knob('DNM_NATIVE_COMM', '0') == '1'
         # eigsolve of a real-symmetric operator (every matrix element real in the product basis): real arithmetic on
         # vectors stored two amplitudes to a complex128 element (Full / Parity, on a power-of-two number of ranks) or one
         # double per position of the internal layout (SpinConserve, any rank count) -- DNM_MAT_REAL_PACKED, half the

@@ -1,0 +1,446 @@
+// The partitioned multiply as ONE native call: y = A x on rank r of P with the rank exchange on RCCL
+// (grouped ncclSend / ncclRecv over xGMI) running on the library's own second HIP stream under the rank-local
+// kernels.  The reference handles its ranks inside C as well (MatMult_CPU_Fast / _General's MPI branches,
+// src/dynamite/_backend/bpetsc_template_2.c:413-504, 787-879; the CUDA shell all-gathers x, bcuda_template_2.cu:161-171);
+// here the exchange is what the operator needs and nothing more:
+//   * Full / Parity on 2^p ranks: XOR-partner sub-blocks (dnm_mat_exchange_plan); the rank-local passes run while the
+//     blocks travel, the partner passes follow;
+//   * every other partition (SpinConserve, Explicit / Auto, projections, odd rank counts): the rank's column window is
+//     assembled from the owners' blocks -- only the ranges its rows read -- while the part of the multiply that needs
+//     nothing from other ranks runs (two tiled SpinConserve passes: the lo pass; otherwise: the rows that read only the
+//     rank's own block), the rest follows.
+// The transposed exchange of Full / Parity on four and more ranks keeps its host schedule (dynamite_amd/backend.py): it
+// multiplies with two more handles that the host builds from a split of the operator.
+// A communicator can also stand for one rank of P inside ONE process ("loop-back": the peers' blocks live in the same
+// device memory and every message is an RCCL send to the process itself) -- how the schedules run, transport included,
+// on the one-GPU boxes the tests have.
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <vector>
+
+#include "../../include/dynamite_amd.h"
+#include "dnm_common.h"
+#include "mat.h"
+
+using namespace dnm;
+
+// RCCL is bound at run time (dlopen), on the first communicator: the library itself loads without it (CPU-only hosts,
+// the symbol checks of tests/test_abi.py), and a process that already holds a copy -- PyTorch ships its own -- shares
+// that copy instead of loading a second one.  DNM_RCCL_LIB names a specific file.
+#include <dlfcn.h>
+namespace {
+struct Rccl {
+  void *h = nullptr;
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclSend) Send = nullptr;
+  decltype(&ncclRecv) Recv = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
+  decltype(&ncclAllReduce) AllReduce = nullptr;
+  decltype(&ncclAllGather) AllGather = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+Rccl g_rccl;
+int rccl_load() {
+  if (g_rccl.h) return 0;
+  void *h = nullptr;
+  if (const char *e = getenv("DNM_RCCL_LIB")) h = dlopen(e, RTLD_NOW | RTLD_LOCAL);
+  for (const char *n : {"librccl.so", "librccl.so.1"})
+    if (!h) h = dlopen(n, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);           // a copy the process already has
+  for (const char *n : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+    if (!h) h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+  DNM_CHECK(h, "RCCL not found (librccl.so.1; DNM_RCCL_LIB names a file): %s", dlerror());
+  Rccl r;
+  r.h = h;
+#define DNM_SYM(name) DNM_CHECK((r.name = (decltype(r.name))dlsym(h, "nccl" #name)) != nullptr, "RCCL: no symbol nccl" #name)
+  DNM_SYM(GetUniqueId); DNM_SYM(CommInitRank); DNM_SYM(CommDestroy); DNM_SYM(Send); DNM_SYM(Recv); DNM_SYM(GroupStart);
+  DNM_SYM(GroupEnd); DNM_SYM(AllReduce); DNM_SYM(AllGather); DNM_SYM(GetErrorString);
+#undef DNM_SYM
+  g_rccl = r;
+  return 0;
+}
+}  // namespace
+#define ncclGetUniqueId g_rccl.GetUniqueId
+#define ncclCommInitRank g_rccl.CommInitRank
+#define ncclCommDestroy g_rccl.CommDestroy
+#define ncclSend g_rccl.Send
+#define ncclRecv g_rccl.Recv
+#define ncclGroupStart g_rccl.GroupStart
+#define ncclGroupEnd g_rccl.GroupEnd
+#define ncclAllReduce g_rccl.AllReduce
+#define ncclAllGather g_rccl.AllGather
+#define ncclGetErrorString g_rccl.GetErrorString
+
+#define DNM_NCCL(call)                                                                        \
+  do {                                                                                        \
+    ncclResult_t r_ = (call);                                                                 \
+    if (r_ != ncclSuccess) {                                                                  \
+      set_error("RCCL: %s (%s:%d)", ncclGetErrorString(r_), __FILE__, __LINE__);              \
+      return 1;                                                                               \
+    }                                                                                         \
+  } while (0)
+
+namespace {
+
+struct Range { int64_t lo, hi; };        // [lo, hi)
+
+// per-operator state of the window schedule
+struct WindowState {
+  bool ready = false;
+  std::vector<int64_t> own0, ownn;               // every rank's block (positions of the right vector's own order)
+  std::vector<int64_t> wlo, whi;                 // every rank's inclusive column window
+  std::vector<std::vector<Range>> needs;         // ... and the ranges of it the rank reads
+  DevBuf window;                                 // this rank's assembled window
+  int64_t wlen = 0;
+  int split = 0;                                 // dnm_mat_window_split
+  std::vector<Range> rows_local, rows_remote;    // row split of the other window kernels
+};
+
+struct PartnerState {
+  std::vector<dnm_xfer> sends, recvs;
+  std::vector<std::unique_ptr<DevBuf>> bufs;
+  bool ready = false;
+};
+
+}  // namespace
+
+struct dnm_comm {
+  ncclComm_t nccl = nullptr;
+  int rank = 0, nranks = 1;                      // of the RCCL communicator
+  hipStream_t xs = nullptr;                      // exchange stream
+  hipEvent_t ev_ready = nullptr, ev_done = nullptr;
+  DevBuf red;                                    // staging for reductions / gathers
+  // loop-back: this process stands for rank vrank of vranks; peer q's block of x is peer_x[q], its handle peer_mat[q]
+  int vrank = -1, vranks = 0;
+  std::vector<const void *> peer_x;
+  std::vector<dnm_mat *> peer_mat;
+  std::map<dnm_mat *, WindowState> win;
+  std::map<dnm_mat *, PartnerState> par;
+  int me() const { return vrank >= 0 ? vrank : rank; }
+  int world() const { return vrank >= 0 ? vranks : nranks; }
+};
+
+namespace {
+
+constexpr int WINDOW_CHUNKS = 1024;              // resolution of the needed-columns map (backend.py: the same)
+
+// Post one received block: `count` complex128 elements that rank q holds at `src_off` of ITS vector land in dst.
+// Real ranks: a receive from q (q posts the matching send from its own list).  Loop-back: a send to this process from
+// the peer's block, and its receive.
+int post_recv(dnm_comm *c, int q, int64_t src_off, int64_t count, void *dst) {
+  if (c->vrank >= 0) {
+    DNM_CHECK(q >= 0 && q < c->vranks && c->peer_x[(size_t)q], "loop-back: no block for rank %d", q);
+    DNM_NCCL(ncclSend((const char *)c->peer_x[(size_t)q] + src_off * 16, (size_t)count * 2, ncclDouble, 0, c->nccl, c->xs));
+    DNM_NCCL(ncclRecv(dst, (size_t)count * 2, ncclDouble, 0, c->nccl, c->xs));
+    return 0;
+  }
+  DNM_NCCL(ncclRecv(dst, (size_t)count * 2, ncclDouble, q, c->nccl, c->xs));
+  return 0;
+}
+int post_send(dnm_comm *c, int q, const void *x, int64_t off, int64_t count) {
+  if (c->vrank >= 0) return 0;                   // the peers of a loop-back communicator receive nothing
+  DNM_NCCL(ncclSend((const char *)x + off * 16, (size_t)count * 2, ncclDouble, q, c->nccl, c->xs));
+  return 0;
+}
+
+// ranges covering the marked chunks of a window (backend.needed_ranges)
+std::vector<Range> ranges_of(const std::vector<uint8_t> &map, int shift, int64_t wlo, int64_t whi_excl) {
+  std::vector<Range> out;
+  const int64_t first = wlo >> shift;
+  size_t i = 0;
+  while (i < map.size()) {
+    if (!map[i]) { ++i; continue; }
+    size_t j = i;
+    while (j + 1 < map.size() && map[j + 1]) ++j;
+    out.push_back({std::max(wlo, (first + (int64_t)i) << shift), std::min(whi_excl, (first + (int64_t)j + 1) << shift)});
+    i = j + 1;
+  }
+  return out;
+}
+
+// one rank's window and needs from its handle (device sweeps, cached in the handle)
+int window_of(dnm_mat *A, int64_t *lo, int64_t *hi, std::vector<Range> *needs, hipStream_t st) {
+  DNM_TRY(dnm_mat_column_window(A, lo, hi, st));
+  int shift = 0;
+  while (((*hi - *lo + 1) >> shift) > WINDOW_CHUNKS) ++shift;
+  const int64_t n = (*hi >> shift) - (*lo >> shift) + 1;
+  std::vector<uint8_t> map((size_t)n, 0);
+  DNM_TRY(dnm_mat_column_chunks(A, shift, map.data(), n, st));
+  *needs = ranges_of(map, shift, *lo, *hi + 1);
+  return 0;
+}
+
+// the block of the right vector rank q owns, in the order the window is expressed in
+int ownership_of(const dnm_mat *A, int q, int P, int64_t *o0, int64_t *on) {
+  if (A->use_sc3) {
+    const std::vector<uint32_t> Tb = sc3_partition(*A->sc3->ly, P);
+    int64_t is, il, ns, nl;
+    sc3_range(*A->sc3->ly, Tb[(size_t)q], Tb[(size_t)q + 1], &is, &il, &ns, &nl);
+    *o0 = A->real_packed ? is / 2 : is;
+    *on = A->real_packed ? il / 2 : il;
+    return 0;
+  }
+  const int64_t qn = A->N / P, rem = A->N % P;
+  *o0 = (int64_t)q * qn + std::min<int64_t>(q, rem);
+  *on = qn + (q < rem ? 1 : 0);
+  return 0;
+}
+
+int setup_windows(dnm_comm *c, dnm_mat *A, WindowState &W, hipStream_t st) {
+  const int P = c->world(), me = c->me();
+  W.own0.assign((size_t)P, 0); W.ownn.assign((size_t)P, 0);
+  W.wlo.assign((size_t)P, 0); W.whi.assign((size_t)P, -1);
+  W.needs.assign((size_t)P, {});
+  for (int q = 0; q < P; ++q) DNM_TRY(ownership_of(A, q, P, &W.own0[(size_t)q], &W.ownn[(size_t)q]));
+  DNM_TRY(window_of(A, &W.wlo[(size_t)me], &W.whi[(size_t)me], &W.needs[(size_t)me], st));
+  if (c->vrank >= 0) {
+    // loop-back: the peers' windows from their handles (what they need decides nothing this rank does: it sends nothing)
+    for (int q = 0; q < P; ++q)
+      if (q != me && c->peer_mat[(size_t)q])
+        DNM_TRY(window_of(c->peer_mat[(size_t)q], &W.wlo[(size_t)q], &W.whi[(size_t)q], &W.needs[(size_t)q], st));
+  } else {
+    // every rank's (window, needed ranges) to every rank: fixed-size records through one all-gather
+    constexpr int MAXR = 2 * WINDOW_CHUNKS + 4;
+    const size_t rec = (size_t)MAXR;
+    std::vector<int64_t> mine(rec, 0), all(rec * (size_t)P, 0);
+    mine[0] = W.wlo[(size_t)me]; mine[1] = W.whi[(size_t)me]; mine[2] = (int64_t)W.needs[(size_t)me].size();
+    DNM_CHECK(2 * W.needs[(size_t)me].size() + 3 <= rec, "internal: too many window ranges");
+    for (size_t i = 0; i < W.needs[(size_t)me].size(); ++i) {
+      mine[3 + 2 * i] = W.needs[(size_t)me][i].lo;
+      mine[4 + 2 * i] = W.needs[(size_t)me][i].hi;
+    }
+    if (c->red.bytes < rec * 8 * (size_t)(P + 1)) DNM_TRY(c->red.alloc(rec * 8 * (size_t)(P + 1)));
+    char *dsend = (char *)c->red.p, *drecv = dsend + rec * 8;
+    DNM_HIP(hipMemcpyAsync(dsend, mine.data(), rec * 8, hipMemcpyHostToDevice, c->xs));
+    DNM_NCCL(ncclAllGather(dsend, drecv, rec, ncclInt64, c->nccl, c->xs));
+    DNM_HIP(hipMemcpyAsync(all.data(), drecv, rec * 8 * (size_t)P, hipMemcpyDeviceToHost, c->xs));
+    DNM_HIP(hipStreamSynchronize(c->xs));
+    for (int q = 0; q < P; ++q) {
+      const int64_t *r = all.data() + rec * (size_t)q;
+      W.wlo[(size_t)q] = r[0]; W.whi[(size_t)q] = r[1];
+      W.needs[(size_t)q].clear();
+      for (int64_t i = 0; i < r[2]; ++i) W.needs[(size_t)q].push_back({r[3 + 2 * i], r[4 + 2 * i]});
+    }
+  }
+  W.wlen = W.whi[(size_t)me] - W.wlo[(size_t)me] + 1;
+  DNM_CHECK(W.wlen >= 1, "internal: empty column window");
+  DNM_TRY(W.window.alloc((size_t)W.wlen * 16));
+  DNM_HIP(hipMemsetAsync(W.window.p, 0, (size_t)W.wlen * 16, st));       // what never travels is never read, but is defined
+  DNM_TRY(dnm_mat_window_split(A, &W.split));
+  W.rows_local.clear(); W.rows_remote.clear();
+  if (!W.split) {
+    // rows that read only the rank's own block of x run under the exchange (backend.ShellMat._window_row_ranges)
+    constexpr int MAXRG = 8;
+    int64_t buf[2 * MAXRG];
+    int n = 0;
+    DNM_TRY(dnm_mat_window_local_rows(A, W.own0[(size_t)me], W.own0[(size_t)me] + W.ownn[(size_t)me], MAXRG, 64, buf, &n, st));
+    int64_t covered = 0;
+    for (int i = 0; i < n; ++i) covered += buf[2 * i + 1] - buf[2 * i];
+    if (n > 0 && covered * 20 >= A->m_local) {
+      int64_t at = 0;
+      for (int i = 0; i < n; ++i) {
+        W.rows_local.push_back({buf[2 * i], buf[2 * i + 1]});
+        if (buf[2 * i] > at) W.rows_remote.push_back({at, buf[2 * i]});
+        at = buf[2 * i + 1];
+      }
+      if (at < A->m_local) W.rows_remote.push_back({at, A->m_local});
+    }
+  }
+  W.ready = true;
+  return 0;
+}
+
+int mult_window(dnm_comm *c, dnm_mat *A, const void *x, void *y, hipStream_t st) {
+  WindowState &W = c->win[A];
+  if (!W.ready) DNM_TRY(setup_windows(c, A, W, st));
+  const int P = c->world(), me = c->me();
+  const int64_t wlo = W.wlo[(size_t)me], whi = W.whi[(size_t)me] + 1;
+  const int64_t my0 = W.own0[(size_t)me], myn = W.ownn[(size_t)me];
+  // the exchange: x is ready when the compute stream gets here
+  DNM_HIP(hipEventRecord(c->ev_ready, st));
+  DNM_HIP(hipStreamWaitEvent(c->xs, c->ev_ready, 0));
+  DNM_NCCL(ncclGroupStart());
+  for (int q = 0; q < P; ++q) {
+    if (q == me) continue;
+    const int64_t q0 = W.own0[(size_t)q], qn = W.ownn[(size_t)q];
+    for (const Range &r : W.needs[(size_t)me]) {           // what this rank reads of q's block
+      const int64_t lo = std::max(r.lo, q0), hi = std::min(r.hi, q0 + qn);
+      if (lo < hi) DNM_TRY(post_recv(c, q, lo - q0, hi - lo, (char *)W.window.p + (lo - wlo) * 16));
+    }
+    for (const Range &r : W.needs[(size_t)q]) {            // what q reads of this rank's block
+      const int64_t lo = std::max(r.lo, my0), hi = std::min(r.hi, my0 + myn);
+      if (lo < hi) DNM_TRY(post_send(c, q, x, lo - my0, hi - lo));
+    }
+  }
+  DNM_NCCL(ncclGroupEnd());
+  DNM_HIP(hipEventRecord(c->ev_done, c->xs));
+  // the rank's own part of its window
+  const int64_t a = std::max(wlo, my0), b = std::min(whi, my0 + myn);
+  if (a < b) DNM_TRY(dnm_vec_copy((const char *)x + (a - my0) * 16, (char *)W.window.p + (a - wlo) * 16, b - a, st));
+  if (W.split) {
+    DNM_TRY(dnm_mat_mult_window_local(A, x, y, st));                  // under the exchange
+    DNM_HIP(hipStreamWaitEvent(st, c->ev_done, 0));
+    return dnm_mat_mult_window_remote(A, W.window.p, wlo, W.wlen, y, st);
+  }
+  if (!W.rows_local.empty()) {
+    for (const Range &r : W.rows_local) DNM_TRY(dnm_mat_mult_window_rows(A, W.window.p, wlo, W.wlen, y, r.lo, r.hi, st));
+    DNM_HIP(hipStreamWaitEvent(st, c->ev_done, 0));
+    for (const Range &r : W.rows_remote) DNM_TRY(dnm_mat_mult_window_rows(A, W.window.p, wlo, W.wlen, y, r.lo, r.hi, st));
+    return 0;
+  }
+  DNM_HIP(hipStreamWaitEvent(st, c->ev_done, 0));
+  return dnm_mat_mult_window(A, W.window.p, wlo, W.wlen, y, st);
+}
+
+int mult_partner(dnm_comm *c, dnm_mat *A, const void *x, void *y, hipStream_t st) {
+  PartnerState &Q = c->par[A];
+  if (!Q.ready) {
+    int ns = 0, nr = 0;
+    DNM_TRY(dnm_mat_exchange_plan(A, &ns, nullptr, &nr, nullptr));
+    Q.sends.resize((size_t)std::max(1, ns));
+    Q.recvs.resize((size_t)std::max(1, nr));
+    DNM_TRY(dnm_mat_exchange_plan(A, &ns, Q.sends.data(), &nr, Q.recvs.data()));
+    Q.sends.resize((size_t)ns);
+    Q.recvs.resize((size_t)nr);
+    for (const dnm_xfer &r : Q.recvs) {
+      Q.bufs.emplace_back(new DevBuf());
+      DNM_TRY(Q.bufs.back()->alloc((size_t)r.count * 16));
+    }
+    Q.ready = true;
+  }
+  if (Q.recvs.empty() && Q.sends.empty()) return dnm_mat_mult(A, x, y, st);
+  DNM_HIP(hipEventRecord(c->ev_ready, st));
+  DNM_HIP(hipStreamWaitEvent(c->xs, c->ev_ready, 0));
+  DNM_NCCL(ncclGroupStart());
+  for (const dnm_xfer &s : Q.sends) DNM_TRY(post_send(c, s.partner, x, s.offset, s.count));
+  for (size_t i = 0; i < Q.recvs.size(); ++i)
+    DNM_TRY(post_recv(c, Q.recvs[i].partner, Q.recvs[i].offset, Q.recvs[i].count, Q.bufs[i]->p));
+  DNM_NCCL(ncclGroupEnd());
+  DNM_HIP(hipEventRecord(c->ev_done, c->xs));
+  DNM_TRY(dnm_mat_mult_local(A, x, y, st));                           // under the exchange
+  DNM_HIP(hipStreamWaitEvent(st, c->ev_done, 0));
+  for (size_t i = 0; i < Q.recvs.size(); ++i) DNM_TRY(dnm_mat_mult_remote(A, (int32_t)i, Q.bufs[i]->p, y, st));
+  return 0;
+}
+
+struct HookCtx {
+  dnm_comm *c;
+  dnm_mat *A;
+  hipStream_t st;
+};
+std::vector<std::unique_ptr<HookCtx>> g_hookctx;
+
+int hook_mult(void *ctx, const void *x, void *y) {
+  HookCtx *h = (HookCtx *)ctx;
+  return dnm_mat_mult_partitioned(h->A, h->c, x, y, h->st);
+}
+int hook_sum(void *ctx, double *buf, int n) { return dnm_comm_allreduce(((HookCtx *)ctx)->c, buf, n, 0); }
+int hook_max(void *ctx, double *buf, int n) { return dnm_comm_allreduce(((HookCtx *)ctx)->c, buf, n, 1); }
+
+}  // namespace
+
+extern "C" {
+
+int dnm_comm_unique_id(void *id128) {
+  DNM_CHECK(id128, "null argument");
+  DNM_TRY(rccl_load());
+  ncclUniqueId id;
+  DNM_NCCL(ncclGetUniqueId(&id));
+  static_assert(sizeof(id) == 128, "ncclUniqueId is 128 bytes");
+  memcpy(id128, &id, sizeof id);
+  return 0;
+}
+
+int dnm_comm_create(const void *id128, int rank, int nranks, dnm_comm **out) {
+  DNM_CHECK(id128 && out && nranks >= 1 && rank >= 0 && rank < nranks, "bad argument");
+  *out = nullptr;
+  DNM_TRY(rccl_load());
+  std::unique_ptr<dnm_comm> c(new dnm_comm());
+  c->rank = rank;
+  c->nranks = nranks;
+  ncclUniqueId id;
+  memcpy(&id, id128, sizeof id);
+  DNM_NCCL(ncclCommInitRank(&c->nccl, nranks, id, rank));
+  DNM_HIP(hipStreamCreateWithFlags(&c->xs, hipStreamNonBlocking));
+  DNM_HIP(hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming));
+  DNM_HIP(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
+  DNM_TRY(c->red.alloc(1 << 16));
+  *out = c.release();
+  return 0;
+}
+
+int dnm_comm_destroy(dnm_comm *c) {
+  if (!c) return 0;
+  for (auto it = g_hookctx.begin(); it != g_hookctx.end();)
+    it = ((*it)->c == c) ? g_hookctx.erase(it) : it + 1;
+  if (c->xs) (void)hipStreamSynchronize(c->xs);
+  if (c->nccl) (void)ncclCommDestroy(c->nccl);
+  if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
+  if (c->ev_done) (void)hipEventDestroy(c->ev_done);
+  if (c->xs) (void)hipStreamDestroy(c->xs);
+  delete c;
+  return 0;
+}
+
+int dnm_comm_forget(dnm_comm *c, dnm_mat *A) {
+  DNM_CHECK(c, "null communicator");
+  c->win.erase(A);
+  c->par.erase(A);
+  return 0;
+}
+
+int dnm_comm_loopback(dnm_comm *c, int vrank, int vranks, const void *const *peer_x, dnm_mat *const *peer_mat) {
+  DNM_CHECK(c && c->nranks == 1, "loop-back needs a communicator of one rank");
+  DNM_CHECK(vranks >= 1 && vrank >= 0 && vrank < vranks && peer_x, "bad argument");
+  c->vrank = vrank;
+  c->vranks = vranks;
+  c->peer_x.assign(peer_x, peer_x + vranks);
+  c->peer_mat.assign((size_t)vranks, nullptr);
+  if (peer_mat) c->peer_mat.assign(peer_mat, peer_mat + vranks);
+  c->win.clear();
+  c->par.clear();
+  return 0;
+}
+
+int dnm_comm_allreduce(dnm_comm *c, double *vals, int n, int op) {
+  DNM_CHECK(c && (vals || n == 0) && n >= 0 && (op == 0 || op == 1), "bad argument");
+  if (n == 0 || (c->nranks == 1 && c->vrank < 0)) return 0;
+  if (c->vrank >= 0) return 0;                   // loop-back: one process, nothing to add
+  if (c->red.bytes < (size_t)n * 8) DNM_TRY(c->red.alloc((size_t)n * 8));
+  DNM_HIP(hipMemcpyAsync(c->red.p, vals, (size_t)n * 8, hipMemcpyHostToDevice, c->xs));
+  DNM_NCCL(ncclAllReduce(c->red.p, c->red.p, (size_t)n, ncclDouble, op == 0 ? ncclSum : ncclMax, c->nccl, c->xs));
+  DNM_HIP(hipMemcpyAsync(vals, c->red.p, (size_t)n * 8, hipMemcpyDeviceToHost, c->xs));
+  DNM_HIP(hipStreamSynchronize(c->xs));
+  return 0;
+}
+
+int dnm_mat_mult_partitioned(dnm_mat *A, dnm_comm *c, const void *x, void *y, void *stream) {
+  DNM_CHECK(A && c && x && y && x != y, "bad argument");
+  DNM_CHECK(!A->host_only, "host-only matrix");
+  DNM_CHECK(A->nranks == c->world() && A->rank == c->me(), "the matrix is rank %d of %d, the communicator rank %d of %d",
+            A->rank, A->nranks, c->me(), c->world());
+  hipStream_t st = (hipStream_t)stream;
+  if (A->nranks == 1) return dnm_mat_mult(A, x, y, stream);
+  if (A->hypercube && A->plan.use_tiled) return mult_partner(c, A, x, y, st);
+  DNM_CHECK(A->use_sc3 || A->right.host.swz == 0,
+            "window partitions assemble their window in index order: swizzled right vectors go through the host schedule");
+  return mult_window(c, A, x, y, st);
+}
+
+int dnm_comm_hooks(dnm_comm *c, dnm_mat *A, void *stream, dnm_hooks *out) {
+  DNM_CHECK(c && A && out, "null argument");
+  g_hookctx.emplace_back(new HookCtx{c, A, (hipStream_t)stream});
+  out->ctx = g_hookctx.back().get();
+  out->mult = hook_mult;
+  out->allreduce_sum = hook_sum;
+  out->allreduce_max = hook_max;
+  return 0;
+}
+
+}  // extern "C"

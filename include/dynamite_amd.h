@@ -450,6 +450,40 @@ int dnm_workspace_bytes(size_t *bytes);
  * 1-2 s for 64 GiB of fresh device memory).  No-op when the cached workspace is already that large. */
 int dnm_workspace_reserve(size_t bytes, void *stream);
 
+/* ------------------------------------------------------------------ */
+/* ranks -- the partitioned multiply as one native call                */
+/* ------------------------------------------------------------------ */
+/* The reference handles its ranks inside C: MatMult_CPU_Fast / _General post their scatters themselves
+ * (bpetsc_template_2.c:413-504, 787-879), the CUDA shell all-gathers x (bcuda_template_2.cu:161-171), PETSc's
+ * communicator comes with the Mat.  Here a dnm_comm is an RCCL communicator (one rank per GPU, xGMI) plus the
+ * library's own exchange stream; RCCL is bound at run time (the library loads without it).
+ *   dnm_comm_unique_id: ncclGetUniqueId -- one rank makes the 128 bytes, the host program hands them to the others
+ *     (MPI_Bcast, a file, torch.distributed's store);
+ *   dnm_comm_create: ncclCommInitRank -- collective;
+ *   dnm_mat_mult_partitioned: y = A x on this rank's blocks, A built with the same (rank, nranks) partition: the
+ *     exchange -- XOR-partner sub-blocks of a Full / Parity pair on 2^p ranks, the needed ranges of the column window
+ *     of every other partition -- is posted on the exchange stream as one group of ncclSend / ncclRecv, the part of
+ *     the multiply that reads nothing from other ranks runs under it on `stream`, the rest follows its event.
+ *     Collective.  (Full / Parity on four and more ranks are faster through the transposed exchange, whose schedule
+ *     multiplies with two further handles the host builds: dynamite_amd/backend.py.)
+ *   dnm_comm_allreduce: n doubles summed (op 0) / maximised (op 1) over the ranks, in place, host memory;
+ *   dnm_comm_hooks: the dnm_hooks of dnm_expm_multiply / dnm_eigsolve filled with the two above (valid until the
+ *     communicator is destroyed);
+ *   dnm_comm_forget: drop what the communicator caches for A (receive buffers, windows) before A is destroyed;
+ *   dnm_comm_loopback (tests): a communicator of ONE rank stands for rank vrank of vranks; peer q's block of x is the
+ *     device pointer peer_x[q] (peer_mat[q]: its handle, needed by window partitions; entries for vrank itself are
+ *     ignored) and every message becomes an RCCL send of this process to itself -- the schedules and the transport
+ *     on a one-GPU box. */
+typedef struct dnm_comm dnm_comm;
+int dnm_comm_unique_id(void *id128);
+int dnm_comm_create(const void *id128, int rank, int nranks, dnm_comm **out);
+int dnm_comm_destroy(dnm_comm *c);
+int dnm_comm_forget(dnm_comm *c, dnm_mat *A);
+int dnm_comm_loopback(dnm_comm *c, int vrank, int vranks, const void *const *peer_x, dnm_mat *const *peer_mat);
+int dnm_comm_allreduce(dnm_comm *c, double *vals, int n, int op);
+int dnm_mat_mult_partitioned(dnm_mat *A, dnm_comm *c, const void *x, void *y, void *stream);
+int dnm_comm_hooks(dnm_comm *c, dnm_mat *A, void *stream, dnm_hooks *out);
+
 enum { DNM_WHICH_LOWEST = 0, DNM_WHICH_HIGHEST = 1, DNM_WHICH_EXTERIOR = 2 };
 
 /* Thick-restart Lanczos (SLEPc EPSKRYLOVSCHUR on a HEP).  evals: [nev_max]

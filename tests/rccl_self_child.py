@@ -8,6 +8,7 @@ replaces the all-gather of bcuda_template_2.cu:161-171 and the scatters of bpets
   C  post_exchange / post_transpose with the message lists of real plans (rank 0 of 2 partner blocks, rank 1 of 4
      transposed exchange), every peer rewritten to this rank,
   D  evolve and eigsolve with the solver hooks reducing through RCCL, and exchange_only on a world-size-1 operator,
+  F  the same through the native call (dnm_mat_mult_partitioned on the library's own communicator, ShellMat._native),
   E  the partitioned multiply itself (ShellMat.mult, partner blocks): rank 0 of 2 and rank 5 of 8 of a Full-space
      operator, the state chosen with all rank blocks equal so that what a partner would send is a slice of this rank's
      own block -- the production code posts the exchange on RCCL's stream, runs the rank-local passes under it, waits
@@ -160,6 +161,31 @@ def main():
             assert err < 1e-12, "partitioned multiply over RCCL (rank %d of %d): %.3e" % (me, P, err)
             mat.destroy()
         report["stage"] = "E"
+
+        # ---- F: the same multiply as ONE native call (dnm_mat_mult_partitioned) through ShellMat.mult: the library's
+        # own communicator (sharing the RCCL this process already holds), made to stand for rank 5 of 8
+        import ctypes as C
+        comm = backend.native_comm()
+        P, me = 8, 5
+        c = sub._c()
+        c.vec_swizzle = 10
+        n_loc = (1 << L) // P
+        h = backend.create_mat(masks, offs, Hm.msc['signs'], Hm.msc['coeffs'], c, c, False, 0, me, P)
+        mat = backend.ShellMat(h, c, c, P, me)
+        x0 = rs.standard_normal(n_loc) + 1j * rs.standard_normal(n_loc)
+        xv, yv = backend.Vec(n_loc, swz=10), backend.Vec(n_loc, swz=10)
+        xv.set_local_from_numpy(x0)
+        px = (C.c_void_p * P)(*[xv.array.data_ptr()] * P)           # all rank blocks equal: every peer's block is this one
+        _lib.check(_lib.lib().dnm_comm_loopback(comm, me, P, px, None))
+        mat._native = comm
+        yv.set(3.0)
+        mat.mult(xv, yv)
+        torch.cuda.synchronize()
+        ref = orc.matvec(orc_msc(Hm), orc_sub(sub), orc_sub(sub), np.tile(x0, P), nthreads=4)[me * n_loc:(me + 1) * n_loc]
+        err = float(np.abs(yv.local_numpy() - ref).max())
+        assert err < 1e-12, "native partitioned multiply (rank %d of %d): %.3e" % (me, P, err)
+        mat.destroy()
+        report["stage"] = "F"
     except AssertionError:
         raise
     except Exception as e:          # RCCL's own refusal (recorded in DESIGN.md section 6 if it ever shows up)

@@ -402,6 +402,52 @@ def test_rccl_transport_world_one():
     rep = json.loads(lines[-1])
     assert rep["backend"] == "nccl" and rep["stage"].endswith("D") and rep["hook_allreduces"] > 0, rep
     if out.returncode == 77:
-        assert rep["stage"] in ("AD", "BD", "CD"), rep
+        assert rep["stage"] in ("AD", "BD", "CD", "ED"), rep
         pytest.skip("RCCL refused a send to the sending rank: " + str(rep["refused"]))
-    assert rep["stage"] == "ED" and rep["refused"] is None, rep
+    assert rep["stage"] == "FD" and rep["refused"] is None, rep
+
+
+def test_native_partitioned_multiply(tmp_path):
+    """The partitioned multiply as one native call (dnm_comm_* / dnm_mat_mult_partitioned, csrc/comm.cpp) from a
+    process that binds the C ABI with ctypes alone (no torch, no backend.py: tests/native_comm_child.py): RCCL
+    communicator of one rank standing, in turn, for every rank of P (dnm_comm_loopback) -- XOR-partner blocks of a
+    swizzled Full-space operator on 2 and 8 ranks, column windows of SpinConserve in reference order and of the Full
+    space on 3 ranks, the two tiled SpinConserve passes split around the exchange on 2 and 3 ranks, the solver hooks --
+    every rank's rows against the oracle (bpetsc_template_2.c:413-504, 787-879 are what this replaces)."""
+    import json
+    import subprocess
+    from dynamite_amd import models
+    from gpu_util import marshal, orc_msc, orc_sub, rand_state
+    from dynamite_amd.subspaces import Full, SpinConserve
+    from oracle import oracle as orc
+    cases = {}
+
+    def add(name, H, sub, P, typ, swz):
+        masks, offs, signs, coeffs = marshal(H)
+        x = rand_state(sub.get_dimension(), seed=len(cases) + 1)
+        y = orc.matvec(orc_msc(H), orc_sub(sub), orc_sub(sub), x)
+        L = sub.L
+        k = getattr(sub, "k", 0)
+        nck = sub._nchoosek if typ == 3 else np.zeros((1, L + 1), dtype=np.int64)
+        for key, val in (("masks", masks), ("mask_offsets", offs), ("signs", signs), ("coeffs", coeffs), ("x", x),
+                         ("y", y), ("type", typ), ("L", L), ("k", k), ("P", P), ("swz", swz), ("nck", nck)):
+            cases[name + "/" + key] = np.asarray(val)
+
+    add("full_P2", models.mbl(16), Full(L=16), 2, 0, 10)
+    add("full_P8", models.mbl(17), Full(L=17), 8, 0, 10)
+    add("full_P3_window", models.mbl(12), Full(L=12), 3, 0, 0)
+    add("sc_ref_P3", models.mbl(14), SpinConserve(14, 7), 3, 3, 0)
+    add("sc3_P2", models.mbl(15), SpinConserve(15, 7), 2, 3, 6 | (4 << 8))
+    add("sc3_P3", models.heisenberg(16), SpinConserve(16, 8), 3, 3, 6 | (4 << 8))
+    fn = os.path.join(str(tmp_path), "cases.npz")
+    np.savez(fn, **cases)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "native_comm_child.py"), fn], env=env, cwd=ROOT,
+                         capture_output=True, text=True, timeout=900)
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert out.returncode == 0 and lines, "rc %d\n%s\n%s" % (out.returncode, out.stdout[-1500:], out.stderr[-3000:])
+    rep = json.loads(lines[-1])
+    assert rep["worst_relative"] < 1e-12 and rep.get("hooks") == "ok", rep
+    assert "tiled=1" in rep["cases"]["full_P8"]["plan"] and "internal layout" in rep["cases"]["sc3_P3"]["plan"], rep
