@@ -276,12 +276,13 @@ def eigsolve(H, getvecs=False, nev=1, which='lowest', target=None, tol=None, sub
         want = max(2 * nev, nev + 15)
 
         def fitting():
+            # (beside the want + 1 basis vectors the driver may take two work vectors for its Chebyshev filter: a
+            # multiply's own vectors, freed by the caller but still in torch's cache, once made a solve at
+            # SpinConserve(33,16) run out of memory with "17 fit")
             free, _ = torch.cuda.mem_get_info()
-            return int((free + cached.value) // vec_bytes) - 1 - (nev_max if getvecs else 0)
+            return int((free + cached.value) // vec_bytes) - 3 - (nev_max if getvecs else 0)
+        torch.cuda.empty_cache()            # memory torch holds for reuse counts as free
         fit = _min_over_ranks(fitting())
-        if fit < want:
-            torch.cuda.empty_cache()        # memory torch holds for reuse counts as free
-            fit = _min_over_ranks(fitting())
         if fit < want:
             if fit < nev + 2:
                 raise RuntimeError('not enough device memory for a Krylov basis: %d vectors of %.1f GiB fit, '

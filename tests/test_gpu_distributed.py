@@ -58,7 +58,7 @@ def _worker(rank, world, port, case, out_dir):
     L = 24 if case == "sc_big" else 14
     config.L = L
     config._initialize()
-    if case == "sc3":
+    if case in ("sc3", "sc3_graph"):
         # SpinConserve states in the internal three-field layout (csrc/sc3.h): ranks own whole blocks of equal top
         # bits, windows and the exchange are expressed in positions of the layout (small kernel instances (6, 4))
         config.sc_layout, config.sc_layout_min_dim = (6, 4), 0
@@ -138,6 +138,12 @@ def _worker(rank, world, port, case, out_dir):
         sub, H = Full(L=L), models.mbl(L)
     elif case == "parity":
         sub, H = Parity('even', L=L), models.mbl(L)
+    elif case == "sc3_graph":
+        # an operator on a bond graph (a J1-J2 ring with two long bonds) in the internal layout on several ranks: the
+        # bond-graph passes of csrc/sc3g_kernels.hip read their gathered hops through the column window (no site
+        # relabelling on partitions: a rank owns whole blocks of equal top bits of the reference's labelling)
+        edges = [(i, (i + 1) % L) for i in range(L)] + [(i, (i + 2) % L) for i in range(0, L, 2)] + [(0, 7), (3, 11)]
+        sub, H = SpinConserve(L, L // 2), models.bond_heisenberg([(min(a, b), max(a, b)) for a, b in edges], L=L)
     else:
         sub, H = SpinConserve(L, L // 2), models.mbl(L)
     H.add_subspace(sub)
@@ -146,8 +152,9 @@ def _worker(rank, world, port, case, out_dir):
     x = State(subspace=sub, state='random', seed=3)
     start, end = x.vec.getOwnershipRange()
     from dynamite_amd.backend import split_ownership
-    if case == "sc3":
+    if case in ("sc3", "sc3_graph"):
         assert x.vec.internal and "internal layout" in H.get_mat().describe()
+        assert ("bond graph" in H.get_mat().describe()) == (case == "sc3_graph")
         import torch
         t = torch.tensor([start, end], dtype=torch.int64)
         allr = [torch.zeros(2, dtype=torch.int64) for _ in range(world)]
@@ -161,7 +168,7 @@ def _worker(rank, world, port, case, out_dir):
     assert abs(x.norm() - 1) < 1e-12
 
     # multiply
-    if case not in ("sc", "sc3"):
+    if case not in ("sc", "sc3", "sc3_graph"):
         # exchange scheme: partner blocks on two ranks, the transposed all-to-all from four on (backend.py)
         want_scheme = {"full": "transpose" if world >= 4 else "partner", "full_partner": "partner",
                        "full_transpose": "transpose", "parity": "transpose" if world >= 4 else "partner"}[case]
@@ -224,7 +231,7 @@ def _worker(rank, world, port, case, out_dir):
         assert np.max(np.abs(np.array(er[:2]) - lowest)) < 1e-8, "partitioned eigsolve, real arithmetic"
         vg = vr[0].to_numpy(to_all=True)
         assert np.abs(vg.imag).max() == 0.0 and np.linalg.norm(Hs @ vg - er[0] * vg) < 1e-7
-    if case == "sc3":
+    if case in ("sc3", "sc3_graph"):
         # the same solves in real arithmetic (DNM_MAT_REAL_PACKED on the partitioned internal layout: one double per
         # position, windows and exchange in pairs of positions -- half the bytes on the links)
         from dynamite_amd.computations import eigsolve as _eig
@@ -268,7 +275,7 @@ def _worker(rank, world, port, case, out_dir):
 
 
 @pytest.mark.parametrize("case,world", [("full", 2), ("full", 4), ("full", 8), ("full_partner", 4), ("full_transpose", 2),
-                                        ("parity", 2), ("parity", 4), ("sc", 2), ("sc", 3), ("sc3", 2), ("sc3", 3),
+                                        ("parity", 2), ("parity", 4), ("sc", 2), ("sc", 3), ("sc3", 2), ("sc3", 3), ("sc3_graph", 2),
                                         ("sc_big", 3), ("explicit", 3), ("auto", 2), ("projection", 3),
                                         ("projection", 2), ("full_odd", 3), ("parity_odd", 3)])
 def test_partitioned_end_to_end_one_gpu(tmp_path, case, world):
