@@ -158,6 +158,7 @@ SIGNATURES = {
     "dnm_vec_basis_update": (C.c_int, [vp, C.c_int64, C.c_int, C.c_int, C.c_int64, f64p, vp]),
     "dnm_workspace_bytes": (C.c_int, [C.POINTER(C.c_size_t)]),
     "dnm_release_workspace": (C.c_int, []),
+    "dnm_mat_is_real_packed": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "dnm_comm_unique_id": (C.c_int, [C.c_void_p]),
     "dnm_comm_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "dnm_comm_destroy": (C.c_int, [C.c_void_p]),

@@ -617,7 +617,6 @@ class RawVec:
 
 class ShellMat:
     """Matrix-free operator handle (PETSc MatShell + shell_context in the reference)."""
-    real_packed = False       # DNM_MAT_REAL_PACKED handle (set by build_mat)
 
     def __init__(self, handle, left_c, right_c, nranks, rank):
         self._h = handle
@@ -626,6 +625,9 @@ class ShellMat:
         M, N, m, n = (C.c_int64() for _ in range(4))
         _lib.check(_lib.lib().dnm_mat_sizes(handle, C.byref(M), C.byref(N), C.byref(m), C.byref(n)))
         self.M, self.N, self.m_local, self.n_local = M.value, N.value, m.value, n.value
+        rp = C.c_int()
+        _lib.check(_lib.lib().dnm_mat_is_real_packed(handle, C.byref(rp)))
+        self.real_packed = bool(rp.value)       # DNM_MAT_REAL_PACKED handle: real vectors, sizes in complex128 elements
         # layouts of y and x the matrix works in: the descriptors' where it supports them (Full / Parity swizzle, the
         # SpinConserve internal layout of a same-subspace pair on one rank), reference order otherwise
         ll, lr = C.c_int(), C.c_int()
@@ -1350,7 +1352,6 @@ def build_mat(masks, mask_offsets, signs, coeffs, left_subspace, right_subspace,
     h = create_mat(masks, mask_offsets, signs, coeffs, lc, rc, xparity, flags,
                    rank=config.rank, nranks=config.world_size)
     mat = ShellMat(h, lc, rc, config.world_size, config.rank)
-    mat.real_packed = bool(flags & _lib.MAT_REAL_PACKED)
     if not xparity:
         mat._msc = (np.array(masks, dtype=np.int64), np.array(mask_offsets, dtype=np.int64),
                     np.array(signs, dtype=np.int64), np.array(coeffs, dtype=np.complex128), left_subspace, right_subspace)

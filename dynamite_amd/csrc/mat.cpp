@@ -1071,6 +1071,12 @@ int dnm_mat_layouts(const dnm_mat *A, int *left, int *right) {
   return 0;
 }
 
+int dnm_mat_is_real_packed(const dnm_mat *A, int *packed) {
+  DNM_CHECK(A && packed, "null argument");
+  *packed = A->real_packed ? 1 : 0;
+  return 0;
+}
+
 // y = A x (- b z + c z2) in the SpinConserve internal layout; dot3 != null: the fused sums (device partials reduced here)
 static int sc3_mult(dnm_mat *A, const void *x, void *y, const void *z, double b, const void *z2, double c_re, double c_im,
                     double *dot3_host, void *stream, int64_t win_start = -1, int phase = 0) {

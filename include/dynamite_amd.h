@@ -203,6 +203,8 @@ int dnm_mat_norm_inf(dnm_mat *A, double *nrm, void *stream);
  * with another subspace or under XParity.  The caller converts (dnm_vec_layout_copy) when a
  * vector's layout differs.  With an internal layout dnm_mat_sizes reports the local lengths incl. padding. */
 int dnm_mat_layouts(const dnm_mat *A, int *left, int *right);
+/* 1 if the handle was built with DNM_MAT_REAL_PACKED and multiplies real vectors (sizes then count complex128 elements) */
+int dnm_mat_is_real_packed(const dnm_mat *A, int *packed);
 int dnm_mat_set_norm(dnm_mat *A, double nrm);
 /* human-readable description of the execution plan (passes, tiles) */
 int dnm_mat_plan_describe(const dnm_mat *A, char *buf, size_t buflen);

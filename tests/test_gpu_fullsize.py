@@ -271,7 +271,6 @@ def test_config5_rank3_of_eight_real_arithmetic():
     istart, ilen, nstart, nlen = backend.layout_partition(d, P, R)
     h = backend.create_mat(*arrs, d, d, flags=_lib.MAT_REAL_PACKED, rank=R, nranks=P)
     mat = backend.ShellMat(h, d, d, P, R)
-    mat.real_packed = True
     assert "two-pass" in mat.describe()
     assert (mat.row0, mat.m_local) == (istart // 2, ilen // 2)
     lo, hi = mat.column_window()                     # pairs of positions

@@ -30,7 +30,7 @@ def main():
     config._initialize()
     L = int(sys.argv[1]) if len(sys.argv) > 1 else 32
     sub = SpinConserve(L, L // 2)
-    for drop in (0, 1, 2, 3):
+    for drop in ([int(os.environ['DROP'])] if 'DROP' in os.environ else (0, 1, 2, 3)):
         H = chain(L, drop)
         H.establish_L()
         H.reduce_msc()
