@@ -965,10 +965,8 @@ int dnm_mat_create(int64_t nmasks, const int64_t *masks, const int64_t *mask_off
       // Partitions: every position the C ABI speaks of for such a handle -- ownership, column windows, chunk maps,
       // window starts -- counts complex128 ELEMENTS (pairs of entries; blocks of equal top bits start at multiples of 8
       // entries), so the caller's exchange code is the one it runs for complex vectors, on half the bytes
-      // (XParity's flip-composed hops read their columns backwards: the window pass on pairs of entries cannot)
-      DNM_CHECK(A->sc3->tiled && A->sc3->sym && !A->xparity,
-                "operator has an imaginary matrix element, is not a sum of pair hops, or lives under XParity: no "
-                "real-packed form in this layout");
+      DNM_CHECK(A->sc3->tiled && A->sc3->sym,
+                "operator has an imaginary matrix element or is not a sum of pair hops: no real-packed form in this layout");
       A->real_packed = true;
       A->m_local = A->n_local = il / 2;
     }

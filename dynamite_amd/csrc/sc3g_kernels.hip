@@ -554,7 +554,11 @@ sc3g_lo_pass_r(const Sc3Tab S, const Sc3Op O, const uint32_t *__restrict__ perm,
 // ---------------------------------------------------------------------------------------------------------
 // window pass: y (+)= (hops inside W from the LDS tile, hops between W and T and inside T gathered) x.  Workgroup =
 // (T, cw, run of R = 16 << s columns), the tile all window patterns of the class x R columns, as sc3_win_pass.
-template <int WB, int NT, bool SYM, bool ACC>
+// REALV: real vectors (DNM_MAT_REAL_PACKED): the kernel runs on the layout's halved position tables, an element being a
+// pair of adjacent real entries that gets the same real coefficient -- it never looks inside a pair, except where
+// XParity's flip-composed hops read their columns from the other end of the row: there the two entries of a pair come
+// from two real columns, in reverse order.
+template <int WB, int NT, bool SYM, bool ACC, bool REALV = false>
 __global__ void __launch_bounds__(NT, sc3_win_waves(NT, (cbinom(WB, WB / 2) * 16 * 16 + 1023) / 1024 + 12))
 sc3g_win_pass(const Sc3Tab S, const Sc3Op O, const uint32_t *__restrict__ perm, const Sc3Call C,
               const c128 *__restrict__ xw, c128 *__restrict__ y) {
@@ -677,7 +681,21 @@ sc3g_win_pass(const Sc3Tab S, const Sc3Op O, const uint32_t *__restrict__ perm, 
     const uint32_t xm = (uint32_t)rl_i32((int)g.xm, m);
     const int rev = rl_i32(g.rev, m);
     c128 v[RPT];
-    if (rev) {                     // rows by rank, columns from the other end of the row
+    if (rev && REALV) {            // ... of REAL entries: element (row, j) holds the real columns 2 (lr0 + j) and the next
+      const double *__restrict__ pr = reinterpret_cast<const double *>(pp - lr0);      // the partner class, in real entries
+      const int nlr = S.nl[kl];
+#pragma unroll
+      for (int i = 0; i < RPT; ++i) {
+        v[i] = make_double2(0.0, 0.0);
+        const uint32_t wp = wpat[i] & WM;
+        const int wrr = (int)(wpat[i] >> 16), c0 = 2 * (lr0 + off[i] - wrr * p);
+        if (off[i] >= 0 && c0 < nlr && __popc(wp & xm) == nd) {
+          const double *q = pr + (int64_t)wrk[wp ^ xm] * (2 * p) + (nlr - 1 - c0);
+          v[i].x = q[0];
+          if (c0 + 1 < nlr) v[i].y = q[-1];
+        }
+      }
+    } else if (rev) {              // rows by rank, columns from the other end of the row
       const int last = S.nl[kl] - 1 - lr0;            // column of the partner of this run's first column, from cbase - lr0
 #pragma unroll
       for (int i = 0; i < RPT; ++i) {
@@ -802,9 +820,9 @@ static int launch_graph_passes(const Sc3Mat &M, const Sc3Call &call, const doubl
   second.zinit = nullptr;
   second.zinit2 = nullptr;
   if (M.real) {
-    // real vectors: the window pass is the complex kernel on the halved tables (pairs of entries as elements: it never
-    // looks inside a row -- which is why the flip-composed hops of XParity, whose columns run backwards, have no real
-    // form), the lo pass its own kernel on doubles
+    // real vectors: the window pass is the complex kernel on the halved tables (pairs of entries as elements; its REALV
+    // instance takes the pairs apart where XParity's flip-composed hops read columns backwards), the lo pass its own
+    // kernel on doubles
     DNM_CHECK(M.sym, "internal: real vectors need a real operator");
     using kern_r = void (*)(const Sc3Tab, const Sc3Op, const uint32_t *, const Sc3Call, const double *, double *);
     kern_r kR = nullptr;
@@ -820,8 +838,13 @@ static int launch_graph_passes(const Sc3Mat &M, const Sc3Call &call, const doubl
     Sc3Call firstw = phase == 0 ? first : second;
     firstw.row0 /= 2;
     firstw.win_start /= 2;
+    kern_t kBr = lo_first ? (kern_t)sc3g_win_pass<W, NTW, true, true, true> : (kern_t)sc3g_win_pass<W, NTW, true, false, true>;
+    if (attr_done[(const void *)kBr] < ldsB) {
+      DNM_HIP(hipFuncSetAttribute((const void *)kBr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsB));
+      attr_done[(const void *)kBr] = ldsB;
+    }
     if (phase == 0 || phase == 2)
-      hipLaunchKernelGGL(kB, dim3((unsigned)M.permB.size()), dim3(NTW), ldsB, st, M.ly->dev_h, op, (const uint32_t *)M.d_permB,
+      hipLaunchKernelGGL(kBr, dim3((unsigned)M.permB.size()), dim3(NTW), ldsB, st, M.ly->dev_h, op, (const uint32_t *)M.d_permB,
                          firstw, (const c128 *)xw, (c128 *)y);
     if (phase == 0 || phase == 1)
       hipLaunchKernelGGL(kR, dim3((unsigned)(M.permA.size() / 8)), dim3(NTR), ldsR, st, S, op, (const uint32_t *)M.d_permA,

@@ -324,18 +324,21 @@ class Operator:
         amplitudes to a complex128 element (Full / Parity) or one double per position of the layout (SpinConserve) --
         half the bytes per multiply and per Krylov vector.  Not in the reference (its PETSc build is complex
         throughout); used inside ``eigsolve`` only, which hands back complex states as the reference does."""
-        from .subspaces import Full, Parity, SpinConserve
+        from .subspaces import Full, Parity, SpinConserve, XParity
         key = ('real_packed', hash(subspace))
         if key in self._mats:
             return self._mats[key]
         mat = None
-        sc = isinstance(subspace, SpinConserve) and subspace.vec_swizzle >= 256
+        # (XParity on top of a SpinConserve subspace in the internal layout: the same passes on the layout's first half)
+        xp = isinstance(subspace, XParity) and isinstance(subspace.parent, SpinConserve) and subspace.vec_swizzle >= 256
+        sc = xp or (isinstance(subspace, SpinConserve) and subspace.vec_swizzle >= 256)
         ws = config.world_size
         ok = sc or (isinstance(subspace, (Full, Parity)) and ws & (ws - 1) == 0)
         if ok and self.shell:
             self.establish_L()
             self.reduce_msc()
-            masks, mask_offsets = msc_tools.get_mask_offsets(self.msc)
+            msc = self.msc if subspace.product_state_basis else subspace.reduce_msc(self.msc)
+            masks, mask_offsets = msc_tools.get_mask_offsets(msc)
             sc_desc = subspace._to_c()
             if not sc and ws >= 4:
                 # Full / Parity on four or more ranks: the packed vectors are one index bit shorter, and the transposed
@@ -353,8 +356,8 @@ class Operator:
             try:
                 mat = backend.build_mat(
                     masks=np.ascontiguousarray(masks), mask_offsets=np.ascontiguousarray(mask_offsets),
-                    signs=np.ascontiguousarray(self.msc['signs']), coeffs=np.ascontiguousarray(self.msc['coeffs']),
-                    left_subspace=sc_desc, right_subspace=sc_desc, flags=_lib.MAT_REAL_PACKED)
+                    signs=np.ascontiguousarray(msc['signs']), coeffs=np.ascontiguousarray(msc['coeffs']),
+                    left_subspace=sc_desc, right_subspace=sc_desc, xparity=xp, flags=_lib.MAT_REAL_PACKED)
             except _lib.BackendError as e:
                 # the native layer's refusals all name the form: an imaginary matrix element, no chain operator in the
                 # SpinConserve layout, a vector too small for the tiled kernel.  Anything else (memory, a bad table) is

@@ -387,6 +387,25 @@ def test_xparity_production_instance():
     assert "bond graph" in d1 and "[T 6 | W 10 | Lo 14]" in d1, d1
     assert np.array_equal(x1, x2)
     assert np.abs(y1 - y2).max() <= 1e-12 * max(1.0, np.abs(y2).max())
+    # ... and the real-arithmetic handle of the same operator against the complex one on a real vector
+    import ctypes as C
+    import torch
+    from dynamite_amd import _lib
+    from dynamite_amd.subspaces import XParity
+    sub = XParity(SpinConserve(30, 15), '-')
+    H.add_subspace(sub)
+    cmat, rmat = H.get_mat(subspaces=(sub, sub)), H.get_real_packed_mat(sub)
+    assert rmat is not None and rmat.real_packed
+    xv, yv = cmat.createVecs()
+    xv.set_random(5)
+    xv.array.imag.zero_()
+    cmat.mult(xv, yv)
+    xd = xv.array.real.contiguous()
+    yd = torch.empty_like(xd)
+    _lib.check(_lib.lib().dnm_mat_mult(rmat.handle, C.c_void_p(xd.data_ptr()), C.c_void_p(yd.data_ptr()), None))
+    torch.cuda.synchronize()
+    assert float((yd - yv.array.real).abs().max()) <= 1e-12 * float(yv.array.real.abs().max())
+    H.destroy_mat()
 
 
 # ---- real arithmetic ---------------------------------------------------------------------------------------
@@ -452,4 +471,57 @@ def test_kagome_eigsolve_real_arithmetic(small_layout, monkeypatch, mode):
     xv = vecs[0].to_numpy()
     Hx = orc.matvec(orc_msc(H), orc_sub(sub), orc_sub(sub), xv)
     assert np.linalg.norm(Hx - vals[0] * xv) < 1e-8 and abs(np.linalg.norm(xv) - 1.0) < 1e-12
+    H.destroy_mat()
+
+
+@pytest.mark.parametrize("sector", ['+', '-'])
+@pytest.mark.parametrize("kind", ["kagome12", "graph14", "chain14"])
+def test_xparity_real_arithmetic(small_layout, kind, sector):
+    """XParity(SpinConserve) in REAL arithmetic: the lo pass ranks the complemented pattern as in complex128, the window
+    pass (on pairs of entries) takes the pairs apart where the flip-composed hops read columns from the other end of the
+    row.  The real handle's multiply against the complex one on the same real vector, then eigsolve against the
+    reference-built spectrum (kagome-12) / the complex solve."""
+    import ctypes as C
+    import torch
+    from dynamite_amd import _lib
+    from dynamite_amd.states import State
+    from dynamite_amd.subspaces import XParity
+    from dynamite_amd.computations import eigsolve
+    if kind == "kagome12":
+        H, L = models.kagome("12"), 12
+    elif kind == "graph14":
+        H, L = pair_graph(14, seed=23, nbonds=30, complex_hops=False, fields=False), 14
+    else:
+        H, L = models.heisenberg(14), 14
+    sub = XParity(SpinConserve(L, L // 2), sector)
+    H.add_subspace(sub)
+    cmat = H.get_mat(subspaces=(sub, sub))
+    rmat = H.get_real_packed_mat(sub)
+    assert rmat is not None and rmat.real_packed and "bond graph" in rmat.describe()
+    assert rmat.perm_left == cmat.perm_left
+    xv, yv = cmat.createVecs()
+    xv.set_random(11)
+    xv.array.imag.zero_()
+    cmat.mult(xv, yv)
+    xd = xv.array.real.contiguous()
+    yd = torch.full_like(xd, 3.0)
+    _lib.check(_lib.lib().dnm_mat_mult(rmat.handle, C.c_void_p(xd.data_ptr()), C.c_void_p(yd.data_ptr()), None))
+    torch.cuda.synchronize()
+    want = yv.array.real
+    assert float((yd - want).abs().max()) <= 1e-12 * max(1.0, float(want.abs().max())), rmat.describe()
+    assert float(yv.array.imag.abs().max()) == 0.0
+    config.eigs_real_arithmetic = True
+    try:
+        er = H.eigsolve(nev=1, subspace=sub, tol=1e-11)
+        assert eigsolve.last_stats["real_arithmetic"]
+        config.eigs_real_arithmetic = False
+        ec = H.eigsolve(nev=1, subspace=sub, tol=1e-11)
+        assert not eigsolve.last_stats["real_arithmetic"]
+    finally:
+        config.eigs_real_arithmetic = None
+    assert abs(er[0] - ec[0]) < 1e-9
+    if kind == "kagome12":
+        g = np.load(os.path.join(GOLDEN, "kagome.npz"))
+        pre = "kagome_12_sc_xparity_%s/" % ("plus" if sector == '+' else "minus")
+        assert abs(er[0] - g[pre + "evals_lowest"][0]) < 1e-9
     H.destroy_mat()
