@@ -892,7 +892,7 @@ int sc_rows_per_block() { return SC_NT; }
 int launch_sc_matvec(const DevMsc &msc, const ScMask *scm, const ScLow &low, const SubView &sub, int64_t M, int64_t row0,
                      int64_t win_start, const double *diag, const void *xw, void *y, int64_t *colrange,
                      hipStream_t st, ColMark mark) {
-  DNM_CHECK(M > 0 && (M + SC_NT - 1) / SC_NT < (int64_t)1 << 31, "row count out of range");
+  DNM_CHECK(M > 0 && M + SC_NT < (int64_t)1 << 32, "row count out of range (one thread per row, fewer than 2^32 per launch)");
   const dim3 grid((unsigned)sc_num_blocks(M)), blk(SC_NT);
   if ((sub.k + 1) * sub.ld <= NCK_LDS_MAX)
     hipLaunchKernelGGL(sc_matvec_kernel<true>, grid, blk, 0, st, msc, scm, low, sub, M, row0, win_start, diag,
@@ -1353,13 +1353,13 @@ norm_kernel(const DevMsc msc, const SubView left_g, const SubView right_g, int64
 template <int LT, int RT>
 __global__ void __launch_bounds__(GATHER_NT)
 conserves_kernel(const DevMsc msc, const double *__restrict__ coeffs_im, const SubView left_g,
-                 const SubView right_g, int64_t N, int *__restrict__ bad) {
+                 const SubView right_g, int64_t N, int *__restrict__ bad, int64_t col0) {
   __shared__ int64_t nck[NCK_LDS_MAX];
   int used = 0;
   const SubView left = stage_sub<LT>(left_g, nck, used);
   const SubView right = stage_sub<RT>(right_g, nck, used);
   if (used) __syncthreads();
-  const int64_t col = (int64_t)blockIdx.x * GATHER_NT + threadIdx.x;
+  const int64_t col = col0 + (int64_t)blockIdx.x * GATHER_NT + threadIdx.x;
   if (col >= N) return;
   const int64_t bra = Sub<RT>::i2s(col, right);
   for (int m = 0; m < msc.nmasks; ++m) {
@@ -1382,17 +1382,21 @@ conserves_kernel(const DevMsc msc, const double *__restrict__ coeffs_im, const S
 template <int LT>
 static int conserves_dispatch_r(const DevMsc &msc, const double *cim, const SubView &l, const SubView &r,
                                 int64_t N, int *bad, hipStream_t st) {
-  const dim3 grid((unsigned)((N + GATHER_NT - 1) / GATHER_NT)), blk(GATHER_NT);
-#define DNM_C(RT)                                                                                 \
-  case RT:                                                                                        \
-    hipLaunchKernelGGL((conserves_kernel<LT, RT>), grid, blk, 0, st, msc, cim, l, r, N, bad);     \
+  // (one thread per column, fewer than 2^32 threads to a launch: slices of 2^30 columns)
+  const int64_t SLICE = (int64_t)1 << 30;
+  for (int64_t c0 = 0; c0 < N; c0 += SLICE) {
+    const dim3 grid((unsigned)((std::min(SLICE, N - c0) + GATHER_NT - 1) / GATHER_NT)), blk(GATHER_NT);
+#define DNM_C(RT)                                                                                      \
+  case RT:                                                                                             \
+    hipLaunchKernelGGL((conserves_kernel<LT, RT>), grid, blk, 0, st, msc, cim, l, r, N, bad, c0);      \
     break;
-  switch (r.type) {
-    DNM_C(DNM_FULL) DNM_C(DNM_PARITY) DNM_C(DNM_SPIN_CONSERVE) DNM_C(DNM_EXPLICIT)
-    default: set_error("bad right subspace type"); return 1;
-  }
+    switch (r.type) {
+      DNM_C(DNM_FULL) DNM_C(DNM_PARITY) DNM_C(DNM_SPIN_CONSERVE) DNM_C(DNM_EXPLICIT)
+      default: set_error("bad right subspace type"); return 1;
+    }
 #undef DNM_C
-  DNM_HIP(hipGetLastError());
+    DNM_HIP(hipGetLastError());
+  }
   return 0;
 }
 
@@ -1434,7 +1438,7 @@ int gather_rows_per_block() { return GATHER_NT; }
 int launch_gather_matvec(const DevMsc &msc, const SubView &left, const SubView &right, int64_t M,
                          const double *diag, const void *x, void *y, hipStream_t st, int64_t row0,
                          int64_t win_start, int xswz, int64_t *colrange, ColMark mark) {
-  DNM_CHECK(M > 0 && (M + GATHER_NT - 1) / GATHER_NT < (int64_t)1 << 31, "row count out of range");
+  DNM_CHECK(M > 0 && M + GATHER_NT < (int64_t)1 << 32, "row count out of range (one thread per row, fewer than 2^32 per launch)");
   if (xswz < 0) xswz = right.swz;
   switch (left.type) {
     case DNM_FULL: return gather_dispatch_r<DNM_FULL>(msc, left, right, M, row0, win_start, xswz, diag, x, y, colrange, st, mark);
@@ -1447,15 +1451,21 @@ int launch_gather_matvec(const DevMsc &msc, const SubView &left, const SubView &
 }
 
 int launch_diag(const DevMsc &msc, const SubView &sub, int64_t M, int64_t row0, double *diag, hipStream_t st) {
-  const dim3 grid((unsigned)((M + GATHER_NT - 1) / GATHER_NT)), blk(GATHER_NT);
-  switch (sub.type) {
-    case DNM_FULL: hipLaunchKernelGGL((diag_kernel<DNM_FULL>), grid, blk, 0, st, msc, sub, M, row0, diag); break;
-    case DNM_PARITY: hipLaunchKernelGGL((diag_kernel<DNM_PARITY>), grid, blk, 0, st, msc, sub, M, row0, diag); break;
-    case DNM_SPIN_CONSERVE: hipLaunchKernelGGL((diag_kernel<DNM_SPIN_CONSERVE>), grid, blk, 0, st, msc, sub, M, row0, diag); break;
-    case DNM_EXPLICIT: hipLaunchKernelGGL((diag_kernel<DNM_EXPLICIT>), grid, blk, 0, st, msc, sub, M, row0, diag); break;
-    default: set_error("bad subspace type"); return 1;
+  // One thread per row, and a launch holds fewer than 2^32 threads: rows go in slices of 2^30 (XParity on
+  // SpinConserve(36,18) has 4.54 G of them -- its first run, round 5, silently computed with no diagonal at all)
+  const int64_t SLICE = (int64_t)1 << 30;
+  for (int64_t r0 = 0; r0 < M; r0 += SLICE) {
+    const int64_t m = std::min(SLICE, M - r0);
+    const dim3 grid((unsigned)((m + GATHER_NT - 1) / GATHER_NT)), blk(GATHER_NT);
+    switch (sub.type) {
+      case DNM_FULL: hipLaunchKernelGGL((diag_kernel<DNM_FULL>), grid, blk, 0, st, msc, sub, m, row0 + r0, diag + r0); break;
+      case DNM_PARITY: hipLaunchKernelGGL((diag_kernel<DNM_PARITY>), grid, blk, 0, st, msc, sub, m, row0 + r0, diag + r0); break;
+      case DNM_SPIN_CONSERVE: hipLaunchKernelGGL((diag_kernel<DNM_SPIN_CONSERVE>), grid, blk, 0, st, msc, sub, m, row0 + r0, diag + r0); break;
+      case DNM_EXPLICIT: hipLaunchKernelGGL((diag_kernel<DNM_EXPLICIT>), grid, blk, 0, st, msc, sub, m, row0 + r0, diag + r0); break;
+      default: set_error("bad subspace type"); return 1;
+    }
+    DNM_HIP(hipGetLastError());
   }
-  DNM_HIP(hipGetLastError());
   return 0;
 }
 

@@ -492,3 +492,22 @@ def test_full_space_solver_beyond_the_complex_limit():
         config.L = saved
         _lib.check(_lib.lib().dnm_release_workspace())
         torch.cuda.empty_cache()
+
+
+@pytest.mark.skipif(os.environ.get('DNM_TEST_LARGEST') != '1', reason='largest single-GPU problems: opt-in (DNM_TEST_LARGEST=1), run in the builder\'s sessions')
+def test_kagome36_ground_state_on_one_gpu():
+    """The 36-site kagome torus in XParity(SpinConserve(36, 18)) -- 4.54 G representatives, more than 2^32: the size at
+    which a one-thread-per-row launch (the cached diagonal's) silently did nothing before its rows went out in slices --
+    ground state by Lanczos without a stored basis in real arithmetic (36 GB per vector).  E / N of the 36-site kagome
+    tori lies at -0.438 (Lauchli et al., PRB 83, 212401, table 1); the first run of this case returned -0.382, the
+    energy of the operator without its diagonal."""
+    from dynamite_amd.subspaces import XParity
+    from dynamite_amd.computations import eigsolve
+    H = models.kagome("36a")
+    sub = XParity(SpinConserve(36, 18), sector=+1)
+    H.add_subspace(sub)
+    ev = H.eigsolve(nev=1, subspace=sub)
+    st = eigsolve.last_stats
+    assert st["real_arithmetic"] and st["max_rel_residual"] <= 1.01e-8
+    assert -0.4395 < ev[0] / 36 < -0.4370, ev[0] / 36
+    H.destroy_mat()
