@@ -525,3 +525,49 @@ def test_xparity_real_arithmetic(small_layout, kind, sector):
         pre = "kagome_12_sc_xparity_%s/" % ("plus" if sector == '+' else "minus")
         assert abs(er[0] - g[pre + "evals_lowest"][0]) < 1e-9
     H.destroy_mat()
+
+
+def test_states_in_a_relabelled_layout_behave_like_any_state(small_layout, tmp_path):
+    """A state that has adopted an operator's relabelled layout (an eigenvector of the kagome model) through the rest of
+    the State surface: reduced density matrix and entropy against the oracle's, save / from_file, set_product, project,
+    expectation -- everything index-wise stays in the reference's order (states.py:102-241, 403-447, 627-701)."""
+    from dynamite_amd.states import State
+    from dynamite_amd.computations import reduced_density_matrix, entanglement_entropy
+    from dynamite_amd.operators import sigmaz
+    H = models.kagome("15")
+    sub = SpinConserve(15, 7)
+    H.add_subspace(sub)
+    vals, vecs = H.eigsolve(nev=1, getvecs=True, subspace=sub, tol=1e-11)
+    psi = vecs[0]
+    assert psi.vec.perm is not None
+    x = psi.to_numpy()
+    keep = [0, 3, 4, 9]
+    rho = reduced_density_matrix(psi, keep)
+    want = orc.rdm(orc_sub(sub), x, np.array(keep, dtype=np.int64))
+    assert np.abs(rho - want).max() < 1e-12
+    s = entanglement_entropy(psi, keep)
+    w = np.linalg.eigvalsh(want)
+    assert abs(s + np.sum(w[w > 1e-300] * np.log(w[w > 1e-300]))) < 1e-10
+    fn = str(tmp_path / "kagome_state")
+    psi.save(fn)
+    back = State.from_file(fn)
+    assert np.array_equal(back.to_numpy(), x) and back.vec.perm is None
+    assert abs(back.dot(psi) - 1.0) < 1e-12                                  # two layouts, one inner product
+    Z = sigmaz(3)
+    Z.L = 15
+    Z.add_subspace(sub)
+    ez = Z.expectation(psi)
+    st = orc_sub(sub).i2s(np.arange(sub.get_dimension()))
+    assert abs(ez - np.sum((1 - 2 * ((st >> 3) & 1)) * np.abs(x) ** 2)) < 1e-12
+    # an index-wise write into a vector of the relabelled layout
+    phi = State(L=15, subspace=sub)
+    phi._vec = H.get_mat(subspaces=(sub, sub)).createVecs()[0]
+    phi.set_product('U' * 8 + 'D' * 7)
+    arr = phi.to_numpy()
+    idx = sub.state_to_idx(int('1' * 7 + '0' * 8, 2))
+    assert arr[idx] == 1.0 and np.count_nonzero(arr) == 1
+    e1 = H.expectation(phi)
+    ref = orc.matvec(orc_msc(H), orc_sub(sub), orc_sub(sub), arr)
+    assert abs(e1 - np.vdot(arr, ref).real) < 1e-12
+    H.destroy_mat()
+    Z.destroy_mat()
