@@ -1659,6 +1659,35 @@ int Sc3Mat::init(const Sc3Layout *layout, const std::vector<int64_t> &masks, con
     }
   }
   permA = pack_lo_rows(deal(gA), *ly, a == 14 ? 1024 : 256, real);       // thread counts of launch_sc3's instances
+  // Bond graphs, window pass: a hop between W and T couples the class (T, cw) to (T ^ bit, cw -+ 1) at the same columns
+  // -- the same number of ones in Lo.  Workgroups of one Lo population and one block of 256 columns form a group,
+  // ordered by their first column inside it, so that such partners run on one XCD at about the same time (the chain's
+  // groups hold the T's of one popcount class only: partners under the hops inside T, which this order keeps together
+  // as well).  kagome-30: the pass's fetch 59.6 -> 28.6 B/row, L2 hits 49 -> 70 %, 2.40 -> 2.22 ms
+  // (profiles/r05_kagome_window_order.txt; DNM_SC3G_WORDER=0: the chain's order).
+  if (graph && !(knob("DNM_SC3G_WORDER") && knob("DNM_SC3G_WORDER")[0] == '0')) {
+    struct Wg { uint32_t e; int kl, col; };
+    std::vector<Wg> all;
+    for (auto &g : gB)
+      for (uint32_t e : g) {
+        const uint32_t T = e >> 16;
+        const int cw = (e >> 12) & 15, run = e & 0xfff;
+        all.push_back({e, k - __builtin_popcount(T) - cw, run * (16 << S.rs[cw])});
+      }
+    std::stable_sort(all.begin(), all.end(), [](const Wg &x, const Wg &y) {
+      if (x.kl != y.kl) return x.kl < y.kl;
+      if ((x.col >> 8) != (y.col >> 8)) return (x.col >> 8) < (y.col >> 8);
+      return x.col < y.col;
+    });
+    gB.clear();
+    for (size_t i = 0; i < all.size();) {
+      size_t j = i;
+      std::vector<uint32_t> g;
+      while (j < all.size() && all[j].kl == all[i].kl && (all[j].col >> 8) == (all[i].col >> 8)) g.push_back(all[j++].e);
+      gB.push_back(g);
+      i = j;
+    }
+  }
   permB = deal(gB);
   if (permA.empty()) permA.assign(8, 0xffffffffu);
   if (permB.empty()) permB.assign(8, 0xffffffffu);

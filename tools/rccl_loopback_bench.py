@@ -77,6 +77,16 @@ def main():
             return (time.perf_counter() - t0) / n * 1e3
         t_full = timed(lambda: mat.mult(x, y))
         t_exch = timed(lambda: mat.exchange_only(x))
+        # the same multiply as ONE native call (dnm_mat_mult_partitioned, csrc/comm.cpp): the library's own communicator
+        # (sharing this process's RCCL) standing for this rank, every peer's block = this rank's x (round 5)
+        import ctypes as C
+        comm = backend.native_comm()
+        px = (C.c_void_p * P)(*[x.array.data_ptr()] * P)
+        _lib.check(_lib.lib().dnm_comm_loopback(comm, me, P, px, None))
+        t_native = timed(lambda: _lib.check(_lib.lib().dnm_mat_mult_partitioned(mat.handle, comm, x.ptr, y.ptr, backend._stream())))
+        _lib.check(_lib.lib().dnm_comm_forget(comm, mat.handle))
+        print("   the same as one native call (dnm_mat_mult_partitioned, exchange on the library's own stream): %.2f ms" % t_native,
+              flush=True)
         L_ = _lib.lib()
         t_local = timed(lambda: _lib.check(L_.dnm_mat_mult_local(mat.handle, x.ptr, y.ptr, backend._stream())))
 
