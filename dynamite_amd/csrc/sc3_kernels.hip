@@ -1659,13 +1659,16 @@ int Sc3Mat::init(const Sc3Layout *layout, const std::vector<int64_t> &masks, con
     }
   }
   permA = pack_lo_rows(deal(gA), *ly, a == 14 ? 1024 : 256, real);       // thread counts of launch_sc3's instances
-  // Bond graphs, window pass: a hop between W and T couples the class (T, cw) to (T ^ bit, cw -+ 1) at the same columns
-  // -- the same number of ones in Lo.  Workgroups of one Lo population and one block of 256 columns form a group,
-  // ordered by their first column inside it, so that such partners run on one XCD at about the same time (the chain's
-  // groups hold the T's of one popcount class only: partners under the hops inside T, which this order keeps together
-  // as well).  kagome-30: the pass's fetch 59.6 -> 28.6 B/row, L2 hits 49 -> 70 %, 2.40 -> 2.22 ms
-  // (profiles/r05_kagome_window_order.txt; DNM_SC3G_WORDER=0: the chain's order).
-  if (graph && !(knob("DNM_SC3G_WORDER") && knob("DNM_SC3G_WORDER")[0] == '0')) {
+  // Window pass: a hop between W and T (the chain's W/T boundary bond; any such pair of a bond graph) couples the class
+  // (T, cw) to (T ^ bit, cw -+ 1) at the same columns -- the same number of ones in Lo.  Workgroups of one Lo population
+  // and one block of 256 columns form a group, ordered by their first column inside it, so that such partners run on one
+  // XCD at about the same time (the first order grouped the T's of one popcount class at fixed (cw, run): partners under
+  // the hops inside T only, which this order keeps together as well).  kagome-30: the pass's fetch 59.6 -> 28.6 B/row, L2
+  // hits 49 -> 70 %, 2.40 -> 2.22 ms (profiles/r05_kagome_window_order.txt); chains: SpinConserve(32,16) 35.8 -> 30.5
+  // B/row, 5.30 -> 5.07 ms, a rank of config 5 24.6 -> 24.2 ms (profiles/r05_chain_window_order.txt).
+  // DNM_SC3G_WORDER=0: the first order.
+  const char *worder = knob("DNM_SC3G_WORDER");
+  if (!(worder && worder[0] == '0')) {
     struct Wg { uint32_t e; int kl, col; };
     std::vector<Wg> all;
     for (auto &g : gB)
