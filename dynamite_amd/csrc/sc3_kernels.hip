@@ -1661,7 +1661,7 @@ int Sc3Mat::init(const Sc3Layout *layout, const std::vector<int64_t> &masks, con
   permA = pack_lo_rows(deal(gA), *ly, a == 14 ? 1024 : 256, real);       // thread counts of launch_sc3's instances
   // Window pass: a hop between W and T (the chain's W/T boundary bond; any such pair of a bond graph) couples the class
   // (T, cw) to (T ^ bit, cw -+ 1) at the same columns -- the same number of ones in Lo.  Workgroups of one Lo population
-  // and one block of 256 columns form a group, ordered by their first column inside it, so that such partners run on one
+  // and one block of 64 columns form a group, ordered by their first column inside it, so that such partners run on one
   // XCD at about the same time (the first order grouped the T's of one popcount class at fixed (cw, run): partners under
   // the hops inside T only, which this order keeps together as well).  kagome-30: the pass's fetch 59.6 -> 28.6 B/row, L2
   // hits 49 -> 70 %, 2.40 -> 2.22 ms (profiles/r05_kagome_window_order.txt); chains: SpinConserve(32,16) 35.8 -> 30.5
@@ -1677,16 +1677,18 @@ int Sc3Mat::init(const Sc3Layout *layout, const std::vector<int64_t> &masks, con
         const int cw = (e >> 12) & 15, run = e & 0xfff;
         all.push_back({e, k - __builtin_popcount(T) - cw, run * (16 << S.rs[cw])});
       }
-    std::stable_sort(all.begin(), all.end(), [](const Wg &x, const Wg &y) {
+    int bs = 6;                                        // log2 of the column block (2^5 ... 2^7 level, 2^8: +1.5 %, 2^10: +6 %)
+    if (const char *e = knob("DNM_SC3G_WBLOCK")) bs = atoi(e);
+    std::stable_sort(all.begin(), all.end(), [bs](const Wg &x, const Wg &y) {
       if (x.kl != y.kl) return x.kl < y.kl;
-      if ((x.col >> 8) != (y.col >> 8)) return (x.col >> 8) < (y.col >> 8);
+      if ((x.col >> bs) != (y.col >> bs)) return (x.col >> bs) < (y.col >> bs);
       return x.col < y.col;
     });
     gB.clear();
     for (size_t i = 0; i < all.size();) {
       size_t j = i;
       std::vector<uint32_t> g;
-      while (j < all.size() && all[j].kl == all[i].kl && (all[j].col >> 8) == (all[i].col >> 8)) g.push_back(all[j++].e);
+      while (j < all.size() && all[j].kl == all[i].kl && (all[j].col >> bs) == (all[i].col >> bs)) g.push_back(all[j++].e);
       gB.push_back(g);
       i = j;
     }
