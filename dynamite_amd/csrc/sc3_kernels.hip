@@ -1633,26 +1633,39 @@ int Sc3Mat::init(const Sc3Layout *layout, const std::vector<int64_t> &masks, con
   // the partner blocks of the hops between Lo and T are at least in the Infinity Cache.  DNM_SC3G_ORDER=0: the chain's
   // order (pairs under window bit 0).
   if (graph && !(knob("DNM_SC3G_ORDER") && knob("DNM_SC3G_ORDER")[0] == '0')) {
-    uint32_t jw = 0;
-    for (size_t q = nh[0]; q < nh[0] + nh[1]; ++q)
-      if (hops[q].mT == 0 && __builtin_popcount(hops[q].mW) == 1) jw |= hops[q].mW;
-    while (__builtin_popcount(jw) > 6) jw &= jw - 1;              // at most 64 rows to a group (what an XCD holds)
+    // the bits of a row's id (T << w | W) its gathered hops flip, by the number of hops that flip them; the six most
+    // used ones span a group (DNM_SC3G_ORDER=w: window bits only, the first form of this order)
+    const bool wonly = knob("DNM_SC3G_ORDER") && knob("DNM_SC3G_ORDER")[0] == 'w';
+    std::vector<std::pair<int, int>> use;                        // (-count, bit)
+    for (int b = 0; b < t + w; ++b) {
+      int cnt = 0;
+      for (size_t q = nh[0]; q < nh[0] + nh[1]; ++q) {
+        const uint64_t fl = ((uint64_t)hops[q].mT << w) | hops[q].mW;
+        if (__builtin_popcountll(fl) == 1 && ((fl >> b) & 1ull) && !(wonly && b >= w)) ++cnt;
+      }
+      if (cnt) use.push_back({-cnt, b});
+    }
+    std::sort(use.begin(), use.end());
+    uint32_t jm = 0;
+    for (size_t q = 0; q < use.size() && q < 6; ++q) jm |= 1u << use[q].second;     // at most 64 rows to a group (what an XCD holds)
     gA.clear();
     std::vector<uint32_t> subs;
-    for (uint32_t sset = jw;; sset = (sset - 1) & jw) {           // the subsets of jw, descending
+    for (uint32_t sset = jm;; sset = (sset - 1) & jm) {           // the subsets of jm, descending
       subs.push_back(sset);
       if (!sset) break;
     }
     std::reverse(subs.begin(), subs.end());
+    const uint32_t wm = (1u << w) - 1u;
     for (uint32_t W0 = 0; W0 < (1u << w); ++W0) {
-      if (W0 & jw) continue;
-      for (uint32_t T = T0; T < T1 && T < (1u << t); ++T) {
-        if (ly->ibase[T] < 0) continue;
-        const int kr = k - __builtin_popcount(T);
+      if (W0 & jm & wm) continue;
+      for (uint32_t Tb = 0; Tb < (1u << t); ++Tb) {
+        if ((Tb << w) & jm) continue;
         std::vector<uint32_t> g;
         for (uint32_t sset : subs) {
-          const int kl = kr - __builtin_popcount(W0 | sset);
-          if (kl >= 0 && kl <= a) g.push_back((T << w) | W0 | sset);
+          const uint32_t id = ((Tb << w) | W0) | sset, T = id >> w, W = id & wm;
+          if (T < T0 || T >= T1 || ly->ibase[T] < 0) continue;
+          const int kl = k - __builtin_popcount(T) - __builtin_popcount(W);
+          if (kl >= 0 && kl <= a) g.push_back(id);
         }
         if (!g.empty()) gA.push_back(g);
       }
