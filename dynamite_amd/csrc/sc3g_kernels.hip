@@ -46,8 +46,14 @@ sc3g_lo_pass(const Sc3Tab S, const Sc3Op O, const uint32_t *__restrict__ perm, c
              const c128 *__restrict__ xw, c128 *__restrict__ y) {
   constexpr int MAXROWS = cbinom(A, A / 2);
   constexpr int RPT = (MAXROWS + NT - 1) / NT;
-  constexpr int H = A / 2, HB = A - H;
+  constexpr int H = A / 2, HB = A - H, HS = ilog2c(H + 1);
   constexpr uint32_t HM = (1u << H) - 1u;
+  static_assert((1 << HS) == H + 1, "the rows of lo_rhi must be a power of two long (a = 6, 14)");
+  // The rank of a flipped pattern costs: byte offsets of its two halves into the LDS tables, two 16-bit reads, one add.
+  // The tables hold the ranks times 16 (the byte offset of a tile entry); where registers allow (no on-the-fly diagonal)
+  // an entry keeps the two byte offsets of its own pattern and a hop flips them with its own (XOR commutes with the
+  // shifts): 10 vector instructions per (entry, hop) where the first form of this loop had 16 (round 5, lab notes).
+  constexpr bool HOIST = DIAGM != 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ uint16_t rka[1 << H];
   __shared__ uint16_t rkb[(1 << HB) * (H + 1)];
@@ -124,13 +130,36 @@ sc3g_lo_pass(const Sc3Tab S, const Sc3Op O, const uint32_t *__restrict__ perm, c
 #pragma unroll
   for (int i = 0; i < ((1 << H) + NT - 1) / NT; ++i) {
     const int tt = threadIdx.x + i * NT;
-    if (tt < (1 << H)) rka[tt] = tka[i];
+    if (tt < (1 << H)) rka[tt] = (uint16_t)(tka[i] << 4);
   }
 #pragma unroll
   for (int i = 0; i < ((1 << HB) * (H + 1) + NT - 1) / NT; ++i) {
     const int tt = threadIdx.x + i * NT;
-    if (tt < (1 << HB) * (H + 1)) rkb[tt] = tkb[i];
+    if (tt < (1 << HB) * (H + 1)) rkb[tt] = (uint16_t)(tkb[i] << 4);
   }
+  const unsigned char *rkab = reinterpret_cast<const unsigned char *>(rka), *rkbb = reinterpret_cast<const unsigned char *>(rkb);
+  uint32_t elo[HOIST ? RPT : 1], ehi[HOIST ? RPT : 1];
+  if constexpr (HOIST) {
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+      elo[i] = (lowb[i] & HM) << 1;
+      ehi[i] = (lowb[i] >> H) << (HS + 1);
+    }
+  }
+  // byte offset of the tile entry of (pattern of entry i) ^ (mask m; its halves' offsets mlo, mhi)
+  auto flipped = [&](int i, uint32_t m, uint32_t mlo, uint32_t mhi) -> uint32_t {
+    uint32_t t, u;
+    if constexpr (HOIST) {
+      t = elo[i] ^ mlo;
+      u = ehi[i] ^ mhi;
+    } else {
+      const uint32_t p2 = lowb[i] ^ m;
+      t = (p2 & HM) << 1;
+      u = (p2 >> H) << (HS + 1);
+    }
+    return (uint32_t)*reinterpret_cast<const uint16_t *>(rkab + t) +
+           (uint32_t)*reinterpret_cast<const uint16_t *>(rkbb + (u | ((uint32_t)__popc(t) << 1)));
+  };
   // on-the-fly diagonal: per-row sums by the first wavefront of each sub-group (as sc3_lo_pass)
   if (DIAGM == 2 && tsub < 64) {
     const uint64_t hi = ((uint64_t)T << w) | W;
@@ -178,16 +207,14 @@ sc3g_lo_pass(const Sc3Tab S, const Sc3Op O, const uint32_t *__restrict__ perm, c
     const double cr = rl_f64(g.c0, m), ci = rl_f64(g.c1, m);
     const int nd = rl_i32(g.need, m);
     const uint32_t xm = (uint32_t)rl_i32((int)g.xm, m);
+    const uint32_t xlo = (xm & HM) << 1, xhi = (xm >> H) << (HS + 1);
     c128 v[RPT];
 #pragma unroll
     for (int i = 0; i < RPT; ++i) {
       const int r = tsub + i * NTS;
       v[i] = make_double2(0.0, 0.0);
-      if (r < nrows && __popc(lowb[i] & xm) == nd) {
-        const uint32_t p2 = lowb[i] ^ xm;
-        const int col = (int)rka[p2 & HM] + (int)rkb[(p2 >> H) * (H + 1) + __popc(p2 & HM)];
-        v[i] = pp[col];
-      }
+      if (r < nrows && __popc(lowb[i] & xm) == nd)
+        v[i] = *reinterpret_cast<const c128 *>(reinterpret_cast<const unsigned char *>(pp) + flipped(i, xm, xlo, xhi));
     }
 #pragma unroll
     for (int i = 0; i < RPT; ++i) {
@@ -236,15 +263,14 @@ sc3g_lo_pass(const Sc3Tab S, const Sc3Op O, const uint32_t *__restrict__ perm, c
   for (int hq = 0; hq < O.nldsA; ++hq) {
     const auto hp = SC3_CP(Sc3Hop, O.ldsA) + hq;
     const uint32_t m = hp->mLo;
+    const uint32_t mlo = (m & HM) << 1, mhi = (m >> H) << (HS + 1);
     const int half = hp->half, dbit = hp->dbit;
     const double ure = hp->up_re, uim = hp->up_im, dre = hp->dn_re, dim_ = hp->dn_im;
 #pragma unroll
     for (int i = 0; i < RPT; ++i) {
       const int r = tsub + i * NTS;
       if (r < nrows && __popc(lowb[i] & m) == half) {
-        const uint32_t p2 = lowb[i] ^ m;
-        const int col = (int)rka[p2 & HM] + (int)rkb[(p2 >> H) * (H + 1) + __popc(p2 & HM)];
-        const c128 xp = xs[col];
+        const c128 xp = *reinterpret_cast<const c128 *>(reinterpret_cast<const unsigned char *>(xs) + flipped(i, m, mlo, mhi));
         if (SYM) {
           accr[i] = fma(ure, xp.x, accr[i]);
           acci[i] = fma(ure, xp.y, acci[i]);
@@ -323,8 +349,9 @@ sc3g_lo_pass_r(const Sc3Tab S, const Sc3Op O, const uint32_t *__restrict__ perm,
                const double *__restrict__ xw, double *__restrict__ y) {
   constexpr int MAXROWS = cbinom(A, A / 2);
   constexpr int EPT = 2 * PPT;
-  constexpr int H = A / 2, HB = A - H;
+  constexpr int H = A / 2, HB = A - H, HS = ilog2c(H + 1);
   constexpr uint32_t HM = (1u << H) - 1u;
+  static_assert((1 << HS) == H + 1, "the rows of lo_rhi must be a power of two long (a = 6, 14)");
   static_assert(NT * EPT >= MAXROWS, "the longest row does not fit the workgroup");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ uint16_t rka[1 << H];
@@ -401,13 +428,20 @@ sc3g_lo_pass_r(const Sc3Tab S, const Sc3Op O, const uint32_t *__restrict__ perm,
 #pragma unroll
   for (int i = 0; i < ((1 << H) + NT - 1) / NT; ++i) {
     const int tt = threadIdx.x + i * NT;
-    if (tt < (1 << H)) rka[tt] = tka[i];
+    if (tt < (1 << H)) rka[tt] = (uint16_t)(tka[i] << 3);         // ranks times 8: byte offsets of real entries
   }
 #pragma unroll
   for (int i = 0; i < ((1 << HB) * (H + 1) + NT - 1) / NT; ++i) {
     const int tt = threadIdx.x + i * NT;
-    if (tt < (1 << HB) * (H + 1)) rkb[tt] = tkb[i];
+    if (tt < (1 << HB) * (H + 1)) rkb[tt] = (uint16_t)(tkb[i] << 3);
   }
+  const unsigned char *rkab = reinterpret_cast<const unsigned char *>(rka), *rkbb = reinterpret_cast<const unsigned char *>(rkb);
+  // byte offset of the entry of a flipped pattern p2 (as in sc3g_lo_pass; no registers here to keep an entry's own offsets)
+  auto rank8 = [&](uint32_t p2) -> uint32_t {
+    const uint32_t t = (p2 & HM) << 1;
+    return (uint32_t)*reinterpret_cast<const uint16_t *>(rkab + t) +
+           (uint32_t)*reinterpret_cast<const uint16_t *>(rkbb + (((p2 >> H) << (HS + 1)) | ((uint32_t)__popc(t) << 1)));
+  };
   if (DIAGM == 2 && tsub < 64) {
     const uint64_t hi = ((uint64_t)T << w) | W;
     double v0 = 0.0, vm[4] = {0.0, 0.0, 0.0, 0.0};
@@ -459,10 +493,8 @@ sc3g_lo_pass_r(const Sc3Tab S, const Sc3Op O, const uint32_t *__restrict__ perm,
       const int r = SC3R_ENT(i);
       const uint32_t pt = SC3R_PAT(i);
       v[i] = 0.0;
-      if (r < nrows && __popc(pt & xm) == nd) {
-        const uint32_t p2 = pt ^ xm;
-        v[i] = pp[(int)rka[p2 & HM] + (int)rkb[(p2 >> H) * (H + 1) + __popc(p2 & HM)]];
-      }
+      if (r < nrows && __popc(pt & xm) == nd)
+        v[i] = *reinterpret_cast<const double *>(reinterpret_cast<const unsigned char *>(pp) + rank8(pt ^ xm));
     }
 #pragma unroll
     for (int i = 0; i < EPT; ++i) acc[i] = fma(cr, v[i], acc[i]);
@@ -499,10 +531,8 @@ sc3g_lo_pass_r(const Sc3Tab S, const Sc3Op O, const uint32_t *__restrict__ perm,
     for (int i = 0; i < EPT; ++i) {
       const int r = SC3R_ENT(i);
       const uint32_t pt = SC3R_PAT(i);
-      if (r < nrows && __popc(pt & m) == half) {
-        const uint32_t p2 = pt ^ m;
-        acc[i] = fma(ure, xs[(int)rka[p2 & HM] + (int)rkb[(p2 >> H) * (H + 1) + __popc(p2 & HM)]], acc[i]);
-      }
+      if (r < nrows && __popc(pt & m) == half)
+        acc[i] = fma(ure, *reinterpret_cast<const double *>(reinterpret_cast<const unsigned char *>(xs) + rank8(pt ^ m)), acc[i]);
     }
   }
   double dr = 0.0, dn = 0.0;
