@@ -610,6 +610,12 @@ class RawVec:
         self.array, self.swz = array, int(swz)
         self.local_size = self.rows = array.numel()
 
+    def positions(self, idx):
+        S = self.swz
+        if S >= 256:
+            raise ValueError('no index-wise access to a raw vector of the SpinConserve layout')
+        return idx if not S else idx ^ (((idx >> S) & ((1 << (S - 4)) - 1)) << 4)
+
     @property
     def ptr(self):
         return C.c_void_p(self.array.data_ptr())
@@ -839,13 +845,29 @@ class ShellMat:
             return 1.0, 1.0
         masks, offs, signs, coeffs, lsub, rsub = self._msc
         lib = _lib.lib()
+        # A real-packed handle (Full / Parity; eigsolve's real arithmetic) holds two real amplitudes per complex128
+        # element: the rows sampled are REAL indices -- element index >> 1 through the vector's own swizzle, lane index
+        # & 1 -- and the operator's (real) matrix elements are applied to real amplitudes (the packed
+        # transposed exchange ran unguarded).
+        packed = bool(self.real_packed)
+        if packed and (x.swz >= 256 or y.swz >= 256):
+            raise RuntimeError('selfcheck: no packed mode for the SpinConserve internal layout')
+
+        def read(v, local_idx):
+            """amplitudes of the local (real, if packed) indices of a vector"""
+            idx = torch.from_numpy(np.ascontiguousarray(local_idx, dtype=np.int64)).to(v.array.device)
+            if not packed:
+                return v.array[v.positions(idx)].cpu().numpy()
+            flat = torch.view_as_real(v.array).reshape(-1)
+            return flat[2 * v.positions(idx >> 1) + (idx & 1)].cpu().numpy()
+        mult = 2 if packed else 1
 
         def maps(sub, fn, vals):
             vals = np.ascontiguousarray(vals, dtype=np.int64)
             out = np.empty_like(vals)
             _lib.check(fn(C.byref(sub['data']), vals.size, _lib.p64(vals), _lib.p64(out)))
             return out
-        nloc = y.rows
+        nloc = mult * y.rows
         # rows: both ends, the middle and the neighbourhood of every power of two of the local index
         cand = {0, nloc - 1, nloc // 2}
         b = 1
@@ -855,14 +877,15 @@ class ShellMat:
         rs = np.random.RandomState(1234 + self.rank)
         rows = sorted(cand)[:max(0, nsample // 2)]
         rows = np.unique(np.concatenate([np.asarray(rows, dtype=np.int64), rs.randint(0, nloc, size=nsample - len(rows))]))
-        grow = rows + y.start
+        ystart = mult * (y.start if hasattr(y, 'start') else self.rank * y.rows)
+        grow = rows + ystart
         kets = maps(lsub, lib.dnm_idx_to_state, grow)
         bras = kets[:, None] ^ np.asarray(masks, dtype=np.int64)[None, :]
         cols = maps(rsub, lib.dnm_state_to_idx, bras.reshape(-1)).reshape(bras.shape)
         # fetch x[col] from the owners
         d = _dist()
         ws = self.nranks
-        owned = [split_ownership(self.N, ws, q) for q in range(ws)]
+        owned = [tuple(mult * v for v in split_ownership(self.N, ws, q)) for q in range(ws)]
         need = np.unique(cols[cols >= 0])
         allneed = [None] * ws
         if d is not None:
@@ -873,8 +896,7 @@ class ShellMat:
         answers = []
         for q in range(ws):
             mine = allneed[q][(allneed[q] >= s0) & (allneed[q] < s0 + sn)]
-            pos = x.positions(torch.from_numpy(mine - s0).to(x.array.device))
-            answers.append((mine, x.array[pos].cpu().numpy()))
+            answers.append((mine, read(x, mine - s0)))
         allans = [None] * ws
         if d is not None:
             d.all_gather_object(allans, answers)
@@ -894,7 +916,7 @@ class ShellMat:
                 t = np.flatnonzero(tm == m)
                 par = np.array([bin(int(bras[i, m]) & int(signs[j])).count('1') & 1 for j in t])
                 want[i] += np.sum(np.where(par == 1, -1.0, 1.0) * coeffs[t]) * xval[int(c)]
-        got = y.array[y.positions(torch.from_numpy(rows).to(y.array.device))].cpu().numpy()
+        got = read(y, rows)
         out = torch.tensor([float(np.abs(got - want).max()), float(np.abs(want).max())], dtype=torch.float64,
                            device=x.array.device)
         if d is not None:
@@ -1362,9 +1384,8 @@ def build_mat(masks, mask_offsets, signs, coeffs, left_subspace, right_subspace,
                                 int(lc.vec_swizzle), shift, packed=mat.real_packed)
         if split is not None:
             mat.set_transposed(split, lc, rc, flags)
-            # (the sampled-row check reads x and y as complex amplitudes: not for the packed form, whose first use
-            # -- eigsolve -- measures its residuals in H anyway)
-            mat._check_pending = knob('DNM_EXCHANGE_SELFCHECK', '1') != '0' and not mat.real_packed
+            # (a packed operator is checked on real amplitudes: ShellMat.selfcheck's packed mode)
+            mat._check_pending = knob('DNM_EXCHANGE_SELFCHECK', '1') != '0'
     return mat
 
 
