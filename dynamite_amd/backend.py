@@ -662,6 +662,7 @@ class ShellMat:
         # communicator and stream) instead of the schedules below over torch.distributed -- config.native_comm, RCCL
         # transport only; the transposed exchange keeps its host schedule
         self._native = None
+        self._native_tr = False   # transposed exchange split and scheduled inside the library (set_native_transposed)
 
     @property
     def handle(self):
@@ -739,8 +740,14 @@ class ShellMat:
                 and self._mult_converted(x, y):
             return
         self.check_layout(x, y)
-        if self._tr is not None:
-            self._mult_transposed(x, y)
+        if self._tr is not None or self._native_tr:
+            if self._native_tr:
+                # split and schedule inside the library (dnm_mat_set_exchange, csrc/comm.cpp)
+                if self._native is None:
+                    self._native = native_comm()
+                _lib.check(L.dnm_mat_mult_partitioned(self.handle, self._native, x.ptr, y.ptr, _stream()))
+            else:
+                self._mult_transposed(x, y)
             if self._check_pending:
                 # The transposed exchange is the scheme with the most asynchronous traffic (buffers shared between
                 # the RCCL stream and the compute stream, batched returns): its first result on a transport is
@@ -966,6 +973,24 @@ class ShellMat:
                          and cnt % sub == 0 and n - int(knob('DNM_TILE_BITS', '12')) >= logsub     # whole tiles per range
                          and (swz == 0 or 2 * swz - 4 <= f - logsub))      # parts keep their order in the swizzled layout
 
+    def set_native_transposed(self):
+        """The transposed exchange with the split and the schedule inside the library (dnm_mat_set_exchange +
+        dnm_mat_mult_partitioned): for RCCL transports under config.native_comm.  Returns whether the operator splits."""
+        chosen = C.c_int()
+        _lib.check(_lib.lib().dnm_mat_set_exchange(self.handle, _lib.EXCHANGE_TRANSPOSE, C.byref(chosen)))
+        self._native_tr = chosen.value == _lib.EXCHANGE_TRANSPOSE
+        return self._native_tr
+
+    def _transposed_parts(self):
+        """(lo handle, hi handle, pieces, own, cnt) of whichever side holds the split"""
+        if self._tr is not None:
+            return self._tr
+        lo, hi, f = C.c_void_p(), C.c_void_p(), C.c_int()
+        _lib.check(_lib.lib().dnm_mat_exchange_parts(self.handle, C.byref(lo), C.byref(hi), C.byref(f)))
+        p = self.nranks.bit_length() - 1
+        n = (self.n_local - 1).bit_length()
+        return (lo, hi) + transpose_pieces(n, p, f.value, self.rank)
+
     def launches_per_mult(self):
         """Kernel launches of one multiply on this rank (rank-local passes, partner passes / the pass in the
         transposed layout and the sum of its result)."""
@@ -973,16 +998,18 @@ class ShellMat:
             nl = C.c_int()
             _lib.check(_lib.lib().dnm_mat_plan_launches(h, C.byref(nl)))
             return nl.value
-        if self._tr is not None:
-            return count(self._tr[0]) + count(self._tr[1]) * (self.TR_SUB if self._tr_pipe else 1) + 1
+        if self._tr is not None or self._native_tr:
+            tr = self._transposed_parts()
+            return count(tr[0]) + count(tr[1]) * (self.TR_SUB if (self._tr_pipe or self._native_tr) else 1) + 1
         return count(self.handle) + len(self.recvs)
 
     def exchange_summary(self):
         """What one multiply moves between ranks: bytes received, sent, peers, and the bytes on the busiest
         link (peer) -- for the link-bound estimate of bench.py.  On a window partition the first call sets the
         windows up, which is collective: call it on every rank."""
-        if self._tr is not None:
-            pieces, cnt = self._tr[2], self._tr[4]
+        if self._tr is not None or self._native_tr:
+            tr = self._transposed_parts()
+            pieces, cnt = tr[2], tr[4]
             per_peer = {}
             for q, _, c in pieces:
                 per_peer[q] = per_peer.get(q, 0) + 2 * 16 * c        # state out and result back
@@ -1125,13 +1152,15 @@ class ShellMat:
         if self.nranks == 1:
             return
         import torch
-        if self._tr is not None:
-            _, _, pieces, own, cnt = self._tr
+        if self._tr is not None or self._native_tr:
+            _, _, pieces, own, cnt = self._transposed_parts()
             xb, wb = self._transpose_buffers(x.array)
             for r in post_transpose(x.array, xb, pieces):        # the state goes out ...
                 r.wait()
             for r in post_transpose(wb, xb, pieces):             # ... and a result of the same size comes back
                 r.wait()
+            if self._native_tr:
+                self._tr_bufs = None                             # (the library has its own pair)
         elif not self.partners and self._is_windowed():
             self._setup_windows()
             self._window_buf = exchange_window(x.array if x.internal else x.local_natural(), self._owned, self._windows,
@@ -1151,6 +1180,11 @@ class ShellMat:
         if self.nranks == 1:
             return
         import torch
+        if self._native_tr or self._native is not None:
+            if self._native is None:
+                self._native = native_comm()
+            _lib.check(_lib.lib().dnm_comm_prepare(self._native, self.handle, _stream()))
+            return
         if self._tr is not None:
             self._transpose_buffers(like)
             return
@@ -1382,7 +1416,11 @@ def build_mat(masks, mask_offsets, signs, coeffs, left_subspace, right_subspace,
         shift = int(lc.type)                   # Full: index = configuration; Parity: index = configuration >> 1
         split = transpose_split(masks, mask_offsets, signs, coeffs, int(lc.L) - shift, config.world_size,
                                 int(lc.vec_swizzle), shift, packed=mat.real_packed)
-        if split is not None:
+        d = _dist()
+        if split is not None and config.native_comm and d is not None and d.get_backend() == 'nccl' and \
+                mat.set_native_transposed():
+            mat._check_pending = knob('DNM_EXCHANGE_SELFCHECK', '1') != '0'
+        elif split is not None:
             mat.set_transposed(split, lc, rc, flags)
             # (a packed operator is checked on real amplitudes: ShellMat.selfcheck's packed mode)
             mat._check_pending = knob('DNM_EXCHANGE_SELFCHECK', '1') != '0'

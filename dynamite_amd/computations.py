@@ -284,10 +284,17 @@ def eigsolve(H, getvecs=False, nev=1, which='lowest', target=None, tol=None, sub
         torch.cuda.empty_cache()            # memory torch holds for reuse counts as free
         fit = _min_over_ranks(fitting())
         if fit < want:
-            if fit < nev + 2:
-                raise RuntimeError('not enough device memory for a Krylov basis: %d vectors of %.1f GiB fit, '
-                                   'eigsolve(nev=%d) needs at least %d' % (max(fit, 0), vec_bytes / 2 ** 30, nev,
-                                                                            nev + 2))
+            if fit < nev + 5:
+                # no room for a restarted basis worth the name (at least nev + 2 vectors beside the Chebyshev filter's
+                # work vectors): the native driver takes the pairs one after the other through the basis-free
+                # recurrence on the operator deflated by the pairs found -- four work vectors and the pairs themselves
+                # (the caller's buffer when the vectors are wanted)
+                need = 4 + (0 if getvecs else nev - 1)
+                if fit + 3 < need or mat.N <= max(64, 4 * nev):
+                    raise RuntimeError('not enough device memory for eigsolve(nev=%d): %d vectors of %.1f GiB fit, '
+                                       'the basis-free solver needs %d' % (nev, max(fit + 3, 0), vec_bytes / 2 ** 30,
+                                                                           need))
+                fit = max(fit, 0)
             # the default basis, capped at what fits (fit + 1 vectors in all): the native driver keeps its automatic
             # choices -- a Chebyshev filter for several pairs of a large operator -- inside that budget
             ncv_native = -(fit + 1)

@@ -9,8 +9,10 @@
 //     assembled from the owners' blocks -- only the ranges its rows read -- while the part of the multiply that needs
 //     nothing from other ranks runs (two tiled SpinConserve passes: the lo pass; otherwise: the rows that read only the
 //     rank's own block), the rest follows.
-// The transposed exchange of Full / Parity on four and more ranks keeps its host schedule (dynamite_amd/backend.py): it
-// multiplies with two more handles that the host builds from a split of the operator.
+//   * Full / Parity under the transposed exchange (dnm_mat_set_exchange; the default from four ranks on): ONE all-to-all
+//     takes the state to the layout in which the rank bits are local, the terms that flip no rank bit run under it, the
+//     others on the redistributed state -- sub-piece by sub-piece as the pieces land -- and the returning all-to-all's
+//     pieces are added on arrival.
 // A communicator can also stand for one rank of P inside ONE process ("loop-back": the peers' blocks live in the same
 // device memory and every message is an RCCL send to the process itself) -- how the schedules run, transport included,
 // on the one-GPU boxes the tests have.
@@ -108,6 +110,32 @@ struct PartnerState {
   bool ready = false;
 };
 
+// per-operator state of the transposed exchange
+struct TransposeState {
+  bool ready = false;
+  int p = 0, n = 0, f = 0, nb = 2;               // rank bits, local index bits, first bit of the exchanged field, pieces per peer
+  int sub = 1;                                   // parts a piece travels in
+  bool pipe = false;                             // the second part runs part by part as the pieces land
+  int64_t cnt = 0, part = 0;                     // elements of a piece / of a part
+  DevBuf xb, wb;                                 // the state in layout B; the second part's result there
+  std::vector<hipEvent_t> ev;
+  // loop-back: what the peers' second parts computed (their returning pieces), and the buffer their input is assembled in
+  std::vector<std::unique_ptr<DevBuf>> peer_wb;
+  DevBuf peer_xb;
+  TransposeState() = default;
+  TransposeState(const TransposeState &) = delete;
+  ~TransposeState() { for (hipEvent_t e : ev) (void)hipEventDestroy(e); }
+  int event(size_t i, hipEvent_t *out) {
+    while (ev.size() <= i) {
+      hipEvent_t e;
+      DNM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      ev.push_back(e);
+    }
+    *out = ev[i];
+    return 0;
+  }
+};
+
 }  // namespace
 
 struct dnm_comm {
@@ -122,6 +150,7 @@ struct dnm_comm {
   std::vector<dnm_mat *> peer_mat;
   std::map<dnm_mat *, WindowState> win;
   std::map<dnm_mat *, PartnerState> par;
+  std::map<dnm_mat *, TransposeState> tr;
   int me() const { return vrank >= 0 ? vrank : rank; }
   int world() const { return vrank >= 0 ? vranks : nranks; }
 };
@@ -133,10 +162,12 @@ constexpr int WINDOW_CHUNKS = 1024;              // resolution of the needed-col
 // Post one received block: `count` complex128 elements that rank q holds at `src_off` of ITS vector land in dst.
 // Real ranks: a receive from q (q posts the matching send from its own list).  Loop-back: a send to this process from
 // the peer's block, and its receive.
-int post_recv(dnm_comm *c, int q, int64_t src_off, int64_t count, void *dst) {
+// (loop_src: the peer's vector the block comes from in loop-back when it is not its block of x)
+int post_recv(dnm_comm *c, int q, int64_t src_off, int64_t count, void *dst, const void *loop_src = nullptr) {
   if (c->vrank >= 0) {
-    DNM_CHECK(q >= 0 && q < c->vranks && c->peer_x[(size_t)q], "loop-back: no block for rank %d", q);
-    DNM_NCCL(ncclSend((const char *)c->peer_x[(size_t)q] + src_off * 16, (size_t)count * 2, ncclDouble, 0, c->nccl, c->xs));
+    DNM_CHECK(q >= 0 && q < c->vranks && (loop_src || c->peer_x[(size_t)q]), "loop-back: no block for rank %d", q);
+    const void *src = loop_src ? loop_src : c->peer_x[(size_t)q];
+    DNM_NCCL(ncclSend((const char *)src + src_off * 16, (size_t)count * 2, ncclDouble, 0, c->nccl, c->xs));
     DNM_NCCL(ncclRecv(dst, (size_t)count * 2, ncclDouble, 0, c->nccl, c->xs));
     return 0;
   }
@@ -298,9 +329,8 @@ int mult_window(dnm_comm *c, dnm_mat *A, const void *x, void *y, hipStream_t st)
   return dnm_mat_mult_window(A, W.window.p, wlo, W.wlen, y, st);
 }
 
-int mult_partner(dnm_comm *c, dnm_mat *A, const void *x, void *y, hipStream_t st) {
-  PartnerState &Q = c->par[A];
-  if (!Q.ready) {
+int setup_partner(dnm_mat *A, PartnerState &Q) {
+  {
     int ns = 0, nr = 0;
     DNM_TRY(dnm_mat_exchange_plan(A, &ns, nullptr, &nr, nullptr));
     Q.sends.resize((size_t)std::max(1, ns));
@@ -314,6 +344,12 @@ int mult_partner(dnm_comm *c, dnm_mat *A, const void *x, void *y, hipStream_t st
     }
     Q.ready = true;
   }
+  return 0;
+}
+
+int mult_partner(dnm_comm *c, dnm_mat *A, const void *x, void *y, hipStream_t st) {
+  PartnerState &Q = c->par[A];
+  if (!Q.ready) DNM_TRY(setup_partner(A, Q));
   if (Q.recvs.empty() && Q.sends.empty()) return dnm_mat_mult(A, x, y, st);
   DNM_HIP(hipEventRecord(c->ev_ready, st));
   DNM_HIP(hipStreamWaitEvent(c->xs, c->ev_ready, 0));
@@ -326,6 +362,151 @@ int mult_partner(dnm_comm *c, dnm_mat *A, const void *x, void *y, hipStream_t st
   DNM_TRY(dnm_mat_mult_local(A, x, y, st));                           // under the exchange
   DNM_HIP(hipStreamWaitEvent(st, c->ev_done, 0));
   for (size_t i = 0; i < Q.recvs.size(); ++i) DNM_TRY(dnm_mat_mult_remote(A, (int32_t)i, Q.bufs[i]->p, y, st));
+  return 0;
+}
+
+constexpr int TR_SUB = 4;                        // parts a piece of the transposed exchange travels in (backend.ShellMat.TR_SUB)
+
+int setup_transposed(dnm_comm *c, dnm_mat *A, TransposeState &T) {
+  const int P = c->world();
+  T.p = 0;
+  while ((1 << T.p) < P) ++T.p;
+  T.n = 0;
+  while (((int64_t)1 << T.n) < A->n_local) ++T.n;
+  DNM_CHECK(((int64_t)1 << T.n) == A->n_local && (1 << T.p) == P, "internal: transposed exchange on blocks that are not subcubes");
+  T.f = A->tr_f;
+  T.cnt = (int64_t)1 << T.f;
+  T.nb = 1 << (T.n - T.f - T.p);
+  // sub-piece pipelining of the second part: its ranges of workgroups must be the top bits inside a piece and must
+  // not read outside themselves (backend.ShellMat.set_transposed: the same conditions)
+  int top = -1, gathers = 0;
+  DNM_TRY(dnm_mat_local_part_bits(A->tr_hi, &top, &gathers));
+  int logsub = 0;
+  while ((1 << logsub) < TR_SUB) ++logsub;
+  const int swz = A->right.host.swz;
+  const char *pk = knob("DNM_TRANSPOSE_PIPE");
+  T.pipe = !(pk && pk[0] == '0') && top == T.f - 1 && gathers == 0 && T.cnt % TR_SUB == 0 &&
+           T.n - A->tr_hi->plan.cfg.B >= logsub && (swz == 0 || 2 * swz - 4 <= T.f - logsub);
+  T.sub = T.pipe ? TR_SUB : ((T.cnt % TR_SUB == 0 && T.cnt / TR_SUB >= 1024) ? TR_SUB : 1);
+  T.part = T.cnt / T.sub;
+  DNM_TRY(T.xb.alloc((size_t)A->n_local * 16));
+  DNM_TRY(T.wb.alloc((size_t)A->n_local * 16));
+  T.ready = true;
+  return 0;
+}
+
+// y = A x with the transposed exchange (see the header of this file and dnm_mat_set_exchange)
+int mult_transposed(dnm_comm *c, dnm_mat *A, const void *x, void *y, hipStream_t st) {
+  TransposeState &T = c->tr[A];
+  if (!T.ready) DNM_TRY(setup_transposed(c, A, T));
+  const int P = c->world(), me = c->me();
+  const int64_t cnt = T.cnt, part = T.part;
+  const int sub = T.sub;
+  auto off = [&](int b, int q) { return ((int64_t)b * P + q) << T.f; };
+  auto at = [](const void *v, int64_t o) { return (void *)((const char *)v + o * 16); };
+  // loop-back with the peers' handles: what comes back is what THEY computed -- run their second parts on the state
+  // as it would reach them (validation at test sizes; without handles the returning pieces carry this rank's own
+  // result: the traffic of the schedule, for timing)
+  std::vector<const void *> back_src((size_t)P, nullptr);
+  if (c->vrank >= 0) {
+    bool have = true;
+    for (int q = 0; q < P; ++q) have = have && (q == me || (c->peer_mat[(size_t)q] && c->peer_mat[(size_t)q]->tr_hi && c->peer_x[(size_t)q]));
+    if (have) {
+      if (T.peer_wb.size() != (size_t)P) {
+        T.peer_wb.clear();
+        for (int q = 0; q < P; ++q) {
+          T.peer_wb.emplace_back(new DevBuf());
+          if (q != me) DNM_TRY(T.peer_wb.back()->alloc((size_t)A->n_local * 16));
+        }
+        DNM_TRY(T.peer_xb.alloc((size_t)A->n_local * 16));
+      }
+      for (int q = 0; q < P; ++q) {
+        if (q == me) continue;
+        for (int r = 0; r < P; ++r)
+          for (int b = 0; b < T.nb; ++b)
+            DNM_TRY(dnm_vec_copy(at(r == me ? x : c->peer_x[(size_t)r], off(b, q)), at(T.peer_xb.p, off(b, r)), cnt, st));
+        DNM_TRY(dnm_mat_mult_local(c->peer_mat[(size_t)q]->tr_hi, T.peer_xb.p, T.peer_wb[(size_t)q]->p, st));
+        back_src[(size_t)q] = T.peer_wb[(size_t)q]->p;
+      }
+    } else {
+      for (int q = 0; q < P; ++q) back_src[(size_t)q] = T.wb.p;
+    }
+  }
+  // one group of the all-to-all: elements [o, o + len) of the pieces with index b in [b0, b1) -- `src` goes out,
+  // the peers' land in `dst` at the same offsets (the map between the layouts is its own inverse)
+  auto post = [&](const void *src, void *dst, int b0, int b1, int64_t o, int64_t len, bool returning) -> int {
+    DNM_NCCL(ncclGroupStart());
+    for (int q = 0; q < P; ++q) {
+      if (q == me) continue;
+      for (int b = b0; b < b1; ++b) {
+        DNM_TRY(post_send(c, q, src, off(b, q) + o, len));
+        DNM_TRY(post_recv(c, q, off(b, me) + o, len, at(dst, off(b, q) + o), returning ? back_src[(size_t)q] : nullptr));
+      }
+    }
+    DNM_NCCL(ncclGroupEnd());
+    return 0;
+  };
+  auto add = [&](const void *src, int64_t o, int64_t len) { return dnm_vec_axpby(at(y, o), at(src, o), len, 1.0, 0.0, 1.0, 0.0, st); };
+  size_t nev = 0;
+  hipEvent_t e;
+  // x is ready when the compute stream gets here
+  DNM_HIP(hipEventRecord(c->ev_ready, st));
+  DNM_HIP(hipStreamWaitEvent(c->xs, c->ev_ready, 0));
+  if (T.pipe) {
+    // part s of ALL pieces is what range s of the second part's workgroups reads and writes
+    std::vector<hipEvent_t> fwd((size_t)sub), back((size_t)sub);
+    for (int s = 0; s < sub; ++s) {
+      DNM_TRY(post(x, T.xb.p, 0, T.nb, s * part, part, false));
+      DNM_TRY(T.event(nev++, &fwd[(size_t)s]));
+      DNM_HIP(hipEventRecord(fwd[(size_t)s], c->xs));
+    }
+    for (int b = 0; b < T.nb; ++b) DNM_TRY(dnm_vec_copy(at(x, off(b, me)), at(T.xb.p, off(b, me)), cnt, st));
+    DNM_TRY(dnm_mat_mult_local(A->tr_lo, x, y, st));                    // under the all-to-all
+    for (int s = 0; s < sub; ++s) {
+      DNM_HIP(hipStreamWaitEvent(st, fwd[(size_t)s], 0));
+      DNM_TRY(dnm_mat_mult_local_part(A->tr_hi, T.xb.p, T.wb.p, s, sub, st));
+      // part s of xb has been consumed: it takes the returning part s
+      DNM_TRY(T.event(nev++, &e));
+      DNM_HIP(hipEventRecord(e, st));
+      DNM_HIP(hipStreamWaitEvent(c->xs, e, 0));
+      DNM_TRY(post(T.wb.p, T.xb.p, 0, T.nb, s * part, part, true));
+      DNM_TRY(T.event(nev++, &back[(size_t)s]));
+      DNM_HIP(hipEventRecord(back[(size_t)s], c->xs));
+      for (int b = 0; b < T.nb; ++b) DNM_TRY(add(T.wb.p, off(b, me) + s * part, part));
+    }
+    for (int s = 0; s < sub; ++s) {
+      DNM_HIP(hipStreamWaitEvent(st, back[(size_t)s], 0));
+      for (int q = 0; q < P; ++q)
+        for (int b = 0; b < T.nb && q != me; ++b) DNM_TRY(add(T.xb.p, off(b, q) + s * part, part));
+    }
+    return 0;
+  }
+  DNM_TRY(post(x, T.xb.p, 0, T.nb, 0, cnt, false));
+  DNM_TRY(T.event(nev++, &e));
+  DNM_HIP(hipEventRecord(e, c->xs));
+  for (int b = 0; b < T.nb; ++b) DNM_TRY(dnm_vec_copy(at(x, off(b, me)), at(T.xb.p, off(b, me)), cnt, st));
+  DNM_TRY(dnm_mat_mult_local(A->tr_lo, x, y, st));                      // under the all-to-all
+  DNM_HIP(hipStreamWaitEvent(st, e, 0));
+  DNM_TRY(dnm_mat_mult_local(A->tr_hi, T.xb.p, T.wb.p, st));
+  // the way back (xb is free again) in nb * sub batches -- every piece travels as `sub` contiguous parts, part by part
+  // over all peers: what a batch brought is added to y while the next ones are on the links
+  DNM_TRY(T.event(nev++, &e));
+  DNM_HIP(hipEventRecord(e, st));
+  DNM_HIP(hipStreamWaitEvent(c->xs, e, 0));
+  std::vector<hipEvent_t> got((size_t)T.nb * (size_t)sub);
+  for (int b = 0; b < T.nb; ++b)
+    for (int k = 0; k < sub; ++k) {
+      DNM_TRY(post(T.wb.p, T.xb.p, b, b + 1, k * part, part, true));
+      DNM_TRY(T.event(nev++, &got[(size_t)b * sub + k]));
+      DNM_HIP(hipEventRecord(got[(size_t)b * sub + k], c->xs));
+    }
+  for (int b = 0; b < T.nb; ++b) DNM_TRY(add(T.wb.p, off(b, me), cnt));
+  for (int b = 0; b < T.nb; ++b)
+    for (int k = 0; k < sub; ++k) {
+      DNM_HIP(hipStreamWaitEvent(st, got[(size_t)b * sub + k], 0));
+      for (int q = 0; q < P; ++q)
+        if (q != me) DNM_TRY(add(T.xb.p, off(b, q) + k * part, part));
+    }
   return 0;
 }
 
@@ -392,6 +573,7 @@ int dnm_comm_forget(dnm_comm *c, dnm_mat *A) {
   DNM_CHECK(c, "null communicator");
   c->win.erase(A);
   c->par.erase(A);
+  c->tr.erase(A);
   return 0;
 }
 
@@ -405,6 +587,7 @@ int dnm_comm_loopback(dnm_comm *c, int vrank, int vranks, const void *const *pee
   if (peer_mat) c->peer_mat.assign(peer_mat, peer_mat + vranks);
   c->win.clear();
   c->par.clear();
+  c->tr.clear();
   return 0;
 }
 
@@ -427,10 +610,29 @@ int dnm_mat_mult_partitioned(dnm_mat *A, dnm_comm *c, const void *x, void *y, vo
             A->rank, A->nranks, c->me(), c->world());
   hipStream_t st = (hipStream_t)stream;
   if (A->nranks == 1) return dnm_mat_mult(A, x, y, stream);
+  if (A->tr_hi) return mult_transposed(c, A, x, y, st);
   if (A->hypercube && A->plan.use_tiled) return mult_partner(c, A, x, y, st);
   DNM_CHECK(A->use_sc3 || A->right.host.swz == 0,
             "window partitions assemble their window in index order: swizzled right vectors go through the host schedule");
   return mult_window(c, A, x, y, st);
+}
+
+int dnm_comm_prepare(dnm_comm *c, dnm_mat *A, void *stream) {
+  DNM_CHECK(A && c, "null argument");
+  DNM_CHECK(A->nranks == c->world() && A->rank == c->me(), "the matrix is rank %d of %d, the communicator rank %d of %d",
+            A->rank, A->nranks, c->me(), c->world());
+  if (A->nranks == 1 || A->host_only) return 0;
+  if (A->tr_hi) {
+    TransposeState &T = c->tr[A];
+    return T.ready ? 0 : setup_transposed(c, A, T);
+  }
+  if (A->hypercube && A->plan.use_tiled) {
+    PartnerState &Q = c->par[A];
+    return Q.ready ? 0 : setup_partner(A, Q);
+  }
+  if (!(A->use_sc3 || A->right.host.swz == 0)) return 0;
+  WindowState &W = c->win[A];
+  return W.ready ? 0 : setup_windows(c, A, W, (hipStream_t)stream);
 }
 
 int dnm_comm_hooks(dnm_comm *c, dnm_mat *A, void *stream, dnm_hooks *out) {

@@ -784,125 +784,170 @@ static double tridiag_eigpair(const std::vector<double> &a, const std::vector<do
 // appear later do not matter because the iteration stops at convergence.  The Ritz vector, if wanted, is built
 // in a second run of the same recurrence with the recorded coefficients.  At 16 GiB per vector a step is the
 // multiply plus one sweep -- no restarts, no re-orthogonalisation passes over a 240 GiB basis.
-static int eigsolve_basis_free(Ops &ops, dnm_mat *A, int64_t n_local, int which, double tol, int max_steps,
+//
+// nev > 1 (problems whose vectors leave no room for a restarted basis: the 36-site kagome torus, 34 GiB per real
+// vector): one pair after the other, each by the same recurrence on the operator deflated by the pairs found --
+// every new Lanczos vector is projected against them (one fused inner-product sweep + one update sweep per step).
+// A found vector is an eigenvector to the residual tol, so the deflated operator's extremal pair is the next pair
+// of H to second order in tol; unlike one Krylov space, deflation also returns every copy of a degenerate level.
+// Memory: 4 work vectors + the nev vectors (in `evecs` when the caller wants them, else nev - 1 in the workspace).
+static int eigsolve_basis_free(Ops &ops, dnm_mat *A, int64_t n_local, int nev, int which, double tol, int max_steps,
                                uint64_t seed, const dnm_hooks *hooks, double *evals, void *evecs,
                                dnm_solver_stats *stats, hipStream_t st) {
   void *W = nullptr;
-  DNM_TRY(basis_workspace((size_t)4 * (size_t)n_local * 16, &W));
+  DNM_TRY(basis_workspace((size_t)(4 + (evecs ? 0 : nev - 1)) * (size_t)n_local * 16, &W));
   const int64_t offset = hooks ? A->row0 : 0;
-  std::vector<double> al, be, svec;
-  struct Step { double are, aim, s1, s2; };      // what the update of a step did, so that the second run repeats it
-  std::vector<Step> rec;
-  double theta = 0, res = 0;
-  bool converged = false;
-  int steps = 0, rounds = 0, matvecs_solve = 0;
-  auto slot = [&](int k) { return (void *)vecptr(W, n_local, k % 3); };
-  // start vector: seeded normal deviates, or (later rounds) the Ritz vector of the round before, kept in `evecs`
-  auto start = [&](bool from_prev) -> int {
-    if (from_prev) return vk_axpby(slot(0), evecs, n_local, 1.0, 0.0, 0.0, 0.0, st);
-    DNM_TRY(random_start(A, slot(0), n_local, seed, offset, st));
-    double n0 = 0;
-    DNM_TRY(ops.norm(slot(0), &n0));
-    DNM_CHECK(n0 > 0, "zero start vector");
-    return vk_scale(slot(0), n_local, 1.0 / n0, 0, st);
-  };
-  auto pick = [&](int n, std::vector<double> &z) {
-    if (which == DNM_WHICH_LOWEST) return tridiag_eigpair(al, be, n, 0, z);
-    if (which == DNM_WHICH_HIGHEST) return tridiag_eigpair(al, be, n, n - 1, z);
-    std::vector<double> z2;
-    const double lo = tridiag_eigpair(al, be, n, 0, z), hi = tridiag_eigpair(al, be, n, n - 1, z2);
-    if (std::fabs(hi) > std::fabs(lo)) { z = z2; return hi; }
-    return lo;
-  };
+  void *F = evecs ? evecs : (void *)vecptr(W, n_local, 4);        // the pairs found so far, contiguous
   const char *venv = knob("DNM_EIGS_VERIFY");
   const bool verify = venv && venv[0] == '1';
-  bool measured = false;
-  while (true) {
-    al.clear(); be.clear(); rec.clear();
-    converged = false;
-    steps = 0;
-    DNM_TRY(start(rounds > 0));
-    for (int j = 0; j < max_steps; ++j) {
-      void *q = slot(j), *p = slot(j + 1), *qm = slot(j + 2);     // (j + 2) % 3 == (j - 1) % 3
+  int nconv = 0, total_steps = 0;
+  double worst = 0;
+  for (int e = 0; e < nev; ++e) {
+    // where this pair's vector goes (the last one is not needed unless the caller wants it)
+    void *dst = evecs ? (void *)vecptr(evecs, n_local, e) : (e + 1 < nev ? (void *)vecptr(W, n_local, 4 + e) : nullptr);
+    std::vector<double> al, be, svec;
+    struct Step { double are, aim, s1, s2; };      // what the update of a step did, so that the second run repeats it
+    std::vector<Step> rec;
+    std::vector<zc> proj;                          // [step][found]: the projections taken out, for the second run
+    double theta = 0, res = 0, err = 0;
+    bool converged = false;
+    int steps = 0, rounds = 0;
+    auto slot = [&](int k) { return (void *)vecptr(W, n_local, k % 3); };
+    // p <- p - F F^H p (first run: coefficients measured and recorded; second run: the recorded ones), |p|^2 after
+    auto deflate = [&](void *p, int j, bool replay, double *n2) -> int {
+      std::vector<zc> h;
+      if (replay) h.assign(proj.begin() + (size_t)j * e, proj.begin() + (size_t)(j + 1) * e);
+      else {
+        DNM_TRY(ops.mdot(F, e, p, h));
+        proj.insert(proj.end(), h.begin(), h.end());
+      }
+      if (e > 1) {
+        std::vector<zc> neg(e - 1);
+        for (int i = 0; i + 1 < e; ++i) neg[i] = -h[i];
+        DNM_TRY(ops.maxpy(p, F, e - 1, neg));
+      }
+      DNM_TRY(vec_lanczos_update_host(p, vecptr(F, n_local, e - 1), nullptr, n_local, h[e - 1].real(), h[e - 1].imag(),
+                                      0.0, n2, st, 1.0));
+      return ops.sum(n2, 1);
+    };
+    // start vector: seeded normal deviates, or (later rounds) the Ritz vector of the round before, kept in `dst`;
+    // without its components along the pairs found
+    auto start = [&](bool from_prev) -> int {
+      if (from_prev) DNM_TRY(vk_axpby(slot(0), dst, n_local, 1.0, 0.0, 0.0, 0.0, st));
+      else DNM_TRY(random_start(A, slot(0), n_local, seed + 7919u * (uint64_t)e, offset, st));
+      for (int pass = 0; pass < (e > 0 ? 2 : 0); ++pass) {
+        std::vector<zc> h, neg(e);
+        DNM_TRY(ops.mdot(F, e, slot(0), h));
+        for (int i = 0; i < e; ++i) neg[i] = -h[i];
+        DNM_TRY(ops.maxpy(slot(0), F, e, neg));
+      }
+      double n0 = 0;
+      DNM_TRY(ops.norm(slot(0), &n0));
+      DNM_CHECK(n0 > 0, "zero start vector");
+      return vk_scale(slot(0), n_local, 1.0 / n0, 0, st);
+    };
+    auto pick = [&](int n, std::vector<double> &z) {
+      if (which == DNM_WHICH_LOWEST) return tridiag_eigpair(al, be, n, 0, z);
+      if (which == DNM_WHICH_HIGHEST) return tridiag_eigpair(al, be, n, n - 1, z);
+      std::vector<double> z2;
+      const double lo = tridiag_eigpair(al, be, n, 0, z), hi = tridiag_eigpair(al, be, n, n - 1, z2);
+      if (std::fabs(hi) > std::fabs(lo)) { z = z2; return hi; }
+      return lo;
+    };
+    bool measured = false;
+    while (true) {
+      al.clear(); be.clear(); rec.clear(); proj.clear();
+      converged = false;
+      steps = 0;
+      DNM_TRY(start(rounds > 0));
+      for (int j = 0; j < max_steps; ++j) {
+        void *q = slot(j), *p = slot(j + 1), *qm = slot(j + 2);     // (j + 2) % 3 == (j - 1) % 3
+        zc d(0);
+        double pn2 = 0;
+        DNM_TRY(ops.mult_dot(q, p, &d, j > 0 ? qm : nullptr, j > 0 ? be[j - 1] : 0.0, &pn2));
+        al.push_back(d.real());
+        const double b2 = pn2 - std::norm(d);
+        const bool fused = b2 > 1e-4 * pn2 && pn2 > 0;
+        double n2 = 0, bn;
+        Step sr{d.real(), d.imag(), fused ? 1.0 / std::sqrt(b2) : 1.0, 0.0};
+        DNM_TRY(vec_lanczos_update_host(p, q, nullptr, n_local, sr.are, sr.aim, 0.0, &n2, st, sr.s1));
+        DNM_TRY(ops.sum(&n2, 1));
+        if (e > 0) DNM_TRY(deflate(p, j, false, &n2));
+        if (fused) {
+          const double nu = std::sqrt(n2 > 0 ? n2 : 0.0);
+          bn = std::sqrt(b2) * nu;
+          if (std::fabs(n2 - 1.0) > 1e-12 && nu > 0) sr.s2 = 1.0 / nu;
+        } else {
+          bn = std::sqrt(n2 > 0 ? n2 : 0.0);
+          if (bn > 0) sr.s2 = 1.0 / bn;
+        }
+        if (sr.s2 != 0.0) DNM_TRY(vk_scale(p, n_local, sr.s2, 0, st));
+        rec.push_back(sr);
+        be.push_back(bn);
+        steps = j + 1;
+        double scale = 0;
+        for (int i = 0; i < steps; ++i) scale = std::max(scale, std::fabs(al[i]) + be[i]);
+        const bool breakdown = bn <= 1e-14 * std::max(1.0, scale);
+        if (steps >= 8 || breakdown || steps == max_steps) {
+          theta = pick(steps, svec);
+          res = std::fabs(bn * svec[steps - 1]);
+          if (breakdown || res <= tol * std::max(std::fabs(theta), 1e-300)) { converged = true; break; }
+        }
+      }
+      total_steps += steps;
+      evals[e] = theta;
+      err = res / std::max(std::fabs(theta), 1e-300);
+      if (!(dst || verify) || steps == 0) break;
+      // second run: the same vectors from the same start by the same arithmetic (recorded coefficients and scales),
+      // v = sum_j s_j q_j accumulated in the fourth slot
+      void *v = vecptr(W, n_local, 3);
+      DNM_TRY(start(rounds > 0));
+      DNM_TRY(vk_axpby(v, slot(0), n_local, svec[0], 0.0, 0.0, 0.0, st));
+      for (int j = 0; j + 1 < steps; ++j) {
+        void *q = slot(j), *p = slot(j + 1), *qm = slot(j + 2);
+        if (j > 0) DNM_TRY(ops.mult_sub(q, p, qm, be[j - 1]));
+        else DNM_TRY(ops.mult(q, p));
+        double n2 = 0;
+        DNM_TRY(vec_lanczos_update_host(p, q, nullptr, n_local, rec[j].are, rec[j].aim, 0.0, &n2, st, rec[j].s1));
+        if (e > 0) DNM_TRY(deflate(p, j, true, &n2));
+        if (rec[j].s2 != 0.0) DNM_TRY(vk_scale(p, n_local, rec[j].s2, 0, st));
+        DNM_TRY(vk_axpby(v, p, n_local, svec[j + 1], 0.0, 1.0, 0.0, st));
+      }
+      double vn = 0;
+      DNM_TRY(ops.norm(v, &vn));
+      DNM_CHECK(vn > 0, "zero Ritz vector");
+      DNM_TRY(vk_scale(v, n_local, 1.0 / vn, 0, st));
+      // what was promised, measured on H itself (not the deflated operator): |H v - <v, H v> v| / |theta|
       zc d(0);
-      double pn2 = 0;
-      DNM_TRY(ops.mult_dot(q, p, &d, j > 0 ? qm : nullptr, j > 0 ? be[j - 1] : 0.0, &pn2));
-      al.push_back(d.real());
-      const double b2 = pn2 - std::norm(d);
-      const bool fused = b2 > 1e-4 * pn2 && pn2 > 0;
-      double n2 = 0, bn;
-      Step sr{d.real(), d.imag(), fused ? 1.0 / std::sqrt(b2) : 1.0, 0.0};
-      DNM_TRY(vec_lanczos_update_host(p, q, nullptr, n_local, sr.are, sr.aim, 0.0, &n2, st, sr.s1));
-      DNM_TRY(ops.sum(&n2, 1));
-      if (fused) {
-        const double nu = std::sqrt(n2 > 0 ? n2 : 0.0);
-        bn = std::sqrt(b2) * nu;
-        if (std::fabs(n2 - 1.0) > 1e-12 && nu > 0) sr.s2 = 1.0 / nu;
-      } else {
-        bn = std::sqrt(n2 > 0 ? n2 : 0.0);
-        if (bn > 0) sr.s2 = 1.0 / bn;
-      }
-      if (sr.s2 != 0.0) DNM_TRY(vk_scale(p, n_local, sr.s2, 0, st));
-      rec.push_back(sr);
-      be.push_back(bn);
-      steps = j + 1;
-      double scale = 0;
-      for (int i = 0; i < steps; ++i) scale = std::max(scale, std::fabs(al[i]) + be[i]);
-      const bool breakdown = bn <= 1e-14 * std::max(1.0, scale);
-      if (steps >= 8 || breakdown || steps == max_steps) {
-        theta = pick(steps, svec);
-        res = std::fabs(bn * svec[steps - 1]);
-        if (breakdown || res <= tol * std::max(std::fabs(theta), 1e-300)) { converged = true; break; }
-      }
-    }
-    evals[0] = theta;
-    stats->err_est = res / std::max(std::fabs(theta), 1e-300);
-    matvecs_solve = ops.matvecs;
-    if (!(evecs || verify) || steps == 0) break;
-    // second run: the same vectors from the same start by the same arithmetic (recorded coefficients and scales),
-    // v = sum_j s_j q_j accumulated in the fourth slot
-    void *v = vecptr(W, n_local, 3);
-    DNM_TRY(start(rounds > 0));
-    DNM_TRY(vk_axpby(v, slot(0), n_local, svec[0], 0.0, 0.0, 0.0, st));
-    for (int j = 0; j + 1 < steps; ++j) {
-      void *q = slot(j), *p = slot(j + 1), *qm = slot(j + 2);
-      if (j > 0) DNM_TRY(ops.mult_sub(q, p, qm, be[j - 1]));
-      else DNM_TRY(ops.mult(q, p));
+      void *hv = slot(0);
+      DNM_TRY(ops.mult_dot(v, hv, &d));
       double n2 = 0;
-      DNM_TRY(vec_lanczos_update_host(p, q, nullptr, n_local, rec[j].are, rec[j].aim, 0.0, &n2, st, rec[j].s1));
-      if (rec[j].s2 != 0.0) DNM_TRY(vk_scale(p, n_local, rec[j].s2, 0, st));
-      DNM_TRY(vk_axpby(v, p, n_local, svec[j + 1], 0.0, 1.0, 0.0, st));
+      DNM_TRY(vec_lanczos_update_host(hv, v, nullptr, n_local, d.real(), d.imag(), 0.0, &n2, st));
+      DNM_TRY(ops.sum(&n2, 1));
+      evals[e] = d.real();
+      err = std::sqrt(n2 > 0 ? n2 : 0.0) / std::max(std::fabs(evals[e]), 1e-300);
+      measured = true;
+      if (dst) DNM_TRY(vk_copy(dst, v, n_local, st));
+      // the contract is a residual below tol (computations.py:274-275 raises otherwise): the estimate of the first
+      // run is not the vector's residual once rounding has crept into a long recurrence.  Polish: Lanczos again from
+      // the Ritz vector itself (a handful of steps); a vector that still misses tol is reported as not converged.
+      if (!converged || !dst || err <= tol) break;
+      if (++rounds >= 3) { converged = false; break; }
     }
-    double vn = 0;
-    DNM_TRY(ops.norm(v, &vn));
-    DNM_CHECK(vn > 0, "zero Ritz vector");
-    DNM_TRY(vk_scale(v, n_local, 1.0 / vn, 0, st));
-    // what was promised, measured: |H v - <v, H v> v| / |theta|
-    zc d(0);
-    void *hv = slot(0);
-    DNM_TRY(ops.mult_dot(v, hv, &d));
-    double n2 = 0;
-    DNM_TRY(vec_lanczos_update_host(hv, v, nullptr, n_local, d.real(), d.imag(), 0.0, &n2, st));
-    DNM_TRY(ops.sum(&n2, 1));
-    evals[0] = d.real();
-    stats->err_est = std::sqrt(n2 > 0 ? n2 : 0.0) / std::max(std::fabs(evals[0]), 1e-300);
-    measured = true;
-    if (evecs) DNM_TRY(vk_copy(evecs, v, n_local, st));
-    // the contract is a residual below tol (computations.py:274-275 raises otherwise): the estimate of the first
-    // run is not the vector's residual once rounding has crept into a long recurrence.  Polish: Lanczos again from
-    // the Ritz vector itself (a handful of steps); a vector that still misses tol is reported as not converged.
-    if (!converged || !evecs || stats->err_est <= tol) break;
-    if (++rounds >= 3) { converged = false; break; }
+    if (knob("DNM_KRYLOV_DEBUG"))
+      fprintf(stderr, "dnm_eigsolve (basis-free Lanczos, pair %d of %d): %d steps, %d matvecs in all, theta = %.12g, relative residual %.2e (%s)\n",
+              e + 1, nev, steps, ops.matvecs, evals[e], err, measured ? "measured" : "Lanczos estimate");
+    worst = std::max(worst, err);
+    if (!converged) break;
+    ++nconv;
   }
-  if (knob("DNM_KRYLOV_DEBUG"))
-    fprintf(stderr, "dnm_eigsolve (basis-free Lanczos): %d steps, %d matvecs in all, theta = %.12g, relative residual %.2e (%s)\n",
-            steps, ops.matvecs, evals[0], stats->err_est, measured ? "measured" : "Lanczos estimate");
-  (void)rounds;
   DNM_HIP(hipStreamSynchronize(st));
-  stats->its = 1;
-  stats->matvecs = measured ? ops.matvecs : matvecs_solve;
-  stats->nconv = converged ? 1 : 0;
-  stats->reason = converged ? DNM_CONVERGED_TOL : DNM_DIVERGED_ITS;
+  stats->its = nev;
+  stats->matvecs = ops.matvecs;
+  stats->err_est = worst;
+  stats->nconv = nconv;
+  stats->reason = nconv == nev ? DNM_CONVERGED_TOL : DNM_DIVERGED_ITS;
+  (void)total_steps;
   return 0;
 }
 
@@ -1264,8 +1309,12 @@ int dnm_eigsolve(dnm_mat *A, int64_t n_local, int nev, int which, double tol, in
     DNM_TRY(ops.maxr(&neg, 1));
     m = (int)(-neg);
   }
-  DNM_CHECK(m >= nev, "ncv smaller than nev");
-  if (max_its <= 0) max_its = (int)std::max<int64_t>(100, 2 * Nglob / m);
+  // (several pairs whose restarted basis does not fit -- fewer than nev + 2 vectors beside the residual and the
+  // filter's two work vectors -- go one after the other through the basis-free recurrence on the deflated
+  // operator, see eigsolve_basis_free)
+  const bool no_room = cap > 0 && cap < nev + 6;
+  DNM_CHECK(m >= nev || no_room, "ncv smaller than nev");
+  if (max_its <= 0) max_its = (int)std::min<int64_t>(std::max<int64_t>(100, 2 * Nglob / std::max(m, 1)), 1 << 30);
   bool filtered = false;
   {
     // one extremal pair of a large operator under default parameters: Lanczos without a stored basis (a step is
@@ -1276,11 +1325,13 @@ int dnm_eigsolve(dnm_mat *A, int64_t n_local, int nev, int which, double tol, in
     DNM_TRY(ops.maxr(&negn, 1));
     const bool large = -negn >= (double)((int64_t)1 << 22);
     const bool want = bf ? bf[0] == '1' : large;
-    if (want && nev == 1 && ncv <= 0 && Nglob > 64) {
-      const int64_t steps64 = std::min<int64_t>((int64_t)max_its * m, Nglob);
-      return eigsolve_basis_free(ops, A, n_local, which, tol, (int)std::min<int64_t>(steps64, 100000), seed, hooks,
-                                 evals, evecs, stats, st);
+    const bool forced = bf && bf[0] == '1';
+    if (ncv <= 0 && Nglob > 64 && Nglob > 4 * (int64_t)nev && ((want && nev == 1) || forced || no_room)) {
+      const int64_t steps64 = std::min<int64_t>((int64_t)max_its * std::max(m, nev + 15), Nglob);
+      return eigsolve_basis_free(ops, A, n_local, nev, which, tol, (int)std::min<int64_t>(steps64, 100000), seed,
+                                 hooks, evals, evecs, stats, st);
     }
+    DNM_CHECK(m >= nev, "not enough memory for a restarted basis");
     // several pairs at one end of the spectrum of a large operator: thick-restart Lanczos on a Chebyshev filter
     // p(H) -- d fused multiplies per Lanczos vector, so the orthogonalisation and restart traffic per multiply
     // drops by d (at 4-16 GiB per vector the plain scheme spends 80 % of its time there).  DNM_EIGS_FILTER=0 / 1

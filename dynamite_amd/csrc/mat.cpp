@@ -1053,6 +1053,114 @@ int dnm_mat_destroy(dnm_mat *A) {
   return 0;
 }
 
+// Exchange scheme of a partitioned Full / Parity operator.  The transposed exchange (backend.transpose_split is the
+// host-side statement of the same split, tests/test_transpose_exchange.py compares the two): a rank's block holds the
+// n = L - p low index bits, the rank number is the p top ones.  A term that flips a top bit couples blocks of different
+// ranks; instead of shipping a partner block per such mask (bpetsc_template_2.c:787-879 scatters the needed entries) the
+// state is redistributed ONCE so that the top bits become local: layout B swaps bits [n, n + p) with the local field
+// F = [f, f + p), f = n - 1 - p (right below the top local bit, which the boundary bond touches).  In layout B every
+// term that flips a top bit is rank-local provided it leaves F alone -- the same MSC term with the two fields swapped.
+int dnm_mat_set_exchange(dnm_mat *A, int scheme, int *chosen) {
+  DNM_CHECK(A && chosen, "null argument");
+  DNM_CHECK(scheme == DNM_EXCHANGE_AUTO || scheme == DNM_EXCHANGE_PARTNER || scheme == DNM_EXCHANGE_TRANSPOSE,
+            "unknown exchange scheme %d", scheme);
+  delete A->tr_lo; delete A->tr_hi;
+  A->tr_lo = A->tr_hi = nullptr;
+  A->tr_f = -1;
+  *chosen = DNM_EXCHANGE_PARTNER;
+  const int P = A->nranks;
+  if (scheme == DNM_EXCHANGE_PARTNER || P < 2 || (scheme == DNM_EXCHANGE_AUTO && P < 4)) return 0;
+  const SubView &lh = A->left.host, &rh = A->right.host;
+  if (!(A->hypercube && A->plan.use_tiled && !A->xparity && lh.type == rh.type && lh.L == rh.L &&
+        (lh.type == DNM_FULL || lh.space == rh.space) && lh.swz == rh.swz))
+    return 0;
+  int p = 0;
+  while ((1 << p) < P) ++p;
+  const int shift = lh.type == DNM_PARITY ? 1 : 0;      // Parity: index = configuration >> 1, index bit j is spin j + 1
+  const int packed = A->real_packed ? 1 : 0;            // index bit 0 is the lane of an element: F must leave it alone
+  const int n = (int)lh.L - shift - p, f = n - 1 - p;
+  if ((1 << p) != P || f < packed) return 0;
+  if (lh.swz && f - packed < 2 * lh.swz - 4) return 0;  // pieces of 2^f amplitudes keep their internal order in both layouts
+  const int fs = f + shift, ns = n + shift;             // the two fields as spins
+  const int64_t fld = P - 1;
+  struct Term { int64_t m, s; double c; };
+  std::vector<Term> lo, hi;
+  for (size_t i = 0; i < A->masks.size(); ++i)
+    for (int64_t t = A->mask_offsets[i]; t < A->mask_offsets[i + 1]; ++t) {
+      const int64_t m = A->masks[i], s = A->signs[(size_t)t];
+      if ((m >> ns) == 0) { lo.push_back({m, s, A->real_coeffs[(size_t)t]}); continue; }
+      if ((m >> fs) & fld) return 0;                    // a term that flips a rank bit AND the field it would move to
+      auto swap = [&](int64_t v) {
+        const int64_t d = ((v >> fs) ^ (v >> ns)) & fld;
+        return v ^ (d << fs) ^ (d << ns);
+      };
+      hi.push_back({swap(m), swap(s), A->real_coeffs[(size_t)t]});
+    }
+  if (lo.empty() || hi.empty()) return 0;
+  // the pieces of the packed operator sit one bit lower
+  const int np = n - packed, fp = f - packed;
+  dnm_subspace ld{}, rd{};
+  ld.type = lh.type; ld.L = lh.L; ld.space = lh.space; ld.vec_swizzle = lh.swz;
+  rd.type = rh.type; rd.L = rh.L; rd.space = rh.space; rd.vec_swizzle = rh.swz;
+  const dnm_partition part{A->rank, A->nranks};
+  dnm_mat *made[2] = {nullptr, nullptr};
+  for (int which = 0; which < 2; ++which) {
+    std::vector<Term> &T = which ? hi : lo;
+    std::stable_sort(T.begin(), T.end(), [](const Term &a, const Term &b) { return a.m < b.m; });
+    std::vector<int64_t> masks, offs, signs;
+    std::vector<double> coeffs;
+    for (size_t i = 0; i < T.size(); ++i) {
+      if (i == 0 || T[i].m != T[i - 1].m) { masks.push_back(T[i].m); offs.push_back((int64_t)i); }
+      signs.push_back(T[i].s);
+      coeffs.push_back(T[i].c); coeffs.push_back(0.0);  // (one double per term is all a handle keeps: see dnm_mat_create)
+    }
+    offs.push_back((int64_t)T.size());
+    int fl = A->flags & ~(0xff << DNM_MAT_AMIN_SHIFT);
+    if (which == 1 && np - fp <= 8) {
+      // layout B's masks live on the p exchanged bits and the top bit: a tile [0, a) + [f, n) holds them all and
+      // leaves the bits right below f -- the top bits INSIDE a piece -- to the workgroup index, so that ranges of
+      // workgroups are contiguous sub-pieces (dnm_mat_mult_local_part)
+      const char *tb = knob("DNM_TILE_BITS");
+      const int a = (tb ? atoi(tb) : 12) - (np - fp);
+      if (a >= 2 && a <= 9) fl |= a << DNM_MAT_AMIN_SHIFT;
+    } else {
+      fl |= A->flags & (0xff << DNM_MAT_AMIN_SHIFT);
+    }
+    int rc = dnm_mat_create((int64_t)masks.size(), masks.data(), offs.data(), signs.data(), coeffs.data(), &ld, &rd, 0, fl,
+                            &part, &made[which]);
+    int ns_ = 0, nr_ = 0;
+    if (rc == 0) rc = dnm_mat_exchange_plan(made[which], &ns_, nullptr, &nr_, nullptr);
+    if (rc == 0 && (ns_ || nr_)) { set_error("transposed exchange: a pass is not rank-local"); rc = 1; }
+    if (rc == 0 && !(made[which]->hypercube && made[which]->plan.use_tiled)) {
+      set_error("transposed exchange: a part of the operator has no tiled plan"); rc = 1;
+    }
+    if (rc != 0) { delete made[0]; delete made[1]; return rc; }
+  }
+  A->tr_lo = made[0];
+  A->tr_hi = made[1];
+  A->tr_f = fp;
+  *chosen = DNM_EXCHANGE_TRANSPOSE;
+  return 0;
+}
+
+int dnm_mat_operator(const dnm_mat *A, int64_t *nmasks, int64_t *nterms, int64_t *masks, int64_t *mask_offsets,
+                     int64_t *signs, double *coeffs) {
+  DNM_CHECK(A && nmasks && nterms, "null argument");
+  *nmasks = (int64_t)A->masks.size();
+  *nterms = (int64_t)A->signs.size();
+  if (masks) std::copy(A->masks.begin(), A->masks.end(), masks);
+  if (mask_offsets) std::copy(A->mask_offsets.begin(), A->mask_offsets.end(), mask_offsets);
+  if (signs) std::copy(A->signs.begin(), A->signs.end(), signs);
+  if (coeffs) std::copy(A->real_coeffs.begin(), A->real_coeffs.end(), coeffs);
+  return 0;
+}
+
+int dnm_mat_exchange_parts(const dnm_mat *A, dnm_mat **lo, dnm_mat **hi, int *f) {
+  DNM_CHECK(A && lo && hi && f, "null argument");
+  *lo = A->tr_lo; *hi = A->tr_hi; *f = A->tr_f;
+  return 0;
+}
+
 int dnm_mat_sizes(const dnm_mat *A, int64_t *M, int64_t *N, int64_t *m_local, int64_t *n_local) {
   DNM_CHECK(A, "null matrix");
   if (M) *M = A->M;
@@ -1649,3 +1757,8 @@ int dnm_mat_plan_launches(const dnm_mat *A, int *n) {
 }
 
 }  // extern "C"
+
+dnm_mat::~dnm_mat() {
+  delete tr_lo;
+  delete tr_hi;
+}

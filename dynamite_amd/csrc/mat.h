@@ -94,6 +94,12 @@ struct dnm_mat {
   int expm_bound = 0;             // what the Lanczos probe of the norm bound found: +1 tight, -1 loose, 0 not probed
   dnm::DevBuf d_scmasks;          // SpinConserve kernel: per-mask precomputation (ScMask[nmasks])
 
+  // transposed exchange (dnm_mat_set_exchange): the terms that flip no rank bit in the vectors' own layout, the
+  // others with the rank bits swapped against the local field [tr_f, tr_f + p) -- both rank-local; owned by this handle
+  dnm_mat *tr_lo = nullptr, *tr_hi = nullptr;
+  int tr_f = -1;
+  ~dnm_mat();
+
   dnm::DevBuf diag;              // cached diagonal (double[m_local]) if precomputed
   bool have_diag = false;
   double nrm = -1.0;             // ctx->nrm cache, -1 = unset (bpetsc_template_2.c:926-929)

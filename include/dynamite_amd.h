@@ -466,24 +466,48 @@ int dnm_workspace_reserve(size_t bytes, void *stream);
  *     exchange -- XOR-partner sub-blocks of a Full / Parity pair on 2^p ranks, the needed ranges of the column window
  *     of every other partition -- is posted on the exchange stream as one group of ncclSend / ncclRecv, the part of
  *     the multiply that reads nothing from other ranks runs under it on `stream`, the rest follows its event.
- *     Collective.  (Full / Parity on four and more ranks are faster through the transposed exchange, whose schedule
- *     multiplies with two further handles the host builds: dynamite_amd/backend.py.)
+ *     Collective.
+ *   dnm_mat_set_exchange: the scheme of a tiled Full / Parity operator on 2^p ranks.  DNM_EXCHANGE_TRANSPOSE (AUTO: from
+ *     four ranks on, where an all-to-all puts less on the busiest xGMI link than the partner blocks): the operator is
+ *     split inside the handle into the terms that flip no rank bit and the others rewritten for the layout in which the
+ *     rank bits are local (the p index bits [f, f + p), f = n_local_bits - 1 - p, swapped with them); both parts are
+ *     rank-local.  dnm_mat_mult_partitioned then sends the state through ONE all-to-all, runs the first part under it,
+ *     the second on the redistributed state -- sub-piece by sub-piece as the pieces land, where the plan allows -- and
+ *     adds what the returning all-to-all brings (bpetsc_template_2.c:866-873 overlaps assembly and compute block by
+ *     block).  *chosen = the scheme in force: an operator that does not split (a term flips a rank bit and the field it
+ *     would move to; too few local bits; no tiled plan) keeps DNM_EXCHANGE_PARTNER.  dnm_mat_exchange_parts hands out the
+ *     two parts (owned by A; NULL under the partner scheme) and f, for hosts that run the schedule themselves.
  *   dnm_comm_allreduce: n doubles summed (op 0) / maximised (op 1) over the ranks, in place, host memory;
  *   dnm_comm_hooks: the dnm_hooks of dnm_expm_multiply / dnm_eigsolve filled with the two above (valid until the
  *     communicator is destroyed);
+ *   dnm_comm_prepare: allocate now what the first dnm_mat_mult_partitioned of A would (receive buffers, the column
+ *     window -- collective --, the two vectors of the transposed exchange), so that a solver sizing its Krylov basis
+ *     to the free device memory sees what is really left;
  *   dnm_comm_forget: drop what the communicator caches for A (receive buffers, windows) before A is destroyed;
  *   dnm_comm_loopback (tests): a communicator of ONE rank stands for rank vrank of vranks; peer q's block of x is the
- *     device pointer peer_x[q] (peer_mat[q]: its handle, needed by window partitions; entries for vrank itself are
- *     ignored) and every message becomes an RCCL send of this process to itself -- the schedules and the transport
- *     on a one-GPU box. */
+ *     device pointer peer_x[q] (peer_mat[q]: its handle, needed by window partitions and by the transposed exchange,
+ *     whose returning pieces are what the PEERS computed -- the loop-back runs their second part too; without handles
+ *     the returning pieces carry this rank's own data: right traffic, wrong numbers, for timing; entries for vrank
+ *     itself are ignored) and every message becomes an RCCL send of this process to itself -- the schedules and the
+ *     transport on a one-GPU box. */
 typedef struct dnm_comm dnm_comm;
 int dnm_comm_unique_id(void *id128);
 int dnm_comm_create(const void *id128, int rank, int nranks, dnm_comm **out);
 int dnm_comm_destroy(dnm_comm *c);
+int dnm_comm_prepare(dnm_comm *c, dnm_mat *A, void *stream);
 int dnm_comm_forget(dnm_comm *c, dnm_mat *A);
 int dnm_comm_loopback(dnm_comm *c, int vrank, int vranks, const void *const *peer_x, dnm_mat *const *peer_mat);
 int dnm_comm_allreduce(dnm_comm *c, double *vals, int n, int op);
 int dnm_mat_mult_partitioned(dnm_mat *A, dnm_comm *c, const void *x, void *y, void *stream);
+enum { DNM_EXCHANGE_AUTO = 0, DNM_EXCHANGE_PARTNER = 1, DNM_EXCHANGE_TRANSPOSE = 2 };
+int dnm_mat_set_exchange(dnm_mat *A, int scheme, int *chosen);
+int dnm_mat_exchange_parts(const dnm_mat *A, dnm_mat **lo, dnm_mat **hi, int *f);
+/* The operator a handle holds (its own copies, as BuildContext_* keeps them): counts first (arrays may be NULL), then
+ * masks[nmasks], mask_offsets[nmasks + 1], signs[nterms], coeffs[nterms] -- ONE double per term, the real part of the
+ * coefficient where that is non-zero, else the imaginary part (ctx->real_coeffs, bpetsc_template_2.c:286-289; which of
+ * the two it is follows from mask and sign: TERM_REAL, :398-404). */
+int dnm_mat_operator(const dnm_mat *A, int64_t *nmasks, int64_t *nterms, int64_t *masks, int64_t *mask_offsets,
+                     int64_t *signs, double *coeffs);
 int dnm_comm_hooks(dnm_comm *c, dnm_mat *A, void *stream, dnm_hooks *out);
 
 enum { DNM_WHICH_LOWEST = 0, DNM_WHICH_HIGHEST = 1, DNM_WHICH_EXTERIOR = 2 };

@@ -10,6 +10,10 @@ Cases come from the parent as an .npz (operator arrays, subspace parameters, the
   partner  Full space on P = 2 / 8 ranks, swizzled vectors (XOR-partner sub-blocks, bpetsc_template_2.c:787-879);
   window   SpinConserve in reference order on 3 ranks (rows split like PetscSplitOwnership, row-range overlap), Full
            on 3 ranks, SpinConserve in the internal layout on 2 / 3 ranks (two tiled passes split around the exchange).
+  transpose  Full / Parity on 2 / 4 / 8 ranks under dnm_mat_set_exchange(DNM_EXCHANGE_TRANSPOSE): the operator split
+           inside the handle, the state through one all-to-all, the second part sub-piece by sub-piece (and in one
+           piece: DNM_TRANSPOSE_PIPE=0), the returning pieces -- what the PEERS' second parts computed, run by the
+           loop-back from their handles -- added on arrival; also a real-packed operator (DNM_MAT_REAL_PACKED).
 Then the solvers through dnm_comm_hooks on one of the partitions.  Prints one JSON line; exit code 0 = all equal.
 """
 import ctypes as C
@@ -73,15 +77,23 @@ def main():
         g = {k.split("/", 1)[1]: cases[k] for k in cases.files if k.startswith(name + "/")}
         typ, Lsp, k, P = int(g["type"]), int(g["L"]), int(g["k"]), int(g["P"])
         swz = int(g["swz"])
+        exchange, flags, packed = int(g["exchange"]), int(g["flags"]), bool(int(g["flags"]) & B.MAT_REAL_PACKED)
+        if "env" in g:
+            for kv in str(g["env"]).split():
+                os.environ[kv.split("=")[0]] = kv.split("=")[1]
         nck = np.ascontiguousarray(g["nck"], dtype=np.int64)
         sub = B.Subspace()
         sub.type, sub.L, sub.k = typ, Lsp, k
+        sub.space = int(g["space"])
         sub.ld_nchoosek = Lsp + 1
         sub.nchoosek = nck.ctypes.data_as(B.i64p)
         sub.vec_swizzle = swz
         masks, offs = np.ascontiguousarray(g["masks"]), np.ascontiguousarray(g["mask_offsets"])
         signs, coeffs = np.ascontiguousarray(g["signs"]), np.ascontiguousarray(g["coeffs"])
         x, want = g["x"], g["y"]
+        if packed:             # real vectors, two amplitudes to an element
+            assert not np.abs(x.imag).any() and not np.abs(want.imag).any()
+            x, want = x.real[0::2] + 1j * x.real[1::2], want.real[0::2] + 1j * want.real[1::2]
         dim = x.size
         internal = typ == 3 and swz >= 256
 
@@ -126,8 +138,12 @@ def main():
             h = vp()
             pq = B.Partition(q, P)
             ck(L.dnm_mat_create(masks.size, B.p64(masks), B.p64(offs), B.p64(signs),
-                                coeffs.view(np.float64).ctypes.data_as(B.f64p), C.byref(sub), C.byref(sub), 0, 0,
+                                coeffs.view(np.float64).ctypes.data_as(B.f64p), C.byref(sub), C.byref(sub), 0, flags,
                                 C.byref(pq), C.byref(h)))
+            if exchange:
+                chosen = C.c_int()
+                ck(L.dnm_mat_set_exchange(h, exchange, C.byref(chosen)))
+                assert chosen.value == exchange, (name, chosen.value)
             if masks.size and masks[0] == 0 and typ == 3:
                 ck(L.dnm_mat_precompute_diagonal(h, None))        # the SpinConserve kernels read a cached diagonal
             mats.append(h)
@@ -166,6 +182,8 @@ def main():
             ck(hooks.allreduce_sum(hooks.ctx, vals, 2))
             assert list(vals) == [3.0, 4.0]
             report["hooks"] = "ok"
+        for kv in (str(g["env"]).split() if "env" in g else []):
+            os.environ.pop(kv.split("=")[0])
         for q in range(P):
             ck(L.dnm_comm_forget(comm, mats[q]))
             ck(L.dnm_mat_destroy(mats[q]))

@@ -80,6 +80,88 @@ def test_split_reproduces_the_operator_parity(name, L, P, space):
     assert np.max(np.abs(y - ref)) <= 1e-13 * max(1.0, np.abs(ref).max())
 
 
+@pytest.mark.parametrize("name,L,P,kind", [("mbl", 16, 4, "full"), ("heisenberg", 17, 8, "full"), ("ising", 15, 2, "full"),
+                                           ("long_range", 16, 4, "full"), ("mbl", 17, 4, "parity"),
+                                           ("heisenberg", 17, 8, "packed")])
+def test_native_split_is_the_host_split(name, L, P, kind):
+    """dnm_mat_set_exchange (csrc/mat.cpp) splits inside the handle what backend.transpose_split splits on the host: the
+    two parts of every rank, term by term (dnm_mat_operator), the field, and the plans the parts get (host-only handles:
+    no device needed)."""
+    import ctypes as C
+    from dynamite_amd import _lib, backend
+    from dynamite_amd.subspaces import Full, Parity
+    arrs = _arrays(name, L)
+    sub = Parity('even', L=L) if kind == "parity" else Full(L=L)
+    shift = 1 if kind == "parity" else 0
+    flags = _lib.MAT_HOST_ONLY | (_lib.MAT_REAL_PACKED if kind == "packed" else 0)
+    sc = sub._to_c()['data']
+    sc.vec_swizzle = 6 if name == "heisenberg" else 0              # (pieces of 2^f >= 2^8 amplitudes: a swizzle of 6 fits)
+    split = backend.transpose_split(*arrs, L - shift, P, int(sc.vec_swizzle), shift, packed=kind == "packed")
+    assert split is not None
+    lib = _lib.lib()
+
+    def operator_of(h):
+        nm, nt = C.c_int64(), C.c_int64()
+        _lib.check(lib.dnm_mat_operator(h, C.byref(nm), C.byref(nt), None, None, None, None))
+        m, o = np.zeros(nm.value, np.int64), np.zeros(nm.value + 1, np.int64)
+        s_, c = np.zeros(nt.value, np.int64), np.zeros(nt.value, np.float64)
+        _lib.check(lib.dnm_mat_operator(h, C.byref(nm), C.byref(nt), _lib.p64(m), _lib.p64(o), _lib.p64(s_), _lib.pf64(c)))
+        return m, o, s_, c
+
+    def describe(h):
+        buf = C.create_string_buffer(1 << 14)
+        _lib.check(lib.dnm_mat_plan_describe(h, buf, len(buf)))
+        return buf.value.decode()
+
+    for rank in (0, P - 1, P // 2):
+        h = backend.create_mat(*arrs, sc, sc, False, flags, rank, P)
+        chosen = C.c_int()
+        _lib.check(lib.dnm_mat_set_exchange(h, _lib.EXCHANGE_AUTO, C.byref(chosen)))
+        assert chosen.value == (_lib.EXCHANGE_TRANSPOSE if P >= 4 else _lib.EXCHANGE_PARTNER)
+        _lib.check(lib.dnm_mat_set_exchange(h, _lib.EXCHANGE_TRANSPOSE, C.byref(chosen)))
+        assert chosen.value == _lib.EXCHANGE_TRANSPOSE
+        lo, hi, f = C.c_void_p(), C.c_void_p(), C.c_int()
+        _lib.check(lib.dnm_mat_exchange_parts(h, C.byref(lo), C.byref(hi), C.byref(f)))
+        assert f.value == split[2] - (1 if kind == "packed" else 0)
+        for part, want in ((lo, split[0]), (hi, split[1])):
+            m, o, s_, c = operator_of(part)
+            assert np.array_equal(m, want[0]) and np.array_equal(o, want[1]) and np.array_equal(s_, want[2])
+            wc = np.where(want[3].real != 0, want[3].real, want[3].imag)
+            assert np.array_equal(c, wc)
+        n = (L - shift - (P.bit_length() - 1)) - (1 if kind == "packed" else 0)
+        fl = flags
+        a = 12 - (n - f.value)
+        if n - f.value <= 8 and 2 <= a <= 9:
+            fl |= a << _lib.MAT_AMIN_SHIFT
+        ref_hi = backend.create_mat(*split[1], sc, sc, False, fl, rank, P)
+        assert describe(hi) == describe(ref_hi)
+        lib.dnm_mat_destroy(ref_hi)
+        _lib.check(lib.dnm_mat_set_exchange(h, _lib.EXCHANGE_PARTNER, C.byref(chosen)))
+        _lib.check(lib.dnm_mat_exchange_parts(h, C.byref(lo), C.byref(hi), C.byref(f)))
+        assert chosen.value == _lib.EXCHANGE_PARTNER and not lo.value and not hi.value
+        lib.dnm_mat_destroy(h)
+
+
+def test_native_split_refuses_what_the_host_split_refuses():
+    import ctypes as C
+    from dynamite_amd import _lib, backend, msc_tools
+    from dynamite_amd.operators import sigmax, index_sum
+    from dynamite_amd.subspaces import Full
+    lib = _lib.lib()
+    H = index_sum(sigmax(0) * sigmax(3), size=16)       # flips three sites apart couple the rank bits to the field F
+    H.L = 16
+    H.reduce_msc()
+    m, o = msc_tools.get_mask_offsets(H.msc)
+    sc = Full(L=16)._to_c()['data']
+    for arrs, P in (((m, o, H.msc['signs'], H.msc['coeffs']), 4), (_arrays("mbl", 16), 1)):
+        h = backend.create_mat(*arrs, sc, sc, False, _lib.MAT_HOST_ONLY, 0, P)
+        chosen = C.c_int(7)
+        _lib.check(lib.dnm_mat_set_exchange(h, _lib.EXCHANGE_TRANSPOSE, C.byref(chosen)))
+        assert chosen.value == _lib.EXCHANGE_PARTNER
+        assert lib.dnm_mat_set_exchange(h, 5, C.byref(chosen)) != 0
+        lib.dnm_mat_destroy(h)
+
+
 def test_split_refuses_what_it_cannot_do():
     from dynamite_amd.backend import transpose_split
     from dynamite_amd import msc_tools

@@ -128,6 +128,21 @@ def main():
             print("   transposed exchange looped back (swizzle %d, %s): %.2f ms per multiply; its two all-to-alls alone %.2f ms "
                   "(%.1f GiB, %.0f GB/s through RCCL's copies)"
                   % (S, "pipelined" if mat2._tr_pipe else "whole pieces", t_tr, t_ex, moved / 2 ** 30, moved / t_ex / 1e6), flush=True)
+            # ... and split and scheduled inside the library (dnm_mat_set_exchange + dnm_mat_mult_partitioned): the host's
+            # buffers go first (the library has its own pair), every peer's block = this rank's x, no peer handles
+            # (the returning pieces carry this rank's own result)
+            for h_ in mat2._tr[:2]:
+                _lib.check(_lib.lib().dnm_mat_destroy(h_))
+            mat2._tr, mat2._tr_bufs = None, None
+            torch.cuda.empty_cache()
+            assert mat2.set_native_transposed()
+            px = (C.c_void_p * P)(*[x.array.data_ptr()] * P)
+            _lib.check(_lib.lib().dnm_comm_loopback(comm, me, P, px, None))
+            t_ntr = timed(lambda: _lib.check(_lib.lib().dnm_mat_mult_partitioned(mat2.handle, comm, x.ptr, y.ptr, backend._stream())))
+            _lib.check(_lib.lib().dnm_comm_forget(comm, mat2.handle))
+            print("   the same as one native call (split by dnm_mat_set_exchange, schedule in csrc/comm.cpp): %.2f ms" % t_ntr,
+                  flush=True)
+            assert torch.isfinite(torch.view_as_real(y.array)).all()
             mat2.destroy()
             del x, y
             torch.cuda.empty_cache()
