@@ -1145,7 +1145,9 @@ def test_eigsolve_deflated_pairs(monkeypatch, name, L, sub, which, real, getvecs
     from dynamite_amd.computations import eigsolve
     st = eigsolve.last_stats
     assert st['nconv'] == nev and st['max_rel_residual'] <= 1.01e-10
-    if sub != "sc":                       # (SpinConserve has a real form in the internal layout only: test_gpu_sc3*.py)
+    if sub != "sc" and name != "long_range":
+        # (SpinConserve has a real form in the internal layout only: test_gpu_sc3*.py; the packed form refuses the
+        # long-range model under these small tiles and complex128 runs)
         assert st['real_arithmetic'] is (real == "1")
     assert len(ev) == nev and np.max(np.abs(np.array(ev) - want)) < 1e-8 * max(1.0, np.abs(want).max()), (ev, want)
     for i, (e, v) in enumerate(zip(ev, vecs)):
