@@ -189,6 +189,16 @@ struct Sc3Op {
   // window pass, its LDS hops: wnb[(w_off[cw] + wr) * nldsB + h] = rank of the row hop h couples row wr of class cw to,
   // nw[cw] (the zero row behind the tile) where it does not act
   const uint8_t *wnb = nullptr;
+  // lo pass, its LDS hops by table (at most SC3G_MAX_PTAB of them): ptab[(ptab_row[kl] + r) * nhp + h] = byte offset in
+  // the row's LDS tile (entries of 16 bytes; 8 in real arithmetic) of the entry hop h couples entry r of class kl to --
+  // the entry behind the row's nl[kl] entries, which the kernels keep at zero, where the hop does not act.  nhp = the
+  // hops rounded up to 8 (a table row is whole 16-byte words); a class has nl[kl] + 1 rows rounded up to even.  One
+  // 16-bit extract per (entry, hop) in place of a pair test and a two-table rank: the pass was bound by those
+  // instructions (profiles/r05_kagome_real_counters.txt).  Null: the rank tables.
+  const uint16_t *ptab = nullptr;
+  const double *pcoef = nullptr;   // [nhp] the hops' matrix elements (up_re; zeros behind the last hop): direction-independent real operators
+  int32_t nhp = 0;
+  int32_t ptab_row[SC3_MAXA + 2] = {};
 };
 // Per-call data: partition offsets (x holds the internal positions [win_start, ...), y / diag / z are this rank's
 // vectors starting at internal position row0), start vectors and fused sums as in launch_sc_block
@@ -223,9 +233,11 @@ struct Sc3Mat {
   Sc3Op op{};
   std::vector<uint32_t> permA, permB;
   void *d_permA = nullptr, *d_permB = nullptr, *d_bond = nullptr, *d_dlo = nullptr, *d_dt_sign = nullptr,
-       *d_dt_coef = nullptr, *d_dt_group = nullptr, *d_hops = nullptr, *d_wnb = nullptr;
+       *d_dt_coef = nullptr, *d_dt_group = nullptr, *d_hops = nullptr, *d_wnb = nullptr, *d_ptab = nullptr, *d_pcoef = nullptr;
   std::vector<Sc3Hop> hops;        // ldsA, gatA, ldsB, gatB back to back
   std::vector<uint8_t> wnb;
+  std::vector<uint16_t> ptab;
+  std::vector<double> pcoef;
   Sc3Mat() = default;
   Sc3Mat(const Sc3Mat &) = delete;
   Sc3Mat &operator=(const Sc3Mat &) = delete;
@@ -240,6 +252,7 @@ struct Sc3Mat {
 bool sc3_instance(int a, int w);           // kernel instances exist for this field split
 // the two passes for operators on any bond graph (sc3g_kernels.hip); same contract as launch_sc3's tiled branch
 constexpr int SC3G_MAX_GATHER = 64, SC3G_MAX_WLDS = 40;
+constexpr int SC3G_MAX_PTAB = 32;     // LDS hops of the lo pass the partner table serves (four 16-byte words per row)
 int launch_sc3g(const Sc3Mat &M, const Sc3Call &call, const double *cached_diag, const void *xw, void *y, hipStream_t st,
                 int phase);
 size_t sc3_dot_partials(const Sc3Mat &M);

@@ -1391,7 +1391,7 @@ static std::vector<uint32_t> pack_lo_rows(const std::vector<uint32_t> &order, co
 bool sc3_instance(int a, int w) { return (a == 14 && w == 10) || (a == 6 && w == 4); }
 
 Sc3Mat::~Sc3Mat() {
-  for (void *p : {d_permA, d_permB, d_bond, d_dlo, d_dt_sign, d_dt_coef, d_dt_group, d_rowsel, d_hops, d_wnb})
+  for (void *p : {d_permA, d_permB, d_bond, d_dlo, d_dt_sign, d_dt_coef, d_dt_group, d_rowsel, d_hops, d_wnb, d_ptab, d_pcoef})
     if (p) (void)hipFree(p);
 }
 
@@ -1555,6 +1555,51 @@ int Sc3Mat::init(const Sc3Layout *layout, const std::vector<int64_t> &masks, con
       }
   }
   op.nldsA = (int32_t)nh[0]; op.ngatA = (int32_t)nh[1]; op.nldsB = (int32_t)nh[2]; op.ngatB = (int32_t)nh[3];
+  // partner table of the lo pass's LDS hops (Sc3Op::ptab).  Needs the zero entry behind a row's entries inside the
+  // row's share of the tile: true for every class of the instances (C(a, kl) is no power of two above 1).
+  ptab.clear();
+  op.ptab = nullptr;
+  op.nhp = 0;
+  {
+    const char *pe = knob("DNM_SC3G_PTAB");
+    const int ntl = a == 14 ? 1024 : 256;          // threads of the lo pass (launch_sc3g)
+    const int cap = real ? sc3_lo_cap_r(a, ntl) : sc3_lo_cap(a, ntl);
+    const int nthr = real ? sc3r_threads(ntl) : ntl;
+    int maxm = 0;
+    while (maxm < 3 && (nthr >> (maxm + 1)) >= 64) ++maxm;
+    bool ok = graph && nh[0] > 0 && (int)nh[0] <= SC3G_MAX_PTAB && !(pe && pe[0] == '0');
+    for (int kl = 0; kl <= a && ok; ++kl) {
+      int m = 0;
+      while (m < maxm && S.nl[kl] <= (cap >> (m + 1))) ++m;
+      if (S.nl[kl] >= (cap >> m) || (S.nl[kl] + 1) * (real ? 8 : 16) > 0xffff) ok = false;
+    }
+    if (ok) {
+      const int nhp = ((int)nh[0] + 7) & ~7, esz = real ? 8 : 16;
+      int row = 0;
+      for (int kl = 0; kl <= a; ++kl) {
+        op.ptab_row[kl] = row;
+        row += (S.nl[kl] + 2) & ~1;
+      }
+      ptab.assign((size_t)row * nhp, 0);
+      for (int kl = 0; kl <= a; ++kl) {
+        const uint16_t zero = (uint16_t)(S.nl[kl] * esz);
+        const int nrow = (S.nl[kl] + 2) & ~1;
+        for (int r = 0; r < nrow; ++r) {
+          uint16_t *t = ptab.data() + (size_t)(op.ptab_row[kl] + r) * nhp;
+          for (int q = 0; q < nhp; ++q) t[q] = zero;
+          if (r >= S.nl[kl]) continue;
+          const uint32_t v = ly->lo_pat[S.lo_off[kl] + r];
+          for (size_t q = 0; q < nh[0]; ++q) {
+            const Sc3Hop &h = hops[q];               // (the LDS hops of the lo pass come first)
+            if (__builtin_popcount(v & h.mLo) == h.half) t[q] = (uint16_t)(ly->lo_rank[v ^ h.mLo] * esz);
+          }
+        }
+      }
+      op.nhp = nhp;
+      pcoef.assign((size_t)nhp, 0.0);
+      for (size_t q = 0; q < nh[0]; ++q) pcoef[q] = hops[q].up_re;
+    }
+  }
   // diagonal on the fly: split the mask-0 terms by what their sign masks see
   diag_mode = 0;
   std::vector<double> dlo;
@@ -1717,6 +1762,12 @@ int Sc3Mat::init(const Sc3Layout *layout, const std::vector<int64_t> &masks, con
       const Sc3Hop *hp = (const Sc3Hop *)d_hops;
       op.ldsA = hp; op.gatA = hp + nh[0]; op.ldsB = hp + nh[0] + nh[1]; op.gatB = hp + nh[0] + nh[1] + nh[2];
       op.wnb = (const uint8_t *)d_wnb;
+      if (!ptab.empty()) {
+        DNM_TRY(up(ptab, &d_ptab));
+        op.ptab = (const uint16_t *)d_ptab;
+        DNM_TRY(up(pcoef, &d_pcoef));
+        op.pcoef = (const double *)d_pcoef;
+      }
     }
     if (diag_mode == 2) {
       DNM_TRY(up(dlo, &d_dlo)); DNM_TRY(up(dt_sign, &d_dt_sign)); DNM_TRY(up(dt_coef, &d_dt_coef));

@@ -185,6 +185,8 @@ sc3g_lo_pass(const Sc3Tab S, const Sc3Op O, const uint32_t *__restrict__ perm, c
       }
   }
   double accr[RPT], acci[RPT];
+  // the zero entry behind the row's entries, where the partner table points for hops that do not act
+  if (O.ptab && has_row && tsub == 0) xs[nrows] = make_double2(0.0, 0.0);
 #pragma unroll
   for (int i = 0; i < RPT; ++i) {
     const int r = tsub + i * NTS;
@@ -192,10 +194,15 @@ sc3g_lo_pass(const Sc3Tab S, const Sc3Op O, const uint32_t *__restrict__ perm, c
     acci[i] = 0.0;
     if (r < nrows) {
       xs[r] = xv[i];
+      if (ACC) {                   // the accumulators start from what the window pass wrote (no registers for y later)
+        const c128 yo = load_nt(y + lbase + r);
+        accr[i] = yo.x;
+        acci[i] = yo.y;
+      }
       if (DIAGM == 1) {
         const double dg = __builtin_nontemporal_load(O.diag + lbase + r);
-        accr[i] = dg * xv[i].x;
-        acci[i] = dg * xv[i].y;
+        accr[i] = fma(dg, xv[i].x, accr[i]);
+        acci[i] = fma(dg, xv[i].y, acci[i]);
       }
     }
   }
@@ -226,15 +233,6 @@ sc3g_lo_pass(const Sc3Tab S, const Sc3Op O, const uint32_t *__restrict__ perm, c
       }
     }
   }
-  c128 yv[RPT];
-  if (ACC) {
-#pragma unroll
-    for (int i = 0; i < RPT; ++i) {
-      const int r = tsub + i * NTS;
-      yv[i] = make_double2(0.0, 0.0);
-      if (r < nrows) yv[i] = load_nt(y + lbase + r);
-    }
-  }
   double dlv[RPT];
   if (DIAGM == 2) {
     const auto dl = SC3_CP(double, O.dlo) + S.lo_off[kl];
@@ -259,7 +257,58 @@ sc3g_lo_pass(const Sc3Tab S, const Sc3Op O, const uint32_t *__restrict__ perm, c
       }
     }
   }
-  // hops inside Lo: the partner column is the rank of the flipped pattern
+  // hops inside Lo: the partner column is the rank of the flipped pattern -- from the partner table (Sc3Op::ptab: the
+  // table row of an entry in 16-byte words straight from the L2, then one extract, one LDS read and the FMAs per hop)
+  if (O.ptab) {
+    constexpr int NQ = SC3G_MAX_PTAB / 8;
+    const int nq = O.nhp >> 3;
+    const uint4 *__restrict__ trow = reinterpret_cast<const uint4 *>(O.ptab + (size_t)O.ptab_row[kl] * (size_t)O.nhp);
+    const unsigned char *xb = reinterpret_cast<const unsigned char *>(xs);
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+      const int r = tsub + i * NTS;
+      if (r < nrows) {
+#pragma unroll
+        for (int c = 0; c < NQ; ++c) {
+          if (c < nq) {
+            const uint4 q0 = trow[(size_t)r * nq + c];
+            const uint32_t d0[4] = {q0.x, q0.y, q0.z, q0.w};
+            if (SYM) {
+              // two hops at a time, no branch among them (the table's last word is padded with hops of coefficient zero
+              // that point at the zero entry): their LDS reads go out together
+#pragma unroll
+              for (int g2 = 0; g2 < 4; ++g2) {
+                __builtin_amdgcn_sched_barrier(0);
+                const uint32_t ta = d0[g2] & 0xffffu, tb = d0[g2] >> 16;
+                const c128 va = *reinterpret_cast<const c128 *>(xb + ta), vb = *reinterpret_cast<const c128 *>(xb + tb);
+                const double ua = SC3_CP(double, O.pcoef)[8 * c + 2 * g2], ub = SC3_CP(double, O.pcoef)[8 * c + 2 * g2 + 1];
+                accr[i] = fma(ua, va.x, accr[i]);
+                acci[i] = fma(ua, va.y, acci[i]);
+                accr[i] = fma(ub, vb.x, accr[i]);
+                acci[i] = fma(ub, vb.y, acci[i]);
+              }
+            } else {
+#pragma unroll
+              for (int hh = 0; hh < 8; ++hh) {
+                const int h = 8 * c + hh;
+                if (h < O.nldsA) {
+                  const auto hp = SC3_CP(Sc3Hop, O.ldsA) + h;
+                  const uint32_t t = (hh & 1) ? d0[hh >> 1] >> 16 : d0[hh >> 1] & 0xffffu;
+                  const c128 xp = *reinterpret_cast<const c128 *>(xb + t);
+                  const bool up = (lowb[i] >> hp->dbit) & 1u;
+                  const double cre = up ? hp->up_re : hp->dn_re, cim = up ? hp->up_im : hp->dn_im;
+                  accr[i] = fma(cre, xp.x, accr[i]);
+                  acci[i] = fma(cre, xp.y, acci[i]);
+                  accr[i] = fma(-cim, xp.y, accr[i]);
+                  acci[i] = fma(cim, xp.x, acci[i]);
+                }
+              }
+            }
+          }
+        }
+      }
+    }
+  } else
   for (int hq = 0; hq < O.nldsA; ++hq) {
     const auto hp = SC3_CP(Sc3Hop, O.ldsA) + hq;
     const uint32_t m = hp->mLo;
@@ -293,10 +342,7 @@ sc3g_lo_pass(const Sc3Tab S, const Sc3Op O, const uint32_t *__restrict__ perm, c
     if (r < p) {                                  // the padding of a row is written too (zeros)
       double ar = accr[i], ai = acci[i];
       if (r < nrows) {
-        if (ACC) {
-          ar += yv[i].x;
-          ai += yv[i].y;
-        } else if (C.zinit) {
+        if (!ACC && C.zinit) {
           const c128 zv = C.zinit[lbase + r];
           ar = fma(-C.zscale, zv.x, ar);
           ai = fma(-C.zscale, zv.y, ai);
@@ -466,16 +512,26 @@ sc3g_lo_pass_r(const Sc3Tab S, const Sc3Op O, const uint32_t *__restrict__ perm,
       }
   }
   double acc[EPT];
+  // the zero entry behind the row's entries, where the partner table points for hops that do not act: the padding of x
+  // holds zeros by the layout's contract, but the tile does not rely on it; a row without padding gets the entry here
+  if (O.ptab && has_row && nrows == p && tsub == 0) xs[nrows] = 0.0;
 #pragma unroll
   for (int i = 0; i < EPT; i += 2) {
     const int r = SC3R_ENT(i);
     acc[i] = acc[i + 1] = 0.0;
     if (r < p) {
+      if (r >= nrows) xv[i] = 0.0;
+      if (r + 1 >= nrows) xv[i + 1] = 0.0;
       *reinterpret_cast<d2v *>(xs + r) = d2v{xv[i], xv[i + 1]};
+      if (ACC) {                   // the accumulators start from what the window pass wrote (no registers for y later)
+        const d2v yo = __builtin_nontemporal_load(reinterpret_cast<const d2v *>(y + lbase + r));
+        acc[i] = yo.x;
+        acc[i + 1] = yo.y;
+      }
       if (DIAGM == 1) {
         const d2v dg = __builtin_nontemporal_load(reinterpret_cast<const d2v *>(O.diag + lbase + r));
-        acc[i] = dg.x * xv[i];
-        acc[i + 1] = dg.y * xv[i + 1];
+        acc[i] = fma(dg.x, xv[i], acc[i]);
+        acc[i + 1] = fma(dg.y, xv[i + 1], acc[i + 1]);
       }
     }
   }
@@ -499,15 +555,6 @@ sc3g_lo_pass_r(const Sc3Tab S, const Sc3Op O, const uint32_t *__restrict__ perm,
 #pragma unroll
     for (int i = 0; i < EPT; ++i) acc[i] = fma(cr, v[i], acc[i]);
   }
-  d2v yv[PPT];
-  if (ACC) {
-#pragma unroll
-    for (int i = 0; i < EPT; i += 2) {
-      const int r = SC3R_ENT(i);
-      yv[i >> 1] = d2v{0.0, 0.0};
-      if (r < p) yv[i >> 1] = __builtin_nontemporal_load(reinterpret_cast<const d2v *>(y + lbase + r));
-    }
-  }
   SC3_PRIO_LDS();
   if (DIAGM == 2) {
     const auto dl = SC3_CP(double, O.dlo) + S.lo_off[kl];
@@ -522,6 +569,48 @@ sc3g_lo_pass_r(const Sc3Tab S, const Sc3Op O, const uint32_t *__restrict__ perm,
       }
     }
   }
+  if (O.ptab) {
+    // hops inside Lo by the partner table: the two table rows of a pair of entries (16-byte words, straight from the
+    // L2: every row of the class reads the same ones), then per (entry, hop) one 16-bit extract, one LDS read, one FMA
+    constexpr int NQ = SC3G_MAX_PTAB / 8;
+    const int nq = O.nhp >> 3;
+    const uint4 *__restrict__ trow = reinterpret_cast<const uint4 *>(O.ptab + (size_t)O.ptab_row[kl] * (size_t)O.nhp);
+    const unsigned char *xb = reinterpret_cast<const unsigned char *>(xs);
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+      const int r = SC3R_ENT(2 * j);
+      if (r < nrows) {
+        // four hops at a time, no branch among them (the table's last word is padded with hops of coefficient zero that
+        // point at the zero entry): their LDS reads go out together
+#pragma unroll
+        for (int c = 0; c < NQ; ++c) {
+          if (c < nq) {
+            const uint4 q0 = trow[(size_t)r * nq + c], q1 = trow[(size_t)(r + 1) * nq + c];
+            const uint32_t d0[4] = {q0.x, q0.y, q0.z, q0.w}, d1[4] = {q1.x, q1.y, q1.z, q1.w};
+#pragma unroll
+            for (int g4 = 0; g4 < 2; ++g4) {
+              __builtin_amdgcn_sched_barrier(0);
+              double v0[4], v1[4];
+#pragma unroll
+              for (int hh = 0; hh < 4; ++hh) {
+                const int h8 = 4 * g4 + hh;
+                const uint32_t t0 = (h8 & 1) ? d0[h8 >> 1] >> 16 : d0[h8 >> 1] & 0xffffu;
+                const uint32_t t1 = (h8 & 1) ? d1[h8 >> 1] >> 16 : d1[h8 >> 1] & 0xffffu;
+                v0[hh] = *reinterpret_cast<const double *>(xb + t0);
+                v1[hh] = *reinterpret_cast<const double *>(xb + t1);
+              }
+#pragma unroll
+              for (int hh = 0; hh < 4; ++hh) {
+                const double ure = SC3_CP(double, O.pcoef)[8 * c + 4 * g4 + hh];
+                acc[2 * j] = fma(ure, v0[hh], acc[2 * j]);
+                acc[2 * j + 1] = fma(ure, v1[hh], acc[2 * j + 1]);
+              }
+            }
+          }
+        }
+      }
+    }
+  } else
   for (int hq = 0; hq < O.nldsA; ++hq) {
     const auto hp = SC3_CP(Sc3Hop, O.ldsA) + hq;
     const uint32_t m = hp->mLo;
@@ -545,8 +634,7 @@ sc3g_lo_pass_r(const Sc3Tab S, const Sc3Op O, const uint32_t *__restrict__ perm,
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
         if (r + b < nrows) {
-          if (ACC) a2[b] += b ? yv[i >> 1].y : yv[i >> 1].x;
-          else if (C.zinit) {
+          if (!ACC && C.zinit) {
             a2[b] = fma(-C.zscale, reinterpret_cast<const double *>(C.zinit)[lbase + r + b], a2[b]);
             if (C.zinit2) a2[b] = fma(C.z2re, reinterpret_cast<const double *>(C.zinit2)[lbase + r + b], a2[b]);
           }

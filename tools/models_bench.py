@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """One table over the Hamiltonians the reference's harness and flagship example run (benchmarking/benchmark.py:129-170,
 examples/scripts/kagome/run_kagome.py): for each (model, subspace, size) the plan line, ms per multiply, Gamp/s and the
-32 B/amp rate; `--eigs` adds the wall time of eigsolve(nev=2) for the kagome cases.
+32 B/amp rate; `--eigs` adds the wall time of eigsolve(nev=2) for the kagome cases, `--real` the multiply in real
+arithmetic (what eigsolve runs for real-symmetric operators).
 
     python tools/models_bench.py CASE ...       CASE = model:subspace:L[:k]   e.g. kagome30:sc, bench_long_range:full:28,
                                                  bench_long_range:sc:28, kagome30:scx (SpinConserve + XParity)
@@ -83,6 +84,22 @@ def main():
               (ms, dim / ms / 1e6, 32.0 * dim / ms / 1e6, 32.0 * dim / ms / 1e6 / 8000.0, ms_dot,
                ", site relabelling %s" % (list(mat.perm_left),) if getattr(mat, "perm_left", None) else ""), flush=True)
         del xv, yv
+        if "--real" in sys.argv:
+            # the multiply eigsolve runs for a real-symmetric operator (DNM_MAT_REAL_PACKED): 16 B per amplitude
+            pm = H.get_real_packed_mat(sub)
+            if pm is None:
+                print("   real arithmetic: no packed form", flush=True)
+            else:
+                # (raw arrays of the packed operator's size -- for timing: padding positions hold numbers too)
+                from dynamite_amd.backend import RawVec
+                xr = RawVec(torch.randn(2 * pm.n_local, dtype=torch.float64, device=config.device).view(torch.complex128),
+                            pm.swz_right)
+                yr = RawVec(torch.zeros(pm.m_local, dtype=torch.complex128, device=config.device), pm.swz_left)
+                xr.perm, yr.perm = pm.perm_right, pm.perm_left
+                msr = timed(lambda: pm.mult(xr, yr))
+                print("   multiply in real arithmetic %.3f ms  %.2f Gamp/s  %.1f GB/s (16 B/amp)  frac %.3f" %
+                      (msr, dim / msr / 1e6, 16.0 * dim / msr / 1e6, 16.0 * dim / msr / 1e6 / 8000.0), flush=True)
+                del xr, yr
         if eigs:
             del x, y
             t0 = time.perf_counter()
