@@ -475,8 +475,10 @@ int dnm_workspace_reserve(size_t bytes, void *stream);
  *     the second on the redistributed state -- sub-piece by sub-piece as the pieces land, where the plan allows -- and
  *     adds what the returning all-to-all brings (bpetsc_template_2.c:866-873 overlaps assembly and compute block by
  *     block).  *chosen = the scheme in force: an operator that does not split (a term flips a rank bit and the field it
- *     would move to; too few local bits; no tiled plan) keeps DNM_EXCHANGE_PARTNER.  dnm_mat_exchange_parts hands out the
- *     two parts (owned by A; NULL under the partner scheme) and f, for hosts that run the schedule themselves.
+ *     would move to; too few local bits; no tiled plan) keeps DNM_EXCHANGE_PARTNER.  Call it before the first
+ *     dnm_mat_mult_partitioned of A (or dnm_comm_forget(c, A) first: a communicator caches buffers per scheme), on every
+ *     rank alike.  dnm_mat_exchange_parts hands out the two parts (owned by A; NULL under the partner scheme) and f, for
+ *     hosts that run the schedule themselves.
  *   dnm_comm_allreduce: n doubles summed (op 0) / maximised (op 1) over the ranks, in place, host memory;
  *   dnm_comm_hooks: the dnm_hooks of dnm_expm_multiply / dnm_eigsolve filled with the two above (valid until the
  *     communicator is destroyed);
