@@ -813,10 +813,14 @@ static int eigsolve_basis_free(Ops &ops, dnm_mat *A, int64_t n_local, int nev, i
     bool converged = false;
     int steps = 0, rounds = 0;
     auto slot = [&](int k) { return (void *)vecptr(W, n_local, k % 3); };
-    // p <- p - F F^H p (first run: coefficients measured and recorded; second run: the recorded ones), |p|^2 after
+    // p <- p - F F^H p (first run: coefficients measured and recorded; second run: the recorded ones), |p|^2 after.
+    // At EVERY step: projecting only every fourth one (a quarter of the sweeps) lets the recurrence alternate between H
+    // and the deflated operator, and once the first Ritz value has converged the tridiagonal matrix is that of no
+    // symmetric operator any more -- Ritz values far below the spectrum (measured: docs/lab/r05.md section 10).
     auto deflate = [&](void *p, int j, bool replay, double *n2) -> int {
       std::vector<zc> h;
-      if (replay) h.assign(proj.begin() + (size_t)j * e, proj.begin() + (size_t)(j + 1) * e);
+      const size_t at = (size_t)j * e;
+      if (replay) h.assign(proj.begin() + at, proj.begin() + at + e);
       else {
         DNM_TRY(ops.mdot(F, e, p, h));
         proj.insert(proj.end(), h.begin(), h.end());

@@ -1312,6 +1312,7 @@ int sc3_positions(const Sc3Layout &Ly, int64_t n, const int64_t *idx, int64_t *p
                   const Sc3Perm *perm) {
   DNM_CHECK(Ly.on_device, "layout tables are not on the device");
   if (n <= 0) return 0;
+  DNM_CHECK(n < ((int64_t)1 << 32), "more than 2^32 indices in one call (one thread each: a launch holds fewer)");
   const RowRange r = row_range(Ly, T0, T1);
   DNM_TRY(perm_whole(Ly, perm, r));
   if (perm && perm->on) {

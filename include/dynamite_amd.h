@@ -520,7 +520,12 @@ enum { DNM_WHICH_LOWEST = 0, DNM_WHICH_HIGHEST = 1, DNM_WHICH_EXTERIOR = 2 };
  * ncv<=0 -> max(2*nev, nev+15); max_its<=0 -> max(100, 2N/ncv).  Partial
  * re-orthogonalisation with a tolerance-driven trigger (DNM_EIGS_ORTHO=full:
  * every step against the whole basis, as SLEPc); stats->err_est returns the
- * measured largest relative residual of the returned pairs. */
+ * measured largest relative residual of the returned pairs.
+ * Automatic choices under default parameters (ncv <= 0) for large operators: nev = 1 -> Lanczos without a stored basis
+ * (four work vectors); nev > 1 -> thick restart on a Chebyshev filter of H; ncv = -c (the caller's memory limit: at most
+ * c vectors in all) with c < nev + 6 -> the pairs one after the other by the basis-free recurrence on the operator
+ * deflated by the pairs found (four work vectors + the pairs; evals then count multiplicities -- a degenerate level
+ * comes back once per copy, where a single Krylov space, SLEPc's included, shows one).  DESIGN.md section 5. */
 int dnm_eigsolve(dnm_mat *A, int64_t n_local, int nev, int which, double tol,
                  int ncv, int max_its, uint64_t seed, const dnm_hooks *hooks,
                  int nev_max, double *evals, void *evecs,
