@@ -271,7 +271,8 @@ sc3g_lo_pass(const Sc3Tab S, const Sc3Op O, const uint32_t *__restrict__ perm, c
 #pragma unroll
         for (int c = 0; c < NQ; ++c) {
           if (c < nq) {
-            const uint4 q0 = trow[(size_t)r * nq + c];
+            const uint4 q0 = *reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(trow) +
+                                                              ((uint32_t)r * ((uint32_t)nq * 16u) + 16u * c));
             const uint32_t d0[4] = {q0.x, q0.y, q0.z, q0.w};
             if (SYM) {
               // two hops at a time, no branch among them (the table's last word is padded with hops of coefficient zero
@@ -432,25 +433,37 @@ sc3g_lo_pass_r(const Sc3Tab S, const Sc3Op O, const uint32_t *__restrict__ perm,
   const int64_t base = R.base;
   const double *__restrict__ x = xw - C.win_start;
   const int64_t lbase = base - C.row0;
-#define SC3R_ENT(i) (2 * (tsub + ((i) >> 1) * NTS) + ((i) & 1))
+  // entry i of a thread is column tsub + i * NTS: the lanes of a wavefront hold CONSECUTIVE entries, so a gathered hop's
+  // 32 or so live lanes ask for one run of the partner row -- 4-8 cache lines where pairs of entries per lane (the shape
+  // of the chain kernel: 16-byte loads) spread them over 16-24, and the texture path was 90 % busy with those
+  // (profiles/r05_kagome_real_counters.txt)
+#define SC3R_ENT(i) (tsub + (i) * NTS)
 
   SC3_PRIO_MEM();
   uint32_t lowp[PPT];                                   // the Lo patterns of a pair's entries, 16 bits each
 #define SC3R_PAT(i) ((lowp[(i) >> 1] >> (((i) & 1) * 16)) & 0xffffu)
   double xv[EPT];
+  // the row's own pieces of x, y and the cached diagonal: uniform bases, one 32-bit offset per entry serves all three
+  const double *__restrict__ xrow = x + base;
+  double *__restrict__ yrow = y + lbase;
+  const double *__restrict__ drow = DIAGM == 1 ? O.diag + lbase : nullptr;
   const auto pat = SC3_CP(uint16_t, S.lo_pat) + S.lo_off[kl];
 #pragma unroll
-  for (int i = 0; i < EPT; i += 2) {
-    const int r = SC3R_ENT(i);
-    lowp[i >> 1] = 0;
-    xv[i] = xv[i + 1] = 0.0;
-    if (r < p) {
-      const d2v v = *reinterpret_cast<const d2v *>(x + base + r);
-      xv[i] = v.x;
-      xv[i + 1] = v.y;
-      if (r < nrows) lowp[i >> 1] = pat[r];
-      if (r + 1 < nrows) lowp[i >> 1] |= (uint32_t)pat[r + 1] << 16;
+  for (int i = 0; i < PPT; ++i) lowp[i] = 0;
+  // (loads without a branch each: an entry behind the row's end reads the row's last one and drops it)
+  const int rlast = nrows > 0 ? nrows - 1 : 0;
+  if (has_row) {
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+      const int r = SC3R_ENT(i), rc = min(r, rlast);
+      const double xl = xrow[rc];
+      const uint32_t pl = pat[rc];
+      xv[i] = r < nrows ? xl : 0.0;
+      lowp[i >> 1] |= (r < nrows ? pl : 0u) << ((i & 1) * 16);
     }
+  } else {
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) xv[i] = 0.0;
   }
   HopEval g{0, 0, 0.0, 0.0, 0, 0u, 0};
   if (lane < O.ngatA) {
@@ -514,25 +527,20 @@ sc3g_lo_pass_r(const Sc3Tab S, const Sc3Op O, const uint32_t *__restrict__ perm,
   double acc[EPT];
   // the zero entry behind the row's entries, where the partner table points for hops that do not act: the padding of x
   // holds zeros by the layout's contract, but the tile does not rely on it; a row without padding gets the entry here
-  if (O.ptab && has_row && nrows == p && tsub == 0) xs[nrows] = 0.0;
+  if (O.ptab && has_row && tsub == 0) xs[nrows] = 0.0;
 #pragma unroll
-  for (int i = 0; i < EPT; i += 2) {
-    const int r = SC3R_ENT(i);
-    acc[i] = acc[i + 1] = 0.0;
-    if (r < p) {
-      if (r >= nrows) xv[i] = 0.0;
-      if (r + 1 >= nrows) xv[i + 1] = 0.0;
-      *reinterpret_cast<d2v *>(xs + r) = d2v{xv[i], xv[i + 1]};
-      if (ACC) {                   // the accumulators start from what the window pass wrote (no registers for y later)
-        const d2v yo = __builtin_nontemporal_load(reinterpret_cast<const d2v *>(y + lbase + r));
-        acc[i] = yo.x;
-        acc[i + 1] = yo.y;
+  for (int i = 0; i < EPT; ++i) acc[i] = 0.0;
+  if (has_row) {
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+      const int r = SC3R_ENT(i), rc = min(r, rlast);
+      if (r < nrows) xs[r] = xv[i];
+      // the accumulators start from what the window pass wrote (no registers hold y to the end); xv is zero behind the row
+      if (ACC) {
+        const double yl = __builtin_nontemporal_load(yrow + rc);
+        acc[i] = r < nrows ? yl : 0.0;
       }
-      if (DIAGM == 1) {
-        const d2v dg = __builtin_nontemporal_load(reinterpret_cast<const d2v *>(O.diag + lbase + r));
-        acc[i] = fma(dg.x, xv[i], acc[i]);
-        acc[i + 1] = fma(dg.y, xv[i + 1], acc[i + 1]);
-      }
+      if (DIAGM == 1) acc[i] = fma(__builtin_nontemporal_load(drow + rc), xv[i], acc[i]);
     }
   }
   __syncthreads();
@@ -576,16 +584,22 @@ sc3g_lo_pass_r(const Sc3Tab S, const Sc3Op O, const uint32_t *__restrict__ perm,
     const int nq = O.nhp >> 3;
     const uint4 *__restrict__ trow = reinterpret_cast<const uint4 *>(O.ptab + (size_t)O.ptab_row[kl] * (size_t)O.nhp);
     const unsigned char *xb = reinterpret_cast<const unsigned char *>(xs);
+    const unsigned char *__restrict__ tb = reinterpret_cast<const unsigned char *>(trow);     // uniform base + 32-bit offsets
+    const uint32_t rowb = (uint32_t)nq * 16u;
 #pragma unroll
     for (int j = 0; j < PPT; ++j) {
       const int r = SC3R_ENT(2 * j);
+      // (two entries of the thread at a time; the second one's table row is the class's padding row -- every hop at the
+      // zero entry -- where the row has ended)
+      const int r2 = SC3R_ENT(2 * j + 1) < nrows ? SC3R_ENT(2 * j + 1) : nrows;
       if (r < nrows) {
         // four hops at a time, no branch among them (the table's last word is padded with hops of coefficient zero that
         // point at the zero entry): their LDS reads go out together
 #pragma unroll
         for (int c = 0; c < NQ; ++c) {
           if (c < nq) {
-            const uint4 q0 = trow[(size_t)r * nq + c], q1 = trow[(size_t)(r + 1) * nq + c];
+            const uint4 q0 = *reinterpret_cast<const uint4 *>(tb + ((uint32_t)r * rowb + 16u * c));
+            const uint4 q1 = *reinterpret_cast<const uint4 *>(tb + ((uint32_t)r2 * rowb + 16u * c));
             const uint32_t d0[4] = {q0.x, q0.y, q0.z, q0.w}, d1[4] = {q1.x, q1.y, q1.z, q1.w};
 #pragma unroll
             for (int g4 = 0; g4 < 2; ++g4) {
@@ -627,26 +641,22 @@ sc3g_lo_pass_r(const Sc3Tab S, const Sc3Op O, const uint32_t *__restrict__ perm,
   double dr = 0.0, dn = 0.0;
   SC3_PRIO_MEM();
 #pragma unroll
-  for (int i = 0; i < EPT; i += 2) {
+  for (int i = 0; i < EPT; ++i) {
     const int r = SC3R_ENT(i);
-    if (r < p) {
-      double a2[2] = {acc[i], acc[i + 1]};
-#pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        if (r + b < nrows) {
-          if (!ACC && C.zinit) {
-            a2[b] = fma(-C.zscale, reinterpret_cast<const double *>(C.zinit)[lbase + r + b], a2[b]);
-            if (C.zinit2) a2[b] = fma(C.z2re, reinterpret_cast<const double *>(C.zinit2)[lbase + r + b], a2[b]);
-          }
-          if (ACC && C.dot_out) {
-            dr = fma(xs[r + b], a2[b], dr);
-            dn = fma(a2[b], a2[b], dn);
-          }
-        } else {
-          a2[b] = 0.0;
+    if (r < p) {                                  // the padding of a row is written too (zeros)
+      double a = 0.0;
+      if (r < nrows) {
+        a = acc[i];
+        if (!ACC && C.zinit) {
+          a = fma(-C.zscale, reinterpret_cast<const double *>(C.zinit)[lbase + r], a);
+          if (C.zinit2) a = fma(C.z2re, reinterpret_cast<const double *>(C.zinit2)[lbase + r], a);
+        }
+        if (ACC && C.dot_out) {
+          dr = fma(xs[r], a, dr);
+          dn = fma(a, a, dn);
         }
       }
-      __builtin_nontemporal_store(d2v{a2[0], a2[1]}, reinterpret_cast<d2v *>(y + lbase + r));
+      __builtin_nontemporal_store(a, yrow + r);
     }
   }
 #undef SC3R_ENT
