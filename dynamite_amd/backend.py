@@ -660,7 +660,7 @@ class ShellMat:
         self._check_pending = False
         # the partitioned multiply as one native call (dnm_mat_mult_partitioned: exchange on the library's own RCCL
         # communicator and stream) instead of the schedules below over torch.distributed -- config.native_comm, RCCL
-        # transport only; the transposed exchange keeps its host schedule
+        # transport only; the transposed exchange too (set_native_transposed)
         self._native = None
         self._native_tr = False   # transposed exchange split and scheduled inside the library (set_native_transposed)
 
