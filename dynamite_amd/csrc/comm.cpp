@@ -571,6 +571,7 @@ int dnm_comm_destroy(dnm_comm *c) {
 
 int dnm_comm_forget(dnm_comm *c, dnm_mat *A) {
   DNM_CHECK(c, "null communicator");
+  if (c->xs) DNM_HIP(hipStreamSynchronize(c->xs));      // buffers and events of a schedule still running go with it
   c->win.erase(A);
   c->par.erase(A);
   c->tr.erase(A);
