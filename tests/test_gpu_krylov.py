@@ -1360,7 +1360,8 @@ def test_real_packed_multiply_vs_oracle(monkeypatch, name, L, sub):
 
 
 @pytest.mark.parametrize("mode", ["restarted", "basis_free", "filtered"])
-@pytest.mark.parametrize("name,L,sub", [("mbl", 12, "full"), ("xxz", 13, "parity"), ("heisenberg", 11, "full")])
+@pytest.mark.parametrize("name,L,sub", [("mbl", 12, "full"), ("xxz", 13, "parity"), ("heisenberg", 11, "full"),
+                                        ("ising", 13, "fullx+"), ("heisenberg", 12, "fullx-")])
 def test_eigsolve_real_arithmetic(monkeypatch, name, L, sub, mode):
     """eigsolve of a real-symmetric operator in real arithmetic (the default from 2^23 amplitudes on one rank, forced
     here): the same eigenvalues as dense diagonalisation, and the returned COMPLEX states pass the reference's
@@ -1376,7 +1377,10 @@ def test_eigsolve_real_arithmetic(monkeypatch, name, L, sub, mode):
     if mode == "filtered":
         monkeypatch.setenv("DNM_EIGS_FILTER", "1")
     H = models.BY_NAME[name](L)
-    s = Full(L=L) if sub == "full" else Parity('even', L=L)
+    # (fullx: XParity on top of the Full space -- the Z2 sector of the transverse-field Ising chain, the spin-flip
+    # sector of the Heisenberg chain: the reduced operator of subspaces.py:632-674 on the tiled kernel, packed)
+    s = {"full": Full(L=L), "parity": Parity('even', L=L), "fullx+": XParity(Full(L=L), sector='+'),
+         "fullx-": XParity(Full(L=L), sector='-')}[sub]
     H.add_subspace(s)
     w = dense_spectrum(H, s)
     ev, vecs = H.eigsolve(nev=nev, tol=1e-11, subspace=s, getvecs=True)

@@ -5,7 +5,8 @@ examples/scripts/kagome/run_kagome.py): for each (model, subspace, size) the pla
 arithmetic (what eigsolve runs for real-symmetric operators).
 
     python tools/models_bench.py CASE ...       CASE = model:subspace:L[:k]   e.g. kagome30:sc, bench_long_range:full:28,
-                                                 bench_long_range:sc:28, kagome30:scx (SpinConserve + XParity)
+                                                 bench_long_range:sc:28, kagome30:scx (SpinConserve + XParity),
+                                                 ising:fullx:28 (XParity on the Full space), heisenberg:parity:28
 """
 import os
 os.environ.setdefault("DNM_EXPERIMENTAL", "1")
@@ -38,8 +39,13 @@ def build(case):
         sub = SpinConserve(L, k)
     elif space == "scx":
         sub = XParity(SpinConserve(L, k), sector='+' if L % 4 == 0 else '-')
+    elif space == "fullx":
+        sub = XParity(Full(L=L), sector='+')
+    elif space == "parity":
+        from dynamite_amd.subspaces import Parity
+        sub = Parity('even', L=L)
     else:
-        raise SystemExit("subspace: full / sc / scx")
+        raise SystemExit("subspace: full / fullx (XParity on the Full space) / parity / sc / scx")
     H.allow_projection = True
     H.add_subspace(sub)
     return H, sub, L
