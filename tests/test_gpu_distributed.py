@@ -91,6 +91,45 @@ def _worker(rank, world, port, case, out_dir):
             open(os.path.join(out_dir, "ok_%s_%d" % (case, world)), "w").write("ok")
         dist.destroy_process_group()
         return
+    if case.startswith("xparity"):
+        # XParity on top of a product-state subspace on several ranks (the reference halves the local sizes of the parent's
+        # partition, bpetsc_template_2.c:223-230, and multiplies with the operator XParity.reduce_msc wrote,
+        # subspaces.py:632-674): the flip-composed hops reach the mirror image of a rank's block.  Oracle: the reduced
+        # operator (the Python layer's reduce_msc is pinned by tests/golden/xparity.npz) through orc.xparity(parent).
+        from dynamite_amd.subspaces import XParity
+        from dynamite_amd import msc_tools
+        import scipy.sparse.linalg as spla2
+        parent = Full(L=L) if case == "xparity_full" else SpinConserve(L, L // 2)
+        for sector in ('+', '-'):
+            sub = XParity(parent, sector=sector)
+            H = models.heisenberg(L) if case == "xparity_sc" else models.ising(L)
+            H.add_subspace(sub)
+            x = State(subspace=sub, state='random', seed=3)
+            y = H.dot(x)
+            xg, yg = x.to_numpy(to_all=True), y.to_numpy(to_all=True)
+            assert xg.shape == (sub.get_dimension(),) and abs(np.linalg.norm(xg) - 1) < 1e-12
+            H.establish_L()
+            H.reduce_msc()
+            m = sub.reduce_msc(H.msc)
+            masks, offs = msc_tools.get_mask_offsets(m)
+            osub = orc.xparity(orc_sub(parent))
+            ref = orc.matvec(orc.Msc(masks, offs, m['signs'], m['coeffs']), osub, osub, xg)
+            assert np.max(np.abs(yg - ref)) < 1e-12, "partitioned XParity multiply (%s, sector %s)" % (case, sector)
+            assert abs(x.dot(y) - np.vdot(xg, yg)) < 1e-12
+            Hs = H.to_numpy(subspaces=(sub, sub), sparse=True)
+            z = H.evolve(x, t=0.4)
+            want = spla2.expm_multiply(-0.4j * Hs, xg)
+            assert np.max(np.abs(z.to_numpy(to_all=True) - want)) < 1e-8, "partitioned XParity evolve"
+            ev = H.eigsolve(nev=2, tol=1e-10, subspace=sub)
+            low = np.sort(spla2.eigsh(Hs, k=2, which='SA', tol=1e-12, return_eigenvectors=False))
+            assert np.max(np.abs(np.array(ev[:2]) - low)) < 1e-8, "partitioned XParity eigsolve"
+            H.destroy_mat()
+        dist.barrier()
+        faulthandler.cancel_dump_traceback_later()
+        if rank == 0:
+            open(os.path.join(out_dir, "ok_%s_%d" % (case, world)), "w").write("ok")
+        dist.destroy_process_group()
+        return
     if case in ("explicit", "auto", "projection", "full_odd", "parity_odd"):
         # partitions that are not XOR-partner exchanges: rows in index order, columns through a window
         # (the reference runs these through MatMult_CPU_General's MPI branch, bpetsc_template_2.c:413-504,
@@ -278,7 +317,8 @@ def _worker(rank, world, port, case, out_dir):
 @pytest.mark.parametrize("case,world", [("full", 2), ("full", 4), ("full", 8), ("full_partner", 4), ("full_transpose", 2),
                                         ("parity", 2), ("parity", 4), ("sc", 2), ("sc", 3), ("sc3", 2), ("sc3", 3), ("sc3_graph", 2),
                                         ("sc_big", 3), ("explicit", 3), ("auto", 2), ("projection", 3),
-                                        ("projection", 2), ("full_odd", 3), ("parity_odd", 3)])
+                                        ("projection", 2), ("full_odd", 3), ("parity_odd", 3),
+                                        ("xparity_full", 2), ("xparity_full", 4), ("xparity_sc", 2), ("xparity_sc", 3)])
 def test_partitioned_end_to_end_one_gpu(tmp_path, case, world):
     import torch.multiprocessing as mp
     mp.spawn(_worker, args=(world, _free_port(), case, str(tmp_path)), nprocs=world, join=True)
