@@ -739,6 +739,58 @@ def test_fuzz_random_operators(monkeypatch, seed):
             assert np.max(np.abs(yp - ref)) <= tol_for(arrs, x), (L, Pw, "sc windows")
 
 
+@pytest.mark.parametrize("seed", range(24))
+def test_fuzz_xparity_random_operators(monkeypatch, seed):
+    """Random Pauli-string Hamiltonians inside XParity sectors of Full, Parity and half-filled SpinConserve parents
+    (subspaces.py:632-674: strings that anticommute with the global flip are projected away, strings that flip spin L-1
+    come composed with the flip -- masks of up to L-1 bits): Operator.dot against the oracle's xparity(parent) on the
+    reduced operator (whose construction tests/golden/xparity.npz pins), on random tile shapes and plan modes; for real
+    symmetric operators the lowest level in real arithmetic (DNM_MAT_REAL_PACKED under XParity) against a dense solve."""
+    from dynamite_amd import msc_tools
+    from dynamite_amd.states import State
+    from dynamite_amd.subspaces import XParity
+    from dynamite_amd.computations import eigsolve
+    rs = np.random.RandomState(700 + seed)
+    L = 2 * int(rs.randint(5, 7))                      # 10, 12 (Parity and SpinConserve parents need an even L; the dense
+    #                                                    solve on the host sets the size)
+    B, logR = [(8, 2), (10, 2), (10, 3)][rs.randint(3)]
+    cfg(monkeypatch, B=B, logR=logR, mode=int(rs.randint(3)), amin=int(rs.randint(3, 5)), gbits=int(rs.randint(0, 4)))
+    real = seed % 2 == 0
+    H = (_random_real_symmetric if real else _random_hermitian)(L, int(rs.randint(6, 40)), rs)
+    kind = ["full", "parity", "sc"][rs.randint(3)]
+    parent = {"full": Full(L=L), "parity": Parity(int(rs.randint(2)), L=L), "sc": SpinConserve(L, L // 2)}[kind]
+    sub = XParity(parent, sector=['+', '-'][rs.randint(2)])
+    H.establish_L()
+    H.reduce_msc()
+    m = sub.reduce_msc(H.msc)
+    if m.size == 0:
+        return                                          # every string anticommuted with the flip
+    H.add_subspace(sub)
+    H.allow_projection = True
+    x = rand_state(sub.get_dimension(), seed=seed)
+    xs = State(L=L, subspace=sub)
+    xs.vec.set_local_from_numpy(x)
+    xs.set_initialized()
+    y = H.dot(xs).to_numpy()
+    masks, offs = msc_tools.get_mask_offsets(m)
+    osub = orc.xparity(orc_sub(parent))
+    red = orc.Msc(masks, offs, m['signs'], m['coeffs'])
+    ref = orc.matvec(red, osub, osub, x)
+    assert np.max(np.abs(y - ref)) <= tol_for((masks, offs, m['signs'], m['coeffs']), x), (L, kind, B, logR, H.get_mat(subspaces=(sub, sub)).describe())
+    if real and kind != "sc":
+        A = H.to_numpy(subspaces=(sub, sub), sparse=False)
+        if np.abs(A - A.conj().T).max() < 1e-12 and np.abs(A.imag).max() == 0 and np.ptp(np.linalg.eigvalsh(A)) > 1e-6:
+            monkeypatch.setenv("DNM_EIGS_REAL", "1")
+            ev = H.eigsolve(nev=1, tol=1e-11, subspace=sub)
+            w = np.linalg.eigvalsh(A)
+            assert abs(ev[0] - w[0]) < 1e-9 * max(1.0, abs(w[0])), (L, kind)
+            if eigsolve.last_stats['real_arithmetic'] is not True:
+                # (a projection that drops strings can leave an operator the packed form refuses, and a packed
+                # vector of L - 2 index bits can be too short for the tile: complex ran)
+                assert kind == "parity" or L - 2 <= B, (L, B, kind)
+    H.destroy_mat()
+
+
 def _random_real_symmetric(L, nterms, rs):
     """Sum of random Pauli strings with an EVEN number of sigma_y each and real coefficients: a real symmetric matrix
     (many terms per mask, signs that reach bit 0, masks that flip bit 0 alone, diagonal strings)."""
