@@ -495,6 +495,47 @@ def test_full_space_solver_beyond_the_complex_limit():
 
 
 @pytest.mark.skipif(os.environ.get('DNM_TEST_LARGEST') != '1', reason='largest single-GPU problems: opt-in (DNM_TEST_LARGEST=1), run in the builder\'s sessions')
+def test_ising_33_spins_against_the_free_fermion_energy():
+    """The transverse-field Ising chain of the reference's harness (hamiltonians.py:25-31: sum ZZ + 0.5 sum X, open ends)
+    on 33 spins in its two spin-flip sectors, XParity(Full(33)): 2^32 states each, in real arithmetic (32 GiB per vector,
+    Lanczos without a stored basis) on ONE GPU -- against the exact ground-state energy of the chain, minus the sum of the
+    singular values of the L x L matrix with the field on its diagonal and the coupling above it (Lieb-Schultz-Mattis /
+    Pfeuty): a known answer at a size no dense method reaches."""
+    import torch
+    from dynamite_amd.computations import eigsolve
+    from dynamite_amd.config import config
+    from dynamite_amd.subspaces import XParity
+    _need(200 * 2**30)
+    L = 33
+    M = np.diag(np.full(L, 0.5)) + np.diag(np.full(L - 1, 1.0), 1)
+    exact = -np.linalg.svd(M, compute_uv=False).sum()
+    saved = config.L
+    try:
+        config.L = L
+        H = models.ising(L)
+        lowest = []
+        for sector in ('+', '-'):
+            sub = XParity(Full(L=L), sector=sector)
+            H.add_subspace(sub)
+            ev = H.eigsolve(nev=1, tol=1e-9, subspace=sub)
+            st = eigsolve.last_stats
+            assert st['real_arithmetic'] is True and st['max_rel_residual'] <= 1.01e-9
+            lowest.append(ev[0])
+            print("ising-33, sector %s: E0 = %.10f (%d multiplies)" % (sector, ev[0], st['matvecs']))
+            H.destroy_mat()
+            _lib.check(_lib.lib().dnm_release_workspace())
+            torch.cuda.empty_cache()
+        assert abs(min(lowest) - exact) < 1e-8 * abs(exact), (lowest, exact)
+        # field 0.5 < coupling 1: the ordered phase -- the other sector's lowest level lies above it by a splitting that
+        # falls like (field / coupling)^L = 1.2e-10 (measured: 1.7e-10)
+        assert 0 <= max(lowest) - min(lowest) < 1e-7, lowest
+    finally:
+        config.L = saved
+        _lib.check(_lib.lib().dnm_release_workspace())
+        torch.cuda.empty_cache()
+
+
+@pytest.mark.skipif(os.environ.get('DNM_TEST_LARGEST') != '1', reason='largest single-GPU problems: opt-in (DNM_TEST_LARGEST=1), run in the builder\'s sessions')
 def test_kagome36_ground_state_on_one_gpu():
     """The 36-site kagome torus in XParity(SpinConserve(36, 18)) -- 4.54 G representatives, more than 2^32: the size at
     which a one-thread-per-row launch (the cached diagonal's) silently did nothing before its rows went out in slices --
