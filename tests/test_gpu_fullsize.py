@@ -495,6 +495,54 @@ def test_full_space_solver_beyond_the_complex_limit():
 
 
 @pytest.mark.skipif(os.environ.get('DNM_TEST_LARGEST') != '1', reason='largest single-GPU problems: opt-in (DNM_TEST_LARGEST=1), run in the builder\'s sessions')
+@pytest.mark.parametrize("case", ["chain32", "chain34", "ring30", "ring30x"])
+def test_xx_models_against_free_fermions(case):
+    """0.25 sum (XX + YY) -- free fermions hopping with amplitude 1/2 -- in SpinConserve(L, L/2) at full size, against the
+    filled Fermi sea: on the open chain (the two tiled chain passes; 601 M states at L=32, config 5's subspace, and 2.33 G
+    at L=34) the L/2 lowest of cos(pi j / (L + 1)); on the ring (one bond that is no chain bond: the bond-graph passes of
+    csrc/sc3g_kernels.hip, relabelled layout; 155 M states, and 77.6 M in its XParity sector) the L/2 lowest of
+    cos(2 pi n / L) -- 15 fermions: periodic momenta.  (Both formulas checked against dense solves at L=10.)"""
+    import torch
+    from dynamite_amd.computations import eigsolve
+    from dynamite_amd.config import config
+    from dynamite_amd.operators import sigmax, sigmay, op_sum
+    from dynamite_amd.subspaces import XParity
+    L = int("".join(ch for ch in case if ch.isdigit()))
+    k = L // 2
+    _need((60 if L == 34 else 30) * 2**30)
+    if case.startswith("chain"):
+        bonds = [(i, i + 1) for i in range(L - 1)]
+        exact = np.sort(np.cos(np.pi * np.arange(1, L + 1) / (L + 1)))[:k].sum()
+    else:
+        bonds = [(i, (i + 1) % L) for i in range(L)]
+        n = np.arange(L) + (0.5 if k % 2 == 0 else 0.0)
+        exact = np.sort(np.cos(2 * np.pi * n / L))[:k].sum()
+    saved = config.L
+    try:
+        config.L = L
+        H = op_sum(0.25 * (sigmax(min(i, j)) * sigmax(max(i, j)) + sigmay(min(i, j)) * sigmay(max(i, j))) for i, j in bonds)
+        H.L = L
+        sub = SpinConserve(L, k)
+        subs = [XParity(sub, sector=sec) for sec in ('+', '-')] if case.endswith("x") else [sub]
+        lowest = []
+        for s_ in subs:
+            H.add_subspace(s_)
+            ev = H.eigsolve(nev=1, tol=1e-9, subspace=s_)
+            st = eigsolve.last_stats
+            plan = H.get_mat(subspaces=(s_, s_)).describe()
+            assert st['real_arithmetic'] is True and st['max_rel_residual'] <= 1.01e-9
+            assert ("bond graph" in plan) == case.startswith("ring"), plan
+            lowest.append(ev[0])
+            print("%s %s: E0 = %.12f, exact %.12f (%d multiplies)" % (case, s_, ev[0], exact, st['matvecs']))
+            H.destroy_mat()
+        assert abs(min(lowest) - exact) < 1e-8 * abs(exact), (lowest, exact)
+    finally:
+        config.L = saved
+        _lib.check(_lib.lib().dnm_release_workspace())
+        torch.cuda.empty_cache()
+
+
+@pytest.mark.skipif(os.environ.get('DNM_TEST_LARGEST') != '1', reason='largest single-GPU problems: opt-in (DNM_TEST_LARGEST=1), run in the builder\'s sessions')
 def test_ising_33_spins_against_the_free_fermion_energy():
     """The transverse-field Ising chain of the reference's harness (hamiltonians.py:25-31: sum ZZ + 0.5 sum X, open ends)
     on 33 spins in its two spin-flip sectors, XParity(Full(33)): 2^32 states each, in real arithmetic (32 GiB per vector,
