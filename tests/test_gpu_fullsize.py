@@ -495,6 +495,60 @@ def test_full_space_solver_beyond_the_complex_limit():
 
 
 @pytest.mark.skipif(os.environ.get('DNM_TEST_LARGEST') != '1', reason='largest single-GPU problems: opt-in (DNM_TEST_LARGEST=1), run in the builder\'s sessions')
+@pytest.mark.parametrize("case", ["full30", "sc32"])
+def test_evolve_against_free_fermions(case):
+    """evolve at full size with a known answer: a domain wall (left half up, right half down) under 0.25 sum (XX + YY)
+    on the open chain for t = 3 -- the magnetisation profile <sigma_z_i>(t) of free fermions, n_i(t) = sum_j
+    |exp(-i h t)_ij|^2 n_j(0) with h the L x L hopping matrix of amplitude 1/2 -- on the Full space at L = 30 (2^30
+    complex amplitudes: the headline's size and kernel) and on SpinConserve(32, 16) (601 M: config 5's subspace and
+    kernels).  The sign convention of sigma_z is read off the initial state."""
+    import torch
+    from dynamite_amd.config import config
+    from dynamite_amd.states import State
+    from dynamite_amd.operators import sigmax, sigmay, sigmaz, op_sum
+    import scipy.linalg as sla
+    L = 30 if case == "full30" else 32
+    t = 3.0
+    _need(150 * 2**30)
+    h = np.diag(np.full(L - 1, 0.5), 1) + np.diag(np.full(L - 1, 0.5), -1)
+    U = sla.expm(-1j * h * t)
+    n0 = np.array([1.0] * (L // 2) + [0.0] * (L - L // 2))
+    nt = (np.abs(U) ** 2) @ n0
+    assert 0.2 < nt[L // 2 - 1] < 0.8 and nt[L // 2 - 4] < 0.99          # (the wall has melted over several sites by then)
+    saved = config.L
+    try:
+        config.L = L
+        sub = Full(L=L) if case == "full30" else SpinConserve(L, L // 2)
+        H = op_sum(0.25 * (sigmax(i) * sigmax(i + 1) + sigmay(i) * sigmay(i + 1)) for i in range(L - 1))
+        H.L = L
+        H.add_subspace(sub)
+        psi = State(L=L, subspace=sub, state='U' * (L // 2) + 'D' * (L - L // 2))
+        z0 = sigmaz(0)
+        z0.L = L
+        z0.add_subspace(sub)
+        s0 = z0.expectation(psi)                      # the sign sigma_z gives an 'U' spin
+        assert abs(abs(s0) - 1.0) < 1e-14
+        out = H.evolve(psi, t=t, tol=1e-10)
+        assert abs(out.norm() - 1.0) < 1e-9
+        tmp = State(L=L, subspace=sub)
+        worst = 0.0
+        for i in range(L):
+            zi = sigmaz(i)
+            zi.L = L
+            zi.add_subspace(sub)
+            got = zi.expectation(out, tmp_state=tmp)
+            worst = max(worst, abs(got - s0 * (2 * nt[i] - 1)))
+            zi.destroy_mat()
+        print("%s: evolve(t=%g), largest deviation of <sigma_z_i> from the free-fermion profile: %.2e" % (case, t, worst))
+        assert worst < 1e-8, worst
+        H.destroy_mat()
+    finally:
+        config.L = saved
+        _lib.check(_lib.lib().dnm_release_workspace())
+        torch.cuda.empty_cache()
+
+
+@pytest.mark.skipif(os.environ.get('DNM_TEST_LARGEST') != '1', reason='largest single-GPU problems: opt-in (DNM_TEST_LARGEST=1), run in the builder\'s sessions')
 @pytest.mark.parametrize("case", ["chain32", "chain34", "ring30", "ring30x"])
 def test_xx_models_against_free_fermions(case):
     """0.25 sum (XX + YY) -- free fermions hopping with amplitude 1/2 -- in SpinConserve(L, L/2) at full size, against the
