@@ -318,7 +318,7 @@ def _worker(rank, world, port, case, out_dir):
                                         ("parity", 2), ("parity", 4), ("sc", 2), ("sc", 3), ("sc3", 2), ("sc3", 3), ("sc3_graph", 2),
                                         ("sc_big", 3), ("explicit", 3), ("auto", 2), ("projection", 3),
                                         ("projection", 2), ("full_odd", 3), ("parity_odd", 3),
-                                        ("xparity_full", 2), ("xparity_full", 4), ("xparity_sc", 2), ("xparity_sc", 3)])
+                                        ("xparity_full", 2), ("xparity_sc", 2), ("xparity_sc", 3)])
 def test_partitioned_end_to_end_one_gpu(tmp_path, case, world):
     import torch.multiprocessing as mp
     mp.spawn(_worker, args=(world, _free_port(), case, str(tmp_path)), nprocs=world, join=True)

@@ -494,7 +494,44 @@ def test_full_space_solver_beyond_the_complex_limit():
         torch.cuda.empty_cache()
 
 
-@pytest.mark.skipif(os.environ.get('DNM_TEST_LARGEST') != '1', reason='largest single-GPU problems: opt-in (DNM_TEST_LARGEST=1), run in the builder\'s sessions')
+def test_half_chain_entropy_against_free_fermions():
+    """Reduced density matrices with a known answer at the size of the matrix-core kernel's headline (13 of 26 spins kept,
+    an 8192 x 8192 matrix): the ground state of 0.25 sum (XX + YY) on the open chain in SpinConserve(26, 13) is a filled
+    Fermi sea, whose entanglement entropy across a cut follows from the correlation matrix C_ij = <c_i^+ c_j> of the block
+    (Peschel): S = -sum nu ln nu + (1 - nu) ln(1 - nu) over the eigenvalues nu of C restricted to the block (checked
+    against exact diagonalisation at L=10).  eigsolve(getvecs) -> entanglement_entropy, half chain and a quarter."""
+    import torch
+    from dynamite_amd.config import config
+    from dynamite_amd.operators import sigmax, sigmay, op_sum
+    L, k = 26, 13
+    j = np.arange(1, L + 1)
+    modes = np.argsort(np.cos(np.pi * j / (L + 1)))[:k] + 1
+    phi = np.sqrt(2.0 / (L + 1)) * np.sin(np.pi * np.outer(j, modes) / (L + 1))
+    Cm = phi @ phi.T
+
+    def peschel(nA):
+        nu = np.linalg.eigvalsh(Cm[:nA, :nA])
+        nu = nu[(nu > 1e-15) & (nu < 1 - 1e-15)]
+        return float(-(nu * np.log(nu) + (1 - nu) * np.log(1 - nu)).sum())
+    saved = config.L
+    try:
+        config.L = L
+        sub = SpinConserve(L, k)
+        H = op_sum(0.25 * (sigmax(i) * sigmax(i + 1) + sigmay(i) * sigmay(i + 1)) for i in range(L - 1))
+        H.L = L
+        H.add_subspace(sub)
+        ev, vecs = H.eigsolve(nev=1, tol=1e-11, getvecs=True, subspace=sub)
+        exact = np.sort(np.cos(np.pi * j / (L + 1)))[:k].sum()
+        assert abs(ev[0] - exact) < 1e-9 * abs(exact)
+        for nA in (13, 6):
+            got = vecs[0].entanglement_entropy(list(range(nA)))
+            assert abs(got - peschel(nA)) < 1e-7, (nA, got, peschel(nA))
+        H.destroy_mat()
+    finally:
+        config.L = saved
+        torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("case", ["full30", "sc32"])
 def test_evolve_against_free_fermions(case):
     """evolve at full size with a known answer: a domain wall (left half up, right half down) under 0.25 sum (XX + YY)
@@ -548,8 +585,8 @@ def test_evolve_against_free_fermions(case):
         torch.cuda.empty_cache()
 
 
-@pytest.mark.skipif(os.environ.get('DNM_TEST_LARGEST') != '1', reason='largest single-GPU problems: opt-in (DNM_TEST_LARGEST=1), run in the builder\'s sessions')
-@pytest.mark.parametrize("case", ["chain32", "chain34", "ring30", "ring30x"])
+@pytest.mark.parametrize("case", ["chain32", pytest.param("chain34", marks=pytest.mark.skipif(
+    os.environ.get('DNM_TEST_LARGEST') != '1', reason='largest single-GPU problems: opt-in (DNM_TEST_LARGEST=1)')), "ring30", "ring30x"])
 def test_xx_models_against_free_fermions(case):
     """0.25 sum (XX + YY) -- free fermions hopping with amplitude 1/2 -- in SpinConserve(L, L/2) at full size, against the
     filled Fermi sea: on the open chain (the two tiled chain passes; 601 M states at L=32, config 5's subspace, and 2.33 G

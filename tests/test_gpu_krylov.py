@@ -1115,8 +1115,7 @@ def test_workspace_released_on_memory_pressure():
     H.evolve(x, t=0.1)                                        # and solves allocate it again
 
 
-@pytest.mark.parametrize("getvecs", [False, True])
-@pytest.mark.parametrize("real", ["0", "1"])
+@pytest.mark.parametrize("real,getvecs", [("0", True), ("1", False), ("1", True)])
 @pytest.mark.parametrize("name,L,sub,which", [("heisenberg", 12, "sc", "lowest"), ("mbl", 12, "full", "highest"),
                                               ("xxz", 11, "parity", "lowest"), ("long_range", 10, "full", "exterior")])
 def test_eigsolve_deflated_pairs(monkeypatch, name, L, sub, which, real, getvecs):
@@ -1363,6 +1362,8 @@ def test_real_packed_multiply_vs_oracle(monkeypatch, name, L, sub):
 @pytest.mark.parametrize("name,L,sub", [("mbl", 12, "full"), ("xxz", 13, "parity"), ("heisenberg", 11, "full"),
                                         ("ising", 13, "fullx+"), ("heisenberg", 12, "fullx-")])
 def test_eigsolve_real_arithmetic(monkeypatch, name, L, sub, mode):
+    if sub == "fullx-" and mode != "restarted":
+        pytest.skip("one scheme for the second XParity sector (suite time)")
     """eigsolve of a real-symmetric operator in real arithmetic (the default from 2^23 amplitudes on one rank, forced
     here): the same eigenvalues as dense diagonalisation, and the returned COMPLEX states pass the reference's
     residual / Rayleigh-quotient / orthogonality bars (tests/integration/test_eigsolve.py:17-88, 127-137) -- through
