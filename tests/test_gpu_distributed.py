@@ -85,6 +85,15 @@ def _worker(rank, world, port, case, out_dir):
             assert local and remote and sum(b - a for a, b in local) > 0.05 * H.get_mat().m_local, (local, remote)
         z = H.evolve(x, t=0.3, algo='chebyshev')
         assert abs(z.norm() - 1) < 1e-9 and abs(z.dot(H.dot(z)).imag) < 1e-9
+        # a known answer beyond what a dense solve reaches, through the partitioned solver: 0.25 sum (XX + YY) on the same
+        # subspace and partition is a chain of free fermions; its ground state the filled Fermi sea
+        from dynamite_amd.operators import sigmax, sigmay, op_sum
+        Hx = op_sum(0.25 * (sigmax(i) * sigmax(i + 1) + sigmay(i) * sigmay(i + 1)) for i in range(L - 1))
+        Hx.L = L
+        Hx.add_subspace(sub)
+        e0 = Hx.eigsolve(nev=1, tol=1e-10, subspace=sub)[0]
+        exact = np.sort(np.cos(np.pi * np.arange(1, L + 1) / (L + 1)))[:L // 2].sum()
+        assert abs(e0 - exact) < 1e-8 * abs(exact), (e0, exact)
         dist.barrier()
         faulthandler.cancel_dump_traceback_later()
         if rank == 0:

@@ -19,7 +19,7 @@ import numpy as np
 import pytest
 
 from dynamite_amd import _lib, backend, models
-from dynamite_amd.subspaces import Full, SpinConserve
+from dynamite_amd.subspaces import Full, Parity, SpinConserve
 from gpu_util import marshal
 
 pytestmark = [pytest.mark.gpu, pytest.mark.default_layout]
@@ -586,13 +586,16 @@ def test_evolve_against_free_fermions(case):
 
 
 @pytest.mark.parametrize("case", ["chain32", pytest.param("chain34", marks=pytest.mark.skipif(
-    os.environ.get('DNM_TEST_LARGEST') != '1', reason='largest single-GPU problems: opt-in (DNM_TEST_LARGEST=1)')), "ring30", "ring30x"])
+    os.environ.get('DNM_TEST_LARGEST') != '1', reason='largest single-GPU problems: opt-in (DNM_TEST_LARGEST=1)')), "ring30", "ring30x",
+    "parity30"])
 def test_xx_models_against_free_fermions(case):
     """0.25 sum (XX + YY) -- free fermions hopping with amplitude 1/2 -- in SpinConserve(L, L/2) at full size, against the
     filled Fermi sea: on the open chain (the two tiled chain passes; 601 M states at L=32, config 5's subspace, and 2.33 G
     at L=34) the L/2 lowest of cos(pi j / (L + 1)); on the ring (one bond that is no chain bond: the bond-graph passes of
     csrc/sc3g_kernels.hip, relabelled layout; 155 M states, and 77.6 M in its XParity sector) the L/2 lowest of
-    cos(2 pi n / L) -- 15 fermions: periodic momenta.  (Both formulas checked against dense solves at L=10.)"""
+    cos(2 pi n / L) -- 15 fermions: periodic momenta.  (Both formulas checked against dense solves at L=10.)  parity30: the
+    open chain of 30 spins on Parity('even') -- 2^29 states on the Full-space kernel -- where the sea holds an even number
+    of fermions: the 14 lowest levels (15 are negative; 14 and 16 fermions tie)."""
     import torch
     from dynamite_amd.computations import eigsolve
     from dynamite_amd.config import config
@@ -601,9 +604,9 @@ def test_xx_models_against_free_fermions(case):
     L = int("".join(ch for ch in case if ch.isdigit()))
     k = L // 2
     _need((60 if L == 34 else 30) * 2**30)
-    if case.startswith("chain"):
+    if case.startswith("chain") or case == "parity30":
         bonds = [(i, i + 1) for i in range(L - 1)]
-        exact = np.sort(np.cos(np.pi * np.arange(1, L + 1) / (L + 1)))[:k].sum()
+        exact = np.sort(np.cos(np.pi * np.arange(1, L + 1) / (L + 1)))[:k - (1 if case == "parity30" else 0)].sum()
     else:
         bonds = [(i, (i + 1) % L) for i in range(L)]
         n = np.arange(L) + (0.5 if k % 2 == 0 else 0.0)
@@ -613,7 +616,7 @@ def test_xx_models_against_free_fermions(case):
         config.L = L
         H = op_sum(0.25 * (sigmax(min(i, j)) * sigmax(max(i, j)) + sigmay(min(i, j)) * sigmay(max(i, j))) for i, j in bonds)
         H.L = L
-        sub = SpinConserve(L, k)
+        sub = SpinConserve(L, k) if case != "parity30" else Parity('even', L=L)
         subs = [XParity(sub, sector=sec) for sec in ('+', '-')] if case.endswith("x") else [sub]
         lowest = []
         for s_ in subs:
