@@ -509,10 +509,12 @@ def test_half_chain_entropy_against_free_fermions():
     phi = np.sqrt(2.0 / (L + 1)) * np.sin(np.pi * np.outer(j, modes) / (L + 1))
     Cm = phi @ phi.T
 
-    def peschel(nA):
+    def peschel(nA, alpha=1):
         nu = np.linalg.eigvalsh(Cm[:nA, :nA])
         nu = nu[(nu > 1e-15) & (nu < 1 - 1e-15)]
-        return float(-(nu * np.log(nu) + (1 - nu) * np.log(1 - nu)).sum())
+        if alpha == 1:
+            return float(-(nu * np.log(nu) + (1 - nu) * np.log(1 - nu)).sum())
+        return float(np.log(nu ** alpha + (1 - nu) ** alpha).sum() / (1 - alpha))
     saved = config.L
     try:
         config.L = L
@@ -526,6 +528,9 @@ def test_half_chain_entropy_against_free_fermions():
         for nA in (13, 6):
             got = vecs[0].entanglement_entropy(list(range(nA)))
             assert abs(got - peschel(nA)) < 1e-7, (nA, got, peschel(nA))
+        from dynamite_amd.computations import renyi_entropy
+        got2 = renyi_entropy(vecs[0], list(range(13)), 2)          # the second Renyi entropy of the half chain
+        assert abs(got2 - peschel(13, alpha=2)) < 1e-7, (got2, peschel(13, alpha=2))
         H.destroy_mat()
     finally:
         config.L = saved
