@@ -312,6 +312,27 @@ def secondary(wd, budget_s=22.0):
         H.destroy_mat()
     else:
         out["eigsolve_kagome30_xparity_nev2"] = "skipped: budget"
+    # -- a known answer at config 5's subspace: 0.25 sum (XX + YY) on the open chain in SpinConserve(32, 16) is a chain of
+    #    free fermions; its ground state the filled Fermi sea (tests/test_gpu_fullsize.py::test_xx_models_against_free_fermions)
+    if left() > 3.0:
+        wd.phase("secondary: XX chain against the Fermi sea")
+        import numpy as _np
+        from dynamite_amd.operators import sigmax, sigmay, op_sum
+        Lx = 32
+        H = op_sum(0.25 * (sigmax(i) * sigmax(i + 1) + sigmay(i) * sigmay(i + 1)) for i in range(Lx - 1))
+        H.L = Lx
+        sub = SpinConserve(Lx, Lx // 2)
+        H.add_subspace(sub)
+        (ev, dt) = timed(lambda: H.eigsolve(nev=1, tol=1e-9, subspace=sub))
+        exact = float(_np.sort(_np.cos(_np.pi * _np.arange(1, Lx + 1) / (Lx + 1)))[:Lx // 2].sum())
+        r = {"wall_s": dt, "E0": float(ev[0]), "exact": exact, "abs_error": abs(float(ev[0]) - exact),
+             "dim": sub.get_dimension(), "matvecs": eigsolve.last_stats["matvecs"], "tol": 1e-9}
+        if not r["abs_error"] < 1e-7:
+            r["failed_checks"] = ["ground-state energy %r against the filled Fermi sea %r" % (r["E0"], exact)]
+        out["known_answer_xx_chain_sc32_16"] = r
+        H.destroy_mat()
+    else:
+        out["known_answer_xx_chain_sc32_16"] = "skipped: budget"
     out["total_s"] = time.perf_counter() - t_begin
     return out
 
