@@ -592,7 +592,7 @@ def test_evolve_against_free_fermions(case):
 
 @pytest.mark.parametrize("case", ["chain32", pytest.param("chain34", marks=pytest.mark.skipif(
     os.environ.get('DNM_TEST_LARGEST') != '1', reason='largest single-GPU problems: opt-in (DNM_TEST_LARGEST=1)')), "ring30", "ring30x",
-    "parity30"])
+    "parity30", "field30"])
 def test_xx_models_against_free_fermions(case):
     """0.25 sum (XX + YY) -- free fermions hopping with amplitude 1/2 -- in SpinConserve(L, L/2) at full size, against the
     filled Fermi sea: on the open chain (the two tiled chain passes; 601 M states at L=32, config 5's subspace, and 2.33 G
@@ -600,7 +600,10 @@ def test_xx_models_against_free_fermions(case):
     csrc/sc3g_kernels.hip, relabelled layout; 155 M states, and 77.6 M in its XParity sector) the L/2 lowest of
     cos(2 pi n / L) -- 15 fermions: periodic momenta.  (Both formulas checked against dense solves at L=10.)  parity30: the
     open chain of 30 spins on Parity('even') -- 2^29 states on the Full-space kernel -- where the sea holds an even number
-    of fermions: the 14 lowest levels (15 are negative; 14 and 16 fermions tie)."""
+    of fermions: the 14 lowest levels (15 are negative; 14 and 16 fermions tie).  field30: the same chain in a random field,
+    sum w_i sigma_z_i with w uniform in (-1, 1) -- the headline's random-field Heisenberg chain without its ZZ terms -- on
+    the Full space at L = 30: still free fermions, in the potential 2 w_i; the sea fills the negative levels of the L x L
+    matrix and E0 = their sum - sum w_i (checked against a dense solve at L=10)."""
     import torch
     from dynamite_amd.computations import eigsolve
     from dynamite_amd.config import config
@@ -609,7 +612,14 @@ def test_xx_models_against_free_fermions(case):
     L = int("".join(ch for ch in case if ch.isdigit()))
     k = L // 2
     _need((60 if L == 34 else 30) * 2**30)
-    if case.startswith("chain") or case == "parity30":
+    field = None
+    if case == "field30":
+        bonds = [(i, i + 1) for i in range(L - 1)]
+        field = np.random.RandomState(30).uniform(-1, 1, L)
+        hm = np.diag(np.full(L - 1, 0.5), 1) + np.diag(np.full(L - 1, 0.5), -1) + np.diag(2 * field)
+        eps = np.linalg.eigvalsh(hm)
+        exact = eps[eps < 0].sum() - field.sum()
+    elif case.startswith("chain") or case == "parity30":
         bonds = [(i, i + 1) for i in range(L - 1)]
         exact = np.sort(np.cos(np.pi * np.arange(1, L + 1) / (L + 1)))[:k - (1 if case == "parity30" else 0)].sum()
     else:
@@ -620,8 +630,11 @@ def test_xx_models_against_free_fermions(case):
     try:
         config.L = L
         H = op_sum(0.25 * (sigmax(min(i, j)) * sigmax(max(i, j)) + sigmay(min(i, j)) * sigmay(max(i, j))) for i, j in bonds)
+        if field is not None:
+            from dynamite_amd.operators import sigmaz
+            H = H + op_sum(float(field[i]) * sigmaz(i) for i in range(L))
         H.L = L
-        sub = SpinConserve(L, k) if case != "parity30" else Parity('even', L=L)
+        sub = Full(L=L) if case == "field30" else (SpinConserve(L, k) if case != "parity30" else Parity('even', L=L))
         subs = [XParity(sub, sector=sec) for sec in ('+', '-')] if case.endswith("x") else [sub]
         lowest = []
         for s_ in subs:
