@@ -739,7 +739,7 @@ def test_fuzz_random_operators(monkeypatch, seed):
             assert np.max(np.abs(yp - ref)) <= tol_for(arrs, x), (L, Pw, "sc windows")
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("DNM_FUZZ_XPARITY_N", "24"))))
 def test_fuzz_xparity_random_operators(monkeypatch, seed):
     """Random Pauli-string Hamiltonians inside XParity sectors of Full, Parity and half-filled SpinConserve parents
     (subspaces.py:632-674: strings that anticommute with the global flip are projected away, strings that flip spin L-1

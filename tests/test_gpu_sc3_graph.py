@@ -141,7 +141,7 @@ def test_fields_that_leave_the_subspace_are_skipped(small_layout):
     mat.destroy()
 
 
-@pytest.mark.parametrize("seed", range(32))
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("DNM_SC3G_FUZZ_N", "32"))))
 def test_fuzz_pair_graphs(small_layout, seed):
     """Random sizes, fillings, graphs (sparse to all-to-all), real and complex hops."""
     rs = np.random.RandomState(1000 + seed)
@@ -369,7 +369,7 @@ def test_xparity_in_the_layout(small_layout, kind, sector):
         H.destroy_mat()
 
 
-@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("DNM_SC3G_FUZZ_X_N", "8"))))
 def test_fuzz_xparity_pair_graphs(small_layout, seed):
     rs = np.random.RandomState(300 + seed)
     L = int(rs.choice([12, 14]))
