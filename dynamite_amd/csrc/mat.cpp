@@ -979,9 +979,9 @@ int dnm_mat_create(int64_t nmasks, const int64_t *masks, const int64_t *mask_off
     if (flags & DNM_MAT_REAL_PACKED) {
       // (partitions: the rank bits are the top index bits, the packed bit is bit 0 -- the partner exchange of the packed
       // operator is that of an operator on one bit less; the transposed exchange is not built for it)
-      // (XParity on top, one rank: the reduced operator is packed like any other -- its flip-composed masks reach index
-      // bit 0, the lane, like every odd mask -- and loses its top index bit below)
-      DNM_CHECK(A->M == A->N && (!A->xparity || A->nranks == 1), "real-packed operators: square; under XParity on one rank");
+      // (XParity on top: the reduced operator is packed like any other -- its flip-composed masks reach index bit 0, the
+      // lane, like every odd mask -- and loses its top index bit below)
+      DNM_CHECK(A->M == A->N, "real-packed operators: square");
       DNM_TRY(pack_opform(&A->op));
       A->real_packed = true;
       A->M /= 2; A->N /= 2; A->m_local /= 2; A->n_local /= 2;         // complex128 elements, two amplitudes each

@@ -319,7 +319,7 @@ class Operator:
     def get_real_packed_mat(self, subspace):
         """The operator in real arithmetic on ``subspace`` -- Full or Parity on a power-of-two number of ranks (two
         ranks: partner exchange; four and more: the transposed exchange with a swizzle of its own; with XParity on top:
-        one rank), or SpinConserve in the internal layout on any rank count -- or None when it has an imaginary matrix element in the product basis
+        partner blocks), or SpinConserve in the internal layout on any rank count -- or None when it has an imaginary matrix element in the product basis
         (or the subspace / size has no such form): a second native handle built with ``DNM_MAT_REAL_PACKED`` that multiplies real vectors -- two
         amplitudes to a complex128 element (Full / Parity) or one double per position of the layout (SpinConserve) --
         half the bytes per multiply and per Krylov vector.  Not in the reference (its PETSc build is complex
@@ -333,8 +333,8 @@ class Operator:
         xp = isinstance(subspace, XParity) and isinstance(subspace.parent, SpinConserve) and subspace.vec_swizzle >= 256
         sc = xp or (isinstance(subspace, SpinConserve) and subspace.vec_swizzle >= 256)
         ws = config.world_size
-        # (XParity on top of Full / Parity, one rank: the reduced operator on the tiled kernel, packed like any other)
-        xpf = isinstance(subspace, XParity) and isinstance(subspace.parent, (Full, Parity)) and ws == 1
+        # (XParity on top of Full / Parity: the reduced operator on the tiled kernel, packed like any other)
+        xpf = isinstance(subspace, XParity) and isinstance(subspace.parent, (Full, Parity)) and ws & (ws - 1) == 0
         ok = sc or xpf or (isinstance(subspace, (Full, Parity)) and ws & (ws - 1) == 0)
         if ok and self.shell:
             self.establish_L()

@@ -132,6 +132,16 @@ def _worker(rank, world, port, case, out_dir):
             ev = H.eigsolve(nev=2, tol=1e-10, subspace=sub)
             low = np.sort(spla2.eigsh(Hs, k=2, which='SA', tol=1e-12, return_eigenvectors=False))
             assert np.max(np.abs(np.array(ev[:2]) - low)) < 1e-8, "partitioned XParity eigsolve"
+            if case == "xparity_full":
+                # ... and in real arithmetic (DNM_MAT_REAL_PACKED under XParity on a power-of-two number of ranks)
+                from dynamite_amd.computations import eigsolve as _eig
+                os.environ["DNM_EIGS_REAL"] = "1"
+                er, vr = H.eigsolve(nev=2, tol=1e-10, subspace=sub, getvecs=True)
+                os.environ.pop("DNM_EIGS_REAL")
+                assert _eig.last_stats['real_arithmetic'] is True
+                assert np.max(np.abs(np.array(er[:2]) - low)) < 1e-8, "partitioned XParity eigsolve, real arithmetic"
+                vg = vr[0].to_numpy(to_all=True)
+                assert np.abs(vg.imag).max() == 0.0 and np.linalg.norm(Hs @ vg - er[0] * vg) < 1e-7
             H.destroy_mat()
         dist.barrier()
         faulthandler.cancel_dump_traceback_later()
@@ -327,7 +337,8 @@ def _worker(rank, world, port, case, out_dir):
                                         ("parity", 2), ("parity", 4), ("sc", 2), ("sc", 3), ("sc3", 2), ("sc3", 3), ("sc3_graph", 2),
                                         ("sc_big", 3), ("explicit", 3), ("auto", 2), ("projection", 3),
                                         ("projection", 2), ("full_odd", 3), ("parity_odd", 3),
-                                        ("xparity_full", 2), ("xparity_sc", 2), ("xparity_sc", 3)])
+                                        ("xparity_full", 2), ("xparity_sc", 2), ("xparity_sc", 3)] +
+                         ([("xparity_full", 4)] if os.environ.get("DNM_TEST_LARGEST") == "1" else []))
 def test_partitioned_end_to_end_one_gpu(tmp_path, case, world):
     import torch.multiprocessing as mp
     mp.spawn(_worker, args=(world, _free_port(), case, str(tmp_path)), nprocs=world, join=True)
