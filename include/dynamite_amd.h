@@ -126,13 +126,13 @@ enum {
                                  diagnostics and CPU tests) -- such a handle cannot multiply */
   DNM_MAT_REAL_PACKED  = 16   /* Real arithmetic for a real-symmetric operator (every matrix element real in the
                                  product basis: Heisenberg, XXZ, Ising, random-field chains ...) on a Full / Parity pair
-                                 (one rank or 2^p ranks: the exchange is that of an operator on one index bit less): the handle multiplies REAL vectors of the same dimension, stored two
+                                 (one rank or 2^p ranks: the exchange is that of an operator on one index bit less; XParity on top allowed): the handle multiplies REAL vectors of the same dimension, stored two
                                  amplitudes to a complex128 element -- element j holds the amplitudes of indices 2j
                                  (real part) and 2j + 1 (imaginary part), so a vector is dim / 2 elements, 8 bytes per
                                  amplitude, and dnm_mat_sizes reports the halved sizes.  Solver-internal (eigsolve of a
                                  real-symmetric operator needs no complex arithmetic; the reference's PETSc build is
                                  complex throughout).  Also for a SpinConserve pair in the internal layout (chain
-                                 operators): the vector is then one double per position of the layout, i.e.
+                                 operators and operators on bond graphs, XParity on one rank): one double per position, i.e.
                                  dnm_vec_layout_size / 2 complex128 elements (dnm_vec_layout_unpack_real).
                                  dnm_eigsolve on such a handle keeps every inner product real, and
                                  dnm_vec_unpack_real turns a packed vector into the complex128 vector the caller sees.
