@@ -451,6 +451,68 @@ def test_real_packed_graph_multiply(small_layout, case):
     mat.destroy()
 
 
+@pytest.mark.parametrize("arith", ["complex", "real"])
+@pytest.mark.parametrize("case", ["no_table_small", pytest.param("no_table_27b", marks=pytest.mark.skipif(
+    os.environ.get("DNM_TEST_LARGEST") != "1", reason="opt-in (DNM_TEST_LARGEST=1): 11 s of oracle per case")), "dense_lo_25"])
+def test_lo_hops_by_rank_tables(small_layout, monkeypatch, case, arith):
+    """The lo pass's LDS hops WITHOUT the partner table (Sc3Op::ptab): the two-table rank of the flipped pattern -- what an
+    operator with more than 32 hops inside Lo runs (dense_lo_25: all 91 pairs of the 14 Lo spins of the (14, 10) instance
+    plus a chain through the rest, identity labelling) and what DNM_SC3G_PTAB=0 forces (a random graph on the small
+    instance, the 27-site kagome torus on the production one) -- complex and real arithmetic, against the oracle."""
+    import ctypes as C
+    import torch
+    from dynamite_amd import _lib
+    from dynamite_amd.operators import sigmax, sigmay, sigmaz, op_sum
+    from gpu_util import vec_for
+    saved = (config.sc_layout, config.sc_layout_min_dim)
+    try:
+        if case == "no_table_small":
+            monkeypatch.setenv("DNM_SC3G_PTAB", "0")
+            H, L, k = pair_graph(14, seed=31, nbonds=30, complex_hops=False, fields=True), 14, 6
+        else:
+            config.sc_layout, config.sc_layout_min_dim = (14, 10), 0
+            if case == "no_table_27b":
+                monkeypatch.setenv("DNM_SC3G_PTAB", "0")
+                H = models.kagome("27b")
+                L, k = H.L, 13
+            else:
+                L, k = 25, 12
+                rs = np.random.RandomState(9)
+                pairs = [(i, j) for i in range(14) for j in range(i + 1, 14)] + [(i, i + 1) for i in range(13, L - 1)]
+                H = op_sum(float(rs.uniform(-1, 1)) * (sigmax(i) * sigmax(j) + sigmay(i) * sigmay(j)) +
+                           float(rs.uniform(-1, 1)) * sigmaz(i) * sigmaz(j) for i, j in pairs)
+                H.L = L
+        sub = SpinConserve(L, k)
+        n = sub.get_dimension()
+        mat = shell(H, sub, flags=_lib.MAT_REAL_PACKED if arith == "real" else 0, site_perm=False)
+        d = mat.describe()
+        assert "bond graph" in d, d
+        if case == "dense_lo_25":
+            assert "91 hops in LDS" in d, d
+        if mat.uses_cached_diagonal():
+            mat.precompute_diagonal()
+        xr = np.random.RandomState(L + 1).standard_normal(n)
+        x = xr.astype(np.complex128) if arith == "real" else xr + 1j * np.random.RandomState(L + 2).standard_normal(n)
+        want = orc.matvec(orc_msc(H), orc_sub(sub), orc_sub(sub), x, nthreads=4)
+        if arith == "complex":
+            got = mult_numpy(mat, x)
+            assert np.abs(got - want).max() <= tol_for(H, L, x) * (4 if case == "dense_lo_25" else 1), d
+        else:
+            v = vec_for(sub)
+            v.set_local_from_numpy(x)
+            xd = v.array.real.contiguous()
+            yd = torch.full_like(xd, 7.0)
+            _lib.check(_lib.lib().dnm_mat_mult(mat.handle, C.c_void_p(xd.data_ptr()), C.c_void_p(yd.data_ptr()), None))
+            out = vec_for(sub)
+            _lib.check(_lib.lib().dnm_vec_layout_unpack_real(C.byref(sub._c()), None, out.ptr, C.c_void_p(yd.data_ptr()), None))
+            got = out.local_numpy()
+            assert np.abs(got.imag).max() == 0.0
+            assert np.abs(got.real - want.real).max() <= tol_for(H, L, xr) * (4 if case == "dense_lo_25" else 1), d
+        mat.destroy()
+    finally:
+        config.sc_layout, config.sc_layout_min_dim = saved
+
+
 @pytest.mark.parametrize("mode", ["basis_free", "restarted"])
 def test_kagome_eigsolve_real_arithmetic(small_layout, monkeypatch, mode):
     """eigsolve of the 12-site kagome torus in real arithmetic, in the relabelled layout: eigenvalues against the
