@@ -142,6 +142,28 @@ def test_native_split_is_the_host_split(name, L, P, kind):
         lib.dnm_mat_destroy(h)
 
 
+@pytest.mark.parametrize("L,P", [(17, 4), (18, 8)])
+def test_shellmat_reports_the_native_transposed_exchange_like_the_host_one(L, P):
+    """backend.ShellMat with the split inside the library (set_native_transposed) tells the same story as with the host's
+    split (set_transposed): scheme, bytes per multiply, peers, busiest link, kernel launches (host-only handles)."""
+    from dynamite_amd import _lib, backend
+    from dynamite_amd.subspaces import Full
+    arrs = _arrays("mbl", L)
+    sc = Full(L=L)._to_c()['data']
+    sc.vec_swizzle = 0
+    for rank in (0, P - 1):
+        h = backend.create_mat(*arrs, sc, sc, False, _lib.MAT_HOST_ONLY, rank, P)
+        m = backend.ShellMat(h, sc, sc, P, rank)
+        assert m.set_native_transposed()
+        h2 = backend.create_mat(*arrs, sc, sc, False, _lib.MAT_HOST_ONLY, rank, P)
+        m2 = backend.ShellMat(h2, sc, sc, P, rank)
+        m2.set_transposed(backend.transpose_split(*arrs, L, P, 0), sc, sc, _lib.MAT_HOST_ONLY)
+        assert m.exchange_summary() == m2.exchange_summary() and m.exchange_summary()["scheme"] == "transpose"
+        assert m2._tr_pipe and m.launches_per_mult() == m2.launches_per_mult()
+        m.destroy()
+        m2.destroy()
+
+
 def test_native_split_refuses_what_the_host_split_refuses():
     import ctypes as C
     from dynamite_amd import _lib, backend, msc_tools
