@@ -1158,6 +1158,31 @@ def test_eigsolve_deflated_pairs(monkeypatch, name, L, sub, which, real, getvecs
     H.destroy_mat()
 
 
+def test_eigsolve_falls_back_to_deflation_when_memory_is_short(monkeypatch):
+    """What computations.eigsolve does when no restarted basis fits (the 36-site kagome torus: five vectors of 34 GiB):
+    device memory made to look short here -- six vectors' worth: the pairs come one after the other through the deflated
+    basis-free recurrence (cap < nev + 6 in dnm_eigsolve); three vectors' worth: the error names what is needed."""
+    import torch
+    from dynamite_amd.computations import eigsolve
+    L = 12
+    H = models.mbl(L)
+    w = dense_spectrum(H)
+    vec_bytes = 16 << L
+    cached = C.c_size_t()
+    _lib.check(_lib.lib().dnm_release_workspace())
+    total = torch.cuda.mem_get_info()[1]
+    monkeypatch.setattr(torch.cuda, "mem_get_info", lambda *a, **k: (6 * vec_bytes + 100, total))
+    ev = H.eigsolve(nev=2, tol=1e-10)
+    st = eigsolve.last_stats
+    assert st["its"] == 2 and st["nconv"] == 2          # (the deflated driver reports one "restart" per pair)
+    assert np.max(np.abs(np.array(ev[:2]) - w[:2])) < 1e-8
+    _lib.check(_lib.lib().dnm_release_workspace())
+    monkeypatch.setattr(torch.cuda, "mem_get_info", lambda *a, **k: (3 * vec_bytes + 100, total))
+    with pytest.raises(RuntimeError, match="basis-free solver needs"):
+        H.eigsolve(nev=2, tol=1e-10)
+    H.destroy_mat()
+
+
 def test_eigsolve_deflated_degenerate_level():
     """The '-' sector of XParity(SpinConserve(12, 6)) on the 12-site kagome torus has a triply degenerate lowest
     level (tests/golden/kagome.npz, the reference's own reduced matrix): a single Krylov space holds one copy of it,
