@@ -1379,11 +1379,18 @@ conserves_kernel(const DevMsc msc, const double *__restrict__ coeffs_im, const S
   }
 }
 
+// rows / columns per launch of the one-thread-per-row kernels (DNM_LAUNCH_SLICE_LOG2: tests slice small problems)
+static int64_t launch_slice() {
+  const char *e = knob("DNM_LAUNCH_SLICE_LOG2");
+  const int lg = e ? atoi(e) : 30;
+  return (int64_t)1 << (lg < 8 ? 8 : (lg > 30 ? 30 : lg));
+}
+
 template <int LT>
 static int conserves_dispatch_r(const DevMsc &msc, const double *cim, const SubView &l, const SubView &r,
                                 int64_t N, int *bad, hipStream_t st) {
   // (one thread per column, fewer than 2^32 threads to a launch: slices of 2^30 columns)
-  const int64_t SLICE = (int64_t)1 << 30;
+  const int64_t SLICE = launch_slice();
   for (int64_t c0 = 0; c0 < N; c0 += SLICE) {
     const dim3 grid((unsigned)((std::min(SLICE, N - c0) + GATHER_NT - 1) / GATHER_NT)), blk(GATHER_NT);
 #define DNM_C(RT)                                                                                      \
@@ -1453,7 +1460,7 @@ int launch_gather_matvec(const DevMsc &msc, const SubView &left, const SubView &
 int launch_diag(const DevMsc &msc, const SubView &sub, int64_t M, int64_t row0, double *diag, hipStream_t st) {
   // One thread per row, and a launch holds fewer than 2^32 threads: rows go in slices of 2^30 (XParity on
   // SpinConserve(36,18) has 4.54 G of them -- its first run, round 5, silently computed with no diagonal at all)
-  const int64_t SLICE = (int64_t)1 << 30;
+  const int64_t SLICE = launch_slice();
   for (int64_t r0 = 0; r0 < M; r0 += SLICE) {
     const int64_t m = std::min(SLICE, M - r0);
     const dim3 grid((unsigned)((m + GATHER_NT - 1) / GATHER_NT)), blk(GATHER_NT);

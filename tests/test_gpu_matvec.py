@@ -656,6 +656,29 @@ def test_default_plan_real_packed_vs_oracle(monkeypatch, name, L, kind):
     H.destroy_mat()
 
 
+def test_row_kernels_launched_in_slices(monkeypatch):
+    """The cached diagonal and CheckConserves run one thread per row / column, and a launch holds fewer than 2^32 threads:
+    past 2^30 rows they go out in slices (round 5: XParity(SpinConserve(36, 18)) has 4.54 G rows, and its first solve ran
+    with no diagonal at all).  Slices of 2^10 here: the same results as in one launch."""
+    monkeypatch.setenv("DNM_LAUNCH_SLICE_LOG2", "10")
+    for sub in (SpinConserve(16, 8), Full(L=13), Explicit(np.arange(0, 1 << 14, 3), L=14)):
+        H = models.mbl(sub.L)
+        mat = shell(H, sub, flags=_lib.MAT_FORCE_GATHER)
+        mat.precompute_diagonal()
+        d = np.empty(sub.get_dimension())
+        _lib.check(_lib.lib().dnm_mat_get_diagonal(mat.handle, d.ctypes.data_as(_lib.f64p), None))
+        want = orc.precompute_diagonal(orc_msc(H), orc_sub(sub))
+        assert np.abs(d - want).max() <= 1e-13
+        x = rand_state(sub.get_dimension(), seed=2)
+        assert np.abs(mult_numpy(mat, x) - orc.matvec(orc_msc(H), orc_sub(sub), orc_sub(sub), x)).max() <= 1e-12
+        mat.destroy()
+        assert backend.check_conserves(*marshal(H), sub._to_c(), sub._to_c()) == orc.check_conserves(
+            orc_msc(H), orc_sub(sub), orc_sub(sub))
+    H = models.ising(12)            # sigma_x leaves SpinConserve: the verdict must survive the slicing too
+    sub = SpinConserve(12, 6)
+    assert backend.check_conserves(*marshal(H), sub._to_c(), sub._to_c()) is False
+
+
 def _random_hermitian(L, nterms, rs):
     """Sum of random Pauli strings with real coefficients (Hermitian by construction)."""
     from dynamite_amd.operators import sigmax, sigmay, sigmaz, op_sum, op_product
