@@ -14,8 +14,15 @@ row-block partitioned, L = 30 + log2(N) so every GPU keeps 2^30 amplitudes
 all-to-all between two layouts from 4 on -- DESIGN.md section 6) travels over
 RCCL while the rank-local masks run.  Prints ONE JSON line on rank 0.
 
-Every N > 1 line also carries the link rate MEASURED in the same run (the multiply's exchange posted alone,
-`xgmi_link_GBs_measured`) next to the assumed one the prediction uses.  Every rank runs a watchdog thread: a
+Every N > 1 line also carries, under `multi_gpu`, the multiply split three ways for BOTH schedules of the exchange -- the
+native one (dnm_mat_mult_partitioned: the library's own RCCL communicator and stream; the default on RCCL) and the host
+one (torch.distributed) --: the whole multiply, its messages alone (with the rate the busiest link reached,
+`link_GBs_measured`, next to the assumed one the prediction uses), its kernels alone, and how much of the exchange the
+schedule hid; the verdict of the first multiply's check against the MSC definition; and `secondary.config5`:
+`eigsolve(nev=1)` of the Heisenberg chain in SpinConserve(36, 18) at N=8 (BASELINE.json configs[4]; (35,17) / (34,17) at
+N = 4 / 2: the same rows per GPU).  Before a rank touches its GPU it sends a CHILD process through the native schedule
+at a small size (`first_contact_probe`): a schedule that hangs or fails on hardware nobody has run it on costs that
+child, and the measurement falls back to the host schedule and says so.  Every rank runs a watchdog thread: a
 phase that makes no progress for `--watchdog` seconds prints the plan and the phase and ends the process with a
 non-zero code (so a hung collective cannot hold the node); the parent of a self-launched run ends the other
 ranks as soon as one fails.
@@ -40,6 +47,9 @@ HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 ALG_BYTES_PER_AMP = 32.0  # read x once + write y once
 # what a two-launch plan must move per amplitude whatever the kernels do
 FLOOR_BYTES_PER_AMP = 80.0
+# what a device-to-device copy sustains on this chip (read + write, profiles/r03_copy_probe2.txt; 5.2-5.5 TB/s with the
+# 64 KB-tile workgroup shape): the rate a memory-bound kernel can be held to, where 8 TB/s is the spec sheet
+COPY_RATE_GBS = 6300.0
 FLOOR_DERIVATION = ("two launches: x is read by both (2 x 16 B), y is written by the first, read back and written by "
                     "the second (3 x 16 B); one launch would have to keep all 29 bond exchanges of the 2^30 hypercube "
                     "on chip (DESIGN.md 4.2)")
@@ -432,6 +442,7 @@ class Watchdog:
         self.limit, self.rank = limit_s, rank
         self.name, self.t, self.info = "start", time.monotonic(), ""
         self.done = []
+        self.partial = None       # rank 0: the result line as far as it has been measured
         if limit_s > 0:
             threading.Thread(target=self._run, daemon=True).start()
 
@@ -447,6 +458,16 @@ class Watchdog:
                                  "[bench watchdog] %s\n" % (self.rank, self.name, self.limit,
                                                             self.done[-1] if self.done else "-", self.info))
                 sys.stderr.flush()
+                if self.partial is not None:
+                    # what has been measured is not lost to a later phase that hangs
+                    try:
+                        line = dict(self.partial)
+                        line["aborted"] = {"phase": self.name, "reason": "no progress for %.0f s (watchdog)" % self.limit,
+                                           "last_completed": self.done[-1] if self.done else None}
+                        sys.stdout.write(json.dumps(line) + "\n")
+                        sys.stdout.flush()
+                    except Exception:       # noqa: BLE001
+                        pass
                 os._exit(3)
 
 
@@ -550,9 +571,25 @@ def dry_run(args, world, rank, wd=None):
         ok = all(bool((b == complex(p + 1, 0)).all()) for (p, _, _), b in zip(recvs, bufs))
     t = torch.tensor([wall, 0.0 if ok else 1.0], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    # config 5's exchange at a toy size: every rank's column window from its host-only handle, the ranges travel over gloo
+    sec = None
+    if not args.no_secondary:
+        if wd:
+            wd.phase("dry run: config 5's window exchange")
+        try:
+            sec = {"config5": config5_dry_run(world, rank, tuple(int(v) for v in args.config5.split(",")) if args.config5
+                                              else (18, 9))}
+        except Exception as e:       # noqa: BLE001
+            sec = {"error": repr(e)}
     if rank == 0:
         buf = C_describe(h) if plans is None else "transposed exchange | A: " + plans[0] + " | B: " + plans[1]
-        est = exchange_estimate(summary, float(t[0]) / args.steps)
+        exch_s = float(t[0]) / args.steps
+        est = exchange_estimate(summary, exch_s)
+        host = schedule_entry("host", float("nan"), exch_s * 1e3, float("nan"), summary,
+                              "exchange_ok: every message arrived where the schedule says" if t[1] == 0.0 else "failed")
+        for k in ("ms_per_step", "compute_only_ms", "hidden_ms", "hidden_frac_of_the_shorter"):
+            host[k] = None          # no kernel runs without a GPU
+        sec_ok = sec is None or ("error" not in sec and sec["config5"].get("exchange_ok") is True)
         print(json.dumps({
             "metric": "matrix-free H|psi> Gamplitudes/s, random-field Heisenberg", "value": None,
             "unit": "Gamplitudes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -561,16 +598,81 @@ def dry_run(args, world, rank, wd=None):
             "transport": "gloo", "exchange_ok": bool(t[1] == 0.0),
             "config": dict({"workload": f"DRY RUN (no GPU): plan + exchange schedule of the L={L} random-field "
                                         f"Heisenberg chain on {world} ranks, no multiply executed",
-                            "L": L, "plan": buf.strip().replace("\n", " | ")}, **est)}))
+                            "L": L, "schedule": "host (torch.distributed)", "exchange_selfcheck": None,
+                            "plan": buf.strip().replace("\n", " | ")}, **est),
+            "multi_gpu": {"default_schedule": "host", "first_contact_probe": None, "xgmi_link_GBs_assumed": XGMI_LINK_GBS,
+                          "schedules": {"host": host, "native": "not run: no GPU (dnm_mat_mult_partitioned launches kernels)"}},
+            "secondary": sec, "secondary_ok": sec_ok}))
     _lib.check(_lib.lib().dnm_mat_destroy(h))
     dist.destroy_process_group()
-    sys.exit(0 if t[1] == 0.0 else 1)
+    sys.exit(0 if (t[1] == 0.0 and (sec is None or "error" not in sec)) else 1)
+
+
+def config5_dry_run(world, rank, Lk):
+    """Without a GPU: the exchange of config 5's multiply -- the Heisenberg chain in SpinConserve(L, k), internal
+    three-field layout, whole blocks of equal top bits per rank -- planned by every rank from a host-only handle (its
+    column window and the ranges of it its rows read), posted over gloo as ShellMat._mult_window posts it, and checked:
+    every position a rank reads must hold what its owner holds there."""
+    import ctypes as C
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from dynamite_amd import models, backend, msc_tools, _lib
+    from dynamite_amd.subspaces import SpinConserve
+    L, k = Lk
+    sub = SpinConserve(L, k)
+    d = _lib.Subspace.from_buffer_copy(sub._c())
+    a, w = (14, 10) if L >= 28 else (6, 4)
+    d.vec_swizzle = a | (w << 8)
+    H = models.heisenberg(L)
+    H.establish_L()
+    H.reduce_msc()
+    masks, offs = msc_tools.get_mask_offsets(H.msc)
+    h = backend.create_mat(masks, offs, H.msc['signs'], H.msc['coeffs'], d, d, False, _lib.MAT_HOST_ONLY, rank, world)
+    lo, hi = C.c_int64(), C.c_int64()
+    _lib.check(_lib.lib().dnm_mat_column_window(h, C.byref(lo), C.byref(hi), None))
+    window = (lo.value, hi.value)
+    shift = max(0, int(hi.value - lo.value + 1).bit_length() - backend.ShellMat.WINDOW_CHUNKS.bit_length())
+    n = (hi.value >> shift) - (lo.value >> shift) + 1
+    cmap = np.zeros(n, dtype=np.uint8)
+    _lib.check(_lib.lib().dnm_mat_column_chunks(h, shift, cmap.ctypes.data_as(C.POINTER(C.c_uint8)), n, None))
+    needs = backend.needed_ranges(cmap, shift, window)
+    allw = [None] * world
+    dist.all_gather_object(allw, (window, needs))
+    windows, allneeds = [v[0] for v in allw], [v[1] for v in allw]
+    owned = [backend.layout_partition(d, world, q)[:2] for q in range(world)]
+    i0, il = owned[rank]
+    x = (torch.arange(il, dtype=torch.float64) + float(i0)).to(torch.complex128)     # every position holds its own number
+    buf = backend.exchange_window(x, owned, windows, rank, None, allneeds)
+    ok = True
+    for a_, b_ in needs:
+        ok = ok and bool((buf[a_ - window[0]:b_ - window[0]].real == torch.arange(a_, b_, dtype=torch.float64)).all())
+    recvs, sends = backend.window_exchange_ops(owned, windows, rank, allneeds)
+    t = torch.tensor([0.0 if ok else 1.0, float(sum(16 * (b_ - a_) for _, a_, b_ in recvs))], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    _lib.check(_lib.lib().dnm_mat_destroy(h))
+    return {"workload": "DRY RUN: window exchange of the Heisenberg chain in SpinConserve(%d,%d) on %d ranks, layout (%d,%d)"
+                        % (L, k, world, a, w),
+            "dim": sub.get_dimension(), "exchange": "window", "exchange_ok": bool(t[0] == 0.0),
+            "bytes_received_per_multiply_busiest_rank": int(t[1]), "window_bytes_rank0": 16 * (window[1] - window[0] + 1),
+            "ranges_read_rank0": len(needs), "heisenberg": None, "known_answer_xx_chain": None}
 
 
 def plan_signature(mat):
     """Identifies the executed plan in profiles/latest_pmc.json (the counter run must be of the same plan)."""
     import hashlib
     return hashlib.sha256(mat.describe().strip().replace("\n", " | ").encode()).hexdigest()[:16]
+
+
+def kernel_source_hash():
+    """Hash of the sources the headline kernel and its plan come from: profiles/latest_pmc.json carries the hash of
+    the tree its counters were taken on, and the line's `traffic` is null when the code has moved since."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("dynamite_amd/csrc/matvec_kernels.hip", "dynamite_amd/csrc/plan.cpp", "dynamite_amd/csrc/plan.h",
+              "dynamite_amd/csrc/kernels.h"):
+        h.update(open(os.path.join(ROOT, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def C_describe(handle):
@@ -581,6 +683,199 @@ def C_describe(handle):
     return buf.value.decode()
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# several GPUs
+# ---------------------------------------------------------------------------------------------------------------
+CONFIG5_BY_WORLD = {2: (34, 17), 4: (35, 17), 8: (36, 18)}      # about 1.13-1.17 G rows per GPU each; 8: BASELINE configs[4]
+PROBE_PORT_OFFSET = 23
+
+
+def first_contact_probe(args, world, rank, which="native"):
+    """Send a CHILD process (one per rank, its own rendezvous on MASTER_PORT + offset, started before this process
+    touches the GPU) through one schedule of the exchange at a small size: a partitioned Full-space multiply checked
+    against the MSC definition, its exchange alone, and an eigsolve on a partitioned SpinConserve subspace through the
+    solver hooks.  A schedule that hangs or fails on a machine nobody has run it on then costs that child -- ended by
+    exact PID after `--probe-timeout` seconds -- and not the measurement.  Returns {"ok": bool, ...}."""
+    import subprocess
+    import tempfile
+    # (under torch.distributed.run the ranks would look for the agent's store: the children make their own rendezvous)
+    env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")}
+    env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + PROBE_PORT_OFFSET + (0 if which == "native" else 1))
+    env["DNM_NATIVE_COMM"] = "1" if which == "native" else "0"
+    out = tempfile.NamedTemporaryFile(prefix="dnm_probe_%d_" % rank, suffix=".json", delete=False)
+    out.close()
+    cmd = [sys.executable, os.path.abspath(__file__), "--probe-child", out.name, "--gpus", str(world),
+           "--watchdog", str(max(30, args.probe_timeout - 20))]
+    t0 = time.monotonic()
+    res = {"ok": False, "schedule": which, "timeout_s": args.probe_timeout}
+    try:
+        p = subprocess.Popen(cmd, env=env, stdout=subprocess.DEVNULL)     # (the report comes through the file)
+        try:
+            rc = p.wait(timeout=args.probe_timeout)
+            res["returncode"] = rc
+        except subprocess.TimeoutExpired:
+            p.kill()                        # this exact child
+            p.wait()
+            res["error"] = "no answer within %d s: ended" % args.probe_timeout
+            rc = None
+        if rc == 0:
+            try:
+                res.update(json.load(open(out.name)))
+            except Exception as e:       # noqa: BLE001
+                res["error"] = "no report: %r" % (e,)
+        elif rc is not None:
+            res["error"] = "exit code %d" % rc
+    except Exception as e:       # noqa: BLE001
+        res["error"] = repr(e)
+    finally:
+        try:
+            os.unlink(out.name)
+        except OSError:
+            pass
+    res["wall_s"] = time.monotonic() - t0
+    return res
+
+
+def probe_child(args):
+    """The child of `first_contact_probe`: a rank of a small run through the schedule DNM_NATIVE_COMM names."""
+    world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ.get("RANK", "0"))
+    wd = Watchdog(args.watchdog, rank)
+    wd.phase("probe: import torch")
+    import torch
+    import torch.distributed as dist
+    local = int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(local)
+    backend_name = os.environ.get("DNM_BENCH_BACKEND", "nccl")
+    wd.phase("probe: init_process_group(%s)" % backend_name)
+    if backend_name == "nccl":
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        dist.init_process_group(backend_name)
+    from dynamite_amd import models, backend
+    from dynamite_amd.config import config
+    from dynamite_amd.subspaces import Full, SpinConserve
+    from dynamite_amd.states import State
+    from dynamite_amd.computations import eigsolve
+    config._initialize()
+    rep = {"ok": False, "native": backend.native_transport()}
+    L = args.L or (22 + int(math.log2(world)))
+    wd.phase("probe: multiply L=%d" % L)
+    H = models.mbl(L)
+    sub = Full(L=L)
+    H.add_subspace(sub)
+    mat = H.get_mat(subspaces=(sub, sub))
+    x, y = mat.createVecs()
+    x.set_random(0)
+    for _ in range(2):
+        mat.mult(x, y)          # (the first one of a transposed exchange checks itself)
+    err, scale = mat.selfcheck(x, y)
+    rep["multiply_selfcheck"] = {"max_abs_dev": err, "scale": scale, "scheme": mat.exchange_summary()["scheme"]}
+    assert err <= 1e-9 * max(scale, 1e-300), "sampled rows of the multiply are off by %r" % err
+    wd.phase("probe: exchange alone")
+    mat.exchange_only(x, y)
+    wd.phase("probe: eigsolve on a partitioned SpinConserve subspace")
+    Ls = 26
+    ssub = SpinConserve(Ls, Ls // 2)
+    Hs = models.heisenberg(Ls)
+    Hs.add_subspace(ssub)
+    ev = Hs.eigsolve(nev=1, tol=1e-8, subspace=ssub)
+    st = dict(eigsolve.last_stats)
+    rep["eigsolve_sc26_13"] = {"E0": float(ev[0]), "matvecs": st["matvecs"], "rel_residual": st["max_rel_residual"]}
+    # (the Bethe-ansatz energy per site of the infinite chain is 1/4 - ln 2 = -0.4431: an open chain of 26 sits a little above)
+    assert st["max_rel_residual"] <= 1.01e-8 and -0.4432 * Ls < float(ev[0]) < -0.40 * Ls, rep
+    torch.cuda.synchronize()
+    dist.barrier()
+    rep["ok"] = True
+    json.dump(rep, open(args.probe_child, "w"))
+    Hs.destroy_mat()
+    H.destroy_mat()
+    backend.release_native_comm()
+    dist.destroy_process_group()
+    return 0
+
+
+def phase_times(mat, x, y, steps, barrier, reduce_max):
+    """One schedule of a partitioned multiply split three ways: (whole multiply, messages alone, kernels alone) in ms,
+    each the max over ranks of the mean over `steps` calls between barriers."""
+    def run(fn, n):
+        fn()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        barrier()
+        return reduce_max((time.perf_counter() - t0) / n) * 1e3
+    whole = run(lambda: mat.mult(x, y), steps)
+    exch = run(lambda: mat.exchange_only(x, y), max(1, min(3, steps)))
+    comp = run(lambda: mat.compute_only(x, y), max(1, min(5, steps)))
+    return whole, exch, comp
+
+
+def schedule_entry(name, whole_ms, exch_ms, comp_ms, summary, selfcheck):
+    hidden = exch_ms + comp_ms - whole_ms
+    busiest = summary["busiest_link_bytes"]
+    return {"schedule": name, "ms_per_step": whole_ms, "exchange_only_ms": exch_ms, "compute_only_ms": comp_ms,
+            "hidden_ms": hidden, "hidden_frac_of_the_shorter": hidden / max(1e-9, min(exch_ms, comp_ms)),
+            "busiest_link_bytes": int(busiest),
+            "link_GBs_measured": (busiest / (exch_ms * 1e-3) / 1e9) if busiest else None,
+            "selfcheck": selfcheck}
+
+
+def config5(wd, world, rank, Lk=None, tol=1e-8):
+    """BASELINE.json configs[4]: `eigsolve(nev=1)` of the Heisenberg chain in SpinConserve(36, 18) on 8 GPUs
+    (computations.py:128-292 on bsubspace_impl.h:161-261 in the reference); (35,17) / (34,17) on 4 / 2 GPUs keep the rows
+    per GPU.  Column windows over the ranks, the real arithmetic eigsolve takes on its own for a real-symmetric operator,
+    reductions and multiplies through the solver hooks.  Then the same subspace's known answer: 0.25 sum (XX + YY) against the
+    filled Fermi sea."""
+    import numpy as np
+    import torch
+    from dynamite_amd import models
+    from dynamite_amd.subspaces import SpinConserve
+    from dynamite_amd.computations import eigsolve
+    from dynamite_amd.operators import sigmax, sigmay, op_sum
+    L, k = Lk or CONFIG5_BY_WORLD[world]
+    out = {"workload": "eigsolve(nev=1, tol=%g), Heisenberg chain, SpinConserve(%d,%d) on %d GPUs" % (tol, L, k, world),
+           "baseline_config": "BASELINE.json configs[4]" if (L, k, world) == (36, 18, 8) else
+                              "configs[4]'s family at this rank count (rows per GPU kept)"}
+    sub = SpinConserve(L, k)
+    out["dim"] = sub.get_dimension()
+
+    def solve(H, name):
+        wd.phase("config 5: %s" % name)
+        H.add_subspace(sub)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ev = H.eigsolve(nev=1, tol=tol, subspace=sub)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        st = dict(eigsolve.last_stats)
+        mat = H.get_real_packed_mat(sub) if st["real_arithmetic"] else H.get_mat(subspaces=(sub, sub))
+        summ = mat.exchange_summary()
+        r = {"wall_s": dt, "includes": "building the operator (tables, windows of all ranks) and the solve",
+             "matvecs": st["matvecs"], "ms_per_step": dt / max(1, st["matvecs"]) * 1e3, "E0": float(ev[0]),
+             "measured_rel_residual": st["max_rel_residual"], "tol": tol,
+             "arithmetic": "real (f64, 8 B per amplitude)" if st["real_arithmetic"] else "complex128 (16 B per amplitude)",
+             "rows_this_rank": int(mat.m_local) * (2 if st["real_arithmetic"] else 1),
+             "exchange": summ["scheme"], "bytes_received_per_multiply_rank0": int(summ["bytes_in"]),
+             "busiest_link_bytes_rank0": int(summ["busiest_link_bytes"]),
+             "window_bytes_rank0": int(summ.get("window_bytes", 0)),
+             "plan": mat.describe().strip().split("\n")[0][:160]}
+        if not st["max_rel_residual"] <= tol * 1.01:
+            r["failed_checks"] = ["residual %r above tol" % st["max_rel_residual"]]
+        H.destroy_mat()
+        return r
+    out["heisenberg"] = solve(models.heisenberg(L), "Heisenberg chain")
+    Hx = op_sum(0.25 * (sigmax(i) * sigmax(i + 1) + sigmay(i) * sigmay(i + 1)) for i in range(L - 1))
+    Hx.L = L
+    r = solve(Hx, "XX chain against the filled Fermi sea")
+    exact = float(np.sort(np.cos(np.pi * np.arange(1, L + 1) / (L + 1)))[:k].sum())
+    r["exact"], r["abs_error"] = exact, abs(r["E0"] - exact)
+    if not r["abs_error"] < 1e-6 * abs(exact):
+        r.setdefault("failed_checks", []).append("ground-state energy %r against the filled Fermi sea %r" % (r["E0"], exact))
+    out["known_answer_xx_chain"] = r
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -589,11 +884,17 @@ def main():
     ap.add_argument("--L", type=int, default=0)
     ap.add_argument("--model", default="mbl")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the evolve / eigsolve phases of the one-GPU line")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the evolve / eigsolve phases of the line")
     ap.add_argument("--watchdog", type=int, default=900, help="seconds a phase may take before the rank gives up (0: off)")
     ap.add_argument("--timeout", type=int, default=3600, help="time limit of a self-launched multi-rank run (0: none)")
+    ap.add_argument("--no-probe", action="store_true", help="several GPUs: skip the first-contact probe of the native schedule")
+    ap.add_argument("--probe-timeout", type=int, default=300)
+    ap.add_argument("--probe-child", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--config5", default=None, help="L,k of the SpinConserve eigsolve of a multi-GPU line (default by rank count)")
     args = ap.parse_args()
 
+    if args.probe_child:
+        sys.exit(probe_child(args))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args.gpus, args.timeout)          # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -606,14 +907,24 @@ def main():
         wd.phase("init_process_group(gloo)")
         dist.init_process_group("gloo")
         dry_run(args, world, rank, wd)      # does not return
+    probe = None
     if world > 1:
         import torch.distributed as dist
+        backend_name = os.environ.get("DNM_BENCH_BACKEND", "nccl")
+        # The native schedule has never met a second device: before this process touches its GPU, a child goes through it
+        # at a small size (torch.cuda.device_count() above does not initialise the runtime).  DNM_NATIVE_COMM=0 / 1 is a
+        # decision already taken: no probe.
+        # (DNM_BENCH_FORCE_PROBE=1: tests send the probe through a stand-in transport -- DNM_RCCL_LIB -- on gloo-staged ranks)
+        if ((backend_name == "nccl" or os.environ.get("DNM_BENCH_FORCE_PROBE") == "1")
+                and os.environ.get("DNM_NATIVE_COMM", "") == "" and not args.no_probe):
+            wd.phase("first-contact probe of the native schedule (child process)")
+            wd.t += args.probe_timeout          # (the probe has its own limit)
+            probe = first_contact_probe(args, world, rank, "native")
         # rank % device count, as the reference picks its GPU (bcuda_template_2.cu:64-67)
         local = int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count())
         torch.cuda.set_device(local)
         # DNM_BENCH_BACKEND=gloo: dry run of the multi-rank flow with several ranks on one GPU (blocks staged
         # through the host; RCCL refuses two ranks on one device) -- a plumbing check, not a measurement
-        backend_name = os.environ.get("DNM_BENCH_BACKEND", "nccl")
         wd.phase("init_process_group(%s)" % backend_name)
         if backend_name == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
@@ -623,6 +934,18 @@ def main():
     from dynamite_amd.config import config
     from dynamite_amd.subspaces import Full
     config._initialize()
+    if probe is not None:
+        # every rank or none
+        t = torch.tensor([1.0 if probe["ok"] else 0.0], dtype=torch.float64, device=config.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        probe["all_ranks_ok"] = bool(t.item() == 1.0)
+        if probe["all_ranks_ok"] and dist.get_backend() != "nccl":
+            config.native_comm = True           # (a forced probe on gloo-staged ranks: the stand-in transport it went through)
+        if not probe["all_ranks_ok"]:
+            config.native_comm = False
+            if rank == 0:
+                print("[bench] first-contact probe of the native schedule failed (%s): host schedule over torch.distributed"
+                      % probe.get("error", "on another rank"), file=sys.stderr)
 
     n_gpus = world
     L = args.L or default_L(n_gpus)
@@ -633,7 +956,10 @@ def main():
     from dynamite_amd import msc_tools
     masks, offs = msc_tools.get_mask_offsets(H.msc)
     sub = Full(L=L)
-    mat = backend.build_mat(masks, offs, H.msc['signs'], H.msc['coeffs'], sub._to_c(), sub._to_c())
+
+    def build(exchange=None):
+        return backend.build_mat(masks, offs, H.msc['signs'], H.msc['coeffs'], sub._to_c(), sub._to_c(), exchange=exchange)
+    mat = build()
     if rank == 0:
         print(mat.describe(), file=sys.stderr)
     wd.info = "plan: " + mat.describe().strip().replace("\n", " | ")
@@ -643,31 +969,50 @@ def main():
     x.set_random(0)
     x.normalize()
 
-    launches = mat.launches_per_mult()
-
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
             torch.cuda.synchronize()
 
-    exchange_fallback = None
-    for i in range(max(1, args.warmup) if world > 1 else args.warmup):
-        wd.phase("warm-up multiply %d of %d" % (i + 1, args.warmup))
-        try:
-            mat.mult(x, y)     # the first multiply of a transposed-exchange operator checks sampled rows (collective)
-        except backend.ExchangeCheckError as e:
-            # every rank sees the same verdict: fall back to the partner blocks, say so in the line
-            exchange_fallback = str(e)
-            if rank == 0:
-                print("[bench] " + exchange_fallback, file=sys.stderr)
-            mat.destroy()
-            mat = backend.build_mat(masks, offs, H.msc['signs'], H.msc['coeffs'], sub._to_c(), sub._to_c(),
-                                    exchange='partner')
-            launches = mat.launches_per_mult()
-            mat.mult(x, y)
-        if world > 1:
-            torch.cuda.synchronize()        # so that the watchdog names the multiply that hangs
+    def reduce_max(v):
+        if world == 1:
+            return v
+        t = torch.tensor([v], dtype=torch.float64, device=config.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def warm(mat, n, what):
+        """n warm-up multiplies; the first multiply of a transposed-exchange operator checks sampled rows (collective):
+        on a disagreement every rank sees the same verdict and the operator is rebuilt on partner blocks.  Returns
+        (matrix, verdict)."""
+        verdict = None
+        for i in range(n):
+            wd.phase("%s: warm-up multiply %d of %d" % (what, i + 1, n))
+            try:
+                mat.mult(x, y)
+            except backend.ExchangeCheckError as e:
+                verdict = "failed: " + str(e)
+                if rank == 0:
+                    print("[bench] " + str(e), file=sys.stderr)
+                mat.destroy()
+                mat = build(exchange='partner')
+                mat.mult(x, y)
+            if world > 1:
+                torch.cuda.synchronize()        # so that the watchdog names the multiply that hangs
+        if world > 1 and verdict is None:
+            if mat.exchange_summary()["scheme"] == "transpose":
+                verdict = "sampled rows of the first multiply agree with the MSC definition"
+            else:
+                # (partner blocks need no check of their own; on a first contact they get one all the same)
+                err, scale = mat.selfcheck(x, y)
+                verdict = ("sampled rows agree with the MSC definition" if err <= 1e-9 * max(scale, 1e-300)
+                           else "failed: sampled rows off by %.3e (scale %.3e)" % (err, scale))
+        return mat, verdict
+
+    mat, selfcheck = warm(mat, max(1, args.warmup) if world > 1 else args.warmup, "default schedule")
+    launches = mat.launches_per_mult()
+    native_default = world > 1 and mat._native_in_use(x)
     wd.phase("barrier before the timed steps")
     barrier()
     wd.phase("%d timed multiplies" % args.steps)
@@ -685,31 +1030,17 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall, dev_ms = float(t[0]), float(t[1])
     ms_per_step = wall * 1e3 / args.steps
+    # sanity: the timed multiply produced a finite vector of the expected size
+    ynorm = y.norm()
+    assert math.isfinite(ynorm) and ynorm > 0
     summary = mat.exchange_summary()
-    exchange_only_s = None
     if world > 1:       # the heaviest rank (partner blocks differ from rank to rank: rank 0 needs the least)
         t = torch.tensor([summary["bytes_in"], summary["bytes_out"], summary["busiest_link_bytes"], summary["peers"]],
                          dtype=torch.float64, device=config.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         summary.update(bytes_in=int(t[0]), bytes_out=int(t[1]), busiest_link_bytes=int(t[2]), peers=int(t[3]))
-        # the multiply's exchange on its own (no kernels): what the links really carry per second
-        wd.phase("exchange alone (link rate)")
-        mat.exchange_only(x)
-        barrier()
-        t1 = time.perf_counter()
-        nrep = max(1, min(3, args.steps))
-        for _ in range(nrep):
-            mat.exchange_only(x)
-        barrier()
-        t = torch.tensor([(time.perf_counter() - t1) / nrep], dtype=torch.float64, device=config.device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        exchange_only_s = float(t[0])
-    wd.phase("result line")
 
-    # sanity: the timed multiply produced a finite vector of the expected size
-    ynorm = y.norm()
-    assert math.isfinite(ynorm) and ynorm > 0
-
+    out = None
     if rank == 0:
         # kernel time from HIP events on the launch stream (events bracket K steps
         # of back-to-back launches; per-launch = total / (K * launches per step))
@@ -720,18 +1051,24 @@ def main():
         achieved = alg_bytes_launch / (avg_launch_ms * 1e-3) / 1e9
         # HBM traffic needs the PMC counters, i.e. a separate rocprofv3 --pmc run of this same command
         # (tools/profile_bench.sh): the line carries the committed figure of that run, and says so, when it was
-        # taken for the same size / rank count / plan; otherwise null
+        # taken for the same size / rank count / plan AND on the same kernel and planner sources; otherwise null
         traffic, traffic_source = None, None
         pmc = os.path.join(ROOT, "profiles", "latest_pmc.json")
         if os.path.exists(pmc):
             try:
                 p = json.load(open(pmc))
                 if p.get("L") == L and p.get("n_gpus") == n_gpus and p.get("plan_signature") == plan_signature(mat):
-                    traffic = p.get("hbm_bytes_per_launch")
-                    traffic_source = ("profiles/latest_pmc.json: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE of "
-                                      "this command, separate run" + (", " + p["source"] if p.get("source") else ""))
+                    if p.get("kernel_source_hash") == kernel_source_hash():
+                        traffic = p.get("hbm_bytes_per_launch")
+                        traffic_source = ("profiles/latest_pmc.json: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE of "
+                                          "this command, separate run, same kernel sources (hash %s)" % p["kernel_source_hash"]
+                                          + (", " + p["source"] if p.get("source") else ""))
+                    else:
+                        traffic_source = ("null: the kernel / planner sources have changed since the counter run of "
+                                          "profiles/latest_pmc.json (tools/profile_bench.sh renews it)")
             except Exception:
                 traffic, traffic_source = None, None
+        two = launches == 2 and n_gpus == 1
         out = {
             "metric": "matrix-free H|psi> Gamplitudes/s, random-field Heisenberg",
             "value": dim / (ms_per_step * 1e-3) / 1e9,
@@ -747,12 +1084,11 @@ def main():
                        "baseline_config": BASELINE_CONFIG.get((n_gpus, L, args.model)),
                        "launches_per_step": launches,
                        "transport": (os.environ.get("DNM_BENCH_BACKEND", "nccl") if world > 1 else "none"),
+                       "schedule": (None if world == 1 else
+                                    "native (dnm_mat_mult_partitioned)" if native_default else "host (torch.distributed)"),
                        "amplitudes_per_gpu": dim_local,
-                       "exchange_selfcheck": (None if world == 1 else
-                                              ("failed: " + exchange_fallback if exchange_fallback else
-                                               "sampled rows of the first multiply agree with the MSC definition"
-                                               if summary["scheme"] == "transpose" else "not needed (partner blocks)")),
-                       **exchange_estimate(summary, exchange_only_s),
+                       "exchange_selfcheck": selfcheck,
+                       **exchange_estimate(summary, None),
                        "plan": mat.describe().strip().replace("\n", " | "),
                        "plan_signature": plan_signature(mat)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -763,32 +1099,106 @@ def main():
                          "floor_bytes_per_amp": FLOOR_BYTES_PER_AMP if launches == 2 else None,
                          "floor_derivation": FLOOR_DERIVATION if launches == 2 else None,
                          "frac_of_floor": (FLOOR_BYTES_PER_AMP * dim_local / launches / traffic) if (traffic and launches == 2) else None,
+                         # the north star's target against what this algorithm class can reach: a sum over
+                         # 29 bonds of a 30-cube takes two launches, 80 B/amp where 32 are credited -- 0.40 of the roofline
+                         # at the 8 TB/s spec peak, 0.315 at the 6.3 TB/s this chip copies at
+                         "target_frac": 0.60, "target_met": bool(achieved / HBM_PEAK_GBS >= 0.60),
+                         "floor_frac_at_spec": (ALG_BYTES_PER_AMP / FLOOR_BYTES_PER_AMP) if two else None,
+                         "copy_rate_GBs": COPY_RATE_GBS if two else None,
+                         "floor_frac_at_copy_rate": (ALG_BYTES_PER_AMP / FLOOR_BYTES_PER_AMP * COPY_RATE_GBS / HBM_PEAK_GBS) if two else None,
+                         "frac_vs_copy_ceiling": (FLOOR_BYTES_PER_AMP * dim_local / (kern_ms * 1e-3) / 1e9 / COPY_RATE_GBS) if two else None,
+                         "target_note": ("0.60 of the 32 B/amp roofline is out of reach for complex128 at L=30 with any "
+                                         "two-launch plan: the ceiling is floor_frac_at_spec; the kernel runs at "
+                                         "frac_vs_copy_ceiling of what a copy of the same 80 B/amp would take") if two else None,
                          "kernel": "tile_pass_kernel", "avg_launch_ms": avg_launch_ms,
                          "alg_bytes_per_launch": alg_bytes_launch,
                          "read_only_frac": 0.5 * achieved / HBM_PEAK_GBS},
         }
-        if n_gpus == 1 and not args.no_secondary and L == 30:
-            # the headline's vectors and operator go first: the solvers size their work space to the free memory
-            mat.destroy()
-            mat = None
-            del x, y
-            torch.cuda.empty_cache()
-            # (a failure in the Krylov phases -- memory for the 64 GiB of work vectors, a failed check -- is recorded,
-            # it must not cost the headline that has already been measured)
+        wd.partial = out
+
+    if world > 1:
+        # the multiply split three ways, for both schedules of the exchange
+        mg = {"default_schedule": "native" if native_default else "host", "first_contact_probe": probe,
+              "xgmi_link_GBs_assumed": XGMI_LINK_GBS, "schedules": {}}
+        if out is not None:
+            out["multi_gpu"] = mg
+        nph = max(2, min(args.steps, 5))
+        try:
+            wd.phase("phases of the default schedule")
+            w, e, c = phase_times(mat, x, y, nph, barrier, reduce_max)
+            mg["schedules"]["native" if native_default else "host"] = schedule_entry(
+                "native" if native_default else "host", w, e, c, summary, selfcheck)
+            if out is not None:
+                out["config"].update(exchange_estimate(summary, e * 1e-3))
+        except Exception as e:       # noqa: BLE001
+            mg["schedules"]["native" if native_default else "host"] = {"error": repr(e)}
+        # ... and the other schedule: the host one after a native default; after a host default the native one only when
+        # nothing has spoken against it (no failed probe) and the transport is RCCL (or a stand-in is named)
+        other = "host" if native_default else "native"
+        may = native_default or (probe is None and os.environ.get("DNM_NATIVE_COMM", "") != "0"
+                                 and (dist.get_backend() == "nccl" or os.environ.get("DNM_RCCL_LIB")))
+        if may:
+            saved = config.native_comm
             try:
-                out["secondary"] = secondary(wd)
+                wd.phase("%s schedule: build" % other)
+                mat.destroy()
+                mat = None
+                torch.cuda.empty_cache()
+                config.native_comm = (other == "native")
+                mat = build()
+                mat, verdict = warm(mat, 1, "%s schedule" % other)
+                wd.phase("phases of the %s schedule" % other)
+                w, e, c = phase_times(mat, x, y, nph, barrier, reduce_max)
+                mg["schedules"][other] = schedule_entry(other, w, e, c, summary, verdict)
             except Exception as e:       # noqa: BLE001
-                out["secondary"] = {"error": repr(e)}
+                mg["schedules"][other] = {"error": repr(e)}
+            finally:
+                config.native_comm = saved
+        else:
+            mg["schedules"][other] = "not run: " + ("the first-contact probe failed" if probe is not None else
+                                                    "DNM_NATIVE_COMM=0" if os.environ.get("DNM_NATIVE_COMM", "") == "0" else
+                                                    "no RCCL transport (gloo-staged ranks)")
+
+    if not args.no_secondary and ((n_gpus == 1 and L == 30) or n_gpus > 1):
+        # the headline's vectors and operator go first: the solvers size their work space to the free memory
+        if mat is not None:
+            mat.destroy()
+        mat = None
+        del x, y
+        torch.cuda.empty_cache()
+        # (a failure in the Krylov phases -- memory for the work vectors, a failed check -- is recorded, it must not
+        # cost the headline that has already been measured)
+        sec = None
+        try:
+            if n_gpus == 1:
+                sec = secondary(wd)
+            else:
+                Lk = tuple(int(v) for v in args.config5.split(",")) if args.config5 else None
+                sec = {"config5": config5(wd, world, rank, Lk)}
+        except Exception as e:       # noqa: BLE001
+            sec = {"error": repr(e)}
+        if out is not None:
+            out["secondary"] = sec
+            bad = [k for k, v in sec.items() if isinstance(v, dict) and ("failed_checks" in v or "error" in v or any(
+                isinstance(w, dict) and "failed_checks" in w for w in v.values()))]
+            out["secondary_ok"] = "error" not in sec and not bad
+            if not out["secondary_ok"]:
+                print("[bench] secondary phases with failed checks or errors: %s" % (bad or sec.get("error")), file=sys.stderr)
+    if rank == 0:
         if n_gpus == 1 and not args.no_cpu_baseline:
             wd.phase("cpu baseline")
             try:
                 out["cpu_baseline"] = cpu_baseline()
             except Exception as e:       # noqa: BLE001
                 out["cpu_baseline"] = {"error": repr(e)}
+        wd.phase("result line")
+        wd.partial = None
         print(json.dumps(out))
+        sys.stdout.flush()
     if mat is not None:
         mat.destroy()
     if world > 1:
+        backend.release_native_comm()
         dist.destroy_process_group()
 
 

@@ -80,6 +80,7 @@ class Xfer(C.Structure):
 MAT_DEFAULT, MAT_FORCE_GATHER, MAT_USE_GLDS, MAT_HOST_ONLY = 0, 1, 2, 4
 MAT_REAL_PACKED = 16      # real arithmetic for a real-symmetric operator: vectors of dim / 2 elements, two amplitudes each
 EXCHANGE_AUTO, EXCHANGE_PARTNER, EXCHANGE_TRANSPOSE = 0, 1, 2      # dnm_mat_set_exchange
+PHASE_ALL, PHASE_EXCHANGE, PHASE_COMPUTE = 0, 1, 2                  # dnm_comm_set_phase
 MAT_AMIN_SHIFT = 8        # flags bits 8..15: log2 of the contiguous run of a window tile
 WHICH = {"lowest": 0, "highest": 1, "exterior": 2}
 CONVERGED_TOL, CONVERGED_ITS, DIVERGED_ITS, DIVERGED_BREAKDOWN, DIVERGED_SYMMETRY_LOST = 1, 2, -1, -2, -3
@@ -168,6 +169,7 @@ SIGNATURES = {
     "dnm_comm_allreduce": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_int]),
     "dnm_mat_mult_partitioned": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dnm_comm_prepare": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dnm_comm_set_phase": (C.c_int, [C.c_void_p, C.c_int]),
     "dnm_mat_set_exchange": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     "dnm_mat_operator": (C.c_int, [C.c_void_p, i64p, i64p, i64p, i64p, i64p, f64p]),
     "dnm_mat_exchange_parts": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int)]),

@@ -56,6 +56,26 @@ def native_comm():
     return _NATIVE_COMM
 
 
+def release_native_comm():
+    """Destroy the library's communicator (ncclCommDestroy, the exchange stream): collective in spirit -- every rank
+    calls it, after the last operator that used it has been destroyed and before the process group goes."""
+    global _NATIVE_COMM
+    if _NATIVE_COMM is not None:
+        h, _NATIVE_COMM = _NATIVE_COMM, None
+        _lib.check(_lib.lib().dnm_comm_destroy(h))
+
+
+def native_transport():
+    """Whether partitioned multiplies (and the solvers' hooks) go through the library's own communicator:
+    config.native_comm, by default whenever the ranks talk over RCCL."""
+    d = _dist()
+    if d is None:
+        return False
+    if config.native_comm is None:
+        return d.get_backend() == 'nccl'
+    return bool(config.native_comm)
+
+
 def split_ownership(size, world, rank):
     """PetscSplitOwnership: size // world entries each, the first size % world ranks one more.
     Returns (start, local_size)."""
@@ -659,8 +679,8 @@ class ShellMat:
         self._msc = None          # (masks, mask_offsets, signs, coeffs, left subspace dict, right subspace dict): selfcheck
         self._check_pending = False
         # the partitioned multiply as one native call (dnm_mat_mult_partitioned: exchange on the library's own RCCL
-        # communicator and stream) instead of the schedules below over torch.distributed -- config.native_comm, RCCL
-        # transport only; the transposed exchange too (set_native_transposed)
+        # communicator and stream) instead of the schedules below over torch.distributed -- the default on RCCL
+        # transports (native_transport()); the transposed exchange too (set_native_transposed)
         self._native = None
         self._native_tr = False   # transposed exchange split and scheduled inside the library (set_native_transposed)
 
@@ -758,7 +778,7 @@ class ShellMat:
                     raise ExchangeCheckError('transposed exchange: sampled rows of the first multiply are off by %.3e '
                                              '(scale %.3e); build the operator with exchange="partner"' % (err, scale))
             return
-        if self._native is None and self.nranks > 1 and config.native_comm and self._native_applies(x):
+        if self._native is None and self.nranks > 1 and self._native_applies(x):
             self._native = native_comm()
         if self._native is not None and self.nranks > 1:
             _lib.check(L.dnm_mat_mult_partitioned(self.handle, self._native, x.ptr, y.ptr, _stream()))
@@ -816,8 +836,7 @@ class ShellMat:
     def _native_applies(self, x):
         """The native schedule moves device memory over RCCL: not for the gloo-staged transport of the CPU / one-GPU
         tests, nor for window partitions whose right vectors are swizzled (their window is assembled in index order)."""
-        d = _dist()
-        if d is None or d.get_backend() != 'nccl' or not x.array.is_cuda:
+        if not native_transport() or not x.array.is_cuda:
             return False
         return bool(self.partners) or x.internal or not x.swz
 
@@ -975,7 +994,7 @@ class ShellMat:
 
     def set_native_transposed(self):
         """The transposed exchange with the split and the schedule inside the library (dnm_mat_set_exchange +
-        dnm_mat_mult_partitioned): for RCCL transports under config.native_comm.  Returns whether the operator splits."""
+        dnm_mat_mult_partitioned): the default on RCCL transports (config.native_comm).  Returns whether the operator splits."""
         chosen = C.c_int()
         _lib.check(_lib.lib().dnm_mat_set_exchange(self.handle, _lib.EXCHANGE_TRANSPOSE, C.byref(chosen)))
         self._native_tr = chosen.value == _lib.EXCHANGE_TRANSPOSE
@@ -1145,13 +1164,66 @@ class ShellMat:
 
     TR_SUB = 4     # parts a piece of the returning all-to-all travels in (_mult_transposed)
 
-    def exchange_only(self, x):
+    def _native_in_use(self, x):
+        """Whether ``mult`` runs this operator through dnm_mat_mult_partitioned (binds the communicator on first use)."""
+        if self.nranks == 1:
+            return False
+        if self._native is None and (self._native_tr or (self._tr is None and self._native_applies(x))):
+            self._native = native_comm()
+        return self._native is not None and (self._native_tr or self._tr is None)
+
+    def _native_phase(self, x, y, phase):
+        L = _lib.lib()
+        _lib.check(L.dnm_comm_set_phase(self._native, phase))
+        try:
+            _lib.check(L.dnm_mat_mult_partitioned(self.handle, self._native, x.ptr, y.ptr, _stream()))
+        finally:
+            _lib.check(L.dnm_comm_set_phase(self._native, _lib.PHASE_ALL))
+
+    def compute_only(self, x, y):
+        """The kernels of ONE multiply with nothing on the links (receive buffers / the window / the redistributed state
+        hold whatever the last multiply left there): the rank's compute time, for bench.py's split of a partitioned
+        multiply into exchange, compute and what the schedule hides.  ``y`` does not hold A x afterwards."""
+        L = _lib.lib()
+        if self.nranks == 1:
+            _lib.check(L.dnm_mat_mult(self.handle, x.ptr, y.ptr, _stream()))
+            return
+        if self._native_in_use(x):
+            return self._native_phase(x, y, _lib.PHASE_COMPUTE)
+        vp = lambda t: C.c_void_p(t.data_ptr())
+        if self._tr is not None:
+            lo, hi, pieces, own, cnt = self._tr
+            xb, wb = self._transpose_buffers(x.array)
+            _lib.check(L.dnm_mat_mult_local(lo, x.ptr, y.ptr, _stream()))
+            _lib.check(L.dnm_mat_mult_local(hi, vp(xb), vp(wb), _stream()))
+            _lib.check(L.dnm_vec_axpby(y.ptr, vp(wb), self.n_local, 1.0, 0.0, 1.0, 0.0, _stream()))
+        elif not self.partners and self._is_windowed():
+            self._setup_windows()
+            self.prepare_exchange(x.array)
+            w0, wb = self._windows[self.rank][0], self._window_buf
+            if self._window_splits():
+                _lib.check(L.dnm_mat_mult_window_local(self.handle, x.ptr, y.ptr, _stream()))
+                _lib.check(L.dnm_mat_mult_window_remote(self.handle, vp(wb), w0, wb.numel(), y.ptr, _stream()))
+            else:
+                _lib.check(L.dnm_mat_mult_window(self.handle, vp(wb), w0, wb.numel(), y.ptr, _stream()))
+        else:
+            self.prepare_exchange(x.array)
+            _lib.check(L.dnm_mat_mult_local(self.handle, x.ptr, y.ptr, _stream()))
+            for i in range(len(self.recvs)):
+                _lib.check(L.dnm_mat_mult_remote(self.handle, i, vp(self._recv[i]), y.ptr, _stream()))
+
+    def exchange_only(self, x, y=None):
         """Post and complete the rank exchange of ONE multiply without running any kernel: the same messages over
         the same transport, for measuring what the links sustain (bench.py's ``xgmi_link_GBs_measured``).
-        Collective: every rank calls it."""
+        Collective: every rank calls it.  Under the native schedule (``y``: any result vector; it is left alone) the
+        library posts the very groups of its multiply (dnm_comm_set_phase)."""
         if self.nranks == 1:
             return
         import torch
+        if y is not None and self._native_in_use(x):
+            self._native_phase(x, y, _lib.PHASE_EXCHANGE)
+            torch.cuda.synchronize()
+            return
         if self._tr is not None or self._native_tr:
             _, _, pieces, own, cnt = self._transposed_parts()
             xb, wb = self._transpose_buffers(x.array)
@@ -1335,7 +1407,9 @@ class ShellMat:
     def destroy(self):
         if self._h is not None:
             if self._native is not None:
-                _lib.check(_lib.lib().dnm_comm_forget(self._native, self._h))
+                # (a communicator released before its operators -- release_native_comm -- has nothing left to forget)
+                if _NATIVE_COMM is not None and self._native.value == _NATIVE_COMM.value:
+                    _lib.check(_lib.lib().dnm_comm_forget(self._native, self._h))
                 self._native = None
             _lib.check(_lib.lib().dnm_mat_destroy(self._h))
             self._h = None
@@ -1416,9 +1490,7 @@ def build_mat(masks, mask_offsets, signs, coeffs, left_subspace, right_subspace,
         shift = int(lc.type)                   # Full: index = configuration; Parity: index = configuration >> 1
         split = transpose_split(masks, mask_offsets, signs, coeffs, int(lc.L) - shift, config.world_size,
                                 int(lc.vec_swizzle), shift, packed=mat.real_packed)
-        d = _dist()
-        if split is not None and config.native_comm and d is not None and d.get_backend() == 'nccl' and \
-                mat.set_native_transposed():
+        if split is not None and native_transport() and mat.set_native_transposed():
             mat._check_pending = knob('DNM_EXCHANGE_SELFCHECK', '1') != '0'
         elif split is not None:
             mat.set_transposed(split, lc, rc, flags)

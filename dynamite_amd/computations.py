@@ -29,9 +29,9 @@ def _hooks(mat, keep):
     if d is None:
         return None
     import torch
-    from .backend import Vec, RawVec, native_comm
-    if config.native_comm and d.get_backend() == 'nccl' and mat._tr is None and (mat.partners or mat.swz_right >= 256
-                                                                                or mat.swz_right == 0):
+    from .backend import Vec, RawVec, native_comm, native_transport
+    if native_transport() and mat._tr is None and (mat._native_tr or mat.partners or mat.swz_right >= 256
+                                                   or mat.swz_right == 0):
         # the library's own communicator: multiply and reductions of every solver step stay native (dnm_comm_hooks)
         mat._native = native_comm()
         h = _lib.Hooks()

@@ -51,9 +51,16 @@ class _Config:
         # XParity on top of a SpinConserve subspace in the internal layout: its vectors are the layout's first half
         # (one rank); DNM_SC_XPARITY_LAYOUT=0 keeps them in reference order (the row kernels)
         self.sc_xparity_layout = knob('DNM_SC_XPARITY_LAYOUT', '1') != '0'
-        # partitioned multiplies through the library's own RCCL communicator and exchange stream
-        # (dnm_mat_mult_partitioned) instead of the host schedules over torch.distributed; RCCL transport only
-        self.native_comm = knob('DNM_NATIVE_COMM', '0') == '1'
+        # partitioned multiplies as ONE native call (dnm_mat_mult_partitioned, csrc/comm.cpp: the library's own RCCL
+        # communicator and exchange stream; the reference posts its scatters inside C as well,
+        # bpetsc_template_2.c:413-504) instead of the host schedules over torch.distributed.
+        # None (the default): whenever the process group's transport is RCCL (backend "nccl") -- the host schedules
+        # remain for gloo-staged ranks (CPU tests, several ranks on one GPU); True: always (tests: a stand-in transport
+        # named by DNM_RCCL_LIB under a gloo process group); False: never.  DNM_NATIVE_COMM=0 / 1 sets it from outside --
+        # a production switch, not an experiment knob: the way back to the host schedules should the native one
+        # misbehave on a machine nobody has tested it on.
+        v = os.environ.get('DNM_NATIVE_COMM', '')
+        self.native_comm = None if v == '' else v == '1'
         # eigsolve of a real-symmetric operator (every matrix element real in the product basis): real arithmetic on
         # vectors stored two amplitudes to a complex128 element (Full / Parity, on a power-of-two number of ranks) or one
         # double per position of the internal layout (SpinConserve, any rank count) -- DNM_MAT_REAL_PACKED, half the

@@ -151,6 +151,9 @@ struct dnm_comm {
   std::map<dnm_mat *, WindowState> win;
   std::map<dnm_mat *, PartnerState> par;
   std::map<dnm_mat *, TransposeState> tr;
+  int phase = DNM_PHASE_ALL;                     // dnm_comm_set_phase: the whole multiply, its messages alone, its kernels alone
+  bool msgs() const { return phase != DNM_PHASE_COMPUTE; }
+  bool kernels() const { return phase != DNM_PHASE_EXCHANGE; }
   int me() const { return vrank >= 0 ? vrank : rank; }
   int world() const { return vrank >= 0 ? vranks : nranks; }
 };
@@ -296,8 +299,8 @@ int mult_window(dnm_comm *c, dnm_mat *A, const void *x, void *y, hipStream_t st)
   // the exchange: x is ready when the compute stream gets here
   DNM_HIP(hipEventRecord(c->ev_ready, st));
   DNM_HIP(hipStreamWaitEvent(c->xs, c->ev_ready, 0));
-  DNM_NCCL(ncclGroupStart());
-  for (int q = 0; q < P; ++q) {
+  if (c->msgs()) DNM_NCCL(ncclGroupStart());
+  for (int q = 0; q < P && c->msgs(); ++q) {
     if (q == me) continue;
     const int64_t q0 = W.own0[(size_t)q], qn = W.ownn[(size_t)q];
     for (const Range &r : W.needs[(size_t)me]) {           // what this rank reads of q's block
@@ -309,8 +312,12 @@ int mult_window(dnm_comm *c, dnm_mat *A, const void *x, void *y, hipStream_t st)
       if (lo < hi) DNM_TRY(post_send(c, q, x, lo - my0, hi - lo));
     }
   }
-  DNM_NCCL(ncclGroupEnd());
+  if (c->msgs()) DNM_NCCL(ncclGroupEnd());
   DNM_HIP(hipEventRecord(c->ev_done, c->xs));
+  if (!c->kernels()) {                           // the messages alone (dnm_comm_set_phase): the caller's stream sees them done
+    DNM_HIP(hipStreamWaitEvent(st, c->ev_done, 0));
+    return 0;
+  }
   // the rank's own part of its window
   const int64_t a = std::max(wlo, my0), b = std::min(whi, my0 + myn);
   if (a < b) DNM_TRY(dnm_vec_copy((const char *)x + (a - my0) * 16, (char *)W.window.p + (a - wlo) * 16, b - a, st));
@@ -353,15 +360,17 @@ int mult_partner(dnm_comm *c, dnm_mat *A, const void *x, void *y, hipStream_t st
   if (Q.recvs.empty() && Q.sends.empty()) return dnm_mat_mult(A, x, y, st);
   DNM_HIP(hipEventRecord(c->ev_ready, st));
   DNM_HIP(hipStreamWaitEvent(c->xs, c->ev_ready, 0));
-  DNM_NCCL(ncclGroupStart());
-  for (const dnm_xfer &s : Q.sends) DNM_TRY(post_send(c, s.partner, x, s.offset, s.count));
-  for (size_t i = 0; i < Q.recvs.size(); ++i)
-    DNM_TRY(post_recv(c, Q.recvs[i].partner, Q.recvs[i].offset, Q.recvs[i].count, Q.bufs[i]->p));
-  DNM_NCCL(ncclGroupEnd());
+  if (c->msgs()) {
+    DNM_NCCL(ncclGroupStart());
+    for (const dnm_xfer &s : Q.sends) DNM_TRY(post_send(c, s.partner, x, s.offset, s.count));
+    for (size_t i = 0; i < Q.recvs.size(); ++i)
+      DNM_TRY(post_recv(c, Q.recvs[i].partner, Q.recvs[i].offset, Q.recvs[i].count, Q.bufs[i]->p));
+    DNM_NCCL(ncclGroupEnd());
+  }
   DNM_HIP(hipEventRecord(c->ev_done, c->xs));
-  DNM_TRY(dnm_mat_mult_local(A, x, y, st));                           // under the exchange
+  if (c->kernels()) DNM_TRY(dnm_mat_mult_local(A, x, y, st));         // under the exchange
   DNM_HIP(hipStreamWaitEvent(st, c->ev_done, 0));
-  for (size_t i = 0; i < Q.recvs.size(); ++i) DNM_TRY(dnm_mat_mult_remote(A, (int32_t)i, Q.bufs[i]->p, y, st));
+  for (size_t i = 0; i < Q.recvs.size() && c->kernels(); ++i) DNM_TRY(dnm_mat_mult_remote(A, (int32_t)i, Q.bufs[i]->p, y, st));
   return 0;
 }
 
@@ -402,6 +411,7 @@ int mult_transposed(dnm_comm *c, dnm_mat *A, const void *x, void *y, hipStream_t
   const int P = c->world(), me = c->me();
   const int64_t cnt = T.cnt, part = T.part;
   const int sub = T.sub;
+  const bool ker = c->kernels();                 // (dnm_comm_set_phase: the messages alone skip every kernel)
   auto off = [&](int b, int q) { return ((int64_t)b * P + q) << T.f; };
   auto at = [](const void *v, int64_t o) { return (void *)((const char *)v + o * 16); };
   // loop-back with the peers' handles: what comes back is what THEY computed -- run their second parts on the state
@@ -411,7 +421,7 @@ int mult_transposed(dnm_comm *c, dnm_mat *A, const void *x, void *y, hipStream_t
   if (c->vrank >= 0) {
     bool have = true;
     for (int q = 0; q < P; ++q) have = have && (q == me || (c->peer_mat[(size_t)q] && c->peer_mat[(size_t)q]->tr_hi && c->peer_x[(size_t)q]));
-    if (have) {
+    if (have && ker) {
       if (T.peer_wb.size() != (size_t)P) {
         T.peer_wb.clear();
         for (int q = 0; q < P; ++q) {
@@ -435,6 +445,7 @@ int mult_transposed(dnm_comm *c, dnm_mat *A, const void *x, void *y, hipStream_t
   // one group of the all-to-all: elements [o, o + len) of the pieces with index b in [b0, b1) -- `src` goes out,
   // the peers' land in `dst` at the same offsets (the map between the layouts is its own inverse)
   auto post = [&](const void *src, void *dst, int b0, int b1, int64_t o, int64_t len, bool returning) -> int {
+    if (!c->msgs()) return 0;
     DNM_NCCL(ncclGroupStart());
     for (int q = 0; q < P; ++q) {
       if (q == me) continue;
@@ -446,7 +457,7 @@ int mult_transposed(dnm_comm *c, dnm_mat *A, const void *x, void *y, hipStream_t
     DNM_NCCL(ncclGroupEnd());
     return 0;
   };
-  auto add = [&](const void *src, int64_t o, int64_t len) { return dnm_vec_axpby(at(y, o), at(src, o), len, 1.0, 0.0, 1.0, 0.0, st); };
+  auto add = [&](const void *src, int64_t o, int64_t len) { return ker ? dnm_vec_axpby(at(y, o), at(src, o), len, 1.0, 0.0, 1.0, 0.0, st) : 0; };
   size_t nev = 0;
   hipEvent_t e;
   // x is ready when the compute stream gets here
@@ -460,11 +471,11 @@ int mult_transposed(dnm_comm *c, dnm_mat *A, const void *x, void *y, hipStream_t
       DNM_TRY(T.event(nev++, &fwd[(size_t)s]));
       DNM_HIP(hipEventRecord(fwd[(size_t)s], c->xs));
     }
-    for (int b = 0; b < T.nb; ++b) DNM_TRY(dnm_vec_copy(at(x, off(b, me)), at(T.xb.p, off(b, me)), cnt, st));
-    DNM_TRY(dnm_mat_mult_local(A->tr_lo, x, y, st));                    // under the all-to-all
+    for (int b = 0; b < T.nb && ker; ++b) DNM_TRY(dnm_vec_copy(at(x, off(b, me)), at(T.xb.p, off(b, me)), cnt, st));
+    if (ker) DNM_TRY(dnm_mat_mult_local(A->tr_lo, x, y, st));           // under the all-to-all
     for (int s = 0; s < sub; ++s) {
       DNM_HIP(hipStreamWaitEvent(st, fwd[(size_t)s], 0));
-      DNM_TRY(dnm_mat_mult_local_part(A->tr_hi, T.xb.p, T.wb.p, s, sub, st));
+      if (ker) DNM_TRY(dnm_mat_mult_local_part(A->tr_hi, T.xb.p, T.wb.p, s, sub, st));
       // part s of xb has been consumed: it takes the returning part s
       DNM_TRY(T.event(nev++, &e));
       DNM_HIP(hipEventRecord(e, st));
@@ -484,10 +495,10 @@ int mult_transposed(dnm_comm *c, dnm_mat *A, const void *x, void *y, hipStream_t
   DNM_TRY(post(x, T.xb.p, 0, T.nb, 0, cnt, false));
   DNM_TRY(T.event(nev++, &e));
   DNM_HIP(hipEventRecord(e, c->xs));
-  for (int b = 0; b < T.nb; ++b) DNM_TRY(dnm_vec_copy(at(x, off(b, me)), at(T.xb.p, off(b, me)), cnt, st));
-  DNM_TRY(dnm_mat_mult_local(A->tr_lo, x, y, st));                      // under the all-to-all
+  for (int b = 0; b < T.nb && ker; ++b) DNM_TRY(dnm_vec_copy(at(x, off(b, me)), at(T.xb.p, off(b, me)), cnt, st));
+  if (ker) DNM_TRY(dnm_mat_mult_local(A->tr_lo, x, y, st));             // under the all-to-all
   DNM_HIP(hipStreamWaitEvent(st, e, 0));
-  DNM_TRY(dnm_mat_mult_local(A->tr_hi, T.xb.p, T.wb.p, st));
+  if (ker) DNM_TRY(dnm_mat_mult_local(A->tr_hi, T.xb.p, T.wb.p, st));
   // the way back (xb is free again) in nb * sub batches -- every piece travels as `sub` contiguous parts, part by part
   // over all peers: what a batch brought is added to y while the next ones are on the links
   DNM_TRY(T.event(nev++, &e));
@@ -616,6 +627,12 @@ int dnm_mat_mult_partitioned(dnm_mat *A, dnm_comm *c, const void *x, void *y, vo
   DNM_CHECK(A->use_sc3 || A->right.host.swz == 0,
             "window partitions assemble their window in index order: swizzled right vectors go through the host schedule");
   return mult_window(c, A, x, y, st);
+}
+
+int dnm_comm_set_phase(dnm_comm *c, int phase) {
+  DNM_CHECK(c && (phase == DNM_PHASE_ALL || phase == DNM_PHASE_EXCHANGE || phase == DNM_PHASE_COMPUTE), "bad argument");
+  c->phase = phase;
+  return 0;
 }
 
 int dnm_comm_prepare(dnm_comm *c, dnm_mat *A, void *stream) {

@@ -500,6 +500,13 @@ int dnm_comm_prepare(dnm_comm *c, dnm_mat *A, void *stream);
 int dnm_comm_forget(dnm_comm *c, dnm_mat *A);
 int dnm_comm_loopback(dnm_comm *c, int vrank, int vranks, const void *const *peer_x, dnm_mat *const *peer_mat);
 int dnm_comm_allreduce(dnm_comm *c, double *vals, int n, int op);
+/* Measurement: which half of the schedule the following dnm_mat_mult_partitioned calls run -- the whole multiply
+ * (default), its messages alone (what the links sustain: nothing is computed, y is left alone), or its kernels alone (the
+ * rank's compute with nothing on the links: results are not those of the multiply).  The three times together say how
+ * much of the exchange the schedule hides (bench.py --gpus N).  The reference has no counterpart: its -log_view splits
+ * VecScatterBegin/End from MatMult the same way. */
+enum { DNM_PHASE_ALL = 0, DNM_PHASE_EXCHANGE = 1, DNM_PHASE_COMPUTE = 2 };
+int dnm_comm_set_phase(dnm_comm *c, int phase);
 int dnm_mat_mult_partitioned(dnm_mat *A, dnm_comm *c, const void *x, void *y, void *stream);
 enum { DNM_EXCHANGE_AUTO = 0, DNM_EXCHANGE_PARTNER = 1, DNM_EXCHANGE_TRANSPOSE = 2 };
 int dnm_mat_set_exchange(dnm_mat *A, int scheme, int *chosen);

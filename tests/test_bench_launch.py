@@ -29,6 +29,20 @@ def test_bench_spawns_its_ranks(n):
     out = json.loads(lines[0])
     assert out["n_gpus"] == n and out["dry_run"] is True and out["exchange_ok"] is True
     assert out["value"] is None and out["scaling"] == "weak"
+    # every key of the N > 1 line is there (what cannot run without a GPU says so): both schedules of the exchange, each
+    # split three ways, the probe's verdict, config 5
+    mg = out["multi_gpu"]
+    assert set(mg) == {"default_schedule", "first_contact_probe", "xgmi_link_GBs_assumed", "schedules"}
+    assert set(mg["schedules"]) == {"host", "native"} and mg["schedules"]["native"].startswith("not run")
+    host = mg["schedules"]["host"]
+    assert set(host) == {"schedule", "ms_per_step", "exchange_only_ms", "compute_only_ms", "hidden_ms",
+                         "hidden_frac_of_the_shorter", "busiest_link_bytes", "link_GBs_measured", "selfcheck"}
+    assert host["exchange_only_ms"] > 0 and host["link_GBs_measured"] > 0 and host["compute_only_ms"] is None
+    c5 = out["secondary"]["config5"]
+    assert c5["exchange"] == "window" and c5["exchange_ok"] is True and c5["dim"] == 48620
+    assert 0 < c5["bytes_received_per_multiply_busiest_rank"] < 16 * c5["dim"]
+    assert {"heisenberg", "known_answer_xx_chain"} <= set(c5) and out["secondary_ok"] is True
+    assert out["config"]["schedule"].startswith("host") and "exchange_selfcheck" in out["config"]
     cfg = out["config"]
     nloc = (1 << 16) // n
     if n < 4:
@@ -140,3 +154,27 @@ def test_bench_watchdog_ends_a_hung_run():
     assert time.time() - t0 < 120
     assert "[bench watchdog] rank" in p.stderr and "no progress in phase" in p.stderr and "plan:" in p.stderr
     assert "ending the other ranks" in p.stderr
+
+
+def test_line_keys_are_the_same_with_and_without_a_gpu():
+    """The keys the GPU run's `multi_gpu` entries and config 5 carry are those of the dry run (bench.schedule_entry is the
+    one constructor of both); config 5's sizes by rank count keep about 1.1 G rows per GPU, 8 ranks = BASELINE configs[4]."""
+    import math
+    sys.path.insert(0, ROOT)
+    import bench
+    e = bench.schedule_entry("native", 10.0, 8.0, 6.0, {"busiest_link_bytes": 1 << 30}, "ok")
+    assert e["hidden_ms"] == 4.0 and abs(e["hidden_frac_of_the_shorter"] - 4.0 / 6.0) < 1e-12
+    assert abs(e["link_GBs_measured"] - (1 << 30) / 8e-3 / 1e9) < 1e-9
+    assert bench.CONFIG5_BY_WORLD[8] == (36, 18)
+    rows = {w: math.comb(*lk) / w for w, lk in bench.CONFIG5_BY_WORLD.items()}
+    assert all(1.1e9 < r < 1.2e9 for r in rows.values()), rows
+
+
+def test_probe_child_environment():
+    """The probe's children make their own rendezvous: another port, no torch-elastic agent store, the schedule forced."""
+    sys.path.insert(0, ROOT)
+    import bench
+    import inspect
+    src = inspect.getsource(bench.first_contact_probe)
+    assert "TORCHELASTIC_" in src and "PROBE_PORT_OFFSET" in src and 'env["DNM_NATIVE_COMM"]' in src
+    assert "p.kill()" in src and "pkill" not in src          # the exact child, never a pattern

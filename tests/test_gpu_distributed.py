@@ -94,6 +94,7 @@ def _worker(rank, world, port, case, out_dir):
         e0 = Hx.eigsolve(nev=1, tol=1e-10, subspace=sub)[0]
         exact = np.sort(np.cos(np.pi * np.arange(1, L + 1) / (L + 1)))[:L // 2].sum()
         assert abs(e0 - exact) < 1e-8 * abs(exact), (e0, exact)
+        _native_ran(H, case)
         dist.barrier()
         faulthandler.cancel_dump_traceback_later()
         if rank == 0:
@@ -142,6 +143,7 @@ def _worker(rank, world, port, case, out_dir):
                 assert np.max(np.abs(np.array(er[:2]) - low)) < 1e-8, "partitioned XParity eigsolve, real arithmetic"
                 vg = vr[0].to_numpy(to_all=True)
                 assert np.abs(vg.imag).max() == 0.0 and np.linalg.norm(Hs @ vg - er[0] * vg) < 1e-7
+            _native_ran(H, case)
             H.destroy_mat()
         dist.barrier()
         faulthandler.cancel_dump_traceback_later()
@@ -186,6 +188,7 @@ def _worker(rank, world, port, case, out_dir):
             ev = H.eigsolve(nev=1, tol=1e-10, subspace=left)
             low = spla2.eigsh(Hs, k=1, which='SA', tol=1e-12, return_eigenvectors=False)
             assert abs(ev[0] - low[0]) < 1e-8, "eigsolve on a window partition"
+        _native_ran(H, case)
         dist.barrier()
         faulthandler.cancel_dump_traceback_later()
         if rank == 0:
@@ -233,7 +236,7 @@ def _worker(rank, world, port, case, out_dir):
         assert H.get_mat().exchange_summary()["scheme"] == want_scheme
         if want_scheme == "transpose" and case in ("full", "parity"):
             # ... and runs sub-piece by sub-piece (forward parts, ranges of the layout-B pass, returns)
-            assert H.get_mat()._tr_pipe, "the transposed exchange should pipeline at this size"
+            assert H.get_mat()._tr_pipe or H.get_mat()._native_tr, "the transposed exchange should pipeline at this size"
     y = H.dot(x)
     yg = y.to_numpy(to_all=True)
     ref = orc.matvec(orc_msc(H), orc_sub(sub), orc_sub(sub), xg, nthreads=2)
@@ -262,6 +265,7 @@ def _worker(rank, world, port, case, out_dir):
     v0 = evecs[0].to_numpy(to_all=True)
     assert np.linalg.norm(Hs @ v0 - evals[0] * v0) < 1e-7
     if light:
+        _native_ran(H, case)
         dist.barrier()
         faulthandler.cancel_dump_traceback_later()
         if rank == 0:
@@ -326,11 +330,67 @@ def _worker(rank, world, port, case, out_dir):
     z2 = State.from_file(fn)
     assert np.array_equal(z2.to_numpy(to_all=True), zg)
 
+    _native_ran(H, case)
     dist.barrier()
     faulthandler.cancel_dump_traceback_later()
     if rank == 0:
         open(os.path.join(out_dir, "ok_%s_%d" % (case, world)), "w").write("ok")
     dist.destroy_process_group()
+
+
+def _native_ran(H, case):
+    """Under DNM_NATIVE_COMM=1 (test_native_schedule_between_rank_processes) every multiply and solver step of the
+    cases the native schedule covers must have gone through dnm_mat_mult_partitioned -- a silent fall-back to the host
+    schedules would make that test a copy of the one above."""
+    if os.environ.get("DNM_NATIVE_COMM") != "1":
+        return
+    mats = list(H._mats.values())
+    assert mats
+    if case not in ("projection", "full_odd", "parity_odd"):
+        # (window partitions of swizzled vectors stay on the host schedule: comm.cpp says why)
+        for m in mats:
+            assert m._native is not None, "the native schedule did not run (%s)" % case
+            assert m._tr is None, "the host's transposed schedule was built beside the native one (%s)" % case
+    # the operators go first, then the communicator (the stand-in transport removes its mailboxes with the last rank)
+    from dynamite_amd import backend
+    H.destroy_mat()
+    backend.release_native_comm()
+
+
+FAKE_RCCL = os.path.join(ROOT, "tests", "fake_rccl", "libfake_rccl.so")
+
+
+def build_fake_rccl():
+    """tests/fake_rccl/fake_rccl.cpp -> libfake_rccl.so (hipcc; also built by __graft_entry__.build())."""
+    import subprocess
+    src = os.path.join(ROOT, "tests", "fake_rccl", "fake_rccl.cpp")
+    if not os.path.exists(FAKE_RCCL) or os.path.getmtime(FAKE_RCCL) < os.path.getmtime(src):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-fPIC", "-shared", "-o", FAKE_RCCL, src])
+    return FAKE_RCCL
+
+
+@pytest.mark.parametrize("case,world", [("full", 2), ("full", 4), ("full", 8), ("full_partner", 4), ("full_transpose", 2),
+                                        ("parity", 4), ("sc", 3), ("sc3", 2), ("sc3", 3), ("sc3_graph", 2), ("sc_big", 3),
+                                        ("explicit", 3), ("auto", 2), ("full_odd", 3), ("xparity_full", 2),
+                                        ("xparity_sc", 3)])
+def test_native_schedule_between_rank_processes(tmp_path, monkeypatch, case, world):
+    """The NATIVE schedule (dnm_mat_mult_partitioned, dnm_comm_hooks -- the default on RCCL transports) between real rank
+    processes.  RCCL refuses two ranks on one device, so on this one-GPU box the library binds a stand-in for librccl
+    (tests/fake_rccl: mailboxes in /dev/shm, host-staged copies, message sizes CHECKED) through DNM_RCCL_LIB: every rank is
+    its own process with its own handle and message lists -- partner blocks, the pipelined transposed exchange, column
+    windows with their all-gather of needs, the all-reduces of the solver hooks -- and the checks are those of
+    test_partitioned_end_to_end_one_gpu: multiply against the oracle, evolve / eigsolve against scipy, real arithmetic,
+    reduced density matrices.  What this cannot show (asynchronous RCCL kernels against the compute stream) is what the
+    loop-back tests with the real RCCL show (test_native_partitioned_multiply).  Replaces bpetsc_template_2.c:413-504,
+    787-879 / bcuda_template_2.cu:161-171."""
+    import torch.multiprocessing as mp
+    monkeypatch.setenv("DNM_RCCL_LIB", build_fake_rccl())
+    monkeypatch.setenv("DNM_NATIVE_COMM", "1")
+    monkeypatch.setenv("DNM_FAKE_RCCL_TIMEOUT_S", "300")
+    mp.spawn(_worker, args=(world, _free_port(), case, str(tmp_path)), nprocs=world, join=True)
+    assert os.path.exists(os.path.join(str(tmp_path), "ok_%s_%d" % (case, world)))
+    left = [d for d in os.listdir("/dev/shm") if d.startswith("dnmfake_")]
+    assert not left, "mailboxes left behind: %r" % left
 
 
 @pytest.mark.parametrize("case,world", [("full", 2), ("full", 4), ("full", 8), ("full_partner", 4), ("full_transpose", 2),
@@ -345,31 +405,107 @@ def test_partitioned_end_to_end_one_gpu(tmp_path, case, world):
     assert os.path.exists(os.path.join(str(tmp_path), "ok_%s_%d" % (case, world)))
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_bench_multi_rank_flow_one_gpu(world):
-    """bench.py exactly as the driver launches it for N > 1 (torch.distributed.run, one rank per 'GPU'), with the
-    ranks sharing this GPU over gloo (DNM_BENCH_BACKEND): the exchange plan, barriers, max-over-ranks timing and
-    the JSON line -- a plumbing check of the multi-rank flow, not a measurement."""
+def _bench_ranks(world, extra_env, argv=(), L=22, timeout=900):
+    """bench.py exactly as the driver launches it for N > 1 (torch.distributed.run, one rank per 'GPU'), with the ranks
+    sharing this GPU over gloo (DNM_BENCH_BACKEND)"""
     import json
     import subprocess
-    env = dict(os.environ, DNM_BENCH_BACKEND="gloo")
+    env = dict(os.environ, DNM_BENCH_BACKEND="gloo", **extra_env)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
-           "--gpus", str(world), "--steps", "2", "--warmup", "1", "--L", "22"]
-    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stderr[-2000:]
+           "--gpus", str(world), "--steps", "2", "--warmup", "1", "--L", str(L), "--config5", "18,9"] + list(argv)
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
+    assert out.returncode == 0, out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout
-    d = json.loads(lines[0])
+    return json.loads(lines[0]), out.stderr
+
+
+def _check_schedule_entry(e, world):
+    assert e["ms_per_step"] > 0 and e["exchange_only_ms"] > 0 and e["compute_only_ms"] > 0
+    assert e["busiest_link_bytes"] > 0 and e["link_GBs_measured"] > 0
+    assert abs(e["hidden_ms"] - (e["exchange_only_ms"] + e["compute_only_ms"] - e["ms_per_step"])) < 1e-9
+    assert e["selfcheck"].startswith("sampled rows"), e
+
+
+def _check_config5(sec):
+    c5 = sec["config5"]
+    assert c5["dim"] == 48620 and "SpinConserve(18,9)" in c5["workload"]
+    h, kx = c5["heisenberg"], c5["known_answer_xx_chain"]
+    assert h["exchange"] == "window" and h["matvecs"] > 10 and h["measured_rel_residual"] <= 1.01e-8
+    assert h["bytes_received_per_multiply_rank0"] > 0 and "failed_checks" not in h
+    assert kx["abs_error"] < 1e-6 and "failed_checks" not in kx
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_bench_multi_rank_flow_one_gpu(world):
+    """The N > 1 line on gloo-staged ranks (host schedule; RCCL refuses two ranks on one device): the exchange plan,
+    barriers, max-over-ranks timing, the multiply split into exchange / compute / hidden, the check of the first multiply
+    against the MSC definition, config 5's eigsolve at a toy size -- a plumbing check of the multi-rank flow, not a
+    measurement."""
+    d, _ = _bench_ranks(world, {})
     assert d["n_gpus"] == world and d["steps"] == 2 and d["warmup"] == 1 and d["unit"] == "Gamplitudes/s"
     assert d["value"] > 0 and d["scaling"] == "weak" and d["config"]["L"] == 22
     assert d["config"]["launches_per_step"] >= 3          # rank-local passes plus partner / transposed-layout passes
     assert d["config"]["exchange"] == ("transpose" if world >= 4 else "partner")
     assert d["config"]["xgmi_busiest_link_bytes"] > 0
     assert "cpu_baseline" not in d and d["roofline"]["bound"] == "hbm"
-    # the link rate measured in the run sits next to the assumed one; the transposed exchange validated itself
+    # the link rate measured in the run sits next to the assumed one; the first multiply was checked
     assert d["config"]["xgmi_link_GBs_measured"] > 0 and d["config"]["xgmi_exchange_only_ms"] > 0
-    assert d["config"]["exchange_selfcheck"].startswith("sampled rows" if world >= 4 else "not needed")
+    assert d["config"]["exchange_selfcheck"].startswith("sampled rows")
+    assert d["config"]["schedule"].startswith("host")
+    mg = d["multi_gpu"]
+    assert mg["default_schedule"] == "host" and mg["first_contact_probe"] is None
+    _check_schedule_entry(mg["schedules"]["host"], world)
+    assert mg["schedules"]["native"].startswith("not run")
+    _check_config5(d["secondary"])
+    assert d["secondary_ok"] is True
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_bench_multi_rank_flow_native_schedule(world):
+    """The same launch with the native schedule as the default (what an RCCL transport gives; here the stand-in
+    transport of tests/fake_rccl under DNM_NATIVE_COMM=1): the line times BOTH schedules, each split three ways, and
+    config 5's eigsolve runs through the native hooks."""
+    d, _ = _bench_ranks(world, {"DNM_NATIVE_COMM": "1", "DNM_RCCL_LIB": build_fake_rccl()})
+    assert d["value"] > 0 and d["config"]["schedule"].startswith("native")
+    assert d["config"]["exchange"] == ("transpose" if world >= 4 else "partner")
+    mg = d["multi_gpu"]
+    assert mg["default_schedule"] == "native" and mg["first_contact_probe"] is None      # (a decision already taken: no probe)
+    _check_schedule_entry(mg["schedules"]["native"], world)
+    _check_schedule_entry(mg["schedules"]["host"], world)
+    assert mg["schedules"]["native"]["busiest_link_bytes"] == mg["schedules"]["host"]["busiest_link_bytes"]
+    _check_config5(d["secondary"])
+    assert d["secondary_ok"] is True
+
+
+def test_bench_first_contact_probe():
+    """Before a rank touches its GPU a child process goes through the native schedule at a small size (here forced onto
+    the stand-in transport): passed -> the native schedule is the default of the run and the probe's report is in the
+    line."""
+    d, _ = _bench_ranks(2, {"DNM_BENCH_FORCE_PROBE": "1", "DNM_RCCL_LIB": build_fake_rccl()}, ["--probe-timeout", "400"])
+    pr = d["multi_gpu"]["first_contact_probe"]
+    assert pr["ok"] is True and pr["all_ranks_ok"] is True and pr["native"] is True, pr
+    assert pr["multiply_selfcheck"]["scheme"] == "partner" and pr["eigsolve_sc26_13"]["matvecs"] > 10
+    assert d["multi_gpu"]["default_schedule"] == "native" and d["config"]["schedule"].startswith("native")
+    _check_schedule_entry(d["multi_gpu"]["schedules"]["host"], 2)
+
+
+@pytest.mark.parametrize("how", ["fails", "hangs"])
+def test_bench_first_contact_probe_saves_the_run(how):
+    """A native schedule that does not come up (the stand-in transport refuses to initialise) or never returns (its first
+    exchange hangs): that costs the probe's child -- ended after --probe-timeout -- and the run measures the host
+    schedule and says why."""
+    env = {"DNM_BENCH_FORCE_PROBE": "1", "DNM_RCCL_LIB": build_fake_rccl(),
+           "DNM_FAKE_RCCL_FAIL" if how == "fails" else "DNM_FAKE_RCCL_HANG": "1"}
+    d, err = _bench_ranks(2, env, ["--probe-timeout", "240" if how == "fails" else "90"])
+    pr = d["multi_gpu"]["first_contact_probe"]
+    assert pr["ok"] is False and pr["all_ranks_ok"] is False and pr["error"], pr
+    assert ("no answer within" in pr["error"]) == (how == "hangs")
+    assert d["value"] > 0 and d["multi_gpu"]["default_schedule"] == "host"
+    assert d["multi_gpu"]["schedules"]["native"] == "not run: the first-contact probe failed"
+    _check_schedule_entry(d["multi_gpu"]["schedules"]["host"], 2)
+    assert "first-contact probe of the native schedule failed" in err
 
 
 def test_bench_falls_back_when_the_selfcheck_fails():
@@ -385,7 +521,7 @@ def test_bench_falls_back_when_the_selfcheck_fails():
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
     assert d["config"]["exchange"] == "partner" and d["config"]["exchange_selfcheck"].startswith("failed")
-    assert d["value"] > 0
+    assert d["value"] > 0 and d["multi_gpu"]["schedules"]["host"]["selfcheck"].startswith("failed")
 
 
 def _rccl_worker(rank, world, port, out_dir):
