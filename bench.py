@@ -400,6 +400,9 @@ def spawn_ranks(n, timeout_s):
                HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     if ndev < n:
         env["DNM_BENCH_BACKEND"] = "gloo"      # ranks share devices (or there is none): host-staged transport
+        # (processes sharing a device: fewer hardware queues each, or four of them oversubscribe its queue slots and
+        # every cross-stream wait costs a scheduler time slice -- tests/test_gpu_distributed.py::_worker)
+        env.setdefault("GPU_MAX_HW_QUEUES", "2")
     procs = []
     for r in range(n):
         e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
@@ -724,7 +727,7 @@ def first_contact_probe(args, world, rank, which="native"):
             except Exception as e:       # noqa: BLE001
                 res["error"] = "no report: %r" % (e,)
         elif rc is not None:
-            res["error"] = "exit code %d" % rc
+            res["error"] = "exit code %d" % rc + (" (the child's own watchdog: a phase made no progress)" if rc == 3 else "")
     except Exception as e:       # noqa: BLE001
         res["error"] = repr(e)
     finally:

@@ -24,6 +24,7 @@
 
 #include <dirent.h>
 #include <fcntl.h>
+#include <sched.h>
 #include <sys/stat.h>
 #include <sys/time.h>
 #include <unistd.h>
@@ -53,6 +54,9 @@ struct Comm {
   std::vector<uint64_t> sent, rcvd;        // messages so far per peer
   std::vector<char> host;
 };
+
+// DNM_FAKE_RCCL_STATS=1: where the time of this transport went, printed when the communicator is destroyed
+struct Stats { double sync = 0, copy = 0, put = 0, wait = 0; long groups = 0, msgs = 0, coll = 0; } g_stats;
 
 thread_local int g_depth = 0;
 thread_local std::vector<std::pair<Comm *, Op>> g_queue;
@@ -123,13 +127,13 @@ ncclResult_t get(Comm *c, int peer, void *host, size_t bytes) {
   const std::string path = msg_path(c, peer, c->rank, c->rcvd[(size_t)peer]++);
   const double t0 = now_s(), limit = timeout_s();
   int fd = -1;
-  useconds_t nap = 50;
   while ((fd = open(path.c_str(), O_RDONLY)) < 0) {
-    if (now_s() - t0 > limit)
+    const double waited = now_s() - t0;
+    if (waited > limit)
       return fail(ncclSystemError, "rank %d: message %llu from rank %d never arrived (a receive nobody sends to)", c->rank,
                   (unsigned long long)(c->rcvd[(size_t)peer] - 1), peer);
-    usleep(nap);
-    if (nap < 2000) nap *= 2;
+    if (waited < 2e-3) sched_yield();            // the peer is usually a few microseconds behind
+    else usleep(waited < 0.1 ? 100 : 1000);
   }
   struct stat st;
   fstat(fd, &st);
@@ -170,6 +174,8 @@ ncclResult_t run(std::vector<std::pair<Comm *, Op>> &queue) {
     for (;;) sleep(1000);
   }
   std::vector<hipStream_t> synced;
+  ++g_stats.groups;
+  double t0 = now_s();
   for (auto &e : q) {
     bool seen = false;
     for (hipStream_t s : synced) seen = seen || s == e.second.stream;
@@ -178,14 +184,20 @@ ncclResult_t run(std::vector<std::pair<Comm *, Op>> &queue) {
       synced.push_back(e.second.stream);
     }
   }
+  g_stats.sync += now_s() - t0;
   for (auto &e : q) {
     Comm *c = e.first;
     const Op &o = e.second;
     if (!o.send) continue;
+    ++g_stats.msgs;
     if (c->host.size() < o.bytes) c->host.resize(o.bytes);
+    t0 = now_s();
     if (o.bytes && copy(c->host.data(), o.src, o.bytes) != hipSuccess)
       return fail(ncclUnhandledCudaError, "copy of a send buffer to the host failed");
+    g_stats.copy += now_s() - t0;
+    t0 = now_s();
     ncclResult_t r = put(c, o.peer, c->host.data(), o.bytes);
+    g_stats.put += now_s() - t0;
     if (r != ncclSuccess) return r;
   }
   for (auto &e : q) {
@@ -193,10 +205,14 @@ ncclResult_t run(std::vector<std::pair<Comm *, Op>> &queue) {
     const Op &o = e.second;
     if (o.send) continue;
     if (c->host.size() < o.bytes) c->host.resize(o.bytes);
+    t0 = now_s();
     ncclResult_t r = get(c, o.peer, c->host.data(), o.bytes);
+    g_stats.wait += now_s() - t0;
     if (r != ncclSuccess) return r;
+    t0 = now_s();
     if (o.bytes && copy(o.dst, c->host.data(), o.bytes) != hipSuccess)
       return fail(ncclUnhandledCudaError, "copy of a received message to its buffer failed");
+    g_stats.copy += now_s() - t0;
   }
   return ncclSuccess;
 }
@@ -249,6 +265,10 @@ ncclResult_t ncclCommInitRank(ncclComm_t *out, int nranks, ncclUniqueId id, int 
 ncclResult_t ncclCommDestroy(ncclComm_t comm) {
   Comm *c = (Comm *)comm;
   if (!c) return ncclSuccess;
+  if (getenv("DNM_FAKE_RCCL_STATS"))
+    fprintf(stderr, "[fake_rccl] rank %d: %ld groups, %ld messages sent, %ld all-reduces; stream syncs %.2f s, copies %.2f s, "
+            "writing %.2f s, waiting for messages %.2f s\n", c->rank, g_stats.groups, g_stats.msgs, g_stats.coll, g_stats.sync,
+            g_stats.copy, g_stats.put, g_stats.wait);
   // what this rank never read (a failed test) goes with it; the directory with the last rank to leave
   if (DIR *d = opendir(c->dir.c_str())) {
     while (dirent *e = readdir(d)) {
@@ -294,8 +314,12 @@ ncclResult_t ncclAllGather(const void *send, void *recv, size_t count, ncclDataT
     if (p != c->rank) q.emplace_back(c, Op{false, nullptr, (char *)recv + (size_t)p * bytes, bytes, p, s});
   ncclResult_t r = run(q);
   if (r != ncclSuccess) return r;
-  if (bytes && copy((char *)recv + (size_t)c->rank * bytes, send, bytes) != hipSuccess)
+  // (device to device: hipMemcpy would return before the copy has run, and the caller's stream does not wait for the
+  // null stream -- on the collective's own stream, then)
+  if (bytes && !host_only() &&
+      (hipMemcpyAsync((char *)recv + (size_t)c->rank * bytes, send, bytes, hipMemcpyDeviceToDevice, s) != hipSuccess || sync(s) != hipSuccess))
     return fail(ncclUnhandledCudaError, "all-gather: copy of the rank's own part failed");
+  if (bytes && host_only()) memcpy((char *)recv + (size_t)c->rank * bytes, send, bytes);
   return ncclSuccess;
 }
 
@@ -305,6 +329,7 @@ ncclResult_t ncclAllReduce(const void *send, void *recv, size_t count, ncclDataT
   if (t != ncclDouble || (op != ncclSum && op != ncclMax)) return fail(ncclInvalidArgument, "all-reduce: doubles, sum or max");
   if (g_depth > 0) return fail(ncclInvalidUsage, "collectives inside a group are not part of this stand-in");
   const size_t bytes = count * 8;
+  ++g_stats.coll;
   if (sync(s) != hipSuccess) return fail(ncclUnhandledCudaError, "hipStreamSynchronize failed");
   std::vector<double> mine(count), other(count);
   if (bytes && copy(mine.data(), send, bytes) != hipSuccess)
