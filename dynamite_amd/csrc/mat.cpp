@@ -1724,7 +1724,7 @@ int dnm_mat_export_pass(const dnm_mat *A, int remote, int idx, void *desc_out, s
   if (quads_out) {
     DNM_CHECK(quad_bytes == sizeof(DevQuad), "DevQuad size mismatch (%zu vs %zu)", quad_bytes, sizeof(DevQuad));
     DNM_CHECK(max_quads >= *nquads, "record buffer too small");
-    memcpy(quads_out, p.h_quads.data(), p.h_quads.size() * sizeof(DevQuad));
+    if (!p.h_quads.empty()) memcpy(quads_out, p.h_quads.data(), p.h_quads.size() * sizeof(DevQuad));   // (an empty pass: no null source)
   }
   return 0;
 }

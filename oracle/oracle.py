@@ -22,7 +22,9 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libdnm_oracle.so")
+# DNM_LIB_VARIANT=san: the AddressSanitizer + UBSan build (tools/sanitize.sh; the process must LD_PRELOAD the runtime)
+_SAN = os.environ.get("DNM_LIB_VARIANT") == "san"
+_SO = os.path.join(_HERE, "libdnm_oracle_san.so" if _SAN else "libdnm_oracle.so")
 
 FULL, PARITY, EXPLICIT, SPIN_CONSERVE = 0, 1, 2, 3   # bsubspace_impl.h:17-23
 
@@ -48,7 +50,7 @@ def build(force=False):
     stale = (not os.path.exists(_SO)) or any(
         os.path.getmtime(s) > os.path.getmtime(_SO) for s in src)
     if force or stale:
-        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "libdnm_oracle.so"])
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", os.path.basename(_SO)])
     return _SO
 
 
