@@ -195,6 +195,35 @@ def secondary(wd, budget_s=22.0):
                                 "norm_error": abs(nrm - 1.0), "dim": 1 << L}
     if not abs(nrm - 1.0) < 1e-8:
         out["evolve_L26_xxz_t1"]["failed_checks"] = ["evolve did not preserve the norm: %r" % nrm]
+    # -- the multiply of the same configuration (BASELINE.json configs[1]: L=26 XXZ, one GPU) on its own
+    wd.phase("secondary: multiply L=26")
+    mat = H.get_mat(subspaces=(sub, sub))
+    xv, yv = psi.vec, res.vec
+    for _ in range(3):
+        mat.mult(xv, yv)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    nrep = 20
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(nrep):
+        mat.mult(xv, yv)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / nrep
+    gbs = ALG_BYTES_PER_AMP * (1 << L) / (ms * 1e-3) / 1e9
+    r = {"ms": ms, "Gamplitudes_per_s": (1 << L) / (ms * 1e-3) / 1e9, "launches": mat.launches_per_mult(),
+         "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS},
+         "traffic_bytes_per_amp": None, "traffic_source": None, "plan_signature": plan_signature(mat), "dim": 1 << L,
+         "baseline_config": "BASELINE.json configs[1]: L=26 XXZ chain, full space, 1 GPU"}
+    try:        # counter bytes of the same plan on the same kernel sources, if the committed profile run holds them
+        p = json.load(open(os.path.join(ROOT, "profiles", "latest_pmc.json"))).get("config2") or {}
+        if p.get("plan_signature") == r["plan_signature"] and p.get("kernel_source_hash") == kernel_source_hash():
+            r["traffic_bytes_per_amp"] = p["bytes_per_amplitude"]
+            r["traffic_source"] = "profiles/latest_pmc.json config2: rocprofv3 --pmc, separate run of `bench.py --L 26 --model xxz`"
+    except Exception:       # noqa: BLE001
+        pass
+    out["multiply_L26_xxz"] = r
+    del mat, xv, yv
     H.destroy_mat()
     del psi, res, H
 

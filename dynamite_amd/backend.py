@@ -449,6 +449,11 @@ class Vec:
         """Fill this rank's block from a device tensor in index order."""
         if self.internal:
             t = t.contiguous()
+            if t.numel() != self.rows:
+                # (on several ranks a reference-order block -- PetscSplitOwnership -- is not this rank's share of the
+                # layout -- whole blocks of equal top bits: the kernel would read past the end of the smaller one)
+                raise ValueError('set_local_natural: %d elements for a block of %d rows (vectors of different '
+                                 'partitions go through backend.redistribute)' % (t.numel(), self.rows))
             _lib.check(_lib.lib().dnm_vec_layout_copy(C.byref(self.sub_c), C.byref(self._part), self.ptr,
                                                       C.c_void_p(t.data_ptr()), 1, _stream()))
         else:
@@ -499,6 +504,8 @@ class Vec:
             return other
         if other.size != self.size or not (self.internal or other.internal):
             raise ValueError('vectors of different layouts (%r, %r)' % (self.layout, other.layout))
+        if other.start != self.start or other.rows != self.rows:
+            raise ValueError('vectors of different layouts (%r, %r) and partitions' % (self.layout, other.layout))
         tmp = Vec(self.size, swz=self.swz, sub_c=self.sub_c)
         tmp.set_local_natural(other.local_natural())
         return tmp
@@ -507,7 +514,8 @@ class Vec:
         if result is None:
             result = Vec(self.size, swz=self.swz, sub_c=self.sub_c)
         if result.layout != self.layout:
-            if not (self.internal and result.internal and result.size == self.size):
+            if not (self.internal and result.internal and result.size == self.size and result.start == self.start
+                    and result.rows == self.rows):
                 raise ValueError('vectors of different layouts')
             result.set_local_natural(self.local_natural())
             return result

@@ -333,10 +333,18 @@ def eigsolve(H, getvecs=False, nev=1, which='lowest', target=None, tol=None, sub
         piece = evec_buf[i * mat.n_local:(i + 1) * mat.n_local]
         if packed:
             # the real eigenvector as the complex state of the full dimension (imaginary parts zero)
-            v._vec = Vec(cmat.N, swz=cmat.swz_right, sub_c=cmat._keep[1])
-            if v._vec.internal:           # SpinConserve: one double per position of the layout
-                _lib.check(_lib.lib().dnm_vec_layout_unpack_real(C.byref(cmat._keep[1]), C.byref(v._vec._part),
+            if mat.swz_right >= 256:      # SpinConserve: one double per position of the PACKED handle's own layout
+                # (its descriptor and site relabelling, not the complex handle's: the two builds choose theirs
+                # separately, and positions of one are not positions of the other -- ADVICE r5)
+                v._vec = Vec(cmat.N, swz=mat.swz_right, sub_c=mat._keep[1])
+                _lib.check(_lib.lib().dnm_vec_layout_unpack_real(C.byref(mat._keep[1]), C.byref(v._vec._part),
                                                                  v._vec.ptr, C.c_void_p(piece.data_ptr()), _stream()))
+                v.set_initialized()
+                evecs.append(v)
+                continue
+            v._vec = Vec(cmat.N, swz=cmat.swz_right, sub_c=cmat._keep[1])
+            if v._vec.internal:
+                raise RuntimeError('internal: a packed Full / Parity handle beside a SpinConserve layout')
             else:                         # Full / Parity: two amplitudes per element
                 _lib.check(_lib.lib().dnm_vec_unpack_real(v._vec.ptr, C.c_void_p(piece.data_ptr()), mat.n_local,
                                                           mat.swz_right, cmat.swz_right, _stream()))

@@ -237,7 +237,9 @@ int dnm_vec_layout_positions_host(const dnm_subspace *s, const dnm_partition *pa
   v.nchoosek = ly->host.nck;
   Sc3Perm P;
   DNM_TRY(perm_of(s, &P));
-  DNM_CHECK(!P.on || (is == 0 && il == ly->host.nint), "a relabelled SpinConserve layout is not partitioned over ranks");
+  // (whole vectors, or the half whose top bit is clear -- an XParity vector on top of the layout: both start at position 0
+  // of the layout and at index 0 of the reference order, as perm_whole of the device paths accepts them)
+  DNM_CHECK(!P.on || (is == 0 && ns == 0), "a relabelled SpinConserve layout is not partitioned over ranks");
   for (int64_t i = 0; i < n; ++i) {
     DNM_CHECK(idx[i] >= 0 && idx[i] < nl, "index %lld out of range", (long long)idx[i]);
     uint64_t st = (uint64_t)Sub<DNM_SPIN_CONSERVE>::i2s(idx[i] + ns, v);

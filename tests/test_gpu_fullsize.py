@@ -427,7 +427,6 @@ def test_config4_transposed_exchange_layouts(rank, monkeypatch):
         _lib.check(Lb.dnm_mat_destroy(h))
 
 
-@pytest.mark.skipif(os.environ.get('DNM_TEST_LARGEST') != '1', reason='largest single-GPU problems: opt-in (DNM_TEST_LARGEST=1), run in the builder\'s sessions')
 def test_config5_solver_at_the_largest_single_gpu_size():
     """BASELINE config 5's solver -- eigsolve(nev=1) by Lanczos without a stored basis, SpinConserve vectors in the
     internal layout -- at the largest half-filling subspace one MI355X holds: SpinConserve(34,17), 2.33 G states
@@ -461,7 +460,6 @@ def test_config5_solver_at_the_largest_single_gpu_size():
         torch.cuda.empty_cache()
 
 
-@pytest.mark.skipif(os.environ.get('DNM_TEST_LARGEST') != '1', reason='largest single-GPU problems: opt-in (DNM_TEST_LARGEST=1), run in the builder\'s sessions')
 def test_full_space_solver_beyond_the_complex_limit():
     """eigsolve(nev=1) on the Full space at L = 31 (2^31 states) on ONE GPU: the solver runs in real arithmetic (the
     default for a real-symmetric operator of this size: 16 GiB per work vector where complex128 takes 32), and the
@@ -590,8 +588,7 @@ def test_evolve_against_free_fermions(case):
         torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("case", ["chain32", pytest.param("chain34", marks=pytest.mark.skipif(
-    os.environ.get('DNM_TEST_LARGEST') != '1', reason='largest single-GPU problems: opt-in (DNM_TEST_LARGEST=1)')), "ring30", "ring30x",
+@pytest.mark.parametrize("case", ["chain32", "chain34", "ring30", "ring30x",
     "parity30", "field30"])
 def test_xx_models_against_free_fermions(case):
     """0.25 sum (XX + YY) -- free fermions hopping with amplitude 1/2 -- in SpinConserve(L, L/2) at full size, against the
@@ -654,7 +651,6 @@ def test_xx_models_against_free_fermions(case):
         torch.cuda.empty_cache()
 
 
-@pytest.mark.skipif(os.environ.get('DNM_TEST_LARGEST') != '1', reason='largest single-GPU problems: opt-in (DNM_TEST_LARGEST=1), run in the builder\'s sessions')
 def test_ising_33_spins_against_the_free_fermion_energy():
     """The transverse-field Ising chain of the reference's harness (hamiltonians.py:25-31: sum ZZ + 0.5 sum X, open ends)
     on 33 spins in its two spin-flip sectors, XParity(Full(33)): 2^32 states each, in real arithmetic (32 GiB per vector,

@@ -452,8 +452,9 @@ def test_real_packed_graph_multiply(small_layout, case):
 
 
 @pytest.mark.parametrize("arith", ["complex", "real"])
-@pytest.mark.parametrize("case", ["no_table_small", pytest.param("no_table_27b", marks=pytest.mark.skipif(
-    os.environ.get("DNM_TEST_LARGEST") != "1", reason="opt-in (DNM_TEST_LARGEST=1): 11 s of oracle per case")), "dense_lo_25"])
+@pytest.mark.parametrize("case", ["no_table_small", "dense_lo_25"] +
+                         # (opt-in: 11 s of oracle per case)
+                         (["no_table_27b"] if os.environ.get("DNM_TEST_LARGEST") == "1" else []))
 def test_lo_hops_by_rank_tables(small_layout, monkeypatch, case, arith):
     """The lo pass's LDS hops WITHOUT the partner table (Sc3Op::ptab): the two-table rank of the flipped pattern -- what an
     operator with more than 32 hops inside Lo runs (dense_lo_25: all 91 pairs of the 14 Lo spins of the (14, 10) instance
@@ -633,3 +634,36 @@ def test_states_in_a_relabelled_layout_behave_like_any_state(small_layout, tmp_p
     assert abs(e1 - np.vdot(arr, ref).real) < 1e-12
     H.destroy_mat()
     Z.destroy_mat()
+
+
+def test_set_product_on_an_adopted_xparity_state(small_layout):
+    """An XParity(SpinConserve) state that has adopted an operator's relabelled layout (the layout's first half):
+    index-wise writes through Vec.positions(int) -- State.set_product -- land where the reference order says
+    (dnm_vec_layout_positions_host used to refuse every relabelled vector that is not the whole layout: ADVICE r5)."""
+    from dynamite_amd.states import State
+    from dynamite_amd.subspaces import XParity
+    H = models.kagome("12")
+    N = H.L
+    parent = SpinConserve(N, N // 2)
+    sub = XParity(parent, sector='+')
+    H.add_subspace(sub)
+    psi = State(L=N, subspace=sub, state='random', seed=5)
+    phi = H.dot(psi)                          # psi adopts the operator's layout (Operator.dot)
+    mat = H.get_mat(subspaces=(sub, sub))
+    if psi.vec.perm is None:
+        pytest.skip("this build keeps the identity labelling for the 12-site torus")
+    assert psi.vec.half and phi.vec.perm == psi.vec.perm
+    before = psi.to_numpy().copy()
+    # positions of single indices agree with the device path's
+    import torch
+    some = [0, 1, 17, sub.get_dimension() - 1]
+    dev = psi.vec.positions(torch.tensor(some, dtype=torch.int64)).cpu().numpy()
+    assert [psi.vec.positions(i) for i in some] == dev.tolist()
+    # a product state written index-wise into the adopted vector: a representative (spin N-1 up)
+    s = 'U' * (N // 2 - 1) + 'D' * (N // 2) + 'U'
+    psi.set_product(s)
+    arr = psi.to_numpy()
+    assert np.count_nonzero(arr) == 1 and arr[sub.state_to_idx(State.str_to_state(s, N))] == 1.0
+    assert np.count_nonzero(before) > 1
+    H.destroy_mat()
+    del mat
