@@ -1532,6 +1532,13 @@ int Sc3Mat::init(const Sc3Layout *layout, const std::vector<int64_t> &masks, con
       h.up_re = scm[m].up_re; h.up_im = scm[m].up_im; h.dn_re = scm[m].dn_re; h.dn_im = scm[m].dn_im;
       part[fi == 0 ? (fj == 0 ? 0 : 1) : (fi == 1 && fj == 1 ? 2 : 3)].push_back(h);
     }
+    // probes (timing only, WRONG results): keep the first n hops of a kind -- what a pass would take without the others
+    // bounds what any reworking of them can gain (tools/probes/sc3g_drop_hops.sh)
+    for (int q = 0; q < 4; ++q) {
+      static const char *names[4] = {"DNM_SC3G_KEEP_LDSA", "DNM_SC3G_KEEP_GATA", "DNM_SC3G_KEEP_LDSB", "DNM_SC3G_KEEP_GATB"};
+      if (const char *e = knob(names[q]))
+        if ((size_t)atoi(e) < part[q].size()) part[q].resize((size_t)atoi(e));
+    }
     if ((int)part[1].size() > SC3G_MAX_GATHER || (int)part[3].size() > SC3G_MAX_GATHER ||
         (int)part[2].size() > SC3G_MAX_WLDS) {      // more hops than a pass has lanes / table columns for: the row kernel
       tiled = graph = false;
