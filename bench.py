@@ -1206,6 +1206,8 @@ def main():
                 sec = secondary(wd)
             else:
                 Lk = tuple(int(v) for v in args.config5.split(",")) if args.config5 else None
+                if Lk is None and dist.get_backend() != "nccl":
+                    Lk = (26, 13)       # ranks sharing a device (a plumbing run): config 5's sizes are for a GPU per rank
                 sec = {"config5": config5(wd, world, rank, Lk)}
         except Exception as e:       # noqa: BLE001
             sec = {"error": repr(e)}

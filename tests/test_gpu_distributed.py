@@ -423,11 +423,21 @@ def _bench_ranks(world, extra_env, argv=(), L=22, timeout=900):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
            "--gpus", str(world), "--steps", "2", "--warmup", "1", "--L", str(L), "--config5", "18,9"] + list(argv)
-    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
-    assert out.returncode == 0, out.stderr[-3000:]
-    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, out.stdout
-    return json.loads(lines[0]), out.stderr
+    # a session of its own: a run that exceeds the limit is ended as a whole (the launcher AND its ranks -- orphaned ranks
+    # would keep their device memory for the rest of the suite)
+    import signal
+    p = subprocess.Popen(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                         start_new_session=True)
+    try:
+        stdout, stderr = p.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        os.killpg(p.pid, signal.SIGKILL)
+        stdout, stderr = p.communicate()
+        raise AssertionError("bench.py did not finish within %d s\n%s" % (timeout, stderr[-3000:]))
+    assert p.returncode == 0, stderr[-3000:]
+    lines = [ln for ln in stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, stdout
+    return json.loads(lines[0]), stderr
 
 
 def _check_schedule_entry(e, world):
@@ -521,16 +531,7 @@ def test_bench_first_contact_probe_saves_the_run(how):
 def test_bench_falls_back_when_the_selfcheck_fails():
     """A transposed-exchange operator whose first multiply fails its sampled-row check (forced here): every rank gets
     the same verdict, the bench rebuilds the operator with partner blocks, times that, and says so in its line."""
-    import json
-    import subprocess
-    env = dict(os.environ, DNM_BENCH_BACKEND="gloo", DNM_TEST_FAIL_SELFCHECK="1", DNM_EXPERIMENTAL="1")
-    env.setdefault("GPU_MAX_HW_QUEUES", "2")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4",
-           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
-           "--gpus", "4", "--steps", "2", "--warmup", "1", "--L", "22"]
-    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stderr[-2000:]
-    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    d, _ = _bench_ranks(4, {"DNM_TEST_FAIL_SELFCHECK": "1", "DNM_EXPERIMENTAL": "1"})
     assert d["config"]["exchange"] == "partner" and d["config"]["exchange_selfcheck"].startswith("failed")
     assert d["value"] > 0 and d["multi_gpu"]["schedules"]["host"]["selfcheck"].startswith("failed")
 
