@@ -23,6 +23,10 @@
 #include "kernels.h"
 #include "sc3_dev.h"
 
+#ifndef DNM_SC3G_PROBE_STAGE
+#define DNM_SC3G_PROBE_STAGE 0
+#endif
+
 namespace dnm {
 
 namespace {
@@ -480,6 +484,9 @@ sc3g_lo_pass_r(const Sc3Tab S, const Sc3Op O, const uint32_t *__restrict__ perm,
         g.need = nd;
         g.xm = h.mLo;
         g.c0 = h.up_re;
+#if DNM_SC3G_PROBE_STAGE
+        g.rev = S.nl[kl2];
+#endif
       }
     }
   }
@@ -552,6 +559,32 @@ sc3g_lo_pass_r(const Sc3Tab S, const Sc3Op O, const uint32_t *__restrict__ perm,
     const int nd = rl_i32(g.need, m);
     const uint32_t xm = (uint32_t)rl_i32((int)g.xm, m);
     double v[EPT];
+#if DNM_SC3G_PROBE_STAGE
+    // TIMING PROBE (wrong numbers): what a gathered hop would cost with its partner row STAGED in LDS -- the row read by
+    // coalesced 16-byte loads (the data goes nowhere), one LDS read per live entry (from the row's own tile)
+    {
+      const int nl2 = rl_i32(g.rev, m);
+      double sink = 0.0;
+#pragma unroll
+      for (int c = 0; c < EPT / 2; ++c) {
+        const int idx = 2 * (tsub + c * NTS);
+        if (idx < nl2) {
+          const d2v q = *reinterpret_cast<const d2v *>(pp + idx);
+          sink += q.x + q.y;
+        }
+      }
+      acc[0] = fma(sink, 1e-300, acc[0]);
+      const uint32_t slotmask = (uint32_t)(((NT * EPT) >> logm) * 8 - 8);
+#pragma unroll
+      for (int i = 0; i < EPT; ++i) {
+        const int r = SC3R_ENT(i);
+        const uint32_t pt = SC3R_PAT(i);
+        v[i] = 0.0;
+        if (r < nrows && __popc(pt & xm) == nd)
+          v[i] = *reinterpret_cast<const double *>(reinterpret_cast<const unsigned char *>(xs) + (rank8(pt ^ xm) & slotmask));
+      }
+    }
+#else
 #pragma unroll
     for (int i = 0; i < EPT; ++i) {
       const int r = SC3R_ENT(i);
@@ -560,6 +593,7 @@ sc3g_lo_pass_r(const Sc3Tab S, const Sc3Op O, const uint32_t *__restrict__ perm,
       if (r < nrows && __popc(pt & xm) == nd)
         v[i] = *reinterpret_cast<const double *>(reinterpret_cast<const unsigned char *>(pp) + rank8(pt ^ xm));
     }
+#endif
 #pragma unroll
     for (int i = 0; i < EPT; ++i) acc[i] = fma(cr, v[i], acc[i]);
   }
