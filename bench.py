@@ -861,6 +861,7 @@ def config5(wd, world, rank, Lk=None, tol=1e-8):
     filled Fermi sea."""
     import numpy as np
     import torch
+    import torch.distributed as dist
     from dynamite_amd import models
     from dynamite_amd.subspaces import SpinConserve
     from dynamite_amd.computations import eigsolve
@@ -894,6 +895,31 @@ def config5(wd, world, rank, Lk=None, tol=1e-8):
              "plan": mat.describe().strip().split("\n")[0][:160]}
         if not st["max_rel_residual"] <= tol * 1.01:
             r["failed_checks"] = ["residual %r above tol" % st["max_rel_residual"]]
+        # the multiply of the solve on its own, split as the Full-space one above: whole / messages alone / kernels alone
+        try:
+            wd.phase("config 5: %s, phases of the multiply" % name)
+            from dynamite_amd.backend import RawVec
+            xr = RawVec(torch.randn(2 * mat.n_local, dtype=torch.float64, device=torch.device("cuda", torch.cuda.current_device()))
+                        .view(torch.complex128), mat.swz_right)
+            yr = RawVec(torch.zeros(mat.m_local, dtype=torch.complex128, device=xr.array.device), mat.swz_left)
+            xr.perm, yr.perm = mat.perm_right, mat.perm_left
+
+            def barrier():
+                torch.cuda.synchronize()
+                dist.barrier()
+                torch.cuda.synchronize()
+
+            def reduce_max(v):
+                t = torch.tensor([v], dtype=torch.float64, device=xr.array.device)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                return float(t.item())
+            w_, e_, c_ = phase_times(mat, xr, yr, 3, barrier, reduce_max)
+            r["multiply"] = {"ms": w_, "exchange_only_ms": e_, "compute_only_ms": c_, "hidden_ms": e_ + c_ - w_,
+                             "schedule": "native" if mat._native_in_use(xr) else "host",
+                             "link_GBs_measured_rank0": (summ["busiest_link_bytes"] / (e_ * 1e-3) / 1e9) if summ["busiest_link_bytes"] else None}
+            del xr, yr
+        except Exception as e:       # noqa: BLE001
+            r["multiply"] = {"error": repr(e)}
         H.destroy_mat()
         return r
     out["heisenberg"] = solve(models.heisenberg(L), "Heisenberg chain")

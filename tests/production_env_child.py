@@ -29,7 +29,7 @@ def main():
         return hashlib.sha256(np.ascontiguousarray(state.to_numpy()).tobytes()).hexdigest()[:24]
     out = {"vec_swizzle": config.vec_swizzle, "sc_layout": list(config.sc_layout or ()), "cases": {}}
     cases = [("mbl_full_22", models.mbl(22), Full(L=22)),
-             ("long_range_parity_21", models.long_range(21), Parity('even', L=21)),
+             ("xxz_parity_21", models.xxz(21), Parity('even', L=21)),
              ("heisenberg_sc_26_13", models.heisenberg(26), SpinConserve(26, 13)),        # internal layout: 10.4 M states
              ("kagome_sc_27", models.kagome("27b"), SpinConserve(27, 13)),                 # bond-graph passes, relabelled
              ("ising_xparity_20", models.ising(20), XParity(Full(L=20), sector='+'))]

@@ -453,6 +453,8 @@ def _check_config5(sec):
     h, kx = c5["heisenberg"], c5["known_answer_xx_chain"]
     assert h["exchange"] == "window" and h["matvecs"] > 10 and h["measured_rel_residual"] <= 1.01e-8
     assert h["bytes_received_per_multiply_rank0"] > 0 and "failed_checks" not in h
+    m = h["multiply"]
+    assert m["ms"] > 0 and m["exchange_only_ms"] > 0 and m["compute_only_ms"] > 0, m
     assert kx["abs_error"] < 1e-6 and "failed_checks" not in kx
 
 
