@@ -684,3 +684,83 @@ def test_native_partitioned_multiply(tmp_path):
     assert rep["worst_relative"] < 1e-12 and rep.get("hooks") == "ok", rep
     assert "tiled=1" in rep["cases"]["full_P8"]["plan"] and "internal layout" in rep["cases"]["sc3_P3"]["plan"], rep
     assert {"tr_P4", "tr_P8_swz", "tr_P2", "tr_P4_whole", "tr_P4_parity", "tr_P4_packed"} <= set(rep["cases"]), rep
+
+
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_c_abi_alone_between_rank_processes(tmp_path, world):
+    """Rank PROCESSES that bind the C ABI with ctypes alone (tests/native_ranks_child.py: no torch, no backend.py, no
+    torch.distributed -- what a C / Cython / MPI host of include/dynamite_amd.h does): the communicator id through a file,
+    dnm_comm_create with real ranks (stand-in transport), dnm_mat_mult_partitioned against the oracle for partner blocks,
+    the transposed exchange (pipelined, Parity, real-packed) and column windows; dnm_comm_allreduce over the ranks; and the
+    Krylov drivers ACROSS the processes through dnm_comm_hooks -- dnm_eigsolve against a dense solve, dnm_expm_multiply
+    against scipy.  Replaces bpetsc_template_2.c:413-504, 787-879 and computations.py:89-112, 208-257."""
+    import json
+    import signal
+    import subprocess
+    import scipy.sparse.linalg as spla
+    from dynamite_amd import models, _lib
+    from dynamite_amd.subspaces import Full, SpinConserve, Parity
+    from gpu_util import marshal, orc_msc, orc_sub, rand_state
+    from oracle import oracle as orc
+    cases = {}
+
+    def add(name, H, sub, P, typ, swz, exchange=0, flags=0, solver=False):
+        masks, offs, signs, coeffs = marshal(H)
+        x = rand_state(sub.get_dimension(), seed=len(cases) + 1)
+        if flags & _lib.MAT_REAL_PACKED:
+            x = x.real + 0j
+        y = orc.matvec(orc_msc(H), orc_sub(sub), orc_sub(sub), x)
+        if flags & _lib.MAT_REAL_PACKED:            # real vectors travel two amplitudes to an element
+            x, y = x.real[0::2] + 1j * x.real[1::2], y.real[0::2] + 1j * y.real[1::2]
+        L = sub.L
+        nck = sub._nchoosek if typ == 3 else np.zeros((1, L + 1), dtype=np.int64)
+        for key, val in (("masks", masks), ("mask_offsets", offs), ("signs", signs), ("coeffs", coeffs), ("x", x), ("y", y),
+                         ("type", typ), ("L", L), ("k", getattr(sub, "k", 0)), ("P", P), ("swz", swz), ("nck", nck),
+                         ("exchange", exchange), ("flags", flags), ("space", getattr(sub, "space", 0))):
+            cases[name + "/" + key] = np.asarray(val)
+        if solver:
+            H.add_subspace(sub)
+            Hs = H.to_numpy(subspaces=(sub, sub), sparse=True)
+            cases[name + "/E0"] = np.asarray(spla.eigsh(Hs, k=1, which='SA', tol=1e-12, return_eigenvectors=False)[0])
+            cases[name + "/z"] = spla.expm_multiply(-0.3j * Hs, x)
+    TR = _lib.EXCHANGE_TRANSPOSE
+    if world == 2:
+        add("full_P2", models.mbl(16), Full(L=16), 2, 0, 10, solver=True)
+        add("tr_P2", models.ising(16), Full(L=16), 2, 0, 0, exchange=TR)
+        add("sc3_P2", models.mbl(15), SpinConserve(15, 7), 2, 3, 6 | (4 << 8))
+        solver_case = "full_P2"
+    elif world == 3:
+        add("full_P3_window", models.mbl(12), Full(L=12), 3, 0, 0)
+        add("sc_ref_P3", models.mbl(14), SpinConserve(14, 7), 3, 3, 0)
+        add("sc3_P3", models.heisenberg(16), SpinConserve(16, 8), 3, 3, 6 | (4 << 8), solver=True)
+        solver_case = "sc3_P3"
+    else:
+        add("tr_P4", models.mbl(17), Full(L=17), 4, 0, 0, exchange=TR, solver=True)
+        add("tr_P4_parity", models.mbl(18), Parity('odd', L=18), 4, 1, 0, exchange=TR)
+        add("tr_P4_packed", models.heisenberg(18), Full(L=18), 4, 0, 0, exchange=TR, flags=_lib.MAT_REAL_PACKED)
+        add("full_P4_partner", models.mbl(16), Full(L=16), 4, 0, 6)
+        solver_case = "tr_P4"
+    fn = os.path.join(str(tmp_path), "cases.npz")
+    np.savez(fn, **cases)
+    env = dict(os.environ, DNM_RCCL_LIB=build_fake_rccl(), DNM_NATIVE_SOLVER_CASE=solver_case, DNM_FAKE_RCCL_TIMEOUT_S="300")
+    env.setdefault("GPU_MAX_HW_QUEUES", "2")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    idfile = os.path.join(str(tmp_path), "comm_id")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "native_ranks_child.py"), fn, str(r), str(world),
+                               idfile, os.path.join(str(tmp_path), "rep%d.json" % r)], env=env, cwd=ROOT,
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+             for r in range(world)]
+    errs = []
+    try:
+        for p in procs:
+            errs.append(p.communicate(timeout=600)[1])
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                os.killpg(p.pid, signal.SIGKILL)
+    assert [p.returncode for p in procs] == [0] * world, "\n".join(e[-1500:] for e in errs)
+    reps = [json.load(open(os.path.join(str(tmp_path), "rep%d.json" % r))) for r in range(world)]
+    assert all(r["worst_relative"] < 1e-12 and len(r["cases"]) == len({k.split("/")[0] for k in cases}) for r in reps), reps
+    assert all("eigsolve" in r and "expm" in r and r["eigsolve"]["matvecs"] > 5 for r in reps), reps
+    assert len({r["eigsolve"]["E0"] for r in reps}) == 1          # every rank returns the same number, bit for bit
