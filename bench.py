@@ -780,7 +780,8 @@ def probe_child(args):
     backend_name = os.environ.get("DNM_BENCH_BACKEND", "nccl")
     wd.phase("probe: init_process_group(%s)" % backend_name)
     if backend_name == "nccl":
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        from dynamite_amd import _comm
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local), pg_options=_comm.nccl_options())
     else:
         dist.init_process_group(backend_name)
     from dynamite_amd import models, backend
@@ -985,7 +986,10 @@ def main():
         # through the host; RCCL refuses two ranks on one device) -- a plumbing check, not a measurement
         wd.phase("init_process_group(%s)" % backend_name)
         if backend_name == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            from dynamite_amd import _comm
+            # (RCCL's stream with high priority: without it the exchange and the kernels it should hide under serialise on
+            # this system -- _comm.nccl_options)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local), pg_options=_comm.nccl_options())
         else:
             dist.init_process_group(backend_name)
     from dynamite_amd import models, backend, _lib

@@ -11,6 +11,17 @@ import torch
 import torch.distributed as dist
 
 
+def nccl_options():
+    """Options for ``dist.init_process_group("nccl", pg_options=...)``: RCCL's stream with HIGH priority.  On MI355X / ROCm 7
+    streams of one priority share the process's few hardware queues, and a transfer on one stream and a kernel on another
+    ran one after the other whenever the two landed on the same queue -- no overlap of exchange and compute at all
+    (tools/probes/rccl_concurrency_probe.py: 25.1 ms together = 3.6 + 20.7; 21.8 with this option).  The library's own
+    exchange stream (csrc/comm.cpp) is created with the highest priority for the same reason."""
+    opts = dist.ProcessGroupNCCL.Options()
+    opts.is_high_priority_stream = True
+    return opts
+
+
 def _staged(t):
     return t.is_cuda and dist.get_backend() == 'gloo'
 

@@ -559,7 +559,19 @@ int dnm_comm_create(const void *id128, int rank, int nranks, dnm_comm **out) {
   ncclUniqueId id;
   memcpy(&id, id128, sizeof id);
   DNM_NCCL(ncclCommInitRank(&c->nccl, nranks, id, rank));
-  DNM_HIP(hipStreamCreateWithFlags(&c->xs, hipStreamNonBlocking));
+  // The exchange stream gets the HIGHEST priority the device offers.  Streams of one priority share the process's few
+  // hardware queues round-robin (GPU_MAX_HW_QUEUES, default 4): on this system an RCCL transfer on one stream and a kernel on
+  // another ran ONE AFTER THE OTHER whenever the two streams landed on the same queue (tools/probes/rccl_concurrency_probe.py:
+  // 25.3 ms together = 3.7 + 20.6, against 21.4 with eight queues) -- no overlap of exchange and compute at all.  A
+  // high-priority stream has a queue of its own class, and RCCL's few workgroups get their slots ahead of the bulk of the
+  // rank-local pass's.  DNM_COMM_PRIORITY=0: the default priority (A/B runs).
+  {
+    int least = 0, greatest = 0;
+    DNM_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    const char *pe = getenv("DNM_COMM_PRIORITY");
+    if (pe && pe[0] == '0') DNM_HIP(hipStreamCreateWithFlags(&c->xs, hipStreamNonBlocking));
+    else DNM_HIP(hipStreamCreateWithPriority(&c->xs, hipStreamNonBlocking, greatest));
+  }
   DNM_HIP(hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming));
   DNM_HIP(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
   DNM_TRY(c->red.alloc(1 << 16));

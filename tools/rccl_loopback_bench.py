@@ -27,13 +27,16 @@ def main():
     import torch
     import torch.distributed as dist
     torch.cuda.set_device(0)
+    # (RCCL's stream with high priority, as bench.py creates its group: _comm.nccl_options; --default-priority: without)
+    from dynamite_amd import _comm
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0),
-                            timeout=datetime.timedelta(seconds=300))
+                            timeout=datetime.timedelta(seconds=300),
+                            pg_options=None if "--default-priority" in sys.argv else _comm.nccl_options())
     from dynamite_amd import backend, models, msc_tools, _lib
     from dynamite_amd.config import config
     from dynamite_amd.subspaces import Full
     config._initialize()
-    args = [int(a) for a in sys.argv[1:]] or [31, 2, 0, 33, 8, 5]
+    args = [int(a) for a in sys.argv[1:] if not a.startswith("--")] or [31, 2, 0, 33, 8, 5]
     for L, P, me in zip(args[0::3], args[1::3], args[2::3]):
         sub = Full(L=L)
         H = models.mbl(L)
@@ -84,9 +87,19 @@ def main():
         px = (C.c_void_p * P)(*[x.array.data_ptr()] * P)
         _lib.check(_lib.lib().dnm_comm_loopback(comm, me, P, px, None))
         t_native = timed(lambda: _lib.check(_lib.lib().dnm_mat_mult_partitioned(mat.handle, comm, x.ptr, y.ptr, backend._stream())))
+        def phases(handle, xv, yv):
+            """the native call's messages alone / kernels alone (dnm_comm_set_phase, round 6)"""
+            out = []
+            for ph in (_lib.PHASE_EXCHANGE, _lib.PHASE_COMPUTE):
+                _lib.check(_lib.lib().dnm_comm_set_phase(comm, ph))
+                out.append(timed(lambda: _lib.check(_lib.lib().dnm_mat_mult_partitioned(handle, comm, xv.ptr, yv.ptr, backend._stream()))))
+            _lib.check(_lib.lib().dnm_comm_set_phase(comm, _lib.PHASE_ALL))
+            return out
+        t_ne, t_nc = phases(mat.handle, x, y)
         _lib.check(_lib.lib().dnm_comm_forget(comm, mat.handle))
-        print("   the same as one native call (dnm_mat_mult_partitioned, exchange on the library's own stream): %.2f ms" % t_native,
-              flush=True)
+        print("   the same as one native call (dnm_mat_mult_partitioned, exchange on the library's own stream): %.2f ms; its messages "
+              "alone %.2f ms, its kernels alone %.2f ms: %.2f ms hidden (%.0f %% of the shorter)"
+              % (t_native, t_ne, t_nc, t_ne + t_nc - t_native, 100 * (t_ne + t_nc - t_native) / min(t_ne, t_nc)), flush=True)
         L_ = _lib.lib()
         t_local = timed(lambda: _lib.check(L_.dnm_mat_mult_local(mat.handle, x.ptr, y.ptr, backend._stream())))
 
@@ -139,9 +152,11 @@ def main():
             px = (C.c_void_p * P)(*[x.array.data_ptr()] * P)
             _lib.check(_lib.lib().dnm_comm_loopback(comm, me, P, px, None))
             t_ntr = timed(lambda: _lib.check(_lib.lib().dnm_mat_mult_partitioned(mat2.handle, comm, x.ptr, y.ptr, backend._stream())))
+            t_ne, t_nc = phases(mat2.handle, x, y)
             _lib.check(_lib.lib().dnm_comm_forget(comm, mat2.handle))
-            print("   the same as one native call (split by dnm_mat_set_exchange, schedule in csrc/comm.cpp): %.2f ms" % t_ntr,
-                  flush=True)
+            print("   the same as one native call (split by dnm_mat_set_exchange, schedule in csrc/comm.cpp): %.2f ms; its messages "
+                  "alone %.2f ms, its kernels alone %.2f ms: %.2f ms hidden (%.0f %% of the shorter)"
+                  % (t_ntr, t_ne, t_nc, t_ne + t_nc - t_ntr, 100 * (t_ne + t_nc - t_ntr) / min(t_ne, t_nc)), flush=True)
             assert torch.isfinite(torch.view_as_real(y.array)).all()
             mat2.destroy()
             del x, y
