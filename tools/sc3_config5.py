@@ -106,6 +106,38 @@ def main():
     e1.record()
     torch.cuda.synchronize()
     print("   split as a partitioned multiply runs it (lo pass writes y, window pass adds): %.2f ms" % (e0.elapsed_time(e1) / n))
+    if "--native-loopback" in sys.argv:
+        # round 6: the same rank through dnm_mat_mult_partitioned with its exchange looped back over the real RCCL (a
+        # communicator of one rank standing for rank `rank` of P; every peer's block = one buffer of the largest block's
+        # size: the bytes mean nothing, the messages, their sizes and the overlap with the lo pass are the production
+        # ones), whole / messages alone / kernels alone
+        import time
+        del xw
+        torch.cuda.empty_cache()
+        comm = backend.native_comm()
+        unit = 2 if real else 1
+        blocks = [backend.layout_partition(d, P, q)[1] // unit for q in range(P)]
+        peer = torch.randn(2 * max(blocks), dtype=torch.float64, device=config.device).view(torch.complex128)
+        px = (C.c_void_p * P)(*[peer.data_ptr()] * P)
+        _lib.check(_lib.lib().dnm_comm_loopback(comm, rank, P, px, None))
+        xl = peer[:mat.n_local]
+
+        def timed(ph, nrep=4):
+            _lib.check(L_.dnm_comm_set_phase(comm, ph))
+            for _ in range(2):
+                _lib.check(L_.dnm_mat_mult_partitioned(mat.handle, comm, C.c_void_p(xl.data_ptr()), C.c_void_p(y.data_ptr()), backend._stream()))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(nrep):
+                _lib.check(L_.dnm_mat_mult_partitioned(mat.handle, comm, C.c_void_p(xl.data_ptr()), C.c_void_p(y.data_ptr()), backend._stream()))
+            torch.cuda.synchronize()
+            _lib.check(L_.dnm_comm_set_phase(comm, _lib.PHASE_ALL))
+            return (time.perf_counter() - t0) / nrep * 1e3
+        tw, te, tc = timed(_lib.PHASE_ALL), timed(_lib.PHASE_EXCHANGE), timed(_lib.PHASE_COMPUTE)
+        summ = mat.exchange_summary() if False else None
+        print("   native call, exchange looped back over RCCL: %.2f ms per multiply; its messages alone %.2f ms, its kernels alone "
+              "%.2f ms: %.2f ms hidden (%.0f %% of the shorter)" % (tw, te, tc, te + tc - tw, 100 * (te + tc - tw) / min(te, tc)))
+        _lib.check(L_.dnm_comm_forget(comm, mat.handle))
 
 
 if __name__ == "__main__":
