@@ -764,3 +764,25 @@ def test_c_abi_alone_between_rank_processes(tmp_path, world):
     assert all(r["worst_relative"] < 1e-12 and len(r["cases"]) == len({k.split("/")[0] for k in cases}) for r in reps), reps
     assert all("eigsolve" in r and "expm" in r and r["eigsolve"]["matvecs"] > 5 for r in reps), reps
     assert len({r["eigsolve"]["E0"] for r in reps}) == 1          # every rank returns the same number, bit for bit
+
+
+def test_native_exchange_runs_under_the_kernels():
+    """The exchange of the native partitioned multiply must RUN AT THE SAME TIME as the rank-local kernels: on this system
+    two streams of one priority can share a hardware queue and then serialise (round 6: every multi-rank time before was
+    taken without any overlap), so the library's exchange stream has the highest priority (csrc/comm.cpp).  Rank 0 of 2 at
+    L=30 with its exchange looped back over the real RCCL (tools/rccl_loopback_bench.py): whole multiply against messages
+    alone + kernels alone (dnm_comm_set_phase) -- a good part of the shorter of the two must be hidden, even though in
+    loop-back both compete for the same HBM."""
+    import re
+    import subprocess
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "DNM_COMM_PRIORITY"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rccl_loopback_bench.py"), "30", "2", "0"], env=env,
+                         cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    m = re.search(r"one native call .*?: ([\d.]+) ms; its messages alone ([\d.]+) ms, its kernels alone ([\d.]+) ms: "
+                  r"(-?[\d.]+) ms hidden \((-?\d+) % of the shorter\)", out.stdout)
+    assert m, out.stdout[-2000:]
+    whole, msgs, kern, hidden, pct = (float(v) for v in m.groups())
+    assert whole < 0.93 * (msgs + kern) and pct >= 25, out.stdout[-1500:]
