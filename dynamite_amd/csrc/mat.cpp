@@ -954,6 +954,8 @@ int dnm_mat_create(int64_t nmasks, const int64_t *masks, const int64_t *mask_off
                          Tb[A->rank + 1], want_real));
     if (const char *e = knob("DNM_SC3_TILED")) if (e[0] == '0') A->sc3->tiled = false;     // tests: the row kernel
     if (const char *e = knob("DNM_SC3_DIAG")) if (e[0] == 'c' && A->sc3->diag_mode == 2) A->sc3->diag_mode = 1;
+    // (timing probe, WRONG results: the passes without any diagonal -- what dropping the cached diagonal's 8 B/row could save)
+    if (const char *e = knob("DNM_SC3_DIAG")) if (e[0] == 'n') A->sc3->diag_mode = 0;
     int64_t is, il, ns, nl;
     sc3_range(*ly, Tb[A->rank], Tb[A->rank + 1], &is, &il, &ns, &nl);
     A->m_local = A->n_local = il;          // what the vector kernels sweep: rows + padding
