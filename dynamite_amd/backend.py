@@ -842,11 +842,10 @@ class ShellMat:
         return Vec(v.size, swz=self.swz_left, sub_c=self._keep[0])
 
     def _native_applies(self, x):
-        """The native schedule moves device memory over RCCL: not for the gloo-staged transport of the CPU / one-GPU
-        tests, nor for window partitions whose right vectors are swizzled (their window is assembled in index order)."""
-        if not native_transport() or not x.array.is_cuda:
-            return False
-        return bool(self.partners) or x.internal or not x.swz
+        """The native schedule moves device memory over RCCL: every partition takes it (round 6: also window partitions whose
+        right vectors are stored swizzled -- the library straightens the block before it travels); the host schedules
+        remain for the gloo-staged transport of the CPU / one-GPU tests."""
+        return native_transport() and x.array.is_cuda
 
     def check_layout(self, x, y):
         """Raise unless the vectors are laid out as this matrix expects them (x: right subspace, y: left).  Every

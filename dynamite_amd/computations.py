@@ -30,8 +30,7 @@ def _hooks(mat, keep):
         return None
     import torch
     from .backend import Vec, RawVec, native_comm, native_transport
-    if native_transport() and mat._tr is None and (mat._native_tr or mat.partners or mat.swz_right >= 256
-                                                   or mat.swz_right == 0):
+    if native_transport() and mat._tr is None:
         # the library's own communicator: multiply and reductions of every solver step stay native (dnm_comm_hooks)
         mat._native = native_comm()
         h = _lib.Hooks()

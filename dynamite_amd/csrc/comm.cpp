@@ -99,6 +99,7 @@ struct WindowState {
   std::vector<int64_t> wlo, whi;                 // every rank's inclusive column window
   std::vector<std::vector<Range>> needs;         // ... and the ranges of it the rank reads
   DevBuf window;                                 // this rank's assembled window
+  DevBuf xnat;                                   // this rank's block in index order (right vectors that are stored swizzled)
   int64_t wlen = 0;
   int split = 0;                                 // dnm_mat_window_split
   std::vector<Range> rows_local, rows_remote;    // row split of the other window kernels
@@ -296,6 +297,16 @@ int mult_window(dnm_comm *c, dnm_mat *A, const void *x, void *y, hipStream_t st)
   const int P = c->world(), me = c->me();
   const int64_t wlo = W.wlo[(size_t)me], whi = W.whi[(size_t)me] + 1;
   const int64_t my0 = W.own0[(size_t)me], myn = W.ownn[(size_t)me];
+  // The window is expressed in index order (or, for SpinConserve vectors in the internal layout, in positions of the
+  // layout, where blocks travel as they lie): a block of a Full / Parity vector that is stored XOR-swizzled (odd rank counts,
+  // projections between subspaces) is straightened first -- what the peers receive and what the rank's own part of the
+  // window holds is index order.
+  if (!A->use_sc3 && A->right.host.swz != 0) {
+    DNM_CHECK(c->vrank < 0, "loop-back: window partitions of swizzled vectors are not looped back");
+    if (W.xnat.bytes < (size_t)A->n_local * 16) DNM_TRY(W.xnat.alloc((size_t)A->n_local * 16));
+    DNM_TRY(dnm_vec_swizzle_copy(W.xnat.p, x, A->n_local, A->right.host.swz, st));
+    x = W.xnat.p;
+  }
   // the exchange: x is ready when the compute stream gets here
   DNM_HIP(hipEventRecord(c->ev_ready, st));
   DNM_HIP(hipStreamWaitEvent(c->xs, c->ev_ready, 0));
@@ -636,8 +647,6 @@ int dnm_mat_mult_partitioned(dnm_mat *A, dnm_comm *c, const void *x, void *y, vo
   if (A->nranks == 1) return dnm_mat_mult(A, x, y, stream);
   if (A->tr_hi) return mult_transposed(c, A, x, y, st);
   if (A->hypercube && A->plan.use_tiled) return mult_partner(c, A, x, y, st);
-  DNM_CHECK(A->use_sc3 || A->right.host.swz == 0,
-            "window partitions assemble their window in index order: swizzled right vectors go through the host schedule");
   return mult_window(c, A, x, y, st);
 }
 
@@ -660,7 +669,6 @@ int dnm_comm_prepare(dnm_comm *c, dnm_mat *A, void *stream) {
     PartnerState &Q = c->par[A];
     return Q.ready ? 0 : setup_partner(A, Q);
   }
-  if (!(A->use_sc3 || A->right.host.swz == 0)) return 0;
   WindowState &W = c->win[A];
   return W.ready ? 0 : setup_windows(c, A, W, (hipStream_t)stream);
 }

@@ -352,11 +352,9 @@ def _native_ran(H, case):
         return
     mats = list(H._mats.values())
     assert mats
-    if case not in ("projection", "full_odd", "parity_odd"):
-        # (window partitions of swizzled vectors stay on the host schedule: comm.cpp says why)
-        for m in mats:
-            assert m._native is not None, "the native schedule did not run (%s)" % case
-            assert m._tr is None, "the host's transposed schedule was built beside the native one (%s)" % case
+    for m in mats:
+        assert m._native is not None, "the native schedule did not run (%s)" % case
+        assert m._tr is None, "the host's transposed schedule was built beside the native one (%s)" % case
     # the operators go first, then the communicator (the stand-in transport removes its mailboxes with the last rank)
     from dynamite_amd import backend
     H.destroy_mat()
@@ -389,8 +387,8 @@ def test_partitioned_end_to_end_one_gpu(tmp_path, case, world):
 
 @pytest.mark.parametrize("case,world", [("full", 2), ("full", 4), ("full", 8), ("parity", 4), ("sc", 3), ("sc3", 2), ("sc3", 3),
                                         ("sc3_graph", 2), ("sc_big", 3), ("explicit", 3), ("xparity_full", 2),
-                                        ("xparity_sc", 3)] +
-                         ([("full_partner", 4), ("full_transpose", 2), ("auto", 2), ("full_odd", 3)]
+                                        ("xparity_sc", 3), ("full_odd", 3), ("projection", 2)] +
+                         ([("full_partner", 4), ("full_transpose", 2), ("auto", 2), ("parity_odd", 3), ("projection", 3)]
                           if os.environ.get("DNM_TEST_LARGEST") == "1" else []))
 def test_native_schedule_between_rank_processes(tmp_path, monkeypatch, case, world):
     """The NATIVE schedule (dnm_mat_mult_partitioned, dnm_comm_hooks -- the default on RCCL transports) between real rank
