@@ -653,22 +653,31 @@ def config5_dry_run(world, rank, Lk):
     from dynamite_amd.subspaces import SpinConserve
     L, k = Lk
     sub = SpinConserve(L, k)
-    d = _lib.Subspace.from_buffer_copy(sub._c())
     a, w = (14, 10) if L >= 28 else (6, 4)
-    d.vec_swizzle = a | (w << 8)
     H = models.heisenberg(L)
     H.establish_L()
     H.reduce_msc()
     masks, offs = msc_tools.get_mask_offsets(H.msc)
-    h = backend.create_mat(masks, offs, H.msc['signs'], H.msc['coeffs'], d, d, False, _lib.MAT_HOST_ONLY, rank, world)
-    lo, hi = C.c_int64(), C.c_int64()
-    _lib.check(_lib.lib().dnm_mat_column_window(h, C.byref(lo), C.byref(hi), None))
-    window = (lo.value, hi.value)
-    shift = max(0, int(hi.value - lo.value + 1).bit_length() - backend.ShellMat.WINDOW_CHUNKS.bit_length())
-    n = (hi.value >> shift) - (lo.value >> shift) + 1
-    cmap = np.zeros(n, dtype=np.uint8)
-    _lib.check(_lib.lib().dnm_mat_column_chunks(h, shift, cmap.ctypes.data_as(C.POINTER(C.c_uint8)), n, None))
-    needs = backend.needed_ranges(cmap, shift, window)
+
+    def plan(order):
+        """(descriptor, handle, window, exact needed ranges) of this rank in one block order of the layout"""
+        dd = _lib.Subspace.from_buffer_copy(sub._c())
+        dd.vec_swizzle = a | (w << 8) | (order << 16)
+        hh = backend.create_mat(masks, offs, H.msc['signs'], H.msc['coeffs'], dd, dd, False, _lib.MAT_HOST_ONLY, rank, world)
+        lo, hi = C.c_int64(), C.c_int64()
+        _lib.check(_lib.lib().dnm_mat_column_window(hh, C.byref(lo), C.byref(hi), None))
+        nr = C.c_int64()
+        _lib.check(_lib.lib().dnm_mat_column_ranges(hh, 0, None, C.byref(nr)))
+        rg = (C.c_int64 * (2 * max(1, nr.value)))()
+        _lib.check(_lib.lib().dnm_mat_column_ranges(hh, nr.value, rg, C.byref(nr)))
+        return dd, hh, (lo.value, hi.value), [(int(rg[2 * i]), int(rg[2 * i + 1])) for i in range(nr.value)]
+    # the reference-compatible partition (planned only: its volume beside the other's) ...
+    d0, h0, _, needs0 = plan(0)
+    i00, il0 = backend.layout_partition(d0, world, rank)[:2]
+    remote0 = sum(max(0, min(b_, i00) - a_) + max(0, b_ - max(a_, i00 + il0)) for a_, b_ in needs0)
+    _lib.check(_lib.lib().dnm_mat_destroy(h0))
+    # ... and the one made for the exchange, which eigsolve(getvecs=False) takes on several ranks: posted for real
+    d, h, window, needs = plan(1)
     allw = [None] * world
     dist.all_gather_object(allw, (window, needs))
     windows, allneeds = [v[0] for v in allw], [v[1] for v in allw]
@@ -680,13 +689,16 @@ def config5_dry_run(world, rank, Lk):
     for a_, b_ in needs:
         ok = ok and bool((buf[a_ - window[0]:b_ - window[0]].real == torch.arange(a_, b_, dtype=torch.float64)).all())
     recvs, sends = backend.window_exchange_ops(owned, windows, rank, allneeds)
-    t = torch.tensor([0.0 if ok else 1.0, float(sum(16 * (b_ - a_) for _, a_, b_ in recvs))], dtype=torch.float64)
+    t = torch.tensor([0.0 if ok else 1.0, float(sum(16 * (b_ - a_) for _, a_, b_ in recvs)), 16.0 * remote0],
+                     dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     _lib.check(_lib.lib().dnm_mat_destroy(h))
-    return {"workload": "DRY RUN: window exchange of the Heisenberg chain in SpinConserve(%d,%d) on %d ranks, layout (%d,%d)"
-                        % (L, k, world, a, w),
+    return {"workload": "DRY RUN: window exchange of the Heisenberg chain in SpinConserve(%d,%d) on %d ranks, layout (%d,%d), "
+                        "on the partition made for the exchange (block order 1)" % (L, k, world, a, w),
             "dim": sub.get_dimension(), "exchange": "window", "exchange_ok": bool(t[0] == 0.0),
-            "bytes_received_per_multiply_busiest_rank": int(t[1]), "window_bytes_rank0": 16 * (window[1] - window[0] + 1),
+            "bytes_received_per_multiply_busiest_rank": int(t[1]),
+            "bytes_received_per_multiply_busiest_rank_reference_compatible_partition": int(t[2]),
+            "window_bytes_rank0": 16 * (window[1] - window[0] + 1),
             "ranges_read_rank0": len(needs), "heisenberg": None, "known_answer_xx_chain": None}
 
 
@@ -883,13 +895,19 @@ def config5(wd, world, rank, Lk=None, tol=1e-8):
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         st = dict(eigsolve.last_stats)
-        mat = H.get_real_packed_mat(sub) if st["real_arithmetic"] else H.get_mat(subspaces=(sub, sub))
+        # the handle the solve multiplied with: eigenvalues alone run on the partition made for the exchange
+        # (Operator.get_solver_mat: T blocks in an order whose contiguous ranges cut one bond of the chain)
+        mat = eigsolve.last_mat
         summ = mat.exchange_summary()
+        ref = (H.get_real_packed_mat(sub) if st["real_arithmetic"] else H.get_mat(subspaces=(sub, sub))).exchange_summary()
         r = {"wall_s": dt, "includes": "building the operator (tables, windows of all ranks) and the solve",
              "matvecs": st["matvecs"], "ms_per_step": dt / max(1, st["matvecs"]) * 1e3, "E0": float(ev[0]),
              "measured_rel_residual": st["max_rel_residual"], "tol": tol,
              "arithmetic": "real (f64, 8 B per amplitude)" if st["real_arithmetic"] else "complex128 (16 B per amplitude)",
              "rows_this_rank": int(mat.m_local) * (2 if st["real_arithmetic"] else 1),
+             "partition": ("made for the exchange (block order %d of the layout: csrc/sc3.h)" % (mat.swz_right >> 16)
+                           if mat.swz_right >= (1 << 16) else "reference-compatible (ranges of the reference order)"),
+             "bytes_received_per_multiply_rank0_reference_compatible_partition": int(ref["bytes_in"]),
              "exchange": summ["scheme"], "bytes_received_per_multiply_rank0": int(summ["bytes_in"]),
              "busiest_link_bytes_rank0": int(summ["busiest_link_bytes"]),
              "window_bytes_rank0": int(summ.get("window_bytes", 0)),

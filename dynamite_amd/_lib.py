@@ -168,6 +168,7 @@ SIGNATURES = {
     "dnm_comm_loopback": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "dnm_comm_allreduce": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_int]),
     "dnm_mat_mult_partitioned": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dnm_mat_column_ranges": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "dnm_comm_prepare": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "dnm_comm_set_phase": (C.c_int, [C.c_void_p, C.c_int]),
     "dnm_mat_set_exchange": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int)]),

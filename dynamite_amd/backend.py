@@ -1308,6 +1308,13 @@ class ShellMat:
         """The [lo, hi) ranges of the window this rank's rows read (one device sweep), at a resolution of
         ``WINDOW_CHUNKS`` chunks over the window."""
         lo, hi = window
+        # exactly, where the library knows it without a sweep (SpinConserve in the internal layout: whole blocks)
+        n = C.c_int64()
+        _lib.check(_lib.lib().dnm_mat_column_ranges(self.handle, 0, None, C.byref(n)))
+        if 0 < n.value <= self.WINDOW_CHUNKS:
+            rg = (C.c_int64 * (2 * n.value))()
+            _lib.check(_lib.lib().dnm_mat_column_ranges(self.handle, n.value, rg, C.byref(n)))
+            return [(int(rg[2 * i]), int(rg[2 * i + 1])) for i in range(n.value)]
         shift = max(0, int(hi - lo + 1).bit_length() - self.WINDOW_CHUNKS.bit_length())
         n = (hi >> shift) - (lo >> shift) + 1
         cmap = np.zeros(n, dtype=np.uint8)

@@ -251,6 +251,16 @@ def eigsolve(H, getvecs=False, nev=1, which='lowest', target=None, tol=None, sub
         if _min_over_ranks(0 if pm is None else 1) == 1:
             mat = pm
     packed = mat is not cmat
+    # Eigenvalues alone need no vector in the reference's order: on several ranks a SpinConserve operator in the internal
+    # layout is solved on a partition made for the exchange (dnm_subspace.vec_swizzle bits 16-19 = 1, csrc/sc3.h: the T
+    # blocks ordered so that contiguous ranges cut ONE bond of a chain instead of log2(ranks) + 1 -- SpinConserve(36,18) on
+    # 8 ranks: 14.3 GiB to the busiest rank per multiply instead of 42.4).  The start vector holds the numbers the
+    # reference order would (keyed by reference index), so the Krylov space is the same one.
+    if not getvecs and config.sc_solver_partition:
+        sm = H.get_solver_mat(subspace, packed)
+        if _min_over_ranks(0 if sm is None else 1) == 1:
+            mat = sm
+    eigsolve.last_mat = mat
     keep = []
     hooks = _hooks(mat, keep)
     import torch
@@ -356,6 +366,7 @@ def eigsolve(H, getvecs=False, nev=1, which='lowest', target=None, tol=None, sub
 
 
 eigsolve.last_stats = None
+eigsolve.last_mat = None          # the handle the last call multiplied with (bench.py: its exchange summary)
 
 
 def reduced_density_matrix(state, keep):

@@ -202,6 +202,19 @@ std::vector<Range> ranges_of(const std::vector<uint8_t> &map, int shift, int64_t
 // one rank's window and needs from its handle (device sweeps, cached in the handle)
 int window_of(dnm_mat *A, int64_t *lo, int64_t *hi, std::vector<Range> *needs, hipStream_t st) {
   DNM_TRY(dnm_mat_column_window(A, lo, hi, st));
+  {
+    // exact runs of needed blocks where the library has them (SpinConserve in the internal layout), as long as they fit
+    // the fixed-size record the ranks exchange; else the chunk map
+    int64_t n = 0;
+    DNM_TRY(dnm_mat_column_ranges(A, 0, nullptr, &n));
+    if (n > 0 && n <= WINDOW_CHUNKS) {
+      std::vector<int64_t> rg((size_t)(2 * n));
+      DNM_TRY(dnm_mat_column_ranges(A, n, rg.data(), &n));
+      needs->clear();
+      for (int64_t i = 0; i < n; ++i) needs->push_back({rg[(size_t)(2 * i)], rg[(size_t)(2 * i + 1)]});
+      return 0;
+    }
+  }
   int shift = 0;
   while (((*hi - *lo + 1) >> shift) > WINDOW_CHUNKS) ++shift;
   const int64_t n = (*hi >> shift) - (*lo >> shift) + 1;

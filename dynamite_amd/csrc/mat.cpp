@@ -897,7 +897,7 @@ int dnm_mat_create(int64_t nmasks, const int64_t *masks, const int64_t *mask_off
   }
   if (A->use_sc3) {
     const SubView &h = A->left.host;
-    const Sc3Layout *ly = sc3_get(h.L, h.k, sc3_code_a(h.sc3), sc3_code_w(h.sc3), !A->host_only);
+    const Sc3Layout *ly = sc3_get(h.L, h.k, sc3_code_a(h.sc3), sc3_code_w(h.sc3), !A->host_only, sc3_code_order(h.sc3));
     DNM_CHECK(ly, "could not build the SpinConserve vector layout");
     A->sc3.reset(new Sc3Mat());
     // partitioned: whole T blocks per rank (a contiguous range of both the internal layout and the reference order)
@@ -1471,6 +1471,20 @@ int dnm_mat_column_window(dnm_mat *A, int64_t *cmin, int64_t *cmax, void *stream
   }
   *cmin = A->win_min;
   *cmax = A->win_max;
+  return 0;
+}
+
+int dnm_mat_column_ranges(dnm_mat *A, int64_t max_ranges, int64_t *ranges, int64_t *nranges) {
+  DNM_CHECK(A && nranges && max_ranges >= 0 && (ranges || max_ranges == 0), "bad argument");
+  *nranges = 0;
+  if (!A->use_sc3) return 0;             // (other partitions: dnm_mat_column_chunks)
+  const auto rg = A->sc3->ranges();
+  *nranges = (int64_t)rg.size();
+  const int64_t unit = A->real_packed ? 2 : 1;       // a real-packed handle counts pairs of positions (whole blocks: even)
+  for (int64_t i = 0; i < *nranges && i < max_ranges; ++i) {
+    ranges[2 * i] = rg[(size_t)i].first / unit;
+    ranges[2 * i + 1] = rg[(size_t)i].second / unit;
+  }
   return 0;
 }
 

@@ -20,6 +20,7 @@
 
 #include <array>
 #include <cstdint>
+#include <utility>
 #include <vector>
 
 #include <hip/hip_runtime.h>
@@ -34,6 +35,15 @@ constexpr int SC3_MAXA = 16, SC3_MAXW = 12;
 static inline int sc3_code(int a, int w) { return a | (w << 8); }
 static inline int sc3_code_a(int code) { return code & 0xff; }
 static inline int sc3_code_w(int code) { return (code >> 8) & 0xff; }
+// Order of the T blocks in memory (bits 16-19 of the code).  0: ascending T -- the reference's order, so that a rank's
+// contiguous share of the layout is a contiguous range of the reference order too.  1 (round 6; vectors that live inside a
+// solver): by (popcount(T >> 1), popcount of T's upper half, T >> 1, T & 1).  The two blocks that differ in T's lowest bit
+// -- partners under the W/T boundary bond -- lie side by side; a chain's bonds inside T >> 1 keep the first key; only ONE
+// bond -- between T's two lowest bits -- changes it.  A partition into contiguous ranges of this order cuts far fewer hops
+// than ranges of ascending T, which cut every bond among the top log2(ranks) + 1 spins: SpinConserve(36,18) on 8 ranks,
+// busiest rank: 14.3 GiB received per multiply instead of 42.2 (complex128), mean 11.3 instead of 25.5.  A rank's share is then NO range of the reference
+// order: the maps to and from it (dnm_vec_layout_copy / _positions) serve whole vectors only.
+static inline int sc3_code_order(int code) { return (code >> 16) & 0xf; }
 
 struct Sc3Tab {
   int32_t L, k, a, w, t;
@@ -111,7 +121,11 @@ struct Sc3Layout {
   std::vector<int64_t> ibase, nbase, icoff, ncoff, nck;
   std::vector<uint16_t> lo_pat, w_pat, lo_rank, w_rank;
   std::vector<int32_t> cbin;
-  std::vector<uint32_t> rows;      // every row (T << w | W) of the layout, in reference order
+  std::vector<uint32_t> rows;      // every row (T << w | W) of the layout, block by block in the layout's block order
+  int order = 0;                   // sc3_code_order
+  std::vector<uint32_t> tseq;      // the non-empty T blocks in the order they lie in memory
+  std::vector<uint32_t> tidx;      // [1 << t] place of a T block in tseq (0xffffffff: empty block)
+  std::vector<size_t> rowstart;    // [tseq.size() + 1] first row of a block inside `rows`
   std::vector<uint64_t> w_nb;
   void *d_w_nb = nullptr;
   std::vector<uint16_t> lo_rlo, lo_rhi;
@@ -123,17 +137,22 @@ struct Sc3Layout {
   Sc3Layout &operator=(const Sc3Layout &) = delete;
   ~Sc3Layout();
   // 0 on success; want_device: upload the tables
-  int init(int L, int k, int a, int w, bool want_device);
+  int init(int L, int k, int a, int w, bool want_device, int order = 0);
+  // is T one of the blocks [b0, b1) of the block sequence?
+  bool in_range(uint32_t T, uint32_t b0, uint32_t b1) const {
+    return T < tidx.size() && tidx[T] != 0xffffffffu && tidx[T] >= b0 && tidx[T] < b1;
+  }
 };
 
 // does a (L, k, a, w) combination describe a usable layout?
 bool sc3_valid(int L, int k, int a, int w);
 // shared, cached layouts (a process uses a handful): the pointer stays valid for the life of the process
-const Sc3Layout *sc3_get(int L, int k, int a, int w, bool want_device);
+const Sc3Layout *sc3_get(int L, int k, int a, int w, bool want_device, int order = 0);
 
 // ---- vector-level operations (sc3_kernels.hip) --------------------------------------------------------------
-// All of them act on the part of a vector that covers the T blocks [T0, T1) (default: everything): the vectors
-// start at that range's first position of the internal layout / first index of the reference order.
+// All of them act on the part of a vector that covers the blocks [T0, T1) OF THE LAYOUT'S BLOCK SEQUENCE (Sc3Layout::tseq;
+// places in it, not values of T -- default: everything): the vectors start at that range's first position of the internal
+// layout / first index of the reference order (block order 0; in any other order only whole vectors have a reference side).
 // dst (internal) <- src (reference order) when to_internal, else dst (reference order) <- src (internal);
 // padding of an internal destination is zeroed
 int sc3_layout_copy(const Sc3Layout &Ly, void *dst, const void *src, bool to_internal, hipStream_t st, uint32_t T0 = 0,
@@ -211,15 +230,17 @@ struct Sc3Call {
   double *dot_out = nullptr;       // 3 * sc3_dot_partials() doubles: per-workgroup <x,y> (re, im) and |y|^2
 };
 
-// Partition of the layout over ranks: rank r owns the T blocks [Tb[r], Tb[r+1]) (whole blocks, balanced by internal
-// length), i.e. a contiguous range of the internal layout AND of the reference order.  Tb has nranks + 1 entries.
+// Partition of the layout over ranks: rank r owns the blocks [Tb[r], Tb[r+1]) of the block sequence (whole blocks, balanced
+// by internal length), i.e. a contiguous range of the internal layout -- and, in block order 0, of the reference order.
+// Tb has nranks + 1 entries.
 std::vector<uint32_t> sc3_partition(const Sc3Layout &ly, int nranks);
-// internal / reference offsets of the block range [T0, T1): start and length
+// internal / reference offsets of the block range [T0, T1) of the sequence: start and length (block orders other than 0:
+// *nstart = -1 unless the range starts the sequence; *nlen = the states in the range)
 void sc3_range(const Sc3Layout &ly, uint32_t T0, uint32_t T1, int64_t *istart, int64_t *ilen, int64_t *nstart, int64_t *nlen);
 
 struct Sc3Mat {
   const Sc3Layout *ly = nullptr;
-  uint32_t T0 = 0, T1 = 0;         // the T blocks this rank's rows cover
+  uint32_t T0 = 0, T1 = 0;         // the blocks of the layout's sequence this rank's rows cover
   int64_t row0 = 0;                // internal position of its first row
   std::vector<uint32_t> rowsel;    // its rows (T << w | W), for the row kernel
   void *d_rowsel = nullptr;
@@ -248,6 +269,8 @@ struct Sc3Mat {
   // the internal positions [lo, hi] this rank's rows read; marks the chunks of 2^shift positions among them
   void window(int64_t *lo, int64_t *hi) const;
   void chunks(int shift, int64_t first_chunk, int64_t nchunks, uint8_t *map) const;
+  // ... and exactly: the needed blocks merged into maximal runs of positions [lo, hi), ascending
+  std::vector<std::pair<int64_t, int64_t>> ranges() const;
 };
 bool sc3_instance(int a, int w);           // kernel instances exist for this field split
 // the two passes for operators on any bond graph (sc3g_kernels.hip); same contract as launch_sc3's tiled branch

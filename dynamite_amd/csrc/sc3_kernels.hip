@@ -1011,8 +1011,10 @@ static int up(const std::vector<T_> &v, void **d) {
   return 0;
 }
 
-int Sc3Layout::init(int L, int k, int a, int w, bool want_device) {
+int Sc3Layout::init(int L, int k, int a, int w, bool want_device, int order_) {
   DNM_CHECK(sc3_valid(L, k, a, w), "no such vector layout: L=%d k=%d a=%d w=%d", L, k, a, w);
+  DNM_CHECK(order_ == 0 || order_ == 1, "unknown block order %d of a SpinConserve layout", order_);
+  order = order_;
   Sc3Tab &S = host;
   S = Sc3Tab{};
   S.L = L; S.k = k; S.a = a; S.w = w; S.t = L - a - w;
@@ -1108,18 +1110,44 @@ int Sc3Layout::init(int L, int k, int a, int w, bool want_device) {
   nbase.assign((size_t)1 << t, -1);
   rows.clear();
   int64_t ni = 0, nn = 0;
+  // reference indices: ascending T
+  tseq.clear();
   for (uint32_t T = 0; T < (1u << t); ++T) {
     const int kr = k - __builtin_popcount(T);
     if (kr < 0 || kr > a + w) continue;
-    ibase[T] = ni;
     nbase[T] = nn;
-    ni += isize[kr];
     nn += hbinom(a + w, kr);
+    tseq.push_back(T);
+  }
+  // the order the blocks lie in (sc3_code_order)
+  if (order == 1) {
+    // by (ones of T above its lowest bit, ones of T's upper half, T >> 1, T & 1): the two blocks that differ in T's lowest
+    // bit -- partners under the W/T boundary bond -- lie side by side, the bonds inside T >> 1 keep the first key, and of
+    // a chain's bonds only the one between T's two lowest bits changes it (sc3.h: sc3_code_order)
+    const int th = t / 2;
+    std::stable_sort(tseq.begin(), tseq.end(), [th](uint32_t x, uint32_t y) {
+      const int px = __builtin_popcount(x >> 1), py = __builtin_popcount(y >> 1);
+      if (px != py) return px < py;
+      const int hx = __builtin_popcount(x >> th), hy = __builtin_popcount(y >> th);
+      if (hx != hy) return hx < hy;
+      return x < y;                    // (T >> 1, then T & 1)
+    });
+  }
+  tidx.assign((size_t)1 << t, 0xffffffffu);
+  rowstart.assign(tseq.size() + 1, 0);
+  for (size_t b = 0; b < tseq.size(); ++b) {
+    const uint32_t T = tseq[b];
+    const int kr = k - __builtin_popcount(T);
+    tidx[T] = (uint32_t)b;
+    ibase[T] = ni;
+    ni += isize[kr];
+    rowstart[b] = rows.size();
     for (uint32_t W = 0; W < (1u << w); ++W) {
       const int kl = kr - __builtin_popcount(W);
       if (kl >= 0 && kl <= a) rows.push_back((T << w) | W);
     }
   }
+  rowstart[tseq.size()] = rows.size();
   S.nint = ni;
   dim = nn;
   DNM_CHECK(nn == hbinom(L, k), "internal: layout does not cover the subspace");
@@ -1168,15 +1196,15 @@ int Sc3Layout::init(int L, int k, int a, int w, bool want_device) {
   return 0;
 }
 
-const Sc3Layout *sc3_get(int L, int k, int a, int w, bool want_device) {
+const Sc3Layout *sc3_get(int L, int k, int a, int w, bool want_device, int order) {
   static std::mutex mu;
-  static std::map<std::array<int, 5>, std::unique_ptr<Sc3Layout>> cache;
+  static std::map<std::array<int, 6>, std::unique_ptr<Sc3Layout>> cache;
   std::lock_guard<std::mutex> g(mu);
-  const std::array<int, 5> key{L, k, a, w, want_device ? 1 : 0};
+  const std::array<int, 6> key{L, k, a, w, want_device ? 1 : 0, order};
   auto it = cache.find(key);
   if (it != cache.end()) return it->second.get();
   std::unique_ptr<Sc3Layout> lay(new Sc3Layout());
-  if (lay->init(L, k, a, w, want_device)) return nullptr;
+  if (lay->init(L, k, a, w, want_device, order)) return nullptr;
   return (cache[key] = std::move(lay)).get();
 }
 
@@ -1184,17 +1212,21 @@ const Sc3Layout *sc3_get(int L, int k, int a, int w, bool want_device) {
 // the rows of the T blocks [T0, T1) inside Ly.rows (sorted by T, then W) and the offsets of that range
 struct RowRange { size_t first, count; int64_t ioff, noff; };
 static RowRange row_range(const Sc3Layout &Ly, uint32_t T0, uint32_t T1) {
-  const int w = Ly.host.w;
-  const auto lo = std::lower_bound(Ly.rows.begin(), Ly.rows.end(), (uint64_t)T0 << w,
-                                   [](uint32_t e, uint64_t v) { return (uint64_t)e < v; });
-  const auto hi = std::lower_bound(Ly.rows.begin(), Ly.rows.end(), (uint64_t)T1 << w,
-                                   [](uint32_t e, uint64_t v) { return (uint64_t)e < v; });
+  const uint32_t nb = (uint32_t)Ly.tseq.size();
+  const uint32_t b0 = std::min(T0, nb), b1 = std::max(b0, std::min(T1, nb));
   RowRange r;
-  r.first = (size_t)(lo - Ly.rows.begin());
-  r.count = (size_t)(hi - lo);
+  r.first = Ly.rowstart[b0];
+  r.count = Ly.rowstart[b1] - Ly.rowstart[b0];
   int64_t il, nl;
   sc3_range(Ly, T0, T1, &r.ioff, &il, &r.noff, &nl);
   return r;
+}
+// the maps between a layout and the reference order need the range's reference side to be a range too: every range of
+// block order 0, whole vectors of the others
+static int ref_side(const Sc3Layout &Ly, const RowRange &r) {
+  DNM_CHECK(Ly.order == 0 || (r.first == 0 && r.count == Ly.rows.size()),
+            "a rank's share of a SpinConserve layout in block order %d is no range of the reference order", Ly.order);
+  return 0;
 }
 
 bool sc3_perm_make(const int8_t *site_perm, int L, Sc3Perm *out) {
@@ -1229,6 +1261,7 @@ int sc3_layout_copy(const Sc3Layout &Ly, void *dst, const void *src, bool to_int
   const RowRange r = row_range(Ly, T0, T1);
   if (!r.count) return 0;
   DNM_TRY(perm_whole(Ly, perm, r));
+  DNM_TRY(ref_side(Ly, r));
   if (perm && perm->on) {
     hipLaunchKernelGGL(sc3_copy_perm_kernel<c128>, dim3((unsigned)r.count), dim3(256), 0, st, Ly.dev, *perm,
                        (const uint32_t *)Ly.d_rows, (c128 *)dst, (const c128 *)src, to_internal ? 1 : 0);
@@ -1246,6 +1279,7 @@ int sc3_layout_copy_f64(const Sc3Layout &Ly, double *dst, const double *src, boo
   const RowRange r = row_range(Ly, T0, T1);
   if (!r.count) return 0;
   DNM_TRY(perm_whole(Ly, perm, r));
+  DNM_TRY(ref_side(Ly, r));
   if (perm && perm->on) {
     hipLaunchKernelGGL(sc3_copy_perm_kernel<double>, dim3((unsigned)r.count), dim3(256), 0, st, Ly.dev, *perm,
                        (const uint32_t *)Ly.d_rows, dst, src, to_internal ? 1 : 0);
@@ -1315,6 +1349,7 @@ int sc3_positions(const Sc3Layout &Ly, int64_t n, const int64_t *idx, int64_t *p
   DNM_CHECK(n < ((int64_t)1 << 32), "more than 2^32 indices in one call (one thread each: a launch holds fewer)");
   const RowRange r = row_range(Ly, T0, T1);
   DNM_TRY(perm_whole(Ly, perm, r));
+  DNM_TRY(ref_side(Ly, r));
   if (perm && perm->on) {
     hipLaunchKernelGGL(sc3_positions_perm_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, Ly.dev, *perm, n, idx, pos);
     DNM_HIP(hipGetLastError());
@@ -1398,31 +1433,41 @@ Sc3Mat::~Sc3Mat() {
 
 static int64_t block_len(const Sc3Layout &ly, uint32_t T) {        // internal length of the T block
   if (ly.ibase[T] < 0) return 0;
-  for (uint32_t U = T + 1; U < (1u << ly.host.t); ++U)
-    if (ly.ibase[U] >= 0) return ly.ibase[U] - ly.ibase[T];
-  return ly.host.nint - ly.ibase[T];
+  const uint32_t b = ly.tidx[T];                                     // (the next block of the layout's sequence, whatever its order)
+  return (b + 1 < (uint32_t)ly.tseq.size() ? ly.ibase[ly.tseq[b + 1]] : ly.host.nint) - ly.ibase[T];
 }
 
 std::vector<uint32_t> sc3_partition(const Sc3Layout &ly, int nranks) {
-  const uint32_t nT = 1u << ly.host.t;
-  std::vector<uint32_t> Tb((size_t)nranks + 1, nT);
+  const uint32_t nb = (uint32_t)ly.tseq.size();
+  std::vector<uint32_t> Tb((size_t)nranks + 1, nb);
   Tb[0] = 0;
-  uint32_t T = 0;
+  uint32_t b = 0;
   for (int r = 1; r < nranks; ++r) {
     const int64_t target = (int64_t)((__int128)ly.host.nint * r / nranks);
-    while (T < nT && (ly.ibase[T] < 0 || ly.ibase[T] < target)) ++T;
-    Tb[r] = T;
+    while (b < nb && ly.ibase[ly.tseq[b]] < target) ++b;
+    Tb[r] = b;
   }
   return Tb;
 }
 
 void sc3_range(const Sc3Layout &ly, uint32_t T0, uint32_t T1, int64_t *istart, int64_t *ilen, int64_t *nstart, int64_t *nlen) {
-  const uint32_t nT = 1u << ly.host.t;
-  auto first_valid = [&](uint32_t T) { while (T < nT && ly.ibase[T] < 0) ++T; return T; };
-  const uint32_t A = first_valid(T0), B = first_valid(T1);
-  const int64_t i0 = A < nT ? ly.ibase[A] : ly.host.nint, i1 = B < nT ? ly.ibase[B] : ly.host.nint;
-  const int64_t n0 = A < nT ? ly.nbase[A] : ly.dim, n1 = B < nT ? ly.nbase[B] : ly.dim;
-  *istart = i0; *ilen = i1 - i0; *nstart = n0; *nlen = n1 - n0;
+  const uint32_t nb = (uint32_t)ly.tseq.size();
+  const uint32_t b0 = std::min(T0, nb), b1 = std::max(b0, std::min(T1, nb));
+  const int64_t i0 = b0 < nb ? ly.ibase[ly.tseq[b0]] : ly.host.nint, i1 = b1 < nb ? ly.ibase[ly.tseq[b1]] : ly.host.nint;
+  *istart = i0;
+  *ilen = i1 - i0;
+  if (ly.order == 0) {
+    const int64_t n0 = b0 < nb ? ly.nbase[ly.tseq[b0]] : ly.dim, n1 = b1 < nb ? ly.nbase[ly.tseq[b1]] : ly.dim;
+    *nstart = n0;
+    *nlen = n1 - n0;
+    return;
+  }
+  // any other block order: the states of the range (its reference side is a range only for the whole sequence)
+  int64_t n = 0;
+  const int aw = ly.host.a + ly.host.w;
+  for (uint32_t b = b0; b < b1; ++b) n += hbinom(aw, ly.host.k - __builtin_popcount(ly.tseq[b]));
+  *nstart = b0 == 0 ? 0 : -1;
+  *nlen = n;
 }
 
 void Sc3Mat::window(int64_t *lo, int64_t *hi) const {
@@ -1435,6 +1480,20 @@ void Sc3Mat::window(int64_t *lo, int64_t *hi) const {
   if (b < a) a = b = row0;
   *lo = a;
   *hi = b;
+}
+
+// the needed blocks as maximal runs of positions [lo, hi), ascending
+std::vector<std::pair<int64_t, int64_t>> Sc3Mat::ranges() const {
+  std::vector<std::pair<int64_t, int64_t>> blk;
+  for (uint32_t T = 0; T < (uint32_t)needT.size(); ++T)
+    if (needT[T] && ly->ibase[T] >= 0) blk.push_back({ly->ibase[T], ly->ibase[T] + block_len(*ly, T)});
+  std::sort(blk.begin(), blk.end());
+  std::vector<std::pair<int64_t, int64_t>> out;
+  for (const auto &b : blk) {
+    if (!out.empty() && out.back().second == b.first) out.back().second = b.second;
+    else out.push_back(b);
+  }
+  return out;
 }
 
 void Sc3Mat::chunks(int shift, int64_t first_chunk, int64_t nchunks, uint8_t *map) const {
@@ -1461,13 +1520,17 @@ int Sc3Mat::init(const Sc3Layout *layout, const std::vector<int64_t> &masks, con
     sc3_range(*ly, T0, T1, &row0, &il, &ns, &nl);
   }
   rowsel.clear();
-  for (uint32_t e : ly->rows) if ((e >> w) >= T0 && (e >> w) < T1) rowsel.push_back(e);
+  {
+    const uint32_t nb = (uint32_t)ly->tseq.size();
+    const uint32_t b0 = std::min(T0, nb), b1 = std::max(b0, std::min(T1, nb));
+    rowsel.assign(ly->rows.begin() + (ptrdiff_t)ly->rowstart[b0], ly->rows.begin() + (ptrdiff_t)ly->rowstart[b1]);
+  }
   if (rowsel.empty()) rowsel.push_back(0xffffffffu);
   if (want_device) DNM_TRY(up(rowsel, &d_rowsel));
   // the T blocks these rows read: their own and, for every mask that flips bits of T, the partner's
   needT.assign((size_t)1 << t, 0);
-  for (uint32_t T = T0; T < T1; ++T) {
-    if (ly->ibase[T] < 0) continue;
+  for (uint32_t bq = T0; bq < T1 && bq < (uint32_t)ly->tseq.size(); ++bq) {
+    const uint32_t T = ly->tseq[bq];
     needT[T] = 1;
     for (int64_t m = 0; m < nmasks; ++m) {
       const uint64_t hm = (uint64_t)masks[m] >> (a + w);
@@ -1649,7 +1712,8 @@ int Sc3Mat::init(const Sc3Layout *layout, const std::vector<int64_t> &masks, con
   // dispatch order: workgroups that gather from each other run on one XCD at one time (their requests meet in that
   // XCD's L2).  Window pass: groups (kt, cw, run) over the T's of a popcount class -- siblings under the T bonds.
   std::vector<std::vector<uint32_t>> Tby(t + 1), gA, gB;
-  for (uint32_t T = T0; T < T1 && T < (1u << t); ++T) if (ly->ibase[T] >= 0) Tby[__builtin_popcount(T)].push_back(T);
+  for (uint32_t bq = T0; bq < T1 && bq < (uint32_t)ly->tseq.size(); ++bq) Tby[__builtin_popcount(ly->tseq[bq])].push_back(ly->tseq[bq]);
+  for (auto &v : Tby) std::sort(v.begin(), v.end());
   for (int kt = 0; kt <= t; ++kt) {
     if (Tby[kt].empty()) continue;
     const int kr = k - kt;
@@ -1716,7 +1780,7 @@ int Sc3Mat::init(const Sc3Layout *layout, const std::vector<int64_t> &masks, con
         std::vector<uint32_t> g;
         for (uint32_t sset : subs) {
           const uint32_t id = ((Tb << w) | W0) | sset, T = id >> w, W = id & wm;
-          if (T < T0 || T >= T1 || ly->ibase[T] < 0) continue;
+          if (!ly->in_range(T, T0, T1)) continue;
           const int kl = k - __builtin_popcount(T) - __builtin_popcount(W);
           if (kl >= 0 && kl <= a) g.push_back(id);
         }

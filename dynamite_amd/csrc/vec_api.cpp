@@ -135,7 +135,7 @@ static const Sc3Layout *layout_of(const dnm_subspace *s, bool device) {
     set_error("no such vector layout: L=%d k=%d a=%d w=%d", (int)s->L, (int)s->k, a, w);
     return nullptr;
   }
-  return sc3_get((int)s->L, (int)s->k, a, w, device);
+  return sc3_get((int)s->L, (int)s->k, a, w, device, sc3_code_order(s->vec_swizzle));
 }
 
 // the descriptor's site relabelling

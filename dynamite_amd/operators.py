@@ -372,10 +372,53 @@ class Operator:
         self._mats[key] = mat
         return mat
 
+    SOLVER_BLOCK_ORDER = 1
+
+    def get_solver_mat(self, subspace, real):
+        """The operator on ``subspace`` for vectors that live INSIDE a solver (no state of the caller's ever meets them):
+        SpinConserve in the internal layout on several ranks, its T blocks in the order made for partitions
+        (``dnm_subspace.vec_swizzle`` bits 16-19 = 1, csrc/sc3.h) -- a rank's contiguous share is no range of the
+        reference order, but its rows read far less from other ranks.  None where that does not apply (one rank, other
+        subspaces, operators that need a cached diagonal: its rows are computed in reference order)."""
+        from .subspaces import SpinConserve
+        key = ('solver', hash(subspace), bool(real))
+        if key in self._mats:
+            return self._mats[key]
+        mat = None
+        if (config.world_size > 1 and isinstance(subspace, SpinConserve) and 256 <= subspace.vec_swizzle < (1 << 16)
+                and self.shell):
+            self.establish_L()
+            self.reduce_msc()
+            masks, mask_offsets = msc_tools.get_mask_offsets(self.msc)
+            desc = subspace._to_c()
+            d = type(desc['data']).from_buffer_copy(desc['data'])
+            d.vec_swizzle = int(d.vec_swizzle) | (self.SOLVER_BLOCK_ORDER << 16)
+            sd = {'type': desc['type'], 'data': d, '_keep': desc}
+            ws = config.world_size
+            rows = [backend.layout_partition(d, ws, q)[3] for q in range(ws)]
+            if min(rows) <= 0 or max(rows) > 1.5 * sum(rows) / ws:
+                self._mats[key] = None        # (few, uneven blocks: this order has nothing to share out)
+                return None
+            try:
+                mat = backend.build_mat(
+                    masks=np.ascontiguousarray(masks), mask_offsets=np.ascontiguousarray(mask_offsets),
+                    signs=np.ascontiguousarray(self.msc['signs']), coeffs=np.ascontiguousarray(self.msc['coeffs']),
+                    left_subspace=sd, right_subspace=sd, flags=_lib.MAT_REAL_PACKED if real else 0, site_perm=False)
+            except _lib.BackendError as e:
+                if 'real-packed' not in str(e):
+                    raise
+                mat = None
+            if mat is not None and (mat.uses_cached_diagonal() or 'internal layout' not in mat.describe()):
+                mat.destroy()
+                mat = None
+        self._mats[key] = mat
+        return mat
+
     def destroy_mat(self, subspaces=None):
         keys = [(hash(subspaces[0]), hash(subspaces[1]))] if subspaces is not None else list(self._mats)
         if subspaces is not None:
             keys.append(('real_packed', hash(subspaces[0])))
+            keys += [('solver', hash(subspaces[0]), r) for r in (False, True)]
         for k in keys:
             mat = self._mats.pop(k, None)
             if mat is not None:

@@ -306,6 +306,12 @@ int dnm_mat_column_window(dnm_mat *A, int64_t *cmin, int64_t *cmax, void *stream
  * ranks: 1.5 blocks needed of a 4.2-block window): only marked chunks have to be received, the multiply never
  * reads the others (the reference scatters exactly the entries it needs, bpetsc_template_2.c:413-504) */
 int dnm_mat_column_chunks(dnm_mat *A, int chunk_shift, uint8_t *map, int64_t nchunks, void *stream);
+/* The same exactly, where the library knows it without a sweep (SpinConserve pairs in the internal layout: whole blocks of
+ * equal top bits): the positions the rank's rows read as maximal runs [lo, hi), ascending -- ranges[2 i], ranges[2 i + 1];
+ * *nranges = their number (call with max_ranges = 0 to size the array; 0 for every other partition: use the chunk map).
+ * In the block order that keeps the reference's ranges (dnm_subspace.vec_swizzle bits 16-19 = 0) the chunk map is as
+ * good; in the order made for partitions (1) the needed blocks interleave with others and only this list is tight. */
+int dnm_mat_column_ranges(dnm_mat *A, int64_t max_ranges, int64_t *ranges, int64_t *nranges);
 /* y_local = A[own rows, :] x, x_window holding columns [win_start, win_start + win_len) */
 int dnm_mat_mult_window(dnm_mat *A, const void *x_window, int64_t win_start, int64_t win_len,
                         void *y_local, void *stream);

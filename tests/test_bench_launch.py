@@ -41,6 +41,8 @@ def test_bench_spawns_its_ranks(n):
     c5 = out["secondary"]["config5"]
     assert c5["exchange"] == "window" and c5["exchange_ok"] is True and c5["dim"] == 48620
     assert 0 < c5["bytes_received_per_multiply_busiest_rank"] < 16 * c5["dim"]
+    # ... on the partition made for the exchange: less than the reference-compatible one moves
+    assert c5["bytes_received_per_multiply_busiest_rank"] <= c5["bytes_received_per_multiply_busiest_rank_reference_compatible_partition"]
     assert {"heisenberg", "known_answer_xx_chain"} <= set(c5) and out["secondary_ok"] is True
     assert out["config"]["schedule"].startswith("host") and "exchange_selfcheck" in out["config"]
     cfg = out["config"]

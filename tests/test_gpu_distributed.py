@@ -318,6 +318,61 @@ def _worker(rank, world, port, case, out_dir):
         v2g = v2[0].to_numpy(to_all=True)
         assert np.linalg.norm(Hs @ v2g - e2[0] * v2g) < 1e-7
 
+    if case == "sc3":
+        # The partition made for the exchange (dnm_subspace.vec_swizzle bits 16-19 = 1, csrc/sc3.h): the T blocks in an order
+        # whose contiguous ranges cut one bond of the chain.  A rank's share is no range of the reference order, so the
+        # global vector goes through the WHOLE-vector map on every rank (test size) and is cut by positions of the layout.
+        import ctypes as _C
+        import torch
+        from dynamite_amd import backend as _b, _lib as _l, _comm as _cm
+        from gpu_util import marshal
+        desc = sub._to_c()
+        d1 = type(desc['data']).from_buffer_copy(desc['data'])
+        d1.vec_swizzle = int(d1.vec_swizzle) | (1 << 16)
+        sd = {'type': desc['type'], 'data': d1, '_keep': desc}
+        m1 = _b.build_mat(*marshal(H), sd, sd, site_perm=False)
+        assert "internal layout" in m1.describe() and m1.swz_right >> 16 == 1
+        nint = _C.c_int64()
+        _l.check(_l.lib().dnm_vec_layout_size(_C.byref(d1), _C.byref(nint)))
+        whole = _l.Partition(0, 1)
+        full = torch.zeros(nint.value, dtype=torch.complex128, device=config.device)
+        nat = torch.from_numpy(xg).to(config.device)
+        _l.check(_l.lib().dnm_vec_layout_copy(_C.byref(d1), _C.byref(whole), _C.c_void_p(full.data_ptr()),
+                                              _C.c_void_p(nat.data_ptr()), 1, None))
+        shares = [_b.layout_partition(d1, world, q) for q in range(world)]
+        i0, il = shares[rank][0], shares[rank][1]
+        assert sum(s_[1] for s_ in shares) == nint.value and all(s_[1] > 0 for s_ in shares)
+        assert [s_[2] for s_ in shares[1:]] == [-1] * (world - 1)          # no reference side beyond the first share
+        x1 = _b.Vec(dim, array=full[i0:i0 + il].clone(), swz=m1.swz_right, sub_c=d1)
+        y1 = _b.Vec(dim, swz=m1.swz_left, sub_c=d1)
+        m1.mult(x1, y1)
+        if os.environ.get("DNM_NATIVE_COMM") == "1":
+            assert m1._native is not None
+        parts = _cm.gather_varied(y1.array, [s_[1] for s_ in shares], dst=0)
+        if rank == 0:
+            yfull = torch.cat(parts)
+            ynat = torch.empty(dim, dtype=torch.complex128, device=config.device)
+            _l.check(_l.lib().dnm_vec_layout_copy(_C.byref(d1), _C.byref(whole), _C.c_void_p(ynat.data_ptr()),
+                                                  _C.c_void_p(yfull.data_ptr()), 0, None))
+            assert np.max(np.abs(ynat.cpu().numpy() - ref)) < 1e-12, "multiply on the partition made for the exchange"
+        # ... and it receives no more than the reference-compatible partition does
+        s1, s0 = m1.exchange_summary(), H.get_mat().exchange_summary()
+        assert s1["scheme"] == "window" and s1["bytes_in"] <= s0["bytes_in"] * 1.5 + 16 * 64
+        m1.destroy()
+        # eigenvalues alone are solved there (Operator.get_solver_mat) whenever its blocks can be shared out
+        from dynamite_amd.computations import eigsolve as _eig
+        for real in ("0", "1"):
+            os.environ["DNM_EIGS_REAL"] = real
+            e_only = H.eigsolve(nev=2, tol=1e-10, subspace=sub)
+            os.environ.pop("DNM_EIGS_REAL")
+            assert np.max(np.abs(np.array(e_only[:2]) - lowest)) < 1e-8, "eigenvalues on the solver's own partition"
+            sm = H.get_solver_mat(sub, real == "1")
+            assert (_eig.last_mat is sm) == (sm is not None)
+            if sm is not None:
+                assert sm.swz_right >> 16 == 1 and sm.real_packed == (real == "1")
+        if rank == 0:
+            print("solver partition in use: %s" % (H.get_solver_mat(sub, False) is not None), flush=True)
+
     # reduced density matrix / entropy of the partitioned state
     for keep in ([0, 1, 2], [L - 3, L - 2], [1, 5, L - 1]):
         rho = reduced_density_matrix(z, keep)
@@ -350,7 +405,7 @@ def _native_ran(H, case):
     schedules would make that test a copy of the one above."""
     if os.environ.get("DNM_NATIVE_COMM") != "1":
         return
-    mats = list(H._mats.values())
+    mats = [m for m in H._mats.values() if m is not None]        # (None: a form that does not apply, remembered)
     assert mats
     for m in mats:
         assert m._native is not None, "the native schedule did not run (%s)" % case
@@ -450,7 +505,7 @@ def _check_config5(sec):
     assert c5["dim"] == 48620 and "SpinConserve(18,9)" in c5["workload"]
     h, kx = c5["heisenberg"], c5["known_answer_xx_chain"]
     assert h["exchange"] == "window" and h["matvecs"] > 10 and h["measured_rel_residual"] <= 1.01e-8
-    assert h["bytes_received_per_multiply_rank0"] > 0 and "failed_checks" not in h
+    assert h["bytes_received_per_multiply_rank0"] > 0 and "failed_checks" not in h and "partition" in h
     m = h["multiply"]
     assert m["ms"] > 0 and m["exchange_only_ms"] > 0 and m["compute_only_ms"] > 0, m
     assert kx["abs_error"] < 1e-6 and "failed_checks" not in kx

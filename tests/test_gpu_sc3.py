@@ -500,3 +500,84 @@ def test_eigsolve_real_arithmetic_spinconserve(monkeypatch, small_layout, mode):
         assert np.abs(v.to_numpy().imag).max() == 0.0
         for j in range(i):
             assert abs(v.dot(vecs[j])) < 1e-10
+
+
+def _order1(sub):
+    """descriptor dict of ``sub`` with its T blocks in the order made for partitions (vec_swizzle bits 16-19 = 1)"""
+    desc = sub._to_c()
+    d = type(desc['data']).from_buffer_copy(desc['data'])
+    d.vec_swizzle = int(d.vec_swizzle) | (1 << 16)
+    return {'type': desc['type'], 'data': d, '_keep': desc}
+
+
+@pytest.mark.parametrize("name,L,k", [("heisenberg", 13, 6), ("mbl", 14, 7), ("dm", 14, 5), ("nnn", 15, 7), ("long_range", 13, 6)])
+def test_block_order_for_partitions_on_one_rank(small_layout, name, L, k):
+    """The layout with its T blocks in the order made for partitions (csrc/sc3.h: sc3_code_order 1) is the same layout to
+    every kernel -- blocks are found through the ibase table wherever they lie: multiply against the oracle through the
+    whole-vector maps to and from the reference order, positions a bijection that differs from the reference-compatible
+    order's, seeded random vectors hold the same numbers, real arithmetic alike."""
+    import torch
+    from gpu_util import marshal
+    H = MODELS[name](L)
+    sub = SpinConserve(L, k)
+    n = sub.get_dimension()
+    sd = _order1(sub)
+    code = int(sd['data'].vec_swizzle)
+    assert code >> 16 == 1 and (code & 0xffff) == sub.vec_swizzle
+    mat = backend.build_mat(*marshal(H), sd, sd, site_perm=False)
+    if mat.uses_cached_diagonal():
+        mat.precompute_diagonal()                 # (one rank: the whole vector has a reference side)
+    assert "internal layout" in mat.describe() and mat.swz_right == code
+    x = rand_state(n, seed=L)
+    xv, yv = mat.createVecs()
+    assert xv.swz == code and xv.local_size == vec_for(sub).local_size
+    xv.set_local_from_numpy(x)
+    assert np.array_equal(xv.local_numpy(), x)
+    p1 = xv.positions(torch.arange(n, device=xv.array.device)).cpu().numpy()
+    p0 = vec_for(sub).positions(torch.arange(n, device=xv.array.device)).cpu().numpy()
+    assert len(set(p1.tolist())) == n and p1.max() < xv.local_size
+    assert (L - 10 < 4) or not np.array_equal(p0, p1)       # (eight T blocks or fewer lie in ascending order either way)
+    mat.mult(xv, yv)
+    ref = orc.matvec(orc_msc(H), orc_sub(sub), orc_sub(sub), x)
+    assert np.abs(yv.local_numpy() - ref).max() <= 64 * 2.2e-16 * np.abs(H.msc['coeffs']).sum() * np.abs(x).max()
+    # a seeded random vector: the numbers the reference order gets, whatever the block order
+    r1, r0 = mat.createVecs()[0], vec_for(sub)
+    r1.set_random(5)
+    r0.set_random(5)
+    assert np.array_equal(r1.local_numpy(), r0.local_numpy())
+    mat.destroy()
+
+
+def test_block_order_for_partitions_production_instance():
+    """... and the (14, 10) instances at SpinConserve(26, 13) (10.4 M states, T = 2 bits: four blocks in the order
+    0, 1, 2, 3 -> 0, 1 | 2, 3 by ones above the lowest bit): multiply against the oracle, complex and real arithmetic."""
+    from gpu_util import marshal
+    L, k = 26, 13
+    H = models.heisenberg(L)
+    sub = SpinConserve(L, k)
+    assert sub.vec_swizzle == (14 | (10 << 8))
+    sd = _order1(sub)
+    x = rand_state(sub.get_dimension(), seed=3)
+    ref = orc.matvec(orc_msc(H), orc_sub(sub), orc_sub(sub), x, nthreads=8)
+    mat = backend.build_mat(*marshal(H), sd, sd, site_perm=False)
+    xv, yv = mat.createVecs()
+    xv.set_local_from_numpy(x)
+    mat.mult(xv, yv)
+    assert np.abs(yv.local_numpy() - ref).max() < 1e-12
+    mat.destroy()
+    pm = backend.build_mat(*marshal(H), sd, sd, flags=_lib.MAT_REAL_PACKED, site_perm=False)
+    assert pm.real_packed
+    xr = backend.Vec(sub.get_dimension(), swz=pm.swz_right, sub_c=sd['data'])
+    xr.set_local_from_numpy(x.real + 0j)
+    # pack: the real parts of the layout's positions, one double each
+    import torch
+    xp = torch.view_as_real(xr.array)[:, 0].contiguous()
+    yp = torch.zeros_like(xp)
+    xq = backend.RawVec(xp.view(torch.complex128), pm.swz_right)
+    yq = backend.RawVec(yp.view(torch.complex128), pm.swz_left)
+    pm.mult(xq, yq)
+    yfull = backend.Vec(sub.get_dimension(), swz=pm.swz_right, sub_c=sd['data'])
+    torch.view_as_real(yfull.array)[:, 0] = yp
+    refr = orc.matvec(orc_msc(H), orc_sub(sub), orc_sub(sub), x.real + 0j, nthreads=8)
+    assert np.abs(yfull.local_numpy() - refr).max() < 1e-12
+    pm.destroy()

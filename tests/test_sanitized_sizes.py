@@ -159,3 +159,47 @@ def test_kagome36_relabelling_and_handle():
     h = backend.create_mat(masks, offs, signs, coeffs, dp, dp, False, _lib.MAT_HOST_ONLY, 0, 1)
     assert "bond graph" in _describe(h)
     _lib.check(_lib.lib().dnm_mat_destroy(h))
+
+
+def test_config5_exchange_on_the_partition_made_for_it():
+    """BASELINE configs[4] on 8 ranks: what every rank receives per multiply in the reference-compatible block order
+    (ascending T: ranges of the reference order) and in the order made for partitions (dnm_subspace.vec_swizzle bits
+    16-19 = 1: contiguous ranges cut ONE bond of the chain), from host-only handles -- exact runs of needed blocks
+    (dnm_mat_column_ranges).  The busiest rank's 42 GiB become 14."""
+    L, k, P = 36, 18, 8
+    sub = SpinConserve(L, k)
+    arrs = _arrays(models.heisenberg(L))
+    recv = {}
+    for order in (0, 1):
+        d = _lib.Subspace.from_buffer_copy(sub._c())
+        d.vec_swizzle = 14 | (10 << 8) | (order << 16)
+        nint = C.c_int64()
+        _lib.check(_lib.lib().dnm_vec_layout_size(C.byref(d), C.byref(nint)))
+        at, out, nranges, wins = 0, [], [], []
+        for r in range(P):
+            istart, ilen, nstart, nlen = backend.layout_partition(d, P, r)
+            assert istart == at and ilen > 0 and 0.95 * math.comb(L, k) / P < nlen < 1.05 * math.comb(L, k) / P
+            assert (nstart >= 0) == (order == 0 or r == 0)        # a reference side only in the reference-compatible order
+            at += ilen
+            h = backend.create_mat(*arrs, d, d, False, _lib.MAT_HOST_ONLY, r, P)
+            lo, hi = C.c_int64(), C.c_int64()
+            _lib.check(_lib.lib().dnm_mat_column_window(h, C.byref(lo), C.byref(hi), None))
+            n = C.c_int64()
+            _lib.check(_lib.lib().dnm_mat_column_ranges(h, 0, None, C.byref(n)))
+            assert 0 < n.value <= 1024                              # fits the record the ranks exchange (csrc/comm.cpp)
+            rg = (C.c_int64 * (2 * n.value))()
+            _lib.check(_lib.lib().dnm_mat_column_ranges(h, n.value, rg, C.byref(n)))
+            need = [(rg[2 * i], rg[2 * i + 1]) for i in range(n.value)]
+            assert all(a < b for a, b in need) and all(need[i][1] < need[i + 1][0] for i in range(len(need) - 1))
+            assert need[0][0] == lo.value and need[-1][1] == hi.value + 1
+            assert any(a <= istart and istart + ilen <= b for a, b in need)       # a rank reads its own rows
+            out.append(sum(max(0, min(b, istart) - a) + max(0, b - max(a, istart + ilen)) for a, b in need) * 16 / 2 ** 30)
+            nranges.append(n.value)
+            wins.append((hi.value - lo.value + 1) * 16 / 2 ** 30)
+            _lib.check(_lib.lib().dnm_mat_destroy(h))
+        assert at == nint.value
+        recv[order] = out
+        assert max(wins) < 90                                       # GiB of window per rank (complex128; half in real arithmetic)
+    assert 42 < max(recv[0]) < 43 and 25 < sum(recv[0]) / P < 26
+    assert max(recv[1]) < 14.5 and sum(recv[1]) / P < 11.5
+    assert max(recv[1]) < 0.35 * max(recv[0])
