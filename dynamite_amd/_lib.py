@@ -111,6 +111,7 @@ SIGNATURES = {
     "dnm_vec_layout_unpack_real": (C.c_int, [C.POINTER(Subspace), C.POINTER(Partition), vp, vp, vp]),
     "dnm_vec_layout_size": (C.c_int, [C.POINTER(Subspace), C.POINTER(C.c_int64)]),
     "dnm_vec_layout_partition": (C.c_int, [C.POINTER(Subspace), C.c_int, C.c_int, i64p, i64p, i64p, i64p]),
+    "dnm_vec_layout_blocks": (C.c_int, [C.POINTER(Subspace), C.c_int64, i64p, i64p, i64p]),
     "dnm_vec_layout_copy": (C.c_int, [C.POINTER(Subspace), C.POINTER(Partition), vp, vp, C.c_int, vp]),
     "dnm_vec_layout_copy_f64": (C.c_int, [C.POINTER(Subspace), C.POINTER(Partition), vp, vp, C.c_int, vp]),
     "dnm_vec_layout_zero_padding": (C.c_int, [C.POINTER(Subspace), C.POINTER(Partition), vp, vp]),

@@ -119,6 +119,76 @@ def redistribute(local, src_parts, dst_parts, me):
     return out
 
 
+def layout_blocks(sub_c):
+    """(T, ibase): the T blocks of a SpinConserve internal layout in the order they lie in memory and their first
+    positions (ibase has one entry more: the layout's size) -- dnm_vec_layout_blocks, host tables."""
+    n = C.c_int64()
+    _lib.check(_lib.lib().dnm_vec_layout_blocks(C.byref(sub_c), 0, None, None, C.byref(n)))
+    T = np.zeros(n.value, dtype=np.int64)
+    ib = np.zeros(n.value + 1, dtype=np.int64)
+    _lib.check(_lib.lib().dnm_vec_layout_blocks(C.byref(sub_c), n.value, _lib.p64(T), _lib.p64(ib), C.byref(n)))
+    return T, ib
+
+
+def block_moves(d_from, d_to, nranks):
+    """What moving a partitioned vector between two layouts that differ in BLOCK ORDER only (vec_swizzle bits 16-19) takes:
+    per block in ascending T, int64 arrays (src rank, offset inside the source rank's share, dst rank, offset inside the
+    destination's share, positions).  Blocks move whole, padding included."""
+    Tf, ibf = layout_blocks(d_from)
+    Tt, ibt = layout_blocks(d_to)
+    of, ot = np.argsort(Tf, kind='stable'), np.argsort(Tt, kind='stable')
+    lf, lt = np.diff(ibf)[of], np.diff(ibt)[ot]
+    if (int(d_from.vec_swizzle) ^ int(d_to.vec_swizzle)) & 0xffff or not np.array_equal(Tf[of], Tt[ot]) \
+            or not np.array_equal(lf, lt):
+        raise ValueError('block_moves: the two layouts differ in more than the order of their blocks')
+    sf = np.array([layout_partition(d_from, nranks, q)[0] for q in range(nranks)], dtype=np.int64)
+    st = np.array([layout_partition(d_to, nranks, q)[0] for q in range(nranks)], dtype=np.int64)
+    pf, pt = ibf[:-1][of], ibt[:-1][ot]
+    # (a rank without blocks starts where the next one does: the LAST rank starting at or before a block owns it)
+    src = np.searchsorted(sf, pf, side='right') - 1
+    dst = np.searchsorted(st, pt, side='right') - 1
+    return src, pf - sf[src], dst, pt - st[dst], lf
+
+
+def reorder_blocks(local, d_from, d_to, per_position=2):
+    """This rank's share of a vector in layout ``d_to`` from its share ``local`` in layout ``d_from`` -- the same
+    SpinConserve internal layout up to the order of its T blocks (the reference-compatible one that States live in, and
+    the one made for partitions that solvers iterate in: Operator.get_solver_mat).  Collective.  ``per_position``:
+    doubles per position of the layout (2: complex128 vectors; 1: real vectors stored two positions to an element).
+    One message each way between any two ranks per round of a ring schedule (round s: to rank me + s, from rank me - s);
+    a round stages what it sends and receives, at most one share."""
+    import torch
+    from . import _comm
+    ws, me = config.world_size, config.rank
+    src, soff, dst, doff, ln = block_moves(d_from, d_to, ws)
+    u = int(per_position)
+    f = torch.view_as_real(local).reshape(-1)
+    n_from, n_to = layout_partition(d_from, ws, me)[1], layout_partition(d_to, ws, me)[1]
+    if f.numel() != u * n_from:
+        raise ValueError('reorder_blocks: the local share holds %d doubles, its layout says %d' % (f.numel(), u * n_from))
+    out = torch.empty(u * n_to, dtype=f.dtype, device=f.device)
+    mine = np.nonzero((src == me) & (dst == me))[0]
+    for j in mine:
+        out[u * doff[j]:u * (doff[j] + ln[j])] = f[u * soff[j]:u * (soff[j] + ln[j])]
+    for s in range(1, ws):
+        to, frm = (me + s) % ws, (me - s) % ws
+        js = np.nonzero((src == me) & (dst == to))[0]
+        jr = np.nonzero((src == frm) & (dst == me))[0]
+        sends, recvs, rbuf = [], [], None
+        if js.size:
+            sends.append((torch.cat([f[u * soff[j]:u * (soff[j] + ln[j])] for j in js]), to))
+        if jr.size:
+            rbuf = torch.empty(u * int(ln[jr].sum()), dtype=f.dtype, device=f.device)
+            recvs.append((rbuf, frm))
+        for r in _comm.batch_p2p(sends, recvs):
+            r.wait()
+        at = 0
+        for j in jr:
+            out[u * doff[j]:u * (doff[j] + ln[j])] = rbuf[at:at + u * ln[j]]
+            at += u * int(ln[j])
+    return torch.view_as_complex(out.reshape(-1, 2))
+
+
 def window_exchange_ops(owned, windows, me, needs=None):
     """Who sends what to whom so that every rank holds the columns of its window.
     owned[q] = (start, n) of rank q's block; windows[q] = inclusive (cmin, cmax) rank q reads; needs[q] (optional)

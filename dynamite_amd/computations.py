@@ -109,6 +109,40 @@ def _adopt(mat, state, result):
     return state.vec, result.vec
 
 
+def _solver_mat(H, subspace, real):
+    """The operator on the partition made for the exchange (Operator.get_solver_mat) if every rank has one, else None."""
+    if not config.sc_solver_partition or config.world_size == 1:
+        return None
+    sm = H.get_solver_mat(subspace, real)
+    return sm if _min_over_ranks(0 if sm is None else 1) == 1 else None
+
+
+class _OnSolverPartition:
+    """x and y of a solve on the partition made for the exchange: the input state's share moves there block by block
+    (backend.reorder_blocks: one vector's worth of traffic, where every multiply of the solve saves about that much --
+    SpinConserve(36,18) on 8 ranks: 42 -> 14 GiB on the busiest rank), the result moves back into the State."""
+
+    def __init__(self, sm, xin, yout):
+        import torch
+        from . import backend
+        self.sm, self.yout = sm, yout
+        self.x = backend.reorder_blocks(xin.array, xin.sub_c, sm._keep[1])
+        self.y = torch.empty_like(self.x)
+        self.xptr, self.yptr = C.c_void_p(self.x.data_ptr()), C.c_void_p(self.y.data_ptr())
+
+    @staticmethod
+    def applies(sm, xin, yout):
+        return (sm is not None and xin.internal and yout.internal and not xin.half and not yout.half
+                and xin.perm is None and yout.perm is None
+                and (xin.swz & 0xffff) == (yout.swz & 0xffff) == (sm.swz_right & 0xffff))
+
+    def finish(self):
+        from . import backend
+        self.x = None
+        self.yout.array.copy_(backend.reorder_blocks(self.y, self.sm._keep[1], self.yout.sub_c))
+        self.y = None
+
+
 def evolve(H, state, t, result=None, tol=None, ncv=None, algo=None, max_its=None):
     r"""result = exp(-i H t) state   (computations.py:10-126)."""
     state.assert_initialized()
@@ -138,6 +172,17 @@ def evolve(H, state, t, result=None, tol=None, ncv=None, algo=None, max_its=None
     # (an operator on a bond graph works in a relabelled layout of its own: the states adopt it, as in Operator.dot)
     xin, yout = _adopt(mat, state, result)
     mat.check_layout(xin, yout)
+    # several ranks, SpinConserve in the internal layout: the iteration runs on the partition made for the exchange
+    sm = _solver_mat(H, state.subspace, False)
+    side = None
+    if _OnSolverPartition.applies(sm, xin, yout):
+        side = _OnSolverPartition(sm, xin, yout)
+        mat = sm
+        hooks = _hooks(mat, keep)
+        xptr, yptr = side.xptr, side.yptr
+    else:
+        xptr, yptr = xin.ptr, yout.ptr
+    evolve.last_mat = mat
     mat.prepare_exchange(state.vec.array)
     free, _ = torch.cuda.mem_get_info()
     if free < 34 * 16 * mat.n_local:      # the default basis would not fit: hand torch's cached blocks back first
@@ -154,12 +199,13 @@ def evolve(H, state, t, result=None, tol=None, ncv=None, algo=None, max_its=None
             warnings.warn('evolve: only %d Krylov vectors of %.1f GiB fit in device memory; using '
                           "algo='chebyshev' (4 work vectors)" % (max(fit, 0), 16 * mat.n_local / 2 ** 30),
                           stacklevel=2)
+            side = None
             return _evolve_chebyshev(H, state, t, result, tol)
         if fit < 3:
             raise RuntimeError('not enough device memory for a Krylov basis: %d vectors of %.1f GiB fit'
                                % (max(fit, 0), 16 * mat.n_local / 2 ** 30))
     _lib.check(_lib.lib().dnm_expm_multiply(
-        mat.handle, xin.ptr, yout.ptr, mat.n_local, scale.real, scale.imag,
+        mat.handle, xptr, yptr, mat.n_local, scale.real, scale.imag,
         0.0 if tol is None else float(tol), 0 if ncv is None else int(ncv),
         # an explicit algo='krylov' / 'expokit' keeps the Krylov scheme to the end (the driver hands the rest of a
         # real-time interval to the Chebyshev expansion only under all-default parameters)
@@ -176,11 +222,14 @@ def evolve(H, state, t, result=None, tol=None, ncv=None, algo=None, max_its=None
         raise ConvergenceError('solver failed to converge with MFN_DIVERGED_BREAKDOWN.')
     elif stats.reason <= 0:
         raise ConvergenceError('solver failed to converge.')
+    if side is not None:
+        side.finish()
     result.set_initialized()
     return result
 
 
 evolve.last_stats = None
+evolve.last_mat = None            # the handle the last call multiplied with
 
 
 def _evolve_chebyshev(H, state, t, result, tol):
@@ -195,15 +244,26 @@ def _evolve_chebyshev(H, state, t, result, tol):
     stats = _lib.SolverStats()
     xin, yout = _adopt(mat, state, result)
     mat.check_layout(xin, yout)
+    sm = _solver_mat(H, state.subspace, False)
+    side = None
+    xptr, yptr = xin.ptr, yout.ptr
+    if _OnSolverPartition.applies(sm, xin, yout):
+        side = _OnSolverPartition(sm, xin, yout)
+        mat = sm
+        hooks = _hooks(mat, keep)
+        xptr, yptr = side.xptr, side.yptr
+    evolve.last_mat = mat
     mat.prepare_exchange(state.vec.array)
     _lib.check(_lib.lib().dnm_expm_chebyshev(
-        mat.handle, xin.ptr, yout.ptr, mat.n_local, float(complex(t).real),
+        mat.handle, xptr, yptr, mat.n_local, float(complex(t).real),
         0.0 if tol is None else float(tol), C.byref(hooks) if hooks is not None else None, C.byref(stats),
         _stream()))
     evolve.last_stats = {'reason': stats.reason, 'its': stats.its, 'matvecs': stats.matvecs,
                          'err_est': stats.err_est}
     if stats.reason <= 0:
         raise ConvergenceError('solver failed to converge.')
+    if side is not None:
+        side.finish()
     result.set_initialized()
     return result
 
@@ -251,15 +311,16 @@ def eigsolve(H, getvecs=False, nev=1, which='lowest', target=None, tol=None, sub
         if _min_over_ranks(0 if pm is None else 1) == 1:
             mat = pm
     packed = mat is not cmat
-    # Eigenvalues alone need no vector in the reference's order: on several ranks a SpinConserve operator in the internal
+    # The solver's own vectors need not lie in the reference's order: on several ranks a SpinConserve operator in the internal
     # layout is solved on a partition made for the exchange (dnm_subspace.vec_swizzle bits 16-19 = 1, csrc/sc3.h: the T
     # blocks ordered so that contiguous ranges cut ONE bond of a chain instead of log2(ranks) + 1 -- SpinConserve(36,18) on
     # 8 ranks: 14.3 GiB to the busiest rank per multiply instead of 42.4).  The start vector holds the numbers the
     # reference order would (keyed by reference index), so the Krylov space is the same one.
-    if not getvecs and config.sc_solver_partition:
-        sm = H.get_solver_mat(subspace, packed)
-        if _min_over_ranks(0 if sm is None else 1) == 1:
-            mat = sm
+    # Eigenvectors move back block by block at the end (backend.reorder_blocks).
+    base = mat
+    sm = _solver_mat(H, subspace, packed)
+    if sm is not None:
+        mat = sm
     eigsolve.last_mat = mat
     keep = []
     hooks = _hooks(mat, keep)
@@ -337,9 +398,18 @@ def eigsolve(H, getvecs=False, nev=1, which='lowest', target=None, tol=None, sub
     from .states import State
     from .backend import Vec
     evecs = []
+    pieces = [evec_buf[i * mat.n_local:(i + 1) * mat.n_local] for i in range(nconv)]
+    if mat is not base:
+        # from the solver's partition to the one States live on, one vector at a time (the buffer goes as the last leaves)
+        from .backend import reorder_blocks
+        moved = []
+        for i in range(nconv):
+            moved.append(reorder_blocks(pieces[i], mat._keep[1], base._keep[1], per_position=1 if packed else 2))
+            pieces[i] = None
+        pieces, evec_buf, mat = moved, None, base
     for i in range(nconv):
         v = State(L=H.L, subspace=subspace)
-        piece = evec_buf[i * mat.n_local:(i + 1) * mat.n_local]
+        piece = pieces[i]
         if packed:
             # the real eigenvector as the complex state of the full dimension (imaginary parts zero)
             if mat.swz_right >= 256:      # SpinConserve: one double per position of the PACKED handle's own layout

@@ -61,8 +61,9 @@ class _Config:
         # misbehave on a machine nobody has tested it on.
         v = os.environ.get('DNM_NATIVE_COMM', '')
         self.native_comm = None if v == '' else v == '1'
-        # eigsolve without eigenvectors of a partitioned SpinConserve operator in the internal layout: on the partition made
-        # for the exchange (Operator.get_solver_mat; DNM_SC_SOLVER_PARTITION=0: the reference-compatible one)
+        # evolve / eigsolve of a partitioned SpinConserve operator in the internal layout iterate on the partition made for
+        # the exchange (Operator.get_solver_mat; states move there and back block by block, backend.reorder_blocks;
+        # DNM_SC_SOLVER_PARTITION=0: everything on the reference-compatible one)
         self.sc_solver_partition = knob('DNM_SC_SOLVER_PARTITION', '1') != '0'
         # eigsolve of a real-symmetric operator (every matrix element real in the product basis): real arithmetic on
         # vectors stored two amplitudes to a complex128 element (Full / Parity, on a power-of-two number of ranks) or one

@@ -174,6 +174,22 @@ int dnm_vec_layout_partition(const dnm_subspace *s, int nranks, int rank, int64_
   return 0;
 }
 
+int dnm_vec_layout_blocks(const dnm_subspace *s, int64_t max, int64_t *T, int64_t *ibase, int64_t *count) {
+  DNM_CHECK(count && max >= 0, "bad argument");
+  const Sc3Layout *ly = layout_of(s, false);
+  if (!ly) return 1;
+  const int64_t n = (int64_t)ly->tseq.size();
+  *count = n;
+  if (max < n) return 0;
+  DNM_CHECK(T && ibase, "null arrays");
+  for (int64_t j = 0; j < n; ++j) {
+    T[j] = ly->tseq[j];
+    ibase[j] = ly->ibase[ly->tseq[j]];
+  }
+  ibase[n] = ly->host.nint;
+  return 0;
+}
+
 int dnm_vec_layout_copy(const dnm_subspace *s, const dnm_partition *part, void *dst, const void *src, int to_internal,
                         void *stream) {
   DNM_CHECK(dst && src && dst != src, "dnm_vec_layout_copy works out of place on non-null vectors");

@@ -357,6 +357,11 @@ int dnm_vec_layout_size(const dnm_subspace *s, int64_t *n);
  * [nstart, nstart + nlen) of the reference order */
 int dnm_vec_layout_partition(const dnm_subspace *s, int nranks, int rank, int64_t *istart, int64_t *ilen,
                              int64_t *nstart, int64_t *nlen);
+/* the layout's T blocks in the order they lie in memory (the unit a partition shares out, and what moves whole between
+ * two layouts that differ in block order only -- vec_swizzle bits 16-19): T[j] = the block's value of the T field,
+ * ibase[j] = its first position; ibase[*count] = the layout's size.  max < *count (e.g. 0 with null arrays): the count
+ * alone.  T: max entries, ibase: max + 1.  Host tables only. */
+int dnm_vec_layout_blocks(const dnm_subspace *s, int64_t max, int64_t *T, int64_t *ibase, int64_t *count);
 /* `part` (null: one rank) selects the rank whose part of the vector the pointers hold; indices and positions are
  * then local to that part */
 int dnm_vec_layout_copy(const dnm_subspace *s, const dnm_partition *part, void *dst, const void *src, int to_internal,

@@ -200,6 +200,76 @@ def test_redistribute_between_partitions_gloo(tmp_path, world):
     assert float(open(tmp_path / "ok_redist.txt").read()) == 1.0
 
 
+def _reorder_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import ctypes as C
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dynamite_amd import backend, _lib
+    from dynamite_amd.subspaces import SpinConserve
+    ok = True
+    for (L, k, a, w) in ((14, 6, 6, 4), (16, 8, 6, 4), (15, 4, 8, 2)):
+        sub = SpinConserve(L, k)
+        n = sub.get_dimension()
+        ds, glob = [], []
+        for order in (0, 1):
+            d = sub._c()
+            d.vec_swizzle = a | (w << 8) | (order << 16)
+            nint = C.c_int64()
+            _lib.check(_lib.lib().dnm_vec_layout_size(C.byref(d), C.byref(nint)))
+            idx = np.arange(n, dtype=np.int64)
+            pos = np.empty_like(idx)
+            _lib.check(_lib.lib().dnm_vec_layout_positions_host(C.byref(d), None, n, _lib.p64(idx), _lib.p64(pos)))
+            g = np.zeros(nint.value, dtype=np.complex128)
+            g[pos] = (idx + 1) * (1 - 3j)                      # keyed by reference index; padding stays zero
+            ds.append(d)
+            glob.append(torch.from_numpy(g))
+        shares = [backend.layout_partition(d, world, rank)[:2] for d in ds]
+        mine = [g[s:s + c].clone() for g, (s, c) in zip(glob, shares)]
+        T0, ib0 = backend.layout_blocks(ds[0])
+        T1, ib1 = backend.layout_blocks(ds[1])
+        ok = ok and sorted(T0) == sorted(T1) and list(T0) == sorted(T0) and ib0[-1] == ib1[-1] == glob[0].numel()
+        there = backend.reorder_blocks(mine[0], ds[0], ds[1])
+        ok = ok and torch.equal(there, mine[1])
+        back = backend.reorder_blocks(there, ds[1], ds[0])
+        ok = ok and torch.equal(back, mine[0])
+        # real vectors stored two positions to an element: the same moves on half as many elements
+        if all(c % 2 == 0 for _, c in shares):
+            rp = [torch.view_as_complex(m.real.contiguous().reshape(-1, 2)) for m in mine]
+            got = backend.reorder_blocks(rp[0], ds[0], ds[1], per_position=1)
+            ok = ok and torch.equal(got, rp[1])
+        try:
+            backend.reorder_blocks(mine[0][:-1], ds[0], ds[1])
+            ok = False
+        except ValueError:
+            pass
+    # layouts that differ in more than the block order are refused
+    d2 = sub._c()
+    d2.vec_swizzle = 7 | (2 << 8)
+    try:
+        backend.block_moves(ds[0], d2, world)
+        ok = False
+    except (ValueError, _lib.BackendError):
+        pass
+    flag = torch.tensor([1.0 if ok else 0.0])
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        open(os.path.join(out_dir, "ok_reorder.txt"), "w").write(str(flag.item()))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_reorder_blocks_between_block_orders_gloo(tmp_path, world):
+    """backend.reorder_blocks: a rank's share of a SpinConserve vector moves between the reference-compatible block order
+    and the one made for partitions (whole T blocks over a ring of sends and receives) and back, for complex vectors and
+    for real ones stored in pairs; what a vector holds at every reference index is the same in both."""
+    import torch.multiprocessing as mp
+    mp.spawn(_reorder_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert float(open(tmp_path / "ok_reorder.txt").read()) == 1.0
+
+
 def _layout_choice_worker(rank, world, port, out_dir):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))

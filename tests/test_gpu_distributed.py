@@ -372,6 +372,32 @@ def _worker(rank, world, port, case, out_dir):
                 assert sm.swz_right >> 16 == 1 and sm.real_packed == (real == "1")
         if rank == 0:
             print("solver partition in use: %s" % (H.get_solver_mat(sub, False) is not None), flush=True)
+        # ... and so are the solves that hand vectors back: the state moves there block by block, the result moves back
+        # (backend.reorder_blocks) -- same numbers as on the reference-compatible partition
+        from dynamite_amd.computations import evolve as _ev
+        sm = H.get_solver_mat(sub, False)
+        if sm is not None:
+            za = H.evolve(x, t=0.6)
+            assert _ev.last_mat is sm
+            zc2 = H.evolve(x, t=0.6, algo='chebyshev')
+            assert _ev.last_mat is sm
+            config.sc_solver_partition = False
+            zb = H.evolve(x, t=0.6)
+            assert _ev.last_mat is H.get_mat()
+            config.sc_solver_partition = True
+            za, zb, zc2 = (v_.to_numpy(to_all=True) for v_ in (za, zb, zc2))
+            # (two partitions sum the Krylov dot products in different orders: the same answer within the solver's tolerance)
+            errs = (np.max(np.abs(za - zb)), np.max(np.abs(zc2 - want)), np.max(np.abs(za - want)))
+            assert errs[0] < 1e-9 and errs[1] < 1e-8 and errs[2] < 1e-8, "evolve on the solver's partition: %r" % (errs,)
+            for real in ("0", "1"):
+                os.environ["DNM_EIGS_REAL"] = real
+                ev_, vv_ = H.eigsolve(nev=2, getvecs=True, tol=1e-10, subspace=sub)
+                os.environ.pop("DNM_EIGS_REAL")
+                assert _eig.last_mat is H.get_solver_mat(sub, real == "1")
+                assert np.max(np.abs(np.array(ev_[:2]) - lowest)) < 1e-8
+                for e_, v_ in zip(ev_[:2], vv_[:2]):
+                    vg_ = v_.to_numpy(to_all=True)
+                    assert np.linalg.norm(Hs @ vg_ - e_ * vg_) < 1e-7, "eigenvectors moved back from the solver's partition"
 
     # reduced density matrix / entropy of the partitioned state
     for keep in ([0, 1, 2], [L - 3, L - 2], [1, 5, L - 1]):
@@ -405,7 +431,11 @@ def _native_ran(H, case):
     schedules would make that test a copy of the one above."""
     if os.environ.get("DNM_NATIVE_COMM") != "1":
         return
-    mats = [m for m in H._mats.values() if m is not None]        # (None: a form that does not apply, remembered)
+    # (None: a form that does not apply, remembered; the real-packed handle on the reference-compatible partition is only
+    # the eigenvectors' way back when the solves run on the solver's own partition: it never multiplies)
+    idle = {k for k in H._mats if isinstance(k, tuple) and k[0] == 'real_packed'
+            and H._mats.get(('solver', k[1], True)) is not None}
+    mats = [m for k, m in H._mats.items() if m is not None and k not in idle]
     assert mats
     for m in mats:
         assert m._native is not None, "the native schedule did not run (%s)" % case

@@ -2,7 +2,9 @@
 """BASELINE config 5 (SpinConserve(36, 18) Heisenberg chain on 8 ranks) in the internal three-field layout:
 what every rank owns and reads (host tables only, runs anywhere), and -- with a GPU -- one rank's share of the
 multiply at full size: its window of x in device memory, the two tiled passes, time per multiply.
-usage: sc3_config5.py [L k P] [--rank R]"""
+usage: sc3_config5.py [L k P] [--rank R] [--real] [--native-loopback] [--order 1]
+--order 1: the layout whose T blocks lie in the order made for partitions, what eigsolve without
+eigenvectors solves on."""
 import os
 os.environ.setdefault("DNM_EXPERIMENTAL", "1")   # tools drive experiment knobs
 import ctypes as C
@@ -21,9 +23,10 @@ def main():
     L, k, P = (int(args[0]), int(args[1]), int(args[2])) if len(args) >= 3 else (36, 18, 8)
     rank = int(sys.argv[sys.argv.index("--rank") + 1]) if "--rank" in sys.argv else None
     a, w = 14, 10
+    order = int(sys.argv[sys.argv.index("--order") + 1]) if "--order" in sys.argv else 0
     sub = SpinConserve(L, k)
     d = _lib.Subspace.from_buffer_copy(sub._c())
-    d.vec_swizzle = a | (w << 8)
+    d.vec_swizzle = a | (w << 8) | (order << 16)
     dim = math.comb(L, k)
     H = models.heisenberg(L)
     H.establish_L()
@@ -34,22 +37,40 @@ def main():
     print("SpinConserve(%d,%d): dim %d, internal length %d (+%.3f%%), %d ranks" % (L, k, dim, nint.value,
                                                                                  100.0 * (nint.value - dim) / dim, P))
     tot_need = 0
+    links = []
     for r in range(P):
         h = backend.create_mat(masks, offs, H.msc['signs'], H.msc['coeffs'], d, d, False, _lib.MAT_HOST_ONLY, r, P)
         istart, ilen, nstart, nlen = backend.layout_partition(d, P, r)
         lo, hi = C.c_int64(), C.c_int64()
         _lib.check(_lib.lib().dnm_mat_column_window(h, C.byref(lo), C.byref(hi), None))
-        shift = max(0, int(hi.value - lo.value + 1).bit_length() - 11)
-        n = (hi.value >> shift) - (lo.value >> shift) + 1
-        cmap = np.zeros(n, dtype=np.uint8)
-        _lib.check(_lib.lib().dnm_mat_column_chunks(h, shift, cmap.ctypes.data_as(C.POINTER(C.c_uint8)), n, None))
-        need = backend.needed_ranges(cmap, shift, (lo.value, hi.value))
+        nr = C.c_int64()
+        _lib.check(_lib.lib().dnm_mat_column_ranges(h, 0, None, C.byref(nr)))
+        if 0 < nr.value <= 1024:        # exact runs of blocks (what the schedules exchange when they are few enough)
+            rg = (C.c_int64 * (2 * nr.value))()
+            _lib.check(_lib.lib().dnm_mat_column_ranges(h, nr.value, rg, C.byref(nr)))
+            need = [(int(rg[2 * i]), int(rg[2 * i + 1])) for i in range(nr.value)]
+        else:
+            shift = max(0, int(hi.value - lo.value + 1).bit_length() - 11)
+            n = (hi.value >> shift) - (lo.value >> shift) + 1
+            cmap = np.zeros(n, dtype=np.uint8)
+            _lib.check(_lib.lib().dnm_mat_column_chunks(h, shift, cmap.ctypes.data_as(C.POINTER(C.c_uint8)), n, None))
+            need = backend.needed_ranges(cmap, shift, (lo.value, hi.value))
         remote = sum(max(0, min(b, istart) - a_) + max(0, b - max(a_, istart + ilen)) for a_, b in need)
         tot_need += remote
-        print("  rank %d: rows %d (%.2f GiB), window %.2f GiB, reads %.2f GiB from other ranks in %d ranges"
-              % (r, nlen, 16 * ilen / 2 ** 30, 16 * (hi.value - lo.value + 1) / 2 ** 30, 16 * remote / 2 ** 30, len(need)))
+        # by source: xGMI is point to point, a rank's exchange lasts as long as its busiest link
+        own = [backend.layout_partition(d, P, q)[:2] for q in range(P)]
+        by = [sum(max(0, min(b, o0 + ol) - max(a_, o0)) for a_, b in need) if q != r else 0 for q, (o0, ol) in enumerate(own)]
+        links.append(by)
+        print("  rank %d: rows %d (%.2f GiB), window %.2f GiB, reads %.2f GiB from other ranks in %d ranges; by source (GiB): %s"
+              % (r, nlen, 16 * ilen / 2 ** 30, 16 * (hi.value - lo.value + 1) / 2 ** 30, 16 * remote / 2 ** 30, len(need),
+                 " ".join("%.1f" % (16 * v / 2 ** 30) if v else "-" for v in by)))
         _lib.check(_lib.lib().dnm_mat_destroy(h))
     print("  received per multiply, mean over the ranks: %.2f GiB" % (16 * tot_need / P / 2 ** 30))
+    busiest = max(max(row) for row in links)
+    both = max(links[r][q] + links[q][r] for r in range(P) for q in range(P))
+    print("  busiest link, one direction: %.2f GiB; both directions: %.2f GiB; links in use: %d of %d"
+          % (16 * busiest / 2 ** 30, 16 * both / 2 ** 30, sum(1 for r in range(P) for q in range(r) if links[r][q] or links[q][r]),
+             P * (P - 1) // 2))
     if rank is None:
         return
     import torch
