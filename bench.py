@@ -900,6 +900,10 @@ def config5(wd, world, rank, Lk=None, tol=1e-8):
         mat = eigsolve.last_mat
         summ = mat.exchange_summary()
         ref = (H.get_real_packed_mat(sub) if st["real_arithmetic"] else H.get_mat(subspaces=(sub, sub))).exchange_summary()
+        # rank 0 is an end of the partition and receives least: what a link-bound multiply waits for is the busiest rank / link
+        mx = torch.tensor([float(summ["bytes_in"]), float(summ["busiest_link_bytes"]), float(ref["bytes_in"]),
+                           float(ref["busiest_link_bytes"])], dtype=torch.float64, device=torch.device("cuda", torch.cuda.current_device()))
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         r = {"wall_s": dt, "includes": "building the operator (tables, windows of all ranks) and the solve",
              "matvecs": st["matvecs"], "ms_per_step": dt / max(1, st["matvecs"]) * 1e3, "E0": float(ev[0]),
              "measured_rel_residual": st["max_rel_residual"], "tol": tol,
@@ -910,6 +914,9 @@ def config5(wd, world, rank, Lk=None, tol=1e-8):
              "bytes_received_per_multiply_rank0_reference_compatible_partition": int(ref["bytes_in"]),
              "exchange": summ["scheme"], "bytes_received_per_multiply_rank0": int(summ["bytes_in"]),
              "busiest_link_bytes_rank0": int(summ["busiest_link_bytes"]),
+             "bytes_received_per_multiply_busiest_rank": int(mx[0].item()), "busiest_link_bytes_any_rank": int(mx[1].item()),
+             "bytes_received_per_multiply_busiest_rank_reference_compatible_partition": int(mx[2].item()),
+             "busiest_link_bytes_any_rank_reference_compatible_partition": int(mx[3].item()),
              "window_bytes_rank0": int(summ.get("window_bytes", 0)),
              "plan": mat.describe().strip().split("\n")[0][:160]}
         if not st["max_rel_residual"] <= tol * 1.01:

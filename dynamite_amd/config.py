@@ -44,7 +44,7 @@ class _Config:
         # (14, 10): 55 KB and 63 KB LDS tiles, two workgroups per CU (profiles/r03_exp3_sc3_v2.txt).
         lay = knob('DNM_SC_LAYOUT', '14,10')
         self.sc_layout = None if lay in ('0', '') else tuple(int(v) for v in lay.split(','))
-        self.sc_layout_min_dim = 1 << 22
+        self.sc_layout_min_dim = int(knob('DNM_SC_LAYOUT_MIN_DIM', str(1 << 22)))
         # operators on a bond graph in such a subspace (one rank): relabel the spins so that as many pair hops as the
         # graph allows fall inside the layout's fields (backend._relabelled, csrc/sc3_perm.cpp); chains keep the identity
         self.sc_site_perm = knob('DNM_SC_SITE_PERM', '1') != '0'

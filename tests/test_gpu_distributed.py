@@ -583,6 +583,27 @@ def test_bench_multi_rank_flow_native_schedule(world):
     assert d["secondary_ok"] is True
 
 
+@pytest.mark.parametrize("world,native", [(4, True), (3, False)])
+def test_bench_config5_on_the_partition_made_for_the_exchange(world, native):
+    """config 5 of the line with its subspace in the internal layout (at BASELINE's size it is; here the toy size takes it
+    through DNM_SC_LAYOUT / DNM_SC_LAYOUT_MIN_DIM): the eigsolve iterates on the partition made for the exchange and the
+    line says so, with the bytes of both partitions."""
+    env = {"DNM_SC_LAYOUT": "6,4", "DNM_SC_LAYOUT_MIN_DIM": "0", "DNM_EXPERIMENTAL": "1"}
+    if native:
+        env.update(DNM_NATIVE_COMM="1", DNM_RCCL_LIB=build_fake_rccl())
+    d, _ = _bench_ranks(world, env, L=20 if world == 3 else 22)
+    _check_config5(d["secondary"])
+    for key in ("heisenberg", "known_answer_xx_chain"):
+        h = d["secondary"]["config5"][key]
+        assert h["partition"].startswith("made for the exchange (block order 1"), h["partition"]
+        assert h["bytes_received_per_multiply_rank0_reference_compatible_partition"] > 0
+        assert h["bytes_received_per_multiply_busiest_rank"] >= h["bytes_received_per_multiply_rank0"] > 0
+        assert h["busiest_link_bytes_any_rank"] <= h["bytes_received_per_multiply_busiest_rank"]
+        assert h["busiest_link_bytes_any_rank_reference_compatible_partition"] > 0
+        assert h["multiply"]["schedule"] == ("native" if native else "host")
+    assert d["secondary_ok"] is True
+
+
 def test_bench_first_contact_probe():
     """Before a rank touches its GPU a child process goes through the native schedule at a small size (here forced onto
     the stand-in transport): passed -> the native schedule is the default of the run and the probe's report is in the
