@@ -306,9 +306,7 @@ class SpinConserve(Subspace):
         rank must own rows and the largest share may exceed the mean by at most LAYOUT_MAX_IMBALANCE (L=26, k=13 on 4
         ranks would leave a rank empty and give another twice the mean; L=36, k=18 on 8 ranks is balanced to
         0.24 %).  Decided from the host tables of dnm_vec_layout_partition; the same on every rank."""
-        if nranks <= 1:
-            return True
-        key = (self.L, self.k, a, w, nranks)
+        key = (self.L, self.k, a, w, max(1, nranks))
         hit = _LAYOUT_USABLE.get(key)
         if hit is None:
             from . import backend
@@ -317,8 +315,13 @@ class SpinConserve(Subspace):
             d.ld_nchoosek = self.L + 1
             d.nchoosek = _lib.p64(self._nchoosek)
             d.vec_swizzle = a | (w << 8)
-            rows = [backend.layout_partition(d, nranks, q)[3] for q in range(nranks)]
-            mean = sum(rows) / float(nranks)
+            try:
+                rows = [backend.layout_partition(d, max(1, nranks), q)[3] for q in range(max(1, nranks))]
+            except _lib.BackendError:
+                # (an (a, w) the library has no layout for at this (L, k): more top bits than its block tables hold, or a
+                # field wider than the subspace fills -- reference order then, like a subspace too small for the layout)
+                rows = [0]
+            mean = sum(rows) / float(len(rows))
             hit = min(rows) > 0 and max(rows) <= self.LAYOUT_MAX_IMBALANCE * mean
             _LAYOUT_USABLE[key] = hit
         return hit
