@@ -70,7 +70,15 @@ class DevPass(C.Structure):
                 ("nquads", C.c_int32), ("n_eff", C.c_int32), ("quads", vp), ("dot_out", vp), ("zinit", vp), ("zscale", C.c_double), ("zinit2", vp), ("z2re", C.c_double), ("z2im", C.c_double),
                 ("tile_bits", C.c_int32), ("log_rows", C.c_int32),
                 ("swz_shift", C.c_int32), ("swz_xor_y", C.c_uint32), ("swz_xor_src", C.c_uint32), ("block_offset", C.c_uint32),
-                ("pos_tmask", C.c_uint32), ("dtile", vp)]
+                ("pos_tmask", C.c_uint32), ("dtile", vp), ("tabs", vp), ("tabvals", vp), ("tab_loop", C.c_uint32 * 3),
+                ("pad_tab", C.c_uint32)]
+
+
+class DevTab(C.Structure):
+    """plan.h: DevTab"""
+    _fields_ = [("mask_tile", C.c_uint32), ("mask_loc", C.c_uint32), ("src", C.c_uint32), ("nbits", C.c_uint32),
+                ("z_tile", C.c_uint32), ("first", C.c_uint32), ("bit_tile", C.c_uint32), ("bit_ext", C.c_uint32),
+                ("z_ext", C.c_uint64)]
 
 
 class Xfer(C.Structure):
@@ -137,6 +145,7 @@ SIGNATURES = {
     "dnm_mat_plan_launches": (C.c_int, [vp, C.POINTER(C.c_int)]),
     "dnm_mat_plan_counts": (C.c_int, [vp] + [C.POINTER(C.c_int)] * 6),
     "dnm_mat_export_dtile": (C.c_int, [vp, C.c_int, C.c_int, f64p, C.c_int64]),
+    "dnm_mat_export_tabs": (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_size_t, C.c_int, C.POINTER(C.c_int), f64p, C.c_int64, i64p]),
     "dnm_mat_export_pass": (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_size_t, vp, C.c_size_t, C.c_int,
                                       C.POINTER(C.c_int)]),
     "dnm_mat_ownership": (C.c_int, [vp, i64p, i64p]),

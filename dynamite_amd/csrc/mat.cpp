@@ -413,10 +413,71 @@ static int build_pass(const dnm_mat &A, const PassSpec &ps, PassOnDevice *out) {
   // the kernel's loops (tile/gather x k-variant x real/complex)
   struct Rec { int loop; DevQuad q; };
   std::vector<Rec> recs;
+  // masks of many terms as table records (plan.h: DevTab): the terms grouped by their sign mask outside the flipped bits,
+  // one record and one table of 2^(flipped bits) complex entries per group -- taken where that is cheaper than records of
+  // four terms (about 45 against 76 vector instructions each for four rows; DNM_TAB_RECORDS=0: never)
+  std::vector<DevTab> tabs_tile, tabs_gather;
+  std::vector<double> tabvals;
+  const char *tabs_env = knob("DNM_TAB_RECORDS");
+  const bool tabs_on = !(tabs_env && tabs_env[0] == '0');
+  auto push_tabs = [&](const RowMask &m, uint64_t mloc, bool gather, int src) -> bool {
+    const int nb = __builtin_popcountll(m.mask);
+    if (!tabs_on || op.packed || m.pack_flip || nb < 1 || nb > MAXTABBITS || m.terms.size() < 5) return false;
+    size_t nre = 0, nim = 0;
+    std::vector<uint64_t> zs;
+    for (const RowTerm &t : m.terms) {
+      (t.is_imag ? nim : nre)++;
+      const uint64_t z = t.sign & ~m.mask;
+      if (std::find(zs.begin(), zs.end(), z) == zs.end()) zs.push_back(z);
+    }
+    const size_t nq = std::max((nre + 1) / 2, (nim + 1) / 2);
+    if (nq < 2 || zs.size() * 45 >= nq * 76) return false;
+    int pb[MAXTABBITS];
+    for (int q = 0, pos = 0; pos < 64; ++pos)
+      if ((m.mask >> pos) & 1ull) pb[q++] = pos;
+    for (uint64_t z : zs) {
+      DevTab T;
+      memset(&T, 0, sizeof(T));
+      T.mask_tile = compress_to_tile(mloc & tb, ps);
+      T.mask_loc = (uint32_t)mloc;
+      T.src = (uint32_t)src;
+      T.nbits = (uint32_t)nb;
+      T.z_tile = compress_to_tile(z & tb, ps);
+      T.z_ext = z & ~tb;
+      T.first = (uint32_t)(tabvals.size() / 2);
+      T.bit_tile = T.bit_ext = 0;
+      for (int q = 0; q < nb; ++q) {
+        const bool in_tile = pb[q] < 64 && ((tb >> pb[q]) & 1ull);
+        uint32_t tpos = 0xffu;
+        if (in_tile) {
+          const uint32_t c = compress_to_tile((uint64_t)1 << pb[q], ps);
+          tpos = (uint32_t)__builtin_ctz(c);
+        }
+        T.bit_tile |= tpos << (8 * q);
+        T.bit_ext |= (uint32_t)pb[q] << (8 * q);
+      }
+      for (int j = 0; j < (1 << nb); ++j) {
+        uint64_t rowbits = 0;
+        for (int q = 0; q < nb; ++q)
+          if ((j >> q) & 1) rowbits |= (uint64_t)1 << pb[q];
+        double re = 0.0, im = 0.0;
+        for (const RowTerm &t : m.terms) {
+          if ((t.sign & ~m.mask) != z) continue;
+          const double c = (__builtin_popcountll(rowbits & t.sign & m.mask) & 1) ? -t.coeff : t.coeff;
+          (t.is_imag ? im : re) += c;
+        }
+        tabvals.push_back(re);
+        tabvals.push_back(im);
+      }
+      (gather ? tabs_gather : tabs_tile).push_back(T);
+    }
+    return true;
+  };
   auto push_mask = [&](int idx, bool gather, int src) {
     const RowMask &m = op.masks[idx];
     const uint64_t mloc = m.mask & (((uint64_t)1 << n_eff) - 1);
     if (!gather) DNM_CHECK((mloc & ~tb) == 0, "internal: tile mask leaves the tile");
+    if (push_tabs(m, mloc, gather, src)) return 0;
     std::vector<const RowTerm *> re, im;
     for (const RowTerm &t : m.terms) (t.is_imag ? im : re).push_back(&t);
     size_t ir = 0, ii = 0;
@@ -456,6 +517,20 @@ static int build_pass(const dnm_mat &A, const PassSpec &ps, PassOnDevice *out) {
 
   d.nquads = (int32_t)quads.size();
   d.need_tile = (d.has_diag || !ps.tile_masks.empty()) ? 1 : 0;
+  d.tab_loop[0] = 0;
+  d.tab_loop[1] = (uint32_t)tabs_tile.size();
+  d.tab_loop[2] = (uint32_t)(tabs_tile.size() + tabs_gather.size());
+  out->h_tabs = tabs_tile;
+  out->h_tabs.insert(out->h_tabs.end(), tabs_gather.begin(), tabs_gather.end());
+  out->h_tabvals = tabvals;
+  d.tabs = nullptr;
+  d.tabvals = nullptr;
+  if (!out->h_tabs.empty() && !A.host_only) {
+    DNM_TRY(out->tabs.upload(out->h_tabs.data(), out->h_tabs.size() * sizeof(DevTab)));
+    DNM_TRY(out->tabvals.upload(out->h_tabvals.data(), out->h_tabvals.size() * sizeof(double)));
+    d.tabs = (const DevTab *)out->tabs.p;
+    d.tabvals = (const double *)out->tabvals.p;
+  }
   out->h_quads = quads;
   if (!A.host_only) DNM_TRY(out->quads.upload(quads.data(), quads.size() * sizeof(DevQuad)));
   d.quads = (const DevQuad *)out->quads.p;
@@ -1312,6 +1387,7 @@ int dnm_mat_local_part_bits(const dnm_mat *A, int *top_free_bit, int *gathers) {
     while (hi >= 0 && ((tb >> hi) & 1)) --hi;
     if (top == -2) top = hi; else if (top != hi) top = -1;
     *gathers += (int)(p->desc.loop[LP_COUNT] - p->desc.loop[LP_GATHER_REAL]);     // gathered records
+    *gathers += (int)(p->desc.tab_loop[2] - p->desc.tab_loop[1]);
   }
   *top_free_bit = top < 0 ? -1 : top;
   return 0;
@@ -1741,6 +1817,26 @@ int dnm_mat_export_pass(const dnm_mat *A, int remote, int idx, void *desc_out, s
     DNM_CHECK(quad_bytes == sizeof(DevQuad), "DevQuad size mismatch (%zu vs %zu)", quad_bytes, sizeof(DevQuad));
     DNM_CHECK(max_quads >= *nquads, "record buffer too small");
     if (!p.h_quads.empty()) memcpy(quads_out, p.h_quads.data(), p.h_quads.size() * sizeof(DevQuad));   // (an empty pass: no null source)
+  }
+  return 0;
+}
+
+int dnm_mat_export_tabs(const dnm_mat *A, int remote, int idx, void *tabs_out, size_t tab_bytes, int max_tabs, int *ntabs,
+                        double *vals_out, int64_t max_vals, int64_t *nvals) {
+  DNM_CHECK(A && ntabs && nvals, "null argument");
+  const auto &v = remote ? A->remote_passes : A->local_passes;
+  DNM_CHECK(idx >= 0 && idx < (int)v.size(), "pass index out of range");
+  const PassOnDevice &p = *v[idx];
+  *ntabs = (int)p.h_tabs.size();
+  *nvals = (int64_t)p.h_tabvals.size();
+  if (tabs_out && !p.h_tabs.empty()) {
+    DNM_CHECK(tab_bytes == sizeof(DevTab), "DevTab size mismatch (%zu vs %zu)", tab_bytes, sizeof(DevTab));
+    DNM_CHECK(max_tabs >= *ntabs, "record buffer too small");
+    memcpy(tabs_out, p.h_tabs.data(), p.h_tabs.size() * sizeof(DevTab));
+  }
+  if (vals_out && !p.h_tabvals.empty()) {
+    DNM_CHECK(max_vals >= *nvals, "table buffer too small");
+    memcpy(vals_out, p.h_tabvals.data(), p.h_tabvals.size() * sizeof(double));
   }
   return 0;
 }

@@ -40,6 +40,9 @@ struct PassOnDevice {
   DevBuf quads;
   std::vector<double> h_dtile;    // in-tile diagonal per tile coordinate (DevPass::dtile), host copy
   DevBuf dtile;
+  std::vector<DevTab> h_tabs;     // table records (plan.h: DevTab) and their tables, host copies
+  std::vector<double> h_tabvals;
+  DevBuf tabs, tabvals;
   int partner = -1;
   int n_eff = 0;                  // index bits the pass sweeps
   int64_t y_off = 0, src_off = 0; // partner passes: first local row / first partner amplitude

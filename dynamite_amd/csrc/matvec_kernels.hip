@@ -236,6 +236,78 @@ __device__ __forceinline__ void apply_records(CQuad *__restrict__ quads, uint32_
   }
 }
 
+// Table records (plan.h: DevTab): one per mask (or group of a mask's terms) -- the coefficient of a row is a parity times
+// a table entry picked by the row's bits at the flipped positions.  Thread part of the index from tid (bits that lie in
+// the block part or in the k bits are scalar), one 16-byte load of the entry (R of them when a flipped bit is a k bit).
+typedef const __attribute__((address_space(4))) DevTab CTab;
+
+template <int R, int LOGNT, bool GATHER>
+__device__ __forceinline__ void apply_tabs(CTab *__restrict__ tabs, const c128 *__restrict__ vals, uint32_t b, uint32_t e,
+                                           double (&ar)[R], double (&ai)[R], const c128 *tile, const RowAddr<R> &RA,
+                                           const c128 *__restrict__ x, const c128 *__restrict__ xr, uint32_t tid,
+                                           uint64_t sbase, uint32_t skw, uint32_t xrx) {
+  constexpr uint32_t NT = 1u << LOGNT;
+  for (uint32_t qi = b; qi < e; ++qi) {
+    CTab &T = tabs[qi];
+    const uint32_t nb = T.nbits, bt = T.bit_tile, be = T.bit_ext;
+    uint32_t it = 0, kbits = 0;         // kbits: table bits that are k bits (bit b set: table bit b)
+    uint32_t ik[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) ik[k] = 0;
+#pragma unroll
+    for (int q = 0; q < MAXTABBITS; ++q) {
+      if (q < (int)nb) {
+        const uint32_t pos = (bt >> (8 * q)) & 0xffu;
+        if (pos == 0xffu) {
+          it |= (uint32_t)((sbase >> ((be >> (8 * q)) & 0xffu)) & 1ull) << q;
+        } else if (pos < (uint32_t)LOGNT) {
+          it |= ((tid >> pos) & 1u) << q;
+        } else {
+          kbits |= 1u << q;
+#pragma unroll
+          for (int k = 0; k < R; ++k) ik[k] |= (((uint32_t)k >> (pos - LOGNT)) & 1u) << q;
+        }
+      }
+    }
+    const c128 *__restrict__ tv = vals + T.first;
+    c128 cf[R];
+    if (kbits) {
+#pragma unroll
+      for (int k = 0; k < R; ++k) cf[k] = tv[it | ik[k]];
+    } else {
+      const c128 c0 = tv[it];
+#pragma unroll
+      for (int k = 0; k < R; ++k) cf[k] = c0;
+    }
+    c128 xv[R];
+    if constexpr (GATHER) {
+      const c128 *__restrict__ src = T.src ? xr : x;
+      const uint32_t mloc = T.mask_loc;
+      const uint32_t xm = (skw ? (mloc ^ (((mloc >> skw) & ((1u << (skw - 4)) - 1u)) << 4)) : mloc) ^ (T.src ? xrx : 0u);
+#pragma unroll
+      for (int k = 0; k < R; ++k) xv[k] = *RA.at(src, k, xm);
+    } else {
+      const uint32_t mt = T.mask_tile;
+      const uint32_t p_lo = tid ^ (mt & (NT - 1u));
+      const uint32_t mk = mt >> LOGNT;
+#pragma unroll
+      for (int k = 0; k < R; ++k) xv[k] = tile[p_lo + (((uint32_t)k ^ mk) << LOGNT)];
+    }
+    // (-1)^popcount(row & z): the thread-constant part once, the k part is uniform per k
+    const uint32_t p = (uint32_t)(__popc(tid & T.z_tile) + __popcll(sbase & T.z_ext)) & 1u;
+    const uint32_t zk = T.z_tile >> LOGNT;
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      const uint32_t pk = p ^ ((uint32_t)__popc((uint32_t)k & zk) & 1u);
+      const double cr = flip_sign(cf[k].x, pk), ci = flip_sign(cf[k].y, pk);
+      ar[k] = fma(cr, xv[k].x, ar[k]);
+      ar[k] = fma(-ci, xv[k].y, ar[k]);
+      ai[k] = fma(cr, xv[k].y, ai[k]);
+      ai[k] = fma(ci, xv[k].x, ai[k]);
+    }
+  }
+}
+
 // 4 rows per thread need 76 registers as compiled for 4 waves per SIMD -- one 1024-thread workgroup per CU at B=12
 // (19.1 ms at L=30); asked for 8 waves they fit in 64 and two workgroups run: 17.35 ms, level with 8 rows per thread
 // at half the waves (17.45; profiles/r02_exp37_waves8.txt) -- occupancy is not what the passes wait for
@@ -255,7 +327,9 @@ constexpr int tile_waves_per_simd(int B, int LOGR) {
 // GV (gather variant): 0 = gathers after the LDS masks; 1 = right behind the tile loads, before the barrier
 // (default: sibling workgroups then ask for the same lines within the same microsecond and the L2 merges the
 // requests).  (Two records in flight was tried: spills at 8 rows per thread, no gain at 16.)
-template <int B, int LOGR, bool GLDS, int GV, bool PACK = false>
+// TAB: the instance that also knows table records (DevPass::tabs; passes without any run on the plain one, which this
+// parameter leaves as it was)
+template <int B, int LOGR, bool GLDS, int GV, bool PACK = false, bool TAB = false>
 __global__ void __launch_bounds__(1 << (B - LOGR), tile_waves_per_simd(B, LOGR))
 tile_pass_kernel(const DevPass P, const c128 *__restrict__ x, c128 *__restrict__ y,
                  const c128 *__restrict__ xr) {
@@ -367,6 +441,9 @@ tile_pass_kernel(const DevPass P, const c128 *__restrict__ x, c128 *__restrict__
     DNM_LOOP(LP_GATHER_KVAR_CPLX, true, true, true, false);
   }
 #undef DNM_LOOP
+  if constexpr (TAB)
+    apply_tabs<R, LOGNT, true>((CTab *)P.tabs, (const c128 *)P.tabvals, P.tab_loop[1], P.tab_loop[2], ar, ai, tile, RA, x, xr,
+                               tid, sbase, skw, P.swz_xor_src);
   DNM_PH(2, 1);
 
   // ---- diagonal, part 1 (before the barrier, under the tile loads): the terms
@@ -459,6 +536,9 @@ tile_pass_kernel(const DevPass P, const c128 *__restrict__ x, c128 *__restrict__
     DNM_LOOP(LP_GATHER_KVAR_CPLX, true, true, true, false);
   }
 #undef DNM_LOOP
+  if constexpr (TAB)
+    apply_tabs<R, LOGNT, false>((CTab *)P.tabs, (const c128 *)P.tabvals, P.tab_loop[0], P.tab_loop[1], ar, ai, tile, RA, x, xr,
+                                tid, sbase, skw, P.swz_xor_src);
 
   DNM_PH(5, 0);
   DNM_PRIO_MEM();
@@ -552,12 +632,14 @@ static int launch_cfg(const DevPass &P, bool glds, int n_loc, const void *x, voi
   using kern_t = void (*)(const DevPass, const c128 *, c128 *, const c128 *);
   kern_t k = nullptr;
   const bool pack = (P.cache_policy & 256) != 0;          // real-packed records: their own instance (early gathers only)
+  const bool tab = P.tab_loop[2] > 0;                     // table records: their own instance (early gathers, plain tile loads)
   if (pack) k = tile_pass_kernel<B, LOGR, false, 1, true>;
+  else if (tab) k = tile_pass_kernel<B, LOGR, false, 1, false, true>;
   else if (glds) k = tile_pass_kernel<B, LOGR, true, 1>;
   else if (gv == 0) k = tile_pass_kernel<B, LOGR, false, 0>;
   else k = tile_pass_kernel<B, LOGR, false, 1>;
-  static size_t attr_done[5] = {0, 0, 0, 0, 0};
-  const int slot = pack ? 4 : (glds ? 3 : gv);
+  static size_t attr_done[6] = {0, 0, 0, 0, 0, 0};
+  const int slot = pack ? 4 : (tab ? 5 : (glds ? 3 : gv));
   if (attr_done[slot] < lds) {
     DNM_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_done[slot] = lds;

@@ -74,6 +74,25 @@ struct DevQuad {
   double coeff[4];
 };
 
+// A mask with MANY terms (SYK: 16 Majorana products per set of four flipped spins) whose sign masks agree outside the
+// flipped bits: s_t = z ^ sigma_t, sigma_t inside the mask.  Its matrix element is then
+//     c(row) = (-1)^popcount(row & z) * F[the row's bits at the flipped positions],
+// F a table of 2^nbits complex numbers computed once on the host (the Walsh-Hadamard sum of the terms over the flipped
+// bits) -- one parity, one table look-up and one complex multiply per row instead of a sign, an add and a multiply per
+// TERM.  Masks whose terms fall into several such groups get one record per group.
+constexpr int MAXTABBITS = 4;
+struct DevTab {
+  uint32_t mask_tile;     // tile masks: flipped bits in tile coordinates
+  uint32_t mask_loc;      // gather masks: flipped bits of the local index (global positions)
+  uint32_t src;           // gather source slot
+  uint32_t nbits;         // flipped bits = bits of the table index (<= MAXTABBITS), in ascending index position
+  uint32_t z_tile;        // common sign bits inside the tile, tile coordinates
+  uint32_t first;         // first entry of the table in DevPass::tabvals
+  uint32_t bit_tile;      // byte b: place of table bit b in tile coordinates, 0xff: outside the tile ...
+  uint32_t bit_ext;       // byte b: ... at this bit of the global row index
+  uint64_t z_ext;         // common sign bits outside the tile (global positions, incl. rank bits)
+};
+
 // off-diagonal record ranges, in table order
 enum {
   LP_TILE_REAL_K0 = 0,   // LDS, real coefficient, k-invariant, partner keeps this thread's k (immediate LDS offsets)
@@ -135,6 +154,12 @@ struct DevPass {
   // amplitude instead of ~25 vector instructions.  Terms that see the tile AND bits outside it stay in the
   // k-bucket lists; terms outside the tile in the dext list.  Null: every tile term is in the bucket lists.
   const double *dtile;
+  // table records (DevTab): [tab_loop[0], tab_loop[1]) read their partners from the LDS tile, [tab_loop[1], tab_loop[2])
+  // gather them; tabvals: their tables, (re, im) pairs.  Passes with any run on the kernel instance that knows them.
+  const DevTab *tabs;
+  const double *tabvals;
+  uint32_t tab_loop[3];
+  uint32_t pad_tab;
 };
 
 // ---- host-side description --------------------------------------------------

@@ -219,6 +219,10 @@ int dnm_mat_plan_counts(const dnm_mat *A, int *n_local_passes, int *n_remote_pas
 int dnm_mat_export_dtile(const dnm_mat *A, int remote, int idx, double *out, int64_t n);
 int dnm_mat_export_pass(const dnm_mat *A, int remote, int idx, void *desc_out, size_t desc_bytes,
                         void *quads_out, size_t quad_bytes, int max_quads, int *nquads);
+/* the pass's table records (plan.h: DevTab -- masks of many terms, one table look-up per row instead of one sign per term)
+ * and their tables ((re, im) pairs); null buffers: the counts alone */
+int dnm_mat_export_tabs(const dnm_mat *A, int remote, int idx, void *tabs_out, size_t tab_bytes, int max_tabs, int *ntabs,
+                        double *vals_out, int64_t max_vals, int64_t *nvals);
 
 /* --- partitioned multiply: replaces the VecScatterCreateToAll all-gather of
  * bcuda_template_2.cu:161-171 with an XOR-partner exchange. ---------------- */

@@ -23,8 +23,11 @@ def _popc(v):
 
 
 class _Quads(list):
-    """The records of a pass; ``dtile``: its tabulated in-tile diagonal (DevPass::dtile), if any."""
+    """The records of a pass; ``dtile``: its tabulated in-tile diagonal (DevPass::dtile), if any; ``tabs`` / ``tabvals``:
+    its table records (plan.h: DevTab) and their tables as complex numbers."""
     dtile = None
+    tabs = ()
+    tabvals = None
 
 
 class HostMat:
@@ -58,6 +61,16 @@ class HostMat:
         _lib.check(L.dnm_mat_export_pass(self.h, remote, idx, C.byref(desc), C.sizeof(desc), quads,
                                          C.sizeof(_lib.DevQuad), nq.value, C.byref(nq)))
         out = _Quads(quads[i] for i in range(nq.value))
+        nt, nv = C.c_int(), C.c_int64()
+        _lib.check(L.dnm_mat_export_tabs(self.h, remote, idx, None, 0, 0, C.byref(nt), None, 0, C.byref(nv)))
+        assert nt.value == desc.tab_loop[2] and desc.tab_loop[0] == 0
+        if nt.value:
+            tabs = (_lib.DevTab * nt.value)()
+            vals = np.empty(nv.value, dtype=np.float64)
+            _lib.check(L.dnm_mat_export_tabs(self.h, remote, idx, tabs, C.sizeof(_lib.DevTab), nt.value, C.byref(nt),
+                                             vals.ctypes.data_as(_lib.f64p), vals.size, C.byref(nv)))
+            out.tabs = [tabs[i] for i in range(nt.value)]
+            out.tabvals = vals[0::2] + 1j * vals[1::2]
         if desc.has_diag:
             tab = np.empty(1 << desc.tile_bits, dtype=np.float64)
             rc = L.dnm_mat_export_dtile(self.h, remote, idx, tab.ctypes.data_as(_lib.f64p), tab.size)
@@ -206,6 +219,36 @@ def run_pass(hm, p, x, y, xr=None):
                     acc += cre * xv
             else:
                 acc += (cre + 1j * cim) * xv
+
+    # table records (apply_tabs): coefficient = (-1)^popc(row & z) * table[the row's bits at the flipped positions]
+    for q, T in enumerate(quads.tabs):
+        gather = q >= desc.tab_loop[1]
+        assert 1 <= T.nbits <= 4 and not (desc.cache_policy & 256)
+        idx = np.zeros(n, dtype=np.int64)
+        tcoord = tt                                   # tid | k << lognt
+        for b in range(T.nbits):
+            pos = (T.bit_tile >> (8 * b)) & 0xff
+            ext = (T.bit_ext >> (8 * b)) & 0xff
+            if pos == 0xff:
+                bit = (sbase >> np.uint64(ext)) & np.uint64(1)
+                assert not (int(tile_bits) >> ext) & 1 if ext < 64 else True
+            else:
+                assert pos < B
+                bit = (tcoord >> np.uint64(pos)) & np.uint64(1)
+                # (the two descriptions of an in-tile bit agree: tile coordinate `pos` is index bit `ext`)
+                assert int(deposit(np.array([1 << pos], dtype=np.uint64))[0]) == 1 << ext
+            idx |= bit.astype(np.int64) << b
+        coef = quads.tabvals[T.first + idx]
+        par = (_popc(tcoord & np.uint64(T.z_tile)) + _popc(sbase & np.uint64(T.z_ext))) & 1
+        coef = np.where(par == 1, -coef, coef)
+        if gather:
+            src = xr if T.src else x
+            xv = src[(rows ^ np.uint64(T.mask_loc)).astype(np.int64)]
+        else:
+            assert desc.need_tile
+            partner = base | deposit(tt ^ np.uint64(T.mask_tile))
+            xv = x[partner.astype(np.int64)]
+        acc += coef * xv
     y[:] = acc
 
 

@@ -170,6 +170,56 @@ def test_tiled_plan_full_space(monkeypatch, name, B, logR, mode):
     assert np.max(np.abs(y - ref)) <= tol, hm.describe()
 
 
+@pytest.mark.parametrize("B,logR,mode,P", [(8, 2, 2, 1), (8, 2, 1, 1), (8, 2, 0, 1), (10, 3, 2, 1), (10, 4, 1, 1),
+                                           (8, 2, 2, 2), (8, 2, 2, 4), (8, 2, 1, 2)])
+def test_table_records_syk(monkeypatch, B, logR, mode, P):
+    """Masks of many terms as table records (plan.h: DevTab; SYK: sixteen Majorana products per set of four flipped
+    spins): the emulation of the kernel's table arithmetic on the exported records against the oracle, with flipped bits in
+    the tile, in the block part and -- partitioned -- among the rank bits; DNM_TAB_RECORDS=0 gives the records of four
+    terms and the same product."""
+    L = 11
+    _cfg(monkeypatch, B, logR, mode)
+    H = models.syk(L)
+    omsc, arrs = _orc_msc(H)
+    sub = Full(L=L)
+    x = _rand(1 << L, 3)
+    ref = orc.matvec_general(omsc, orc.full(L), orc.full(L), x)
+    tol = 64 * len(arrs[0]) * EPS * np.abs(arrs[3]).max() * np.abs(x).max()
+    nloc = (1 << L) // P
+    kinds = set()
+    for use_tabs in (True, False):
+        monkeypatch.setenv("DNM_TAB_RECORDS", "1" if use_tabs else "0")
+        y = np.zeros(1 << L, dtype=complex)
+        nrec = 0
+        for r in range(P):
+            hm = HostMat(*arrs, sub._c(), sub._c(), rank=r, nranks=P)
+            assert hm.tiled == 1, hm.describe()
+            yl = np.zeros(nloc, dtype=complex)
+            for p in hm.local:
+                run_pass(hm, p, x[r * nloc:(r + 1) * nloc], yl)
+            for i, (partner, off, cnt) in enumerate(hm.recvs):
+                run_remote(hm, i, x[partner * nloc + off:partner * nloc + off + cnt], yl)
+            y[r * nloc:(r + 1) * nloc] = yl
+            for desc, quads in hm.local + hm.remote:
+                nrec += desc.loop[_lib.LP_COUNT] - desc.loop[0]
+                assert (desc.tab_loop[2] > 0) == (len(quads.tabs) > 0)
+                if not use_tabs:
+                    assert desc.tab_loop[2] == 0
+                for q, T in enumerate(quads.tabs):
+                    kinds.add(("gather" if q >= desc.tab_loop[1] else "tile", T.nbits,
+                               "ext" if 0xff in [(T.bit_tile >> (8 * b)) & 0xff for b in range(T.nbits)] else "in",
+                               "k" if any((B - logR) <= ((T.bit_tile >> (8 * b)) & 0xff) < 0xff for b in range(T.nbits)) else "t"))
+        assert np.max(np.abs(y - ref)) <= tol
+        if use_tabs:
+            with_tabs = nrec
+        else:
+            assert nrec > 2 * with_tabs         # the records of four terms the tables replaced
+    # every kind of table record was met: partners from the tile and gathered, 2 and 4 flipped bits, table bits in the
+    # thread part, among a thread's rows (k bits) and outside the tile
+    assert {k[0] for k in kinds} == {"tile", "gather"} and {k[1] for k in kinds} == {2, 4}
+    assert {k[2] for k in kinds} == {"ext", "in"} and {k[3] for k in kinds} == {"k", "t"}
+
+
 @pytest.mark.parametrize("spaces", [(0, 0), (1, 1), (0, 1), (1, 0)])
 @pytest.mark.parametrize("name", ["long_range", "ising", "mbl"])
 def test_tiled_plan_parity(monkeypatch, name, spaces):
