@@ -78,7 +78,7 @@ class DevTab(C.Structure):
     """plan.h: DevTab"""
     _fields_ = [("mask_tile", C.c_uint32), ("mask_loc", C.c_uint32), ("src", C.c_uint32), ("nbits", C.c_uint32),
                 ("z_tile", C.c_uint32), ("first", C.c_uint32), ("bit_tile", C.c_uint32), ("bit_ext", C.c_uint32),
-                ("z_ext", C.c_uint64)]
+                ("z_ext", C.c_uint64), ("last", C.c_uint32), ("pad", C.c_uint32)]
 
 
 class Xfer(C.Structure):

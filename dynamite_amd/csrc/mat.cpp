@@ -252,11 +252,41 @@ static int pack_opform(OpForm *op) {
   return 0;
 }
 
+// A mask of many terms as table records (plan.h: DevTab)?  Its terms grouped by their sign mask outside the flipped bits
+// (`zs`: one record and one table per group) -- taken where that is cheaper than records of four terms (about 45 against
+// 76 vector instructions each for four rows; DNM_TAB_RECORDS=0: never).
+static bool table_form(const OpForm &op, const RowMask &m, std::vector<uint64_t> *zs) {
+  const char *tabs_env = knob("DNM_TAB_RECORDS");
+  if (tabs_env && tabs_env[0] == '0') return false;
+  const int nb = __builtin_popcountll(m.mask);
+  if (op.packed || m.pack_flip || nb < 1 || nb > MAXTABBITS || m.terms.size() < 5) return false;
+  size_t nre = 0, nim = 0;
+  zs->clear();
+  for (const RowTerm &t : m.terms) {
+    (t.is_imag ? nim : nre)++;
+    const uint64_t z = t.sign & ~m.mask;
+    if (std::find(zs->begin(), zs->end(), z) == zs->end()) zs->push_back(z);
+  }
+  const size_t nq = std::max((nre + 1) / 2, (nim + 1) / 2);
+  return nq >= 2 && zs->size() * 45 < nq * 76;
+}
+
 static int build_pass(const dnm_mat &A, const PassSpec &ps, PassOnDevice *out) {
   const OpForm &op = A.op;
   const Plan &pl = A.plan;
   const int B = ps.B;
   int logR = ps.logR ? ps.logR : pl.cfg.logR;
+  {
+    // passes with table records: rows per thread of their own (DNM_TAB_LOG_ROWS; the per-record work of a thread -- table
+    // index, parity -- is shared by its rows)
+    std::vector<uint64_t> zs;
+    bool any = false;
+    for (int idx : ps.tile_masks) any = any || table_form(op, op.masks[idx], &zs);
+    for (int idx : ps.gather_masks) any = any || table_form(op, op.masks[idx], &zs);
+    int want = 3;
+    if (const char *e = knob("DNM_TAB_LOG_ROWS")) want = atoi(e);
+    if (any && want > logR && tile_config_supported(B, want)) logR = want;
+  }
   {
     // the thread part of a position has to fit a 32-bit byte offset (DevPass::pos_tmask): a tile that reaches above
     // bit 27 gives its top bits to the rows of a thread
@@ -413,25 +443,13 @@ static int build_pass(const dnm_mat &A, const PassSpec &ps, PassOnDevice *out) {
   // the kernel's loops (tile/gather x k-variant x real/complex)
   struct Rec { int loop; DevQuad q; };
   std::vector<Rec> recs;
-  // masks of many terms as table records (plan.h: DevTab): the terms grouped by their sign mask outside the flipped bits,
-  // one record and one table of 2^(flipped bits) complex entries per group -- taken where that is cheaper than records of
-  // four terms (about 45 against 76 vector instructions each for four rows; DNM_TAB_RECORDS=0: never)
+  // masks of many terms as table records (table_form above)
   std::vector<DevTab> tabs_tile, tabs_gather;
   std::vector<double> tabvals;
-  const char *tabs_env = knob("DNM_TAB_RECORDS");
-  const bool tabs_on = !(tabs_env && tabs_env[0] == '0');
   auto push_tabs = [&](const RowMask &m, uint64_t mloc, bool gather, int src) -> bool {
-    const int nb = __builtin_popcountll(m.mask);
-    if (!tabs_on || op.packed || m.pack_flip || nb < 1 || nb > MAXTABBITS || m.terms.size() < 5) return false;
-    size_t nre = 0, nim = 0;
     std::vector<uint64_t> zs;
-    for (const RowTerm &t : m.terms) {
-      (t.is_imag ? nim : nre)++;
-      const uint64_t z = t.sign & ~m.mask;
-      if (std::find(zs.begin(), zs.end(), z) == zs.end()) zs.push_back(z);
-    }
-    const size_t nq = std::max((nre + 1) / 2, (nim + 1) / 2);
-    if (nq < 2 || zs.size() * 45 >= nq * 76) return false;
+    if (!table_form(op, m, &zs)) return false;
+    const int nb = __builtin_popcountll(m.mask);
     int pb[MAXTABBITS];
     for (int q = 0, pos = 0; pos < 64; ++pos)
       if ((m.mask >> pos) & 1ull) pb[q++] = pos;
@@ -469,6 +487,7 @@ static int build_pass(const dnm_mat &A, const PassSpec &ps, PassOnDevice *out) {
         tabvals.push_back(re);
         tabvals.push_back(im);
       }
+      T.last = (z == zs.back()) ? 1u : 0u;        // (the groups of a mask: consecutive records, one multiply)
       (gather ? tabs_gather : tabs_tile).push_back(T);
     }
     return true;

@@ -247,8 +247,25 @@ __device__ __forceinline__ void apply_tabs(CTab *__restrict__ tabs, const c128 *
                                            const c128 *__restrict__ x, const c128 *__restrict__ xr, uint32_t tid,
                                            uint64_t sbase, uint32_t skw, uint32_t xrx) {
   constexpr uint32_t NT = 1u << LOGNT;
+  c128 xv[R];
+  bool fresh = true;        // the first record of a mask: fetch the partner amplitudes
   for (uint32_t qi = b; qi < e; ++qi) {
     CTab &T = tabs[qi];
+    if (fresh) {
+      if constexpr (GATHER) {
+        const c128 *__restrict__ src = T.src ? xr : x;
+        const uint32_t mloc = T.mask_loc;
+        const uint32_t xm = (skw ? (mloc ^ (((mloc >> skw) & ((1u << (skw - 4)) - 1u)) << 4)) : mloc) ^ (T.src ? xrx : 0u);
+#pragma unroll
+        for (int k = 0; k < R; ++k) xv[k] = *RA.at(src, k, xm);
+      } else {
+        const uint32_t mt = T.mask_tile;
+        const uint32_t p_lo = tid ^ (mt & (NT - 1u));
+        const uint32_t mk = mt >> LOGNT;
+#pragma unroll
+        for (int k = 0; k < R; ++k) xv[k] = tile[p_lo + (((uint32_t)k ^ mk) << LOGNT)];
+      }
+    }
     const uint32_t nb = T.nbits, bt = T.bit_tile, be = T.bit_ext;
     uint32_t it = 0, kbits = 0;         // kbits: table bits that are k bits (bit b set: table bit b)
     uint32_t ik[R];
@@ -270,41 +287,34 @@ __device__ __forceinline__ void apply_tabs(CTab *__restrict__ tabs, const c128 *
       }
     }
     const c128 *__restrict__ tv = vals + T.first;
-    c128 cf[R];
-    if (kbits) {
-#pragma unroll
-      for (int k = 0; k < R; ++k) cf[k] = tv[it | ik[k]];
-    } else {
-      const c128 c0 = tv[it];
-#pragma unroll
-      for (int k = 0; k < R; ++k) cf[k] = c0;
-    }
-    c128 xv[R];
-    if constexpr (GATHER) {
-      const c128 *__restrict__ src = T.src ? xr : x;
-      const uint32_t mloc = T.mask_loc;
-      const uint32_t xm = (skw ? (mloc ^ (((mloc >> skw) & ((1u << (skw - 4)) - 1u)) << 4)) : mloc) ^ (T.src ? xrx : 0u);
-#pragma unroll
-      for (int k = 0; k < R; ++k) xv[k] = *RA.at(src, k, xm);
-    } else {
-      const uint32_t mt = T.mask_tile;
-      const uint32_t p_lo = tid ^ (mt & (NT - 1u));
-      const uint32_t mk = mt >> LOGNT;
-#pragma unroll
-      for (int k = 0; k < R; ++k) xv[k] = tile[p_lo + (((uint32_t)k ^ mk) << LOGNT)];
-    }
     // (-1)^popcount(row & z): the thread-constant part once, the k part is uniform per k
     const uint32_t p = (uint32_t)(__popc(tid & T.z_tile) + __popcll(sbase & T.z_ext)) & 1u;
     const uint32_t zk = T.z_tile >> LOGNT;
+    if (kbits) {
 #pragma unroll
-    for (int k = 0; k < R; ++k) {
-      const uint32_t pk = p ^ ((uint32_t)__popc((uint32_t)k & zk) & 1u);
-      const double cr = flip_sign(cf[k].x, pk), ci = flip_sign(cf[k].y, pk);
-      ar[k] = fma(cr, xv[k].x, ar[k]);
-      ar[k] = fma(-ci, xv[k].y, ar[k]);
-      ai[k] = fma(cr, xv[k].y, ai[k]);
-      ai[k] = fma(ci, xv[k].x, ai[k]);
+      for (int k = 0; k < R; ++k) {
+        const c128 cf = tv[it | ik[k]];
+        const uint32_t pk = p ^ ((uint32_t)__popc((uint32_t)k & zk) & 1u);
+        const double cr = flip_sign(cf.x, pk), ci = flip_sign(cf.y, pk);
+        ar[k] = fma(cr, xv[k].x, ar[k]);
+        ar[k] = fma(-ci, xv[k].y, ar[k]);
+        ai[k] = fma(cr, xv[k].y, ai[k]);
+        ai[k] = fma(ci, xv[k].x, ai[k]);
+      }
+    } else {
+      const c128 c0 = tv[it];
+      const double c0r = flip_sign(c0.x, p), c0i = flip_sign(c0.y, p);
+#pragma unroll
+      for (int k = 0; k < R; ++k) {
+        const uint32_t pk = (uint32_t)__popc((uint32_t)k & zk) & 1u;      // uniform
+        const double cr = flip_sign(c0r, pk), ci = flip_sign(c0i, pk);
+        ar[k] = fma(cr, xv[k].x, ar[k]);
+        ar[k] = fma(-ci, xv[k].y, ar[k]);
+        ai[k] = fma(cr, xv[k].y, ai[k]);
+        ai[k] = fma(ci, xv[k].x, ai[k]);
+      }
     }
+    fresh = T.last != 0u;       // the groups of one mask share the partner amplitudes: one fetch per MASK
   }
 }
 
@@ -315,7 +325,15 @@ __device__ __forceinline__ void apply_tabs(CTab *__restrict__ tabs, const c128 *
 #define DNM_WAVES_4ROWS 8
 #endif
 // waves per SIMD the launch bounds ask for: what LDS lets be resident, capped at 4
-constexpr int tile_waves_per_simd(int B, int LOGR) {
+constexpr int tile_waves_per_simd(int B, int LOGR, bool TAB = false) {
+  if (TAB) {      // the instance with table records: 128 registers (64 spilled 63 of them: 853 against 199 ms for SYK at L=24)
+    int nt = 1 << (B - LOGR);
+    int blocks = (160 * 1024) / (16 << B);
+    if (blocks < 1) blocks = 1;
+    int w = blocks * nt / 256;
+    const int cap = LOGR <= 2 ? 8 : 4;       // (4 rows: 66 registers uncapped -- one short of two workgroups per CU)
+    return w < 1 ? 1 : (w > cap ? cap : w);
+  }
   int nt = 1 << (B - LOGR);
   int blocks = (160 * 1024) / (16 << B);
   if (blocks < 1) blocks = 1;
@@ -330,7 +348,7 @@ constexpr int tile_waves_per_simd(int B, int LOGR) {
 // TAB: the instance that also knows table records (DevPass::tabs; passes without any run on the plain one, which this
 // parameter leaves as it was)
 template <int B, int LOGR, bool GLDS, int GV, bool PACK = false, bool TAB = false>
-__global__ void __launch_bounds__(1 << (B - LOGR), tile_waves_per_simd(B, LOGR))
+__global__ void __launch_bounds__(1 << (B - LOGR), tile_waves_per_simd(B, LOGR, TAB))
 tile_pass_kernel(const DevPass P, const c128 *__restrict__ x, c128 *__restrict__ y,
                  const c128 *__restrict__ xr) {
   constexpr int R = 1 << LOGR;

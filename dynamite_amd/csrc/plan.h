@@ -91,6 +91,8 @@ struct DevTab {
   uint32_t bit_tile;      // byte b: place of table bit b in tile coordinates, 0xff: outside the tile ...
   uint32_t bit_ext;       // byte b: ... at this bit of the global row index
   uint64_t z_ext;         // common sign bits outside the tile (global positions, incl. rank bits)
+  uint32_t last;          // the groups of one mask are consecutive records that share the partner amplitudes (one fetch
+  uint32_t pad;           //   per MASK); last != 0 on the final one
 };
 
 // off-diagonal record ranges, in table order

@@ -221,6 +221,7 @@ def run_pass(hm, p, x, y, xr=None):
                 acc += (cre + 1j * cim) * xv
 
     # table records (apply_tabs): coefficient = (-1)^popc(row & z) * table[the row's bits at the flipped positions]
+    chain, chain_key = None, None         # the groups of one mask: consecutive records whose coefficients add up
     for q, T in enumerate(quads.tabs):
         gather = q >= desc.tab_loop[1]
         assert 1 <= T.nbits <= 4 and not (desc.cache_policy & 256)
@@ -248,7 +249,18 @@ def run_pass(hm, p, x, y, xr=None):
             assert desc.need_tile
             partner = base | deposit(tt ^ np.uint64(T.mask_tile))
             xv = x[partner.astype(np.int64)]
-        acc += coef * xv
+        key = (gather, T.mask_tile, T.mask_loc, T.src)
+        if chain is None:
+            chain, chain_key = coef, key
+        else:
+            assert key == chain_key and q != desc.tab_loop[1], "a chain of table records spans two masks"
+            chain = chain + coef
+        if T.last:
+            acc += chain * xv
+            chain = None
+        else:
+            assert T.last == 0
+    assert chain is None, "the last table record of a mask is not marked"
     y[:] = acc
 
 
