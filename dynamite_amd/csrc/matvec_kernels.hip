@@ -241,15 +241,27 @@ __device__ __forceinline__ void apply_records(CQuad *__restrict__ quads, uint32_
 // the block part or in the k bits are scalar), one 16-byte load of the entry (R of them when a flipped bit is a k bit).
 typedef const __attribute__((address_space(4))) DevTab CTab;
 
+// The tables of TABB records at a time are staged in LDS (they lie one after the other in DevPass::tabvals): the look-ups
+// then are LDS reads -- through the texture path they were half of the loads of a multiply that waits for exactly that path
+// (SYK L=24: 2.7e9 of 5.3e9 wave loads, data return 91 % busy; profiles/r06_syk_table_records.txt).
+constexpr uint32_t TABB = 32;
+constexpr uint32_t TABL_ENTRIES = TABB << MAXTABBITS;
+
 template <int R, int LOGNT, bool GATHER>
 __device__ __forceinline__ void apply_tabs(CTab *__restrict__ tabs, const c128 *__restrict__ vals, uint32_t b, uint32_t e,
                                            double (&ar)[R], double (&ai)[R], const c128 *tile, const RowAddr<R> &RA,
                                            const c128 *__restrict__ x, const c128 *__restrict__ xr, uint32_t tid,
-                                           uint64_t sbase, uint32_t skw, uint32_t xrx) {
+                                           uint64_t sbase, uint32_t skw, uint32_t xrx, c128 *tabl) {
   constexpr uint32_t NT = 1u << LOGNT;
   c128 xv[R];
   bool fresh = true;        // the first record of a mask: fetch the partner amplitudes
-  for (uint32_t qi = b; qi < e; ++qi) {
+  for (uint32_t b0 = b; b0 < e; b0 += TABB) {
+  const uint32_t b1 = (b0 + TABB < e) ? b0 + TABB : e;
+  const uint32_t f0 = tabs[b0].first, f1 = tabs[b1 - 1].first + (1u << tabs[b1 - 1].nbits);
+  __syncthreads();          // (the readers of the previous batch are done)
+  for (uint32_t i = tid; i < f1 - f0; i += NT) tabl[i] = vals[f0 + i];
+  __syncthreads();
+  for (uint32_t qi = b0; qi < b1; ++qi) {
     CTab &T = tabs[qi];
     if (fresh) {
       if constexpr (GATHER) {
@@ -286,7 +298,7 @@ __device__ __forceinline__ void apply_tabs(CTab *__restrict__ tabs, const c128 *
         }
       }
     }
-    const c128 *__restrict__ tv = vals + T.first;
+    const c128 *tv = tabl + (T.first - f0);
     // (-1)^popcount(row & z): the thread-constant part once, the k part is uniform per k
     const uint32_t p = (uint32_t)(__popc(tid & T.z_tile) + __popcll(sbase & T.z_ext)) & 1u;
     const uint32_t zk = T.z_tile >> LOGNT;
@@ -315,6 +327,7 @@ __device__ __forceinline__ void apply_tabs(CTab *__restrict__ tabs, const c128 *
       }
     }
     fresh = T.last != 0u;       // the groups of one mask share the partner amplitudes: one fetch per MASK
+  }
   }
 }
 
@@ -459,9 +472,14 @@ tile_pass_kernel(const DevPass P, const c128 *__restrict__ x, c128 *__restrict__
     DNM_LOOP(LP_GATHER_KVAR_CPLX, true, true, true, false);
   }
 #undef DNM_LOOP
+  c128 *tabl = nullptr;
+  if constexpr (TAB) {
+    __shared__ __attribute__((aligned(16))) unsigned char tabl_mem[TABL_ENTRIES * 16];
+    tabl = reinterpret_cast<c128 *>(tabl_mem);
+  }
   if constexpr (TAB)
     apply_tabs<R, LOGNT, true>((CTab *)P.tabs, (const c128 *)P.tabvals, P.tab_loop[1], P.tab_loop[2], ar, ai, tile, RA, x, xr,
-                               tid, sbase, skw, P.swz_xor_src);
+                               tid, sbase, skw, P.swz_xor_src, tabl);
   DNM_PH(2, 1);
 
   // ---- diagonal, part 1 (before the barrier, under the tile loads): the terms
@@ -556,7 +574,7 @@ tile_pass_kernel(const DevPass P, const c128 *__restrict__ x, c128 *__restrict__
 #undef DNM_LOOP
   if constexpr (TAB)
     apply_tabs<R, LOGNT, false>((CTab *)P.tabs, (const c128 *)P.tabvals, P.tab_loop[0], P.tab_loop[1], ar, ai, tile, RA, x, xr,
-                                tid, sbase, skw, P.swz_xor_src);
+                                tid, sbase, skw, P.swz_xor_src, tabl);
 
   DNM_PH(5, 0);
   DNM_PRIO_MEM();
