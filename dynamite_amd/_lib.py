@@ -76,9 +76,10 @@ class DevPass(C.Structure):
 
 class DevTab(C.Structure):
     """plan.h: DevTab"""
-    _fields_ = [("mask_tile", C.c_uint32), ("mask_loc", C.c_uint32), ("src", C.c_uint32), ("nbits", C.c_uint32),
-                ("z_tile", C.c_uint32), ("first", C.c_uint32), ("bit_tile", C.c_uint32), ("bit_ext", C.c_uint32),
-                ("z_ext", C.c_uint64), ("last", C.c_uint32), ("pad", C.c_uint32)]
+    _fields_ = [("mask_tile", C.c_uint32), ("mask_loc", C.c_uint32), ("src", C.c_uint32), ("first", C.c_uint32),
+                ("z_tile", C.c_uint32), ("flags", C.c_uint32), ("tpos", C.c_uint32), ("twid", C.c_uint32),
+                ("epos", C.c_uint32), ("ewid", C.c_uint32), ("z_ext", C.c_uint64), ("ik", C.c_uint64),
+                ("ksign", C.c_uint32), ("nbits", C.c_uint32)]
 
 
 class Xfer(C.Structure):

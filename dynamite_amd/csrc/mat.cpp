@@ -460,19 +460,27 @@ static int build_pass(const dnm_mat &A, const PassSpec &ps, PassOnDevice *out) {
       T.mask_loc = (uint32_t)mloc;
       T.src = (uint32_t)src;
       T.nbits = (uint32_t)nb;
-      T.z_tile = compress_to_tile(z & tb, ps);
+      const uint32_t zt = compress_to_tile(z & tb, ps);
+      T.z_tile = zt & ((1u << lognt) - 1u);
       T.z_ext = z & ~tb;
       T.first = (uint32_t)(tabvals.size() / 2);
-      T.bit_tile = T.bit_ext = 0;
+      for (int k = 0; k < R; ++k)
+        if (__builtin_popcount((uint32_t)k & (zt >> lognt)) & 1) T.ksign |= 1u << k;
       for (int q = 0; q < nb; ++q) {
-        const bool in_tile = pb[q] < 64 && ((tb >> pb[q]) & 1ull);
-        uint32_t tpos = 0xffu;
-        if (in_tile) {
-          const uint32_t c = compress_to_tile((uint64_t)1 << pb[q], ps);
-          tpos = (uint32_t)__builtin_ctz(c);
+        if ((tb >> pb[q]) & 1ull) {
+          const int tpos = __builtin_ctz(compress_to_tile((uint64_t)1 << pb[q], ps));
+          if (tpos < lognt) {
+            T.tpos |= (uint32_t)tpos << (8 * q);
+            T.twid |= 1u << (8 * q);
+          } else {
+            T.flags |= 1u;
+            for (int k = 0; k < R; ++k)
+              if ((k >> (tpos - lognt)) & 1) T.ik |= (uint64_t)1 << (4 * k + q);
+          }
+        } else {
+          T.epos |= (uint32_t)pb[q] << (8 * q);
+          T.ewid |= 1u << (8 * q);
         }
-        T.bit_tile |= tpos << (8 * q);
-        T.bit_ext |= (uint32_t)pb[q] << (8 * q);
       }
       for (int j = 0; j < (1 << nb); ++j) {
         uint64_t rowbits = 0;
@@ -487,7 +495,7 @@ static int build_pass(const dnm_mat &A, const PassSpec &ps, PassOnDevice *out) {
         tabvals.push_back(re);
         tabvals.push_back(im);
       }
-      T.last = (z == zs.back()) ? 1u : 0u;        // (the groups of a mask: consecutive records, one multiply)
+      if (z == zs.back()) T.flags |= 2u;        // (the groups of a mask: consecutive records, one fetch of the partners)
       (gather ? tabs_gather : tabs_tile).push_back(T);
     }
     return true;

@@ -278,36 +278,27 @@ __device__ __forceinline__ void apply_tabs(CTab *__restrict__ tabs, const c128 *
         for (int k = 0; k < R; ++k) xv[k] = tile[p_lo + (((uint32_t)k ^ mk) << LOGNT)];
       }
     }
-    const uint32_t nb = T.nbits, bt = T.bit_tile, be = T.bit_ext;
-    uint32_t it = 0, kbits = 0;         // kbits: table bits that are k bits (bit b set: table bit b)
-    uint32_t ik[R];
-#pragma unroll
-    for (int k = 0; k < R; ++k) ik[k] = 0;
+    // table index: thread part by bit-field extracts of tid (width 0: not a thread bit), block part by scalar shifts
+    const uint32_t tp = T.tpos, tw = T.twid, ep = T.epos, ew = T.ewid;
+    uint32_t it = 0, is = 0;
 #pragma unroll
     for (int q = 0; q < MAXTABBITS; ++q) {
-      if (q < (int)nb) {
-        const uint32_t pos = (bt >> (8 * q)) & 0xffu;
-        if (pos == 0xffu) {
-          it |= (uint32_t)((sbase >> ((be >> (8 * q)) & 0xffu)) & 1ull) << q;
-        } else if (pos < (uint32_t)LOGNT) {
-          it |= ((tid >> pos) & 1u) << q;
-        } else {
-          kbits |= 1u << q;
-#pragma unroll
-          for (int k = 0; k < R; ++k) ik[k] |= (((uint32_t)k >> (pos - LOGNT)) & 1u) << q;
-        }
-      }
+      it |= __builtin_amdgcn_ubfe(tid, (tp >> (8 * q)) & 0xffu, (tw >> (8 * q)) & 0xffu) << q;
+      is |= ((uint32_t)(sbase >> ((ep >> (8 * q)) & 0xffu)) & ((ew >> (8 * q)) & 0xffu)) << q;
     }
+    it |= is;
     const c128 *tv = tabl + (T.first - f0);
-    // (-1)^popcount(row & z): the thread-constant part once, the k part is uniform per k
-    const uint32_t p = (uint32_t)(__popc(tid & T.z_tile) + __popcll(sbase & T.z_ext)) & 1u;
-    const uint32_t zk = T.z_tile >> LOGNT;
-    if (kbits) {
+    // (-1)^popcount(row & z): the thread-constant part once, the k part is a bit per row (DevTab::ksign)
+    const uint32_t psign = ((uint32_t)(__popc(tid & T.z_tile) + __popcll(sbase & T.z_ext)) & 1u) << 31;
+    const uint32_t ks = T.ksign;
+    const uint64_t ikp = T.ik;
+    if (T.flags & 1u) {
 #pragma unroll
       for (int k = 0; k < R; ++k) {
-        const c128 cf = tv[it | ik[k]];
-        const uint32_t pk = p ^ ((uint32_t)__popc((uint32_t)k & zk) & 1u);
-        const double cr = flip_sign(cf.x, pk), ci = flip_sign(cf.y, pk);
+        const c128 cf = tv[it | ((uint32_t)(ikp >> (4 * k)) & 0xfu)];
+        const uint32_t sg = psign ^ (((ks >> k) & 1u) << 31);
+        const double cr = __hiloint2double(__double2hiint(cf.x) ^ (int)sg, __double2loint(cf.x));
+        const double ci = __hiloint2double(__double2hiint(cf.y) ^ (int)sg, __double2loint(cf.y));
         ar[k] = fma(cr, xv[k].x, ar[k]);
         ar[k] = fma(-ci, xv[k].y, ar[k]);
         ai[k] = fma(cr, xv[k].y, ai[k]);
@@ -315,18 +306,29 @@ __device__ __forceinline__ void apply_tabs(CTab *__restrict__ tabs, const c128 *
       }
     } else {
       const c128 c0 = tv[it];
-      const double c0r = flip_sign(c0.x, p), c0i = flip_sign(c0.y, p);
+      const double c0r = __hiloint2double(__double2hiint(c0.x) ^ (int)psign, __double2loint(c0.x));
+      const double c0i = __hiloint2double(__double2hiint(c0.y) ^ (int)psign, __double2loint(c0.y));
+      if (ks == 0u) {       // the common sign mask misses the k bits: one coefficient for all rows of the thread
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+          ar[k] = fma(c0r, xv[k].x, ar[k]);
+          ar[k] = fma(-c0i, xv[k].y, ar[k]);
+          ai[k] = fma(c0r, xv[k].y, ai[k]);
+          ai[k] = fma(c0i, xv[k].x, ai[k]);
+        }
+      } else
 #pragma unroll
       for (int k = 0; k < R; ++k) {
-        const uint32_t pk = (uint32_t)__popc((uint32_t)k & zk) & 1u;      // uniform
-        const double cr = flip_sign(c0r, pk), ci = flip_sign(c0i, pk);
+        const uint32_t sg = ((ks >> k) & 1u) << 31;       // uniform
+        const double cr = __hiloint2double(__double2hiint(c0r) ^ (int)sg, __double2loint(c0r));
+        const double ci = __hiloint2double(__double2hiint(c0i) ^ (int)sg, __double2loint(c0i));
         ar[k] = fma(cr, xv[k].x, ar[k]);
         ar[k] = fma(-ci, xv[k].y, ar[k]);
         ai[k] = fma(cr, xv[k].y, ai[k]);
         ai[k] = fma(ci, xv[k].x, ai[k]);
       }
     }
-    fresh = T.last != 0u;       // the groups of one mask share the partner amplitudes: one fetch per MASK
+    fresh = (T.flags & 2u) != 0u;       // the groups of one mask share the partner amplitudes: one fetch per MASK
   }
   }
 }

@@ -81,18 +81,26 @@ struct DevQuad {
 // bits) -- one parity, one table look-up and one complex multiply per row instead of a sign, an add and a multiply per
 // TERM.  Masks whose terms fall into several such groups get one record per group.
 constexpr int MAXTABBITS = 4;
+// Everything the kernel would have to DECIDE per record is decided here, so that its loop is straight-line code (the first
+// form branched per table bit on where the bit lives: 1.4 scalar / branch instructions per vector instruction): a row of a
+// thread is (block part | tid | k << LOGNT); table bit q comes from exactly one of the three --
+//   thread part: bit-field extract of tid at tpos[q], width twid[q] (0: not a thread bit),
+//   block part : bit epos[q] of the global row index, width ewid[q],
+//   k part     : precomputed per row of a thread, nibble k of `ik`.
 struct DevTab {
   uint32_t mask_tile;     // tile masks: flipped bits in tile coordinates
   uint32_t mask_loc;      // gather masks: flipped bits of the local index (global positions)
   uint32_t src;           // gather source slot
-  uint32_t nbits;         // flipped bits = bits of the table index (<= MAXTABBITS), in ascending index position
-  uint32_t z_tile;        // common sign bits inside the tile, tile coordinates
-  uint32_t first;         // first entry of the table in DevPass::tabvals
-  uint32_t bit_tile;      // byte b: place of table bit b in tile coordinates, 0xff: outside the tile ...
-  uint32_t bit_ext;       // byte b: ... at this bit of the global row index
+  uint32_t first;         // first entry of the table in DevPass::tabvals (2^(flipped bits) entries)
+  uint32_t z_tile;        // common sign bits on the THREAD part of the tile coordinate
+  uint32_t flags;         // bit 0: some table bit is a k bit (one look-up per row instead of per thread);
+                          // bit 1: last record of its mask (the groups of a mask are consecutive and share the partner fetch)
+  uint32_t tpos, twid;    // byte q: see above
+  uint32_t epos, ewid;
   uint64_t z_ext;         // common sign bits outside the tile (global positions, incl. rank bits)
-  uint32_t last;          // the groups of one mask are consecutive records that share the partner amplitudes (one fetch
-  uint32_t pad;           //   per MASK); last != 0 on the final one
+  uint64_t ik;            // nibble k: table-index bits of row k of a thread
+  uint32_t ksign;         // bit k: parity of the common sign mask over the k bits of row k
+  uint32_t nbits;         // flipped bits = bits of the table index (<= MAXTABBITS), in ascending index position
 };
 
 // off-diagonal record ranges, in table order

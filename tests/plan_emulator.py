@@ -221,27 +221,52 @@ def run_pass(hm, p, x, y, xr=None):
                 acc += (cre + 1j * cim) * xv
 
     # table records (apply_tabs): coefficient = (-1)^popc(row & z) * table[the row's bits at the flipped positions]
-    chain, chain_key = None, None         # the groups of one mask: consecutive records whose coefficients add up
+    chain_key = None                      # the groups of one mask: consecutive records that share the partner fetch
     for q, T in enumerate(quads.tabs):
         gather = q >= desc.tab_loop[1]
         assert 1 <= T.nbits <= 4 and not (desc.cache_policy & 256)
+        # the table index as apply_tabs forms it: thread part (bit-field extracts of tid), block part (bits of the global
+        # row index), k part (DevTab::ik, a nibble per row of a thread)
         idx = np.zeros(n, dtype=np.int64)
-        tcoord = tt                                   # tid | k << lognt
-        for b in range(T.nbits):
-            pos = (T.bit_tile >> (8 * b)) & 0xff
-            ext = (T.bit_ext >> (8 * b)) & 0xff
-            if pos == 0xff:
-                bit = (sbase >> np.uint64(ext)) & np.uint64(1)
-                assert not (int(tile_bits) >> ext) & 1 if ext < 64 else True
-            else:
-                assert pos < B
-                bit = (tcoord >> np.uint64(pos)) & np.uint64(1)
-                # (the two descriptions of an in-tile bit agree: tile coordinate `pos` is index bit `ext`)
-                assert int(deposit(np.array([1 << pos], dtype=np.uint64))[0]) == 1 << ext
-            idx |= bit.astype(np.int64) << b
+        seen = 0
+        for b in range(4):
+            tpos, twid = (T.tpos >> (8 * b)) & 0xff, (T.twid >> (8 * b)) & 0xff
+            epos, ewid = (T.epos >> (8 * b)) & 0xff, (T.ewid >> (8 * b)) & 0xff
+            assert twid in (0, 1) and ewid in (0, 1) and twid + ewid <= 1
+            assert b < T.nbits or (twid, ewid) == (0, 0)
+            if twid:
+                assert tpos < lognt
+                idx |= ((tid >> np.uint64(tpos)) & np.uint64(1)).astype(np.int64) << b
+            if ewid:
+                assert not (int(tile_bits) >> epos) & 1
+                idx |= ((sbase >> np.uint64(epos)) & np.uint64(1)).astype(np.int64) << b
+            seen |= (twid | ewid) << b
+        iknib = (np.uint64(T.ik) >> (np.uint64(4) * kk)) & np.uint64(0xf)
+        assert np.all((iknib.astype(np.int64) & seen) == 0) and np.all(iknib < np.uint64(1 << T.nbits))
+        if not (T.flags & 1):
+            assert T.ik == 0
+        else:
+            assert T.ik != 0
+        # every table bit is fed by exactly one of the three parts
+        assert (seen | int(np.bitwise_or.reduce(iknib.astype(np.int64)))) == (1 << T.nbits) - 1
+        idx |= iknib.astype(np.int64)
+        # ... and it is the row's bits at the flipped positions, in ascending order of the index position
+        flipped = T.mask_loc if gather else int(deposit(np.array([T.mask_tile], dtype=np.uint64))[0])
+        if not gather or desc.n_eff == n_loc:
+            pos = [i for i in range(64) if (int(flipped) >> i) & 1]
+            if len(pos) == T.nbits:       # (a gather mask of a partitioned operator also flips rank bits: not in mask_loc)
+                want = np.zeros(n, dtype=np.int64)
+                full_row = (sbase | deposit(tt))
+                for b, i in enumerate(pos):
+                    want |= ((full_row >> np.uint64(i)) & np.uint64(1)).astype(np.int64) << b
+                assert np.array_equal(want, idx)
         coef = quads.tabvals[T.first + idx]
-        par = (_popc(tcoord & np.uint64(T.z_tile)) + _popc(sbase & np.uint64(T.z_ext))) & 1
+        assert T.z_tile < NT
+        par = (_popc(tid & np.uint64(T.z_tile)) + _popc(sbase & np.uint64(T.z_ext))
+               + ((np.uint64(T.ksign) >> kk) & np.uint64(1)).astype(np.int64)) & 1
         coef = np.where(par == 1, -coef, coef)
+        key = (gather, T.mask_tile, T.mask_loc, T.src)
+        assert chain_key is None or key == chain_key, "a chain of table records spans two masks"
         if gather:
             src = xr if T.src else x
             xv = src[(rows ^ np.uint64(T.mask_loc)).astype(np.int64)]
@@ -249,18 +274,10 @@ def run_pass(hm, p, x, y, xr=None):
             assert desc.need_tile
             partner = base | deposit(tt ^ np.uint64(T.mask_tile))
             xv = x[partner.astype(np.int64)]
-        key = (gather, T.mask_tile, T.mask_loc, T.src)
-        if chain is None:
-            chain, chain_key = coef, key
-        else:
-            assert key == chain_key and q != desc.tab_loop[1], "a chain of table records spans two masks"
-            chain = chain + coef
-        if T.last:
-            acc += chain * xv
-            chain = None
-        else:
-            assert T.last == 0
-    assert chain is None, "the last table record of a mask is not marked"
+        acc += coef * xv
+        chain_key = None if T.flags & 2 else key
+        if q + 1 == desc.tab_loop[1] or q + 1 == desc.tab_loop[2]:
+            assert chain_key is None, "the last table record of a mask is not marked"
     y[:] = acc
 
 

@@ -206,9 +206,8 @@ def test_table_records_syk(monkeypatch, B, logR, mode, P):
                 if not use_tabs:
                     assert desc.tab_loop[2] == 0
                 for q, T in enumerate(quads.tabs):
-                    kinds.add(("gather" if q >= desc.tab_loop[1] else "tile", T.nbits,
-                               "ext" if 0xff in [(T.bit_tile >> (8 * b)) & 0xff for b in range(T.nbits)] else "in",
-                               "k" if any((B - logR) <= ((T.bit_tile >> (8 * b)) & 0xff) < 0xff for b in range(T.nbits)) else "t"))
+                    kinds.add(("gather" if q >= desc.tab_loop[1] else "tile", T.nbits, "ext" if T.ewid else "in",
+                               "k" if T.flags & 1 else "t"))
         assert np.max(np.abs(y - ref)) <= tol
         if use_tabs:
             with_tabs = nrec
