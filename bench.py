@@ -138,7 +138,7 @@ def cpu_baseline(sample_L=26, reps=3):
     return out
 
 
-def secondary(wd, budget_s=22.0):
+def secondary(wd, budget_s=36.0):
     """The Krylov half of the path (wall time and multiply count of evolve / eigsolve; the
     reference harness times them as phases of their own, benchmarking/benchmark.py:205-226, 311-313), on rank 0 of a
     one-GPU run, after the timed multiplies:
@@ -151,6 +151,8 @@ def secondary(wd, budget_s=22.0):
       * the reference's flagship example as its script runs it (examples/scripts/kagome/run_kagome.py:51-77): the
         30-site kagome torus in XParity(SpinConserve(30, 15)), `eigsolve(nev=2)` (round 5: bond-graph passes on a
         relabelled layout, real arithmetic).
+      * the multiply of the harness's many-term operator, SYK at L=24 (table records, round 6), checked on sampled rows
+        against the MSC definition.
     Each carries a sanity check (norm preserved / measured residual within tol).  A phase is skipped (and says so) once
     the budget is spent."""
     import numpy as np
@@ -372,6 +374,59 @@ def secondary(wd, budget_s=22.0):
         H.destroy_mat()
     else:
         out["known_answer_xx_chain_sc32_16"] = "skipped: budget"
+    # -- the many-term operator of the reference's harness: SYK (benchmarking/benchmark.py:139-160), L=24 -- 10 903 masks,
+    #    194 580 terms; round 6: table records (csrc/plan.h DevTab).  Checked on sampled rows against the
+    #    MSC definition evaluated in numpy (independent of every kernel).
+    if left() > 12.0:
+        wd.phase("secondary: SYK L=24 multiply")
+        import numpy as _np
+        Ls = 24
+        t0 = time.perf_counter()
+        H = models.syk(Ls)
+        sub = Full(L=Ls)
+        H.add_subspace(sub)
+        mat = H.get_mat(subspaces=(sub, sub))
+        build_s = time.perf_counter() - t0
+        psi = State(L=Ls, subspace=sub)
+        psi.set_random(seed=1)
+        res = State(L=Ls, subspace=sub)
+        xv, yv = psi.vec, res.vec
+        for _ in range(2):
+            mat.mult(xv, yv)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        nrep = 5
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(nrep):
+            mat.mult(xv, yv)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / nrep
+        msc = H.msc
+        rows = _np.array([0, 1, (1 << Ls) - 1, 0x5a5a5a, 0x123456, 0xfedcba, 1 << 23, (1 << 12) + 7], dtype=_np.int64)
+        mk, sg, cf = msc['masks'].astype(_np.int64), msc['signs'].astype(_np.int64), msc['coeffs']
+        cols = rows[:, None] ^ mk[None, :]                   # the column state of every term, row by row
+        par = _np.zeros(cols.shape, dtype=_np.int64)
+        v = cols & sg[None, :]
+        while _np.any(v):
+            par ^= v & 1
+            v >>= 1
+        xs = xv.array[xv.positions(torch.from_numpy(cols.reshape(-1)).to(xv.array.device))].cpu().numpy().reshape(cols.shape)
+        want = ((1 - 2 * par) * cf[None, :] * xs).sum(axis=1)
+        got = yv.array[yv.positions(torch.from_numpy(rows).to(yv.array.device))].cpu().numpy()
+        err, scale = float(_np.abs(got - want).max()), float(_np.abs(want).max())
+        r = {"ms": ms, "dim": 1 << Ls, "nmasks": int(_np.unique(mk).size), "nterms": int(mk.size), "launches": mat.launches_per_mult(),
+             "build_s": build_s, "includes": "build_s: the operator in Python (op_product of 194 580 Majorana strings) and its tables",
+             "row_mask_pairs_per_s": float(_np.unique(mk).size) * (1 << Ls) / (ms * 1e-3),
+             "sampled_rows_max_abs_error": err, "sampled_rows_scale": scale,
+             "records": "table records (one look-up per row and mask; rounds 1-5 evaluated every term: 462 ms)"}
+        if not err <= 1e-10 * max(scale, 1e-300):
+            r["failed_checks"] = ["sampled rows off by %r (scale %r)" % (err, scale)]
+        out["multiply_L24_syk"] = r
+        del mat, xv, yv, psi, res
+        H.destroy_mat()
+    else:
+        out["multiply_L24_syk"] = "skipped: budget"
     out["total_s"] = time.perf_counter() - t_begin
     return out
 
