@@ -419,9 +419,12 @@ def secondary(wd, budget_s=36.0):
              "build_s": build_s, "includes": "build_s: the operator in Python (op_product of 194 580 Majorana strings) and its tables",
              "row_mask_pairs_per_s": float(_np.unique(mk).size) * (1 << Ls) / (ms * 1e-3),
              "sampled_rows_max_abs_error": err, "sampled_rows_scale": scale,
-             "records": "table records (one look-up per row and mask; rounds 1-5 evaluated every term: 462 ms)"}
+             "records": "table records (one look-up per row and mask; rounds 1-5 evaluated every term: 462 ms)",
+             "plan_tail": mat.describe().strip().split("\n")[-1]}
+        if not r["plan_tail"].startswith("table records:"):
+            r["failed_checks"] = ["the operator did not take table records: %s" % r["plan_tail"]]
         if not err <= 1e-10 * max(scale, 1e-300):
-            r["failed_checks"] = ["sampled rows off by %r (scale %r)" % (err, scale)]
+            r.setdefault("failed_checks", []).append("sampled rows off by %r (scale %r)" % (err, scale))
         out["multiply_L24_syk"] = r
         del mat, xv, yv, psi, res
         H.destroy_mat()

@@ -1825,6 +1825,13 @@ int dnm_mat_plan_describe(const dnm_mat *A, char *buf, size_t buflen) {
   else s = A->nranks > 1 ? "generic row-gather kernel (rows split in index order, columns through a window)\n"
                          : "generic row-gather kernel (non-hypercube subspace pair)\n";
   if (A->hypercube && !A->plan.use_tiled) s += "generic row-gather kernel in use\n";
+  if (A->hypercube && A->plan.use_tiled) {
+    // masks of many terms run as table records (plan.h: DevTab); said only when there are any: the plans without keep their text
+    size_t ntab = 0, nquad = 0;
+    for (const auto &p : A->local_passes) { ntab += p->h_tabs.size(); nquad += p->desc.loop[LP_COUNT] - p->desc.loop[0]; }
+    for (const auto &p : A->remote_passes) { ntab += p->h_tabs.size(); nquad += p->desc.loop[LP_COUNT] - p->desc.loop[0]; }
+    if (ntab) s += "table records: " + std::to_string(ntab) + " (beside " + std::to_string(nquad) + " records of four terms)\n";
+  }
   snprintf(buf, buflen, "%s", s.c_str());
   return 0;
 }

@@ -19,7 +19,8 @@ pytestmark = [pytest.mark.gpu, pytest.mark.default_layout]
 STRAY = {"DNM_TILE_BITS": "8", "DNM_LOG_ROWS": "3", "DNM_PLAN_MODE": "0", "DNM_GBITS": "2", "DNM_AMIN": "3", "DNM_SWZ": "6",
          "DNM_SC_LAYOUT": "6,4", "DNM_SC_SITE_PERM": "0", "DNM_SC3_TILED": "0", "DNM_SC3G_PTAB": "0", "DNM_EIGS_REAL": "0",
          "DNM_EIGS_BASISFREE": "1", "DNM_EXCHANGE": "partner", "DNM_CACHE_POLICY": "0", "DNM_WINDOW_FIRST": "0",
-         "DNM_SC3G_KEEP_GATA": "0", "DNM_LIB": "/nonexistent/lib.so", "DNM_EXPM_ORTHO": "full", "DNM_DIAG_TABLE": "0"}
+         "DNM_SC3G_KEEP_GATA": "0", "DNM_LIB": "/nonexistent/lib.so", "DNM_EXPM_ORTHO": "full", "DNM_DIAG_TABLE": "0",
+         "DNM_TAB_RECORDS": "0", "DNM_TAB_LOG_ROWS": "2", "DNM_SC_LAYOUT_MIN_DIM": "0", "DNM_SC_SOLVER_PARTITION": "0"}
 
 
 def _child(extra):
@@ -50,6 +51,7 @@ def test_stray_knobs_change_nothing_in_a_production_process(clean):
     assert "B=12 logR=2 mode=2" in clean["cases"]["mbl_full_22"]["plan"]
     assert "internal layout [T 2 | W 10 | Lo 14]" in clean["cases"]["heisenberg_sc_26_13"]["plan"]
     assert "bond graph" in clean["cases"]["kagome_sc_27"]["plan"]
+    assert "table records: " in clean["cases"]["syk_full_16"]["plan"]               # (DNM_TAB_RECORDS=0 among the stray ones)
     # every knob that was read is named (once) as ignored
     named = " ".join(stray["warnings"])
     for k in ("DNM_SWZ", "DNM_SC_LAYOUT", "DNM_SC_SITE_PERM"):
