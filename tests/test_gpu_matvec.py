@@ -512,8 +512,8 @@ def test_default_plan_vs_oracle(monkeypatch, name, L):
     mat = shell(H, sub)
     d = mat.describe()
     lines = d.splitlines()
-    if name == "syk":           # 2^12 amplitudes, 1820 four-Majorana strings: one tile, every mask inside it
-        assert "tiled=1" in d and len(lines) == 2, d
+    if name == "syk":           # 2^12 amplitudes, 1820 four-Majorana strings: one tile, every mask inside it, as table records
+        assert "tiled=1" in d and len(lines) == 3 and lines[2].startswith("table records: "), d
     else:
         assert "tiled=1" in d and "mode=2" in d and "B=12 logR=2" in d, d
     # where DESIGN.md section 4.1 says the plan changes shape
