@@ -111,8 +111,8 @@ def _adopt(mat, state, result):
 
 def _solver_mat(H, subspace, real):
     """The operator on the partition made for the exchange (Operator.get_solver_mat) if every rank has one, else None."""
-    if not config.sc_solver_partition or config.world_size == 1:
-        return None
+    if not config.sc_solver_partition or not H.solver_partition_applies(subspace):
+        return None         # (the same answer on every rank: no collective)
     sm = H.get_solver_mat(subspace, real)
     return sm if _min_over_ranks(0 if sm is None else 1) == 1 else None
 

@@ -374,6 +374,13 @@ class Operator:
 
     SOLVER_BLOCK_ORDER = 1
 
+    def solver_partition_applies(self, subspace):
+        """Could ``get_solver_mat`` give an operator here?  What every rank answers alike without building anything: several
+        ranks, a SpinConserve subspace in the internal layout, a shell operator."""
+        from .subspaces import SpinConserve
+        return bool(config.world_size > 1 and isinstance(subspace, SpinConserve)
+                    and 256 <= subspace.vec_swizzle < (1 << 16) and self.shell)
+
     def get_solver_mat(self, subspace, real):
         """The operator on ``subspace`` for vectors that live INSIDE a solver (no state of the caller's ever meets them):
         SpinConserve in the internal layout on several ranks, its T blocks in the order made for partitions
@@ -385,8 +392,7 @@ class Operator:
         if key in self._mats:
             return self._mats[key]
         mat = None
-        if (config.world_size > 1 and isinstance(subspace, SpinConserve) and 256 <= subspace.vec_swizzle < (1 << 16)
-                and self.shell):
+        if self.solver_partition_applies(subspace):
             self.establish_L()
             self.reduce_msc()
             masks, mask_offsets = msc_tools.get_mask_offsets(self.msc)

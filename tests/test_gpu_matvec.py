@@ -564,6 +564,36 @@ def test_default_plan_parity_vs_oracle(monkeypatch, L):
 
 
 @pytest.mark.default_layout
+@pytest.mark.parametrize("space", ["full", "even", "odd"])
+def test_default_plan_table_records_vs_oracle(monkeypatch, space):
+    """Masks of many terms as table records (csrc/plan.h DevTab) under the production planner at a size whose plan gathers
+    (SYK on 15 spins: 1 366 + 105 masks, tile of 12 bits, 8 rows per thread) -- the Full space and both Parity sectors (the
+    dropped spin folded into the sign masks) element-wise against the oracle; the records of four terms give the same
+    product."""
+    for k in PLAN_KNOBS:
+        monkeypatch.delenv(k, raising=False)
+    L = 15
+    H = models.syk(L)
+    arrs = marshal(H)
+    sub = Full(L=L) if space == "full" else Parity(space, L=L)
+    x = rand_state(sub.get_dimension(), seed=77)
+    ref = orc.matvec(orc_msc(H), orc_sub(sub), orc_sub(sub), x, nthreads=min(16, orc.max_threads()))
+    mat = shell(H, sub)
+    d = mat.describe()
+    assert "tiled=1" in d and "gather_masks=" in d and "gather_masks=0" not in d.splitlines()[1], d
+    assert d.strip().splitlines()[-1].startswith("table records: "), d
+    y = mult_numpy(mat, x)
+    assert np.max(np.abs(y - ref)) <= tol_for(arrs, x), d
+    mat.destroy()
+    monkeypatch.setenv("DNM_TAB_RECORDS", "0")
+    mat = shell(H, sub)
+    assert "table records" not in mat.describe()
+    y0 = mult_numpy(mat, x)
+    assert np.max(np.abs(y0 - ref)) <= tol_for(arrs, x)
+    mat.destroy()
+
+
+@pytest.mark.default_layout
 @pytest.mark.parametrize("L,k,internal", [(24, 12, False), (25, 12, True), (26, 13, True), (25, 9, False)])
 def test_default_spinconserve_vs_oracle(monkeypatch, L, k, internal):
     """SpinConserve under the production configuration on both sides of the 2^22-state threshold of the internal
