@@ -71,7 +71,7 @@ class DevPass(C.Structure):
                 ("tile_bits", C.c_int32), ("log_rows", C.c_int32),
                 ("swz_shift", C.c_int32), ("swz_xor_y", C.c_uint32), ("swz_xor_src", C.c_uint32), ("block_offset", C.c_uint32),
                 ("pos_tmask", C.c_uint32), ("dtile", vp), ("tabs", vp), ("tabvals", vp), ("tab_loop", C.c_uint32 * 3),
-                ("pad_tab", C.c_uint32)]
+                ("pad_tab", C.c_uint32), ("gbucket", C.c_uint32 * (MAXR + 1)), ("pad_g", C.c_uint32)]
 
 
 class DevTab(C.Structure):

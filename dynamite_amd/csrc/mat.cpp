@@ -420,6 +420,28 @@ static int build_pass(const dnm_mat &A, const PassSpec &ps, PassOnDevice *out) {
       const char *dte = knob("DNM_DIAG_TABLE");
       const bool use_table = !(dte && dte[0] == '0') && B <= 13;
       if (use_table) out->h_dtile.assign((size_t)1 << B, 0.0);
+      // terms that see the tile AND bits outside it, grouped by their sign mask inside the tile (DevPass::gbucket): groups of
+      // three terms or more are summed over the outside bits once per workgroup (DNM_DIAG_GROUPS=0: every term per thread)
+      std::vector<std::pair<uint32_t, std::vector<RowTerm>>> groups;
+      {
+        const char *dge = knob("DNM_DIAG_GROUPS");
+        const bool grouping = !(dge && dge[0] == '0') && !op.packed && !(A.flags & DNM_MAT_USE_GLDS);
+        std::vector<std::pair<uint32_t, std::vector<RowTerm>>> all;
+        if (grouping)
+          for (const RowTerm &t : dm->terms) {
+            const uint32_t st = compress_to_tile(t.sign & tb, ps);
+            if (st == 0 || (t.sign & ~tb) == 0) continue;
+            auto it = std::find_if(all.begin(), all.end(), [&](const auto &g) { return g.first == st; });
+            if (it == all.end()) { all.push_back({st, {}}); it = all.end() - 1; }
+            it->second.push_back(t);
+          }
+        std::stable_sort(all.begin(), all.end(), [](const auto &a, const auto &b) { return a.second.size() > b.second.size(); });
+        for (auto &g : all)
+          if (g.second.size() >= 3 && groups.size() < MAXDGROUPS) groups.push_back(std::move(g));
+      }
+      auto grouped = [&](uint32_t st) {
+        return std::any_of(groups.begin(), groups.end(), [&](const auto &g) { return g.first == st; });
+      };
       for (int j = 0; j < R; ++j) {
         lst.clear();
         for (const RowTerm &t : dm->terms) {
@@ -428,6 +450,8 @@ static int build_pass(const dnm_mat &A, const PassSpec &ps, PassOnDevice *out) {
           if (use_table && (t.sign & ~tb) == 0) {
             for (uint32_t tc = 0; tc < (1u << B); ++tc)
               out->h_dtile[tc] += (__builtin_popcount(tc & st) & 1) ? -t.coeff : t.coeff;
+          } else if ((t.sign & ~tb) != 0 && grouped(st)) {
+            continue;
           } else {
             lst.push_back(t);
           }
@@ -436,6 +460,28 @@ static int build_pass(const dnm_mat &A, const PassSpec &ps, PassOnDevice *out) {
         push_diag_list(lst);
       }
       for (int j = R; j <= MAXR; ++j) d.dbucket[j] = (uint32_t)quads.size();
+      // the groups: their term records (the outside part of every sign mask), then one record per group, by k bucket
+      std::vector<std::pair<uint32_t, uint32_t>> where(groups.size());
+      for (size_t g = 0; g < groups.size(); ++g) {
+        std::vector<RowTerm> outside = groups[g].second;
+        for (RowTerm &t : outside) t.sign &= ~tb;
+        where[g].first = (uint32_t)quads.size();
+        push_diag_list(outside);
+        where[g].second = (uint32_t)quads.size() - where[g].first;
+      }
+      for (int j = 0; j < R; ++j) {
+        d.gbucket[j] = (uint32_t)quads.size();
+        for (size_t g = 0; g < groups.size(); ++g) {
+          if ((int)(groups[g].first >> lognt) != j) continue;
+          DevQuad q = empty_quad();
+          q.sign_tile[0] = groups[g].first;
+          q.mask_loc = where[g].first;
+          q.src = where[g].second;
+          q.nslots = 1;
+          quads.push_back(q);
+        }
+      }
+      for (int j = R; j <= MAXR; ++j) d.gbucket[j] = (uint32_t)quads.size();
     }
   }
 

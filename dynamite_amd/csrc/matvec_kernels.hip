@@ -505,6 +505,31 @@ tile_pass_kernel(const DevPass P, const c128 *__restrict__ x, c128 *__restrict__
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) dext += __shfl_xor(dext, off, 64);
   }
+  // grouped diagonal terms (DevPass::gbucket): every group's sum over the bits outside the tile, once per workgroup
+  double *cg = nullptr;
+  if constexpr (TAB) {
+    __shared__ double cg_mem[MAXDGROUPS];
+    cg = cg_mem;
+    if (P.has_diag) {
+      const uint32_t lane = tid & 63u, g0 = P.gbucket[0], g1 = P.gbucket[R];
+      // (a group per wavefront at a time: the workgroup's waves share the groups out)
+      for (uint32_t g = g0 + (tid >> 6); g < g1; g += (NT >> 6)) {
+        const uint32_t q0 = quads[g].mask_loc, nterm = quads[g].src * 4u;
+        double v = 0.0;
+        for (uint32_t t0 = 0; t0 < nterm; t0 += 64u) {
+          const uint32_t t = t0 + lane;
+          if (t < nterm) {
+            CQuad &Q = quads[q0 + (t >> 2)];
+            const uint32_t j = t & 3u;
+            v += flip_sign(Q.coeff[j], (uint32_t)__popcll(sbase & Q.sign_ext[j]) & 1u);
+          }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (lane == 0) cg[g - g0] = v;
+      }
+    }
+  }
   // ---- diagonal, part 2: sum_t c_t chi_t(row) for the terms that see the tile.
   // Terms are bucketed by the part of their sign mask that falls on this
   // thread's k bits; a length-R Walsh-Hadamard butterfly then yields all R row
@@ -530,6 +555,13 @@ tile_pass_kernel(const DevPass P, const c128 *__restrict__ x, c128 *__restrict__
         if (ns > 3) v += slot_amp(quads[q], 3, tid, sbase);
         D[j] += v;
       }
+    if constexpr (TAB) {
+      const uint32_t g0 = P.gbucket[0];
+#pragma unroll
+      for (int j = 0; j < R; ++j)
+        for (uint32_t q = P.gbucket[j]; q < P.gbucket[j + 1]; ++q)
+          D[j] += flip_sign(cg[q - g0], (uint32_t)__popc(tid & quads[q].sign_tile[0]) & 1u);
+    }
 #pragma unroll
     for (int h = 1; h < R; h <<= 1) {
 #pragma unroll
@@ -670,7 +702,8 @@ static int launch_cfg(const DevPass &P, bool glds, int n_loc, const void *x, voi
   using kern_t = void (*)(const DevPass, const c128 *, c128 *, const c128 *);
   kern_t k = nullptr;
   const bool pack = (P.cache_policy & 256) != 0;          // real-packed records: their own instance (early gathers only)
-  const bool tab = P.tab_loop[2] > 0;                     // table records: their own instance (early gathers, plain tile loads)
+  // table records / grouped diagonal terms: their own instance (early gathers, plain tile loads)
+  const bool tab = P.tab_loop[2] > 0 || P.gbucket[MAXR] > P.gbucket[0];
   if (pack) k = tile_pass_kernel<B, LOGR, false, 1, true>;
   else if (tab) k = tile_pass_kernel<B, LOGR, false, 1, false, true>;
   else if (glds) k = tile_pass_kernel<B, LOGR, true, 1>;

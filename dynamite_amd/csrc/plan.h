@@ -170,7 +170,16 @@ struct DevPass {
   const double *tabvals;
   uint32_t tab_loop[3];
   uint32_t pad_tab;
+  // Grouped diagonal terms (same kernel instance as the table records): diagonal terms that see the tile AND bits outside it,
+  // grouped by their sign mask INSIDE the tile.  A group's sum over the outside bits is the same for the whole workgroup
+  // (an all-to-all ZZ coupling: for every spin of the tile one sum over the 16 spins outside it): computed once per
+  // workgroup into LDS, the threads then see one term per GROUP.  Group g = record quads[gbucket[0] + g]: sign_tile[0] =
+  // the group's in-tile sign mask, mask_loc = its first term record, src = how many (terms four to a record, sign_tile 0);
+  // the groups are listed by the k part of their sign mask: bucket j = [gbucket[j], gbucket[j + 1]).
+  uint32_t gbucket[MAXR + 1];
+  uint32_t pad_g;
 };
+constexpr uint32_t MAXDGROUPS = 64;
 
 // ---- host-side description --------------------------------------------------
 struct PassSpec {

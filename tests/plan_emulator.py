@@ -176,6 +176,21 @@ def run_pass(hm, p, x, y, xr=None):
                     if quads[q].coeff[j] != 0:
                         assert quads[q].sign_tile[j] != 0 and (quads[q].sign_tile[j] >> lognt) == b
                     D[b] = D[b] + amp(quads[q], j, tid)
+        # grouped terms (DevPass::gbucket): the group's sum over the bits outside the tile -- the same for a whole workgroup --
+        # times the sign of its in-tile mask
+        g0 = desc.gbucket[0]
+        assert desc.gbucket[R] - g0 <= 64 and desc.gbucket[R] == desc.gbucket[_lib.MAXR]
+        for b in range(R):
+            for q in range(desc.gbucket[b], desc.gbucket[b + 1]):
+                G = quads[q]
+                assert G.nslots == 1 and G.sign_tile[0] != 0 and (G.sign_tile[0] >> lognt) == b and G.src >= 1
+                Cg = np.zeros(n)
+                for tq in range(G.mask_loc, G.mask_loc + G.src):
+                    assert not (desc.dext_begin <= tq < desc.dext_end) and tq < g0
+                    for j in range(quads[tq].nslots):
+                        assert quads[tq].sign_tile[j] == 0 and quads[tq].sign_ext[j] != 0
+                        Cg = Cg + amp(quads[tq], j, zero)
+                D[b] = D[b] + np.where(_popc(tid & np.uint64(G.sign_tile[0])) & 1, -Cg, Cg)
         d = np.zeros(n, dtype=np.float64)      # Walsh-Hadamard over the k bits
         if getattr(quads, "dtile", None) is not None:     # tile-only terms, tabulated per tile coordinate
             assert quads.dtile.shape == (1 << B,)

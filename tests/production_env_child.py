@@ -33,7 +33,8 @@ def main():
              ("heisenberg_sc_26_13", models.heisenberg(26), SpinConserve(26, 13)),        # internal layout: 10.4 M states
              ("kagome_sc_27", models.kagome("27b"), SpinConserve(27, 13)),                 # bond-graph passes, relabelled
              ("ising_xparity_20", models.ising(20), XParity(Full(L=20), sector='+')),
-             ("syk_full_16", models.syk(16), Full(L=16))]                                  # table records
+             ("syk_full_16", models.syk(16), Full(L=16)),                                  # table records
+             ("long_range_full_18", models.long_range(18), Full(L=18))]                    # grouped diagonal terms
     for name, H, sub in cases:
         H.add_subspace(sub)
         x = State(L=H.L, subspace=sub, state='random', seed=7)

@@ -564,6 +564,31 @@ def test_default_plan_parity_vs_oracle(monkeypatch, L):
 
 
 @pytest.mark.default_layout
+@pytest.mark.parametrize("space", ["full", "even"])
+def test_default_plan_grouped_diagonal_vs_oracle(monkeypatch, space):
+    """Diagonal terms with one spin inside the tile and one outside (the harness's long_range: all-to-all ZZ), summed per
+    group and workgroup (DevPass::gbucket) under the production planner, two-pass plan (2^19 / 2^20 amplitudes), against
+    the oracle; DNM_DIAG_GROUPS=0 -- every term by every thread -- gives the same product."""
+    for k in PLAN_KNOBS:
+        monkeypatch.delenv(k, raising=False)
+    L = 20
+    H = models.long_range(L)
+    arrs = marshal(H)
+    sub = Full(L=L) if space == "full" else Parity(space, L=L)
+    x = rand_state(sub.get_dimension(), seed=78)
+    ref = orc.matvec(orc_msc(H), orc_sub(sub), orc_sub(sub), x, nthreads=min(16, orc.max_threads()))
+    ys = []
+    for groups in ("1", "0"):
+        monkeypatch.setenv("DNM_DIAG_GROUPS", groups)
+        mat = shell(H, sub)
+        assert "tiled=1" in mat.describe() and len(mat.describe().strip().splitlines()) == 3, mat.describe()
+        ys.append(mult_numpy(mat, x))
+        assert np.max(np.abs(ys[-1] - ref)) <= tol_for(arrs, x) * L, mat.describe()
+        mat.destroy()
+    assert not np.array_equal(ys[0], ys[1])        # (two ways of summing the same terms: equal to rounding, not bit for bit)
+
+
+@pytest.mark.default_layout
 @pytest.mark.parametrize("space", ["full", "even", "odd"])
 def test_default_plan_table_records_vs_oracle(monkeypatch, space):
     """Masks of many terms as table records (csrc/plan.h DevTab) under the production planner at a size whose plan gathers

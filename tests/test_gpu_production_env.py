@@ -20,7 +20,7 @@ STRAY = {"DNM_TILE_BITS": "8", "DNM_LOG_ROWS": "3", "DNM_PLAN_MODE": "0", "DNM_G
          "DNM_SC_LAYOUT": "6,4", "DNM_SC_SITE_PERM": "0", "DNM_SC3_TILED": "0", "DNM_SC3G_PTAB": "0", "DNM_EIGS_REAL": "0",
          "DNM_EIGS_BASISFREE": "1", "DNM_EXCHANGE": "partner", "DNM_CACHE_POLICY": "0", "DNM_WINDOW_FIRST": "0",
          "DNM_SC3G_KEEP_GATA": "0", "DNM_LIB": "/nonexistent/lib.so", "DNM_EXPM_ORTHO": "full", "DNM_DIAG_TABLE": "0",
-         "DNM_TAB_RECORDS": "0", "DNM_TAB_LOG_ROWS": "2", "DNM_SC_LAYOUT_MIN_DIM": "0", "DNM_SC_SOLVER_PARTITION": "0"}
+         "DNM_TAB_RECORDS": "0", "DNM_DIAG_GROUPS": "0", "DNM_TAB_LOG_ROWS": "2", "DNM_SC_LAYOUT_MIN_DIM": "0", "DNM_SC_SOLVER_PARTITION": "0"}
 
 
 def _child(extra):

@@ -219,6 +219,48 @@ def test_table_records_syk(monkeypatch, B, logR, mode, P):
     assert {k[2] for k in kinds} == {"ext", "in"} and {k[3] for k in kinds} == {"k", "t"}
 
 
+@pytest.mark.parametrize("B,logR,mode,P", [(8, 2, 2, 1), (10, 3, 2, 1), (8, 2, 0, 1), (8, 2, 2, 4)])
+def test_grouped_diagonal_terms(monkeypatch, B, logR, mode, P):
+    """Diagonal terms that see the tile and bits outside it (an all-to-all ZZ coupling: benchmark.py's long_range), grouped by
+    their sign mask inside the tile (DevPass::gbucket): a group's sum over the outside bits once per workgroup, one term per
+    group for the threads.  The emulation of the exported records against the oracle, whole and on four ranks (rank bits
+    among the outside bits); DNM_DIAG_GROUPS=0 lists every term and gives the same product."""
+    L = 14
+    _cfg(monkeypatch, B, logR, mode)
+    H = models.long_range(L)
+    omsc, arrs = _orc_msc(H)
+    sub = Full(L=L)
+    x = _rand(1 << L, 9)
+    ref = orc.matvec_general(omsc, orc.full(L), orc.full(L), x)
+    tol = 64 * len(arrs[0]) * EPS * np.abs(arrs[3]).max() * np.abs(x).max() * L
+    nloc = (1 << L) // P
+    for on in (True, False):
+        monkeypatch.setenv("DNM_DIAG_GROUPS", "1" if on else "0")
+        y = np.zeros(1 << L, dtype=complex)
+        ngroups = nlisted = 0
+        for r in range(P):
+            hm = HostMat(*arrs, sub._c(), sub._c(), rank=r, nranks=P)
+            yl = np.zeros(nloc, dtype=complex)
+            for p in hm.local:
+                run_pass(hm, p, x[r * nloc:(r + 1) * nloc], yl)
+            for i, (partner, off, cnt) in enumerate(hm.recvs):
+                run_remote(hm, i, x[partner * nloc + off:partner * nloc + off + cnt], yl)
+            y[r * nloc:(r + 1) * nloc] = yl
+            for desc, quads in hm.local:
+                if desc.has_diag:
+                    ngroups += desc.gbucket[_lib.MAXR] - desc.gbucket[0]
+                    nlisted += desc.dbucket[_lib.MAXR] - desc.dbucket[0]
+                else:
+                    assert desc.gbucket[_lib.MAXR] == desc.gbucket[0]
+        assert np.max(np.abs(y - ref)) <= tol
+        if on:
+            # every spin of the tile couples to every spin outside it: one group per tile spin (and rank)
+            assert ngroups == P * B, (ngroups, hm.describe())
+            listed_on = nlisted
+        else:
+            assert ngroups == 0 and nlisted > listed_on
+
+
 @pytest.mark.parametrize("spaces", [(0, 0), (1, 1), (0, 1), (1, 0)])
 @pytest.mark.parametrize("name", ["long_range", "ising", "mbl", "syk"])
 def test_tiled_plan_parity(monkeypatch, name, spaces):
