@@ -267,6 +267,9 @@ static bool table_form(const OpForm &op, const RowMask &m, std::vector<uint64_t>
     const uint64_t z = t.sign & ~m.mask;
     if (std::find(zs->begin(), zs->end(), z) == zs->end()) zs->push_back(z);
   }
+  // (masks of one record stay records: a single flip's X + iY -- the harness's long_range -- as a table of two entries made
+  // that operator SLOWER, 7.11 -> 7.59 ms at L=28: a table record has its own fixed costs, the staging of the tables and the
+  // kernel instance of 8 rows per thread among them)
   const size_t nq = std::max((nre + 1) / 2, (nim + 1) / 2);
   return nq >= 2 && zs->size() * 45 < nq * 76;
 }

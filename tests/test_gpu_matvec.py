@@ -581,7 +581,7 @@ def test_default_plan_grouped_diagonal_vs_oracle(monkeypatch, space):
     for groups in ("1", "0"):
         monkeypatch.setenv("DNM_DIAG_GROUPS", groups)
         mat = shell(H, sub)
-        assert "tiled=1" in mat.describe() and len(mat.describe().strip().splitlines()) == 3, mat.describe()
+        assert "tiled=1" in mat.describe() and mat.describe().count("local pass") == 2, mat.describe()
         ys.append(mult_numpy(mat, x))
         assert np.max(np.abs(ys[-1] - ref)) <= tol_for(arrs, x) * L, mat.describe()
         mat.destroy()
