@@ -60,7 +60,7 @@ def _worker(rank, world, port, case, out_dir):
     from oracle import oracle as orc
     from gpu_util import orc_msc, orc_sub
 
-    L = 24 if case == "sc_big" else 14
+    L = 24 if case == "sc_big" else (12 if case == "full_syk" else 14)
     config.L = L
     config._initialize()
     if case in ("sc3", "sc3_graph"):
@@ -203,6 +203,10 @@ def _worker(rank, world, port, case, out_dir):
         return
     if case in ("full", "full_partner", "full_transpose"):
         sub, H = Full(L=L), models.mbl(L)
+    elif case == "full_syk":
+        # masks of many terms as table records (csrc/plan.h DevTab) on several ranks: flipped bits among the rank bits, the
+        # partners' blocks as the source of the gathers
+        sub, H = Full(L=L), models.syk(L)
     elif case == "parity":
         sub, H = Parity('even', L=L), models.mbl(L)
     elif case == "sc3_graph":
@@ -238,8 +242,11 @@ def _worker(rank, world, port, case, out_dir):
     if case not in ("sc", "sc3", "sc3_graph"):
         # exchange scheme: partner blocks on two ranks, the transposed all-to-all from four on (backend.py)
         want_scheme = {"full": "transpose" if world >= 4 else "partner", "full_partner": "partner",
+                       "full_syk": "partner",      # (all-to-all masks: nothing for the transposed exchange to gain)
                        "full_transpose": "transpose", "parity": "transpose" if world >= 4 else "partner"}[case]
         assert H.get_mat().exchange_summary()["scheme"] == want_scheme
+        if case == "full_syk":
+            assert "table records: " in H.get_mat().describe() or want_scheme == "transpose", H.get_mat().describe()
         if want_scheme == "transpose" and case in ("full", "parity"):
             # ... and runs sub-piece by sub-piece (forward parts, ranges of the layout-B pass, returns)
             assert H.get_mat()._tr_pipe or H.get_mat()._native_tr, "the transposed exchange should pipeline at this size"
@@ -253,6 +260,18 @@ def _worker(rank, world, port, case, out_dir):
     y0 = y.to_numpy()
     assert (y0 is None) == (rank != 0)
 
+    if case == "full_syk":
+        # (the multiply is what the table records change; SYK's all-to-all masks make every solver step an exchange with
+        # every other rank, minutes of host staging on one shared GPU: the solvers run on the other cases)
+        z = H.evolve(x, t=0.05)
+        assert abs(z.norm() - 1) < 1e-9
+        _native_ran(H, case)
+        dist.barrier()
+        faulthandler.cancel_dump_traceback_later()
+        if rank == 0:
+            open(os.path.join(out_dir, "ok_%s_%d" % (case, world)), "w").write("ok")
+        dist.destroy_process_group()
+        return
     # Krylov solvers through the hooks
     Hs = H.to_numpy(subspaces=(sub, sub), sparse=True)
     z = H.evolve(x, t=0.6)
@@ -459,6 +478,7 @@ def build_fake_rccl():
 
 
 @pytest.mark.parametrize("case,world", [("full", 2), ("full", 4), ("full", 8), ("full_partner", 4), ("full_transpose", 2),
+                                        ("full_syk", 2), ("full_syk", 4),
                                         ("parity", 2), ("parity", 4), ("sc", 2), ("sc", 3), ("sc3", 2), ("sc3", 3), ("sc3_graph", 2),
                                         ("sc_big", 3), ("explicit", 3), ("auto", 2), ("projection", 3),
                                         ("projection", 2), ("full_odd", 3), ("parity_odd", 3),
@@ -471,7 +491,7 @@ def test_partitioned_end_to_end_one_gpu(tmp_path, case, world):
 
 
 @pytest.mark.parametrize("case,world", [("full", 2), ("full", 4), ("full", 8), ("parity", 4), ("sc", 3), ("sc3", 2), ("sc3", 3),
-                                        ("sc3_graph", 2), ("sc_big", 3), ("explicit", 3), ("xparity_full", 2),
+                                        ("full_syk", 2), ("sc3_graph", 2), ("sc_big", 3), ("explicit", 3), ("xparity_full", 2),
                                         ("xparity_sc", 3), ("full_odd", 3), ("projection", 2)] +
                          ([("full_partner", 4), ("full_transpose", 2), ("auto", 2), ("parity_odd", 3), ("projection", 3)]
                           if os.environ.get("DNM_TEST_LARGEST") == "1" else []))
