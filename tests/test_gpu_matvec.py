@@ -563,6 +563,37 @@ def test_default_plan_parity_vs_oracle(monkeypatch, L):
         mat.destroy()
 
 
+@pytest.mark.parametrize("seed", range(10))
+def test_fuzz_table_records_and_groups_gpu(monkeypatch, seed):
+    """Random operators made to share masks (tests/fuzz_ops.py: table records of one group or several, 1-4 flipped spins, a
+    long-range diagonal on top) under random tile shapes and plan modes, Full and Parity, against the oracle; the same with
+    both record forms switched off."""
+    from fuzz_ops import shared_mask_operator
+    rs = np.random.RandomState(4200 + seed)
+    L = int(rs.randint(13, 17))
+    parity = seed % 2 == 1
+    H = shared_mask_operator(rs, L, parity)
+    sub = Parity(int(rs.randint(2)), L=L) if parity else Full(L=L)
+    B, logR = [(8, 2), (10, 3), (10, 4), (12, 2), (12, 3), (11, 3)][int(rs.randint(6))]
+    cfg(monkeypatch, B, logR)
+    monkeypatch.setenv("DNM_PLAN_MODE", str(int(rs.choice([0, 1, 2]))))
+    arrs = marshal(H)
+    x = rand_state(sub.get_dimension(), seed=seed)
+    ref = orc.matvec(orc_msc(H), orc_sub(sub), orc_sub(sub), x, nthreads=4)
+    seen_tabs = False
+    for on in ("1", "0"):
+        monkeypatch.setenv("DNM_TAB_RECORDS", on)
+        monkeypatch.setenv("DNM_DIAG_GROUPS", on)
+        mat = shell(H, sub)
+        d = mat.describe()
+        assert "tiled=1" in d and (on == "1" or "table records: " not in d), d
+        seen_tabs = seen_tabs or "table records: " in d
+        y = mult_numpy(mat, x)
+        assert np.max(np.abs(y - ref)) <= tol_for(arrs, x) * L, d
+        mat.destroy()
+    assert seen_tabs, "no mask of this operator took the table form"
+
+
 @pytest.mark.default_layout
 @pytest.mark.parametrize("space", ["full", "even"])
 def test_default_plan_grouped_diagonal_vs_oracle(monkeypatch, space):

@@ -219,6 +219,52 @@ def test_table_records_syk(monkeypatch, B, logR, mode, P):
     assert {k[2] for k in kinds} == {"ext", "in"} and {k[3] for k in kinds} == {"k", "t"}
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_fuzz_table_records_and_groups(monkeypatch, seed):
+    """Random operators made to share masks: for a handful of sets of 1-4 flipped spins, 5-24 Pauli strings each (X or Y at
+    every flipped spin, Z strings from a small pool elsewhere -- so that table records have one group or several, of one term
+    or many), a random long-range diagonal on top (grouped diagonal terms), random tile shapes / plan modes / rank counts, Full
+    and Parity: the emulation of the exported records against the oracle, and the same with both forms switched off."""
+    from fuzz_ops import shared_mask_operator
+    rs = np.random.RandomState(4200 + seed)
+    L = int(rs.randint(10, 13))
+    parity = seed % 2 == 1                  # (a Parity sector needs every mask to flip an even number of spins)
+    H = shared_mask_operator(rs, L, parity)
+    sub = Parity(int(rs.randint(2)), L=L) if parity else Full(L=L)
+    osub = orc.parity(L, sub.space) if parity else orc.full(L)
+    n = L - 1 if parity else L
+    B, logR = [(8, 2), (10, 3), (10, 4), (8, 2)][int(rs.randint(4))]
+    P = int(rs.choice([1, 1, 2, 4])) if n - 2 >= B else 1
+    _cfg(monkeypatch, B, logR, int(rs.choice([0, 1, 2])))
+    omsc, arrs = _orc_msc(H)
+    x = _rand(1 << n, seed)
+    ref = orc.matvec_general(omsc, osub, osub, x)
+    tol = 64 * len(arrs[2]) * EPS * max(1.0, np.abs(arrs[3]).max()) * np.abs(x).max()
+    nloc = (1 << n) // P
+    seen = {"tabs": 0, "groups": 0}
+    for on in ("1", "0"):
+        monkeypatch.setenv("DNM_TAB_RECORDS", on)
+        monkeypatch.setenv("DNM_DIAG_GROUPS", on)
+        y = np.zeros(1 << n, dtype=complex)
+        for r in range(P):
+            hm = HostMat(*arrs, sub._c(), sub._c(), rank=r, nranks=P)
+            assert hm.tiled == 1, hm.describe()
+            yl = np.zeros(nloc, dtype=complex)
+            for p in hm.local:
+                run_pass(hm, p, x[r * nloc:(r + 1) * nloc], yl)
+            for i, (partner, off, cnt) in enumerate(hm.recvs):
+                run_remote(hm, i, x[partner * nloc + off:partner * nloc + off + cnt], yl)
+            y[r * nloc:(r + 1) * nloc] = yl
+            for desc, quads in hm.local + hm.remote:
+                if on == "1":
+                    seen["tabs"] += desc.tab_loop[2]
+                    seen["groups"] += desc.gbucket[_lib.MAXR] - desc.gbucket[0]
+                else:
+                    assert desc.tab_loop[2] == 0 and desc.gbucket[_lib.MAXR] == desc.gbucket[0]
+        assert np.max(np.abs(y - ref)) <= tol, (on, hm.describe())
+    assert seen["tabs"] > 0, "no mask of this operator took the table form"
+
+
 @pytest.mark.parametrize("B,logR,mode,P", [(8, 2, 2, 1), (10, 3, 2, 1), (8, 2, 0, 1), (8, 2, 2, 4)])
 def test_grouped_diagonal_terms(monkeypatch, B, logR, mode, P):
     """Diagonal terms that see the tile and bits outside it (an all-to-all ZZ coupling: benchmark.py's long_range), grouped by
